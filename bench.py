@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X BEV-fusion hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One rank per GPU; pure data parallel over the batch axis ("weak" scaling: per-GPU
+batch is fixed).  A step = one pass of the hot path over one batch of synthetic
+input resident in HBM (see DESIGN.md "Measurement").  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+
+# BASELINE.json configs[1]: camera-only BEVDepth, 6 cams 256x704, ds 16, D=112, C=80, BEV 128x128, bs=4
+CFG2 = dict(batch=4, num_cams=6, final_dim=(256, 704), downsample=16, d_bound=(2.0, 58.0, 0.5),
+            channels=80, x_bound=(-51.2, 51.2, 0.8), y_bound=(-51.2, 51.2, 0.8), z_bound=(-5.0, 3.0, 8.0))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="hotpath", choices=["hotpath"],
+                    help="hotpath: voxel_pooling forward+backward at the cfg-2 shape")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag")
+    return ap.parse_args()
+
+
+def init_dist(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
+    return rank, local_rank, world
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def algorithmic_bytes(BP, K, C, B, ny, nx):
+    """BASELINE.md section 2 / SURVEY.md section 8d."""
+    fwd = 12 * BP + 12 * BP + 4 * C * K + 4 * C * B * ny * nx
+    bwd = 12 * BP + 4 * C * B * ny * nx + 4 * C * BP
+    return fwd, bwd
+
+
+def cpu_baseline(geom, feats, vn, grad_out_nhwc, budget_s=12.0):
+    """The oracle's torch-CPU port of the reference semantics (BASELINE.md section 2:
+    scatter_add_ forward + masked gather backward) timed on this host's cores."""
+    import oracle
+    B, P, C = feats.shape
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    nx, ny, nz = vn
+    times = []
+    t_end = time.perf_counter() + budget_s
+    reps = 0
+    while reps < 3 or (time.perf_counter() < t_end and reps < 30):
+        t0 = time.perf_counter()
+        out, pos = oracle.torch_forward_scatter_add(geom, feats, nx, ny, nz)
+        gi = oracle.torch_backward_gather(pos, grad_out_nhwc)
+        times.append(time.perf_counter() - t0)
+        reps += 1
+    times = sorted(times[1:]) if len(times) > 1 else times
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} reps of voxel_pooling fwd (torch scatter_add_) + bwd (masked gather) "
+                      f"on CPU at the full cfg-2 shape B={B} P={P} C={C}, median {med * 1e3:.1f} ms/step"}, out, pos, gi
+
+
+def main():
+    args = parse()
+    rank, local_rank, world = init_dist(args.gpus)
+    from mm_training_amd import _lib, synthetic
+    from mm_training_amd.ops.voxel_pooling import voxel_pooling, voxel_pooling_ext
+    _lib.lib()
+
+    cfg = CFG2
+    B, C = cfg["batch"], cfg["channels"]
+    geom_cpu, vn = synthetic.rig_geometry(B, cfg["num_cams"], cfg["final_dim"], cfg["downsample"],
+                                          cfg["d_bound"], cfg["x_bound"], cfg["y_bound"], cfg["z_bound"],
+                                          seed=rank)
+    feats_cpu = synthetic.features(tuple(geom_cpu.shape[:-1]) + (C,), seed=100 + rank)
+    nx, ny, nz = vn
+    P = feats_cpu[0].numel() // C
+    geom = geom_cpu.cuda()
+    feats = feats_cpu.cuda().requires_grad_(True)
+    g = torch.Generator().manual_seed(1)
+    grad_out = torch.randn(B, ny, nx, C, generator=g).cuda().permute(0, 3, 1, 2)  # channels-last grad
+
+    def step():
+        feats.grad = None
+        out = voxel_pooling(geom, feats, vn)
+        out.backward(grad_out)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    voxel_pooling_ext.TIMING = {}
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    timing = voxel_pooling_ext.TIMING
+    voxel_pooling_ext.TIMING = None
+
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    fwd_ms = sum(s.elapsed_time(e) for s, e in timing["forward"]) / len(timing["forward"])
+    bwd_ms = sum(s.elapsed_time(e) for s, e in timing["backward"]) / len(timing["backward"])
+    g3 = geom.reshape(-1, 3)
+    kept = ((g3[:, 0] >= 0) & (g3[:, 0] < nx) & (g3[:, 1] >= 0) & (g3[:, 1] < ny)
+            & (g3[:, 2] >= 0) & (g3[:, 2] < nz))
+    K = int(kept.sum().item())
+    fwd_bytes, bwd_bytes = algorithmic_bytes(B * P, K, C, B, ny, nx)
+
+    if rank == 0:
+        res = {
+            "metric": "training samples/sec at bs=4/GPU (hot path: voxel_pooling fwd+bwd); voxel_pooling HBM GB/s",
+            "value": world * B * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] camera half: voxel_pooling forward+backward, "
+                                   "6 cams 256x704 ds16 D=112 fH=16 fW=44 C=80, BEV 128x128x1, "
+                                   "analytic 6-camera rig geometry, bs=4/GPU",
+                       "global_batch": world * B, "points_per_sample": P, "kept_fraction": K / (B * P),
+                       "parallelism": f"dp{world}", "mode": args.mode},
+            "roofline": {"bound": "hbm", "kernel": "vp_fwd_lds_combine (voxel_pooling forward)",
+                         "achieved": fwd_bytes / (fwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": fwd_bytes, "avg_ms": fwd_ms},
+            "roofline_backward": {"bound": "hbm", "kernel": "vp_bwd_rows_vec4 (voxel_pooling backward)",
+                                  "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": None, "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref_out, ref_pos, ref_gi = cpu_baseline(geom_cpu.reshape(B, P, 3), feats_cpu.reshape(B, P, C),
+                                                          vn, grad_out.permute(0, 2, 3, 1).contiguous().cpu())
+            res["cpu_baseline"] = base
+            # same-run parity of the measured path against the CPU port
+            err = (out.detach().permute(0, 2, 3, 1).cpu() - ref_out).abs().max().item()
+            gi_equal = bool(torch.equal(feats.grad.reshape(B, P, C).cpu(), ref_gi))
+            res["parity"] = {"bev_max_abs_err": err, "grad_in_bit_exact": gi_equal}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

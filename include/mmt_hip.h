@@ -1,0 +1,171 @@
+/*
+ * mmt_hip.h -- C ABI of libmmt_hip.so: the MI355X (gfx950) BEV-fusion hot path of
+ * aimotive/mm_training as hand-written HIP kernels.
+ *
+ * Plain pointers + sizes only; no torch / ATen types.  Every pointer is a DEVICE
+ * pointer unless stated otherwise.  `stream` is a hipStream_t passed as void*
+ * (NULL = the null stream).  All entry points are asynchronous on `stream`, never
+ * synchronise the device, never allocate and keep no pointers after returning, so
+ * they can be captured into a hipGraph.
+ *
+ * Return value: 0 on success; MMT_ERR_* (< 0) for argument errors detected on the
+ * host before anything is launched; a positive hipError_t if the launch failed.
+ * mmt_last_error() returns a thread-local message for the last non-zero return.
+ * (The reference prints to stderr and calls exit(-1) on a failed launch,
+ * ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:51-55; this library returns
+ * the error instead -- documented deviation.)
+ *
+ * Reference paths are relative to the aimotive/mm_training checkout.
+ */
+#ifndef MMT_HIP_H_
+#define MMT_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMT_ABI_VERSION 1
+
+#define MMT_OK 0
+#define MMT_ERR_NULL_POINTER (-1)
+#define MMT_ERR_BAD_SHAPE (-2)
+#define MMT_ERR_TOO_LARGE (-3)
+#define MMT_ERR_BAD_FLAG (-4)
+#define MMT_ERR_WORKSPACE (-5)
+
+int mmt_abi_version(void);
+const char *mmt_last_error(void);
+
+/* ------------------------------------------------------------------ camera half */
+
+/* Replaces voxel_pooling_forward_kernel_launcher
+ * (ops/voxel_pooling/src/voxel_pooling_forward.cpp:21-22,
+ *  ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:9-56), i.e. what
+ * voxel_pooling_forward_wrapper (voxel_pooling_forward.cpp:24-37) binds.
+ * Same argument order and meaning:
+ *   geom_xyz        int32 [B*P,3]   (x,y,z) integer voxel coordinates
+ *   input_features  fp32  [B*P,C]   row-major
+ *   output_features fp32  [B,ny,nx,C] channels-last, ACCUMULATED INTO (caller zero-fills)
+ *   pos_memo        int32 [B*P,3]   rows of kept points overwritten with (b,y,x);
+ *                                   rows of dropped points left untouched (caller pre-fills -1)
+ * A point is kept iff 0<=x<nx && 0<=y<ny && 0<=z<nz (z only filters). */
+int mmt_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
+                              int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                              const int32_t *geom_xyz, const float *input_features,
+                              float *output_features, int32_t *pos_memo, void *stream);
+
+/* Same computation with explicit algorithm / behaviour flags. */
+#define MMT_VP_ALGO_AUTO 0        /* LDS-staged BEV-tile combine, then row atomics */
+#define MMT_VP_ALGO_ROW_ATOMIC 1  /* one coalesced row of global fp32 atomics per kept point */
+#define MMT_VP_ALGO_MASK 0xF
+#define MMT_VP_WRITE_DROPPED 0x10 /* also write (-1,-1,-1) to pos_memo rows of dropped points,
+                                     so the caller need not pre-fill pos_memo */
+int mmt_voxel_pooling_forward_ex(int batch_size, int num_points, int num_channels,
+                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                 const int32_t *geom_xyz, const float *input_features,
+                                 float *output_features, int32_t *pos_memo, int flags,
+                                 void *stream);
+
+/* Replaces VoxelPooling.backward (ops/voxel_pooling/voxel_pooling.py:58-69), which the
+ * reference runs as ATen boolean-mask + advanced-index ops:
+ *   grad_in[t,:] = grad_out[b,:,y,x]  if pos_memo[t] = (b,y,x) != -1,  else 0.
+ * grad_out is addressed as a [B,C,ny,nx] tensor through ELEMENT strides
+ * (stride_b, stride_c, stride_y, stride_x) so any view autograd hands over works.
+ * grad_in fp32 [B*P,C] is fully written (zeros for dropped points).
+ * If stride_c != 1 and `workspace` (fp32, >= B*ny*nx*C elements) is non-NULL the
+ * gradient is first transposed to channels-last in the workspace (coalesced gather);
+ * with workspace == NULL a slower strided gather is used. */
+int mmt_voxel_pooling_backward(int batch_size, int num_points, int num_channels,
+                               int num_voxel_x, int num_voxel_y, const int32_t *pos_memo,
+                               const float *grad_output, int64_t stride_b, int64_t stride_c,
+                               int64_t stride_y, int64_t stride_x, float *grad_input,
+                               float *workspace, void *stream);
+
+/* Replaces the quantise expression layers/backbones/lss_fpn.py:461-462
+ *   ((xyz - (voxel_coord - voxel_size/2)) / voxel_size).int()
+ * xyz fp32 [n,3] -> geom int32 [n,3].  voxel_coord / voxel_size are HOST pointers to 3
+ * floats (the module buffers lss_fpn.py:278-285).  fp32 subtract + IEEE divide +
+ * truncation toward zero (saturating, NaN -> 0), bit-exact with the reference on its device. */
+int mmt_quantize_geometry(int64_t n_points, const float *xyz, const float *voxel_coord_host,
+                          const float *voxel_size_host, int32_t *geom_xyz, void *stream);
+
+/* Fused LSSFPN.get_geometry + quantise (lss_fpn.py:328-361 + :461-462): for every camera
+ * (bn in [0,BN)) and frustum point s in [0,D*fH*fW): p = (u*d, v*d, d, 1),
+ * xyz = (combine[bn] @ p)[:3] (fp32, k-ordered, no FMA contraction), then quantise.
+ * frustum fp32 [D*fH*fW,4] (lss_fpn.py:308-326), combine fp32 [BN,4,4] = sensor2ego @ inverse(intrin).
+ * Writes geom int32 [BN*D*fH*fW,3]; xyz_out (nullable) receives the fp32 points. */
+int mmt_frustum_geometry(int num_cams_total, int64_t frustum_points, const float *frustum,
+                         const float *combine, const float *voxel_coord_host,
+                         const float *voxel_size_host, int32_t *geom_xyz, float *xyz_out,
+                         void *stream);
+
+/* Replaces the lift + layout step layers/backbones/lss_fpn.py:441-463:
+ * feats[bn,d,h,w,c] = depth[bn,d,h,w] * context[bn,c,h,w]  (fp32), written directly in the
+ * [B,N,D,fH,fW,C] channels-last layout voxel_pooling consumes (no permute+contiguous copy).
+ * depth fp32 [BN,D,fH*fW]; context fp32 [BN,C,fH*fW]. */
+int mmt_lift_features(int num_cams_total, int D, int HW, int C, const float *depth,
+                      const float *context, float *feats, void *stream);
+/* and its backward: grad_depth[bn,d,s] = sum_c g[bn,d,s,c]*context[bn,c,s];
+ * grad_context[bn,c,s] = sum_d g[bn,d,s,c]*depth[bn,d,s]. */
+int mmt_lift_features_backward(int num_cams_total, int D, int HW, int C, const float *depth,
+                               const float *context, const float *grad_feats, float *grad_depth,
+                               float *grad_context, void *stream);
+
+/* ------------------------------------------------------------------- LiDAR half */
+
+/* Replaces mmcv-full 1.7.0 ops.Voxelization (hard, deterministic) as called per sample by
+ * mmdet3d MVXTwoStageDetector.voxelize (call site models/bev_depth.py:181; parameters
+ * exps/conf_aim.py:16-18,194-197), batched over B samples in one call.
+ *   points        fp32 [sum Ni, F]   samples concatenated
+ *   point_offsets int32 [B+1]        DEVICE prefix offsets of the samples in `points`
+ *   voxel_size / range_min  HOST float[3];  grid HOST int[3] (x,y,z)
+ * Outputs are laid out with a fixed per-sample capacity so nothing is sized by a device count:
+ *   voxels       fp32  [B*max_voxels, max_points, F]  sample b starts at row b*max_voxels
+ *   coors        int32 [B*max_voxels, 4] = (b,z,y,x)
+ *   num_points   int32 [B*max_voxels]
+ *   voxel_count  int32 [B]   number of voxels of each sample (M_b <= max_voxels)
+ * Voxels are numbered in order of their first point; <= max_points points per voxel,
+ * first come first kept; voxels beyond max_voxels (in first-point order) are dropped.
+ * workspace: int32, at least mmt_voxelize_workspace_elems(...) elements (device). */
+int64_t mmt_voxelize_workspace_elems(int batch_size, int64_t total_points, const int32_t *grid_host);
+int mmt_hard_voxelize(int batch_size, int64_t total_points, int num_features,
+                      const float *points, const int32_t *point_offsets,
+                      const float *voxel_size_host, const float *range_min_host,
+                      const int32_t *grid_host, int max_points, int max_voxels, float *voxels,
+                      int32_t *coors, int32_t *num_points, int32_t *voxel_count,
+                      int32_t *workspace, void *stream);
+
+/* Compacts the fixed-capacity outputs above into the dense (concatenated) tensors the
+ * reference returns: rows [sum_{b'<b} M_b', ...) <- sample b's first M_b rows.
+ * dst_offsets int32 [B+1] device prefix sums of voxel_count. */
+int mmt_compact_voxels(int batch_size, int max_voxels, int row_elems_voxels,
+                       const int32_t *voxel_count, const int32_t *dst_offsets,
+                       const float *voxels, const int32_t *coors, const int32_t *num_points,
+                       float *voxels_out, int32_t *coors_out, int32_t *num_points_out,
+                       void *stream);
+
+/* Replaces mmdet3d 1.0.0rc4 HardSimpleVFE(num_features) (models/bev_depth.py:182;
+ * exps/conf_aim.py:198-201): out[m,k] = sum_t voxels[m,t,k] / num_points[m], k < num_features,
+ * summed in slot order. */
+int mmt_simple_vfe(int64_t num_voxels, int max_points, int F, int num_features,
+                   const float *voxels, const int32_t *num_points, float *out, void *stream);
+
+/* Replaces mmdet3d PointPillarsScatter behind pts_middle_encoder(voxel_feats, coors, batch_size)
+ * (models/bev_depth.py:183): canvas[b,:,y,x] = feats[m,:] for coors[m]=(b,z,y,x), zeros
+ * elsewhere; canvas fp32 [B,C,ny,nx] is fully written (memset folded in).
+ * workspace: int32 [B*ny*nx] (device) cell -> row map.  Duplicate cells: highest row wins. */
+int mmt_pillar_scatter(int64_t num_voxels, int C, int batch_size, int ny, int nx,
+                       const float *feats, const int32_t *coors, float *canvas,
+                       int32_t *workspace, void *stream);
+/* grad_feats[m,:] = grad_canvas[b,:,y,x] for rows owning their cell (else 0);
+ * uses the cell->row map left in `workspace` by mmt_pillar_scatter. */
+int mmt_pillar_scatter_backward(int64_t num_voxels, int C, int batch_size, int ny, int nx,
+                                const float *grad_canvas, const int32_t *coors,
+                                const int32_t *workspace, float *grad_feats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMT_HIP_H_ */

@@ -1,0 +1,79 @@
+"""ctypes binding of libmmt_hip.so (the C ABI declared in include/mmt_hip.h).
+
+There is deliberately no CPU fallback: if the library is missing or a launch
+fails, callers get an exception.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmmt_hip.so")
+
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/mmt_hip.h one to one
+SIGNATURES = {
+    "mmt_abi_version": (_c_int, []),
+    "mmt_last_error": (ctypes.c_char_p, []),
+    "mmt_voxel_pooling_forward": (_c_int, [_c_int] * 6 + [_c_ptr] * 4 + [_c_ptr]),
+    "mmt_voxel_pooling_forward_ex": (_c_int, [_c_int] * 6 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
+    "mmt_voxel_pooling_backward": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr] + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_ptr]),
+    "mmt_quantize_geometry": (_c_int, [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    "mmt_frustum_geometry": (_c_int, [_c_int, _c_i64] + [_c_ptr] * 6 + [_c_ptr]),
+    "mmt_lift_features": (_c_int, [_c_int] * 4 + [_c_ptr] * 3 + [_c_ptr]),
+    "mmt_lift_features_backward": (_c_int, [_c_int] * 4 + [_c_ptr] * 5 + [_c_ptr]),
+    "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr]),
+    "mmt_hard_voxelize": (_c_int, [_c_int, _c_i64, _c_int] + [_c_ptr] * 5 + [_c_int, _c_int] + [_c_ptr] * 5 + [_c_ptr]),
+    "mmt_compact_voxels": (_c_int, [_c_int] * 3 + [_c_ptr] * 8 + [_c_ptr]),
+    "mmt_simple_vfe": (_c_int, [_c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    "mmt_pillar_scatter": (_c_int, [_c_i64] + [_c_int] * 4 + [_c_ptr] * 4 + [_c_ptr]),
+    "mmt_pillar_scatter_backward": (_c_int, [_c_i64] + [_c_int] * 4 + [_c_ptr] * 4 + [_c_ptr]),
+}
+
+# flags of mmt_voxel_pooling_forward_ex (include/mmt_hip.h)
+VP_ALGO_AUTO = 0
+VP_ALGO_ROW_ATOMIC = 1
+VP_WRITE_DROPPED = 0x10
+
+_lib = None
+
+
+class MmtError(RuntimeError):
+    """A libmmt_hip entry point returned non-zero."""
+
+
+def lib():
+    """Load libmmt_hip.so (once). Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m mm_training_amd.build` "
+                "(hipcc, gfx950). mm_training_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise MmtError with the library's message."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        msg = lib().mmt_last_error()
+        raise MmtError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+def float3(values):
+    """Host float[3] argument."""
+    return (ctypes.c_float * 3)(*[float(v) for v in values])
+
+
+def int3(values):
+    return (ctypes.c_int32 * 3)(*[int(v) for v in values])

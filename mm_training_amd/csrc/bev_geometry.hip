@@ -1,0 +1,255 @@
+// Producers of voxel_pooling's operands: quantise (lss_fpn.py:461-462), fused
+// frustum geometry (lss_fpn.py:328-361) and the lift + channels-last layout step
+// (lss_fpn.py:441-463).  All HBM-streaming kernels; fp32 throughout.
+#include "mmt_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct GridQ {
+    float lo[3];  // fp32(voxel_coord - fp32(voxel_size/2))
+    float vs[3];
+};
+
+__device__ __forceinline__ int quantize_one(float v, float lo, float vs) {
+    // fp32 subtract, correctly rounded IEEE divide, truncate toward zero
+    // (v_cvt_i32_f32 saturates and maps NaN to 0, as the reference's device does).
+    return (int)__fdiv_rn(__fsub_rn(v, lo), vs);
+}
+
+__global__ __launch_bounds__(kBlock) void quantize_kernel(int64_t n, const float *xyz, GridQ q,
+                                                          int32_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += stride) {
+        const float x = xyz[t * 3], y = xyz[t * 3 + 1], z = xyz[t * 3 + 2];
+        out[t * 3] = quantize_one(x, q.lo[0], q.vs[0]);
+        out[t * 3 + 1] = quantize_one(y, q.lo[1], q.vs[1]);
+        out[t * 3 + 2] = quantize_one(z, q.lo[2], q.vs[2]);
+    }
+}
+
+// One workgroup column per camera (blockIdx.y): the 3x4 matrix is wave-uniform.
+__global__ __launch_bounds__(kBlock) void frustum_geometry_kernel(int64_t S, const float4 *frustum,
+                                                                  const float *combine, GridQ q,
+                                                                  int32_t *geom, float *xyz_out) {
+    const int bn = blockIdx.y;
+    const float *M = combine + (int64_t)bn * 16;
+    float m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = M[i];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < S; s += stride) {
+        const float4 f = frustum[s];
+        // p = (u*d, v*d, d, 1); explicit *_rn ops forbid FMA contraction so the result
+        // equals the k-ordered fp32 dot product of the oracle bit for bit.
+        const float p0 = __fmul_rn(f.x, f.z), p1 = __fmul_rn(f.y, f.z), p2 = f.z, p3 = f.w;
+        float r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float acc = __fmul_rn(m[k * 4], p0);
+            acc = __fadd_rn(acc, __fmul_rn(m[k * 4 + 1], p1));
+            acc = __fadd_rn(acc, __fmul_rn(m[k * 4 + 2], p2));
+            acc = __fadd_rn(acc, __fmul_rn(m[k * 4 + 3], p3));
+            r[k] = acc;
+        }
+        const int64_t t = (int64_t)bn * S + s;
+        geom[t * 3] = quantize_one(r[0], q.lo[0], q.vs[0]);
+        geom[t * 3 + 1] = quantize_one(r[1], q.lo[1], q.vs[1]);
+        geom[t * 3 + 2] = quantize_one(r[2], q.lo[2], q.vs[2]);
+        if (xyz_out) {
+            xyz_out[t * 3] = r[0];
+            xyz_out[t * 3 + 1] = r[1];
+            xyz_out[t * 3 + 2] = r[2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Lift: feats[bn,d,s,c] = depth[bn,d,s] * context[bn,c,s].
+// Workgroup = (camera bn, tile of kTile positions, range of kDRange depth bins).
+// The context tile is transposed once through LDS ([c][s] -> [s][c], rows padded to
+// C+4 floats so they stay 16-byte aligned); every depth bin then emits one fully
+// contiguous kTile*C*4-byte block of the channels-last output with 16-byte
+// non-temporal stores.
+constexpr int kTile = 64;
+constexpr int kDRange = 16;
+
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void lift_kernel(int D, int HW, int C, const float *depth,
+                                                      const float *context, float *feats) {
+    extern __shared__ __align__(16) float lds[];
+    const int CP = C + 4;
+    float *ctx = lds;                 // [kTile][CP]
+    float *dep = lds + kTile * CP;    // [kDRange][kTile]
+    const int bn = blockIdx.z;
+    const int s0 = blockIdx.x * kTile;
+    const int d0 = blockIdx.y * kDRange;
+    const int ns = (HW - s0) < kTile ? (HW - s0) : kTile;
+    const int nd = (D - d0) < kDRange ? (D - d0) : kDRange;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < C * kTile; i += kBlock) {
+        const int c = i / kTile, j = i - c * kTile;
+        if (j < ns) ctx[j * CP + c] = context[((int64_t)bn * C + c) * HW + s0 + j];
+    }
+    for (int i = tid; i < nd * kTile; i += kBlock) {
+        const int dd = i / kTile, j = i - dd * kTile;
+        if (j < ns) dep[i] = depth[((int64_t)bn * D + d0 + dd) * HW + s0 + j];
+    }
+    __syncthreads();
+
+    if (VEC4) {
+        const int C4 = C >> 2;
+        const int nvec = ns * C4;
+        for (int dd = 0; dd < nd; ++dd) {
+            float4 *dst = reinterpret_cast<float4 *>(feats + (((int64_t)bn * D + d0 + dd) * HW + s0) * C);
+            for (int i = tid; i < nvec; i += kBlock) {
+                const int j = i / C4, c4 = i - j * C4;
+                const float dv = dep[dd * kTile + j];
+                const float4 cv = *reinterpret_cast<const float4 *>(ctx + j * CP + c4 * 4);
+                mmt_nt_store4(make_float4(dv * cv.x, dv * cv.y, dv * cv.z, dv * cv.w), dst + i);
+            }
+        }
+    } else {
+        const int nel = ns * C;
+        for (int dd = 0; dd < nd; ++dd) {
+            float *dst = feats + (((int64_t)bn * D + d0 + dd) * HW + s0) * C;
+            for (int i = tid; i < nel; i += kBlock) {
+                const int j = i / C, c = i - j * C;
+                dst[i] = dep[dd * kTile + j] * ctx[j * CP + c];
+            }
+        }
+    }
+}
+
+// Lift backward.  Workgroup = (camera, tile of kTile positions); it walks ALL depth bins
+// so grad_context needs no cross-workgroup sum.  Lane (j, c4) keeps its float4 of
+// grad_context in registers across the depth loop; grad_depth[d, j] = sum_c g*ctx is
+// reduced across the lanes of one position with LDS float atomics.
+constexpr int kBTile = 16;  // positions per workgroup (more workgroups: BN*HW/16)
+
+__global__ __launch_bounds__(kBlock) void lift_backward_kernel(int D, int HW, int C,
+                                                               const float *depth,
+                                                               const float *context,
+                                                               const float *g, float *grad_depth,
+                                                               float *grad_context) {
+    extern __shared__ __align__(16) float lds[];
+    const int CP = C + 4;
+    float *ctx = lds;                    // [kBTile][CP]
+    float *gctx = ctx + kBTile * CP;     // [kBTile][CP]  accumulated grad_context
+    float *gd = gctx + kBTile * CP;      // [2][kBTile]   grad_depth of the bin in flight
+    const int bn = blockIdx.y;
+    const int s0 = blockIdx.x * kBTile;
+    const int ns = (HW - s0) < kBTile ? (HW - s0) : kBTile;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C * kBTile; i += kBlock) {
+        const int c = i / kBTile, j = i - c * kBTile;
+        if (j < ns) ctx[j * CP + c] = context[((int64_t)bn * C + c) * HW + s0 + j];
+    }
+    for (int i = tid; i < kBTile * CP; i += kBlock) gctx[i] = 0.f;
+    if (tid < 2 * kBTile) gd[tid] = 0.f;
+    __syncthreads();
+    const int nel = ns * C;
+    for (int d = 0; d < D; ++d) {
+        float *gdb = gd + (d & 1) * kBTile;
+        const float *src = g + (((int64_t)bn * D + d) * HW + s0) * C;
+        const float *drow = depth + ((int64_t)bn * D + d) * HW + s0;
+        for (int i = tid; i < nel; i += kBlock) {
+            const int j = i / C, c = i - j * C;
+            const float gv = src[i];
+            atomicAdd(&gdb[j], gv * ctx[j * CP + c]);
+            gctx[j * CP + c] += gv * drow[j];  // (j,c) is owned by exactly one lane
+        }
+        __syncthreads();
+        if (tid < ns) {
+            grad_depth[((int64_t)bn * D + d) * HW + s0 + tid] = gdb[tid];
+            gdb[tid] = 0.f;
+        }
+        // the other gd buffer is used by the next bin; the barrier above orders the reset
+    }
+    __syncthreads();
+    for (int i = tid; i < C * kBTile; i += kBlock) {
+        const int c = i / kBTile, j = i - c * kBTile;
+        if (j < ns) grad_context[((int64_t)bn * C + c) * HW + s0 + j] = gctx[j * CP + c];
+    }
+}
+
+int make_grid(const float *vc, const float *vs, GridQ *q) {
+    for (int a = 0; a < 3; ++a) {
+        volatile float half = vs[a] / 2.0f;   // fp32, as torch computes voxel_size / 2.0
+        volatile float lo = vc[a] - half;
+        q->lo[a] = lo;
+        q->vs[a] = vs[a];
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mmt_quantize_geometry(int64_t n, const float *xyz, const float *vc_host,
+                                     const float *vs_host, int32_t *geom, void *stream) {
+    MMT_REQUIRE_PTR(xyz);
+    MMT_REQUIRE_PTR(vc_host);
+    MMT_REQUIRE_PTR(vs_host);
+    MMT_REQUIRE_PTR(geom);
+    if (n < 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "quantize_geometry: negative point count");
+    if (n == 0) return MMT_OK;
+    GridQ q;
+    make_grid(vc_host, vs_host, &q);
+    hipLaunchKernelGGL(quantize_kernel, dim3(mmt::stream_grid(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, n, xyz, q, geom);
+    return mmt::check_launch("quantize_geometry");
+}
+
+extern "C" int mmt_frustum_geometry(int BN, int64_t S, const float *frustum, const float *combine,
+                                    const float *vc_host, const float *vs_host, int32_t *geom,
+                                    float *xyz_out, void *stream) {
+    MMT_REQUIRE_PTR(frustum);
+    MMT_REQUIRE_PTR(combine);
+    MMT_REQUIRE_PTR(vc_host);
+    MMT_REQUIRE_PTR(vs_host);
+    MMT_REQUIRE_PTR(geom);
+    if (BN <= 0 || S <= 0 || BN > 65535) return mmt::fail(MMT_ERR_BAD_SHAPE, "frustum_geometry: bad sizes BN=%d S=%lld", BN, (long long)S);
+    if (((uintptr_t)frustum & 15) != 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "frustum_geometry: frustum must be 16-byte aligned");
+    GridQ q;
+    make_grid(vc_host, vs_host, &q);
+    dim3 grid((unsigned)mmt::stream_grid(S, kBlock, 1024), (unsigned)BN);
+    hipLaunchKernelGGL(frustum_geometry_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, S,
+                       reinterpret_cast<const float4 *>(frustum), combine, q, geom, xyz_out);
+    return mmt::check_launch("frustum_geometry");
+}
+
+extern "C" int mmt_lift_features(int BN, int D, int HW, int C, const float *depth,
+                                 const float *context, float *feats, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(feats);
+    if (BN <= 0 || D <= 0 || HW <= 0 || C <= 0 || BN > 65535)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_features: bad sizes");
+    const size_t lds = ((size_t)kTile * (C + 4) + (size_t)kDRange * kTile) * 4;
+    if (lds > 160 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_features: C=%d too large for the LDS tile", C);
+    dim3 grid((unsigned)mmt::ceil_div(HW, kTile), (unsigned)mmt::ceil_div(D, kDRange), (unsigned)BN);
+    const bool vec4 = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0);
+    if (vec4) hipLaunchKernelGGL((lift_kernel<true>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    else hipLaunchKernelGGL((lift_kernel<false>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    return mmt::check_launch("lift_features");
+}
+
+extern "C" int mmt_lift_features_backward(int BN, int D, int HW, int C, const float *depth,
+                                          const float *context, const float *grad_feats,
+                                          float *grad_depth, float *grad_context, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_feats);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    if (BN <= 0 || D <= 0 || HW <= 0 || C <= 0 || BN > 65535)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_features_backward: bad sizes");
+    const size_t lds = ((size_t)2 * kBTile * (C + 4) + 2 * kBTile) * 4;
+    if (lds > 160 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_features_backward: C too large");
+    dim3 grid((unsigned)mmt::ceil_div(HW, kBTile), (unsigned)BN);
+    hipLaunchKernelGGL(lift_backward_kernel, grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C,
+                       depth, context, grad_feats, grad_depth, grad_context);
+    return mmt::check_launch("lift_features_backward");
+}

@@ -1,0 +1,42 @@
+// Shared host-side helpers for libmmt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mmt_hip.h"
+
+namespace mmt {
+
+// thread-local message behind mmt_last_error()
+char *error_buffer();
+int fail(int code, const char *fmt, ...);
+
+// post-launch check: returns 0 or the hipError_t (recorded in the error buffer)
+int check_launch(const char *what);
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for streaming kernels: enough workgroups to fill 256 CUs several times over,
+// capped so very large problems grid-stride instead of queueing >100k tiny blocks.
+static inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 16) {
+    int64_t g = ceil_div(work_items, block);
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+}  // namespace mmt
+
+// 16-byte non-temporal store (streaming output that must not evict reused lines)
+typedef float mmt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mmt_nt_store4(float4 v, float4 *p) {
+    mmt_f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<mmt_f32x4 *>(p));
+}
+
+#define MMT_REQUIRE_PTR(p)                                                        \
+    do {                                                                          \
+        if ((p) == nullptr) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: %s is NULL", __func__, #p); \
+    } while (0)

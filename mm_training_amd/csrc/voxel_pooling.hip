@@ -1,0 +1,431 @@
+// voxel_pooling forward / backward for MI355X (gfx950, wave64).
+//
+// Replaces ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:9-56 (forward kernel +
+// launcher) and ops/voxel_pooling/voxel_pooling.py:58-69 (backward, pure ATen in the
+// reference).  Not a translation of the CUDA kernel: the reference maps one THREAD to
+// a point and loops over channels with strided loads + one contended fp32 atomic per
+// channel.  Here the [B*P, C] feature matrix is streamed as flat 16-byte vectors
+// (1 KiB contiguous per wave instruction), points of one chunk that fall into the
+// same BEV cell are summed in an LDS-resident tile of BEV rows (ds_add_f32), and each
+// touched cell leaves the workgroup as ONE coalesced row of global fp32 atomics.
+//
+// HBM traffic per call (algorithmic): 12*BP geom + 12*BP pos_memo + 4*C*K features
+// of kept points + 4*C*B*ny*nx BEV rows.
+#include "mmt_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;       // 4 waves
+constexpr int kEmpty = -1;        // hash-table empty marker (cell keys are >= 0)
+constexpr int kDropped = -1;      // pt_slot: point outside the grid
+constexpr int kOverflow = -2;     // pt_slot: no LDS row available -> direct row atomics
+constexpr int kHashSize = 512;    // entries, power of two
+constexpr int kChunk = 512;       // points per chunk (2 per thread)
+
+struct VpArgs {
+    int64_t BP;  // B*P
+    int P, C, nx, ny, nz;
+    const int32_t *geom;
+    const float *feats;
+    float *out;
+    int32_t *pos_memo;
+    int write_dropped;
+    int nslot;    // LDS BEV rows per workgroup
+    int nchunks;
+};
+
+__device__ __forceinline__ bool in_grid(int x, int y, int z, int nx, int ny, int nz) {
+    // voxel_pooling_forward_cuda.cu:24-26 (negated)
+    return !(x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz);
+}
+
+__device__ __forceinline__ void write_pos(int32_t *pos_memo, int64_t t, int b, int y, int x) {
+    // voxel_pooling_forward_cuda.cu:27-29
+    pos_memo[t * 3] = b;
+    pos_memo[t * 3 + 1] = y;
+    pos_memo[t * 3 + 2] = x;
+}
+
+// ---------------------------------------------------------------------------
+// ALGO_ROW_ATOMIC: every kept point adds its row to the BEV with global fp32
+// atomics; lanes run along the channel axis so each wave instruction covers
+// contiguous bytes (the shape the memory-side atomic units want).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void vp_fwd_row_atomic(VpArgs a) {
+    const int CV = a.C / VEC;
+    const int64_t total = a.BP * CV;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const int64_t t = i / CV;
+        const int cv = (int)(i - t * CV);
+        const int x = a.geom[t * 3], y = a.geom[t * 3 + 1], z = a.geom[t * 3 + 2];
+        const bool kept = in_grid(x, y, z, a.nx, a.ny, a.nz);
+        const int b = (int)(t / a.P);
+        if (cv == 0) {
+            if (kept) write_pos(a.pos_memo, t, b, y, x);
+            else if (a.write_dropped) write_pos(a.pos_memo, t, -1, -1, -1);
+        }
+        if (!kept) continue;
+        float *o = a.out + (((int64_t)b * a.ny + y) * a.nx + x) * a.C + cv * VEC;
+        const float *f = a.feats + t * a.C + cv * VEC;
+        if (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(f);
+            atomicAdd(o, v.x);
+            atomicAdd(o + 1, v.y);
+            atomicAdd(o + 2, v.z);
+            atomicAdd(o + 3, v.w);
+        } else {
+            atomicAdd(o, f[0]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ALGO_AUTO: LDS-staged BEV-tile combine.
+//
+// A workgroup owns chunks of kChunk consecutive points.  Per chunk:
+//  A. index pass: read geom, bounds test, write pos_memo, insert the cell key
+//     (b*ny+y)*nx+x into an LDS hash table; the inserting lane claims the next free
+//     LDS BEV row ("slot").
+//  B. stream pass: the chunk's [points, C] feature block is read as flat float4s
+//     (fully coalesced; rows of dropped points are not fetched) and added into the
+//     slot rows with LDS float atomics.
+//  C. flush: every used slot is added to the global BEV as one coalesced row of
+//     global fp32 atomics.
+// Points whose cell finds no slot (more distinct cells in the chunk than LDS rows)
+// fall back to direct row atomics, so any geometry is handled.
+//
+// LDS row layout for VEC==4: channel 4j+k is stored at k*C4 + j, so that the four
+// ds_add_f32 of a lane's float4 hit consecutive banks across lanes (conflict-free
+// within a row); the flush undoes the permutation.
+template <int VEC, int C4T>
+__global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C = a.C;
+    const int CV = (VEC == 4) ? (C4T > 0 ? C4T : C / 4) : C;
+    float *acc = reinterpret_cast<float *>(smem);               // [nslot][C]
+    int *tab = reinterpret_cast<int *>(acc + (size_t)a.nslot * C);  // [kHashSize] keys
+    int *ent_slot = tab + kHashSize;                            // [kHashSize] slot of entry
+    int *slot_key = ent_slot + kHashSize;                       // [nslot]
+    int *pt_slot = slot_key + a.nslot;                          // [kChunk]
+    int *counter = pt_slot + kChunk;                            // [1]
+
+    const int tid = threadIdx.x;
+    constexpr int PPT = kChunk / kBlock;  // points per thread
+
+    for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+        const int64_t base = (int64_t)chunk * kChunk;
+        const int npts = (int)((a.BP - base) < kChunk ? (a.BP - base) : kChunk);
+
+        for (int i = tid; i < kHashSize; i += kBlock) tab[i] = kEmpty;
+        if (tid == 0) *counter = 0;
+        __syncthreads();
+
+        // ---- A: index pass
+        int ent[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int lp = tid + k * kBlock;
+            int e = kDropped;
+            if (lp < npts) {
+                const int64_t t = base + lp;
+                const int x = a.geom[t * 3], y = a.geom[t * 3 + 1], z = a.geom[t * 3 + 2];
+                if (in_grid(x, y, z, a.nx, a.ny, a.nz)) {
+                    const int b = (int)(t / a.P);
+                    write_pos(a.pos_memo, t, b, y, x);
+                    const int key = (b * a.ny + y) * a.nx + x;
+                    unsigned h = ((unsigned)key * 2654435761u) >> (32 - 9);  // log2(kHashSize)=9
+                    e = kOverflow;
+                    for (int probe = 0; probe < kHashSize; ++probe) {
+                        const int prev = atomicCAS(&tab[h], kEmpty, key);
+                        if (prev == kEmpty) {
+                            const int s = atomicAdd(counter, 1);
+                            if (s < a.nslot) { ent_slot[h] = s; slot_key[s] = key; }
+                            else ent_slot[h] = kOverflow;
+                            e = (int)h;
+                            break;
+                        }
+                        if (prev == key) { e = (int)h; break; }
+                        h = (h + 1) & (kHashSize - 1);
+                    }
+                } else if (a.write_dropped) {
+                    write_pos(a.pos_memo, t, -1, -1, -1);
+                }
+            }
+            ent[k] = e;
+        }
+        __syncthreads();
+        const int nused = (*counter < a.nslot) ? *counter : a.nslot;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            pt_slot[tid + k * kBlock] = ent[k] >= 0 ? ent_slot[ent[k]] : ent[k];
+        for (int i = tid; i < nused * C; i += kBlock) acc[i] = 0.0f;
+        __syncthreads();
+
+        // ---- B: stream pass
+        const int nvec = npts * CV;
+        if (VEC == 4) {
+            const float4 *src = reinterpret_cast<const float4 *>(a.feats + base * C);
+            constexpr int U = 4;
+            for (int i0 = tid; i0 < nvec; i0 += kBlock * U) {
+                float4 v[U];
+                int slot[U], cv[U], row[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kBlock;
+                    slot[u] = kDropped;
+                    if (i < nvec) {
+                        row[u] = i / CV;
+                        cv[u] = i - row[u] * CV;
+                        slot[u] = pt_slot[row[u]];
+                        if (slot[u] != kDropped) v[u] = src[i];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (slot[u] >= 0) {
+                        float *r = acc + slot[u] * C + cv[u];
+                        atomicAdd(r, v[u].x);
+                        atomicAdd(r + CV, v[u].y);
+                        atomicAdd(r + 2 * CV, v[u].z);
+                        atomicAdd(r + 3 * CV, v[u].w);
+                    } else if (slot[u] == kOverflow) {
+                        const int64_t t = base + row[u];
+                        const int x = a.geom[t * 3], y = a.geom[t * 3 + 1];
+                        const int b = (int)(t / a.P);
+                        float *o = a.out + (((int64_t)b * a.ny + y) * a.nx + x) * C + cv[u] * 4;
+                        atomicAdd(o, v[u].x);
+                        atomicAdd(o + 1, v[u].y);
+                        atomicAdd(o + 2, v[u].z);
+                        atomicAdd(o + 3, v[u].w);
+                    }
+                }
+            }
+        } else {
+            const float *src = a.feats + base * C;
+            for (int i = tid; i < nvec; i += kBlock) {
+                const int row = i / C;
+                const int c = i - row * C;
+                const int slot = pt_slot[row];
+                if (slot >= 0) {
+                    atomicAdd(acc + slot * C + c, src[i]);
+                } else if (slot == kOverflow) {
+                    const int64_t t = base + row;
+                    const int x = a.geom[t * 3], y = a.geom[t * 3 + 1];
+                    const int b = (int)(t / a.P);
+                    atomicAdd(a.out + (((int64_t)b * a.ny + y) * a.nx + x) * C + c, src[i]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- C: flush used slots as coalesced rows of global atomics
+        for (int i = tid; i < nused * C; i += kBlock) {
+            const int s = i / C;
+            const int c = i - s * C;
+            const int pos = (VEC == 4) ? ((c & 3) * CV + (c >> 2)) : c;
+            atomicAdd(a.out + (int64_t)slot_key[s] * C + c, acc[s * C + pos]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Backward: grad_in[t,:] = grad_out[b,:,y,x] (kept) or 0.  Pure gather: the BEV
+// gradient (B*ny*nx*C fp32, 21 MB at cfg2) is served from L2 / Infinity Cache, the
+// [B*P, C] result is streamed out with non-temporal 16-byte stores so it does not
+// evict the gradient rows.
+struct VpBwdArgs {
+    int64_t BP;
+    int C, nx, ny;
+    const int32_t *pos_memo;
+    const float *grad_out;
+    int64_t sb, sc, sy, sx;
+    float *grad_in;
+};
+
+template <int C4T>
+__global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
+    const int CV = C4T > 0 ? C4T : a.C / 4;
+    const int64_t total = a.BP * CV;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    float4 *dst = reinterpret_cast<float4 *>(a.grad_in);
+    constexpr int U = 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < total; i0 += stride * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * kBlock;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < total) {
+                const int64_t t = i / CV;
+                const int cv = (int)(i - t * CV);
+                const int b = a.pos_memo[t * 3];
+                if (b != -1) {
+                    const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
+                    v[u] = *reinterpret_cast<const float4 *>(a.grad_out + b * a.sb + y * a.sy +
+                                                             x * a.sx + cv * 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * kBlock;
+            if (i < total) mmt_nt_store4(v[u], dst + i);
+        }
+    }
+}
+
+// any strides, any C (slow path: one element per lane)
+__global__ __launch_bounds__(kBlock) void vp_bwd_strided(VpBwdArgs a) {
+    const int64_t total = a.BP * a.C;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const int64_t t = i / a.C;
+        const int c = (int)(i - t * a.C);
+        const int b = a.pos_memo[t * 3];
+        float v = 0.f;
+        if (b != -1) {
+            const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
+            v = a.grad_out[b * a.sb + c * a.sc + y * a.sy + x * a.sx];
+        }
+        a.grad_in[i] = v;
+    }
+}
+
+// [B,C,ny,nx] (element strides) -> channels-last workspace [B,ny*nx,C] through a
+// 32x33 LDS tile: reads run along the spatial axis, writes along the channel axis.
+__global__ __launch_bounds__(kBlock) void vp_to_channels_last(int C, int ny, int nx,
+                                                              const float *src, int64_t sb,
+                                                              int64_t sc, int64_t sy, int64_t sx,
+                                                              float *dst) {
+    __shared__ float tile[32][33];
+    const int HW = ny * nx;
+    const int b = blockIdx.z;
+    const int s0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, s = s0 + tx;
+        float v = 0.f;
+        if (c < C && s < HW) {
+            const int y = s / nx, x = s - y * nx;
+            v = src[b * sb + c * sc + y * sy + x * sx];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int s = s0 + r, c = c0 + tx;
+        if (c < C && s < HW) dst[((int64_t)b * HW + s) * C + c] = tile[tx][r];
+    }
+}
+
+template <int VEC>
+int launch_lds_combine(const VpArgs &a, int grid, size_t lds, hipStream_t st) {
+    if (VEC == 4) {
+        if (a.C == 80) hipLaunchKernelGGL((vp_fwd_lds_combine<4, 20>), dim3(grid), dim3(kBlock), lds, st, a);
+        else if (a.C == 64) hipLaunchKernelGGL((vp_fwd_lds_combine<4, 16>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((vp_fwd_lds_combine<4, 0>), dim3(grid), dim3(kBlock), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((vp_fwd_lds_combine<1, 0>), dim3(grid), dim3(kBlock), lds, st, a);
+    }
+    return mmt::check_launch("voxel_pooling_forward(lds_combine)");
+}
+
+}  // namespace
+
+extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny, int nz,
+                                            const int32_t *geom, const float *feats, float *out,
+                                            int32_t *pos_memo, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(feats);
+    MMT_REQUIRE_PTR(out);
+    MMT_REQUIRE_PTR(pos_memo);
+    if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "voxel_pooling_forward: non-positive size (B=%d P=%d C=%d grid=%dx%dx%d)", B, P, C, nx, ny, nz);
+    const int64_t BP = (int64_t)B * P;
+    if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_forward: B*P or B*ny*nx exceeds int32");
+    const int algo = flags & MMT_VP_ALGO_MASK;
+    if (algo != MMT_VP_ALGO_AUTO && algo != MMT_VP_ALGO_ROW_ATOMIC)
+        return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown algorithm %d", algo);
+    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown flag bits 0x%x", flags);
+    hipStream_t st = (hipStream_t)stream;
+
+    VpArgs a;
+    a.BP = BP; a.P = P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
+    a.geom = geom; a.feats = feats; a.out = out; a.pos_memo = pos_memo;
+    a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
+    // float4 path needs 16-byte aligned rows
+    const bool vec4 = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0);
+
+    if (algo == MMT_VP_ALGO_ROW_ATOMIC) {
+        a.nslot = 0; a.nchunks = 0;
+        const int64_t work = BP * (vec4 ? C / 4 : C);
+        const int grid = mmt::stream_grid(work, kBlock);
+        if (vec4) hipLaunchKernelGGL((vp_fwd_row_atomic<4>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((vp_fwd_row_atomic<1>), dim3(grid), dim3(kBlock), 0, st, a);
+        return mmt::check_launch("voxel_pooling_forward(row_atomic)");
+    }
+
+    // LDS budget: ~40 KiB of BEV rows per workgroup -> 3 workgroups (12 waves) per CU.
+    int nslot = (40 * 1024) / (C * 4);
+    if (nslot > 256) nslot = 256;
+    if (nslot < 4) {  // rows too long for the LDS tile: use plain row atomics
+        return mmt_voxel_pooling_forward_ex(B, P, C, nx, ny, nz, geom, feats, out, pos_memo,
+                                            (flags & ~MMT_VP_ALGO_MASK) | MMT_VP_ALGO_ROW_ATOMIC, stream);
+    }
+    a.nslot = nslot;
+    a.nchunks = (int)mmt::ceil_div(BP, kChunk);
+    const size_t lds = (size_t)nslot * C * 4 + (size_t)(2 * kHashSize + nslot + kChunk + 4) * 4;
+    const int grid = a.nchunks < 256 * 32 ? a.nchunks : 256 * 32;
+    return vec4 ? launch_lds_combine<4>(a, grid, lds, st) : launch_lds_combine<1>(a, grid, lds, st);
+}
+
+extern "C" int mmt_voxel_pooling_forward(int B, int P, int C, int nx, int ny, int nz,
+                                         const int32_t *geom, const float *feats, float *out,
+                                         int32_t *pos_memo, void *stream) {
+    return mmt_voxel_pooling_forward_ex(B, P, C, nx, ny, nz, geom, feats, out, pos_memo,
+                                        MMT_VP_ALGO_AUTO, stream);
+}
+
+extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
+                                          const int32_t *pos_memo, const float *grad_out,
+                                          int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                          float *grad_in, float *workspace, void *stream) {
+    MMT_REQUIRE_PTR(pos_memo);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_in);
+    if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "voxel_pooling_backward: non-positive size");
+    const int64_t BP = (int64_t)B * P;
+    if (BP >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_backward: B*P exceeds int32");
+    hipStream_t st = (hipStream_t)stream;
+
+    VpBwdArgs a;
+    a.BP = BP; a.C = C; a.nx = nx; a.ny = ny;
+    a.pos_memo = pos_memo; a.grad_out = grad_out; a.grad_in = grad_in;
+    a.sb = sb; a.sc = sc; a.sy = sy; a.sx = sx;
+
+    if (sc != 1 && workspace != nullptr) {
+        dim3 grid((unsigned)mmt::ceil_div((int64_t)ny * nx, 32), (unsigned)mmt::ceil_div(C, 32), (unsigned)B);
+        hipLaunchKernelGGL(vp_to_channels_last, grid, dim3(kBlock), 0, st, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
+        int rc = mmt::check_launch("voxel_pooling_backward(to_channels_last)");
+        if (rc) return rc;
+        a.grad_out = workspace;
+        a.sc = 1; a.sx = C; a.sy = (int64_t)nx * C; a.sb = (int64_t)ny * nx * C;
+    }
+    const bool vec4 = a.sc == 1 && C % 4 == 0 && a.sb % 4 == 0 && a.sy % 4 == 0 && a.sx % 4 == 0 &&
+                      (((uintptr_t)a.grad_out & 15) == 0) && (((uintptr_t)grad_in & 15) == 0);
+    if (vec4) {
+        const int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock);
+        if (C == 80) hipLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, a);
+        else if (C == 64) hipLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, a);
+        return mmt::check_launch("voxel_pooling_backward(rows_vec4)");
+    }
+    const int grid = mmt::stream_grid(BP * C, kBlock);
+    hipLaunchKernelGGL(vp_bwd_strided, dim3(grid), dim3(kBlock), 0, st, a);
+    return mmt::check_launch("voxel_pooling_backward(strided)");
+}

@@ -1,0 +1,105 @@
+"""Extension module of the op, same entry point as the reference's pybind module
+``ops.voxel_pooling.voxel_pooling_ext`` (ops/voxel_pooling/src/voxel_pooling_forward.cpp:24-41,
+built by setup.py:60-67) -- here a thin Python binding of the C ABI in
+``libmmt_hip.so`` (include/mmt_hip.h) instead of an ATen/pybind11 shim.
+
+``voxel_pooling_forward_wrapper`` keeps the reference's 10-argument signature,
+argument meaning, ownership (caller allocates; ``output_features`` is accumulated
+into, ``pos_memo`` rows of kept points are overwritten) and checked error cases
+(RuntimeError for non-CUDA / non-contiguous geom or features, and for a dtype other
+than int32 / float32).  It launches on the current stream and does not synchronise.
+A failed launch raises instead of calling exit(-1) (voxel_pooling_forward_cuda.cu:51-55).
+
+``voxel_pooling_backward_wrapper`` is new: the reference's backward is pure ATen
+(ops/voxel_pooling/voxel_pooling.py:58-69).
+"""
+import torch
+
+from ... import _lib
+
+
+def _check_input(t, name, dtype):
+    # CHECK_INPUT (voxel_pooling_forward.cpp:10-16) + the data_ptr<T>() dtype check (:28-31)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDAtensor ")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous ")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected scalar type {dtype} but found {t.dtype} for {name}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# Optional per-launch timing for bench.py's roofline figure: when set to a dict, every
+# kernel launch below is bracketed by HIP events recorded on the launch stream and the
+# (start, end) pairs are appended under "forward" / "backward".
+TIMING = None
+
+
+def _timed_call(kind, *args):
+    if TIMING is None:
+        return _lib.call(*args)
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    _lib.call(*args)
+    end.record()
+    TIMING.setdefault(kind, []).append((start, end))
+
+
+def voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, num_voxel_x,
+                                  num_voxel_y, num_voxel_z, geom_xyz_tensor,
+                                  input_features_tensor, output_features_tensor,
+                                  pos_memo_tensor, flags=_lib.VP_ALGO_AUTO):
+    _check_input(geom_xyz_tensor, "geom_xyz_tensor", torch.int32)
+    _check_input(input_features_tensor, "input_features_tensor", torch.float32)
+    if output_features_tensor.dtype != torch.float32 or pos_memo_tensor.dtype != torch.int32:
+        raise RuntimeError("output_features must be float32 and pos_memo int32")
+    if not (output_features_tensor.is_cuda and pos_memo_tensor.is_cuda):
+        raise RuntimeError("output_features and pos_memo must be CUDA tensors")
+    B, P, C = int(batch_size), int(num_points), int(num_channels)
+    nx, ny, nz = int(num_voxel_x), int(num_voxel_y), int(num_voxel_z)
+    # the reference never validates these; a wrong size here would be an out-of-bounds
+    # device access, so refuse it on the host
+    if geom_xyz_tensor.numel() != B * P * 3 or input_features_tensor.numel() != B * P * C:
+        raise RuntimeError("geom_xyz / input_features do not match (batch_size, num_points, num_channels)")
+    if output_features_tensor.numel() != B * ny * nx * C or not output_features_tensor.is_contiguous():
+        raise RuntimeError("output_features must be a contiguous [B, ny, nx, C] tensor")
+    if pos_memo_tensor.numel() != B * P * 3 or not pos_memo_tensor.is_contiguous():
+        raise RuntimeError("pos_memo must be a contiguous [B, P, 3] tensor")
+    with torch.cuda.device(input_features_tensor.device):
+        _timed_call("forward", "mmt_voxel_pooling_forward_ex", B, P, C, nx, ny, nz,
+                  geom_xyz_tensor.data_ptr(), input_features_tensor.data_ptr(),
+                  output_features_tensor.data_ptr(), pos_memo_tensor.data_ptr(),
+                  int(flags), _stream())
+    return 1
+
+
+def voxel_pooling_backward_wrapper(batch_size, num_points, num_channels, num_voxel_x,
+                                   num_voxel_y, pos_memo_tensor, grad_output_tensor,
+                                   grad_input_tensor, workspace_tensor=None):
+    """grad_input[B,P,C] <- gather of grad_output (indexed [B,C,ny,nx], any strides)."""
+    _check_input(pos_memo_tensor, "pos_memo_tensor", torch.int32)
+    _check_input(grad_input_tensor, "grad_input_tensor", torch.float32)
+    if not grad_output_tensor.is_cuda or grad_output_tensor.dtype != torch.float32:
+        raise RuntimeError("grad_output_tensor must be a float32 CUDAtensor ")
+    B, P, C = int(batch_size), int(num_points), int(num_channels)
+    nx, ny = int(num_voxel_x), int(num_voxel_y)
+    if tuple(grad_output_tensor.shape) != (B, C, ny, nx):
+        raise RuntimeError(f"grad_output must have shape {(B, C, ny, nx)}, got {tuple(grad_output_tensor.shape)}")
+    if pos_memo_tensor.numel() != B * P * 3 or grad_input_tensor.numel() != B * P * C:
+        raise RuntimeError("pos_memo / grad_input do not match (batch_size, num_points, num_channels)")
+    sb, sc, sy, sx = grad_output_tensor.stride()
+    ws = 0
+    if workspace_tensor is not None:
+        if (not workspace_tensor.is_cuda or workspace_tensor.dtype != torch.float32
+                or workspace_tensor.numel() < B * ny * nx * C or not workspace_tensor.is_contiguous()):
+            raise RuntimeError("workspace must be a contiguous float32 CUDA tensor of >= B*ny*nx*C elements")
+        ws = workspace_tensor.data_ptr()
+    with torch.cuda.device(grad_input_tensor.device):
+        _timed_call("backward", "mmt_voxel_pooling_backward", B, P, C, nx, ny, pos_memo_tensor.data_ptr(),
+                  grad_output_tensor.data_ptr(), sb, sc, sy, sx, grad_input_tensor.data_ptr(),
+                  ws, _stream())
+    return 1

@@ -1,0 +1,245 @@
+"""CPU oracle for the BEV-fusion hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this package, and only as the checker / reported CPU baseline.  The
+product package ``mm_training_amd`` never imports it and has no CPU fallback.
+
+Two layers:
+  * ``liboracle.so`` (``oracle.c``): single-threaded C restatement, each function
+    citing the reference file:line it follows.  numpy-array front-ends below.
+  * ``torch_*`` helpers: the reference semantics with PyTorch CPU ops
+    (``scatter_add_`` / ``index_add_`` / masked gather), used for the timed CPU
+    baseline exactly as BASELINE.md section 2 prescribes.
+
+Parity status: voxel_pooling fwd/bwd + quantise + frustum/geometry are pinned by
+``tests/golden`` fixtures generated from the reference's own Python; the LiDAR
+functions (voxelize / VFE / pillar scatter) restate un-vendored third-party code
+(mmcv-full 1.7.0, mmdet3d 1.0.0rc4) and are PARITY UNPINNED.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (seconds)."""
+    src = os.path.join(_HERE, "oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+
+
+# ---------------------------------------------------------------- camera half
+def quantize(xyz, voxel_coord, voxel_size):
+    """lss_fpn.py:461-462 -> int32 array of xyz's shape."""
+    xyz = _f32(xyz)
+    out = np.empty(xyz.shape, dtype=np.int32)
+    lib().oracle_quantize(ctypes.c_int64(xyz.size // 3), _p(xyz), _p(_f32(voxel_coord)),
+                          _p(_f32(voxel_size)), _p(out))
+    return out
+
+
+def voxel_pooling_forward(geom, feats, nx, ny, nz, out=None, pos_memo=None):
+    """voxel_pooling_forward_cuda.cu:16-34. geom [B,P,3] i32, feats [B,P,C] f32.
+
+    Returns (out [B,ny,nx,C] f32, pos_memo [B,P,3] i32)."""
+    geom = _i32(geom)
+    feats = _f32(feats)
+    B, P, C = feats.shape
+    assert geom.shape == (B, P, 3)
+    if out is None:
+        out = np.zeros((B, ny, nx, C), dtype=np.float32)
+    if pos_memo is None:
+        pos_memo = np.full((B, P, 3), -1, dtype=np.int32)
+    lib().oracle_voxel_pooling_forward(B, P, C, nx, ny, nz, _p(geom), _p(feats), _p(out),
+                                       _p(pos_memo))
+    return out, pos_memo
+
+
+def voxel_pooling_forward_f64(geom, feats, nx, ny, nz):
+    geom = _i32(geom)
+    feats = _f32(feats)
+    B, P, C = feats.shape
+    out = np.zeros((B, ny, nx, C), dtype=np.float64)
+    lib().oracle_voxel_pooling_forward_f64(B, P, C, nx, ny, nz, _p(geom), _p(feats), _p(out))
+    return out
+
+
+def voxel_pooling_backward(pos_memo, grad_out_bcyx, C=None):
+    """voxel_pooling.py:58-69.  grad_out_bcyx: numpy array indexed [B,C,ny,nx]
+    (any strides).  Returns grad_in [B,P,C]."""
+    pos_memo = _i32(pos_memo)
+    B, P, _ = pos_memo.shape
+    g = np.asarray(grad_out_bcyx)
+    assert g.dtype == np.float32 and g.ndim == 4
+    C = g.shape[1]
+    st = [s // 4 for s in g.strides]
+    # find the base pointer of element [0,0,0,0]
+    base = g.ctypes.data
+    grad_in = np.empty((B, P, C), dtype=np.float32)
+    lib().oracle_voxel_pooling_backward(
+        B, P, C, _p(pos_memo), ctypes.c_void_p(base), ctypes.c_int64(st[0]),
+        ctypes.c_int64(st[1]), ctypes.c_int64(st[2]), ctypes.c_int64(st[3]), _p(grad_in))
+    return grad_in
+
+
+def frustum(final_dim, downsample, d_bound):
+    """lss_fpn.py:308-326 -> [D,fH,fW,4] f32."""
+    D = ctypes.c_int()
+    fH = ctypes.c_int()
+    fW = ctypes.c_int()
+    args = (int(final_dim[0]), int(final_dim[1]), int(downsample),
+            ctypes.c_float(d_bound[0]), ctypes.c_float(d_bound[1]), ctypes.c_float(d_bound[2]),
+            ctypes.byref(D), ctypes.byref(fH), ctypes.byref(fW))
+    lib().oracle_frustum(*args, None)
+    out = np.empty((D.value, fH.value, fW.value, 4), dtype=np.float32)
+    lib().oracle_frustum(*args, _p(out))
+    return out
+
+
+def geometry(frustum_arr, combine):
+    """lss_fpn.py:328-361 given combine = sensor2ego @ inverse(intrin) [B,N,4,4]."""
+    fr = _f32(frustum_arr)
+    cb = _f32(combine)
+    B, N = cb.shape[:2]
+    D, fH, fW, _ = fr.shape
+    out = np.empty((B, N, D, fH, fW, 3), dtype=np.float32)
+    lib().oracle_geometry(B * N, D, fH, fW, _p(fr), _p(cb), _p(out))
+    return out
+
+
+def lift(depth, context):
+    """lss_fpn.py:441-460. depth [BN,D,fH,fW], context [BN,C,fH,fW] -> [BN,D,fH,fW,C]."""
+    depth = _f32(depth)
+    context = _f32(context)
+    BN, D, fH, fW = depth.shape
+    C = context.shape[1]
+    out = np.empty((BN, D, fH, fW, C), dtype=np.float32)
+    lib().oracle_lift(BN, D, fH, fW, C, _p(depth), _p(context), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------- LiDAR half
+def grid_size(point_cloud_range, voxel_size):
+    """mmcv Voxelization.__init__: round((max-min)/voxel_size) in fp32."""
+    r = np.asarray(point_cloud_range, dtype=np.float32)
+    v = np.asarray(voxel_size, dtype=np.float32)
+    return np.round((r[3:] - r[:3]) / v).astype(np.int32)
+
+
+def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels):
+    """One sample. Returns voxels [M,T,F], coors [M,3] (z,y,x), num_points [M]."""
+    pts = _f32(points)
+    n, F = pts.shape
+    vs = _f32(voxel_size)
+    rmin = _f32(point_cloud_range[:3])
+    grid = grid_size(point_cloud_range, voxel_size)
+    voxels = np.empty((max_voxels, max_points, F), dtype=np.float32)
+    coors = np.zeros((max_voxels, 3), dtype=np.int32)
+    npts = np.empty((max_voxels,), dtype=np.int32)
+    scratch = np.empty((int(grid[0]) * int(grid[1]) * int(grid[2]),), dtype=np.int32)
+    M = lib().oracle_hard_voxelize(n, F, _p(pts), _p(vs), _p(rmin), _p(grid), max_points,
+                                   max_voxels, _p(voxels), _p(coors), _p(npts), _p(scratch))
+    return voxels[:M].copy(), coors[:M].copy(), npts[:M].copy()
+
+
+def voxelize_batch(points_list, voxel_size, point_cloud_range, max_points, max_voxels):
+    """mmdet3d MVXTwoStageDetector.voxelize: per-sample hard voxelization, coors
+    padded with the batch index in front -> (voxels, num_points, coors[M,4])."""
+    vs, ns, cs = [], [], []
+    for b, pts in enumerate(points_list):
+        v, c, n = hard_voxelize(pts, voxel_size, point_cloud_range, max_points, max_voxels)
+        vs.append(v)
+        ns.append(n)
+        cs.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    return np.concatenate(vs, 0), np.concatenate(ns, 0), np.concatenate(cs, 0)
+
+
+def simple_vfe(voxels, num_points, num_features):
+    voxels = _f32(voxels)
+    M, T, F = voxels.shape
+    out = np.empty((M, num_features), dtype=np.float32)
+    lib().oracle_simple_vfe(M, T, F, num_features, _p(voxels), _p(_i32(num_points)), _p(out))
+    return out
+
+
+def pillar_scatter(feats, coors, batch_size, ny, nx):
+    feats = _f32(feats)
+    coors = _i32(coors)
+    M, C = feats.shape
+    canvas = np.empty((batch_size, C, ny, nx), dtype=np.float32)
+    lib().oracle_pillar_scatter(M, C, batch_size, ny, nx, _p(feats), _p(coors), _p(canvas))
+    return canvas
+
+
+def pillar_scatter_backward(grad_canvas, coors):
+    g = _f32(grad_canvas)
+    coors = _i32(coors)
+    B, C, ny, nx = g.shape
+    M = coors.shape[0]
+    out = np.empty((M, C), dtype=np.float32)
+    scratch = np.empty((B * ny * nx,), dtype=np.int32)
+    lib().oracle_pillar_scatter_backward(M, C, B, ny, nx, _p(g), _p(coors), _p(out), _p(scratch))
+    return out
+
+
+# ------------------------------------------------- torch CPU baseline (timed)
+def torch_forward_scatter_add(geom, feats, nx, ny, nz, use_index_add=False):
+    """BASELINE.md section 2 forward: reference semantics with torch CPU ops."""
+    import torch
+    B, P, C = feats.shape
+    g = geom.reshape(B * P, 3)
+    kept = ((g[:, 0] >= 0) & (g[:, 0] < nx) & (g[:, 1] >= 0) & (g[:, 1] < ny)
+            & (g[:, 2] >= 0) & (g[:, 2] < nz))
+    b = torch.arange(B * P, dtype=torch.int64) // P
+    idx = ((b * ny + g[:, 1].long()) * nx + g[:, 0].long())[kept]
+    out = torch.zeros(B * ny * nx, C, dtype=feats.dtype)
+    src = feats.reshape(B * P, C)[kept]
+    if use_index_add:
+        out.index_add_(0, idx, src)
+    else:
+        out.scatter_add_(0, idx[:, None].expand(-1, C), src)
+    pos = torch.full((B * P, 3), -1, dtype=torch.int32)
+    pos[kept] = torch.stack([b[kept].int(), g[kept, 1], g[kept, 0]], 1)
+    return out.view(B, ny, nx, C), pos.view(B, P, 3)
+
+
+def torch_backward_gather(pos_memo, grad_out_nhwc):
+    """BASELINE.md section 2 backward (= voxel_pooling.py:60-66 on CPU tensors)."""
+    import torch
+    B, P, _ = pos_memo.shape
+    _, ny, nx, C = grad_out_nhwc.shape
+    pm = pos_memo.reshape(B * P, 3)
+    kept = pm[:, 0] != -1
+    idx = ((pm[:, 0].long() * ny + pm[:, 1].long()) * nx + pm[:, 2].long())[kept]
+    grad_in = torch.zeros(B * P, C, dtype=grad_out_nhwc.dtype)
+    grad_in[kept] = grad_out_nhwc.reshape(-1, C)[idx]
+    return grad_in.view(B, P, C)

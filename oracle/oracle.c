@@ -1,0 +1,300 @@
+/*
+ * oracle.c -- CPU restatement of the aimotive/mm_training BEV-fusion hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the reported CPU baseline.  The product path
+ * (mm_training_amd/) never falls back to it.
+ *
+ * Every function cites the reference lines (relative to /root/reference) it
+ * restates.  Parity status:
+ *   - voxel_pooling forward/backward, quantise, frustum geometry: PINNED against
+ *     the reference's own Python/test code run in the build container
+ *     (tests/golden/make_golden.py, fixtures under tests/golden/).
+ *   - LiDAR hard voxelization / HardSimpleVFE / PointPillarsScatter: the arithmetic
+ *     lives in un-vendored third-party packages (mmcv-full 1.7.0 ops.Voxelization,
+ *     mmdet3d 1.0.0rc4; pinned only by README.md:19-27).  The published sequential
+ *     algorithm is restated here; PARITY UNPINNED (no reference test or fixture
+ *     covers it; call sites models/bev_depth.py:181-183).
+ *
+ * Plain C99, single-threaded, no dependencies.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* float -> int32 conversion with the semantics of the device the reference
+ * runs on.  layers/backbones/lss_fpn.py:461-462 calls Tensor.int() on a CUDA
+ * tensor: cvt.rzi.s32.f32 truncates toward zero, saturates, and maps NaN to 0.
+ * gfx950's v_cvt_i32_f32 behaves the same.  (torch-CPU on x86 would produce
+ * INT_MIN for NaN/out-of-range; that is not the device the reference uses.) */
+static int32_t f2i_rz_sat(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v; /* C cast truncates toward zero */
+}
+
+/* ------------------------------------------------------------------------- */
+/* a6: quantise.  layers/backbones/lss_fpn.py:461-462
+ *   geom_xyz = ((geom_xyz - (voxel_coord - voxel_size / 2.0)) / voxel_size).int()
+ * All arithmetic is fp32 tensor arithmetic: lo = fp32(vc - fp32(vs/2)); then a
+ * subtract and a true IEEE divide per element, then truncation. */
+void oracle_quantize(int64_t n_points, const float *xyz, const float *voxel_coord,
+                     const float *voxel_size, int32_t *out) {
+    volatile float lo[3];
+    for (int a = 0; a < 3; ++a) {
+        volatile float half = voxel_size[a] / 2.0f;
+        lo[a] = voxel_coord[a] - half;
+    }
+    for (int64_t i = 0; i < n_points; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            volatile float d = xyz[i * 3 + a] - lo[a];
+            volatile float q = d / voxel_size[a];
+            out[i * 3 + a] = f2i_rz_sat(q);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a1: forward.  ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:16-34 and the
+ * sequential ground-truth loop test/test_ops/test_voxel_pooling.py:23-30.
+ * out [B,ny,nx,C] is accumulated into (+=), pos_memo rows of kept points are
+ * overwritten with (b, y, x); dropped rows are left untouched.  Accumulation is
+ * fp32 in point order (the order of the reference's test loop). */
+void oracle_voxel_pooling_forward(int B, int P, int C, int nx, int ny, int nz,
+                                  const int32_t *geom, const float *feats,
+                                  float *out, int32_t *pos_memo) {
+    for (int64_t t = 0; t < (int64_t)B * P; ++t) {
+        int b = (int)(t / P);
+        int x = geom[t * 3], y = geom[t * 3 + 1], z = geom[t * 3 + 2];
+        if (x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz) continue;
+        pos_memo[t * 3] = b;
+        pos_memo[t * 3 + 1] = y;
+        pos_memo[t * 3 + 2] = x;
+        float *o = out + (((int64_t)b * ny + y) * nx + x) * C;
+        const float *f = feats + t * C;
+        for (int c = 0; c < C; ++c) o[c] += f[c];
+    }
+}
+
+/* Same, with a float64 accumulator image (tight reference for tolerance tests). */
+void oracle_voxel_pooling_forward_f64(int B, int P, int C, int nx, int ny, int nz,
+                                      const int32_t *geom, const float *feats,
+                                      double *out) {
+    for (int64_t t = 0; t < (int64_t)B * P; ++t) {
+        int b = (int)(t / P);
+        int x = geom[t * 3], y = geom[t * 3 + 1], z = geom[t * 3 + 2];
+        if (x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz) continue;
+        double *o = out + (((int64_t)b * ny + y) * nx + x) * C;
+        const float *f = feats + t * C;
+        for (int c = 0; c < C; ++c) o[c] += (double)f[c];
+    }
+}
+
+/* a5: backward.  ops/voxel_pooling/voxel_pooling.py:58-69:
+ *   kept = (pos_memo != -1)[..., 0]
+ *   grad_in[kept] = grad_out[pos_memo[kept][...,0], :, pos_memo[kept][...,1], pos_memo[kept][...,2]]
+ * grad_out is addressed as [B,C,ny,nx] through element strides (sb,sc,sy,sx) so a
+ * permuted view works.  grad_in rows of dropped points are written as zero (the
+ * reference starts from zeros_like, voxel_pooling.py:29). */
+void oracle_voxel_pooling_backward(int B, int P, int C, const int32_t *pos_memo,
+                                   const float *grad_out, int64_t sb, int64_t sc,
+                                   int64_t sy, int64_t sx, float *grad_in) {
+    for (int64_t t = 0; t < (int64_t)B * P; ++t) {
+        float *g = grad_in + t * C;
+        if (pos_memo[t * 3] == -1) {
+            for (int c = 0; c < C; ++c) g[c] = 0.0f;
+            continue;
+        }
+        int64_t b = pos_memo[t * 3], y = pos_memo[t * 3 + 1], x = pos_memo[t * 3 + 2];
+        const float *src = grad_out + b * sb + y * sy + x * sx;
+        for (int c = 0; c < C; ++c) g[c] = src[c * sc];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a7: frustum + geometry.  layers/backbones/lss_fpn.py:308-326 (create_frustum)
+ * and :328-361 (get_geometry).  The reference evaluates `combine = sensor2ego @
+ * inverse(intrin)` with torch (LAPACK on CPU, cuBLAS/MAGMA on GPU); the inverse is
+ * therefore an INPUT here (combine, fp32 [B*N,4,4] row-major) and the bit-exact
+ * contract starts at that matrix.  Per point: p = (u*d, v*d, d, 1);
+ * xyz = (combine @ p)[:3] as an fp32 dot product accumulated in k order, which is
+ * what a 4x4 @ 4x1 batched matmul does on CPU (no FMA contraction here: compile
+ * with -ffp-contract=off). */
+void oracle_frustum(int ogfH, int ogfW, int downsample, float d_lo, float d_hi,
+                    float d_step, int *D_out, int *fH_out, int *fW_out, float *frustum) {
+    int fH = ogfH / downsample, fW = ogfW / downsample;
+    /* torch.arange(lo, hi, step): ceil((hi-lo)/step) elements computed in double */
+    int D = (int)ceil(((double)d_hi - (double)d_lo) / (double)d_step);
+    *D_out = D; *fH_out = fH; *fW_out = fW;
+    if (!frustum) return;
+    for (int d = 0; d < D; ++d)
+        for (int h = 0; h < fH; ++h)
+            for (int w = 0; w < fW; ++w) {
+                float *f = frustum + (((int64_t)d * fH + h) * fW + w) * 4;
+                /* torch.linspace(0, end, steps) fp32: start + i*step for the first
+                 * half, end - (steps-1-i)*step for the second half, step=(end-start)/(steps-1) */
+                float xs, ys;
+                {
+                    float end = (float)(ogfW - 1), step = fW > 1 ? end / (float)(fW - 1) : 0.f;
+                    xs = (w < fW / 2) ? (0.f + step * (float)w) : (end - step * (float)(fW - 1 - w));
+                }
+                {
+                    float end = (float)(ogfH - 1), step = fH > 1 ? end / (float)(fH - 1) : 0.f;
+                    ys = (h < fH / 2) ? (0.f + step * (float)h) : (end - step * (float)(fH - 1 - h));
+                }
+                f[0] = xs; f[1] = ys;
+                f[2] = (float)((double)d_lo + (double)d * (double)d_step);
+                f[3] = 1.0f;
+            }
+}
+
+void oracle_geometry(int BN, int D, int fH, int fW, const float *frustum,
+                     const float *combine, float *xyz) {
+    int64_t S = (int64_t)D * fH * fW;
+    for (int bn = 0; bn < BN; ++bn) {
+        const float *M = combine + (int64_t)bn * 16;
+        for (int64_t s = 0; s < S; ++s) {
+            const float *f = frustum + s * 4;
+            volatile float p0 = f[0] * f[2], p1 = f[1] * f[2];
+            float p[4] = {p0, p1, f[2], f[3]};
+            float *o = xyz + ((int64_t)bn * S + s) * 3;
+            for (int r = 0; r < 3; ++r) {
+                volatile float acc = M[r * 4 + 0] * p[0];
+                for (int k = 1; k < 4; ++k) {
+                    volatile float prod = M[r * 4 + k] * p[k];
+                    acc = acc + prod;
+                }
+                o[r] = acc;
+            }
+        }
+    }
+}
+
+/* a8: lift.  layers/backbones/lss_fpn.py:441-460: feat[bn,d,h,w,c] =
+ * depth[bn,d,h,w] * context[bn,c,h,w], laid out [B,N,D,fH,fW,C] (the permute
+ * (0,1,3,4,5,2) + .contiguous() at :460,463). */
+void oracle_lift(int BN, int D, int fH, int fW, int C, const float *depth,
+                 const float *context, float *feats) {
+    int64_t HW = (int64_t)fH * fW;
+    for (int bn = 0; bn < BN; ++bn)
+        for (int d = 0; d < D; ++d)
+            for (int64_t s = 0; s < HW; ++s) {
+                float dv = depth[((int64_t)bn * D + d) * HW + s];
+                float *o = feats + ((((int64_t)bn * D + d) * HW) + s) * C;
+                for (int c = 0; c < C; ++c)
+                    o[c] = dv * context[((int64_t)bn * C + c) * HW + s];
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a9: hard voxelization of ONE sample.  Call site models/bev_depth.py:181; params
+ * exps/conf_aim.py:16-18,194-197.  Restates mmcv-full 1.7.0
+ * ops.Voxelization (hard mode, deterministic): PARITY UNPINNED, see header.
+ *   c_j = floor((p_j - range_min_j) / voxel_size_j) in fp32, for j = x,y,z;
+ *   drop the point if any c_j < 0 or >= grid_j; coordinates stored reversed (z,y,x);
+ *   voxels numbered in order of their first point; a voxel that would be number
+ *   >= max_voxels is not created (its points are dropped); at most max_points points
+ *   per voxel, first come first kept; voxels zero-padded.
+ * Returns the number of voxels M.  scratch_grid must hold grid_x*grid_y*grid_z
+ * int32 (filled with -1 by this function). */
+int oracle_hard_voxelize(int n_points, int F, const float *points,
+                         const float *voxel_size, const float *range_min,
+                         const int32_t *grid /* x,y,z */, int max_points, int max_voxels,
+                         float *voxels /* [max_voxels,max_points,F] */,
+                         int32_t *coors /* [max_voxels,3] z,y,x */,
+                         int32_t *num_points_per_voxel /* [max_voxels] */,
+                         int32_t *scratch_grid) {
+    int64_t cells = (int64_t)grid[0] * grid[1] * grid[2];
+    for (int64_t i = 0; i < cells; ++i) scratch_grid[i] = -1;
+    memset(voxels, 0, sizeof(float) * (size_t)max_voxels * max_points * F);
+    memset(num_points_per_voxel, 0, sizeof(int32_t) * (size_t)max_voxels);
+    int voxel_num = 0;
+    for (int i = 0; i < n_points; ++i) {
+        int c[3];
+        int failed = 0;
+        for (int j = 0; j < 3; ++j) {
+            volatile float d = points[(int64_t)i * F + j] - range_min[j];
+            volatile float q = d / voxel_size[j];
+            /* the device kernel does `int c = floor(q)`: a saturating convert with
+             * NaN -> 0 (same device semantics as f2i_rz_sat above), then the
+             * bounds test on the integer. */
+            int ci = f2i_rz_sat(floorf(q));
+            if (ci < 0 || ci >= grid[j]) { failed = 1; break; }
+            c[j] = ci;
+        }
+        if (failed) continue;
+        int64_t cell = ((int64_t)c[2] * grid[1] + c[1]) * grid[0] + c[0];
+        int vid = scratch_grid[cell];
+        if (vid == -1) {
+            if (voxel_num >= max_voxels) continue;
+            vid = voxel_num++;
+            scratch_grid[cell] = vid;
+            coors[vid * 3 + 0] = c[2];
+            coors[vid * 3 + 1] = c[1];
+            coors[vid * 3 + 2] = c[0];
+        }
+        int num = num_points_per_voxel[vid];
+        if (num < max_points) {
+            memcpy(voxels + ((int64_t)vid * max_points + num) * F,
+                   points + (int64_t)i * F, sizeof(float) * F);
+            num_points_per_voxel[vid] = num + 1;
+        }
+    }
+    return voxel_num;
+}
+
+/* a10: mmdet3d 1.0.0rc4 HardSimpleVFE(num_features): call site
+ * models/bev_depth.py:182, exps/conf_aim.py:198-201.
+ *   voxels[:, :, :nf].sum(1) / num_points.view(-1,1)
+ * Summation in slot order 0..T-1 over the zero-padded slots.  PARITY UNPINNED. */
+void oracle_simple_vfe(int M, int T, int F, int nf, const float *voxels,
+                       const int32_t *num_points, float *out /* [M,nf] */) {
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < nf; ++k) {
+            float s = 0.0f;
+            for (int t = 0; t < T; ++t) s += voxels[((int64_t)m * T + t) * F + k];
+            out[(int64_t)m * nf + k] = s / (float)num_points[m];
+        }
+}
+
+/* a11: mmdet3d 1.0.0rc4 PointPillarsScatter: call signature
+ * pts_middle_encoder(voxel_feats, coors, batch_size), models/bev_depth.py:183.
+ *   canvas[b, :, coors[:,2]*nx + coors[:,3]] = feats.T   (zeros elsewhere)
+ * coors rows are (b, z, y, x).  Duplicate (b,y,x) rows: the last row wins
+ * (sequential assignment order).  PARITY UNPINNED. */
+void oracle_pillar_scatter(int M, int C, int B, int ny, int nx, const float *feats,
+                           const int32_t *coors, float *canvas /* [B,C,ny,nx] */) {
+    memset(canvas, 0, sizeof(float) * (size_t)B * C * ny * nx);
+    for (int m = 0; m < M; ++m) {
+        int b = coors[m * 4], y = coors[m * 4 + 2], x = coors[m * 4 + 3];
+        if (b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx) continue;
+        for (int c = 0; c < C; ++c)
+            canvas[(((int64_t)b * C + c) * ny + y) * nx + x] = feats[(int64_t)m * C + c];
+    }
+}
+
+/* gradient of the scatter w.r.t. feats: grad_feats[m,c] = grad_canvas[b,c,y,x]
+ * for rows that own their cell (last-writer rows); overwritten rows get zero. */
+void oracle_pillar_scatter_backward(int M, int C, int B, int ny, int nx,
+                                    const float *grad_canvas, const int32_t *coors,
+                                    float *grad_feats, int32_t *scratch /* [B*ny*nx] */) {
+    for (int64_t i = 0; i < (int64_t)B * ny * nx; ++i) scratch[i] = -1;
+    for (int m = 0; m < M; ++m) {
+        int b = coors[m * 4], y = coors[m * 4 + 2], x = coors[m * 4 + 3];
+        if (b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx) continue;
+        scratch[((int64_t)b * ny + y) * nx + x] = m;
+    }
+    for (int m = 0; m < M; ++m) {
+        int b = coors[m * 4], y = coors[m * 4 + 2], x = coors[m * 4 + 3];
+        int owner = 0;
+        if (!(b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx))
+            owner = scratch[((int64_t)b * ny + y) * nx + x] == m;
+        for (int c = 0; c < C; ++c)
+            grad_feats[(int64_t)m * C + c] =
+                owner ? grad_canvas[(((int64_t)b * C + c) * ny + y) * nx + x] : 0.0f;
+    }
+}
