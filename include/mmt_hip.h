@@ -57,9 +57,12 @@ int mmt_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
                               float *output_features, int32_t *pos_memo, void *stream);
 
 /* Same computation with explicit algorithm / behaviour flags. */
-#define MMT_VP_ALGO_AUTO 0        /* LDS-staged BEV-tile combine, then row atomics */
+#define MMT_VP_ALGO_AUTO 0        /* = SEG_GATHER when C % 4 == 0 and C <= 256, else LDS_ATOMIC */
 #define MMT_VP_ALGO_ROW_ATOMIC 1  /* one coalesced row of global fp32 atomics per kept point */
+#define MMT_VP_ALGO_LDS_ATOMIC 2  /* chunk BEV tile accumulated in LDS with ds_add_f32, then row atomics */
+#define MMT_VP_ALGO_SEG_GATHER 3  /* chunk sorted by cell in LDS, rows summed in registers, one atomic row per (chunk, cell) */
 #define MMT_VP_ALGO_MASK 0xF
+#define MMT_VP_CHUNK_1024 0x20    /* SEG_GATHER: 1024 points per workgroup instead of 512 */
 #define MMT_VP_WRITE_DROPPED 0x10 /* also write (-1,-1,-1) to pos_memo rows of dropped points,
                                      so the caller need not pre-fill pos_memo */
 int mmt_voxel_pooling_forward_ex(int batch_size, int num_points, int num_channels,

@@ -48,6 +48,11 @@ def lib():
     """Load libmmt_hip.so (once). Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64.so.7; it must be in the process BEFORE this
+        # library is loaded so both share one HIP runtime (streams, device pointers).
+        # Loaded the other way round, libmmt_hip binds /opt/rocm's copy and every launch
+        # fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m mm_training_amd.build` "

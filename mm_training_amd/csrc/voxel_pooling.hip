@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_row_atomic(VpArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// ALGO_AUTO: LDS-staged BEV-tile combine.
+// ALGO_LDS_ATOMIC (kept for comparison and for C % 4 != 0): LDS-staged BEV-tile combine
+// with LDS float atomics.
 //
 // A workgroup owns chunks of kChunk consecutive points.  Per chunk:
 //  A. index pass: read geom, bounds test, write pos_memo, insert the cell key
@@ -230,6 +231,179 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// ALGO_AUTO: chunk-local sort by BEV cell + register accumulation.
+//
+// A workgroup owns one chunk of CHUNK consecutive points.
+//  A. index pass: read geom, bounds test, write pos_memo, insert the cell key
+//     (b*ny+y)*nx+x into an LDS hash table (the inserting lane numbers the cell:
+//     "slot"), count points per slot, wave-scan the counts, and scatter the local
+//     point ids into a per-slot list (a counting sort of the chunk by cell).
+//  B. gather pass: each wave takes one slot at a time; the wave is split into
+//     G = 64 / (C/4) lane groups, each lane owning one float4 column of the feature
+//     row.  Group g walks every G-th point of the slot's list, loads whole rows
+//     (C*4 contiguous, 64-byte aligned bytes; rows of dropped points are never
+//     fetched) and sums them in REGISTERS -- no LDS or global atomics in the loop.
+//  C. the G partial rows meet in a 1 KiB LDS staging row and leave the wave as one
+//     contiguous run of global fp32 atomics per touched cell.
+// The BEV tile of the chunk therefore lives in registers + a staging row; HBM sees
+// each kept feature row once and one atomic row per (chunk, cell).
+template <int C4T, int CHUNK>
+__global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
+    constexpr int HT = CHUNK * 2;             // hash entries (load factor <= 0.5)
+    constexpr int HT_LOG2 = (CHUNK == 512) ? 10 : 11;
+    static_assert(CHUNK == 512 || CHUNK == 1024, "chunk size");
+    constexpr int PPT = CHUNK / kBlock;
+    constexpr int NW = kBlock / 64;
+    __shared__ int tab_key[HT];
+    __shared__ int tab_slot[HT];
+    __shared__ int slot_key[CHUNK];
+    __shared__ int slot_cnt[CHUNK];
+    __shared__ int slot_off[CHUNK + 1];
+    __shared__ unsigned short sorted[CHUNK];
+    __shared__ __align__(16) float stage[NW][256];
+    __shared__ int nslots, next_slot;
+
+    const int C = a.C;
+    const int C4 = C4T > 0 ? C4T : C >> 2;
+    const int G = 64 / C4;                    // lane groups per wave (C <= 256)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    const int npts = (int)((a.BP - base) < CHUNK ? (a.BP - base) : CHUNK);
+
+    for (int i = tid; i < HT; i += kBlock) tab_key[i] = kEmpty;
+    for (int i = tid; i < CHUNK; i += kBlock) slot_cnt[i] = 0;
+    if (tid == 0) { nslots = 0; next_slot = 0; }
+    __syncthreads();
+
+    // ---- A1: bounds test, pos_memo, hash insert
+    int ent[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int lp = tid + k * kBlock;
+        int e = -1;
+        if (lp < npts) {
+            const int64_t t = base + lp;
+            const int x = a.geom[t * 3], y = a.geom[t * 3 + 1], z = a.geom[t * 3 + 2];
+            if (in_grid(x, y, z, a.nx, a.ny, a.nz)) {
+                const int b = (int)((unsigned)t / (unsigned)a.P);
+                write_pos(a.pos_memo, t, b, y, x);
+                const int key = (b * a.ny + y) * a.nx + x;
+                unsigned h = ((unsigned)key * 2654435761u) >> (32 - HT_LOG2);
+                for (int probe = 0; probe < HT; ++probe) {  // never fills: <= CHUNK keys in 2*CHUNK entries
+                    const int prev = atomicCAS(&tab_key[h], kEmpty, key);
+                    if (prev == kEmpty) {
+                        const int s = atomicAdd(&nslots, 1);
+                        tab_slot[h] = s;
+                        slot_key[s] = key;
+                        e = (int)h;
+                        break;
+                    }
+                    if (prev == key) { e = (int)h; break; }
+                    h = (h + 1) & (HT - 1);
+                }
+            } else if (a.write_dropped) {
+                write_pos(a.pos_memo, t, -1, -1, -1);
+            }
+        }
+        ent[k] = e;
+    }
+    __syncthreads();
+
+    // ---- A2: per-slot counts (rank of the point inside its cell's list)
+    int slot[PPT], rank[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        slot[k] = -1;
+        rank[k] = 0;
+        if (ent[k] >= 0) {
+            slot[k] = tab_slot[ent[k]];
+            rank[k] = atomicAdd(&slot_cnt[slot[k]], 1);
+        }
+    }
+    __syncthreads();
+
+    // ---- A3: exclusive scan of the counts by wave 0 (CHUNK/64 entries per lane)
+    const int ns = nslots;
+    if (wave == 0) {
+        constexpr int PER = CHUNK / 64;
+        int loc[PER];
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            loc[i] = idx < ns ? slot_cnt[idx] : 0;
+            sum += loc[i];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            if (idx <= ns) slot_off[idx] = run;
+            run += loc[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- A4: counting-sort scatter of local point ids
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (slot[k] >= 0) sorted[slot_off[slot[k]] + rank[k]] = (unsigned short)(tid + k * kBlock);
+    __syncthreads();
+
+    // ---- B/C: one slot per wave at a time, register accumulation, staged flush
+    const int g = lane / C4;
+    const int li = lane - g * C4;
+    const bool active = g < G;
+    const float *fbase = a.feats + base * C + li * 4;
+    float *st = stage[wave];
+    for (;;) {
+        int s = 0;
+        if (lane == 0) s = atomicAdd(&next_slot, 1);
+        s = __builtin_amdgcn_readfirstlane(s);
+        if (s >= ns) break;
+        const int beg = slot_off[s], end = slot_off[s + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+            int j = beg + g;
+            for (; j + 3 * G < end; j += 4 * G) {
+                const int p0 = sorted[j], p1 = sorted[j + G], p2 = sorted[j + 2 * G], p3 = sorted[j + 3 * G];
+                const float4 v0 = *reinterpret_cast<const float4 *>(fbase + p0 * C);
+                const float4 v1 = *reinterpret_cast<const float4 *>(fbase + p1 * C);
+                const float4 v2 = *reinterpret_cast<const float4 *>(fbase + p2 * C);
+                const float4 v3 = *reinterpret_cast<const float4 *>(fbase + p3 * C);
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            }
+            for (; j < end; j += G) {
+                const int p0 = sorted[j];
+                const float4 v0 = *reinterpret_cast<const float4 *>(fbase + p0 * C);
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            }
+            *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float *orow = a.out + (int64_t)slot_key[s] * C;
+        for (int e = lane; e < C; e += 64) {
+            float sum = st[e];
+            for (int gg = 1; gg < G; ++gg) sum += st[gg * C + e];
+            atomicAdd(orow + e, sum);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Backward: grad_in[t,:] = grad_out[b,:,y,x] (kept) or 0.  Pure gather: the BEV
 // gradient (B*ny*nx*C fp32, 21 MB at cfg2) is served from L2 / Infinity Cache, the
@@ -248,10 +422,20 @@ template <int C4T>
 __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
     const int CV = C4T > 0 ? C4T : a.C / 4;
     const int64_t total = a.BP * CV;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
     float4 *dst = reinterpret_cast<float4 *>(a.grad_in);
     constexpr int U = 4;
-    for (int64_t i0 = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < total; i0 += stride * U) {
+    constexpr int64_t kTileVecs = (int64_t)kBlock * U;
+    // XCD-aware tile order: workgroups b, b+8, b+16.. share an XCD and its 4 MiB L2, so
+    // each XCD walks ONE contiguous eighth of the points; the BEV-gradient rows those
+    // points gather (a few cameras' footprint, ~2-3 MB) then stay L2-resident instead of
+    // all 8 L2s thrashing over the whole 21 MB gradient.  Placement only affects speed.
+    const int64_t ntiles = (total + kTileVecs - 1) / kTileVecs;
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const int64_t t_begin = xcd * per_xcd;
+    const int64_t t_end = (t_begin + per_xcd) < ntiles ? (t_begin + per_xcd) : ntiles;
+    for (int64_t tile = t_begin + (blockIdx.x >> 3); tile < t_end; tile += (gridDim.x >> 3)) {
+        const int64_t i0 = tile * kTileVecs + threadIdx.x;
         float4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -346,10 +530,10 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     const int64_t BP = (int64_t)B * P;
     if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_forward: B*P or B*ny*nx exceeds int32");
-    const int algo = flags & MMT_VP_ALGO_MASK;
-    if (algo != MMT_VP_ALGO_AUTO && algo != MMT_VP_ALGO_ROW_ATOMIC)
+    int algo = flags & MMT_VP_ALGO_MASK;
+    if (algo > MMT_VP_ALGO_SEG_GATHER)
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown algorithm %d", algo);
-    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED))
+    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown flag bits 0x%x", flags);
     hipStream_t st = (hipStream_t)stream;
 
@@ -357,11 +541,31 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     a.BP = BP; a.P = P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
     a.geom = geom; a.feats = feats; a.out = out; a.pos_memo = pos_memo;
     a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
-    // float4 path needs 16-byte aligned rows
+    a.nslot = 0; a.nchunks = 0;
+    // float4 paths need 16-byte aligned rows
     const bool vec4 = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0);
+    const bool seg_ok = vec4 && C <= 256;
+    if (algo == MMT_VP_ALGO_AUTO) algo = seg_ok ? MMT_VP_ALGO_SEG_GATHER : MMT_VP_ALGO_LDS_ATOMIC;
+    if (algo == MMT_VP_ALGO_SEG_GATHER && !seg_ok) algo = MMT_VP_ALGO_LDS_ATOMIC;
+
+    if (algo == MMT_VP_ALGO_SEG_GATHER) {
+        const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
+        const int chunk = big ? 1024 : 512;
+        const int64_t nchunks = mmt::ceil_div(BP, chunk);
+        const dim3 grid((unsigned)nchunks), block(kBlock);
+#define MMT_LAUNCH_SEG(C4T)                                                                     \
+    do {                                                                                        \
+        if (big) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 1024>), grid, block, 0, st, a);     \
+        else hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512>), grid, block, 0, st, a);          \
+    } while (0)
+        if (C == 80) MMT_LAUNCH_SEG(20);
+        else if (C == 64) MMT_LAUNCH_SEG(16);
+        else MMT_LAUNCH_SEG(0);
+#undef MMT_LAUNCH_SEG
+        return mmt::check_launch("voxel_pooling_forward(seg_gather)");
+    }
 
     if (algo == MMT_VP_ALGO_ROW_ATOMIC) {
-        a.nslot = 0; a.nchunks = 0;
         const int64_t work = BP * (vec4 ? C / 4 : C);
         const int grid = mmt::stream_grid(work, kBlock);
         if (vec4) hipLaunchKernelGGL((vp_fwd_row_atomic<4>), dim3(grid), dim3(kBlock), 0, st, a);
@@ -369,7 +573,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
         return mmt::check_launch("voxel_pooling_forward(row_atomic)");
     }
 
-    // LDS budget: ~40 KiB of BEV rows per workgroup -> 3 workgroups (12 waves) per CU.
+    // LDS_ATOMIC. LDS budget: ~40 KiB of BEV rows per workgroup -> 3 workgroups per CU.
     int nslot = (40 * 1024) / (C * 4);
     if (nslot > 256) nslot = 256;
     if (nslot < 4) {  // rows too long for the LDS tile: use plain row atomics
@@ -419,7 +623,8 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
     const bool vec4 = a.sc == 1 && C % 4 == 0 && a.sb % 4 == 0 && a.sy % 4 == 0 && a.sx % 4 == 0 &&
                       (((uintptr_t)a.grad_out & 15) == 0) && (((uintptr_t)grad_in & 15) == 0);
     if (vec4) {
-        const int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock);
+        int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock, 256 * 16);
+        grid = (grid + 7) & ~7;  // whole groups of 8 (one workgroup per XCD)
         if (C == 80) hipLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, a);
         else if (C == 64) hipLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, a);
         else hipLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, a);

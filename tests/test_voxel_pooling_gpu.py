@@ -120,7 +120,7 @@ def test_error_behaviour(mmt_lib):
     with pytest.raises(RuntimeError, match="CUDA"):
         voxel_pooling_ext.voxel_pooling_forward_wrapper(1, 8, 4, 2, 2, 1, geom.cpu(), feats, out, pos)
     with pytest.raises(AssertionError):
-        voxel_pooling(geom, feats.transpose(0, 1), [2, 2, 1])
+        voxel_pooling(geom, torch.zeros(1, 8, 8, device="cuda")[..., ::2], [2, 2, 1])
 
 
 SHAPES = {

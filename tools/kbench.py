@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark for libmmt_hip (run on the GPU box):
+   python tools/kbench.py [--shape cfg2|cfg1_full|cfg5] [--reps 20] [--geometry rig|uniform]
+Times every voxel_pooling forward algorithm and the backward with HIP events and
+prints achieved algorithmic GB/s (formulas: BASELINE.md section 2)."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from mm_training_amd import _lib, synthetic  # noqa: E402
+from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext  # noqa: E402
+
+SHAPES = {
+    "cfg2": dict(B=4, N=6, final_dim=(256, 704), ds=16, d_bound=(2.0, 58.0, 0.5), C=80),
+    "cfg1_full": dict(B=1, N=6, final_dim=(256, 704), ds=8, d_bound=(1.0, 60.0, 0.5), C=64),
+    "cfg5": dict(B=2, N=6, final_dim=(512, 1408), ds=16, d_bound=(2.0, 58.0, 0.5), C=80),
+}
+
+
+def timeit(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="cfg2")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--geometry", default="rig")
+    ap.add_argument("--algos", default="3,35,2,1")
+    args = ap.parse_args()
+    sh = SHAPES[args.shape]
+    B, C = sh["B"], sh["C"]
+    if args.geometry == "rig":
+        geom, vn = synthetic.rig_geometry(B, sh["N"], sh["final_dim"], sh["ds"], sh["d_bound"])
+    else:
+        fH, fW = sh["final_dim"][0] // sh["ds"], sh["final_dim"][1] // sh["ds"]
+        D = int((sh["d_bound"][1] - sh["d_bound"][0]) / sh["d_bound"][2])
+        geom = synthetic.uniform_geometry(B, sh["N"] * D * fH * fW, 128, 128).reshape(B, sh["N"], D, fH, fW, 3)
+        vn = [128, 128, 1]
+    nx, ny, nz = vn
+    P = geom[0].numel() // 3
+    feats = synthetic.features((B, P, C), seed=1).cuda()
+    geom = geom.reshape(B, P, 3).cuda()
+    g3 = geom.reshape(-1, 3)
+    K = int((((g3[:, 0] >= 0) & (g3[:, 0] < nx) & (g3[:, 1] >= 0) & (g3[:, 1] < ny) & (g3[:, 2] >= 0) & (g3[:, 2] < nz)).sum()))
+    BP = B * P
+    fwd_bytes = 24 * BP + 4 * C * K + 4 * C * B * ny * nx
+    bwd_bytes = 12 * BP + 4 * C * B * ny * nx + 4 * C * BP
+    out = torch.zeros(B, ny, nx, C, device="cuda")
+    pos = torch.empty(B, P, 3, dtype=torch.int32, device="cuda")
+    res = {"shape": args.shape, "geometry": args.geometry, "BP": BP, "kept": K / BP, "fwd_MB": fwd_bytes / 1e6, "bwd_MB": bwd_bytes / 1e6}
+    ref = None
+    for algo in [int(a) for a in args.algos.split(",")]:
+        flags = (algo % 16) | 0x10 | (0x20 if algo >= 32 else 0)
+
+        def run():
+            voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=flags)
+        out.zero_()
+        run()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out.clone()
+        err = (out - ref).abs().max().item()
+        med, best = timeit(run, args.reps)
+        res[f"fwd_algo{algo}"] = {"ms": med, "best_ms": best, "GBps": fwd_bytes / med / 1e6, "max_abs_diff_vs_first": err}
+    memset_ms, _ = timeit(lambda: out.zero_(), args.reps)
+    res["out_memset_ms"] = memset_ms
+    go = torch.randn(B, ny, nx, C, device="cuda").permute(0, 3, 1, 2)
+    gi = torch.empty(B, P, C, device="cuda")
+    med, best = timeit(lambda: voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, None), args.reps)
+    res["bwd_nhwc"] = {"ms": med, "best_ms": best, "GBps": bwd_bytes / med / 1e6}
+    go2 = go.contiguous()
+    ws = torch.empty(B * ny * nx * C, device="cuda")
+    med, best = timeit(lambda: voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go2, gi, ws), args.reps)
+    res["bwd_nchw_ws"] = {"ms": med, "best_ms": best, "GBps": bwd_bytes / med / 1e6}
+    # streaming ceilings on this box for reference
+    a = torch.empty(BP * C, device="cuda")
+    b = torch.empty_like(a)
+    med, _ = timeit(lambda: b.copy_(a), args.reps)
+    res["copy_GBps"] = 2 * a.numel() * 4 / med / 1e6
+    med, _ = timeit(lambda: b.zero_(), args.reps)
+    res["memset_GBps"] = a.numel() * 4 / med / 1e6
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
