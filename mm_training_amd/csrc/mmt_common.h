@@ -31,6 +31,7 @@ static inline int stream_grid(int64_t work_items, int block, int max_blocks = 25
 
 // 16-byte non-temporal store (streaming output that must not evict reused lines)
 typedef float mmt_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mmt_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mmt_nt_store4(float4 v, float4 *p) {
     mmt_f32x4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<mmt_f32x4 *>(p));

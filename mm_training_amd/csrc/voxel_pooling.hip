@@ -12,6 +12,7 @@
 // HBM traffic per call (algorithmic): 12*BP geom + 12*BP pos_memo + 4*C*K features
 // of kept points + 4*C*B*ny*nx BEV rows.
 #include "mmt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -372,22 +373,20 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
         const int beg = slot_off[s], end = slot_off[s + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
-            int j = beg + g;
-            for (; j + 3 * G < end; j += 4 * G) {
-                const int p0 = sorted[j], p1 = sorted[j + G], p2 = sorted[j + 2 * G], p3 = sorted[j + 3 * G];
-                const float4 v0 = *reinterpret_cast<const float4 *>(fbase + p0 * C);
-                const float4 v1 = *reinterpret_cast<const float4 *>(fbase + p1 * C);
-                const float4 v2 = *reinterpret_cast<const float4 *>(fbase + p2 * C);
-                const float4 v3 = *reinterpret_cast<const float4 *>(fbase + p3 * C);
-                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
-            }
-            for (; j < end; j += G) {
-                const int p0 = sorted[j];
-                const float4 v0 = *reinterpret_cast<const float4 *>(fbase + p0 * C);
-                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            // 4 rows in flight per lane group; short lists (the common far-range case)
+            // issue all their loads before the first add instead of one load per trip.
+            for (int j = beg + g; j < end; j += 4 * G) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u * G;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (jj < end) v[u] = *reinterpret_cast<const float4 *>(fbase + (int)sorted[jj] * C);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                }
             }
             *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
         }
@@ -416,9 +415,16 @@ struct VpBwdArgs {
     const float *grad_out;
     int64_t sb, sc, sy, sx;
     float *grad_in;
+    int64_t span_bytes;  // bytes spanned by the grad_out view (buffer descriptor range)
 };
 
-template <int C4T>
+// Software-pipelined: the dependent chain pos_memo -> BEV-gradient row -> store is
+// what bounds this kernel when the caches are cold (a bare 605 MB memset runs at
+// ~8 TB/s on this chip, a naive load-load-store loop at ~3.5 TB/s because every trip
+// waits two full HBM read latencies behind a saturated write queue).  So each lane
+// keeps the row offsets of tile t+2 and the gathered vectors of tile t+1 in flight
+// while it stores tile t.
+template <int C4T, bool NT, bool XCD>
 __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
     const int CV = C4T > 0 ? C4T : a.C / 4;
     const int64_t total = a.BP * CV;
@@ -432,30 +438,84 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
     const int64_t ntiles = (total + kTileVecs - 1) / kTileVecs;
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int xcd = blockIdx.x & 7;
-    const int64_t t_begin = xcd * per_xcd;
-    const int64_t t_end = (t_begin + per_xcd) < ntiles ? (t_begin + per_xcd) : ntiles;
-    for (int64_t tile = t_begin + (blockIdx.x >> 3); tile < t_end; tile += (gridDim.x >> 3)) {
-        const int64_t i0 = tile * kTileVecs + threadIdx.x;
-        float4 v[U];
+    const int64_t t_begin = XCD ? xcd * per_xcd : 0;
+    const int64_t t_end = XCD ? ((t_begin + per_xcd) < ntiles ? (t_begin + per_xcd) : ntiles) : ntiles;
+    const int64_t t_first = XCD ? t_begin + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t t_step = XCD ? (gridDim.x >> 3) : gridDim.x;
+
+    // Only FULL tiles go through the pipelined loop and every load / store in it is
+    // unconditional (dropped points read row 0 and select zero afterwards): hipcc can
+    // then use counted s_waitcnt vmcnt(N) and really keep two tiles of loads in flight;
+    // a predicated load would force vmcnt(0) and collapse the pipeline.
+    const int64_t nfull = total / kTileVecs;
+    const int64_t my_end = t_end < nfull ? t_end : nfull;
+
+    // The gather goes through a buffer descriptor: a dropped point uses an out-of-range
+    // byte offset and the hardware range check returns zeros -- no select, no branch.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.grad_out), 0, (int)a.span_bytes, 0x00020000);
+
+    // BYTE offset of the lane's float4 inside grad_out, or 0xFFFFFFF0 (dropped point)
+    auto load_offsets = [&](int64_t tile, unsigned (&off)[U]) {
+        tile = tile < my_end ? tile : t_first;  // prefetch past the end re-reads a valid tile
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + (int64_t)u * kBlock;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < total) {
-                const int64_t t = i / CV;
-                const int cv = (int)(i - t * CV);
-                const int b = a.pos_memo[t * 3];
-                if (b != -1) {
-                    const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
-                    v[u] = *reinterpret_cast<const float4 *>(a.grad_out + b * a.sb + y * a.sy +
-                                                             x * a.sx + cv * 4);
-                }
-            }
+            const int64_t i = tile * kTileVecs + threadIdx.x + (int64_t)u * kBlock;
+            const int64_t t = i / CV;
+            const int cv = (int)(i - t * CV);
+            const int b = a.pos_memo[t * 3];
+            const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
+            const unsigned o = ((unsigned)(b * a.sb + y * a.sy + x * a.sx) + cv * 4) * 4u;
+            off[u] = (b != -1) ? o : 0xFFFFFFF0u;
         }
+    };
+    auto gather = [&](const unsigned (&off)[U], float4 (&v)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + (int64_t)u * kBlock;
-            if (i < total) mmt_nt_store4(v[u], dst + i);
+            const mmt_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[u], 0, 0);
+            v[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z),
+                               __uint_as_float(r.w));
+        }
+    };
+
+    if (t_first < my_end) {
+        unsigned off1[U], off2[U];
+        float4 g0[U], g1[U];
+        load_offsets(t_first, off1);
+        gather(off1, g0);
+        load_offsets(t_first + t_step, off1);
+        auto store_tile = [&](int64_t tile, const float4 (&v)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = tile * kTileVecs + threadIdx.x + (int64_t)u * kBlock;
+                if (NT) mmt_nt_store4(v[u], dst + i);
+                else dst[i] = v[u];
+            }
+        };
+        // unrolled by two with the register sets swapping roles: no copies, so nothing
+        // waits on the loads issued in the same trip
+        for (int64_t tile = t_first; tile < my_end; tile += 2 * t_step) {
+            load_offsets(tile + 2 * t_step, off2);
+            gather(off1, g1);
+            store_tile(tile, g0);
+            if (tile + t_step >= my_end) break;
+            load_offsets(tile + 3 * t_step, off1);
+            gather(off2, g0);
+            store_tile(tile + t_step, g1);
+        }
+    }
+    // the single partial tile at the very end
+    if (blockIdx.x == 0 && nfull * kTileVecs < total) {
+        for (int64_t i = nfull * kTileVecs + threadIdx.x; i < total; i += kBlock) {
+            const int64_t t = i / CV;
+            const int cv = (int)(i - t * CV);
+            const int b = a.pos_memo[t * 3];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b != -1) {
+                const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
+                v = *reinterpret_cast<const float4 *>(a.grad_out + b * a.sb + y * a.sy + x * a.sx + cv * 4);
+            }
+            dst[i] = v;
         }
     }
 }
@@ -620,14 +680,29 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
         a.grad_out = workspace;
         a.sc = 1; a.sx = C; a.sy = (int64_t)nx * C; a.sb = (int64_t)ny * nx * C;
     }
+    const int64_t span = (B - 1) * a.sb + (ny - 1) * a.sy + (nx - 1) * a.sx + C;
     const bool vec4 = a.sc == 1 && C % 4 == 0 && a.sb % 4 == 0 && a.sy % 4 == 0 && a.sx % 4 == 0 &&
+                      a.sb >= 0 && a.sy >= 0 && a.sx >= 0 && span < (1ll << 29) &&
                       (((uintptr_t)a.grad_out & 15) == 0) && (((uintptr_t)grad_in & 15) == 0);
+    a.span_bytes = span * 4;
     if (vec4) {
         int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock, 256 * 16);
         grid = (grid + 7) & ~7;  // whole groups of 8 (one workgroup per XCD)
-        if (C == 80) hipLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, a);
-        else if (C == 64) hipLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, a);
+        static const int variant = getenv("MMT_BWD_VARIANT") ? atoi(getenv("MMT_BWD_VARIANT")) : 3;
+        static const int gmul = getenv("MMT_BWD_GRID") ? atoi(getenv("MMT_BWD_GRID")) : 16;
+        grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock, 256 * gmul);
+        grid = (grid + 7) & ~7;
+#define MMT_LAUNCH_BWD(C4T)                                                                              \
+    do {                                                                                                 \
+        if (variant == 3) hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, true, true>), dim3(grid), dim3(kBlock), 0, st, a);        \
+        else if (variant == 2) hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, false, true>), dim3(grid), dim3(kBlock), 0, st, a);  \
+        else if (variant == 1) hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, true, false>), dim3(grid), dim3(kBlock), 0, st, a);  \
+        else hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, false, false>), dim3(grid), dim3(kBlock), 0, st, a);                   \
+    } while (0)
+        if (C == 80) MMT_LAUNCH_BWD(20);
+        else if (C == 64) MMT_LAUNCH_BWD(16);
+        else MMT_LAUNCH_BWD(0);
+#undef MMT_LAUNCH_BWD
         return mmt::check_launch("voxel_pooling_backward(rows_vec4)");
     }
     const int grid = mmt::stream_grid(BP * C, kBlock);

@@ -89,13 +89,77 @@ def main():
     ws = torch.empty(B * ny * nx * C, device="cuda")
     med, best = timeit(lambda: voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go2, gi, ws), args.reps)
     res["bwd_nchw_ws"] = {"ms": med, "best_ms": best, "GBps": bwd_bytes / med / 1e6}
+    # alternating forward / backward (what a training step does): per-kernel times
+    fl = 3 | 0x10
+    fe, be = [], []
+    for it in range(args.reps + 3):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        out.zero_()
+        e[0].record()
+        voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=fl)
+        e[1].record()
+        e[2].record()
+        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, None)
+        e[3].record()
+        if it >= 3:
+            fe.append((e[0], e[1]))
+            be.append((e[2], e[3]))
+    torch.cuda.synchronize()
+    medev = lambda evs: sorted(s_.elapsed_time(e_) for s_, e_ in evs)[len(evs) // 2]
+    res["alternating"] = {"fwd_ms": medev(fe), "bwd_ms": medev(be), "fwd_GBps": fwd_bytes / medev(fe) / 1e6,
+                          "bwd_GBps": bwd_bytes / medev(be) / 1e6}
+    # isolated backward but with a cache-flushing 1 GiB read in between (cold MALL)
+    flush = torch.empty(256 * 1024 * 1024, device="cuda")
+    be = []
+    for it in range(args.reps + 3):
+        flush.sum()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, None)
+        e1.record()
+        if it >= 3:
+            be.append((e0, e1))
+    torch.cuda.synchronize()
+    res["bwd_after_flush_ms"] = medev(be)
+    fe = []
+    for it in range(args.reps + 3):
+        flush.sum()
+        out.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=fl)
+        e1.record()
+        if it >= 3:
+            fe.append((e0, e1))
+    torch.cuda.synchronize()
+    res["fwd_after_flush_ms"] = medev(fe)
     # streaming ceilings on this box for reference
     a = torch.empty(BP * C, device="cuda")
     b = torch.empty_like(a)
     med, _ = timeit(lambda: b.copy_(a), args.reps)
     res["copy_GBps"] = 2 * a.numel() * 4 / med / 1e6
-    med, _ = timeit(lambda: b.zero_(), args.reps)
-    res["memset_GBps"] = a.numel() * 4 / med / 1e6
+    med_, _ = timeit(lambda: b.zero_(), args.reps)
+    res["memset_GBps"] = a.numel() * 4 / med_ / 1e6
+    ze = []
+    for it in range(args.reps):
+        flush.sum()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.zero_()
+        e1.record()
+        ze.append((e0, e1))
+    torch.cuda.synchronize()
+    res["memset_after_flush_GBps"] = a.numel() * 4 / medev(ze) / 1e6
+    ce = []
+    for it in range(args.reps):
+        flush.sum()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        ce.append((e0, e1))
+    torch.cuda.synchronize()
+    res["copy_after_flush_GBps"] = 2 * a.numel() * 4 / medev(ce) / 1e6
     print(json.dumps(res, indent=1))
 
 
