@@ -1,0 +1,3 @@
+from .encoder import LidarEncoder, hard_voxelize_batch, simple_vfe, pillar_scatter
+
+__all__ = ["LidarEncoder", "hard_voxelize_batch", "simple_vfe", "pillar_scatter"]

@@ -1,0 +1,200 @@
+"""LiDAR / radar branch behind the three calls models/bev_depth.py:181-183 makes on
+``self.lidar_encoder`` (an mmdet3d MVXFasterRCNN in the reference, built from
+``lidar_conf`` exps/conf_aim.py:192-213):
+
+    voxels, num_points, coors = lidar_encoder.voxelize(list_of_point_clouds)
+    voxel_feats = lidar_encoder.pts_voxel_encoder(voxels, num_points, coors)
+    lidar_bev   = lidar_encoder.pts_middle_encoder(voxel_feats, coors, batch_size)
+
+Same names, argument meaning and return layouts (voxels [M,T,F] fp32 zero padded,
+num_points [M] int32, coors [M,4] int32 = (b,z,y,x)); the arithmetic runs in the HIP
+kernels of libmmt_hip.so (lidar_voxelize.hip).  The middle encoder is the
+pillar-scatter (mmdet3d PointPillarsScatter) BASELINE.json names, not the reference
+config's SparseEncoder (3-D sparse convolution: out of scope).
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def grid_size(point_cloud_range, voxel_size):
+    """mmcv Voxelization.__init__: round((max - min) / voxel_size) as fp32 tensors."""
+    r = torch.tensor(point_cloud_range, dtype=torch.float32)
+    v = torch.tensor(voxel_size, dtype=torch.float32)
+    return [int(x) for x in torch.round((r[3:] - r[:3]) / v).long()]
+
+
+def hard_voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
+                        compact=True):
+    """Batched hard voxelization (one kernel sequence for the whole batch).
+
+    compact=True returns the reference layout (concatenated, M = sum of per-sample voxel
+    counts; costs ONE device->host copy of B ints).  compact=False returns the
+    fixed-capacity layout [B*max_voxels, ...] plus the per-sample counts, no host sync:
+    unused rows have coors = -1 and num_points = 0."""
+    if len(points_list) == 0:
+        raise ValueError("empty batch")
+    dev = points_list[0].device
+    for p in points_list:
+        if not p.is_cuda:
+            raise RuntimeError("points must be a CUDAtensor ")
+        if p.dtype != torch.float32 or p.dim() != 2:
+            raise RuntimeError("each point cloud must be a float32 [N, F] tensor")
+    B = len(points_list)
+    F = points_list[0].shape[1]
+    sizes = [int(p.shape[0]) for p in points_list]
+    points = torch.cat([p.contiguous() for p in points_list], 0) if B > 1 else points_list[0].contiguous()
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    N = offs[-1]
+    grid = grid_size(point_cloud_range, voxel_size)
+    grid_c = _lib.int3(grid)
+    T = int(max_num_points)
+    V = int(max_voxels)
+    voxels = torch.empty((B * V, T, F), dtype=torch.float32, device=dev)
+    coors = torch.empty((B * V, 4), dtype=torch.int32, device=dev)
+    num_points = torch.empty((B * V,), dtype=torch.int32, device=dev)
+    voxel_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws_elems = _lib.lib().mmt_voxelize_workspace_elems(B, N, grid_c)
+    workspace = torch.empty((ws_elems,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("mmt_hard_voxelize", B, N, F, points.data_ptr(), offsets.data_ptr(),
+                  _lib.float3(voxel_size), _lib.float3(point_cloud_range[:3]), grid_c, T, V,
+                  voxels.data_ptr(), coors.data_ptr(), num_points.data_ptr(), voxel_count.data_ptr(),
+                  workspace.data_ptr(), _stream())
+    if not compact:
+        return voxels, num_points, coors, voxel_count
+    counts = voxel_count.cpu()                      # the one host sync of the drop-in path
+    dst = torch.zeros(B + 1, dtype=torch.int32)
+    dst[1:] = torch.cumsum(counts, 0)
+    M = int(dst[-1])
+    voxels_out = torch.empty((M, T, F), dtype=torch.float32, device=dev)
+    coors_out = torch.empty((M, 4), dtype=torch.int32, device=dev)
+    num_out = torch.empty((M,), dtype=torch.int32, device=dev)
+    if M > 0:
+        dst_dev = dst.to(dev)
+        with torch.cuda.device(dev):
+            _lib.call("mmt_compact_voxels", B, V, T * F, voxel_count.data_ptr(), dst_dev.data_ptr(),
+                      voxels.data_ptr(), coors.data_ptr(), num_points.data_ptr(),
+                      voxels_out.data_ptr(), coors_out.data_ptr(), num_out.data_ptr(), _stream())
+    return voxels_out, num_out, coors_out
+
+
+def simple_vfe(voxels, num_points, num_features):
+    """HardSimpleVFE: voxels[:, :, :num_features].sum(1) / num_points -> [M, num_features]."""
+    if not voxels.is_cuda:
+        raise RuntimeError("voxels must be a CUDAtensor ")
+    M, T, F = voxels.shape
+    out = torch.empty((M, num_features), dtype=torch.float32, device=voxels.device)
+    if M:
+        with torch.cuda.device(voxels.device):
+            _lib.call("mmt_simple_vfe", M, T, F, int(num_features), voxels.contiguous().data_ptr(),
+                      num_points.contiguous().data_ptr(), out.data_ptr(), _stream())
+    return out
+
+
+class _PillarScatter(Function):
+    @staticmethod
+    def forward(ctx, feats, coors, batch_size, ny, nx):
+        if not feats.is_cuda:
+            raise RuntimeError("voxel_features must be a CUDAtensor ")
+        feats = feats.contiguous()
+        coors = coors.contiguous()
+        if coors.dtype != torch.int32:
+            coors = coors.int()
+        M, C = feats.shape
+        canvas = torch.empty((batch_size, C, ny, nx), dtype=torch.float32, device=feats.device)
+        cell_map = torch.empty((batch_size * ny * nx,), dtype=torch.int32, device=feats.device)
+        with torch.cuda.device(feats.device):
+            _lib.call("mmt_pillar_scatter", M, C, batch_size, ny, nx, feats.data_ptr() if M else 0,
+                      coors.data_ptr() if M else 0, canvas.data_ptr(), cell_map.data_ptr(), _stream())
+        ctx.save_for_backward(coors, cell_map)
+        ctx.dims = (M, C, batch_size, ny, nx)
+        ctx.mark_non_differentiable(cell_map)
+        return canvas
+
+    @staticmethod
+    def backward(ctx, grad_canvas):
+        coors, cell_map = ctx.saved_tensors
+        M, C, B, ny, nx = ctx.dims
+        grad_feats = torch.empty((M, C), dtype=torch.float32, device=grad_canvas.device)
+        if M:
+            grad_canvas = grad_canvas.contiguous()
+            with torch.cuda.device(grad_canvas.device):
+                _lib.call("mmt_pillar_scatter_backward", M, C, B, ny, nx, grad_canvas.data_ptr(),
+                          coors.data_ptr(), cell_map.data_ptr(), grad_feats.data_ptr(), _stream())
+        return grad_feats, None, None, None, None
+
+
+def pillar_scatter(voxel_features, coors, batch_size, ny, nx):
+    """PointPillarsScatter: dense [B, C, ny, nx] canvas from per-voxel features."""
+    return _PillarScatter.apply(voxel_features, coors, int(batch_size), int(ny), int(nx))
+
+
+class LidarEncoder(nn.Module):
+    """Object with the reference's three methods (models/bev_depth.py:181-183).
+
+    pts_voxel_layer: dict(point_cloud_range, max_num_points, voxel_size, max_voxels)
+    pts_voxel_encoder: dict(type='HardSimpleVFE', num_features)
+    pts_middle_encoder: dict(type='PointPillarsScatter', in_channels, output_shape=[ny, nx])
+    An optional learned per-pillar MLP (`pillar_channels`) lifts the VFE mean to
+    `in_channels` before the scatter (PointPillars' PFN role)."""
+
+    def __init__(self, pts_voxel_layer, pts_voxel_encoder=None, pts_middle_encoder=None,
+                 pillar_channels=None, **unused):
+        super().__init__()
+        self.voxel_cfg = dict(pts_voxel_layer)
+        mv = self.voxel_cfg.get("max_voxels", 25000)
+        self.max_voxels = int(mv[0] if isinstance(mv, (tuple, list)) else mv)
+        self.max_num_points = int(self.voxel_cfg["max_num_points"])
+        self.voxel_size = list(self.voxel_cfg["voxel_size"])
+        self.point_cloud_range = list(self.voxel_cfg["point_cloud_range"])
+        self.grid = grid_size(self.point_cloud_range, self.voxel_size)
+        enc = dict(pts_voxel_encoder or dict(type="HardSimpleVFE", num_features=5))
+        self.num_features = int(enc.get("num_features", 5))
+        mid = dict(pts_middle_encoder or {})
+        self.output_shape = list(mid.get("output_shape", [self.grid[1], self.grid[0]]))
+        self.in_channels = int(mid.get("in_channels", self.num_features))
+        self.pillar_mlp = None
+        if pillar_channels is not None or self.in_channels != self.num_features:
+            out_c = int(pillar_channels or self.in_channels)
+            # no normalisation layer: rows of the fixed-capacity layout that hold no voxel
+            # must not influence live rows (forward_bev runs without compaction)
+            self.pillar_mlp = nn.Sequential(nn.Linear(self.num_features, out_c), nn.ReLU(inplace=True))
+            self.in_channels = out_c
+
+    @torch.no_grad()
+    def voxelize(self, points):
+        """list[Tensor[Ni,F]] -> (voxels [M,T,F], num_points [M], coors [M,4]=(b,z,y,x))."""
+        pts = [p.float() for p in points]            # mmdet3d forces fp32 here
+        return hard_voxelize_batch(pts, self.voxel_size, self.point_cloud_range,
+                                   self.max_num_points, self.max_voxels, compact=True)
+
+    def pts_voxel_encoder(self, voxels, num_points, coors=None):
+        return simple_vfe(voxels, num_points, self.num_features)
+
+    def pts_middle_encoder(self, voxel_features, coors, batch_size):
+        if self.pillar_mlp is not None:
+            voxel_features = self.pillar_mlp(voxel_features)
+        return pillar_scatter(voxel_features, coors, batch_size, self.output_shape[0], self.output_shape[1])
+
+    def forward_bev(self, points):
+        """voxelize -> mean -> (MLP) -> scatter with NO host synchronisation: stays in the
+        fixed-capacity layout; empty rows carry coors = -1 and are ignored by the scatter."""
+        with torch.no_grad():
+            pts = [p.float() for p in points]
+            voxels, num_points, coors, _ = hard_voxelize_batch(
+                pts, self.voxel_size, self.point_cloud_range, self.max_num_points, self.max_voxels,
+                compact=False)
+            feats = simple_vfe(voxels, num_points, self.num_features)
+        if self.pillar_mlp is not None:
+            feats = self.pillar_mlp(feats)
+        return pillar_scatter(feats, coors, len(points), self.output_shape[0], self.output_shape[1])

@@ -1,0 +1,83 @@
+"""GPU parity of quantise / fused frustum geometry / lift against the oracle and the
+golden vectors produced by the reference's own lss_fpn.py code."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("grid", ["nusc", "aim", "test"])
+def test_quantize_bit_exact_with_reference(mmt_lib, oracle_mod, golden, grid):
+    from mm_training_amd.ops.bev_geometry import quantize_geometry
+    g = golden["quant_geom"]
+    xyz = torch.from_numpy(g[grid + "_q_xyz"]).cuda()
+    q = quantize_geometry(xyz, g[grid + "_voxel_coord"], g[grid + "_voxel_size"]).cpu().numpy()
+    ok = g[grid + "_q_inrange"]
+    assert np.array_equal(q[ok], g[grid + "_q_expected"][ok])       # reference expression, bit-exact
+    assert np.array_equal(q, oracle_mod.quantize(g[grid + "_q_xyz"], g[grid + "_voxel_coord"], g[grid + "_voxel_size"]))
+
+
+def test_quantize_nonfinite_device_semantics(mmt_lib, oracle_mod):
+    from mm_training_amd.ops.bev_geometry import quantize_geometry
+    xyz = torch.tensor([[float("nan"), float("inf"), float("-inf")], [1e30, -1e30, 0.0],
+                        [-0.3, -0.79, -4.99], [-51.2, 51.2, 3.0]], dtype=torch.float32)
+    vc, vs = [-50.8, -50.8, -1.0], [0.8, 0.8, 8.0]
+    q = quantize_geometry(xyz.cuda(), vc, vs).cpu().numpy()
+    assert np.array_equal(q, oracle_mod.quantize(xyz.numpy(), vc, vs))
+    assert q[0, 0] == 0 and q[0, 1] == 2**31 - 1 and q[0, 2] == -2**31   # NaN->0, saturation
+
+
+def test_full_size_quantize_on_rig(mmt_lib, oracle_mod):
+    from mm_training_amd import synthetic
+    from mm_training_amd.ops.bev_geometry import quantize_geometry
+    s2e, K = synthetic.camera_rig(4, 6, 704, 256, jitter=0.02)
+    xyz = synthetic.frustum_geometry_xyz(s2e, K, (256, 704), 16, (2.0, 58.0, 0.5))
+    ref, _ = synthetic.quantize_cpu(xyz, (-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8), (-5.0, 3.0, 8.0))
+    vs = torch.Tensor([0.8, 0.8, 8.0])
+    vc = torch.Tensor([-51.2 + 0.4, -51.2 + 0.4, -5 + 4.0])
+    q = quantize_geometry(xyz.cuda(), vc, vs)
+    assert torch.equal(q.cpu(), ref)                                  # torch-CPU expression == HIP, 5.7M values
+
+
+def test_fused_frustum_geometry(mmt_lib, oracle_mod, golden):
+    from mm_training_amd.ops.bev_geometry import frustum_geometry
+    g = golden["quant_geom"]
+    fr = torch.from_numpy(g["nusc_frustum"]).cuda()
+    cb = torch.from_numpy(g["rig_combine"]).cuda()
+    geom, xyz = frustum_geometry(fr, cb, g["nusc_voxel_coord"], g["nusc_voxel_size"], return_xyz=True)
+    assert tuple(xyz.shape) == tuple(g["rig_shape"])
+    # bit-exact with the oracle's k-ordered, un-contracted fp32 dot product
+    ref_xyz = oracle_mod.geometry(g["nusc_frustum"], g["rig_combine"])
+    assert np.array_equal(xyz.cpu().numpy(), ref_xyz)
+    assert np.array_equal(geom.cpu().numpy(), oracle_mod.quantize(ref_xyz, g["nusc_voxel_coord"], g["nusc_voxel_size"]))
+    # against the reference's torch matmul: equal index OR point within rounding of a boundary
+    sample = geom.reshape(-1, 3)[::97].cpu().numpy()
+    mism = (sample != g["rig_geom_sample"]).any(1)
+    assert mism.mean() < 1e-3
+    assert np.abs(xyz.reshape(-1, 3)[::97].cpu().numpy() - g["rig_xyz_sample"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 4, 6, 7), (24, 112, 16, 44, 80), (2, 9, 3, 70, 64)])
+def test_lift_forward_backward(mmt_lib, oracle_mod, shape):
+    from mm_training_amd.ops.bev_geometry import lift_features
+    BN, D, fH, fW, C = shape
+    g = torch.Generator().manual_seed(0)
+    depth = torch.rand(BN, D, fH, fW, generator=g).softmax(1)
+    ctx = torch.randn(BN, C, fH, fW, generator=g)
+    d = depth.cuda().requires_grad_(True)
+    c = ctx.cuda().requires_grad_(True)
+    out = lift_features(d, c)
+    assert out.shape == (BN, D, fH, fW, C) and out.is_contiguous()
+    if BN * D * fH * fW * C < 5e6:
+        assert np.array_equal(out.detach().cpu().numpy(), oracle_mod.lift(depth.numpy(), ctx.numpy()))
+    # torch fp32 reference of the same op (lss_fpn.py:441-460) incl. gradients
+    d2 = depth.cuda().requires_grad_(True)
+    c2 = ctx.cuda().requires_grad_(True)
+    ref = (d2.unsqueeze(1) * c2.unsqueeze(2)).permute(0, 2, 3, 4, 1).contiguous()
+    assert torch.equal(out, ref)
+    go = torch.randn(out.shape, generator=g).cuda()
+    out.backward(go)
+    ref.backward(go)
+    assert torch.allclose(d.grad, d2.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(c.grad, c2.grad, rtol=1e-4, atol=1e-4)
