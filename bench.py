@@ -31,10 +31,13 @@ CFG2 = dict(batch=4, num_cams=6, final_dim=(256, 704), downsample=16, d_bound=(2
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", default="hotpath", choices=["hotpath"],
-                    help="hotpath: voxel_pooling forward+backward at the cfg-2 shape")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="train", choices=["train", "hotpath"],
+                    help="train: full data-parallel training step of the BASELINE config (default); "
+                         "hotpath: only voxel_pooling forward+backward at the cfg-2 shape")
+    ap.add_argument("--config", default="cfg2", help="cfg2 (BASELINE configs[1], default) | cfg3 | cfg4 | cfg5 | tiny")
+    ap.add_argument("--miopen-tune", action="store_true", help="exhaustive MIOpen search (minutes of warm-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag")
     return ap.parse_args()
@@ -89,9 +92,95 @@ def cpu_baseline(geom, feats, vn, grad_out_nhwc, budget_s=12.0):
                       f"on CPU at the full cfg-2 shape B={B} P={P} C={C}, median {med * 1e3:.1f} ms/step"}, out, pos, gi
 
 
+def roofline_entry(kernel, nbytes, ms):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": nbytes, "avg_ms": ms}
+
+
+def train_main(args, rank, local_rank, world):
+    """Full training step of a BASELINE config: synthetic frames -> depth labels -> BEVDepth
+    (+LiDAR) forward -> detection + depth loss -> backward (DDP bucketed all-reduce over RCCL,
+    overlapped) -> grad clip -> AdamW.  Nothing is skipped inside the timed region."""
+    from mm_training_amd import _lib
+    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
+    from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext
+    _lib.lib()
+    torch.backends.cudnn.benchmark = bool(args.miopen_tune)
+    dev = torch.device("cuda", local_rank)
+    cfg = make_config(args.config)
+    torch.manual_seed(0)
+    ts = TrainStep(cfg, dev, world_size=world)
+    B = cfg["batch_size"]
+    # a small pool of distinct pre-generated batches resident in HBM (input is never the bottleneck)
+    batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i) for i in range(2)]
+    for i in range(args.warmup):
+        ts(batches[i % len(batches)])
+    voxel_pooling_ext.TIMING = {}
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, det, dep = ts(batches[i % len(batches)])
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    timing = voxel_pooling_ext.TIMING
+    voxel_pooling_ext.TIMING = None
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank != 0:
+        return
+    res = {
+        "metric": "training samples/sec at bs=%d/GPU; voxel_pooling HBM GB/s" % B,
+        "value": world * B * args.steps / elapsed, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if cfg["dtype"] == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": {
+            "cfg2": "BASELINE configs[1]: camera-only BEVDepth (ResNet-50, 6 cams 256x704, D=112, C=80, BEV 128x128) "
+                    "full training step (fwd + det/depth loss + bwd + clip + AdamW)",
+            "cfg3": "BASELINE configs[2]: LiDAR-only pillar path, 40k pts, 0.2 m voxels",
+            "cfg4": "BASELINE configs[3]: LiDAR+camera fusion (BEVDepth + pillar BEV concat)",
+            "cfg5": "BASELINE configs[4]: LiDAR+radar+camera, 6 cams 512x1408, 80k pts, bf16",
+            "tiny": "tiny smoke configuration"}[args.config],
+            "global_batch": world * B, "parallelism": f"dp{world}", "mode": "train",
+            "params_M": sum(p.numel() for p in ts.model.parameters()) / 1e6,
+            "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune)},
+    }
+    if cfg["use_cam"] and timing.get("forward"):
+        fwd_ms = sum(s.elapsed_time(e) for s, e in timing["forward"]) / len(timing["forward"])
+        bwd_ms = sum(s.elapsed_time(e) for s, e in timing["backward"]) / len(timing["backward"])
+        lss = ts.model.backbone
+        with torch.no_grad():
+            m = batches[0][1]
+            geom = lss.get_geometry_voxels(m["sensor2ego_mats"][:, 0], m["intrin_mats"][:, 0])
+        nx, ny, nz = lss._voxel_num_host
+        g3 = geom.reshape(-1, 3)
+        kept = ((g3[:, 0] >= 0) & (g3[:, 0] < nx) & (g3[:, 1] >= 0) & (g3[:, 1] < ny) & (g3[:, 2] >= 0) & (g3[:, 2] < nz))
+        K, BP, C = int(kept.sum()), g3.shape[0], lss.output_channels
+        fb, bb = algorithmic_bytes(BP, K, C, B, ny, nx)
+        res["roofline"] = roofline_entry("vp_fwd_seg_gather (voxel_pooling forward, inside the training step)", fb, fwd_ms)
+        res["roofline_backward"] = roofline_entry("vp_bwd_rows_vec4 (voxel_pooling backward, inside the training step)", bb, bwd_ms)
+        res["config"]["kept_fraction"] = K / BP
+        if world == 1 and not args.no_cpu_baseline:
+            from mm_training_amd import synthetic
+            P = BP // B
+            feats_cpu = synthetic.features((B, P, C), seed=100)
+            go = torch.randn(B, ny, nx, C, generator=torch.Generator().manual_seed(1))
+            base, _, _, _ = cpu_baseline(geom.reshape(B, P, 3).cpu(), feats_cpu, (nx, ny, nz), go)
+            res["cpu_baseline"] = base
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse()
     rank, local_rank, world = init_dist(args.gpus)
+    if args.mode == "train":
+        train_main(args, rank, local_rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from mm_training_amd import _lib, synthetic
     from mm_training_amd.ops.voxel_pooling import voxel_pooling, voxel_pooling_ext
     _lib.lib()

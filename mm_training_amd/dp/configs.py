@@ -1,0 +1,83 @@
+"""Model / data configurations of the BASELINE.json workloads, in the shape of the
+reference's config module (exps/conf_aim.py: backbone_conf :42-71, head_conf :177-190,
+lidar_conf :192-213, train_cfg :143-160).
+
+  cfg2  camera-only BEVDepth: ResNet-50, 6 cams 256x704, ds 16, D=112, C=80, BEV 128x128
+  cfg3  LiDAR-only pillar path: 40k points, 0.2 m voxels
+  cfg4  LiDAR + camera fusion (cfg2 camera half + pillar BEV concat)
+  cfg5  LiDAR + radar + camera, 6 cams 512x1408, 80k points (8 columns)
+  tiny  a few-second smoke configuration for tests
+"""
+import copy
+
+CLASSES = ['car', 'truck/bus', 'motorcycle', 'pedestrian', 'other']
+TASKS = [dict(num_class=1, class_names=['car']), dict(num_class=1, class_names=['truck/bus']),
+         dict(num_class=1, class_names=['motorcycle']), dict(num_class=1, class_names=['pedestrian'])]
+COMMON_HEADS = dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))
+
+
+def make_config(name="cfg2"):
+    tiny = name == "tiny"
+    use_cam = name in ("cfg2", "cfg4", "cfg5", "tiny")
+    use_lidar = name in ("cfg3", "cfg4", "cfg5", "tiny")
+    use_radar = name == "cfg5"
+    final_dim = (512, 1408) if name == "cfg5" else ((64, 192) if tiny else (256, 704))
+    pc_range = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    voxel_size = [0.2, 0.2, 8.0]
+    out_size_factor = 4
+    bev_cell = voxel_size[0] * out_size_factor            # 0.8 m camera BEV cells -> 128 x 128
+    cam_channels = 80 if use_cam else 0
+    lidar_channels = 64 if use_lidar else 0
+    if tiny:
+        cam_channels, lidar_channels = 16, 8
+    fuse_channels = cam_channels + lidar_channels
+    grid = [int(round((pc_range[3] - pc_range[0]) / voxel_size[0])), int(round((pc_range[4] - pc_range[1]) / voxel_size[1]))]
+
+    backbone_conf = dict(
+        x_bound=[pc_range[0], pc_range[3], bev_cell], y_bound=[pc_range[1], pc_range[4], bev_cell],
+        z_bound=[pc_range[2], pc_range[5], voxel_size[2]],
+        d_bound=[2.0, 58.0, 4.0 if tiny else 0.5], final_dim=final_dim, output_channels=cam_channels,
+        downsample_factor=16,
+        img_backbone_conf=dict(type='ResNet', depth=18 if tiny else 50, base_channels=8 if tiny else 64,
+                               out_indices=[0, 1, 2, 3]),
+        img_neck_conf=dict(type='SECONDFPN',
+                           in_channels=[8, 16, 32, 64] if tiny else [256, 512, 1024, 2048],
+                           upsample_strides=[0.25, 0.5, 1, 2], out_channels=[8] * 4 if tiny else [128] * 4),
+        depth_net_conf=dict(in_channels=32 if tiny else 512, mid_channels=32 if tiny else 512))
+    base = 16 if tiny else 160
+    head_conf = dict(
+        bev_backbone_conf=dict(type='ResNet', in_channels=fuse_channels, depth=18, num_stages=3, strides=(1, 2, 2),
+                               dilations=(1, 1, 1), out_indices=[0, 1, 2], base_channels=base),
+        # trunk output is /4,/8,/16 of the BEV map; bring all levels back to the 128x128 heatmap
+        bev_neck_conf=dict(type='SECONDFPN', in_channels=[base, base * 2, base * 4], upsample_strides=[4, 8, 16],
+                           out_channels=[64, 64, 64]),
+        tasks=TASKS, common_heads=COMMON_HEADS,
+        bbox_coder=dict(type='CenterPointBBoxCoder', pc_range=pc_range, out_size_factor=out_size_factor,
+                        voxel_size=voxel_size, code_size=9),
+        train_cfg=dict(point_cloud_range=pc_range, grid_size=[grid[0], grid[1], 1], voxel_size=voxel_size,
+                       out_size_factor=out_size_factor, dense_reg=1, gaussian_overlap=0.1, max_objs=500,
+                       min_radius=2, code_weights=[1.0] * 8 + [0.0, 0.0]),
+        test_cfg=None, in_channels=192,
+        loss_cls=dict(type='GaussianFocalLoss', reduction='mean'),
+        loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=0.25),
+        gaussian_overlap=0.1, min_radius=2)
+    # LiDAR pillars at 0.2 m (512 x 512) -> nearest-resized onto the camera BEV (models/bev_depth.py:188-190)
+    lidar_conf = dict(
+        type='MVXFasterRCNN',
+        pts_voxel_layer=dict(point_cloud_range=pc_range, max_num_points=15, voxel_size=voxel_size,
+                             max_voxels=(25000, 25000)),
+        pts_voxel_encoder=dict(type='HardSimpleVFE', num_features=5),
+        pts_middle_encoder=dict(type='PointPillarsScatter', in_channels=max(lidar_channels, 1),
+                                output_shape=[grid[1], grid[0]]))
+    if tiny:
+        lidar_conf['pts_voxel_layer']['max_voxels'] = (2000, 2000)
+    cfg = dict(
+        name=name, use_cam=use_cam, use_lidar=use_lidar, use_radar=use_radar,
+        batch_size={"cfg2": 4, "cfg3": 8, "cfg4": 4, "cfg5": 2, "tiny": 2}[name],
+        num_cams=2 if tiny else 6, final_dim=final_dim,
+        num_points=80000 if name == "cfg5" else (2000 if tiny else 40000),
+        point_features=8 if use_radar else 5,
+        point_cloud_range=pc_range, backbone_conf=backbone_conf, head_conf=head_conf, lidar_conf=lidar_conf,
+        fuse_layer_in_channels=fuse_channels,
+        dtype="bf16" if name == "cfg5" else "f32", num_boxes=20)
+    return copy.deepcopy(cfg)

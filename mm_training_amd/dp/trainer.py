@@ -1,0 +1,153 @@
+"""Single-node data-parallel training step -- the hot loop of the reference's Lightning
+module (exps/mm_training_aim.py:252-289 training_step, :114-215 depth labels / depth
+loss, :510-512 normalise, :524-531 optimiser, :619-628 gradient clipping) without
+Lightning: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI),
+DistributedDataParallel's bucketed all-reduce overlapped with backward on RCCL's stream.
+
+Host-side changes against the reference, none of which alter the arithmetic contract:
+  * depth labels are produced by one vectorised scatter-min per batch instead of the
+    B x N_cam Python loop + per-pixel "last write wins" map (:122-163); identical when no
+    two points fall into the same pixel, deterministic otherwise;
+  * no .item() / boolean-mask host syncs in the loss (see bev_depth_head.py mirror).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from .. import synthetic
+from ..models.bev_depth import BEVDepthLiDAR
+
+IMG_MEAN = (0.485, 0.456, 0.406)
+IMG_STD = (0.229, 0.224, 0.225)
+
+
+def synthetic_batch(cfg, device, seed=0, batch_size=None):
+    """One batch shaped like collate_aim's output (dataset/src/aimotive_dataset.py:182-231):
+    (sweep_imgs [B,1,N,3,H,W] in 0..255, mats dict, pointclouds list[B] of [Ni,F], gt_boxes, gt_labels)."""
+    B = batch_size or cfg["batch_size"]
+    N = cfg["num_cams"]
+    H, W = cfg["final_dim"]
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randint(0, 256, (B, 1, N, 3, H, W), generator=g, dtype=torch.uint8).float()
+    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=seed)
+    mats = {
+        "sensor2ego_mats": s2e.unsqueeze(1).to(device), "intrin_mats": K.unsqueeze(1).to(device),
+        "extrinsics": torch.inverse(s2e).unsqueeze(1).to(device),
+        "bda_mat": torch.eye(4).repeat(B, 1, 1).to(device),
+        "flipped": torch.zeros(B * N, dtype=torch.bool, device=device),
+    }
+    pcs = [synthetic.lidar_frame(cfg["num_points"], cfg["point_features"], cfg["point_cloud_range"],
+                                 num_radar=2000 if cfg["use_radar"] else 0, seed=seed * 1000 + b).to(device)
+           for b in range(B)]
+    pr = cfg["point_cloud_range"]
+    boxes, labels = [], []
+    for b in range(B):
+        k = cfg["num_boxes"]
+        xy = torch.rand(k, 2, generator=g) * torch.tensor([pr[3] - pr[0] - 8, pr[4] - pr[1] - 8]) + torch.tensor([pr[0] + 4, pr[1] + 4])
+        z = torch.rand(k, 1, generator=g) * 2 - 2
+        lab = torch.randint(0, 4, (k,), generator=g)
+        prior = torch.tensor([[1.9, 4.6, 1.7], [2.5, 9.0, 3.2], [0.8, 2.1, 1.5], [0.7, 0.7, 1.75]])[lab]
+        dims = prior * (0.9 + 0.2 * torch.rand(k, 3, generator=g))
+        yaw = (torch.rand(k, 1, generator=g) * 2 - 1) * math.pi
+        vel = torch.randn(k, 2, generator=g)
+        boxes.append(torch.cat([xy, z, dims, yaw, vel], 1).to(device))
+        labels.append(lab.to(device))
+    return imgs.to(device), mats, pcs, boxes, labels
+
+
+class TrainStep(nn.Module):
+    """Owns model + optimiser and runs one optimisation step per call."""
+
+    def __init__(self, cfg, device, world_size=1, lr=None, bucket_cap_mb=64):
+        super().__init__()
+        self.cfg = cfg
+        self.device = device
+        self.use_cam, self.use_lidar = cfg["use_cam"], cfg["use_lidar"]
+        self.model = BEVDepthLiDAR(cfg["backbone_conf"], cfg["head_conf"], cfg["lidar_conf"], is_train_depth=True,
+                                   use_cam=self.use_cam, use_lidar=self.use_lidar,
+                                   fuse_layer_in_channels=cfg["fuse_layer_in_channels"]).to(device)
+        # dense convs consume / produce channels_last: the pooled BEV map already is
+        for m in self.model.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                m.to(memory_format=torch.channels_last)
+        self.net = self.model
+        if world_size > 1:
+            # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183)
+            self.net = nn.parallel.DistributedDataParallel(
+                self.model, device_ids=[device.index] if device.type == "cuda" else None,
+                bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, find_unused_parameters=True)
+        bs = cfg["batch_size"]
+        self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr or 1e-3 / 64 * bs, weight_decay=1e-7,
+                                           fused=(device.type == "cuda"))
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, [19, 23])
+        self.grad_clip = 2.0
+        db = cfg["backbone_conf"]["d_bound"]
+        self.dbound = db
+        self.downsample = cfg["backbone_conf"]["downsample_factor"]
+        self.depth_channels = len(torch.arange(*db)) if self.use_cam else 0
+        self.amp_dtype = torch.bfloat16 if cfg.get("dtype") == "bf16" else None
+        self.register_buffer("mean", torch.tensor(IMG_MEAN).view(1, 1, 1, 3, 1, 1), persistent=False)
+        self.register_buffer("std", torch.tensor(IMG_STD).view(1, 1, 1, 3, 1, 1), persistent=False)
+        self.to(device)
+
+    # ---- exps/mm_training_aim.py:510-512
+    def normalize_images(self, sweep_imgs):
+        return (sweep_imgs[:, :, :, :3] / 255.0 - self.mean) / self.std
+
+    # ---- exps/mm_training_aim.py:114-163 + :180-215, vectorised
+    @torch.no_grad()
+    def get_depth_labels(self, images, mats, pointclouds):
+        B, S, N, _, H, W = images.shape
+        ds = self.downsample
+        fH, fW = H // ds, W // ds
+        ext = mats["extrinsics"][:, 0]                     # [B,N,4,4] ego -> camera
+        K = mats["intrin_mats"][:, 0]
+        bda = mats["bda_mat"]
+        gt = torch.full((B * N, fH * fW), 1e5, device=images.device)
+        for b in range(B):                                 # point counts differ per sample
+            xyz = pointclouds[b][:, :3] @ torch.linalg.inv(bda[b, :3, :3]).T
+            pts = torch.cat([xyz, torch.ones_like(xyz[:, :1])], 1)          # [P,4]
+            cam = torch.einsum("nij,pj->npi", ext[b], pts)                   # [N,P,4]
+            depth = cam[..., 2]
+            proj = torch.einsum("nij,npj->npi", K[b], cam)
+            u = proj[..., 0] / proj[..., 2]
+            v = proj[..., 1] / proj[..., 2]
+            ok = (depth > 1.0) & (u > 1) & (u < W - 1) & (v > 1) & (v < H - 1)
+            cell = (v.long().clamp(0, H - 1) // ds) * fW + (u.long().clamp(0, W - 1) // ds)
+            d = torch.where(ok, depth, torch.full_like(depth, 1e5))
+            gt[b * N:(b + 1) * N].scatter_reduce_(1, cell, d, "amin", include_self=True)
+        gt = (gt - (self.dbound[0] - self.dbound[2])) / self.dbound[2]
+        gt = torch.where((gt < self.depth_channels) & (gt >= 0.0), gt, torch.zeros_like(gt))
+        return F.one_hot(gt.long(), num_classes=self.depth_channels).float().view(-1, self.depth_channels)
+
+    # ---- exps/mm_training_aim.py:165-178
+    def get_depth_loss(self, depth_labels, depth_preds):
+        depth_preds = depth_preds.permute(0, 2, 3, 1).reshape(-1, self.depth_channels).float()
+        fg = (depth_labels.max(1).values > 0.0).float()
+        bce = F.binary_cross_entropy(depth_preds.clamp(0, 1), depth_labels, reduction="none").sum(1)
+        return 3.0 * (bce * fg).sum() / fg.sum().clamp(min=1.0)
+
+    def forward_loss(self, batch):
+        sweep_imgs, mats, pointclouds, gt_boxes, gt_labels = batch
+        depth_labels = None
+        if self.use_cam:
+            depth_labels = self.get_depth_labels(sweep_imgs, mats, pointclouds)
+            sweep_imgs = self.normalize_images(sweep_imgs)
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            preds, depth_preds, _, _ = self.net((sweep_imgs, pointclouds), mats, None)
+        targets = self.model.get_targets(gt_boxes, gt_labels)
+        detection_loss = self.model.loss(targets, preds)
+        depth_loss = self.get_depth_loss(depth_labels, depth_preds) if self.use_cam else detection_loss.new_zeros(())
+        return detection_loss + depth_loss, detection_loss, depth_loss
+
+    def forward(self, batch):
+        """One optimisation step; returns the (detached) loss tensors, no host sync."""
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, det, dep = self.forward_loss(batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip, foreach=True)
+        self.optimizer.step()
+        return loss.detach(), det.detach(), dep.detach()

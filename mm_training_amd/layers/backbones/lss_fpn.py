@@ -1,0 +1,202 @@
+"""LSSFPN -- host-side mirror of layers/backbones/lss_fpn.py of the reference: same
+constructor and ``forward(sweep_imgs, mats_dict, depth_oracle, timestamps,
+is_return_depth)`` signature and outputs (lss_fpn.py:252-254, :469-529), so
+models/bev_depth.py is a drop-in.
+
+The hot path is HIP (libmmt_hip.so): frustum geometry + quantise
+(``frustum_geometry``, replacing :328-361 + :461-462), lift + channels-last layout
+(``lift_features``, replacing :441-463) and ``voxel_pooling`` (:463-464).  The conv
+nets (ResNet / SECONDFPN / DepthNet) are plain PyTorch modules (MIOpen).
+Reference quirks kept: voxel_num truncation (:286-289), depth softmax taken BEFORE
+the per-camera un-flip of depth_feature (:423-425), BDA not applied in
+get_geometry (:355-360), context_se constructed but never called (:183, :240-248).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ...ops.bev_geometry import frustum_geometry, lift_features
+from ...ops.voxel_pooling import voxel_pooling
+from ..nets import BasicBlock, DeformConv2dPack, ResNet, SECONDFPN
+
+__all__ = ['LSSFPN']
+
+
+class _ASPPModule(nn.Module):
+    def __init__(self, inplanes, planes, kernel_size, padding, dilation):
+        super().__init__()
+        self.atrous_conv = nn.Conv2d(inplanes, planes, kernel_size, 1, padding, dilation, bias=False)
+        self.bn = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU()
+        nn.init.kaiming_normal_(self.atrous_conv.weight)
+
+    def forward(self, x):
+        return self.relu(self.bn(self.atrous_conv(x)))
+
+
+class ASPP(nn.Module):
+    """lss_fpn.py:47-117."""
+
+    def __init__(self, inplanes, mid_channels=256):
+        super().__init__()
+        self.aspp1 = _ASPPModule(inplanes, mid_channels, 1, 0, 1)
+        self.aspp2 = _ASPPModule(inplanes, mid_channels, 3, 6, 6)
+        self.aspp3 = _ASPPModule(inplanes, mid_channels, 3, 12, 12)
+        self.aspp4 = _ASPPModule(inplanes, mid_channels, 3, 18, 18)
+        self.global_avg_pool = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)),
+                                             nn.Conv2d(inplanes, mid_channels, 1, bias=False),
+                                             nn.BatchNorm2d(mid_channels), nn.ReLU())
+        self.conv1 = nn.Conv2d(mid_channels * 5, mid_channels, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid_channels)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(0.5)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        # bilinear upsampling of a 1x1 map with align_corners=True (lss_fpn.py:96-99) is a broadcast
+        x5 = self.global_avg_pool(x).expand(-1, -1, x.shape[2], x.shape[3])
+        x = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), x5), 1)
+        return self.dropout(self.relu(self.bn1(self.conv1(x))))
+
+
+class SELayer(nn.Module):
+    """lss_fpn.py:144-157."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, channels, 1)
+        self.act1 = nn.ReLU()
+        self.conv_expand = nn.Conv2d(channels, channels, 1)
+        self.gate = nn.Sigmoid()
+
+    def forward(self, x, x_se):
+        return x * self.gate(self.conv_expand(self.act1(self.conv_reduce(x_se))))
+
+
+class DepthNet(nn.Module):
+    """lss_fpn.py:160-248."""
+
+    def __init__(self, in_channels, mid_channels, context_channels, depth_channels):
+        super().__init__()
+        self.reduce_conv = nn.Sequential(nn.Conv2d(in_channels, mid_channels, 3, 1, 1),
+                                         nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
+        self.context_conv = nn.Conv2d(mid_channels, context_channels, 1)
+        self.depth_se = nn.Identity()
+        self.context_se = SELayer(mid_channels)      # has parameters, never called (reference quirk)
+        self.depth_conv = nn.Sequential(
+            BasicBlock(mid_channels, mid_channels), BasicBlock(mid_channels, mid_channels),
+            BasicBlock(mid_channels, mid_channels), ASPP(mid_channels, mid_channels),
+            DeformConv2dPack(mid_channels, mid_channels, kernel_size=3, padding=1, groups=4),
+            nn.Conv2d(mid_channels, depth_channels, 1))
+
+    def forward(self, x, mats_dict=None):
+        x = self.reduce_conv(x)
+        context = self.context_conv(x)
+        depth = self.depth_conv(self.depth_se(x))
+        return torch.cat([depth, context], 1)
+
+
+class LSSFPN(nn.Module):
+    def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, downsample_factor,
+                 output_channels, img_backbone_conf, img_neck_conf, depth_net_conf):
+        super().__init__()
+        self.downsample_factor = downsample_factor
+        self.d_bound = d_bound
+        self.final_dim = final_dim
+        self.output_channels = output_channels
+        rows = [x_bound, y_bound, z_bound]
+        # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
+        self.register_buffer('voxel_size', torch.Tensor([row[2] for row in rows]))
+        self.register_buffer('voxel_coord', torch.Tensor([row[0] + row[2] / 2.0 for row in rows]))
+        self.register_buffer('voxel_num', torch.LongTensor([(row[1] - row[0]) / row[2] for row in rows]))
+        self.register_buffer('frustum', self.create_frustum())
+        self.depth_channels = self.frustum.shape[0]
+        # host copies: no device->host sync per step (the reference indexes a CUDA tensor)
+        self._voxel_num_host = [int(v) for v in self.voxel_num]
+        self._voxel_size_host = [float(v) for v in self.voxel_size]
+        self._voxel_coord_host = [float(v) for v in self.voxel_coord]
+
+        bb = {k: v for k, v in dict(img_backbone_conf).items() if k not in ('type', 'init_cfg', 'frozen_stages', 'norm_eval')}
+        self.img_backbone = ResNet(**bb)
+        nk = {k: v for k, v in dict(img_neck_conf).items() if k != 'type'}
+        self.img_neck = SECONDFPN(**nk)
+        self.depth_net = self._configure_depth_net(depth_net_conf)
+
+    def _configure_depth_net(self, depth_net_conf):
+        return DepthNet(depth_net_conf['in_channels'], depth_net_conf['mid_channels'],
+                        self.output_channels, self.depth_channels)
+
+    def create_frustum(self):
+        """lss_fpn.py:308-326 (same torch calls, evaluated on the host at init)."""
+        ogfH, ogfW = self.final_dim
+        fH, fW = ogfH // self.downsample_factor, ogfW // self.downsample_factor
+        d_coords = torch.arange(*self.d_bound, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+        D = d_coords.shape[0]
+        x_coords = torch.linspace(0, ogfW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+        y_coords = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+        return torch.stack((x_coords, y_coords, d_coords, torch.ones_like(d_coords)), -1).contiguous()
+
+    def get_geometry_voxels(self, sensor2ego_mat, intrin_mat, bda_mat=None):
+        """get_geometry (lss_fpn.py:328-361) fused with the quantise (:461-462):
+        returns int32 voxel coordinates [B,N,D,fH,fW,3].  bda_mat is ignored like in
+        the reference (:355-360)."""
+        combine = sensor2ego_mat.matmul(torch.inverse(intrin_mat)).contiguous()
+        return frustum_geometry(self.frustum.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
+
+    def get_cam_feats(self, imgs):
+        batch_size, num_sweeps, num_cams, num_channels, imH, imW = imgs.shape
+        imgs = imgs.flatten().view(batch_size * num_sweeps * num_cams, num_channels, imH, imW)
+        img_feats = self.img_neck(self.img_backbone(imgs))[0]
+        return img_feats.reshape(batch_size, num_sweeps, num_cams, *img_feats.shape[1:])
+
+    def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, depth_oracle, is_return_depth=False):
+        batch_size, num_sweeps, num_cams = sweep_imgs.shape[:3]
+        img_feats = self.get_cam_feats(sweep_imgs)
+        source_features = img_feats[:, 0, ...]
+        depth_feature = self.depth_net(source_features.reshape(batch_size * num_cams, *source_features.shape[2:]), mats_dict)
+        depth = depth_feature[:, :self.depth_channels].softmax(1)
+        flipped = mats_dict.get('flipped', None) if isinstance(mats_dict, dict) else None
+        if flipped is not None:
+            fl = torch.as_tensor(flipped, device=depth_feature.device).view(-1, 1, 1, 1).bool()
+            depth_feature = torch.where(fl, depth_feature.flip(-1), depth_feature)      # hflip per camera (:425)
+        if depth_oracle is not None:   # :427-438
+            b, c, h, w = depth.shape
+            fg_mask = (torch.max(depth_oracle, dim=1).values > 0.0).view(-1)
+            depth_flat = depth.permute(0, 2, 3, 1).contiguous().view(-1, c)
+            oracle_flat = depth_oracle.permute(0, 2, 3, 1).contiguous().view(-1, c)
+            depth_flat = torch.where(fg_mask.view(-1, 1), oracle_flat, depth_flat)
+            depth_used = depth_flat.view(b, h, w, c).permute(0, 3, 1, 2)
+        else:
+            depth_used = depth
+        context = depth_feature[:, self.depth_channels:self.depth_channels + self.output_channels]
+        # lift straight into [B, N, D, fH, fW, C]
+        feats = lift_features(depth_used.float(), context.float())
+        feats = feats.view(batch_size, num_cams, *feats.shape[1:])
+        geom_xyz = self.get_geometry_voxels(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
+                                            mats_dict['intrin_mats'][:, sweep_index, ...],
+                                            mats_dict.get('bda_mat', None))
+        feature_map = voxel_pooling(geom_xyz, feats, self._voxel_num_host)
+        # the reference's `.contiguous()` (:467) would transpose to NCHW; the pooled map is
+        # already a dense channels_last tensor, which the BEV convs consume directly
+        if is_return_depth:
+            return feature_map, depth
+        return feature_map
+
+    def forward(self, sweep_imgs, mats_dict, depth_oracle=None, timestamps=None, is_return_depth=False):
+        num_sweeps = sweep_imgs.shape[1]
+        key_frame_res = self._forward_single_sweep(0, sweep_imgs[:, 0:1, ...], mats_dict, depth_oracle,
+                                                   is_return_depth=is_return_depth)
+        if num_sweeps == 1:
+            return key_frame_res
+        key_frame_feature = key_frame_res[0] if is_return_depth else key_frame_res
+        ret_feature_list = [key_frame_feature]
+        for sweep_index in range(1, num_sweeps):
+            with torch.no_grad():
+                ret_feature_list.append(self._forward_single_sweep(
+                    sweep_index, sweep_imgs[:, sweep_index:sweep_index + 1, ...], mats_dict, depth_oracle,
+                    is_return_depth=False))
+        if is_return_depth:
+            return torch.cat(ret_feature_list, 1), key_frame_res[1]
+        return torch.cat(ret_feature_list, 1)

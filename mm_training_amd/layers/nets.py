@@ -1,0 +1,163 @@
+"""Dense building blocks the reference imports from mmdet / mmdet3d / mmcv
+(README.md:14-27; none vendored), restated in plain PyTorch so PyTorch-ROCm runs them
+on MIOpen / hipBLASLt (MFMA).  They are the CALLERS' side of the hot path, not
+hand-written kernels (out of scope for HIP).
+
+  ResNet        mmdet ResNet (depth 18/50, base_channels, num_stages, strides, out_indices)
+                -- lss_fpn.py:293 (image backbone), bev_depth_head.py:79 (BEV trunk)
+  SECONDFPN     mmdet3d SECONDFPN -- lss_fpn.py:294, bev_depth_head.py:81
+  DeformConv2dPack  mmcv 'DCN' (lss_fpn.py:189-197) as bilinear grid_sample + grouped GEMM
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        # mmdet style='pytorch': the stride sits on the 3x3 conv
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+class ResNet(nn.Module):
+    ARCH = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3))}
+
+    def __init__(self, depth=50, in_channels=3, base_channels=64, num_stages=4, strides=(1, 2, 2, 2),
+                 dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), **unused):
+        super().__init__()
+        block, blocks = self.ARCH[depth]
+        self.out_indices = tuple(out_indices)
+        self.conv1 = nn.Conv2d(in_channels, base_channels, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(base_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.stages = nn.ModuleList()
+        inplanes = base_channels
+        for i in range(num_stages):
+            planes = base_channels * 2 ** i
+            stride = strides[i]
+            layers = []
+            for j in range(blocks[i]):
+                s = stride if j == 0 else 1
+                down = None
+                if s != 1 or inplanes != planes * block.expansion:
+                    down = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, s, bias=False),
+                                         nn.BatchNorm2d(planes * block.expansion))
+                layers.append(block(inplanes, planes, s, down))
+                inplanes = planes * block.expansion
+            self.stages.append(nn.Sequential(*layers))
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, stage in enumerate(self.stages):
+            x = stage(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class SECONDFPN(nn.Module):
+    def __init__(self, in_channels, upsample_strides, out_channels, **unused):
+        super().__init__()
+        blocks = []
+        for cin, s, cout in zip(in_channels, upsample_strides, out_channels):
+            if s > 1 or s == 1:
+                up = nn.ConvTranspose2d(cin, cout, int(s), int(s), bias=False)
+            else:
+                k = int(round(1 / s))
+                up = nn.Conv2d(cin, cout, k, k, bias=False)
+            blocks.append(nn.Sequential(up, nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)))
+        self.deblocks = nn.ModuleList(blocks)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, xs):
+        ups = [blk(x) for blk, x in zip(self.deblocks, xs)]
+        return [torch.cat(ups, 1) if len(ups) > 1 else ups[0]]
+
+
+class DeformConv2dPack(nn.Module):
+    """mmcv DCN v1 pack: offsets from a zero-initialised 3x3 conv, then a deformable
+    3x3 convolution = bilinear sampling (zeros outside) of each kernel tap + grouped GEMM."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, groups=1, deform_groups=1, **unused):
+        super().__init__()
+        assert kernel_size == 3 and padding == 1 and deform_groups == 1
+        self.groups = groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, 3, 3))
+        nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
+        self.conv_offset = nn.Conv2d(in_channels, 18, 3, 1, 1, bias=True)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        offset = self.conv_offset(x)
+        ys = torch.arange(H, device=x.device, dtype=x.dtype).view(1, H, 1)
+        xs = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, W)
+        cols = []
+        for k in range(9):
+            ky, kx = divmod(k, 3)
+            py = ys + (ky - 1) + offset[:, 2 * k]
+            px = xs + (kx - 1) + offset[:, 2 * k + 1]
+            grid = torch.stack((2 * px / max(W - 1, 1) - 1, 2 * py / max(H - 1, 1) - 1), -1)
+            cols.append(F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True))
+        col = torch.stack(cols, 2)                                     # [B, C, 9, H, W]
+        g = self.groups
+        col = col.reshape(B, g, (C // g) * 9, H * W)
+        w = self.weight.reshape(g, -1, (C // g) * 9)
+        out = torch.einsum("gok,bgkn->bgon", w, col)
+        return out.reshape(B, -1, H, W)

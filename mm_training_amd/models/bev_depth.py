@@ -1,0 +1,118 @@
+"""BEVDepth / BEVFuseLayer / BEVDepthLiDAR -- drop-in mirror of models/bev_depth.py.
+
+Same constructor arguments and ``forward((img, lidar), mats_dict, lidar_oracle,
+timestamps)`` -> ``(preds, depth_pred, lidar_bev, cam_bev)`` (models/bev_depth.py:163-200).
+``lidar_conf`` builds a mm_training_amd.lidar.LidarEncoder (the three calls at :181-183
+hit the HIP kernels) instead of an mmdet3d MVXFasterRCNN.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..layers.backbones.lss_fpn import LSSFPN
+from ..layers.heads.bev_depth_head import BEVDepthHead
+from ..lidar import LidarEncoder
+
+__all__ = ['BEVDepth', 'BEVFuseLayer', 'BEVDepthLiDAR']
+
+
+def warp_affine_bev(x, mat23):
+    """kornia.geometry.warp_affine(x, M, dsize=x.shape[2:]) (bilinear, zeros, align_corners=True):
+    dst(p) = src(M^-1 p) in pixel coordinates."""
+    b, _, h, w = x.shape
+    M = torch.eye(3, device=x.device, dtype=x.dtype).repeat(b, 1, 1)
+    M[:, :2, :] = mat23
+    Minv = torch.inverse(M)
+    ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=x.dtype),
+                            torch.arange(w, device=x.device, dtype=x.dtype), indexing='ij')
+    pts = torch.stack((xs, ys, torch.ones_like(xs)), -1).view(1, h * w, 3)
+    src = pts @ Minv.transpose(1, 2)
+    gx = 2 * src[..., 0] / max(w - 1, 1) - 1
+    gy = 2 * src[..., 1] / max(h - 1, 1) - 1
+    grid = torch.stack((gx, gy), -1).view(b, h, w, 2)
+    return F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+
+
+class BEVDepth(nn.Module):
+    def __init__(self, backbone_conf, head_conf, is_train_depth=False, use_cam=True):
+        super().__init__()
+        if use_cam:
+            self.backbone = LSSFPN(**backbone_conf)
+        self.head = BEVDepthHead(**head_conf)
+        self.is_train_depth = is_train_depth
+
+    def bev_augment_image(self, x, bda_mat):
+        """models/bev_depth.py:69-84: rotate/flip the camera BEV by the BEV-aug matrix about
+        the map centre."""
+        b, _, h, w = x.shape
+        h, w = h - 1, w - 1
+        t_pos = torch.eye(3, device=x.device, dtype=x.dtype)
+        t_pos[0, 2], t_pos[1, 2] = w / 2, h / 2
+        t_neg = torch.eye(3, device=x.device, dtype=x.dtype)
+        t_neg[0, 2], t_neg[1, 2] = -w / 2, -h / 2
+        mat = t_pos.unsqueeze(0) @ bda_mat[:, :3, :3].to(x.dtype) @ t_neg.unsqueeze(0)
+        return warp_affine_bev(x, mat[:, :2, :3])
+
+    def get_targets(self, gt_boxes, gt_labels):
+        return self.head.get_targets(gt_boxes, gt_labels)
+
+    def loss(self, targets, preds_dicts):
+        return self.head.loss(targets, preds_dicts)
+
+    def forward(self, x, mats_dict, timestamps=None):
+        imgs, _ = x
+        imgs_bev, depth_pred = self.backbone(imgs, mats_dict, None, timestamps, is_return_depth=True)
+        imgs_bev = self.bev_augment_image(imgs_bev, mats_dict['bda_mat'])
+        return self.head(imgs_bev), depth_pred
+
+
+class BEVFuseLayer(nn.Module):
+    """models/bev_depth.py:133-145."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.conv_3 = nn.Conv2d(in_channels, in_channels, 3, padding=1)
+        self.conv_1 = nn.Conv2d(in_channels, in_channels, 1)
+        self.avg_pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.activation = nn.Sigmoid()
+
+    def forward(self, x):
+        x = self.conv_3(x)
+        return x * self.activation(self.conv_1(self.avg_pool(x)))
+
+
+class BEVDepthLiDAR(BEVDepth):
+    def __init__(self, backbone_conf, head_conf, lidar_conf, is_train_depth=False, use_cam=True,
+                 use_lidar=True, fuse_layer_in_channels=144):
+        super().__init__(backbone_conf, head_conf, is_train_depth=False, use_cam=use_cam)
+        self.use_cam = use_cam
+        self.use_lidar = use_lidar
+        if use_lidar:
+            self.lidar_encoder = LidarEncoder(**{k: v for k, v in dict(lidar_conf).items() if k != 'type'})
+        if use_cam and use_lidar:
+            self.bev_fuse = BEVFuseLayer(in_channels=fuse_layer_in_channels)
+
+    def forward(self, x, mats_dict, lidar_oracle=None, timestamps=None):
+        img, lidar = x
+        depth_pred, img_bev, lidar_bev, lidar_bev_ret, cam_bev_ret = None, None, None, None, None
+        if self.use_cam:
+            img_bev, depth_pred = self.backbone(img, mats_dict, lidar_oracle, timestamps, is_return_depth=True)
+            img_bev = self.bev_augment_image(img_bev, mats_dict['bda_mat'])
+            cam_bev_ret = img_bev
+        if self.use_lidar:
+            batch_size = len(lidar)
+            voxels, num_points, coors = self.lidar_encoder.voxelize(lidar)
+            voxel_feats = self.lidar_encoder.pts_voxel_encoder(voxels, num_points, coors)
+            lidar_bev = self.lidar_encoder.pts_middle_encoder(voxel_feats, coors, batch_size)
+            lidar_bev_ret = lidar_bev
+        if self.use_lidar and self.use_cam:
+            if lidar_bev.shape[-2:] != img_bev.shape[-2:]:
+                lidar_bev = F.interpolate(lidar_bev, size=(img_bev.shape[2], img_bev.shape[3]))
+            bev_fused = self.bev_fuse(torch.cat([img_bev, lidar_bev], dim=1))
+        elif self.use_cam:
+            bev_fused = img_bev
+        else:
+            bev_fused = lidar_bev
+        preds = self.head(bev_fused)
+        return preds, depth_pred, lidar_bev_ret, cam_bev_ret

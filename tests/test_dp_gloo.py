@@ -1,0 +1,95 @@
+"""CPU, world_size 2, gloo: the data-parallel path.  The hot-path kernels are per-sample
+(no data-path collective); what DP adds is (1) sharding the batch,
+(2) the gradient all-reduce (mean) and (3) the cross-rank loss normalisers of the head
+(bev_depth_head.py:273-276,300-301).  Checked on the dense part of the model, which runs
+on CPU: two ranks with batch b each == one process with batch 2b."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(seed=0):
+    from mm_training_amd.dp.configs import make_config
+    from mm_training_amd.layers.heads.bev_depth_head import BEVDepthHead
+    cfg = make_config("tiny")
+    torch.manual_seed(seed)
+    head = BEVDepthHead(**cfg["head_conf"])
+    # BatchNorm statistics are per-rank in the reference (no SyncBN): use eval-mode BN so the
+    # 2-rank and 1-rank runs are comparable sample by sample
+    head.eval()
+    return cfg, head
+
+
+def _data(cfg, n, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cfg["fuse_layer_in_channels"], 128, 128, generator=g)
+    boxes, labels = [], []
+    for i in range(n):
+        k = 3 + i
+        xy = torch.rand(k, 2, generator=g) * 80 - 40
+        rest = torch.tensor([[-1.0, 1.9, 4.6, 1.7, 0.3, 0.5, -0.2]]).repeat(k, 1)
+        boxes.append(torch.cat([xy, rest], 1))
+        labels.append(torch.randint(0, 4, (k,), generator=g))
+    return x, boxes, labels
+
+
+def _step(head, x, boxes, labels):
+    preds = head(x)
+    targets = head.get_targets(boxes, labels)
+    return head.loss(targets, preds)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg, head = _make()
+    ddp = torch.nn.parallel.DistributedDataParallel(head, find_unused_parameters=True)
+    x, boxes, labels = _data(cfg, 4)
+    sl = slice(rank * 2, rank * 2 + 2)
+    preds = ddp(x[sl])
+    loss = head.loss(head.get_targets(boxes[sl], labels[sl]), preds)
+    loss.backward()
+    if rank == 0:
+        out["grads"] = {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
+        out["loss"] = loss.item()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_equals_single_process_double_batch():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    cfg, head = _make()
+    x, boxes, labels = _data(cfg, 4)
+    # single process, global batch 4: the loss normalisers are global sums there, while each
+    # DP rank divides by the cross-rank MEAN of its normalisers (reduce_mean): grads then
+    # average to (1/world) * sum_r grad(L_r) with L_r = S_r / mean(N) => 1-proc gradient.
+    loss = _step(head, x, boxes, labels)
+    loss.backward()
+    ref = {n: p.grad for n, p in head.named_parameters() if p.grad is not None}
+    got = out["grads"]
+    assert set(got) == set(ref)
+    for n in ref:
+        assert torch.allclose(got[n], ref[n], rtol=2e-3, atol=2e-5), n
+
+
+def test_loss_normaliser_is_one_collective_and_device_resident():
+    """No .item(): the loss is a tensor with grad_fn and needs no process group when world=1."""
+    cfg, head = _make()
+    x, boxes, labels = _data(cfg, 2)
+    loss = _step(head, x, boxes, labels)
+    assert loss.requires_grad and loss.dim() == 0
