@@ -92,10 +92,24 @@ def cpu_baseline(geom, feats, vn, grad_out_nhwc, budget_s=12.0):
                       f"on CPU at the full cfg-2 shape B={B} P={P} C={C}, median {med * 1e3:.1f} ms/step"}, out, pos, gi
 
 
-def roofline_entry(kernel, nbytes, ms):
+def pmc_traffic(kernels):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 correction, profiles/r01_hotpath_cfg2_pmc.json).  PMC
+    collection cannot run inside this process; the figure belongs to the same kernel, shape
+    (cfg2) and geometry the roofline line is quoted on."""
+    path = os.path.join(ROOT, "profiles", "r01_hotpath_cfg2_pmc.json")
+    try:
+        k = json.load(open(path))["kernels"]
+        return float(sum(k[name]["traffic_bytes"] for name in kernels))
+    except Exception:
+        return None
+
+
+def roofline_entry(kernel, nbytes, ms, pmc_kernels=()):
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": nbytes, "avg_ms": ms}
+            "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_kernels) if pmc_kernels else None,
+            "algorithmic_bytes": nbytes, "avg_ms": ms}
 
 
 def train_main(args, rank, local_rank, world):
@@ -160,8 +174,11 @@ def train_main(args, rank, local_rank, world):
         kept = ((g3[:, 0] >= 0) & (g3[:, 0] < nx) & (g3[:, 1] >= 0) & (g3[:, 1] < ny) & (g3[:, 2] >= 0) & (g3[:, 2] < nz))
         K, BP, C = int(kept.sum()), g3.shape[0], lss.output_channels
         fb, bb = algorithmic_bytes(BP, K, C, B, ny, nx)
-        res["roofline"] = roofline_entry("vp_fwd_seg_gather (voxel_pooling forward, inside the training step)", fb, fwd_ms)
-        res["roofline_backward"] = roofline_entry("vp_bwd_rows_vec4 (voxel_pooling backward, inside the training step)", bb, bwd_ms)
+        cfg2 = args.config == "cfg2"
+        res["roofline"] = roofline_entry("vp_fwd_seg_gather (voxel_pooling forward, inside the training step)", fb, fwd_ms,
+                                         ("vp_fwd_seg_gather",) if cfg2 else ())
+        res["roofline_backward"] = roofline_entry("vp_bwd_prepare + vp_bwd_rows_vec4 (voxel_pooling backward, inside the training step)",
+                                                  bb, bwd_ms, ("vp_bwd_prepare", "vp_bwd_rows_vec4") if cfg2 else ())
         res["config"]["kept_fraction"] = K / BP
         if world == 1 and not args.no_cpu_baseline:
             from mm_training_amd import synthetic
@@ -243,14 +260,9 @@ def main():
                                    "analytic 6-camera rig geometry, bs=4/GPU",
                        "global_batch": world * B, "points_per_sample": P, "kept_fraction": K / (B * P),
                        "parallelism": f"dp{world}", "mode": args.mode},
-            "roofline": {"bound": "hbm", "kernel": "vp_fwd_lds_combine (voxel_pooling forward)",
-                         "achieved": fwd_bytes / (fwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": fwd_bytes, "avg_ms": fwd_ms},
-            "roofline_backward": {"bound": "hbm", "kernel": "vp_bwd_rows_vec4 (voxel_pooling backward)",
-                                  "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": None, "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_ms},
+            "roofline": roofline_entry("vp_fwd_seg_gather (voxel_pooling forward)", fwd_bytes, fwd_ms, ("vp_fwd_seg_gather",)),
+            "roofline_backward": roofline_entry("vp_bwd_prepare + vp_bwd_rows_vec4 (voxel_pooling backward)", bwd_bytes, bwd_ms,
+                                                ("vp_bwd_prepare", "vp_bwd_rows_vec4")),
         }
         if world == 1 and not args.no_cpu_baseline:
             base, ref_out, ref_pos, ref_gi = cpu_baseline(geom_cpu.reshape(B, P, 3), feats_cpu.reshape(B, P, C),

@@ -61,6 +61,7 @@ int mmt_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
 #define MMT_VP_ALGO_ROW_ATOMIC 1  /* one coalesced row of global fp32 atomics per kept point */
 #define MMT_VP_ALGO_LDS_ATOMIC 2  /* chunk BEV tile accumulated in LDS with ds_add_f32, then row atomics */
 #define MMT_VP_ALGO_SEG_GATHER 3  /* chunk sorted by cell in LDS, rows summed in registers, one atomic row per (chunk, cell) */
+#define MMT_VP_ALGO_STREAM 4      /* chunk sorted by cell, balanced stream over the sorted list, LDS row buffer */
 #define MMT_VP_ALGO_MASK 0xF
 #define MMT_VP_CHUNK_1024 0x20    /* SEG_GATHER: 1024 points per workgroup instead of 512 */
 #define MMT_VP_WRITE_DROPPED 0x10 /* also write (-1,-1,-1) to pos_memo rows of dropped points,
@@ -77,14 +78,20 @@ int mmt_voxel_pooling_forward_ex(int batch_size, int num_points, int num_channel
  * grad_out is addressed as a [B,C,ny,nx] tensor through ELEMENT strides
  * (stride_b, stride_c, stride_y, stride_x) so any view autograd hands over works.
  * grad_in fp32 [B*P,C] is fully written (zeros for dropped points).
- * If stride_c != 1 and `workspace` (fp32, >= B*ny*nx*C elements) is non-NULL the
- * gradient is first transposed to channels-last in the workspace (coalesced gather);
- * with workspace == NULL a slower strided gather is used. */
+ * `workspace` (device, 4-byte elements, may be NULL) enables two things by its size:
+ *   >= B*ny*nx*C          : a gradient with stride_c != 1 is first transposed to channels-last
+ *                           there (coalesced row gather instead of a strided one);
+ *   >= B*ny*nx*C + B*P    : additionally a short first pass turns pos_memo into per-point row
+ *                           offsets (stored after the first B*ny*nx*C elements) and pulls the
+ *                           gradient rows on-die, so the write-heavy main pass issues no HBM reads.
+ * mmt_voxel_pooling_backward_workspace_elems() returns the larger figure. */
+int64_t mmt_voxel_pooling_backward_workspace_elems(int batch_size, int num_points, int num_channels,
+                                                   int num_voxel_x, int num_voxel_y);
 int mmt_voxel_pooling_backward(int batch_size, int num_points, int num_channels,
                                int num_voxel_x, int num_voxel_y, const int32_t *pos_memo,
                                const float *grad_output, int64_t stride_b, int64_t stride_c,
                                int64_t stride_y, int64_t stride_x, float *grad_input,
-                               float *workspace, void *stream);
+                               float *workspace, int64_t workspace_elems, void *stream);
 
 /* Replaces the quantise expression layers/backbones/lss_fpn.py:461-462
  *   ((xyz - (voxel_coord - voxel_size/2)) / voxel_size).int()

@@ -123,11 +123,80 @@ __global__ __launch_bounds__(kBlock) void lift_kernel(int D, int HW, int C, cons
     }
 }
 
-// Lift backward.  Workgroup = (camera, tile of kTile positions); it walks ALL depth bins
-// so grad_context needs no cross-workgroup sum.  Lane (j, c4) keeps its float4 of
-// grad_context in registers across the depth loop; grad_depth[d, j] = sum_c g*ctx is
-// reduced across the lanes of one position with LDS float atomics.
-constexpr int kBTile = 16;  // positions per workgroup (more workgroups: BN*HW/16)
+// Lift backward.  grad_depth[bn,d,s] = sum_c g[bn,d,s,c]*ctx[bn,c,s];
+//                 grad_context[bn,c,s] = sum_d g[bn,d,s,c]*depth[bn,d,s].
+// Workgroup = (camera, tile of NG consecutive positions) and walks ALL depth bins, so
+// grad_context needs no cross-workgroup sum.  Like the pooling kernels a wave is split
+// into G = 64/(C/4) lane groups of C/4 lanes, one group per position, one float4 column
+// per lane: per depth bin a group reads one contiguous C*4-byte row of g (the NG groups
+// together NG*C*4 contiguous bytes), keeps its grad_context float4 in registers over the
+// whole depth loop (4 rows in flight), and reduces the row's dot product with ctx across
+// its lanes by two DPP quad adds + one LDS float add per quad.
+template <int C4T>
+__global__ __launch_bounds__(kBlock) void lift_backward_vec4(int D, int HW, int C, const float *depth,
+                                                             const float *context, const float *g,
+                                                             float *grad_depth, float *grad_context) {
+    extern __shared__ __align__(16) float lds[];
+    const int C4 = C4T > 0 ? C4T : C >> 2;
+    const int G = 64 / C4;
+    const int NG = (kBlock / 64) * G;            // positions per workgroup
+    float *dep = lds;                            // [D][NG] depth tile
+    float *gd = dep + D * NG;                    // [D][NG] grad_depth accumulators
+    const int bn = blockIdx.y;
+    const int s0 = blockIdx.x * NG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / C4, li = lane - grp * C4;
+    const int j = wave * G + grp;                // position inside the tile
+    const bool active = grp < G && (s0 + j) < HW;
+
+    for (int i = tid; i < D * NG; i += kBlock) {
+        const int d = i / NG, jj = i - d * NG;
+        dep[i] = (s0 + jj) < HW ? depth[((int64_t)bn * D + d) * HW + s0 + jj] : 0.f;
+        gd[i] = 0.f;
+    }
+    float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        const float *cp = context + ((int64_t)bn * C + li * 4) * HW + s0 + j;
+        cx = make_float4(cp[0], cp[HW], cp[2 * (int64_t)HW], cp[3 * (int64_t)HW]);
+    }
+    __syncthreads();
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = g + (((int64_t)bn * D) * HW + s0 + j) * C + li * 4;
+    const int64_t dstride = (int64_t)HW * C;
+    for (int d0 = 0; d0 < D; d0 += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active && d0 + u < D) v[u] = *reinterpret_cast<const float4 *>(src + (d0 + u) * dstride);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u;
+            if (d < D) {
+                const float dv = dep[d * NG + (active ? j : 0)];
+                acc.x += v[u].x * dv; acc.y += v[u].y * dv; acc.z += v[u].z * dv; acc.w += v[u].w * dv;
+                float dot = v[u].x * cx.x + v[u].y * cx.y + v[u].z * cx.z + v[u].w * cx.w;
+                dot += __shfl_xor(dot, 1);       // quad reduction (lane groups start on multiples of 4
+                dot += __shfl_xor(dot, 2);       // when C/4 is a multiple of 4; otherwise see the host check)
+                if (active && (li & 3) == 0) atomicAdd(&gd[d * NG + j], dot);
+            }
+        }
+    }
+    if (active) {
+        float *gp = grad_context + ((int64_t)bn * C + li * 4) * HW + s0 + j;
+        gp[0] = acc.x; gp[HW] = acc.y; gp[2 * (int64_t)HW] = acc.z; gp[3 * (int64_t)HW] = acc.w;
+    }
+    __syncthreads();
+    for (int i = tid; i < D * NG; i += kBlock) {
+        const int d = i / NG, jj = i - d * NG;
+        if ((s0 + jj) < HW) grad_depth[((int64_t)bn * D + d) * HW + s0 + jj] = gd[i];
+    }
+}
+
+// any C (slow path): one element per lane, LDS float atomics for the dot product
+constexpr int kBTile = 16;
 
 __global__ __launch_bounds__(kBlock) void lift_backward_kernel(int D, int HW, int C,
                                                                const float *depth,
@@ -166,7 +235,6 @@ __global__ __launch_bounds__(kBlock) void lift_backward_kernel(int D, int HW, in
             grad_depth[((int64_t)bn * D + d) * HW + s0 + tid] = gdb[tid];
             gdb[tid] = 0.f;
         }
-        // the other gd buffer is used by the next bin; the barrier above orders the reset
     }
     __syncthreads();
     for (int i = tid; i < C * kBTile; i += kBlock) {
@@ -246,6 +314,20 @@ extern "C" int mmt_lift_features_backward(int BN, int D, int HW, int C, const fl
     MMT_REQUIRE_PTR(grad_context);
     if (BN <= 0 || D <= 0 || HW <= 0 || C <= 0 || BN > 65535)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_features_backward: bad sizes");
+    // vector path: rows are whole float4 columns and every lane group starts on a quad boundary
+    const int C4 = C / 4;
+    const bool vec4 = (C % 16 == 0) && C <= 256 && (((uintptr_t)grad_feats & 15) == 0);
+    if (vec4) {
+        const int NG = (kBlock / 64) * (64 / C4);
+        const size_t lds = (size_t)2 * D * NG * 4;
+        if (lds <= 64 * 1024) {
+            dim3 grid((unsigned)mmt::ceil_div(HW, NG), (unsigned)BN);
+            if (C == 80) hipLaunchKernelGGL((lift_backward_vec4<20>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+            else if (C == 64) hipLaunchKernelGGL((lift_backward_vec4<16>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+            else hipLaunchKernelGGL((lift_backward_vec4<0>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+            return mmt::check_launch("lift_features_backward(vec4)");
+        }
+    }
     const size_t lds = ((size_t)2 * kBTile * (C + 4) + 2 * kBTile) * 4;
     if (lds > 160 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_features_backward: C too large");
     dim3 grid((unsigned)mmt::ceil_div(HW, kBTile), (unsigned)BN);

@@ -12,7 +12,6 @@
 // HBM traffic per call (algorithmic): 12*BP geom + 12*BP pos_memo + 4*C*K features
 // of kept points + 4*C*B*ny*nx BEV rows.
 #include "mmt_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -403,6 +402,218 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// ALGO_STREAM: chunk sorted by BEV cell, then a BALANCED stream over the sorted list.
+//
+// Same index pass as SEG_GATHER (hash -> slot, count, wave scan, counting sort), but
+// the gather no longer iterates cell by cell.  The K kept points of the chunk, in
+// cell-sorted order, are split into equal contiguous segments, one per lane group
+// (4 waves x G groups); a group streams its segment with 4 whole-row loads in flight
+// and keeps the running sum of the current cell in registers.  Only when the cell id
+// changes does it hand the finished row to an LDS row buffer: a plain ds_write if the
+// cell lies entirely inside the group's segment (the common case), ds_add_f32 for the
+// <= (groups-1) cells that straddle a segment boundary.  After one barrier the row
+// buffer leaves the workgroup as contiguous runs of global fp32 atomics.
+// Per-cell overhead (ticket, staging, wave barriers) is gone and every group has the
+// same number of rows, so a chunk with one hot cell costs the same as an even one.
+constexpr int kStreamRowCap = 64;  // LDS row buffer rows; further cells flush straight to HBM
+
+template <int C4T, int CHUNK>
+__global__ __launch_bounds__(kBlock) void vp_fwd_stream(VpArgs a) {
+    constexpr int HT = CHUNK * 2;
+    constexpr int HT_LOG2 = (CHUNK == 512) ? 10 : 11;
+    static_assert(CHUNK == 512 || CHUNK == 1024, "chunk size");
+    constexpr int PPT = CHUNK / kBlock;
+    constexpr int NW = kBlock / 64;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    // [rowbuf: kStreamRowCap*C floats] aliases nothing; tables follow
+    const int C = a.C;
+    float *rowbuf = reinterpret_cast<float *>(smem_raw);
+    int *tab_key = reinterpret_cast<int *>(rowbuf + kStreamRowCap * C);
+    unsigned short *tab_slot = reinterpret_cast<unsigned short *>(tab_key + HT);
+    int *slot_key = reinterpret_cast<int *>(tab_slot + HT);
+    unsigned short *slot_cnt = reinterpret_cast<unsigned short *>(slot_key + CHUNK);
+    unsigned short *slot_off = slot_cnt + CHUNK;            // [CHUNK + 8] (padded: keeps `stage` 16-byte aligned)
+    unsigned short *sorted = slot_off + CHUNK + 8;
+    unsigned short *sorted_slot = sorted + CHUNK;
+    float *stage = reinterpret_cast<float *>(sorted_slot + CHUNK);  // [NW][256] overflow staging
+    __shared__ int nslots;
+
+    const int C4 = C4T > 0 ? C4T : C >> 2;
+    const int G = 64 / C4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    const int npts = (int)((a.BP - base) < CHUNK ? (a.BP - base) : CHUNK);
+
+    for (int i = tid; i < HT; i += kBlock) tab_key[i] = kEmpty;
+    for (int i = tid; i < CHUNK; i += kBlock) slot_cnt[i] = 0;
+    if (tid == 0) nslots = 0;
+    __syncthreads();
+
+    // ---- A1: bounds test, pos_memo, hash insert
+    int ent[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int lp = tid + k * kBlock;
+        int e = -1;
+        if (lp < npts) {
+            const int64_t t = base + lp;
+            const int x = a.geom[t * 3], y = a.geom[t * 3 + 1], z = a.geom[t * 3 + 2];
+            if (in_grid(x, y, z, a.nx, a.ny, a.nz)) {
+                const int b = (int)((unsigned)t / (unsigned)a.P);
+                write_pos(a.pos_memo, t, b, y, x);
+                const int key = (b * a.ny + y) * a.nx + x;
+                unsigned h = ((unsigned)key * 2654435761u) >> (32 - HT_LOG2);
+                for (int probe = 0; probe < HT; ++probe) {
+                    const int prev = atomicCAS(&tab_key[h], kEmpty, key);
+                    if (prev == kEmpty) {
+                        const int sidx = atomicAdd(&nslots, 1);
+                        tab_slot[h] = (unsigned short)sidx;
+                        slot_key[sidx] = key;
+                        e = (int)h;
+                        break;
+                    }
+                    if (prev == key) { e = (int)h; break; }
+                    h = (h + 1) & (HT - 1);
+                }
+            } else if (a.write_dropped) {
+                write_pos(a.pos_memo, t, -1, -1, -1);
+            }
+        }
+        ent[k] = e;
+    }
+    __syncthreads();
+
+    // ---- A2: per-slot counts. 16-bit counters are packed two per dword: add through the
+    // containing dword (a count never exceeds CHUNK <= 1024, so no carry into the neighbour)
+    int slot[PPT], rank[PPT];
+    unsigned *cnt32 = reinterpret_cast<unsigned *>(slot_cnt);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        slot[k] = -1;
+        rank[k] = 0;
+        if (ent[k] >= 0) {
+            slot[k] = tab_slot[ent[k]];
+            const int sh = (slot[k] & 1) * 16;
+            const unsigned old = atomicAdd(&cnt32[slot[k] >> 1], 1u << sh);
+            rank[k] = (int)((old >> sh) & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+
+    // ---- A3: exclusive scan of the counts by wave 0
+    const int ns = nslots;
+    if (wave == 0) {
+        constexpr int PER = CHUNK / 64;
+        int loc[PER];
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            loc[i] = idx < ns ? (int)slot_cnt[idx] : 0;
+            sum += loc[i];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            if (idx <= ns) slot_off[idx] = (unsigned short)run;
+            run += loc[i];
+        }
+        if (lane == 63) slot_off[CHUNK + 1] = (unsigned short)incl;   // total kept (also = slot_off[ns])
+    }
+    __syncthreads();
+
+    // ---- A4: counting-sort scatter (point id and its slot, cell-sorted order)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (slot[k] >= 0) {
+            const int pos = slot_off[slot[k]] + rank[k];
+            sorted[pos] = (unsigned short)(tid + k * kBlock);
+            sorted_slot[pos] = (unsigned short)slot[k];
+        }
+    const int nbuf = ns < kStreamRowCap ? ns : kStreamRowCap;
+    for (int i = tid; i < nbuf * C; i += kBlock) rowbuf[i] = 0.f;
+    __syncthreads();
+
+    // ---- B: balanced stream over the sorted list
+    const int nkept = slot_off[CHUNK + 1];
+    const int g = lane / C4;
+    const int li = lane - g * C4;
+    if (g < G && nkept > 0) {
+        const int NG = NW * G;
+        const int gid = wave * G + g;
+        const int L = (nkept + NG - 1) / NG;
+        const int jb = gid * L;
+        const int je = (jb + L) < nkept ? (jb + L) : nkept;
+        const float *fbase = a.feats + base * C + li * 4;
+        float *st = stage + wave * 256 + g * C;       // this group's private staging row
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cur = jb < je ? (int)sorted_slot[jb] : -1;
+
+        auto flush = [&](int s_) {
+            if (s_ < kStreamRowCap) {
+                float *r = rowbuf + s_ * C + li * 4;
+                const bool interior = (int)slot_off[s_] >= jb && (int)slot_off[s_ + 1] <= je;
+                if (interior) {
+                    *reinterpret_cast<float4 *>(r) = acc;
+                } else {
+                    atomicAdd(r, acc.x); atomicAdd(r + 1, acc.y); atomicAdd(r + 2, acc.z); atomicAdd(r + 3, acc.w);
+                }
+            } else {
+                // row buffer full: transpose through the private staging row so each
+                // atomic instruction of the group covers 80 contiguous bytes
+                *reinterpret_cast<float4 *>(st + li * 4) = acc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                float *orow = a.out + (int64_t)slot_key[s_] * C;
+                for (int e = li; e < C; e += C4) atomicAdd(orow + e, st[e]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        };
+
+        for (int j = jb; j < je; j += 4) {
+            float4 v[4];
+            int sl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + u;
+                sl[u] = -1;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (jj < je) {
+                    sl[u] = sorted_slot[jj];
+                    v[u] = *reinterpret_cast<const float4 *>(fbase + (int)sorted[jj] * C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (sl[u] >= 0) {
+                    if (sl[u] != cur) {
+                        flush(cur);
+                        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        cur = sl[u];
+                    }
+                    acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                }
+            }
+        }
+        if (cur >= 0) flush(cur);
+    }
+    __syncthreads();
+
+    // ---- C: the buffered rows leave as contiguous runs of global fp32 atomics
+    for (int i = tid; i < nbuf * C; i += kBlock) {
+        const int s_ = i / C;
+        atomicAdd(a.out + (int64_t)slot_key[s_] * C + (i - s_ * C), rowbuf[i]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Backward: grad_in[t,:] = grad_out[b,:,y,x] (kept) or 0.  Pure gather: the BEV
 // gradient (B*ny*nx*C fp32, 21 MB at cfg2) is served from L2 / Infinity Cache, the
@@ -416,7 +627,36 @@ struct VpBwdArgs {
     int64_t sb, sc, sy, sx;
     float *grad_in;
     int64_t span_bytes;  // bytes spanned by the grad_out view (buffer descriptor range)
+    const uint32_t *row_off;  // optional [BP] byte offset of each point's BEV-gradient row (prepared), or NULL
+    uint32_t *row_off_out;
 };
+
+// Backward, pass 1 (tiny): pos_memo -> per-point byte offset of its BEV-gradient row
+// (0xFFFFFFF0 = dropped), and touch that row so it is on-die before the write-heavy
+// pass starts.  Why a separate pass: with ~93 % of pass 2's HBM traffic being writes,
+// a read that misses the Infinity Cache queues behind the write drain (measured: the
+// same gather kernel runs 100 us with pos_memo / grad_out cache-warm and 170 us cold,
+// although only 44 MB of its 650 MB are reads).  Pass 1 reads them while the memory
+// system is idle and leaves 4 B/point + the gradient rows in L2 / Infinity Cache.
+// Same XCD-contiguous partition as pass 2, so each XCD warms its own L2.
+__global__ __launch_bounds__(kBlock) void vp_bwd_prepare(VpBwdArgs a, int rows_per_xcd) {
+    const int xcd = blockIdx.x & 7;
+    const int64_t r_begin = (int64_t)xcd * rows_per_xcd;
+    const int64_t r_end = (r_begin + rows_per_xcd) < a.BP ? (r_begin + rows_per_xcd) : a.BP;
+    float sink = 0.f;
+    for (int64_t t = r_begin + (blockIdx.x >> 3) * kBlock + threadIdx.x; t < r_end;
+         t += (int64_t)(gridDim.x >> 3) * kBlock) {
+        const int b = a.pos_memo[t * 3];
+        const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
+        const unsigned o = (unsigned)(b * a.sb + y * a.sy + x * a.sx) * 4u;
+        a.row_off_out[t] = (b != -1) ? o : 0xFFFFFFF0u;
+        if (b != -1) {
+            const float *row = a.grad_out + (b * a.sb + y * a.sy + x * a.sx);
+            for (int c = 0; c < a.C; c += 16) sink += row[c];   // one dword per 64-byte sector
+        }
+    }
+    if (sink == 1.2345e-30f) a.row_off_out[0] = 0;  // never true: keeps the touches alive
+}
 
 // Software-pipelined: the dependent chain pos_memo -> BEV-gradient row -> store is
 // what bounds this kernel when the caches are cold (a bare 605 MB memset runs at
@@ -424,7 +664,7 @@ struct VpBwdArgs {
 // waits two full HBM read latencies behind a saturated write queue).  So each lane
 // keeps the row offsets of tile t+2 and the gathered vectors of tile t+1 in flight
 // while it stores tile t.
-template <int C4T, bool NT, bool XCD>
+template <int C4T>
 __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
     const int CV = C4T > 0 ? C4T : a.C / 4;
     const int64_t total = a.BP * CV;
@@ -438,10 +678,10 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
     const int64_t ntiles = (total + kTileVecs - 1) / kTileVecs;
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int xcd = blockIdx.x & 7;
-    const int64_t t_begin = XCD ? xcd * per_xcd : 0;
-    const int64_t t_end = XCD ? ((t_begin + per_xcd) < ntiles ? (t_begin + per_xcd) : ntiles) : ntiles;
-    const int64_t t_first = XCD ? t_begin + (blockIdx.x >> 3) : blockIdx.x;
-    const int64_t t_step = XCD ? (gridDim.x >> 3) : gridDim.x;
+    const int64_t t_begin = xcd * per_xcd;
+    const int64_t t_end = (t_begin + per_xcd) < ntiles ? (t_begin + per_xcd) : ntiles;
+    const int64_t t_first = t_begin + (blockIdx.x >> 3);
+    const int64_t t_step = gridDim.x >> 3;
 
     // Only FULL tiles go through the pipelined loop and every load / store in it is
     // unconditional (dropped points read row 0 and select zero afterwards): hipcc can
@@ -463,10 +703,15 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
             const int64_t i = tile * kTileVecs + threadIdx.x + (int64_t)u * kBlock;
             const int64_t t = i / CV;
             const int cv = (int)(i - t * CV);
-            const int b = a.pos_memo[t * 3];
-            const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
-            const unsigned o = ((unsigned)(b * a.sb + y * a.sy + x * a.sx) + cv * 4) * 4u;
-            off[u] = (b != -1) ? o : 0xFFFFFFF0u;
+            if (a.row_off) {   // prepared by vp_bwd_prepare (wave-uniform branch)
+                const unsigned ro = a.row_off[t];
+                off[u] = ro == 0xFFFFFFF0u ? ro : ro + cv * 16u;
+            } else {
+                const int b = a.pos_memo[t * 3];
+                const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
+                const unsigned o = ((unsigned)(b * a.sb + y * a.sy + x * a.sx) + cv * 4) * 4u;
+                off[u] = (b != -1) ? o : 0xFFFFFFF0u;
+            }
         }
     };
     auto gather = [&](const unsigned (&off)[U], float4 (&v)[U]) {
@@ -488,8 +733,7 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = tile * kTileVecs + threadIdx.x + (int64_t)u * kBlock;
-                if (NT) mmt_nt_store4(v[u], dst + i);
-                else dst[i] = v[u];
+                mmt_nt_store4(v[u], dst + i);
             }
         };
         // unrolled by two with the register sets swapping roles: no copies, so nothing
@@ -591,7 +835,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_forward: B*P or B*ny*nx exceeds int32");
     int algo = flags & MMT_VP_ALGO_MASK;
-    if (algo > MMT_VP_ALGO_SEG_GATHER)
+    if (algo > MMT_VP_ALGO_STREAM)
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown algorithm %d", algo);
     if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown flag bits 0x%x", flags);
@@ -606,7 +850,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     const bool vec4 = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0);
     const bool seg_ok = vec4 && C <= 256;
     if (algo == MMT_VP_ALGO_AUTO) algo = seg_ok ? MMT_VP_ALGO_SEG_GATHER : MMT_VP_ALGO_LDS_ATOMIC;
-    if (algo == MMT_VP_ALGO_SEG_GATHER && !seg_ok) algo = MMT_VP_ALGO_LDS_ATOMIC;
+    if ((algo == MMT_VP_ALGO_SEG_GATHER || algo == MMT_VP_ALGO_STREAM) && !seg_ok) algo = MMT_VP_ALGO_LDS_ATOMIC;
 
     if (algo == MMT_VP_ALGO_SEG_GATHER) {
         const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
@@ -623,6 +867,27 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
         else MMT_LAUNCH_SEG(0);
 #undef MMT_LAUNCH_SEG
         return mmt::check_launch("voxel_pooling_forward(seg_gather)");
+    }
+
+    if (algo == MMT_VP_ALGO_STREAM) {
+        const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
+        const int chunk = big ? 1024 : 512;
+        const int64_t nchunks = mmt::ceil_div(BP, chunk);
+        const dim3 grid((unsigned)nchunks), block(kBlock);
+        // rowbuf + tab_key + tab_slot + slot_key + slot_cnt + slot_off + sorted + sorted_slot + stage
+        const size_t lds = (size_t)kStreamRowCap * C * 4 + (size_t)chunk * 2 * 4 + (size_t)chunk * 2 * 2 +
+                           (size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)(chunk + 8) * 2 + (size_t)chunk * 2 * 2 +
+                           (size_t)(kBlock / 64) * 256 * 4 + 64;
+#define MMT_LAUNCH_STREAM(C4T)                                                                    \
+    do {                                                                                          \
+        if (big) hipLaunchKernelGGL((vp_fwd_stream<C4T, 1024>), grid, block, lds, st, a);         \
+        else hipLaunchKernelGGL((vp_fwd_stream<C4T, 512>), grid, block, lds, st, a);              \
+    } while (0)
+        if (C == 80) MMT_LAUNCH_STREAM(20);
+        else if (C == 64) MMT_LAUNCH_STREAM(16);
+        else MMT_LAUNCH_STREAM(0);
+#undef MMT_LAUNCH_STREAM
+        return mmt::check_launch("voxel_pooling_forward(stream)");
     }
 
     if (algo == MMT_VP_ALGO_ROW_ATOMIC) {
@@ -654,15 +919,23 @@ extern "C" int mmt_voxel_pooling_forward(int B, int P, int C, int nx, int ny, in
                                         MMT_VP_ALGO_AUTO, stream);
 }
 
+extern "C" int64_t mmt_voxel_pooling_backward_workspace_elems(int B, int P, int C, int nx, int ny) {
+    if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0) return 0;
+    return (int64_t)B * ny * nx * C + (int64_t)B * P;
+}
+
 extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
                                           const int32_t *pos_memo, const float *grad_out,
                                           int64_t sb, int64_t sc, int64_t sy, int64_t sx,
-                                          float *grad_in, float *workspace, void *stream) {
+                                          float *grad_in, float *workspace,
+                                          int64_t workspace_elems, void *stream) {
     MMT_REQUIRE_PTR(pos_memo);
     MMT_REQUIRE_PTR(grad_out);
     MMT_REQUIRE_PTR(grad_in);
     if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "voxel_pooling_backward: non-positive size");
+    if (workspace == nullptr) workspace_elems = 0;
+    const int64_t bev_elems = (int64_t)B * ny * nx * C;
     const int64_t BP = (int64_t)B * P;
     if (BP >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_backward: B*P exceeds int32");
     hipStream_t st = (hipStream_t)stream;
@@ -671,8 +944,9 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
     a.BP = BP; a.C = C; a.nx = nx; a.ny = ny;
     a.pos_memo = pos_memo; a.grad_out = grad_out; a.grad_in = grad_in;
     a.sb = sb; a.sc = sc; a.sy = sy; a.sx = sx;
+    a.row_off = nullptr; a.row_off_out = nullptr;
 
-    if (sc != 1 && workspace != nullptr) {
+    if (sc != 1 && workspace_elems >= bev_elems) {
         dim3 grid((unsigned)mmt::ceil_div((int64_t)ny * nx, 32), (unsigned)mmt::ceil_div(C, 32), (unsigned)B);
         hipLaunchKernelGGL(vp_to_channels_last, grid, dim3(kBlock), 0, st, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
         int rc = mmt::check_launch("voxel_pooling_backward(to_channels_last)");
@@ -685,24 +959,23 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
                       a.sb >= 0 && a.sy >= 0 && a.sx >= 0 && span < (1ll << 29) &&
                       (((uintptr_t)a.grad_out & 15) == 0) && (((uintptr_t)grad_in & 15) == 0);
     a.span_bytes = span * 4;
+    if (vec4 && workspace_elems >= bev_elems + BP && (((uintptr_t)workspace & 3) == 0)) {
+        // pass 1: row offsets + cache warm-up (see vp_bwd_prepare)
+        a.row_off_out = reinterpret_cast<uint32_t *>(workspace + bev_elems);
+        const int rows_per_xcd = (int)mmt::ceil_div(BP, 8);
+        int pgrid = mmt::stream_grid(BP, kBlock, 256 * 8);
+        pgrid = (pgrid + 7) & ~7;
+        hipLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
+        int rc = mmt::check_launch("voxel_pooling_backward(prepare)");
+        if (rc) return rc;
+        a.row_off = a.row_off_out;
+    }
     if (vec4) {
         int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock, 256 * 16);
         grid = (grid + 7) & ~7;  // whole groups of 8 (one workgroup per XCD)
-        static const int variant = getenv("MMT_BWD_VARIANT") ? atoi(getenv("MMT_BWD_VARIANT")) : 3;
-        static const int gmul = getenv("MMT_BWD_GRID") ? atoi(getenv("MMT_BWD_GRID")) : 16;
-        grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock, 256 * gmul);
-        grid = (grid + 7) & ~7;
-#define MMT_LAUNCH_BWD(C4T)                                                                              \
-    do {                                                                                                 \
-        if (variant == 3) hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, true, true>), dim3(grid), dim3(kBlock), 0, st, a);        \
-        else if (variant == 2) hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, false, true>), dim3(grid), dim3(kBlock), 0, st, a);  \
-        else if (variant == 1) hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, true, false>), dim3(grid), dim3(kBlock), 0, st, a);  \
-        else hipLaunchKernelGGL((vp_bwd_rows_vec4<C4T, false, false>), dim3(grid), dim3(kBlock), 0, st, a);                   \
-    } while (0)
-        if (C == 80) MMT_LAUNCH_BWD(20);
-        else if (C == 64) MMT_LAUNCH_BWD(16);
-        else MMT_LAUNCH_BWD(0);
-#undef MMT_LAUNCH_BWD
+        if (C == 80) hipLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, a);
+        else if (C == 64) hipLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, a);
         return mmt::check_launch("voxel_pooling_backward(rows_vec4)");
     }
     const int grid = mmt::stream_grid(BP * C, kBlock);

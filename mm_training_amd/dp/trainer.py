@@ -61,7 +61,7 @@ def synthetic_batch(cfg, device, seed=0, batch_size=None):
 class TrainStep(nn.Module):
     """Owns model + optimiser and runs one optimisation step per call."""
 
-    def __init__(self, cfg, device, world_size=1, lr=None, bucket_cap_mb=64):
+    def __init__(self, cfg, device, world_size=1, lr=None, bucket_cap_mb=64, amp=None):
         super().__init__()
         self.cfg = cfg
         self.device = device
@@ -88,7 +88,7 @@ class TrainStep(nn.Module):
         self.dbound = db
         self.downsample = cfg["backbone_conf"]["downsample_factor"]
         self.depth_channels = len(torch.arange(*db)) if self.use_cam else 0
-        self.amp_dtype = torch.bfloat16 if cfg.get("dtype") == "bf16" else None
+        self.amp_dtype = torch.bfloat16 if (amp or cfg.get("dtype")) == "bf16" else None
         self.register_buffer("mean", torch.tensor(IMG_MEAN).view(1, 1, 1, 3, 1, 1), persistent=False)
         self.register_buffer("std", torch.tensor(IMG_STD).view(1, 1, 1, 3, 1, 1), persistent=False)
         self.to(device)

@@ -142,7 +142,8 @@ class LSSFPN(nn.Module):
         """get_geometry (lss_fpn.py:328-361) fused with the quantise (:461-462):
         returns int32 voxel coordinates [B,N,D,fH,fW,3].  bda_mat is ignored like in
         the reference (:355-360)."""
-        combine = sensor2ego_mat.matmul(torch.inverse(intrin_mat)).contiguous()
+        with torch.autocast("cuda", enabled=False):   # the integer index path is fp32 whatever the AMP mode
+            combine = sensor2ego_mat.float().matmul(torch.inverse(intrin_mat.float())).contiguous()
         return frustum_geometry(self.frustum.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
 
     def get_cam_feats(self, imgs):

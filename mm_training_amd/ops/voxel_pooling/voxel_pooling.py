@@ -65,12 +65,12 @@ class VoxelPooling(Function):
         num_channels = ctx.feat_shape[-1]
         grad_input_features = torch.empty(ctx.feat_shape, dtype=torch.float32,
                                           device=pos_memo.device)
-        workspace = None
-        if grad_output_features.stride(1) != 1:
-            # NCHW-contiguous gradient (what `.contiguous()` at lss_fpn.py:467 produces):
-            # transpose once to channels-last so the gather reads whole rows
-            workspace = torch.empty(batch_size * ny * nx * num_channels, dtype=torch.float32,
-                                    device=pos_memo.device)
+        # scratch for (a) transposing an NCHW-contiguous gradient (what `.contiguous()` at
+        # lss_fpn.py:467 produces) to channels-last and (b) the per-point row offsets of the
+        # prepare pass; comes from torch's caching allocator, no device malloc per step
+        workspace = torch.empty(
+            voxel_pooling_ext.backward_workspace_elems(batch_size, num_points, num_channels, nx, ny),
+            dtype=torch.float32, device=pos_memo.device)
         voxel_pooling_ext.voxel_pooling_backward_wrapper(
             batch_size, num_points, num_channels, nx, ny, pos_memo, grad_output_features,
             grad_input_features, workspace)

@@ -77,10 +77,18 @@ def voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, num_voxe
     return 1
 
 
+def backward_workspace_elems(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y):
+    return int(_lib.lib().mmt_voxel_pooling_backward_workspace_elems(
+        int(batch_size), int(num_points), int(num_channels), int(num_voxel_x), int(num_voxel_y)))
+
+
 def voxel_pooling_backward_wrapper(batch_size, num_points, num_channels, num_voxel_x,
                                    num_voxel_y, pos_memo_tensor, grad_output_tensor,
                                    grad_input_tensor, workspace_tensor=None):
-    """grad_input[B,P,C] <- gather of grad_output (indexed [B,C,ny,nx], any strides)."""
+    """grad_input[B,P,C] <- gather of grad_output (indexed [B,C,ny,nx], any strides).
+
+    workspace_tensor (optional, float32): see mmt_voxel_pooling_backward in include/mmt_hip.h;
+    `backward_workspace_elems` gives the size that enables every fast path."""
     _check_input(pos_memo_tensor, "pos_memo_tensor", torch.int32)
     _check_input(grad_input_tensor, "grad_input_tensor", torch.float32)
     if not grad_output_tensor.is_cuda or grad_output_tensor.dtype != torch.float32:
@@ -92,14 +100,14 @@ def voxel_pooling_backward_wrapper(batch_size, num_points, num_channels, num_vox
     if pos_memo_tensor.numel() != B * P * 3 or grad_input_tensor.numel() != B * P * C:
         raise RuntimeError("pos_memo / grad_input do not match (batch_size, num_points, num_channels)")
     sb, sc, sy, sx = grad_output_tensor.stride()
-    ws = 0
+    ws, ws_elems = 0, 0
     if workspace_tensor is not None:
         if (not workspace_tensor.is_cuda or workspace_tensor.dtype != torch.float32
-                or workspace_tensor.numel() < B * ny * nx * C or not workspace_tensor.is_contiguous()):
-            raise RuntimeError("workspace must be a contiguous float32 CUDA tensor of >= B*ny*nx*C elements")
-        ws = workspace_tensor.data_ptr()
+                or not workspace_tensor.is_contiguous()):
+            raise RuntimeError("workspace must be a contiguous float32 CUDA tensor")
+        ws, ws_elems = workspace_tensor.data_ptr(), workspace_tensor.numel()
     with torch.cuda.device(grad_input_tensor.device):
         _timed_call("backward", "mmt_voxel_pooling_backward", B, P, C, nx, ny, pos_memo_tensor.data_ptr(),
                   grad_output_tensor.data_ptr(), sb, sc, sy, sx, grad_input_tensor.data_ptr(),
-                  ws, _stream())
+                  ws, ws_elems, _stream())
     return 1

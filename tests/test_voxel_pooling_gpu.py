@@ -31,7 +31,7 @@ def _run_ext(mmt_lib, geom, feats, nx, ny, nz, flags):
     return out, pos
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 0x24])
 def test_reference_known_answer_test(mmt_lib, oracle_mod, golden, algo):
     """The reference's own test (test/test_ops/test_voxel_pooling.py) at its own shape."""
     g = golden["vp_ref_test"]
@@ -59,7 +59,7 @@ def test_python_op_forward_backward_golden(mmt_lib, golden):
     out.backward(grad_out)
     assert feats.grad.shape == feats.shape
     assert torch.equal(feats.grad.reshape(2, -1, 80).cpu(), torch.from_numpy(g["grad_in"]))
-    # channels-last gradient takes the no-transpose path and must agree bit for bit
+    # channels-last gradient takes the no-transpose path (+ prepare pass) and must agree bit for bit
     feats.grad = None
     out2 = voxel_pooling(geom, feats, [128, 128, 1])
     out2.backward(grad_out.contiguous(memory_format=torch.channels_last))
@@ -67,7 +67,7 @@ def test_python_op_forward_backward_golden(mmt_lib, golden):
 
 
 @pytest.mark.parametrize("case", ["c1", "c3", "c64", "c80", "c81", "alldrop", "samecell"])
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 0x23, 0x24])
 def test_edge_cases(mmt_lib, golden, case, algo):
     from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext
     g = golden["vp_edge"]
@@ -85,7 +85,9 @@ def test_edge_cases(mmt_lib, golden, case, algo):
     assert torch.equal(pos2.cpu(), torch.from_numpy(g[case + "_pos_memo"]))
     # backward, NCHW gradient with and without workspace (strided slow path)
     go = _dev(g[case + "_grad_out"])
-    for ws in (None, torch.empty(B * ny * nx * C, device="cuda")):
+    full = voxel_pooling_ext.backward_workspace_elems(B, P, C, nx, ny)
+    assert full == B * ny * nx * C + B * P
+    for ws in (None, torch.empty(B * ny * nx * C, device="cuda"), torch.empty(full, device="cuda")):
         gi = torch.empty(B, P, C, device="cuda")
         voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, ws)
         assert torch.equal(gi.cpu(), torch.from_numpy(g[case + "_grad_in"]))

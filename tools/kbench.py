@@ -83,10 +83,11 @@ def main():
     res["out_memset_ms"] = memset_ms
     go = torch.randn(B, ny, nx, C, device="cuda").permute(0, 3, 1, 2)
     gi = torch.empty(B, P, C, device="cuda")
-    med, best = timeit(lambda: voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, None), args.reps)
+    WS = None if os.environ.get("KBENCH_NO_WS") else torch.empty(voxel_pooling_ext.backward_workspace_elems(B, P, C, nx, ny), device="cuda")
+    med, best = timeit(lambda: voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, WS), args.reps)
     res["bwd_nhwc"] = {"ms": med, "best_ms": best, "GBps": bwd_bytes / med / 1e6}
     go2 = go.contiguous()
-    ws = torch.empty(B * ny * nx * C, device="cuda")
+    ws = torch.empty(voxel_pooling_ext.backward_workspace_elems(B, P, C, nx, ny), device="cuda")
     med, best = timeit(lambda: voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go2, gi, ws), args.reps)
     res["bwd_nchw_ws"] = {"ms": med, "best_ms": best, "GBps": bwd_bytes / med / 1e6}
     # alternating forward / backward (what a training step does): per-kernel times
@@ -99,7 +100,7 @@ def main():
         voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=fl)
         e[1].record()
         e[2].record()
-        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, None)
+        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, WS)
         e[3].record()
         if it >= 3:
             fe.append((e[0], e[1]))
@@ -115,7 +116,7 @@ def main():
         flush.sum()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, None)
+        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, WS)
         e1.record()
         if it >= 3:
             be.append((e0, e1))

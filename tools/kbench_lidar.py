@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""LiDAR-half kernel microbenchmark (run on the GPU box): voxelize / VFE / pillar scatter /
+lift / geometry timings with HIP events + algorithmic GB/s (SURVEY.md section 8d formulas)."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mm_training_amd import synthetic
+from mm_training_amd.lidar import hard_voxelize_batch, simple_vfe, pillar_scatter
+from mm_training_amd.ops.bev_geometry import frustum_geometry, lift_features, quantize_geometry
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--points", type=int, default=40000)
+    ap.add_argument("--features", type=int, default=5)
+    ap.add_argument("--range", default="aim", choices=["aim", "nusc"])
+    args = ap.parse_args()
+    rng = [-204.8, -25.6, -5.0, 204.8, 25.6, 3.0] if args.range == "aim" else [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    vs = [0.2, 0.2, 8.0]
+    B, N, F = args.batch, args.points, args.features
+    frames = [synthetic.lidar_frame(N, F, rng, num_radar=2000 if F == 8 else 0, seed=i).cuda() for i in range(B)]
+    res = {"batch": B, "points": N, "F": F, "range": args.range}
+    ms = timeit(lambda: hard_voxelize_batch(frames, vs, rng, 15, 25000, compact=False))
+    voxels, num_points, coors, cnt = hard_voxelize_batch(frames, vs, rng, 15, 25000, compact=False)
+    M = int(cnt.sum())
+    vox_bytes = 4 * F * B * N + 16 * M + 4 * M + 4 * 15 * F * M
+    res["voxelize_fixed_capacity"] = {"ms": ms, "voxels": M, "algorithmic_MB": vox_bytes / 1e6, "GBps": vox_bytes / ms / 1e6}
+    ms = timeit(lambda: hard_voxelize_batch(frames, vs, rng, 15, 25000, compact=True))
+    res["voxelize_compact_with_host_sync"] = {"ms": ms}
+    v, n, c = hard_voxelize_batch(frames, vs, rng, 15, 25000, compact=True)
+    ms = timeit(lambda: simple_vfe(v, n, 5))
+    vb = 4 * 15 * F * M + 4 * M + 4 * 5 * M
+    res["simple_vfe"] = {"ms": ms, "GBps": vb / ms / 1e6}
+    C = 64
+    feats = torch.randn(M, C, device="cuda")
+    ny = int(round((rng[4] - rng[1]) / vs[1])); nx = int(round((rng[3] - rng[0]) / vs[0]))
+    ms = timeit(lambda: pillar_scatter(feats, c, B, ny, nx))
+    sb = 4 * C * M + 16 * M + 4 * C * B * ny * nx
+    res["pillar_scatter"] = {"ms": ms, "canvas": [B, C, ny, nx], "algorithmic_MB": sb / 1e6, "GBps": sb / ms / 1e6}
+    # camera-side producers at cfg2
+    s2e, K = synthetic.camera_rig(4, 6, 704, 256, jitter=0.02)
+    combine = (s2e @ torch.inverse(K)).cuda()
+    d = torch.arange(2.0, 58.0, 0.5).view(-1, 1, 1).expand(-1, 16, 44)
+    xs = torch.linspace(0, 703, 44).view(1, 1, 44).expand(112, 16, 44)
+    ys = torch.linspace(0, 255, 16).view(1, 16, 1).expand(112, 16, 44)
+    frustum = torch.stack((xs, ys, d, torch.ones_like(d)), -1).contiguous().cuda()
+    vc, vsz = [-50.8, -50.8, -1.0], [0.8, 0.8, 8.0]
+    ms = timeit(lambda: frustum_geometry(frustum, combine, vc, vsz))
+    BP = 4 * 6 * 112 * 16 * 44
+    res["frustum_geometry"] = {"ms": ms, "GBps": (12 * BP + 16 * 112 * 16 * 44) / ms / 1e6}
+    depth = torch.rand(24, 112, 16, 44, device="cuda").softmax(1).requires_grad_(True)
+    ctx = torch.randn(24, 80, 16, 44, device="cuda", requires_grad=True)
+    ms = timeit(lambda: lift_features(depth, ctx))
+    lb = 4 * 80 * BP + depth.numel() * 4 + ctx.numel() * 4
+    res["lift_forward"] = {"ms": ms, "GBps": lb / ms / 1e6}
+    out = lift_features(depth, ctx)
+    go = torch.randn_like(out)
+    ms = timeit(lambda: torch.autograd.grad(out, (depth, ctx), go, retain_graph=True))
+    res["lift_backward"] = {"ms": ms, "GBps": lb / ms / 1e6}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
