@@ -47,10 +47,19 @@ def init_dist(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("MMT_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+    if local_rank >= ndev:
+        # fewer GPUs than ranks (functional testing of the N>1 path on a 1-GPU box only):
+        # ranks share a device, which RCCL refuses, so fall back to gloo
+        local_rank, backend = local_rank % max(ndev, 1), "gloo"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
     return rank, local_rank, world
 

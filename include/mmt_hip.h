@@ -123,6 +123,19 @@ int mmt_lift_features_backward(int num_cams_total, int D, int HW, int C, const f
                                const float *context, const float *grad_feats, float *grad_depth,
                                float *grad_context, void *stream);
 
+/* Deformable 3x3 convolution, the data-dependent halves: replaces
+ * mmcv 'DCN' (DeformConv2dPack) inside DepthNet, layers/backbones/lss_fpn.py:189-197.
+ * stride 1, pad 1, dilation 1, deform_groups 1.  All tensors channels-last fp32:
+ *   x [B,H,W,C]; offset [B,H,W,18] = (dy,dx) per tap k=ky*3+kx;
+ *   col [groups][B*H*W][9*C/groups] with K index k*(C/groups)+c_in_group.
+ * The grouped GEMM between im2col and the output (and its two backward GEMMs) is plain and is
+ * left to rocBLAS/hipBLASLt.  mmt_dcn_col2im ACCUMULATES into grad_x (caller zero-fills) and
+ * overwrites grad_offset [B,H,W,18]. */
+int mmt_dcn_im2col(int B, int H, int W, int C, int groups, const float *x, const float *offset,
+                   float *col, void *stream);
+int mmt_dcn_col2im(int B, int H, int W, int C, int groups, const float *x, const float *offset,
+                   const float *grad_col, float *grad_x, float *grad_offset, void *stream);
+
 /* ------------------------------------------------------------------- LiDAR half */
 
 /* Replaces mmcv-full 1.7.0 ops.Voxelization (hard, deterministic) as called per sample by

@@ -1,0 +1,55 @@
+"""Deformable 3x3 convolution (mmcv 'DCN' / DeformConv2dPack, lss_fpn.py:189-197) on the
+HIP im2col / col2im kernels of libmmt_hip.so + torch.bmm for the grouped GEMMs."""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _DeformConv3x3(Function):
+    @staticmethod
+    def forward(ctx, x, offset, weight, groups):
+        if not x.is_cuda:
+            raise RuntimeError("x must be a CUDAtensor ")
+        x_nhwc = x.float().permute(0, 2, 3, 1).contiguous()        # free for channels_last inputs
+        off_nhwc = offset.float().permute(0, 2, 3, 1).contiguous()
+        B, H, W, C = x_nhwc.shape
+        O = weight.shape[0]
+        Cg, Og, N = C // groups, O // groups, B * H * W
+        if off_nhwc.shape != (B, H, W, 18) or tuple(weight.shape) != (O, Cg, 3, 3):
+            raise RuntimeError("deform_conv3x3: expected offset [B,18,H,W] and weight [O, C/groups, 3, 3]")
+        col = torch.empty((groups, N, 9 * Cg), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("mmt_dcn_im2col", B, H, W, C, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(),
+                      col.data_ptr(), _stream())
+        wmat = weight.float().reshape(groups, Og, Cg, 9).permute(0, 3, 2, 1).reshape(groups, 9 * Cg, Og)
+        out = torch.bmm(col, wmat)                                  # [g, N, Og]
+        out_nhwc = out.permute(1, 0, 2).reshape(B, H, W, O)
+        ctx.save_for_backward(x_nhwc, off_nhwc, col, wmat)
+        ctx.dims = (B, H, W, C, O, groups)
+        return out_nhwc.permute(0, 3, 1, 2)                         # channels_last view
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_nhwc, off_nhwc, col, wmat = ctx.saved_tensors
+        B, H, W, C, O, groups = ctx.dims
+        Cg, Og, N = C // groups, O // groups, B * H * W
+        go = grad_out.float().permute(0, 2, 3, 1).reshape(N, groups, Og).permute(1, 0, 2).contiguous()
+        grad_wmat = torch.bmm(col.transpose(1, 2), go)              # [g, 9Cg, Og]
+        grad_weight = grad_wmat.reshape(groups, 9, Cg, Og).permute(0, 3, 2, 1).reshape(O, Cg, 3, 3)
+        grad_col = torch.bmm(go, wmat.transpose(1, 2)).contiguous()  # [g, N, 9Cg]
+        grad_x = torch.zeros_like(x_nhwc)
+        grad_off = torch.empty_like(off_nhwc)
+        with torch.cuda.device(x_nhwc.device):
+            _lib.call("mmt_dcn_col2im", B, H, W, C, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(),
+                      grad_col.data_ptr(), grad_x.data_ptr(), grad_off.data_ptr(), _stream())
+        return grad_x.permute(0, 3, 1, 2), grad_off.permute(0, 3, 1, 2), grad_weight, None
+
+
+def deform_conv3x3(x, offset, weight, groups=1):
+    """x [B,C,H,W], offset [B,18,H,W], weight [O, C/groups, 3, 3] -> [B,O,H,W] (channels_last)."""
+    return _DeformConv3x3.apply(x, offset, weight, int(groups))

@@ -81,3 +81,39 @@ def test_lift_forward_backward(mmt_lib, oracle_mod, shape):
     ref.backward(go)
     assert torch.allclose(d.grad, d2.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(c.grad, c2.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 5, 7, 8, 4, 0.0), (2, 16, 5, 7, 8, 2, 0.4), (3, 64, 16, 44, 32, 4, 1.5), (24, 512, 16, 44, 512, 4, 0.7)])
+def test_deform_conv_matches_torch_reference(mmt_lib, shape):
+    """DCN (lss_fpn.py:189-197): HIP im2col/col2im + GEMM vs the torch fp32 grid_sample
+    restatement of the same operator (forward, grad_input, grad_offset, grad_weight)."""
+    from mm_training_amd.layers.nets import DeformConv2dPack
+    B, C, H, W, O, groups, off_scale = shape
+    torch.manual_seed(0)
+    m = DeformConv2dPack(C, O, groups=groups).cuda()
+    x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    offset = (torch.randn(B, 18, H, W, device="cuda") * off_scale)
+    if off_scale > 0:   # far outside, half-pixel, just inside the border
+        offset[0, :, 2, 2] = torch.tensor([-30.0, -30.0, 50.0, 50.0, -0.5, -0.5, 0.25, -1.25, 0.1, 0.1, 1.5, 1.5, -1.75, 2.25, 0.5, 0.5, 0.99, -0.99])
+    from mm_training_amd.ops.deform_conv import deform_conv3x3
+    xa, oa = x.clone().requires_grad_(True), offset.clone().requires_grad_(True)
+    xb, ob = x.clone().requires_grad_(True), offset.clone().requires_grad_(True)
+    out = deform_conv3x3(xa, oa, m.weight, groups)
+    ref = m.forward_reference(xb, ob)
+    assert out.shape == ref.shape == (B, O, H, W)
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-5 * max(scale, 1.0) + 1e-5
+    go = torch.randn_like(ref)
+    gw_a, = torch.autograd.grad(out, m.weight, go, retain_graph=True)
+    gw_b, = torch.autograd.grad(ref, m.weight, go, retain_graph=True)
+    out.backward(go)
+    ref.backward(go)
+    ga, gb = oa.grad, ob.grad
+    if off_scale == 0.0:
+        # sampling points that sit EXACTLY on the -1 / H / W boundary (zero offsets on the image
+        # border): mmcv's kernels (which the HIP path follows) define the coordinate gradient as 0
+        # there, torch's grid_sample as one-sided; compare the interior only
+        ga, gb = ga[:, :, 1:-1, 1:-1], gb[:, :, 1:-1, 1:-1]
+    for a, b, name in ((xa.grad, xb.grad, "grad_x"), (ga, gb, "grad_offset"), (gw_a, gw_b, "grad_weight")):
+        tol = 1e-4 * max(b.abs().max().item(), 1.0)
+        assert (a - b).abs().max().item() <= tol, name
