@@ -143,7 +143,7 @@ class LSSFPN(nn.Module):
         returns int32 voxel coordinates [B,N,D,fH,fW,3].  bda_mat is ignored like in
         the reference (:355-360)."""
         with torch.autocast("cuda", enabled=False):   # the integer index path is fp32 whatever the AMP mode
-            combine = sensor2ego_mat.float().matmul(torch.inverse(intrin_mat.float())).contiguous()
+            combine = sensor2ego_mat.float().matmul(torch.linalg.inv_ex(intrin_mat.float())[0]).contiguous()
         return frustum_geometry(self.frustum.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
 
     def get_cam_feats(self, imgs):

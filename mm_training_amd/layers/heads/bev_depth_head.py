@@ -114,6 +114,10 @@ class BEVDepthHead(nn.Module):
 
     @torch.no_grad()
     def get_targets_single(self, boxes, labels):
+        """Vectorised and free of host synchronisation: every task looks at ALL K boxes of the
+        sample and masks the ones of other tasks (the reference packs each task's boxes densely
+        at the front of its max_objs slots, bev_depth_head.py:142-163,186-248; the loss only sums
+        over masked slots, so the slot order is immaterial)."""
         cfg = self.train_cfg
         dev = boxes.device
         max_objs = cfg['max_objs'] * cfg['dense_reg']
@@ -122,44 +126,46 @@ class BEVDepthHead(nn.Module):
         fy = int(cfg['grid_size'][1]) // osf
         pc = cfg['point_cloud_range']
         vs = cfg['voxel_size']
+        boxes = boxes[:max_objs]
+        labels = labels[:max_objs].long()
+        K = boxes.shape[0]
         heatmaps, anno_boxes, inds, masks = [], [], [], []
-        ys = torch.arange(fy, device=dev, dtype=torch.float32).view(1, fy, 1)
-        xs = torch.arange(fx, device=dev, dtype=torch.float32).view(1, 1, fx)
+        if K > 0:
+            ys = torch.arange(fy, device=dev, dtype=torch.float32).view(1, fy, 1)
+            xs = torch.arange(fx, device=dev, dtype=torch.float32).view(1, 1, fx)
+            width = boxes[:, 3] / vs[0] / osf
+            length = boxes[:, 4] / vs[1] / osf
+            radius = gaussian_radius(length, width, min_overlap=cfg['gaussian_overlap'])
+            radius = torch.clamp(radius.nan_to_num(0).floor(), min=float(cfg['min_radius']))
+            cx = (boxes[:, 0] - pc[0]) / vs[0] / osf
+            cy = (boxes[:, 1] - pc[1]) / vs[1] / osf
+            cxi, cyi = cx.to(torch.int32), cy.to(torch.int32)
+            in_map = (width > 0) & (length > 0) & (cxi >= 0) & (cxi < fx) & (cyi >= 0) & (cyi < fy)
+            # draw_heatmap_gaussian: sigma = (2r+1)/6, window |d| <= r, max-combine
+            sigma = ((2 * radius + 1) / 6).view(K, 1, 1)
+            dx = xs - cxi.view(K, 1, 1).float()
+            dy = ys - cyi.view(K, 1, 1).float()
+            r = radius.view(K, 1, 1)
+            gauss = torch.exp(-(dx * dx + dy * dy) / (2 * sigma * sigma)) * ((dx.abs() <= r) & (dy.abs() <= r))
+            dims = boxes[:, 3:6].log() if self.norm_bbox else boxes[:, 3:6]
+            anno_all = torch.cat([(cx - cxi.float()).unsqueeze(1), (cy - cyi.float()).unsqueeze(1), boxes[:, 2:3], dims,
+                                  torch.sin(boxes[:, 6:7]), torch.cos(boxes[:, 6:7]), boxes[:, 7:9]], 1)
+            ind_all = (cyi * fx + cxi).long().clamp(0, fx * fy - 1)
         flag = 0
         for t, names in enumerate(self.class_names):
             n_cls = len(names)
-            sel = (labels >= flag) & (labels < flag + n_cls)
-            tb = boxes[sel][:max_objs]
-            tc = (labels[sel][:max_objs] - flag).long()
-            flag += n_cls
-            K = tb.shape[0]
             heatmap = torch.zeros((n_cls, fy, fx), device=dev)
             anno = torch.zeros((max_objs, 10), device=dev)
             ind = torch.zeros((max_objs,), dtype=torch.int64, device=dev)
             mask = torch.zeros((max_objs,), dtype=torch.uint8, device=dev)
             if K > 0:
-                width = tb[:, 3] / vs[0] / osf
-                length = tb[:, 4] / vs[1] / osf
-                radius = gaussian_radius(length, width, min_overlap=cfg['gaussian_overlap'])
-                radius = torch.clamp(radius.nan_to_num(0).floor(), min=float(cfg['min_radius']))
-                cx = (tb[:, 0] - pc[0]) / vs[0] / osf
-                cy = (tb[:, 1] - pc[1]) / vs[1] / osf
-                cxi, cyi = cx.to(torch.int32), cy.to(torch.int32)
-                valid = (width > 0) & (length > 0) & (cxi >= 0) & (cxi < fx) & (cyi >= 0) & (cyi < fy)
-                # draw_heatmap_gaussian: sigma = (2r+1)/6, window |d| <= r, max-combine
-                sigma = ((2 * radius + 1) / 6).view(K, 1, 1)
-                dx = xs - cxi.view(K, 1, 1).float()
-                dy = ys - cyi.view(K, 1, 1).float()
-                g = torch.exp(-(dx * dx + dy * dy) / (2 * sigma * sigma))
-                r = radius.view(K, 1, 1)
-                g = g * ((dx.abs() <= r) & (dy.abs() <= r) & valid.view(K, 1, 1))
-                heatmap.index_reduce_(0, tc, g, 'amax', include_self=True)
-                ind[:K] = torch.where(valid, (cyi * fx + cxi).long(), torch.zeros_like(cyi).long())
+                valid = in_map & (labels >= flag) & (labels < flag + n_cls)
+                cls = (labels - flag).clamp(0, n_cls - 1)
+                heatmap.index_reduce_(0, cls, gauss * valid.view(K, 1, 1), 'amax', include_self=True)
+                ind[:K] = torch.where(valid, ind_all, torch.zeros_like(ind_all))
                 mask[:K] = valid.to(torch.uint8)
-                dims = tb[:, 3:6].log() if self.norm_bbox else tb[:, 3:6]
-                a = torch.cat([(cx - cxi.float()).unsqueeze(1), (cy - cyi.float()).unsqueeze(1), tb[:, 2:3], dims,
-                               torch.sin(tb[:, 6:7]), torch.cos(tb[:, 6:7]), tb[:, 7:9]], 1)
-                anno[:K] = a * valid.view(K, 1)
+                anno[:K] = anno_all * valid.view(K, 1)
+            flag += n_cls
             heatmaps.append(heatmap)
             anno_boxes.append(anno)
             inds.append(ind)
