@@ -72,6 +72,23 @@ def main():
     go = torch.randn_like(out)
     ms = timeit(lambda: torch.autograd.grad(out, (depth, ctx), go, retain_graph=True))
     res["lift_backward"] = {"ms": ms, "GBps": lb / ms / 1e6}
+    # CPU baseline beside it: the oracle's sequential C restatement (1 core) on the same frames
+    import time
+    import oracle
+    np_frames = [f.cpu().numpy() for f in frames]
+    t0 = time.perf_counter()
+    rv, rn, rc = oracle.voxelize_batch(np_frames, vs, rng, 15, 25000)
+    t_vox = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rf = oracle.simple_vfe(rv, rn, 5)
+    t_vfe = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.pillar_scatter(feats.cpu().numpy()[:rc.shape[0]], rc, B, ny, nx)
+    t_sc = time.perf_counter() - t0
+    res["cpu_baseline_oracle_1core_ms"] = {"voxelize": t_vox * 1e3, "simple_vfe": t_vfe * 1e3, "pillar_scatter": t_sc * 1e3}
+    res["hbm_peak_GBps"] = 8000.0
+    for k in ("voxelize_fixed_capacity", "simple_vfe", "pillar_scatter", "lift_forward", "lift_backward", "frustum_geometry"):
+        res[k]["frac_of_peak"] = res[k]["GBps"] / 8000.0
     print(json.dumps(res, indent=1))
 
 
