@@ -256,8 +256,9 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     static_assert(CHUNK == 512 || CHUNK == 1024, "chunk size");
     constexpr int PPT = CHUNK / kBlock;
     constexpr int NW = kBlock / 64;
-    __shared__ int tab_key[HT];
-    __shared__ int tab_slot[HT];
+    __shared__ __align__(16) int tab[2 * HT];    // hash keys | slot ids; reused for pos_memo (12*CHUNK B)
+    int *tab_key = tab, *tab_slot = tab + HT;
+    static_assert(2 * HT * 4 >= CHUNK * 12, "pos_memo block must fit in the hash table's LDS");
     __shared__ int slot_key[CHUNK];
     __shared__ int slot_cnt[CHUNK];
     __shared__ int slot_off[CHUNK + 1];
@@ -277,18 +278,24 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     if (tid == 0) { nslots = 0; next_slot = 0; }
     __syncthreads();
 
-    // ---- A1: bounds test, pos_memo, hash insert
+    // ---- A1: bounds test, hash insert.  pos_memo rows are kept in registers: in WRITE_DROPPED
+    // mode the chunk's whole 12*CHUNK-byte pos_memo block is written later as full 16-byte
+    // coalesced stores (stride-12 dword stores leave partially written L2 lines behind, which
+    // cost a fetch-on-write: 23 MB of avoidable HBM reads at cfg2).
     int ent[PPT];
+    int pm[PPT][3];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int lp = tid + k * kBlock;
         int e = -1;
+        pm[k][0] = pm[k][1] = pm[k][2] = -1;
         if (lp < npts) {
             const int64_t t = base + lp;
             const int x = a.geom[t * 3], y = a.geom[t * 3 + 1], z = a.geom[t * 3 + 2];
             if (in_grid(x, y, z, a.nx, a.ny, a.nz)) {
                 const int b = (int)((unsigned)t / (unsigned)a.P);
-                write_pos(a.pos_memo, t, b, y, x);
+                pm[k][0] = b; pm[k][1] = y; pm[k][2] = x;
+                if (!a.write_dropped) write_pos(a.pos_memo, t, b, y, x);
                 const int key = (b * a.ny + y) * a.nx + x;
                 unsigned h = ((unsigned)key * 2654435761u) >> (32 - HT_LOG2);
                 for (int probe = 0; probe < HT; ++probe) {  // never fills: <= CHUNK keys in 2*CHUNK entries
@@ -303,8 +310,6 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
                     if (prev == key) { e = (int)h; break; }
                     h = (h + 1) & (HT - 1);
                 }
-            } else if (a.write_dropped) {
-                write_pos(a.pos_memo, t, -1, -1, -1);
             }
         }
         ent[k] = e;
@@ -352,11 +357,31 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     }
     __syncthreads();
 
-    // ---- A4: counting-sort scatter of local point ids
+    // ---- A4: counting-sort scatter of local point ids; the hash table is dead now, so its
+    // LDS holds the chunk's pos_memo block for the coalesced write-out
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
         if (slot[k] >= 0) sorted[slot_off[slot[k]] + rank[k]] = (unsigned short)(tid + k * kBlock);
+    if (a.write_dropped) {
+        int *pml = tab;                          // [CHUNK*3] ints
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int lp = tid + k * kBlock;
+            pml[lp * 3] = pm[k][0]; pml[lp * 3 + 1] = pm[k][1]; pml[lp * 3 + 2] = pm[k][2];
+        }
+    }
     __syncthreads();
+    if (a.write_dropped) {
+        const int *pml = tab;
+        int32_t *dstp = a.pos_memo + base * 3;   // 12*CHUNK*blockIdx bytes: 16-byte aligned
+        const int nint = npts * 3;
+        if ((nint & 3) == 0) {
+            for (int i = tid; i < (nint >> 2); i += kBlock)
+                reinterpret_cast<int4 *>(dstp)[i] = reinterpret_cast<const int4 *>(pml)[i];
+        } else {
+            for (int i = tid; i < nint; i += kBlock) dstp[i] = pml[i];
+        }
+    }
 
     // ---- B/C: one slot per wave at a time, register accumulation, staged flush
     const int g = lane / C4;
@@ -613,6 +638,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_stream(VpArgs a) {
         atomicAdd(a.out + (int64_t)slot_key[s_] * C + (i - s_ * C), rowbuf[i]);
     }
 }
+
 
 // ---------------------------------------------------------------------------
 // Backward: grad_in[t,:] = grad_out[b,:,y,x] (kept) or 0.  Pure gather: the BEV
