@@ -38,6 +38,9 @@ def parse():
                          "hotpath: only voxel_pooling forward+backward at the cfg-2 shape")
     ap.add_argument("--config", default="cfg2", help="cfg2 (BASELINE configs[1], default) | cfg3 | cfg4 | cfg5 | tiny")
     ap.add_argument("--miopen-tune", action="store_true", help="exhaustive MIOpen search (minutes of warm-up)")
+    ap.add_argument("--fused-lift-splat", action="store_true",
+                    help="camera branch uses the fused lift-splat kernels (row f1) instead of lift -> voxel_pooling; "
+                         "the voxel_pooling roofline lines are then not produced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag")
     return ap.parse_args()
@@ -150,6 +153,8 @@ def train_main(args, rank, local_rank, world):
     cfg = make_config(args.config)
     torch.manual_seed(0)
     ts = TrainStep(cfg, dev, world_size=world)
+    if args.fused_lift_splat and cfg["use_cam"]:
+        ts.model.backbone.fused_lift_splat = True
     B = cfg["batch_size"]
     # a small pool of distinct pre-generated batches resident in HBM (input is never the bottleneck)
     batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i) for i in range(2)]
@@ -185,7 +190,8 @@ def train_main(args, rank, local_rank, world):
             "tiny": "tiny smoke configuration"}[args.config],
             "global_batch": world * B, "parallelism": f"dp{world}", "mode": "train",
             "params_M": sum(p.numel() for p in ts.model.parameters()) / 1e6,
-            "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune)},
+            "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune),
+            "fused_lift_splat": bool(args.fused_lift_splat)},
     }
     if cfg["use_cam"] and timing.get("forward"):
         fwd_ms = sum(s.elapsed_time(e) for s, e in timing["forward"]) / len(timing["forward"])

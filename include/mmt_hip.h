@@ -123,6 +123,27 @@ int mmt_lift_features_backward(int num_cams_total, int D, int HW, int C, const f
                                const float *context, const float *grad_feats, float *grad_depth,
                                float *grad_context, void *stream);
 
+/* Fused lift-splat (an ADDITIONAL entry point beside the drop-in
+ * pair above): voxel_pooling of features that are never materialised,
+ *   out[b, y, x, :] += sum over kept points t of  depth[t] * context[pix(t), :]
+ * i.e. layers/backbones/lss_fpn.py:441-464 (lift, permute+contiguous, voxel_pooling) in one
+ * pass without the [B*P, C] tensor.  Points are ordered [B][N][D][HW] like geom:
+ *   geom int32 [B*N*D*HW, 3]; depth fp32 [B*N, D, HW] (= one value per point, point order);
+ *   context fp32 [B*N, HW, C] channels-last; out fp32 [B, ny, nx, C] accumulated into;
+ *   pos_memo int32 [B*N*D*HW, 3] as in mmt_voxel_pooling_forward (flags: MMT_VP_WRITE_DROPPED).
+ * Backward:  grad_depth[t] = <grad_out[cell(t), :], context[pix(t), :]>  (0 for dropped points)
+ *            grad_context[pix, :] = sum_d depth[t] * grad_out[cell(t), :]
+ * grad_out is indexed [B, C, ny, nx] through element strides and must be channels-last
+ * (stride_c == 1); grad_depth [B*N, D, HW] and grad_context [B*N, HW, C] are fully written. */
+int mmt_lift_splat_forward(int B, int N, int D, int HW, int C, int nx, int ny, int nz,
+                           const int32_t *geom_xyz, const float *depth, const float *context,
+                           float *output_features, int32_t *pos_memo, int flags, void *stream);
+int mmt_lift_splat_backward(int B, int N, int D, int HW, int C, int nx, int ny,
+                            const int32_t *pos_memo, const float *depth, const float *context,
+                            const float *grad_output, int64_t stride_b, int64_t stride_c,
+                            int64_t stride_y, int64_t stride_x, float *grad_depth,
+                            float *grad_context, void *stream);
+
 /* Deformable 3x3 convolution, the data-dependent halves: replaces
  * mmcv 'DCN' (DeformConv2dPack) inside DepthNet, layers/backbones/lss_fpn.py:189-197.
  * stride 1, pad 1, dilation 1, deform_groups 1.  All tensors channels-last fp32:

@@ -25,6 +25,8 @@ SIGNATURES = {
     "mmt_frustum_geometry": (_c_int, [_c_int, _c_i64] + [_c_ptr] * 6 + [_c_ptr]),
     "mmt_lift_features": (_c_int, [_c_int] * 4 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_lift_features_backward": (_c_int, [_c_int] * 4 + [_c_ptr] * 5 + [_c_ptr]),
+    "mmt_lift_splat_forward": (_c_int, [_c_int] * 8 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
+    "mmt_lift_splat_backward": (_c_int, [_c_int] * 7 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_ptr]),
     "mmt_dcn_im2col": (_c_int, [_c_int] * 5 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_dcn_col2im": (_c_int, [_c_int] * 5 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr]),

@@ -32,6 +32,10 @@ struct VpArgs {
     int write_dropped;
     int nslot;    // LDS BEV rows per workgroup
     int nchunks;
+    // fused lift-splat (feats == nullptr): row(t) = depth[t] * context[pix(t), :]
+    const float *depth;    // [B*P] in point order (= [B*N, D, HW])
+    const float *context;  // [B*N, HW, C] channels-last
+    int DHW, HW;           // D*HW points per camera, HW pixels per camera
 };
 
 __device__ __forceinline__ bool in_grid(int x, int y, int z, int nx, int ny, int nz) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
 //     contiguous run of global fp32 atomics per touched cell.
 // The BEV tile of the chunk therefore lives in registers + a staging row; HBM sees
 // each kept feature row once and one atomic row per (chunk, cell).
-template <int C4T, int CHUNK>
+template <int C4T, int CHUNK, bool FUSED>
 __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     constexpr int HT = CHUNK * 2;             // hash entries (load factor <= 0.5)
     constexpr int HT_LOG2 = (CHUNK == 512) ? 10 : 11;
@@ -265,6 +269,9 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     __shared__ unsigned short sorted[CHUNK];
     __shared__ __align__(16) float stage[NW][256];
     __shared__ int nslots, next_slot;
+    // fused lift-splat: per point of the chunk its depth probability and its pixel's context row
+    __shared__ float pt_depth[FUSED ? CHUNK : 1];
+    __shared__ int pt_pix[FUSED ? CHUNK : 1];
 
     const int C = a.C;
     const int C4 = C4T > 0 ? C4T : C >> 2;
@@ -291,6 +298,12 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
         pm[k][0] = pm[k][1] = pm[k][2] = -1;
         if (lp < npts) {
             const int64_t t = base + lp;
+            if (FUSED) {
+                const unsigned cam = (unsigned)t / (unsigned)a.DHW;
+                const unsigned rem = (unsigned)t - cam * (unsigned)a.DHW;
+                pt_pix[lp] = (int)(cam * (unsigned)a.HW + rem % (unsigned)a.HW);
+                pt_depth[lp] = a.depth[t];
+            }
             const int x = a.geom[t * 3], y = a.geom[t * 3 + 1], z = a.geom[t * 3 + 2];
             if (in_grid(x, y, z, a.nx, a.ny, a.nz)) {
                 const int b = (int)((unsigned)t / (unsigned)a.P);
@@ -387,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     const int g = lane / C4;
     const int li = lane - g * C4;
     const bool active = g < G;
-    const float *fbase = a.feats + base * C + li * 4;
+    const float *fbase = FUSED ? a.context + li * 4 : a.feats + base * C + li * 4;
     float *st = stage[wave];
     for (;;) {
         int s = 0;
@@ -401,15 +414,30 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
             // issue all their loads before the first add instead of one load per trip.
             for (int j = beg + g; j < end; j += 4 * G) {
                 float4 v[4];
+                float dv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int jj = j + u * G;
                     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (jj < end) v[u] = *reinterpret_cast<const float4 *>(fbase + (int)sorted[jj] * C);
+                    dv[u] = 0.f;
+                    if (jj < end) {
+                        const int p = sorted[jj];
+                        if (FUSED) {
+                            dv[u] = pt_depth[p];
+                            v[u] = *reinterpret_cast<const float4 *>(fbase + (int64_t)pt_pix[p] * C);
+                        } else {
+                            v[u] = *reinterpret_cast<const float4 *>(fbase + p * C);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                    if (FUSED) {   // product rounded to fp32 first (= the materialised lift), then added
+                        acc.x += __fmul_rn(dv[u], v[u].x); acc.y += __fmul_rn(dv[u], v[u].y);
+                        acc.z += __fmul_rn(dv[u], v[u].z); acc.w += __fmul_rn(dv[u], v[u].w);
+                    } else {
+                        acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                    }
                 }
             }
             *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
@@ -834,6 +862,81 @@ __global__ __launch_bounds__(kBlock) void vp_to_channels_last(int C, int ny, int
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused lift-splat: voxel_pooling of features that are never
+// materialised,  row(t) = depth[t] * context[pix(t), :]  (lss_fpn.py:441-464 in one pass).
+// Forward = vp_fwd_seg_gather<.., FUSED=true> (the gather reads context rows, 5 MB and
+// L2-resident, instead of 364 MB of lifted rows).  Backward below is pixel-major and needs
+// no atomics:  grad_context[pix,:] = sum_d depth[t] * grad_out[cell(t),:]
+//              grad_depth[t]       = < grad_out[cell(t),:], context[pix,:] >
+// One lane group (C/4 lanes, a float4 column each) owns one pixel and walks its D depth
+// bins; grad_out rows are L2 gathers through a range-checked buffer descriptor (dropped
+// points read zeros), 4 bins in flight.
+template <int C4T>
+__global__ __launch_bounds__(kBlock) void lift_splat_backward_kernel(
+    int D, int HW, int C, const int32_t *pos_memo, const float *depth, const float *context,
+    const float *grad_out, int64_t sb, int64_t sy, int64_t sx, int64_t span_bytes,
+    float *grad_depth, float *grad_context) {
+    extern __shared__ __align__(16) float lds[];
+    const int C4 = C4T > 0 ? C4T : C >> 2;
+    const int G = 64 / C4;
+    const int NG = (kBlock / 64) * G;            // pixels per workgroup
+    float *gd = lds;                             // [D][NG] grad_depth accumulators
+    const int bn = blockIdx.y;
+    const int s0 = blockIdx.x * NG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / C4, li = lane - grp * C4;
+    const int j = wave * G + grp;
+    const bool active = grp < G && (s0 + j) < HW;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(grad_out), 0, (int)span_bytes, 0x00020000);
+    for (int i = tid; i < D * NG; i += kBlock) gd[i] = 0.f;
+    const int64_t pix = (int64_t)bn * HW + s0 + (active ? j : 0);
+    float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) cx = *reinterpret_cast<const float4 *>(context + pix * C + li * 4);
+    __syncthreads();
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t t0 = (int64_t)bn * D * HW + s0 + (active ? j : 0);   // point index of bin 0
+    for (int d0 = 0; d0 < D; d0 += 4) {
+        mmt_u32x4 v[4];
+        float dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u;
+            unsigned off = 0xFFFFFFF0u;
+            dv[u] = 0.f;
+            if (active && d < D) {
+                const int64_t t = t0 + (int64_t)d * HW;
+                const int b = pos_memo[t * 3];
+                const int y = pos_memo[t * 3 + 1], x = pos_memo[t * 3 + 2];
+                if (b != -1) off = ((unsigned)(b * sb + y * sy + x * sx) + li * 4) * 4u;
+                dv[u] = depth[t];
+            }
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u;
+            if (d < D) {
+                const float gx_ = __uint_as_float(v[u].x), gy_ = __uint_as_float(v[u].y);
+                const float gz_ = __uint_as_float(v[u].z), gw_ = __uint_as_float(v[u].w);
+                acc.x += gx_ * dv[u]; acc.y += gy_ * dv[u]; acc.z += gz_ * dv[u]; acc.w += gw_ * dv[u];
+                float dot = gx_ * cx.x + gy_ * cx.y + gz_ * cx.z + gw_ * cx.w;
+                dot += __shfl_xor(dot, 1);
+                dot += __shfl_xor(dot, 2);
+                if (active && (li & 3) == 0) atomicAdd(&gd[d * NG + j], dot);
+            }
+        }
+    }
+    if (active) *reinterpret_cast<float4 *>(grad_context + pix * C + li * 4) = acc;
+    __syncthreads();
+    for (int i = tid; i < D * NG; i += kBlock) {
+        const int d = i / NG, jj = i - d * NG;
+        if ((s0 + jj) < HW) grad_depth[((int64_t)bn * D + d) * HW + s0 + jj] = gd[i];
+    }
+}
+
 template <int VEC>
 int launch_lds_combine(const VpArgs &a, int grid, size_t lds, hipStream_t st) {
     if (VEC == 4) {
@@ -872,6 +975,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     a.geom = geom; a.feats = feats; a.out = out; a.pos_memo = pos_memo;
     a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
     a.nslot = 0; a.nchunks = 0;
+    a.depth = nullptr; a.context = nullptr; a.DHW = 1; a.HW = 1;
     // float4 paths need 16-byte aligned rows
     const bool vec4 = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0);
     const bool seg_ok = vec4 && C <= 256;
@@ -879,14 +983,16 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     if ((algo == MMT_VP_ALGO_SEG_GATHER || algo == MMT_VP_ALGO_STREAM) && !seg_ok) algo = MMT_VP_ALGO_LDS_ATOMIC;
 
     if (algo == MMT_VP_ALGO_SEG_GATHER) {
+        const bool fused = false;
         const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
         const int chunk = big ? 1024 : 512;
         const int64_t nchunks = mmt::ceil_div(BP, chunk);
         const dim3 grid((unsigned)nchunks), block(kBlock);
 #define MMT_LAUNCH_SEG(C4T)                                                                     \
     do {                                                                                        \
-        if (big) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 1024>), grid, block, 0, st, a);     \
-        else hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512>), grid, block, 0, st, a);          \
+        if (fused) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, true>), grid, block, 0, st, a);          \
+        else if (big) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 1024, false>), grid, block, 0, st, a);   \
+        else hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false>), grid, block, 0, st, a);               \
     } while (0)
         if (C == 80) MMT_LAUNCH_SEG(20);
         else if (C == 64) MMT_LAUNCH_SEG(16);
@@ -1007,4 +1113,69 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
     const int grid = mmt::stream_grid(BP * C, kBlock);
     hipLaunchKernelGGL(vp_bwd_strided, dim3(grid), dim3(kBlock), 0, st, a);
     return mmt::check_launch("voxel_pooling_backward(strided)");
+}
+
+extern "C" int mmt_lift_splat_forward(int B, int N, int D, int HW, int C, int nx, int ny, int nz,
+                                      const int32_t *geom, const float *depth, const float *context,
+                                      float *out, int32_t *pos_memo, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    MMT_REQUIRE_PTR(pos_memo);
+    if (B <= 0 || N <= 0 || D <= 0 || HW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_forward: non-positive size");
+    if (C % 4 != 0 || C > 256 || (((uintptr_t)context & 15) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_forward: needs C %% 4 == 0, C <= 256 and a 16-byte aligned context");
+    const int64_t P = (int64_t)N * D * HW, BP = (int64_t)B * P;
+    if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31) || (int64_t)B * N * HW * C >= (1ll << 31))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "lift_splat_forward: index range exceeds int32");
+    if (flags & ~MMT_VP_WRITE_DROPPED) return mmt::fail(MMT_ERR_BAD_FLAG, "lift_splat_forward: unknown flag bits 0x%x", flags);
+    VpArgs a;
+    a.BP = BP; a.P = (int)P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
+    a.geom = geom; a.feats = nullptr; a.out = out; a.pos_memo = pos_memo;
+    a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
+    a.nslot = 0; a.nchunks = 0;
+    a.depth = depth; a.context = context; a.DHW = D * HW; a.HW = HW;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)mmt::ceil_div(BP, 512)), block(kBlock);
+    if (C == 80) hipLaunchKernelGGL((vp_fwd_seg_gather<20, 512, true>), grid, block, 0, st, a);
+    else if (C == 64) hipLaunchKernelGGL((vp_fwd_seg_gather<16, 512, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((vp_fwd_seg_gather<0, 512, true>), grid, block, 0, st, a);
+    return mmt::check_launch("lift_splat_forward");
+}
+
+extern "C" int mmt_lift_splat_backward(int B, int N, int D, int HW, int C, int nx, int ny,
+                                       const int32_t *pos_memo, const float *depth,
+                                       const float *context, const float *grad_out, int64_t sb,
+                                       int64_t sc, int64_t sy, int64_t sx, float *grad_depth,
+                                       float *grad_context, void *stream) {
+    MMT_REQUIRE_PTR(pos_memo);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    if (B <= 0 || N <= 0 || D <= 0 || HW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || B * N > 65535)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_backward: bad sizes");
+    if (C % 16 != 0 || C > 256)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_backward: needs C %% 16 == 0 and C <= 256");
+    const int64_t span = (B - 1) * sb + (ny - 1) * sy + (nx - 1) * sx + C;
+    if (sc != 1 || sb % 4 || sy % 4 || sx % 4 || sb < 0 || sy < 0 || sx < 0 || span >= (1ll << 29) ||
+        (((uintptr_t)grad_out | (uintptr_t)context | (uintptr_t)grad_context) & 15) != 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_backward: grad_out must be channels-last (stride_c == 1), 16-byte aligned");
+    if ((int64_t)B * N * D * HW >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_splat_backward: B*P exceeds int32");
+    const int C4 = C / 4;
+    const int NG = (kBlock / 64) * (64 / C4);
+    const size_t lds = (size_t)D * NG * 4;
+    if (lds > 64 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_splat_backward: D too large for the LDS tile");
+    dim3 grid((unsigned)mmt::ceil_div(HW, NG), (unsigned)(B * N));
+    hipStream_t st = (hipStream_t)stream;
+    // pos_memo's batch index b is the SAMPLE index; cameras of one sample share it
+#define MMT_LSB(C4T) hipLaunchKernelGGL((lift_splat_backward_kernel<C4T>), grid, dim3(kBlock), lds, st, D, HW, C, pos_memo, depth, context, grad_out, sb, sy, sx, span * 4, grad_depth, grad_context)
+    if (C == 80) MMT_LSB(20);
+    else if (C == 64) MMT_LSB(16);
+    else MMT_LSB(0);
+#undef MMT_LSB
+    return mmt::check_launch("lift_splat_backward");
 }

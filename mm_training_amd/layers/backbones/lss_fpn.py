@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ...ops.bev_geometry import frustum_geometry, lift_features
+from ...ops.bev_geometry import frustum_geometry, lift_features, lift_splat
 from ...ops.voxel_pooling import voxel_pooling
 from ..nets import BasicBlock, DeformConv2dPack, ResNet, SECONDFPN
 
@@ -106,6 +106,11 @@ class LSSFPN(nn.Module):
         self.d_bound = d_bound
         self.final_dim = final_dim
         self.output_channels = output_channels
+        # False (default): the reference's op sequence (lift -> voxel_pooling) on the drop-in ops.
+        # True: lift + voxel_pooling run as ONE fused kernel pair (the
+        # [B,N,D,fH,fW,C] tensor of lss_fpn.py:441-463 is never materialised; needs C % 16 == 0).
+        # Same result up to fp32 summation order.
+        self.fused_lift_splat = False
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
         self.register_buffer('voxel_size', torch.Tensor([row[2] for row in rows]))
@@ -172,13 +177,16 @@ class LSSFPN(nn.Module):
         else:
             depth_used = depth
         context = depth_feature[:, self.depth_channels:self.depth_channels + self.output_channels]
-        # lift straight into [B, N, D, fH, fW, C]
-        feats = lift_features(depth_used.float(), context.float())
-        feats = feats.view(batch_size, num_cams, *feats.shape[1:])
         geom_xyz = self.get_geometry_voxels(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
                                             mats_dict['intrin_mats'][:, sweep_index, ...],
                                             mats_dict.get('bda_mat', None))
-        feature_map = voxel_pooling(geom_xyz, feats, self._voxel_num_host)
+        if self.fused_lift_splat:
+            feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host)
+        else:
+            # lift straight into [B, N, D, fH, fW, C], then the drop-in voxel_pooling
+            feats = lift_features(depth_used.float(), context.float())
+            feats = feats.view(batch_size, num_cams, *feats.shape[1:])
+            feature_map = voxel_pooling(geom_xyz, feats, self._voxel_num_host)
         # the reference's `.contiguous()` (:467) would transpose to NCHW; the pooled map is
         # already a dense channels_last tensor, which the BEV convs consume directly
         if is_return_depth:

@@ -97,3 +97,52 @@ class LiftFeatures(Function):
 
 def lift_features(depth, context):
     return LiftFeatures.apply(depth.contiguous(), context.contiguous())
+
+
+class LiftSplat(Function):
+    """Fused lift + voxel_pooling (lss_fpn.py:441-464 in one pass): the
+    [B, N, D, fH, fW, C] feature tensor is never materialised.  Additional entry point beside
+    the drop-in ``voxel_pooling``; same result up to fp32 summation order."""
+
+    @staticmethod
+    def forward(ctx, geom_xyz, depth, context, voxel_num):
+        _need_cuda(geom_xyz, "geom_xyz", torch.int32)
+        B, N, D, fH, fW = geom_xyz.shape[:5]
+        BN, HW, C = B * N, fH * fW, context.shape[1]
+        if tuple(depth.shape) != (BN, D, fH, fW) or tuple(context.shape) != (BN, C, fH, fW):
+            raise RuntimeError("lift_splat: depth must be [B*N, D, fH, fW] and context [B*N, C, fH, fW]")
+        if not (depth.is_cuda and context.is_cuda):
+            raise RuntimeError("depth / context must be a CUDAtensor ")
+        depth_c = depth.float().contiguous()                               # point order [BN, D, HW]
+        ctx_nhwc = context.float().permute(0, 2, 3, 1).contiguous()        # free for channels_last nets
+        nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
+        out = torch.zeros((B, ny, nx, C), dtype=torch.float32, device=depth.device)
+        pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
+        with torch.cuda.device(depth.device):
+            _lib.call("mmt_lift_splat_forward", B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(),
+                      depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), pos_memo.data_ptr(),
+                      _lib.VP_WRITE_DROPPED, _stream())
+        ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
+        ctx.dims = (B, N, D, HW, C, nx, ny)
+        ctx.mark_non_differentiable(geom_xyz) if geom_xyz.requires_grad else None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pos_memo, depth_c, ctx_nhwc = ctx.saved_tensors
+        B, N, D, HW, C, nx, ny = ctx.dims
+        if grad_out.stride(1) != 1 or grad_out.dtype != torch.float32:
+            grad_out = grad_out.float().contiguous(memory_format=torch.channels_last)
+        sb, sc, sy, sx = grad_out.stride()
+        grad_depth = torch.empty_like(depth_c)
+        grad_ctx = torch.empty_like(ctx_nhwc)
+        with torch.cuda.device(depth_c.device):
+            _lib.call("mmt_lift_splat_backward", B, N, D, HW, C, nx, ny, pos_memo.data_ptr(),
+                      depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
+                      grad_depth.data_ptr(), grad_ctx.data_ptr(), _stream())
+        return None, grad_depth, grad_ctx.permute(0, 3, 1, 2), None
+
+
+def lift_splat(geom_xyz, depth, context, voxel_num):
+    """geom int32 [B,N,D,fH,fW,3], depth [B*N,D,fH,fW], context [B*N,C,fH,fW] -> BEV [B,C,ny,nx]."""
+    return LiftSplat.apply(geom_xyz.contiguous(), depth, context, voxel_num)

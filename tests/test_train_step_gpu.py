@@ -54,13 +54,14 @@ def test_bevdepth_lidar_forward_contract(mmt_lib):
     assert depth_pred.shape[1] == model.backbone.depth_channels
 
 
-@pytest.mark.parametrize("name", ["tiny"])
-def test_training_step_decreases_loss(mmt_lib, name):
+@pytest.mark.parametrize("fused", [False, True])
+def test_training_step_decreases_loss(mmt_lib, fused):
     from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
-    cfg = make_config(name)
+    cfg = make_config("tiny")
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     ts = TrainStep(cfg, dev, lr=2e-4)
+    ts.model.backbone.fused_lift_splat = fused
     batch = synthetic_batch(cfg, dev, seed=3)
     before = {n: p.detach().clone() for n, p in list(ts.model.named_parameters())[:5]}
     losses = [float(ts(batch)[0]) for _ in range(6)]

@@ -72,6 +72,27 @@ def main():
     go = torch.randn_like(out)
     ms = timeit(lambda: torch.autograd.grad(out, (depth, ctx), go, retain_graph=True))
     res["lift_backward"] = {"ms": ms, "GBps": lb / ms / 1e6}
+    # fused lift-splat (row f1) vs the unfused pair at cfg2
+    from mm_training_amd.ops.bev_geometry import lift_splat
+    from mm_training_amd.ops.voxel_pooling import voxel_pooling
+    geom6, vn = synthetic.rig_geometry(4)
+    geom6 = geom6.cuda()
+    ctx_cl = ctx.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    dep = depth.detach().requires_grad_(True)
+    ms = timeit(lambda: lift_splat(geom6, dep, ctx_cl, vn))
+    res["fused_lift_splat_forward"] = {"ms": ms}
+    o = lift_splat(geom6, dep, ctx_cl, vn)
+    go2 = torch.randn(4, 128, 128, 80, device="cuda").permute(0, 3, 1, 2)
+    ms = timeit(lambda: torch.autograd.grad(o, (dep, ctx_cl), go2, retain_graph=True))
+    res["fused_lift_splat_backward"] = {"ms": ms}
+    def unfused():
+        f = lift_features(dep, ctx_cl).view(4, 6, 112, 16, 44, 80)
+        return voxel_pooling(geom6, f, vn)
+    ms = timeit(unfused)
+    res["unfused_lift_plus_pool_forward"] = {"ms": ms}
+    o2 = unfused()
+    ms = timeit(lambda: torch.autograd.grad(o2, (dep, ctx_cl), go2, retain_graph=True))
+    res["unfused_lift_plus_pool_backward"] = {"ms": ms}
     # CPU baseline beside it: the oracle's sequential C restatement (1 core) on the same frames
     import time
     import oracle
