@@ -75,10 +75,17 @@ class TrainStep(nn.Module):
                 m.to(memory_format=torch.channels_last)
         self.net = self.model
         if world_size > 1:
-            # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183)
+            # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183; the
+            # reference survives on Lightning's find_unused_parameters=True, which walks the autograd
+            # graph on the host every step).  Tell the reducer to ignore exactly those instead: the
+            # graph is then static and every bucket's all-reduce (RCCL, on its own stream) starts as
+            # soon as its last gradient is produced.
+            unused = [n for n, _ in self.model.named_parameters() if ".context_se." in n]
+            nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(self.model, unused)
             self.net = nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[device.index] if device.type == "cuda" else None,
-                bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, find_unused_parameters=True)
+                bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, find_unused_parameters=False,
+                static_graph=True)
         bs = cfg["batch_size"]
         self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr or 1e-3 / 64 * bs, weight_decay=1e-7,
                                            fused=(device.type == "cuda"))
