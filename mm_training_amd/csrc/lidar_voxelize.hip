@@ -233,34 +233,49 @@ __global__ __launch_bounds__(256) void scatter_map_kernel(int64_t M, int B, int 
     }
 }
 
-// canvas[b,c,y,x] written exactly once, 16 bytes per lane along x; empty cells (the
-// vast majority) cost one int4 map read per 4 outputs and no feature read.
+// canvas[b,c,y,x] written exactly once, 16 bytes per lane along x.  A lane owns 4 consecutive
+// cells for a block of kChanBlock channels: the 16-byte slice of the cell->row map is read once
+// per channel block (not once per channel) and the stores of a wave stay within kChanBlock
+// DRAM pages.  Empty cells -- the vast majority -- never touch the feature matrix; the canvas
+// memset is folded into the same pass.
+constexpr int kChanBlock = 4;
+
 template <bool VEC4>
 __global__ __launch_bounds__(256) void scatter_write_kernel(int C, int B, int HW, const float *feats,
                                                             const int32_t *map, float *canvas) {
     const int XV = VEC4 ? 4 : 1;
-    const int64_t per_b = (int64_t)C * (HW / XV);
+    const int per_c = HW / XV;
+    const int cblocks = (C + kChanBlock - 1) / kChanBlock;
+    const int64_t per_b = (int64_t)cblocks * per_c;
     const int64_t total = (int64_t)B * per_b;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int b = (int)(i / per_b);
         const int64_t r = i - b * per_b;
-        const int c = (int)(r / (HW / XV));
-        const int s = (int)(r - (int64_t)c * (HW / XV)) * XV;
+        const int cb = (int)(r / per_c);
+        const int s = (int)(r - (int64_t)cb * per_c) * XV;
+        const int c0 = cb * kChanBlock;
         const int32_t *mp = map + (int64_t)b * HW + s;
-        float *dst = canvas + ((int64_t)b * C + c) * HW + s;
+        float *dst = canvas + ((int64_t)b * C + c0) * HW + s;
         if (VEC4) {
             const int4 m4 = *reinterpret_cast<const int4 *>(mp);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((m4.x & m4.y & m4.z & m4.w) != -1) {
-                if (m4.x >= 0) v.x = feats[(int64_t)m4.x * C + c];
-                if (m4.y >= 0) v.y = feats[(int64_t)m4.y * C + c];
-                if (m4.z >= 0) v.z = feats[(int64_t)m4.z * C + c];
-                if (m4.w >= 0) v.w = feats[(int64_t)m4.w * C + c];
+            const bool empty = (m4.x & m4.y & m4.z & m4.w) == -1;
+#pragma unroll
+            for (int k = 0; k < kChanBlock; ++k) {
+                const int c = c0 + k;
+                if (c >= C) break;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!empty) {
+                    if (m4.x >= 0) v.x = feats[(int64_t)m4.x * C + c];
+                    if (m4.y >= 0) v.y = feats[(int64_t)m4.y * C + c];
+                    if (m4.z >= 0) v.z = feats[(int64_t)m4.z * C + c];
+                    if (m4.w >= 0) v.w = feats[(int64_t)m4.w * C + c];
+                }
+                mmt_nt_store4(v, reinterpret_cast<float4 *>(dst + (int64_t)k * HW));
             }
-            mmt_nt_store4(v, reinterpret_cast<float4 *>(dst));
         } else {
             const int m = mp[0];
-            dst[0] = m >= 0 ? feats[(int64_t)m * C + c] : 0.f;
+            for (int k = 0; k < kChanBlock && c0 + k < C; ++k)
+                dst[(int64_t)k * HW] = m >= 0 ? feats[(int64_t)m * C + c0 + k] : 0.f;
         }
     }
 }
@@ -395,7 +410,7 @@ extern "C" int mmt_pillar_scatter(int64_t M, int C, int B, int ny, int nx, const
     if (M > 0)
         hipLaunchKernelGGL(scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
     const bool vec4 = (HW % 4 == 0) && (((uintptr_t)canvas & 15) == 0) && (((uintptr_t)workspace & 15) == 0);
-    const int64_t work = (int64_t)B * C * (vec4 ? HW / 4 : HW);
+    const int64_t work = (int64_t)B * ((C + kChanBlock - 1) / kChanBlock) * (vec4 ? HW / 4 : HW);
     if (vec4) hipLaunchKernelGGL((scatter_write_kernel<true>), dim3(mmt::stream_grid(work, 256, 256 * 32)), dim3(256), 0, st, C, B, (int)HW, feats, workspace, canvas);
     else hipLaunchKernelGGL((scatter_write_kernel<false>), dim3(mmt::stream_grid(work, 256, 256 * 32)), dim3(256), 0, st, C, B, (int)HW, feats, workspace, canvas);
     return mmt::check_launch("pillar_scatter");

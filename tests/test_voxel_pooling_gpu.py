@@ -185,3 +185,36 @@ def test_linearity_and_determinism_of_index_path(mmt_lib):
     o2 = voxel_pooling(geom, f2, vn)
     o12 = voxel_pooling(geom, f1 + 2 * f2, vn)
     assert (o12 - (o1 + 2 * o2)).abs().max().item() <= 2 * ATOL
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_shapes_all_algorithms(mmt_lib, oracle_mod, seed):
+    """Random (B, P, C, grid) incl. the fallback paths: C % 4 != 0, C > 256, nz > 1, P < chunk,
+    P straddling chunk and batch boundaries; every forward algorithm + both backward paths."""
+    from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext
+    rng = np.random.default_rng(100 + seed)
+    B = int(rng.integers(1, 4))
+    P = int(rng.choice([1, 63, 511, 512, 513, 1000, 2049, 5000]))
+    C = int(rng.choice([1, 4, 12, 20, 64, 80, 96, 256, 260, 512]))
+    nx, ny, nz = int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 3))
+    geom = np.stack([rng.integers(-2, nx + 2, (B, P)), rng.integers(-2, ny + 2, (B, P)),
+                     rng.integers(-1, nz + 1, (B, P))], -1).astype(np.int32)
+    if seed % 3 == 0:   # hot cell
+        geom[:, : P // 2] = [min(1, nx - 1), min(2, ny - 1), 0]
+    feats = (rng.random((B, P, C), dtype=np.float32) - 0.5)
+    ref, ref_pos = oracle_mod.voxel_pooling_forward(geom, feats, nx, ny, nz)
+    ref64 = oracle_mod.voxel_pooling_forward_f64(geom, feats, nx, ny, nz)
+    g, f = _dev(geom), _dev(feats)
+    for algo in (0, 1, 2, 3, 4, 0x23):
+        out, pos = _run_ext(mmt_lib, g, f, nx, ny, nz, algo)
+        assert torch.equal(pos.cpu(), torch.from_numpy(ref_pos)), (algo, "pos_memo")
+        assert np.abs(out.cpu().numpy() - ref64).max() <= ATOL, algo
+    go = rng.standard_normal((B, C, ny, nx)).astype(np.float32)
+    ref_gi = oracle_mod.voxel_pooling_backward(ref_pos, go)
+    pos_d = _dev(ref_pos)
+    full = voxel_pooling_ext.backward_workspace_elems(B, P, C, nx, ny)
+    for grad in (_dev(go), _dev(go).contiguous(memory_format=torch.channels_last)):
+        for ws in (None, torch.empty(full, device="cuda")):
+            gi = torch.empty(B, P, C, device="cuda")
+            voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos_d, grad, gi, ws)
+            assert np.array_equal(gi.cpu().numpy(), ref_gi)
