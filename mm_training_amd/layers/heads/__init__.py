@@ -1,3 +1,6 @@
-from .bev_depth_head import BEVDepthHead
+"""Detection head namespace (mirror of the reference's ``layers.heads``)."""
+from . import bev_depth_head as _head
 
-__all__ = ['BEVDepthHead']
+BEVDepthHead = _head.BEVDepthHead
+
+__all__ = ("BEVDepthHead",)

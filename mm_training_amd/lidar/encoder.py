@@ -118,7 +118,6 @@ class _PillarScatter(Function):
                       coors.data_ptr() if M else 0, canvas.data_ptr(), cell_map.data_ptr(), _stream())
         ctx.save_for_backward(coors, cell_map)
         ctx.dims = (M, C, batch_size, ny, nx)
-        ctx.mark_non_differentiable(cell_map)
         return canvas
 
     @staticmethod

@@ -124,7 +124,6 @@ class LiftSplat(Function):
                       _lib.VP_WRITE_DROPPED, _stream())
         ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
         ctx.dims = (B, N, D, HW, C, nx, ny)
-        ctx.mark_non_differentiable(geom_xyz) if geom_xyz.requires_grad else None
         return out.permute(0, 3, 1, 2)
 
     @staticmethod

@@ -1,4 +1,9 @@
-"""Drop-in for the reference package ops/voxel_pooling (ops/voxel_pooling/__init__.py:1-3)."""
-from .voxel_pooling import voxel_pooling
+"""HIP-backed replacement for the reference package ``ops.voxel_pooling``: the public name
+is the autograd op ``voxel_pooling(geom_xyz, input_features, voxel_num)``; the extension
+module lives next to it as ``voxel_pooling_ext`` (a ctypes binding of libmmt_hip.so)."""
+from . import voxel_pooling as _op
+from . import voxel_pooling_ext  # noqa: F401  (importable like the reference's pybind module)
 
-__all__ = ['voxel_pooling']
+voxel_pooling = _op.voxel_pooling
+
+__all__ = ("voxel_pooling", "voxel_pooling_ext")

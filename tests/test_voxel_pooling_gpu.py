@@ -128,7 +128,9 @@ def test_error_behaviour(mmt_lib):
 SHAPES = {
     # name: (B, N, D, fH, fW, C)  -- SURVEY.md section 8 shape table
     "cfg1_literal": (1, 6, 118, 32, 1, 64),
+    "cfg1_full": (1, 6, 118, 32, 88, 64),
     "cfg2": (4, 6, 112, 16, 44, 80),
+    "cfg5": (2, 6, 112, 32, 88, 80),
 }
 
 
@@ -139,7 +141,7 @@ def test_full_size_against_oracle(mmt_lib, oracle_mod, name, geometry):
     from mm_training_amd.ops.voxel_pooling import voxel_pooling
     B, N, D, fH, fW, C = SHAPES[name]
     if geometry == "rig":
-        ds = 16 if fW == 44 else 8
+        ds = 16 if D == 112 else 8
         final = (fH * ds, max(fW * ds, ds))
         d_bound = (2.0, 58.0, 0.5) if D == 112 else (1.0, 60.0, 0.5)
         geom, vn = synthetic.rig_geometry(B, N, final, ds, d_bound)
