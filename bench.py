@@ -18,6 +18,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def use_shipped_miopen_db():
+    """MIOpen's per-shape solver choice for the dense nets: the repo ships the user find/perf
+    DB produced by one exhaustive search on an MI355X (mm_training_amd/miopen_db, ~100 KB of
+    text).  Each process works on a private copy (MIOpen rewrites the files), so a fresh box gets
+    the tuned solvers without the ~4 min search.  Must run before the first convolution."""
+    src = os.path.join(ROOT, "mm_training_amd", "miopen_db")
+    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src):
+        return False
+    import shutil
+    import tempfile
+    dst = tempfile.mkdtemp(prefix="mmt_miopen_db_")
+    for f in os.listdir(src):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return True
+
+
+SHIPPED_MIOPEN_DB = use_shipped_miopen_db()
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -148,7 +168,9 @@ def train_main(args, rank, local_rank, world):
     from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
     from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext
     _lib.lib()
-    torch.backends.cudnn.benchmark = bool(args.miopen_tune)
+    # benchmark=True makes PyTorch ask MIOpen's find API, which is answered from the find DB
+    # (only for the configuration the DB was produced on: an unknown shape would start a search)
+    torch.backends.cudnn.benchmark = bool(args.miopen_tune) or (SHIPPED_MIOPEN_DB and args.config == "cfg2")
     dev = torch.device("cuda", local_rank)
     cfg = make_config(args.config)
     torch.manual_seed(0)
@@ -191,6 +213,7 @@ def train_main(args, rank, local_rank, world):
             "global_batch": world * B, "parallelism": f"dp{world}", "mode": "train",
             "params_M": sum(p.numel() for p in ts.model.parameters()) / 1e6,
             "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune),
+            "miopen_shipped_find_db": bool(SHIPPED_MIOPEN_DB and args.config == "cfg2"),
             "fused_lift_splat": bool(args.fused_lift_splat)},
     }
     if cfg["use_cam"] and timing.get("forward"):

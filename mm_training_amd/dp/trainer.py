@@ -11,6 +11,7 @@ Host-side changes against the reference, none of which alter the arithmetic cont
   * no .item() / boolean-mask host syncs in the loss (see bev_depth_head.py mirror).
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -70,9 +71,10 @@ class TrainStep(nn.Module):
                                    use_cam=self.use_cam, use_lidar=self.use_lidar,
                                    fuse_layer_in_channels=cfg["fuse_layer_in_channels"]).to(device)
         # dense convs consume / produce channels_last: the pooled BEV map already is
-        for m in self.model.modules():
-            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
-                m.to(memory_format=torch.channels_last)
+        if os.environ.get("MMT_MEMORY_FORMAT", "channels_last") == "channels_last":
+            for m in self.model.modules():
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                    m.to(memory_format=torch.channels_last)
         self.net = self.model
         if world_size > 1:
             # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183; the
