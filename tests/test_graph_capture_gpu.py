@@ -1,0 +1,127 @@
+"""GPU: the C ABI's promise (include/mmt_hip.h) that every entry point is asynchronous on the
+given stream, never synchronises and never allocates -- i.e. is hipGraph-capturable.  The whole
+camera hot path (geometry -> lift -> pool fwd -> pool bwd -> lift bwd) and the LiDAR chain
+(voxelize -> VFE -> scatter) are captured once and replayed on new input data."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hot_path_replays_from_a_hip_graph(mmt_lib, oracle_mod):
+    from mm_training_amd import _lib, synthetic
+    L = _lib
+    dev = torch.device("cuda", 0)
+    B, N, D, fH, fW, C = 2, 6, 28, 16, 44, 80
+    nx, ny, nz = 128, 128, 1
+    HW, P = fH * fW, N * D * fH * fW
+    s2e, K = synthetic.camera_rig(B, N, 704, 256, jitter=0.02)
+    combine = (s2e @ torch.inverse(K)).to(dev)
+    d = torch.arange(2.0, 58.0, 2.0).view(-1, 1, 1).expand(-1, fH, fW)
+    xs = torch.linspace(0, 703, fW).view(1, 1, fW).expand(D, fH, fW)
+    ys = torch.linspace(0, 255, fH).view(1, fH, 1).expand(D, fH, fW)
+    frustum = torch.stack((xs, ys, d, torch.ones_like(d)), -1).contiguous().to(dev)
+    vc, vs = L.float3([-50.8, -50.8, -1.0]), L.float3([0.8, 0.8, 8.0])
+    depth = torch.empty(B * N, D, fH, fW, device=dev)
+    ctx = torch.empty(B * N, C, fH, fW, device=dev)
+    grad_out = torch.empty(B, ny, nx, C, device=dev)                    # channels-last storage
+    geom = torch.empty(B, P, 3, dtype=torch.int32, device=dev)
+    feats = torch.empty(B, P, C, device=dev)
+    out = torch.empty(B, ny, nx, C, device=dev)
+    pos = torch.empty(B, P, 3, dtype=torch.int32, device=dev)
+    grad_feats = torch.empty(B, P, C, device=dev)
+    ws = torch.empty(L.lib().mmt_voxel_pooling_backward_workspace_elems(B, P, C, nx, ny), device=dev)
+    g_depth, g_ctx = torch.empty_like(depth), torch.empty_like(ctx)
+
+    def launch():
+        st = torch.cuda.current_stream().cuda_stream
+        L.call("mmt_frustum_geometry", B * N, D * HW, frustum.data_ptr(), combine.data_ptr(), vc, vs, geom.data_ptr(), 0, st)
+        L.call("mmt_lift_features", B * N, D, HW, C, depth.data_ptr(), ctx.data_ptr(), feats.data_ptr(), st)
+        out.zero_()
+        L.call("mmt_voxel_pooling_forward_ex", B, P, C, nx, ny, nz, geom.data_ptr(), feats.data_ptr(), out.data_ptr(),
+               pos.data_ptr(), L.VP_WRITE_DROPPED, st)
+        L.call("mmt_voxel_pooling_backward", B, P, C, nx, ny, pos.data_ptr(), grad_out.data_ptr(), ny * nx * C, 1, nx * C, C,
+               grad_feats.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        L.call("mmt_lift_features_backward", B * N, D, HW, C, depth.data_ptr(), ctx.data_ptr(), grad_feats.data_ptr(),
+               g_depth.data_ptr(), g_ctx.data_ptr(), st)
+
+    def fill(seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        depth.copy_(torch.rand(depth.shape, generator=g).softmax(1))
+        ctx.copy_(torch.randn(ctx.shape, generator=g))
+        grad_out.copy_(torch.randn(grad_out.shape, generator=g))
+
+    fill(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch()
+    for seed in (1, 2):
+        fill(seed)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (out.clone(), g_depth.clone(), g_ctx.clone(), pos.clone())
+        launch()                                                         # eager on the same inputs
+        torch.cuda.synchronize()
+        assert torch.equal(got[3], pos)
+        assert (got[0] - out).abs().max().item() <= 1e-4                 # atomics: summation order only
+        assert torch.equal(got[1], g_depth) and torch.equal(got[2], g_ctx)
+    # and the replayed result is the right one
+    ref, ref_pos = oracle_mod.voxel_pooling_forward(geom.cpu().numpy(), feats.cpu().numpy(), nx, ny, nz)
+    assert np.array_equal(pos.cpu().numpy(), ref_pos)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-4
+
+
+def test_lidar_chain_replays_from_a_hip_graph(mmt_lib, oracle_mod):
+    from mm_training_amd import _lib, synthetic
+    L = _lib
+    dev = torch.device("cuda", 0)
+    rng, vsz = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.2, 0.2, 8.0]
+    B, Npts, F, T, V, Cf = 2, 20000, 5, 15, 25000, 5
+    grid = L.int3([512, 512, 1])
+    points = torch.empty(B * Npts, F, device=dev)
+    offsets = torch.tensor([0, Npts, 2 * Npts], dtype=torch.int32, device=dev)
+    voxels = torch.empty(B * V, T, F, device=dev)
+    coors = torch.empty(B * V, 4, dtype=torch.int32, device=dev)
+    num = torch.empty(B * V, dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    wsv = torch.empty(L.lib().mmt_voxelize_workspace_elems(B, B * Npts, grid), dtype=torch.int32, device=dev)
+    mean = torch.empty(B * V, Cf, device=dev)
+    canvas = torch.empty(B, Cf, 512, 512, device=dev)
+    cmap = torch.empty(B * 512 * 512, dtype=torch.int32, device=dev)
+
+    def launch():
+        st = torch.cuda.current_stream().cuda_stream
+        L.call("mmt_hard_voxelize", B, B * Npts, F, points.data_ptr(), offsets.data_ptr(), L.float3(vsz), L.float3(rng[:3]),
+               grid, T, V, voxels.data_ptr(), coors.data_ptr(), num.data_ptr(), cnt.data_ptr(), wsv.data_ptr(), st)
+        L.call("mmt_simple_vfe", B * V, T, F, Cf, voxels.data_ptr(), num.data_ptr(), mean.data_ptr(), st)
+        L.call("mmt_pillar_scatter", B * V, Cf, B, 512, 512, mean.data_ptr(), coors.data_ptr(), canvas.data_ptr(), cmap.data_ptr(), st)
+
+    def fill(seed):
+        fr = [synthetic.lidar_frame(Npts, F, rng, seed=seed + i) for i in range(B)]
+        points.copy_(torch.cat(fr, 0))
+        return fr
+
+    fill(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch()
+    frames = fill(7)
+    graph.replay()
+    torch.cuda.synchronize()
+    rv, rn, rc = oracle_mod.voxelize_batch([f.numpy() for f in frames], vsz, rng, T, V)
+    ref = oracle_mod.pillar_scatter(oracle_mod.simple_vfe(rv, rn, Cf), rc, B, 512, 512)
+    assert int(cnt.sum()) == rc.shape[0]
+    assert np.allclose(canvas.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
