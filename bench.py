@@ -33,6 +33,9 @@ def use_shipped_miopen_db():
     for f in os.listdir(src):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     os.environ["MIOPEN_USER_DB_PATH"] = dst
+    # FAST find mode: a find-DB hit returns the tuned solver, a miss falls back to MIOpen's
+    # immediate-mode heuristic instead of starting a minutes-long search inside the benchmark
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     return True
 
 
