@@ -63,6 +63,9 @@ def main():
     ms = timeit(lambda: frustum_geometry(frustum, combine, vc, vsz))
     BP = 4 * 6 * 112 * 16 * 44
     res["frustum_geometry"] = {"ms": ms, "GBps": (12 * BP + 16 * 112 * 16 * 44) / ms / 1e6}
+    xyz_dev = torch.randn(BP, 3, device="cuda") * 40
+    ms = timeit(lambda: quantize_geometry(xyz_dev, vc, vsz))
+    res["quantize_geometry"] = {"ms": ms, "GBps": 24 * BP / ms / 1e6}
     depth = torch.rand(24, 112, 16, 44, device="cuda").softmax(1).requires_grad_(True)
     ctx = torch.randn(24, 80, 16, 44, device="cuda", requires_grad=True)
     ms = timeit(lambda: lift_features(depth, ctx))
@@ -106,9 +109,20 @@ def main():
     t0 = time.perf_counter()
     oracle.pillar_scatter(feats.cpu().numpy()[:rc.shape[0]], rc, B, ny, nx)
     t_sc = time.perf_counter() - t0
-    res["cpu_baseline_oracle_1core_ms"] = {"voxelize": t_vox * 1e3, "simple_vfe": t_vfe * 1e3, "pillar_scatter": t_sc * 1e3}
+    t0 = time.perf_counter()
+    oracle.quantize(xyz_dev.cpu().numpy(), vc, vsz)
+    t_q = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.geometry(frustum.cpu().numpy(), combine.cpu().numpy())
+    t_g = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.lift(depth.detach().cpu().numpy(), ctx.detach().cpu().numpy())
+    t_l = time.perf_counter() - t0
+    res["cpu_baseline_oracle_1core_ms"] = {"voxelize": t_vox * 1e3, "simple_vfe": t_vfe * 1e3, "pillar_scatter": t_sc * 1e3,
+                                           "quantize_geometry": t_q * 1e3, "frustum_geometry_no_quantize": t_g * 1e3,
+                                           "lift_forward": t_l * 1e3}
     res["hbm_peak_GBps"] = 8000.0
-    for k in ("voxelize_fixed_capacity", "simple_vfe", "pillar_scatter", "lift_forward", "lift_backward", "frustum_geometry"):
+    for k in ("voxelize_fixed_capacity", "simple_vfe", "pillar_scatter", "lift_forward", "lift_backward", "frustum_geometry", "quantize_geometry"):
         res[k]["frac_of_peak"] = res[k]["GBps"] / 8000.0
     print(json.dumps(res, indent=1))
 
