@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One rank per GPU; pure data parallel over the batch axis ("weak" scaling: per-GPU
-batch is fixed).  A step = one pass of the hot path over one batch of synthetic
-input resident in HBM (see DESIGN.md "Measurement").  Rank 0 prints ONE JSON line.
+batch is fixed).  Default (--mode train): a step = one full training step of BASELINE.json
+configs[1] (camera-only BEVDepth, bs=4/GPU) on synthetic frames resident in HBM; the
+voxel_pooling kernels inside the step are timed with HIP events for the roofline lines.
+--mode hotpath times only voxel_pooling forward+backward.  See DESIGN.md "Measurement".
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
