@@ -73,9 +73,9 @@ __global__ __launch_bounds__(kBlock) void frustum_geometry_kernel(int64_t S, con
 // contiguous kTile*C*4-byte block of the channels-last output with 16-byte
 // non-temporal stores.
 constexpr int kTile = 64;
-constexpr int kDRange = 16;
+constexpr int kDRange = 4;
 
-template <bool VEC4>
+template <bool VEC4, int C4T>
 __global__ __launch_bounds__(kBlock) void lift_kernel(int D, int HW, int C, const float *depth,
                                                       const float *context, float *feats) {
     extern __shared__ __align__(16) float lds[];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void lift_kernel(int D, int HW, int C, cons
     __syncthreads();
 
     if (VEC4) {
-        const int C4 = C >> 2;
+        const int C4 = C4T > 0 ? C4T : C >> 2;   // compile-time for the common widths: no runtime division
         const int nvec = ns * C4;
         for (int dd = 0; dd < nd; ++dd) {
             float4 *dst = reinterpret_cast<float4 *>(feats + (((int64_t)bn * D + d0 + dd) * HW + s0) * C);
@@ -299,8 +299,10 @@ extern "C" int mmt_lift_features(int BN, int D, int HW, int C, const float *dept
     if (lds > 160 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_features: C=%d too large for the LDS tile", C);
     dim3 grid((unsigned)mmt::ceil_div(HW, kTile), (unsigned)mmt::ceil_div(D, kDRange), (unsigned)BN);
     const bool vec4 = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0);
-    if (vec4) hipLaunchKernelGGL((lift_kernel<true>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
-    else hipLaunchKernelGGL((lift_kernel<false>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    if (vec4 && C == 80) hipLaunchKernelGGL((lift_kernel<true, 20>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    else if (vec4 && C == 64) hipLaunchKernelGGL((lift_kernel<true, 16>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    else if (vec4) hipLaunchKernelGGL((lift_kernel<true, 0>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    else hipLaunchKernelGGL((lift_kernel<false, 0>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
     return mmt::check_launch("lift_features");
 }
 
