@@ -277,8 +277,11 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     const int C4 = C4T > 0 ? C4T : C >> 2;
     const int G = 64 / C4;                    // lane groups per wave (C <= 256)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * CHUNK;
-    const int npts = (int)((a.BP - base) < CHUNK ? (a.BP - base) : CHUNK);
+    // a.nchunks carries the points per workgroup (<= CHUNK, multiple of 4): the host sizes it so
+    // that the grid is a whole number of rounds of the resident workgroup slots (no half-empty tail)
+    const int cp = a.nchunks > 0 ? a.nchunks : CHUNK;
+    const int64_t base = (int64_t)blockIdx.x * cp;
+    const int npts = (int)((a.BP - base) < cp ? (a.BP - base) : cp);
 
     for (int i = tid; i < HT; i += kBlock) tab_key[i] = kEmpty;
     for (int i = tid; i < CHUNK; i += kBlock) slot_cnt[i] = 0;
@@ -937,6 +940,19 @@ __global__ __launch_bounds__(kBlock) void lift_splat_backward_kernel(
     }
 }
 
+// Points per workgroup for the chunked forward kernels: at most `max_chunk`, and such that the
+// grid is (just under) a whole number of rounds of the 256 CUs x 8 resident workgroups --
+// 3696 workgroups of 512 points are 1.8 rounds, i.e. the second round runs 80 % empty-handed.
+int balanced_chunk_points(int64_t BP, int max_chunk) {
+    const int64_t slots = 256 * 8;
+    const int64_t rounds = mmt::ceil_div(BP, (int64_t)max_chunk * slots);
+    int64_t cp = mmt::ceil_div(BP, rounds * slots);
+    cp = (cp + 3) & ~3ll;
+    if (cp > max_chunk) cp = max_chunk;
+    if (cp < 64) cp = 64 < max_chunk ? 64 : max_chunk;
+    return (int)cp;
+}
+
 template <int VEC>
 int launch_lds_combine(const VpArgs &a, int grid, size_t lds, hipStream_t st) {
     if (VEC == 4) {
@@ -985,7 +1001,8 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     if (algo == MMT_VP_ALGO_SEG_GATHER) {
         const bool fused = false;
         const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
-        const int chunk = big ? 1024 : 512;
+        const int chunk = big ? 1024 : balanced_chunk_points(BP, 512);
+        a.nchunks = chunk;
         const int64_t nchunks = mmt::ceil_div(BP, chunk);
         const dim3 grid((unsigned)nchunks), block(kBlock);
 #define MMT_LAUNCH_SEG(C4T)                                                                     \
@@ -1138,7 +1155,8 @@ extern "C" int mmt_lift_splat_forward(int B, int N, int D, int HW, int C, int nx
     a.nslot = 0; a.nchunks = 0;
     a.depth = depth; a.context = context; a.DHW = D * HW; a.HW = HW;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)mmt::ceil_div(BP, 512)), block(kBlock);
+    a.nchunks = balanced_chunk_points(BP, 512);
+    const dim3 grid((unsigned)mmt::ceil_div(BP, a.nchunks)), block(kBlock);
     if (C == 80) hipLaunchKernelGGL((vp_fwd_seg_gather<20, 512, true>), grid, block, 0, st, a);
     else if (C == 64) hipLaunchKernelGGL((vp_fwd_seg_gather<16, 512, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((vp_fwd_seg_gather<0, 512, true>), grid, block, 0, st, a);
