@@ -14,7 +14,6 @@ import math
 import os
 
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 

@@ -12,7 +12,6 @@ the per-camera un-flip of depth_feature (:423-425), BDA not applied in
 get_geometry (:355-360), context_se constructed but never called (:183, :240-248).
 """
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from ...ops.bev_geometry import frustum_geometry, lift_features, lift_splat

@@ -11,7 +11,6 @@ semantics (bev_depth_head.py:85-111, :113-254, :256-312).  Host-side differences
 """
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 from torch import nn
 
 from ..nets import ResNet, SECONDFPN
