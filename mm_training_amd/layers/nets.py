@@ -145,15 +145,13 @@ class DeformConv2dPack(nn.Module):
 
     def forward(self, x):
         offset = self.conv_offset(x)
-        if x.is_cuda:
-            from ..ops.deform_conv import deform_conv3x3          # HIP im2col/col2im + rocBLAS GEMMs
-            with torch.autocast("cuda", enabled=False):
-                return deform_conv3x3(x, offset, self.weight, self.groups)
-        return self.forward_reference(x, offset)
+        from ..ops.deform_conv import deform_conv3x3              # HIP im2col/col2im + rocBLAS GEMMs
+        with torch.autocast("cuda", enabled=False):
+            return deform_conv3x3(x, offset, self.weight, self.groups)   # raises for CPU tensors: no fallback
 
     def forward_reference(self, x, offset):
-        """The same operator with plain torch ops (bilinear grid_sample per tap + grouped GEMM):
-        the fp32 reference the HIP path is tested against, and the CPU path of this dense layer."""
+        """The same operator with plain torch ops (bilinear grid_sample per tap + grouped GEMM).
+        TEST REFERENCE ONLY (tests/test_geometry_gpu.py calls it explicitly); `forward` never does."""
         B, C, H, W = x.shape
         ys = torch.arange(H, device=x.device, dtype=x.dtype).view(1, H, 1)
         xs = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, W)
