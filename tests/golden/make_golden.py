@@ -288,6 +288,35 @@ def make_quant_and_geom():
     out["rig_geom_sample"] = q.reshape(-1, 3)[::97].numpy().copy()
     out["rig_geom_sum"] = np.array([int(q.long().sum()), int((q.long() ** 2 % 1000003).sum())], np.int64)
     out["rig_shape"] = np.array(xyz.shape, np.int32)
+    # the reference's own test fixture: a real 6-camera nuScenes calibration
+    # (test/data/nuscenes/infos.pkl), full-resolution 900x1600 images, ds 16
+    import pickle
+    info = pickle.load(open(os.path.join(REF, "test/data/nuscenes/infos.pkl"), "rb"))[0]
+    cams = ["CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_LEFT", "CAM_BACK", "CAM_BACK_RIGHT"]
+    s2e_n = np.zeros((1, 6, 4, 4), np.float32)
+    K_n = np.zeros((1, 6, 4, 4), np.float32)
+    for i, cam in enumerate(cams):
+        cs = info["cam_infos"][cam]["calibrated_sensor"]
+        w, x, y, z = cs["rotation"]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        s2e_n[0, i, :3, :3] = R
+        s2e_n[0, i, :3, 3] = cs["translation"]
+        s2e_n[0, i, 3, 3] = 1
+        K_n[0, i, :3, :3] = np.array(cs["camera_intrinsic"])
+        K_n[0, i, 3, 3] = 1
+    ref_lss, mn = _make_lss(gcf["x"], gcf["y"], gcf["z"], gcf["d"], (900, 1600), 16)
+    s2e_t, K_t = torch.from_numpy(s2e_n), torch.from_numpy(K_n)
+    xyz_n = mn.get_geometry(s2e_t, K_t, None)
+    q_n = _quantize_with_reference(ref_lss, mn, xyz_n)
+    out["nusc_fixture_combine"] = s2e_t.matmul(torch.inverse(K_t)).numpy()
+    out["nusc_fixture_frustum_shape"] = np.array(mn.frustum.shape, np.int32)
+    out["nusc_fixture_xyz_sample"] = xyz_n.reshape(-1, 3)[::211].numpy().copy()
+    out["nusc_fixture_geom_sample"] = q_n.reshape(-1, 3)[::211].numpy().copy()
+    kept = ((q_n[..., 0] >= 0) & (q_n[..., 0] < 128) & (q_n[..., 1] >= 0) & (q_n[..., 1] < 128) & (q_n[..., 2] >= 0) & (q_n[..., 2] < 1))
+    out["nusc_fixture_kept_fraction"] = np.array(float(kept.float().mean()))
+    print("nuScenes fixture rig: points", tuple(xyz_n.shape), "kept", float(kept.float().mean()))
     np.savez_compressed(os.path.join(HERE, "quant_geom.npz"), **out)
     print("quant_geom: grids", list(grids), "rig xyz", tuple(xyz.shape))
     return xyz.numpy(), q.numpy()

@@ -160,3 +160,21 @@ def test_fused_lift_splat_equals_lift_then_pool(mmt_lib, oracle_mod, cfg):
     c1.grad = None
     lift_splat(geom_d, d1, c1, vn).backward(go.contiguous())
     assert torch.allclose(d1.grad, d2.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_geometry_on_reference_nuscenes_calibration(mmt_lib, oracle_mod, golden):
+    """HIP frustum geometry + quantise on the reference fixture's real calibration."""
+    from mm_training_amd.ops.bev_geometry import frustum_geometry
+    from tests.test_oracle_golden import _frustum_torch
+    g = golden["quant_geom"]
+    fr = _frustum_torch((900, 1600), 16, (2.0, 58.0, 0.5))
+    geom, xyz = frustum_geometry(fr.cuda(), torch.from_numpy(g["nusc_fixture_combine"]).cuda(),
+                                 g["nusc_voxel_coord"], g["nusc_voxel_size"], return_xyz=True)
+    ref_xyz = oracle_mod.geometry(fr.numpy(), g["nusc_fixture_combine"])
+    assert np.array_equal(xyz.cpu().numpy(), ref_xyz)                   # bit-exact vs the oracle
+    assert np.array_equal(geom.cpu().numpy(), oracle_mod.quantize(ref_xyz, g["nusc_voxel_coord"], g["nusc_voxel_size"]))
+    sample = geom.reshape(-1, 3)[::211].cpu().numpy()
+    assert (sample != g["nusc_fixture_geom_sample"]).any(1).mean() < 2e-3   # vs the reference's torch matmul
+    kept = ((geom[..., 0] >= 0) & (geom[..., 0] < 128) & (geom[..., 1] >= 0) & (geom[..., 1] < 128)
+            & (geom[..., 2] >= 0) & (geom[..., 2] < 1)).float().mean().item()
+    assert abs(kept - float(g["nusc_fixture_kept_fraction"])) < 2e-3

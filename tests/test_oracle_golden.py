@@ -121,3 +121,34 @@ def test_lift_oracle(oracle_mod):
     out = oracle_mod.lift(depth, ctx)
     ref = (torch.from_numpy(depth).unsqueeze(1) * torch.from_numpy(ctx).unsqueeze(2)).permute(0, 2, 3, 4, 1)
     assert np.array_equal(out, ref.contiguous().numpy())
+
+
+def _frustum_torch(final_dim, ds, d_bound):
+    """Same torch calls as lss_fpn.py:308-326 (and the mirror's LSSFPN.create_frustum)."""
+    H, W = final_dim
+    fH, fW = H // ds, W // ds
+    d = torch.arange(*d_bound, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+    D = d.shape[0]
+    xs = torch.linspace(0, W - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+    ys = torch.linspace(0, H - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+    return torch.stack((xs, ys, d, torch.ones_like(d)), -1).contiguous()
+
+
+def test_geometry_on_reference_nuscenes_calibration(oracle_mod, golden):
+    """The real 6-camera rig of the reference's own fixture (test/data/nuscenes/infos.pkl)
+    pushed through the reference get_geometry + quantise; the oracle must agree index for
+    index except for points within rounding distance of a cell boundary."""
+    g = golden["quant_geom"]
+    fr = _frustum_torch((900, 1600), 16, (2.0, 58.0, 0.5)).numpy()
+    assert tuple(fr.shape) == tuple(g["nusc_fixture_frustum_shape"])
+    xyz = oracle_mod.geometry(fr, g["nusc_fixture_combine"])
+    sample = xyz.reshape(-1, 3)[::211]
+    ref = g["nusc_fixture_xyz_sample"]
+    assert np.abs(sample - ref).max() < 3e-4
+    q = oracle_mod.quantize(xyz, g["nusc_voxel_coord"], g["nusc_voxel_size"]).reshape(-1, 3)[::211]
+    mism = (q != g["nusc_fixture_geom_sample"]).any(1)
+    assert mism.mean() < 2e-3
+    if mism.any():
+        lo = g["nusc_voxel_coord"] - g["nusc_voxel_size"] / 2
+        frac = (ref[mism] - lo) / g["nusc_voxel_size"]
+        assert np.abs(frac - np.round(frac)).min(1).max() < 2e-3
