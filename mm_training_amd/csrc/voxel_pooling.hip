@@ -370,6 +370,8 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
             if (idx <= ns) slot_off[idx] = run;
             run += loc[i];
         }
+        // ns == CHUNK (every point of a full chunk in its own cell): idx never reaches ns above
+        if (lane == 63) slot_off[ns] = incl;
     }
     __syncthreads();
 
@@ -583,7 +585,10 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_stream(VpArgs a) {
             if (idx <= ns) slot_off[idx] = (unsigned short)run;
             run += loc[i];
         }
-        if (lane == 63) slot_off[CHUNK + 1] = (unsigned short)incl;   // total kept (also = slot_off[ns])
+        if (lane == 63) {
+            slot_off[ns] = (unsigned short)incl;          // needed when ns == CHUNK (idx never reaches it)
+            slot_off[CHUNK + 1] = (unsigned short)incl;   // total kept
+        }
     }
     __syncthreads();
 

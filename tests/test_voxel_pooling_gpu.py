@@ -220,3 +220,18 @@ def test_randomised_shapes_all_algorithms(mmt_lib, oracle_mod, seed):
             gi = torch.empty(B, P, C, device="cuda")
             voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos_d, grad, gi, ws)
             assert np.array_equal(gi.cpu().numpy(), ref_gi)
+
+
+@pytest.mark.parametrize("algo", [0, 3, 4, 0x23])
+def test_full_chunks_of_distinct_cells(mmt_lib, oracle_mod, algo):
+    """Regression (found by tools/fuzz_pooling.py): a chunk whose points are ALL kept and ALL in
+    different cells fills every slot of the chunk-local tables (ns == chunk size)."""
+    B, P, C = 1, 4096, 256
+    nx, ny, nz = 64, 64, 1
+    idx = np.arange(P)
+    geom = np.stack([idx % nx, idx // nx, np.zeros(P, np.int64)], -1).astype(np.int32)[None]
+    feats = (np.random.default_rng(0).random((B, P, C), dtype=np.float32) - 0.5)
+    ref, ref_pos = oracle_mod.voxel_pooling_forward(geom, feats, nx, ny, nz)
+    out, pos = _run_ext(mmt_lib, _dev(geom), _dev(feats), nx, ny, nz, algo)
+    assert torch.equal(pos.cpu(), torch.from_numpy(ref_pos))
+    assert np.abs(out.cpu().numpy() - ref).max() <= ATOL
