@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Soak / fuzz of the LiDAR kernels (voxelize -> VFE -> pillar scatter + backward) against the
+oracle (run on the GPU box).  Exits non-zero on the first mismatch."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import oracle
+from mm_training_amd.lidar import hard_voxelize_batch, pillar_scatter, simple_vfe
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+it = 0
+while time.time() < t_end:
+    it += 1
+    B = int(rng.integers(1, 5))
+    F = int(rng.choice([3, 4, 5, 8]))
+    vs = [float(rng.choice([0.1, 0.2, 0.5, 1.0])), float(rng.choice([0.1, 0.25, 0.5])), float(rng.choice([1.0, 4.0, 8.0]))]
+    gx, gy, gz = int(rng.integers(1, 300)), int(rng.integers(1, 300)), int(rng.integers(1, 4))
+    lo = [float(rng.uniform(-50, 0)), float(rng.uniform(-50, 0)), float(rng.uniform(-5, 0))]
+    pcr = lo + [lo[0] + gx * vs[0], lo[1] + gy * vs[1], lo[2] + gz * vs[2]]
+    T = int(rng.choice([1, 3, 15, 32]))
+    V = int(rng.choice([1, 10, 500, 25000]))
+    frames = []
+    for b in range(B):
+        n = int(rng.choice([0, 1, 5, 1000, 1024, 1025, 30000]))
+        mode = rng.choice(["uniform", "cluster", "same"])
+        span = np.array([gx * vs[0], gy * vs[1], gz * vs[2]])
+        if mode == "uniform":
+            xyz = np.array(lo) - 0.05 * span + rng.random((n, 3)) * span * 1.1
+        elif mode == "cluster":
+            c = np.array(lo) + rng.random((6, 3)) * span
+            xyz = c[rng.integers(0, 6, n)] + rng.normal(0, 0.3, (n, 3))
+        else:
+            xyz = np.tile(np.array(lo) + 0.5 * span, (n, 1))
+        pts = np.concatenate([xyz, rng.random((n, F - 3))], 1).astype(np.float32)
+        frames.append(pts)
+    cfg = dict(it=it, B=B, F=F, vs=vs, grid=(gx, gy, gz), T=T, V=V, sizes=[f.shape[0] for f in frames])
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("cfg", cfg, flush=True)
+    # the oracle's grid comes from round((max-min)/vs) in fp32, like the product
+    rv, rn, rc = oracle.voxelize_batch(frames, vs, pcr, T, V)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    v, n, c = hard_voxelize_batch(dev, vs, pcr, T, V)
+    if not (np.array_equal(c.cpu().numpy(), rc) and np.array_equal(n.cpu().numpy(), rn)
+            and np.array_equal(v.cpu().numpy().view(np.int32), rv.view(np.int32))):
+        print("MISMATCH voxelize", cfg)
+        sys.exit(1)
+    M = rc.shape[0]
+    nf = min(F, 5)
+    m = simple_vfe(v, n, nf).cpu().numpy()
+    if M and not np.allclose(m, oracle.simple_vfe(rv, rn, nf), rtol=1e-6, atol=1e-7, equal_nan=True):
+        print("MISMATCH vfe", cfg)
+        sys.exit(1)
+    g = oracle.grid_size(pcr, vs)
+    nyy, nxx = int(g[1]), int(g[0])
+    C = int(rng.choice([1, 5, 16, 64]))
+    feats = rng.standard_normal((M, C)).astype(np.float32)
+    ft = torch.from_numpy(feats).cuda().requires_grad_(True)
+    cv = pillar_scatter(ft, c, B, nyy, nxx)
+    if not np.array_equal(cv.detach().cpu().numpy(), oracle.pillar_scatter(feats, rc, B, nyy, nxx)):
+        print("MISMATCH scatter", cfg)
+        sys.exit(1)
+    go = rng.standard_normal((B, C, nyy, nxx)).astype(np.float32)
+    cv.backward(torch.from_numpy(go).cuda())
+    if not np.array_equal(ft.grad.cpu().numpy(), oracle.pillar_scatter_backward(go, rc)):
+        print("MISMATCH scatter backward", cfg)
+        sys.exit(1)
+print("fuzz ok:", it, "random LiDAR configurations")
