@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Soak / fuzz of the remaining HIP ops (DCN, lift, fused lift-splat backward, quantise, frustum
+geometry) against their references (run on the GPU box).  Exits non-zero on the first mismatch."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import oracle
+from mm_training_amd.layers.nets import DeformConv2dPack
+from mm_training_amd.ops.bev_geometry import frustum_geometry, lift_features, lift_splat, quantize_geometry
+from mm_training_amd.ops.deform_conv import deform_conv3x3
+from mm_training_amd.ops.voxel_pooling import voxel_pooling
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+torch.manual_seed(seed)
+t_end = time.time() + budget
+it = 0
+verbose = os.environ.get("FUZZ_VERBOSE")
+
+
+def fail(what, cfg):
+    print("MISMATCH", what, cfg)
+    sys.exit(1)
+
+
+while time.time() < t_end:
+    it += 1
+    # ---- DCN
+    groups = int(rng.choice([1, 2, 4]))
+    C = groups * 4 * int(rng.integers(1, 9))
+    O = groups * int(rng.integers(1, 17))
+    B, H, W = int(rng.integers(1, 4)), int(rng.integers(2, 20)), int(rng.integers(2, 30))   # H or W == 1: the grid_sample reference degenerates (align_corners)
+    cfg = dict(it=it, op="dcn", B=B, C=C, O=O, H=H, W=W, groups=groups)
+    if verbose:
+        print(cfg, flush=True)
+    m = DeformConv2dPack(C, O, groups=groups).cuda()
+    x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    off = torch.randn(B, 18, H, W, device="cuda") * float(rng.choice([0.3, 1.0, 3.0]))
+    xa, oa = x.clone().requires_grad_(True), off.clone().requires_grad_(True)
+    xb, ob = x.clone().requires_grad_(True), off.clone().requires_grad_(True)
+    ya = deform_conv3x3(xa, oa, m.weight, groups)
+    yb = m.forward_reference(xb, ob)
+    sc = max(1.0, yb.abs().max().item())
+    if (ya - yb).abs().max().item() > 1e-4 * sc:
+        fail("dcn forward", cfg)
+    go = torch.randn_like(yb)
+    ga = torch.autograd.grad(ya, (xa, oa, m.weight), go)
+    gb = torch.autograd.grad(yb, (xb, ob, m.weight), go)
+    for a_, b_, nm in zip(ga, gb, ("dx", "doffset", "dweight")):
+        bad = ((a_ - b_).abs() > 3e-4 * max(1.0, b_.abs().max().item())).sum().item()
+        # the bilinear derivative jumps at integer coordinates; the reference reaches the sampling
+        # position through grid normalisation (+-1 ulp), so a point within ~1e-6 of an integer may take
+        # the other one-sided derivative there: tolerate a couple of isolated offset-gradient entries
+        if bad > (2 if nm == "doffset" else 0):
+            fail("dcn " + nm, cfg)
+    # ---- lift + fused lift-splat backward vs the unfused chain
+    Bc, N, D = int(rng.integers(1, 3)), int(rng.integers(1, 4)), int(rng.integers(1, 30))
+    fH, fW = int(rng.integers(1, 6)), int(rng.integers(1, 20))
+    Cc = int(rng.choice([16, 32, 64, 80, 96]))
+    cfg = dict(it=it, op="lift", B=Bc, N=N, D=D, fH=fH, fW=fW, C=Cc)
+    if verbose:
+        print(cfg, flush=True)
+    depth = torch.rand(Bc * N, D, fH, fW, device="cuda").softmax(1)
+    ctx = torch.randn(Bc * N, Cc, fH, fW, device="cuda")
+    nx, ny = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    geom = torch.stack([torch.randint(-1, nx + 1, (Bc, N, D, fH, fW)), torch.randint(-1, ny + 1, (Bc, N, D, fH, fW)),
+                        torch.zeros(Bc, N, D, fH, fW, dtype=torch.long)], -1).int().cuda()
+    d1, c1 = depth.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    d2, c2 = depth.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    f = lift_features(d2, c2)
+    ref_f = (depth.unsqueeze(1) * ctx.unsqueeze(2)).permute(0, 2, 3, 4, 1)
+    if not torch.equal(f, ref_f.contiguous()):
+        fail("lift forward", cfg)
+    o2 = voxel_pooling(geom, f.view(Bc, N, D, fH, fW, Cc), [nx, ny, 1])
+    o1 = lift_splat(geom, d1, c1, [nx, ny, 1])
+    if (o1 - o2).abs().max().item() > 1e-4 * max(1.0, o2.abs().max().item()):
+        fail("fused forward", cfg)
+    go = torch.randn_like(o2)
+    o1.backward(go)
+    o2.backward(go)
+    if not torch.allclose(d1.grad, d2.grad, rtol=1e-4, atol=1e-4 * max(1.0, d2.grad.abs().max().item())):
+        fail("fused grad_depth", cfg)
+    if not torch.allclose(c1.grad, c2.grad, rtol=1e-4, atol=1e-4 * max(1.0, c2.grad.abs().max().item())):
+        fail("fused grad_context", cfg)
+    # ---- quantise + geometry vs the oracle (bit-exact)
+    n = int(rng.integers(1, 5000))
+    xyz = (rng.standard_normal((n, 3)) * 60).astype(np.float32)
+    vc = [float(rng.uniform(-60, -40)), float(rng.uniform(-60, -40)), -1.0]
+    vs = [float(rng.choice([0.2, 0.4, 0.8])), float(rng.choice([0.2, 0.4, 0.8])), 8.0]
+    q = quantize_geometry(torch.from_numpy(xyz).cuda(), vc, vs).cpu().numpy()
+    if not np.array_equal(q, oracle.quantize(xyz, vc, vs)):
+        fail("quantize", dict(it=it, n=n, vc=vc, vs=vs))
+    Dg, gh, gw, BN = int(rng.integers(1, 20)), int(rng.integers(1, 6)), int(rng.integers(1, 12)), int(rng.integers(1, 8))
+    fr = (rng.random((Dg, gh, gw, 4)) * 50).astype(np.float32)
+    fr[..., 3] = 1
+    cb = rng.standard_normal((BN, 4, 4)).astype(np.float32)
+    gq, gx = frustum_geometry(torch.from_numpy(fr).cuda(), torch.from_numpy(cb).cuda(), vc, vs, return_xyz=True)
+    rx = oracle.geometry(fr, cb[None])[0]
+    if not (np.array_equal(gx.cpu().numpy(), rx) and np.array_equal(gq.cpu().numpy(), oracle.quantize(rx, vc, vs))):
+        fail("frustum geometry", dict(it=it, D=Dg, gh=gh, gw=gw, BN=BN))
+print("fuzz ok:", it, "random configurations of DCN / lift / fused lift-splat / quantise / geometry")
