@@ -18,6 +18,9 @@ SHAPES = {
     "cfg2": dict(B=4, N=6, final_dim=(256, 704), ds=16, d_bound=(2.0, 58.0, 0.5), C=80),
     "cfg1_full": dict(B=1, N=6, final_dim=(256, 704), ds=8, d_bound=(1.0, 60.0, 0.5), C=64),
     "cfg5": dict(B=2, N=6, final_dim=(512, 1408), ds=16, d_bound=(2.0, 58.0, 0.5), C=80),
+    # the reference's native aiMotive configuration (exps/conf_aim.py:1-3,16-18,42-52; 2 cameras)
+    "aim": dict(B=4, N=2, final_dim=(704, 1280), ds=16, d_bound=(2.0, 206.4, 0.5), C=80,
+                x_bound=(-204.8, 204.8, 0.8), y_bound=(-25.6, 25.6, 0.8)),
 }
 
 
@@ -47,7 +50,8 @@ def main():
     sh = SHAPES[args.shape]
     B, C = sh["B"], sh["C"]
     if args.geometry == "rig":
-        geom, vn = synthetic.rig_geometry(B, sh["N"], sh["final_dim"], sh["ds"], sh["d_bound"])
+        geom, vn = synthetic.rig_geometry(B, sh["N"], sh["final_dim"], sh["ds"], sh["d_bound"],
+                                          sh.get("x_bound", (-51.2, 51.2, 0.8)), sh.get("y_bound", (-51.2, 51.2, 0.8)))
     else:
         fH, fW = sh["final_dim"][0] // sh["ds"], sh["final_dim"][1] // sh["ds"]
         D = int((sh["d_bound"][1] - sh["d_bound"][0]) / sh["d_bound"][2])
@@ -111,6 +115,19 @@ def main():
                           "bwd_GBps": bwd_bytes / medev(be) / 1e6}
     # isolated backward but with a cache-flushing 1 GiB read in between (cold MALL)
     flush = torch.empty(256 * 1024 * 1024, device="cuda")
+    # full-size check against the oracle (C restatement, a few seconds on the host)
+    if os.environ.get("KBENCH_VERIFY"):
+        import numpy as np
+        import oracle
+        out.zero_()
+        voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=fl)
+        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, pos, go, gi, WS)
+        torch.cuda.synchronize()
+        r_out, r_pos = oracle.voxel_pooling_forward(geom.cpu().numpy(), feats.cpu().numpy(), nx, ny, nz)
+        r_gi = oracle.voxel_pooling_backward(r_pos, go.cpu().numpy())
+        res["verify"] = {"pos_memo_equal": bool(np.array_equal(pos.cpu().numpy(), r_pos)),
+                         "bev_max_abs_err": float(np.abs(out.cpu().numpy() - r_out).max()),
+                         "grad_in_equal": bool(np.array_equal(gi.cpu().numpy(), r_gi))}
     be = []
     for it in range(args.reps + 3):
         flush.sum()
