@@ -36,9 +36,13 @@ def use_shipped_miopen_db():
     for f in os.listdir(src):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     os.environ["MIOPEN_USER_DB_PATH"] = dst
-    # FAST find mode: a find-DB hit returns the tuned solver, a miss falls back to MIOpen's
-    # immediate-mode heuristic instead of starting a minutes-long search inside the benchmark
-    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    # HYBRID find mode: a find-DB hit returns the tuned solver without running anything, a miss
+    # times the applicable solvers once (seconds) instead of trusting the immediate-mode heuristic.
+    # The reference "naive" solvers (tens of ms per call, never chosen) are excluded from that
+    # timing: they alone cost ~15 s of warm-up per process (profiles/r01_miopen_find_modes.txt).
+    os.environ.setdefault("MIOPEN_FIND_MODE", "3")
+    for d in ("FWD", "BWD", "WRW"):
+        os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + d, "0")
     return True
 
 
