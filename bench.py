@@ -68,6 +68,8 @@ def parse():
                          "hotpath: only voxel_pooling forward+backward at the cfg-2 shape")
     ap.add_argument("--config", default="cfg2", help="cfg2 (BASELINE configs[1], default) | cfg3 | cfg4 | cfg5 | tiny")
     ap.add_argument("--miopen-tune", action="store_true", help="exhaustive MIOpen search (minutes of warm-up)")
+    ap.add_argument("--cached-plan", action="store_true",
+                    help="train mode: pass a calibration id so voxel_pooling reuses a cached sort (SURVEY 8/f3)")
     ap.add_argument("--fused-lift-splat", action="store_true",
                     help="camera branch uses the fused lift-splat kernels (row f1) instead of lift -> voxel_pooling; "
                          "the voxel_pooling roofline lines are then not produced")
@@ -190,6 +192,11 @@ def train_main(args, rank, local_rank, world):
     B = cfg["batch_size"]
     # a small pool of distinct pre-generated batches resident in HBM (input is never the bottleneck)
     batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i) for i in range(2)]
+    if args.cached_plan:
+        # each synthetic batch has its own (jittered) rig; its id lets LSSFPN reuse the
+        # sort of the points by BEV cell instead of redoing geometry + sort every step
+        for i, b in enumerate(batches):
+            b[1]["calibration_id"] = ("synthetic", 1000 * rank + i)
     for i in range(args.warmup):
         ts(batches[i % len(batches)])
     voxel_pooling_ext.TIMING = {}
@@ -224,7 +231,7 @@ def train_main(args, rank, local_rank, world):
             "params_M": sum(p.numel() for p in ts.model.parameters()) / 1e6,
             "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune),
             "miopen_shipped_find_db": bool(SHIPPED_MIOPEN_DB and args.config == "cfg2"),
-            "fused_lift_splat": bool(args.fused_lift_splat)},
+            "fused_lift_splat": bool(args.fused_lift_splat), "cached_plan": bool(args.cached_plan)},
     }
     if cfg["use_cam"] and timing.get("forward"):
         fwd_ms = sum(s.elapsed_time(e) for s, e in timing["forward"]) / len(timing["forward"])
@@ -239,8 +246,15 @@ def train_main(args, rank, local_rank, world):
         K, BP, C = int(kept.sum()), g3.shape[0], lss.output_channels
         fb, bb = algorithmic_bytes(BP, K, C, B, ny, nx)
         cfg2 = args.config == "cfg2"
-        res["roofline"] = roofline_entry("vp_fwd_seg_gather (voxel_pooling forward, inside the training step)", fb, fwd_ms,
-                                         ("vp_fwd_seg_gather",) if cfg2 else ())
+        if args.cached_plan and lss._plan_cache:
+            plan = next(iter(lss._plan_cache.values()))
+            # cached sort: no geom read / pos_memo write per step; row ids + item descriptors instead
+            fb = 4 * C * K + 4 * K + 16 * plan.num_items + 4 * C * B * ny * nx
+            res["roofline"] = roofline_entry("vp_planned_items + vp_planned_fold (cached-plan voxel_pooling forward, "
+                                             "inside the training step)", fb, fwd_ms, ())
+        else:
+            res["roofline"] = roofline_entry("vp_fwd_seg_gather (voxel_pooling forward, inside the training step)", fb, fwd_ms,
+                                             ("vp_fwd_seg_gather",) if cfg2 else ())
         res["roofline_backward"] = roofline_entry("vp_bwd_prepare + vp_bwd_rows_vec4 (voxel_pooling backward, inside the training step)",
                                                   bb, bwd_ms, ("vp_bwd_prepare", "vp_bwd_rows_vec4") if cfg2 else ())
         res["config"]["kept_fraction"] = K / BP

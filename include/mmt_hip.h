@@ -4,8 +4,8 @@
  *
  * Plain pointers + sizes only; no torch / ATen types.  Every pointer is a DEVICE
  * pointer unless stated otherwise.  `stream` is a hipStream_t passed as void*
- * (NULL = the null stream).  All entry points are asynchronous on `stream`, never
- * synchronise the device, never allocate and keep no pointers after returning, so
+ * (NULL = the null stream).  All entry points (except mmt_voxel_pooling_plan_info, a one-time
+ * read-back) are asynchronous on `stream`, never synchronise the device, never allocate and keep no pointers after returning, so
  * they can be captured into a hipGraph.
  *
  * Return value: 0 on success; MMT_ERR_* (< 0) for argument errors detected on the
@@ -143,6 +143,40 @@ int mmt_lift_splat_backward(int B, int N, int D, int HW, int C, int nx, int ny,
                             const float *grad_output, int64_t stride_b, int64_t stride_c,
                             int64_t stride_y, int64_t stride_x, float *grad_depth,
                             float *grad_context, void *stream);
+
+/* Cached pooling plan ("cached sort"; an ADDITIONAL entry point beside the
+ * drop-in pair): the point -> BEV-cell assignment (voxel_pooling_forward_cuda.cu:19-29) depends only
+ * on geom_xyz, i.e. on the calibration that layers/backbones/lss_fpn.py:328-361,461-462 turn into
+ * indices.  While it is unchanged, sort the points by cell once and run every forward as a pure
+ * segmented gather: no atomics, no geom read, no pos_memo write, bit-reproducible summation order
+ * (ascending point index inside a cell, cut into items of 32 rows).
+ *   plan      int32 [mmt_voxel_pooling_plan_elems(...)], 16-byte aligned, caller-owned, opaque
+ *   workspace bytes [mmt_voxel_pooling_plan_workspace_bytes(...)], only needed during the build
+ *   pos_memo  int32 [B*P,3] or NULL: FULLY written ((b,y,x) or (-1,-1,-1)) -- what
+ *             mmt_voxel_pooling_backward consumes, so the backward of a planned forward is unchanged
+ * mmt_voxel_pooling_plan_build is asynchronous like everything else.  mmt_voxel_pooling_plan_info is
+ * the ONE entry point of this library that synchronises `stream`: it copies the four counts the
+ * forward needs back to the host, info_host[4] = {num_items, num_kept, num_multi, num_partial}
+ * (once per plan, not per step).
+ * mmt_voxel_pooling_forward_planned WRITES every BEV row (zeros for empty cells; no caller memset):
+ *   output_features fp32: row of cell (b,y,x) starts at out + ((b*ny+y)*nx+x) * out_row_stride
+ *             (out_row_stride >= C, multiple of 4: lets the pooled map land inside a wider
+ *             channels-last buffer, e.g. the camera|LiDAR concat of models/bev_depth.py:187-192)
+ *   partial   fp32 [num_partial * C] scratch (may be NULL when num_multi == 0)
+ * C must be a multiple of 4 and <= 256. */
+int64_t mmt_voxel_pooling_plan_elems(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
+int64_t mmt_voxel_pooling_plan_workspace_bytes(int batch_size, int num_points, int num_voxel_x,
+                                               int num_voxel_y);
+int mmt_voxel_pooling_plan_build(int batch_size, int num_points, int num_voxel_x, int num_voxel_y,
+                                 int num_voxel_z, const int32_t *geom_xyz, int32_t *pos_memo,
+                                 int32_t *plan, int64_t plan_elems, void *workspace,
+                                 int64_t workspace_bytes, void *stream);
+int mmt_voxel_pooling_plan_info(const int32_t *plan, int32_t *info_host /* HOST, 4 ints */, void *stream);
+int mmt_voxel_pooling_forward_planned(int batch_size, int num_points, int num_channels, int num_voxel_x,
+                                      int num_voxel_y, const int32_t *plan, int num_items, int num_multi,
+                                      int num_partial, const float *input_features,
+                                      float *output_features, int64_t out_row_stride, float *partial,
+                                      int64_t partial_elems, void *stream);
 
 /* Deformable 3x3 convolution, the data-dependent halves: replaces
  * mmcv 'DCN' (DeformConv2dPack) inside DepthNet, layers/backbones/lss_fpn.py:189-197.

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmmt_hip.so")
+# MMT_HIP_LIB: load another build of the same library (kernel experiments in tools/scratch)
+LIB_PATH = os.environ.get("MMT_HIP_LIB") or os.path.join(_PKG, "libmmt_hip.so")
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -27,6 +28,11 @@ SIGNATURES = {
     "mmt_lift_features_backward": (_c_int, [_c_int] * 4 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_lift_splat_forward": (_c_int, [_c_int] * 8 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_lift_splat_backward": (_c_int, [_c_int] * 7 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_ptr]),
+    "mmt_voxel_pooling_plan_elems": (_c_i64, [_c_int] * 4),
+    "mmt_voxel_pooling_plan_workspace_bytes": (_c_i64, [_c_int] * 4),
+    "mmt_voxel_pooling_plan_build": (_c_int, [_c_int] * 5 + [_c_ptr] * 3 + [_c_i64, _c_ptr, _c_i64, _c_ptr]),
+    "mmt_voxel_pooling_plan_info": (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
+    "mmt_voxel_pooling_forward_planned": (_c_int, [_c_int] * 5 + [_c_ptr] + [_c_int] * 3 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "mmt_dcn_im2col": (_c_int, [_c_int] * 5 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_dcn_col2im": (_c_int, [_c_int] * 5 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr]),

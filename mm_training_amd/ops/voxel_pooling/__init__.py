@@ -4,6 +4,8 @@ module lives next to it as ``voxel_pooling_ext`` (a ctypes binding of libmmt_hip
 from . import voxel_pooling as _op
 from . import voxel_pooling_ext  # noqa: F401  (importable like the reference's pybind module)
 
+from .plan import VoxelPoolingPlan, voxel_pooling_planned  # noqa: F401  (cached-sort variant)
+
 voxel_pooling = _op.voxel_pooling
 
-__all__ = ("voxel_pooling", "voxel_pooling_ext")
+__all__ = ("voxel_pooling", "voxel_pooling_ext", "VoxelPoolingPlan", "voxel_pooling_planned")

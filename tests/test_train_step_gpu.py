@@ -70,3 +70,39 @@ def test_training_step_decreases_loss(mmt_lib, fused):
     assert any(not torch.equal(before[n], p.detach()) for n, p in list(ts.model.named_parameters())[:5])
     # the unused context_se parameters (reference quirk) never get a gradient
     assert ts.model.backbone.depth_net.context_se.conv_reduce.weight.grad is None
+
+
+def test_lssfpn_cached_plan_matches_uncached(mmt_lib):
+    """mats_dict['calibration_id']: the plan is built on the first call, reused on
+    the next ones, and BEV map + gradients agree with the uncached drop-in path."""
+    from mm_training_amd.dp import make_config, synthetic_batch
+    from mm_training_amd.layers.backbones import LSSFPN
+    cfg = make_config("tiny")
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = LSSFPN(**cfg["backbone_conf"]).to(dev).train()
+    imgs, mats, *_ = synthetic_batch(cfg, dev)
+    x = imgs[:, :, :, :3] / 255.0
+
+    def run(mats_dict):
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(1)
+        bev = m(x, mats_dict)
+        bev.square().mean().backward()
+        g = m.depth_net.depth_conv[0].conv1.weight.grad if hasattr(m.depth_net.depth_conv[0], "conv1") \
+            else next(p.grad for p in m.depth_net.parameters() if p.grad is not None)
+        return bev.detach().clone(), g.detach().clone()
+
+    ref_bev, ref_g = run(mats)
+    cached = dict(mats, calibration_id=("rig", 0))
+    assert len(m._plan_cache) == 0
+    bev1, g1 = run(cached)
+    assert len(m._plan_cache) == 1
+    plan = next(iter(m._plan_cache.values()))
+    bev2, g2 = run(cached)
+    assert len(m._plan_cache) == 1 and next(iter(m._plan_cache.values())) is plan
+    assert (bev1 - ref_bev).abs().max().item() <= 1e-4 * max(1.0, ref_bev.abs().max().item())
+    assert torch.allclose(bev1, bev2, rtol=0, atol=1e-6)  # (bit-reproducibility of the op itself: test_voxel_pooling_plan_gpu)
+    assert torch.allclose(g1, ref_g, rtol=1e-3, atol=1e-6)
+    run(dict(mats, calibration_id=("rig", 1)))
+    assert len(m._plan_cache) == 2

@@ -113,6 +113,35 @@ def main():
     medev = lambda evs: sorted(s_.elapsed_time(e_) for s_, e_ in evs)[len(evs) // 2]
     res["alternating"] = {"fwd_ms": medev(fe), "bwd_ms": medev(be), "fwd_GBps": fwd_bytes / medev(fe) / 1e6,
                           "bwd_GBps": bwd_bytes / medev(be) / 1e6}
+    # cached-plan forward: plan built once, forward = segmented gather
+    from mm_training_amd.ops.voxel_pooling import VoxelPoolingPlan
+    from mm_training_amd.ops.voxel_pooling.plan import planned_forward_into
+    plan = VoxelPoolingPlan(geom, vn)
+    pout = torch.empty(B, ny, nx, C, device="cuda")
+    planned_bytes = 4 * C * K + 4 * K + 16 * plan.num_items + 4 * C * B * ny * nx
+    med, best = timeit(lambda: planned_forward_into(plan, feats, pout, C), args.reps)
+    out.zero_()
+    voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=fl)
+    res["fwd_planned"] = {"ms": med, "best_ms": best, "GBps_own_bytes": planned_bytes / med / 1e6,
+                          "GBps_dropin_bytes": fwd_bytes / med / 1e6, "planned_MB": planned_bytes / 1e6,
+                          "items": plan.num_items, "multi_cells": plan.num_multi, "partial_rows": plan.num_partial,
+                          "max_abs_diff_vs_dropin": (pout - out).abs().max().item(),
+                          "pos_memo_equal": bool(torch.equal(plan.pos_memo, pos))}
+    fe = []
+    for it in range(args.reps + 3):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        e[0].record()
+        planned_forward_into(plan, feats, pout, C)
+        e[1].record()
+        voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, plan.pos_memo, go, gi, WS)
+        if it >= 3:
+            fe.append((e[0], e[1]))
+    torch.cuda.synchronize()
+    res["fwd_planned"]["alternating_ms"] = medev(fe)
+    res["fwd_planned"]["alternating_GBps_own_bytes"] = planned_bytes / medev(fe) / 1e6
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record(); VoxelPoolingPlan(geom, vn); t1.record(); torch.cuda.synchronize()
+    res["fwd_planned"]["plan_build_ms"] = t0.elapsed_time(t1)
     # isolated backward but with a cache-flushing 1 GiB read in between (cold MALL)
     flush = torch.empty(256 * 1024 * 1024, device="cuda")
     # full-size check against the oracle (C restatement, a few seconds on the host)
