@@ -64,6 +64,8 @@ int mmt_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
 #define MMT_VP_ALGO_STREAM 4      /* chunk sorted by cell, balanced stream over the sorted list, LDS row buffer */
 #define MMT_VP_ALGO_MASK 0xF
 #define MMT_VP_CHUNK_1024 0x20    /* SEG_GATHER: 1024 points per workgroup instead of 512 */
+#define MMT_VP_WAVE_PER_SLOT 0x40 /* SEG_GATHER: previous gather schedule (one cell per wave instead of one
+                                     per lane group), kept for A/B measurements */
 #define MMT_VP_WRITE_DROPPED 0x10 /* also write (-1,-1,-1) to pos_memo rows of dropped points,
                                      so the caller need not pre-fill pos_memo */
 int mmt_voxel_pooling_forward_ex(int batch_size, int num_points, int num_channels,

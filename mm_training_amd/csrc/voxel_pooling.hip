@@ -21,6 +21,7 @@ constexpr int kDropped = -1;      // pt_slot: point outside the grid
 constexpr int kOverflow = -2;     // pt_slot: no LDS row available -> direct row atomics
 constexpr int kHashSize = 512;    // entries, power of two
 constexpr int kChunk = 512;       // points per chunk (2 per thread)
+constexpr int kLongSlot = 24;     // seg_gather: cells with more points per chunk are walked by a whole wave
 
 struct VpArgs {
     int64_t BP;  // B*P
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
 //     contiguous run of global fp32 atomics per touched cell.
 // The BEV tile of the chunk therefore lives in registers + a staging row; HBM sees
 // each kept feature row once and one atomic row per (chunk, cell).
-template <int C4T, int CHUNK, bool FUSED>
+template <int C4T, int CHUNK, bool FUSED, bool GROUPED = true>
 __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     constexpr int HT = CHUNK * 2;             // hash entries (load factor <= 0.5)
     constexpr int HT_LOG2 = (CHUNK == 512) ? 10 : 11;
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     __shared__ int slot_off[CHUNK + 1];
     __shared__ unsigned short sorted[CHUNK];
     __shared__ __align__(16) float stage[NW][256];
-    __shared__ int nslots, next_slot;
+    __shared__ int nslots, next_slot, next_long, nlong;
+    __shared__ unsigned short long_list[CHUNK / kLongSlot + 1];
     // fused lift-splat: per point of the chunk its depth probability and its pixel's context row
     __shared__ float pt_depth[FUSED ? CHUNK : 1];
     __shared__ int pt_pix[FUSED ? CHUNK : 1];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
 
     for (int i = tid; i < HT; i += kBlock) tab_key[i] = kEmpty;
     for (int i = tid; i < CHUNK; i += kBlock) slot_cnt[i] = 0;
-    if (tid == 0) { nslots = 0; next_slot = 0; }
+    if (tid == 0) { nslots = 0; next_slot = 0; next_long = 0; nlong = 0; }
     __syncthreads();
 
     // ---- A1: bounds test, hash insert.  pos_memo rows are kept in registers: in WRITE_DROPPED
@@ -380,6 +382,9 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
         if (slot[k] >= 0) sorted[slot_off[slot[k]] + rank[k]] = (unsigned short)(tid + k * kBlock);
+    // cells with more than kLongSlot points of this chunk (at most CHUNK / kLongSlot of them)
+    for (int i = tid; i < ns; i += kBlock)
+        if (slot_cnt[i] > kLongSlot) long_list[atomicAdd(&nlong, 1)] = (unsigned short)i;
     if (a.write_dropped) {
         int *pml = tab;                          // [CHUNK*3] ints
 #pragma unroll
@@ -401,32 +406,99 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
         }
     }
 
-    // ---- B/C: one slot per wave at a time, register accumulation, staged flush
-    const int g = lane / C4;
-    const int li = lane - g * C4;
-    const bool active = g < G;
-    const float *fbase = FUSED ? a.context + li * 4 : a.feats + base * C + li * 4;
-    float *st = stage[wave];
-    for (;;) {
-        int s = 0;
-        if (lane == 0) s = atomicAdd(&next_slot, 1);
-        s = __builtin_amdgcn_readfirstlane(s);
-        if (s >= ns) break;
-        const int beg = slot_off[s], end = slot_off[s + 1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) {
-            // 4 rows in flight per lane group; short lists (the common far-range case)
-            // issue all their loads before the first add instead of one load per trip.
-            for (int j = beg + g; j < end; j += 4 * G) {
-                float4 v[4];
-                float dv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int jj = j + u * G;
+    if constexpr (!GROUPED) {
+        // ---- B/C: one slot per wave at a time, register accumulation, staged flush
+        const int g = lane / C4;
+        const int li = lane - g * C4;
+        const bool active = g < G;
+        const float *fbase = FUSED ? a.context + li * 4 : a.feats + base * C + li * 4;
+        float *st = stage[wave];
+        for (;;) {
+            int s = 0;
+            if (lane == 0) s = atomicAdd(&next_slot, 1);
+            s = __builtin_amdgcn_readfirstlane(s);
+            if (s >= ns) break;
+            const int beg = slot_off[s], end = slot_off[s + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) {
+                // 4 rows in flight per lane group; short lists (the common far-range case)
+                // issue all their loads before the first add instead of one load per trip.
+                for (int j = beg + g; j < end; j += 4 * G) {
+                    float4 v[4];
+                    float dv[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int jj = j + u * G;
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        dv[u] = 0.f;
+                        if (jj < end) {
+                            const int p = sorted[jj];
+                            if (FUSED) {
+                                dv[u] = pt_depth[p];
+                                v[u] = *reinterpret_cast<const float4 *>(fbase + (int64_t)pt_pix[p] * C);
+                            } else {
+                                v[u] = *reinterpret_cast<const float4 *>(fbase + p * C);
+                            }
+                        }
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (FUSED) {   // product rounded to fp32 first (= the materialised lift), then added
+                            acc.x += __fmul_rn(dv[u], v[u].x); acc.y += __fmul_rn(dv[u], v[u].y);
+                            acc.z += __fmul_rn(dv[u], v[u].z); acc.w += __fmul_rn(dv[u], v[u].w);
+                        } else {
+                            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float *orow = a.out + (int64_t)slot_key[s] * C;
+            for (int e = lane; e < C; e += 64) {
+                float sum = st[e];
+                for (int gg = 1; gg < G; ++gg) sum += st[gg * C + e];
+                atomicAdd(orow + e, sum);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // ---- B/C: register accumulation, staged flush.
+        // Pass 1: every lane group owns ONE cell (slot) at a time -- G cells per wave in flight, up to
+        // kRows rows each -- because the typical slot is short (36 slots / ~280 kept rows per chunk at
+        // cfg2): one slot per WAVE left two thirds of the load slots empty and paid the ticket /
+        // staging overhead per slot instead of per G slots.  Pass 2: the few long slots are walked by
+        // a whole wave (G groups, every G-th row) so no group serialises hundreds of rows.
+        constexpr int kRows = 8;
+        const int g = lane / C4;
+        const int li = lane - g * C4;
+        const bool active = g < G;
+        const float *fbase = FUSED ? a.context + li * 4 : a.feats + base * C + li * 4;
+        float *st = stage[wave];
+        for (;;) {
+            int s0 = 0;
+            if (lane == 0) s0 = atomicAdd(&next_slot, G);
+            s0 = __builtin_amdgcn_readfirstlane(s0);
+            if (s0 >= ns) break;
+            const int s = s0 + g;
+            int beg = 0, end = 0;
+            if (active && s < ns) {
+                beg = slot_off[s];
+                end = slot_off[s + 1];
+                if (end - beg > kLongSlot) end = beg;      // left to pass 2
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = beg; j < end; j += kRows) {
+                float4 v[kRows];
+                float dv[kRows];
+    #pragma unroll
+                for (int u = 0; u < kRows; ++u) {
                     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     dv[u] = 0.f;
-                    if (jj < end) {
-                        const int p = sorted[jj];
+                    if (j + u < end) {
+                        const int p = sorted[j + u];
                         if (FUSED) {
                             dv[u] = pt_depth[p];
                             v[u] = *reinterpret_cast<const float4 *>(fbase + (int64_t)pt_pix[p] * C);
@@ -435,8 +507,8 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
                         }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
+    #pragma unroll
+                for (int u = 0; u < kRows; ++u) {
                     if (FUSED) {   // product rounded to fp32 first (= the materialised lift), then added
                         acc.x += __fmul_rn(dv[u], v[u].x); acc.y += __fmul_rn(dv[u], v[u].y);
                         acc.z += __fmul_rn(dv[u], v[u].z); acc.w += __fmul_rn(dv[u], v[u].w);
@@ -445,18 +517,72 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
                     }
                 }
             }
-            *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
+            if (active) *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // G rows leave the wave as contiguous runs of global fp32 atomics
+            for (int e = lane; e < G * C; e += 64) {
+                const int gg = e / C;
+                const int ss = s0 + gg;
+                if (ss < ns) {
+                    const int n = slot_off[ss + 1] - slot_off[ss];
+                    if (n <= kLongSlot) atomicAdd(a.out + (int64_t)slot_key[ss] * C + (e - gg * C), st[e]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        float *orow = a.out + (int64_t)slot_key[s] * C;
-        for (int e = lane; e < C; e += 64) {
-            float sum = st[e];
-            for (int gg = 1; gg < G; ++gg) sum += st[gg * C + e];
-            atomicAdd(orow + e, sum);
+        const int nl = nlong;
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&next_long, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= nl) break;
+            const int s = long_list[t];
+            const int beg = slot_off[s], end = slot_off[s + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) {
+                for (int j = beg + g; j < end; j += 4 * G) {
+                    float4 v[4];
+                    float dv[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int jj = j + u * G;
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        dv[u] = 0.f;
+                        if (jj < end) {
+                            const int p = sorted[jj];
+                            if (FUSED) {
+                                dv[u] = pt_depth[p];
+                                v[u] = *reinterpret_cast<const float4 *>(fbase + (int64_t)pt_pix[p] * C);
+                            } else {
+                                v[u] = *reinterpret_cast<const float4 *>(fbase + p * C);
+                            }
+                        }
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (FUSED) {
+                            acc.x += __fmul_rn(dv[u], v[u].x); acc.y += __fmul_rn(dv[u], v[u].y);
+                            acc.z += __fmul_rn(dv[u], v[u].z); acc.w += __fmul_rn(dv[u], v[u].w);
+                        } else {
+                            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float *orow = a.out + (int64_t)slot_key[s] * C;
+            for (int e = lane; e < C; e += 64) {
+                float sum = st[e];
+                for (int gg = 1; gg < G; ++gg) sum += st[gg * C + e];
+                atomicAdd(orow + e, sum);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -987,7 +1113,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     int algo = flags & MMT_VP_ALGO_MASK;
     if (algo > MMT_VP_ALGO_STREAM)
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown algorithm %d", algo);
-    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024))
+    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024 | MMT_VP_WAVE_PER_SLOT))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown flag bits 0x%x", flags);
     hipStream_t st = (hipStream_t)stream;
 
@@ -1006,6 +1132,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     if (algo == MMT_VP_ALGO_SEG_GATHER) {
         const bool fused = false;
         const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
+        const bool wave_slots = (flags & MMT_VP_WAVE_PER_SLOT) != 0;
         const int chunk = big ? 1024 : balanced_chunk_points(BP, 512);
         a.nchunks = chunk;
         const int64_t nchunks = mmt::ceil_div(BP, chunk);
@@ -1014,6 +1141,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     do {                                                                                        \
         if (fused) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, true>), grid, block, 0, st, a);          \
         else if (big) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 1024, false>), grid, block, 0, st, a);   \
+        else if (wave_slots) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false, false>), grid, block, 0, st, a); \
         else hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false>), grid, block, 0, st, a);               \
     } while (0)
         if (C == 80) MMT_LAUNCH_SEG(20);

@@ -12,7 +12,8 @@ import torch
 
 import oracle
 from mm_training_amd.ops.bev_geometry import lift_splat
-from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext
+from mm_training_amd.ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling_ext
+from mm_training_amd.ops.voxel_pooling.plan import planned_forward_into
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -44,7 +45,7 @@ while time.time() < t_end:
     _, ref_pos = oracle.voxel_pooling_forward(geom, np.zeros((B, P, 1), np.float32), nx, ny, nz)
     gd, fd = torch.from_numpy(geom).cuda(), torch.from_numpy(feats).cuda()
     verbose = os.environ.get("FUZZ_VERBOSE")
-    for algo in (0, 1, 2, 3, 4, 0x23):
+    for algo in (0, 1, 2, 3, 4, 0x23, 0x43):
         if verbose:
             print("cfg", dict(it=it, B=B, P=P, C=C, grid=(nx, ny, nz), mode=str(mode), algo=algo), flush=True)
         out = torch.zeros(B, ny, nx, C, device="cuda")
@@ -57,6 +58,14 @@ while time.time() < t_end:
         tol = 1e-4 + 1e-6 * np.sqrt(P) * max(1.0, np.abs(ref64).max())
         if not np.array_equal(pos.cpu().numpy(), ref_pos) or err > tol:
             print("MISMATCH forward", dict(it=it, B=B, P=P, C=C, grid=(nx, ny, nz), mode=mode, algo=algo, err=float(err)))
+            sys.exit(1)
+    if C % 4 == 0 and C <= 256:   # cached-plan forward
+        plan = VoxelPoolingPlan(gd, [nx, ny, nz])
+        pout = torch.full((B, ny, nx, C), 3.0, device="cuda")
+        planned_forward_into(plan, fd, pout, C)
+        err = np.abs(pout.cpu().numpy() - ref64).max()
+        if not np.array_equal(plan.pos_memo.cpu().numpy(), ref_pos) or err > tol:
+            print("MISMATCH planned", dict(it=it, B=B, P=P, C=C, grid=(nx, ny, nz), mode=mode, err=float(err)))
             sys.exit(1)
     go = rng.standard_normal((B, ny, nx, C)).astype(np.float32)
     ref_gi = oracle.voxel_pooling_backward(ref_pos, go.transpose(0, 3, 1, 2))

@@ -71,7 +71,7 @@ def main():
     res = {"shape": args.shape, "geometry": args.geometry, "BP": BP, "kept": K / BP, "fwd_MB": fwd_bytes / 1e6, "bwd_MB": bwd_bytes / 1e6}
     ref = None
     for algo in [int(a) for a in args.algos.split(",")]:
-        flags = (algo % 16) | 0x10 | (0x20 if algo >= 32 else 0)
+        flags = (algo & 0xF) | 0x10 | (algo & 0x60)   # e.g. 3, 35 = 3|0x20 (chunk 1024), 67 = 3|0x40 (wave per slot)
 
         def run():
             voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=flags)
@@ -83,6 +83,18 @@ def main():
         err = (out - ref).abs().max().item()
         med, best = timeit(run, args.reps)
         res[f"fwd_algo{algo}"] = {"ms": med, "best_ms": best, "GBps": fwd_bytes / med / 1e6, "max_abs_diff_vs_first": err}
+    # interleaved A/B of the listed algorithms (box-to-box and run-to-run noise is ~5 %: only numbers
+    # taken in alternation inside one process are comparable)
+    algos = [int(a) for a in args.algos.split(",")]
+    if len(algos) > 1:
+        per = {a_: [] for a_ in algos}
+        for rnd in range(12):
+            for a_ in algos:
+                fl_ = (a_ & 0xF) | 0x10 | (a_ & 0x60)
+                med_, _ = timeit(lambda: voxel_pooling_ext.voxel_pooling_forward_wrapper(
+                    B, P, C, nx, ny, nz, geom, feats, out, pos, flags=fl_), 8, warm=1)
+                per[a_].append(med_)
+        res["ab_interleaved_ms"] = {str(a_): sorted(v)[len(v) // 2] for a_, v in per.items()}
     memset_ms, _ = timeit(lambda: out.zero_(), args.reps)
     res["out_memset_ms"] = memset_ms
     go = torch.randn(B, ny, nx, C, device="cuda").permute(0, 3, 1, 2)
