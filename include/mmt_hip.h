@@ -245,6 +245,29 @@ int mmt_pillar_scatter_backward(int64_t num_voxels, int C, int batch_size, int n
                                 const float *grad_canvas, const int32_t *coors,
                                 const int32_t *workspace, float *grad_feats, void *stream);
 
+/* --------------------------------------------------------- per-step label generation */
+
+/* LiDAR depth supervision of the camera branch: replaces
+ * get_depth_labels / get_depth_image / get_downsampled_gt_depth,
+ * exps/mm_training_aim.py:114-163,180-215 (B x N_cam Python loop of projections, a dense
+ * H x W depth image per camera, block minimum, depth-bin index, one-hot).
+ *   points        fp32 [sum Ni, F]  all samples' points concatenated (columns x,y,z first)
+ *   point_offsets int32 [B+1]       first row of each sample (DEVICE); max_points >= max Ni (host)
+ *   extrinsics    fp32 [B, N, 4, 4] ego -> camera;  intrinsics fp32 [B, N, 4, 4]
+ *   bda_inv       fp32 [B, 3, 3]    inverse of the BEV-augmentation rotation (:129-131)
+ *   workspace     int32 [mmt_depth_labels_workspace_elems(...)] per-cell minimum depth (float bits)
+ *   depth_bin     int32 [B*N*fH*fW] or NULL: bin index, 0 = no / out-of-range depth (:207-212)
+ *   onehot        fp32  [B*N*fH*fW, D] or NULL: F.one_hot(bin, D).float() (:213-214)
+ * A point counts iff depth > 1, 1 < u < W-1, 1 < v < H-1 (:150-155); its cell is
+ * (int(v)/downsample, int(u)/downsample); the cell keeps the minimum depth (:199-204).
+ * Two points on one PIXEL: the reference keeps the one written last, here the smaller one. */
+int64_t mmt_depth_labels_workspace_elems(int batch_size, int num_cams, int img_h, int img_w, int downsample);
+int mmt_depth_labels(int batch_size, int num_cams, int point_features, int max_points, int img_h,
+                     int img_w, int downsample, float d_lo, float d_step, int depth_channels,
+                     const float *points, const int32_t *point_offsets, const float *extrinsics,
+                     const float *intrinsics, const float *bda_inv, int32_t *workspace,
+                     int64_t workspace_elems, int32_t *depth_bin, float *onehot, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

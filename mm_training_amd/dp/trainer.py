@@ -19,6 +19,7 @@ from torch import nn
 
 from .. import synthetic
 from ..models.bev_depth import BEVDepthLiDAR
+from ..ops.train_targets import depth_labels
 
 IMG_MEAN = (0.485, 0.456, 0.406)
 IMG_STD = (0.229, 0.224, 0.225)
@@ -105,9 +106,17 @@ class TrainStep(nn.Module):
     def normalize_images(self, sweep_imgs):
         return (sweep_imgs[:, :, :, :3] / 255.0 - self.mean) / self.std
 
-    # ---- exps/mm_training_aim.py:114-163 + :180-215, vectorised
+    # ---- exps/mm_training_aim.py:114-163 + :180-215: one HIP op (ops/train_targets.py)
     @torch.no_grad()
     def get_depth_labels(self, images, mats, pointclouds):
+        B, S, N, _, H, W = images.shape
+        return depth_labels(pointclouds, mats["extrinsics"][:, 0], mats["intrin_mats"][:, 0], mats["bda_mat"],
+                            (H, W), self.downsample, self.dbound, self.depth_channels)
+
+    @torch.no_grad()
+    def get_depth_labels_torch(self, images, mats, pointclouds):
+        """The same labels from vectorised torch ops (scatter-amin) -- kept as the cross-check of
+        tests/test_train_targets_gpu.py, not used by the training step."""
         B, S, N, _, H, W = images.shape
         ds = self.downsample
         fH, fW = H // ds, W // ds

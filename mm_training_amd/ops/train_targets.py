@@ -1,0 +1,50 @@
+"""Per-step label generation on the GPU -- HIP only.
+
+``depth_labels`` replaces the reference's B x N_cam Python loop of point-cloud projections
+(exps/mm_training_aim.py:114-163) and the block-minimum / bin / one-hot chain (:180-215) with
+three launches of libmmt_hip.so (``mmt_depth_labels``): no dense H x W depth images, no
+boolean-mask selects, no host synchronisation.
+"""
+import torch
+
+from .. import _lib
+
+
+def depth_labels(pointclouds, extrinsics, intrinsics, bda_mat, img_hw, downsample, d_bound,
+                 depth_channels, return_bins=False):
+    """pointclouds: list of B CUDA tensors [Ni, F] (x, y, z first); extrinsics (ego -> camera) and
+    intrinsics [B, N, 4, 4]; bda_mat [B, 4, 4]; img_hw = (H, W) of the network input.
+
+    Returns the one-hot labels fp32 [B*N*fH*fW, depth_channels] (what get_downsampled_gt_depth
+    returns, :213-214) and, with ``return_bins``, also the int32 bin index per cell."""
+    if not pointclouds or not pointclouds[0].is_cuda:
+        raise RuntimeError("pointclouds must be a non-empty list of CUDAtensors ")
+    dev = pointclouds[0].device
+    B, N = int(extrinsics.shape[0]), int(extrinsics.shape[1])
+    if len(pointclouds) != B:
+        raise RuntimeError("one point cloud per sample expected")
+    H, W = int(img_hw[0]), int(img_hw[1])
+    F = int(pointclouds[0].shape[1])
+    counts = [int(p.shape[0]) for p in pointclouds]            # shapes are host-side: no sync
+    points = torch.cat([p.float() for p in pointclouds], 0).contiguous() if sum(counts) else \
+        torch.zeros((1, F), device=dev)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    bda_inv = torch.linalg.inv_ex(bda_mat[:, :3, :3].float())[0].contiguous()       # inv_ex: no host sync
+    n_ws = _lib.lib().mmt_depth_labels_workspace_elems(B, N, H, W, int(downsample))
+    if n_ws < 0:
+        raise RuntimeError("depth_labels: bad image size / downsample")
+    fH, fW = H // downsample, W // downsample
+    workspace = torch.empty(n_ws, dtype=torch.int32, device=dev)
+    onehot = torch.empty((B * N * fH * fW, int(depth_channels)), dtype=torch.float32, device=dev)
+    bins = torch.empty((B * N * fH * fW,), dtype=torch.int32, device=dev) if return_bins else None
+    ext = extrinsics.float().contiguous()
+    intr = intrinsics.float().contiguous()
+    with torch.cuda.device(dev):
+        _lib.call("mmt_depth_labels", B, N, F, max(counts), H, W, int(downsample), float(d_bound[0]), float(d_bound[2]),
+                  int(depth_channels), points.data_ptr(), offsets.data_ptr(), ext.data_ptr(), intr.data_ptr(),
+                  bda_inv.data_ptr(), workspace.data_ptr(), n_ws, bins.data_ptr() if return_bins else None,
+                  onehot.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return (onehot, bins) if return_bins else onehot

@@ -243,3 +243,25 @@ def torch_backward_gather(pos_memo, grad_out_nhwc):
     grad_in = torch.zeros(B * P, C, dtype=grad_out_nhwc.dtype)
     grad_in[kept] = grad_out_nhwc.reshape(-1, C)[idx]
     return grad_in.view(B, P, C)
+
+
+# ------------------------------------------------- row f4: per-step label generation
+def depth_labels(points_list, extrinsics, intrinsics, bda_mats, img_hw, downsample, d_bound, pixel_last=False,
+                 want_onehot=True):
+    """exps/mm_training_aim.py:114-163,180-215.  points_list: B arrays [Ni, F]; extrinsics / intrinsics
+    [B, N, 4, 4]; bda_mats [B, 4, 4] (its 3x3 rotation is inverted here in float64 -> float32).
+    Returns (bin int32 [B*N*fH*fW], onehot float32 [B*N*fH*fW, D] or None)."""
+    B, N = extrinsics.shape[:2]
+    H, W = img_hw
+    D = int((d_bound[1] - d_bound[0]) / d_bound[2])
+    pts = _f32(np.concatenate([_f32(p) for p in points_list], 0)) if len(points_list) else np.zeros((0, 3), np.float32)
+    F = pts.shape[1]
+    offs = _i32(np.concatenate([[0], np.cumsum([len(p) for p in points_list])]))
+    bda_inv = _f32(np.linalg.inv(np.asarray(bda_mats, np.float64)[:, :3, :3]))
+    fH, fW = H // downsample, W // downsample
+    bins = np.empty((B * N * fH * fW,), np.int32)
+    onehot = np.empty((B * N * fH * fW, D), np.float32) if want_onehot else None
+    lib().oracle_depth_labels(B, N, F, H, W, downsample, ctypes.c_float(d_bound[0]), ctypes.c_float(d_bound[2]), D,
+                              _p(pts), _p(offs), _p(_f32(extrinsics)), _p(_f32(intrinsics)), _p(bda_inv),
+                              int(bool(pixel_last)), _p(bins), _p(onehot) if want_onehot else None)
+    return bins, onehot

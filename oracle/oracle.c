@@ -298,3 +298,59 @@ void oracle_pillar_scatter_backward(int M, int C, int B, int ny, int nx,
                 owner ? grad_canvas[(((int64_t)b * C + c) * ny + y) * nx + x] : 0.0f;
     }
 }
+
+/* ------------------------------------------------------------------ row f4: depth labels
+ * exps/mm_training_aim.py:114-163 (get_depth_labels + get_depth_image) and :180-215
+ * (get_downsampled_gt_depth), as a sequential loop over samples, cameras and points.
+ * fp32 operations in a fixed left-to-right order (the reference's torch matmuls leave the
+ * order to the BLAS: results can differ from it by an ulp at a pixel / bin boundary).
+ * Two points on the same pixel: the reference's indexed write keeps the last one in point
+ * order on the CPU and an arbitrary one on a GPU; `pixel_last` selects that CPU behaviour
+ * (through a dense H x W image, as the reference does), otherwise the cell keeps the minimum
+ * over all its points (what the HIP kernel implements).
+ *   bin  int32 [B*N*fH*fW]; onehot fp32 [B*N*fH*fW, D] (may be NULL) */
+void oracle_depth_labels(int B, int N, int F, int H, int W, int ds, float d_lo, float d_step, int D,
+                         const float *points, const int32_t *offsets, const float *extr,
+                         const float *intr, const float *bda_inv, int pixel_last,
+                         int32_t *bin, float *onehot) {
+    const int fH = H / ds, fW = W / ds;
+    float *img = pixel_last ? (float *)malloc(sizeof(float) * (size_t)H * W) : NULL;
+    float *cellmin = (float *)malloc(sizeof(float) * (size_t)fH * fW);
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const float *E = extr + ((int64_t)b * N + n) * 16, *K = intr + ((int64_t)b * N + n) * 16;
+            const float *R = bda_inv + b * 9;
+            for (int i = 0; i < fH * fW; ++i) cellmin[i] = 1e5f;
+            if (img) memset(img, 0, sizeof(float) * (size_t)H * W);
+            for (int i = offsets[b]; i < offsets[b + 1]; ++i) {
+                const float *p = points + (int64_t)i * F;
+                float q[3], c[4], pr[3];
+                for (int r = 0; r < 3; ++r) q[r] = (R[r * 3] * p[0] + R[r * 3 + 1] * p[1]) + R[r * 3 + 2] * p[2];
+                for (int r = 0; r < 4; ++r)
+                    c[r] = ((E[r * 4] * q[0] + E[r * 4 + 1] * q[1]) + E[r * 4 + 2] * q[2]) + E[r * 4 + 3];
+                for (int r = 0; r < 3; ++r)
+                    pr[r] = ((K[r * 4] * c[0] + K[r * 4 + 1] * c[1]) + K[r * 4 + 2] * c[2]) + K[r * 4 + 3] * c[3];
+                const float depth = c[2], u = pr[0] / pr[2], v = pr[1] / pr[2];
+                if (!(depth > 1.0f && u > 1.0f && u < (float)(W - 1) && v > 1.0f && v < (float)(H - 1))) continue;
+                const int iu = (int)u, iv = (int)v;
+                if (img) img[iv * W + iu] = depth;
+                else if (depth < cellmin[(iv / ds) * fW + iu / ds]) cellmin[(iv / ds) * fW + iu / ds] = depth;
+            }
+            if (img)
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < W; ++x) {
+                        const float d = img[y * W + x];
+                        if (d != 0.0f && d < cellmin[(y / ds) * fW + x / ds]) cellmin[(y / ds) * fW + x / ds] = d;
+                    }
+            for (int i = 0; i < fH * fW; ++i) {
+                const float g = (cellmin[i] - (d_lo - d_step)) / d_step;
+                const int k = (g < (float)D && g >= 0.0f) ? (int)g : 0;
+                const int64_t cell = ((int64_t)b * N + n) * fH * fW + i;
+                bin[cell] = k;
+                if (onehot)
+                    for (int d = 0; d < D; ++d) onehot[cell * D + d] = d == k ? 1.0f : 0.0f;
+            }
+        }
+    free(cellmin);
+    free(img);
+}

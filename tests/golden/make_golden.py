@@ -322,12 +322,86 @@ def make_quant_and_geom():
     return xyz.numpy(), q.numpy()
 
 
+def make_depth_labels():
+    """Depth supervision labels from the reference's own methods:
+    exps/mm_training_aim.py get_depth_labels (:114-140), get_depth_image (:142-163) and
+    get_downsampled_gt_depth (:180-215), read from the file at run time and exec'd as plain
+    functions on CPU tensors (`self` = a namespace with the three attributes they use).
+    Inputs are drawn so that no projected point sits within 0.02 px of a pixel boundary or of
+    the image-border tests, no depth within 1e-3 of a bin boundary or of the depth > 1 test, and
+    no two points share a pixel -- the expected labels then do not depend on the summation
+    order of the reference's matmuls nor on which of two writes to a pixel lands last."""
+    src = "\n".join(_ref_source_lines("exps/mm_training_aim.py", lo, hi) for lo, hi in ((114, 140), (142, 163), (180, 215)))
+    ns = {"torch": torch, "F": torch.nn.functional}
+    exec(src, ns)
+    rng = np.random.default_rng(42)
+    B, N, H, W, ds = 2, 3, 64, 96, 16
+    d_bound = (2.0, 58.0, 0.5)
+    D = int((d_bound[1] - d_bound[0]) / d_bound[2])
+    s2e, K = (torch.from_numpy(m) for m in _rig(B, N, W, H, seed=7))   # sensor2ego, intrinsics [B,N,4,4]
+    extr = torch.inverse(s2e.double()).float()
+    ang = np.array([0.3, -0.2])
+    bda = torch.eye(4).repeat(B, 1, 1)
+    for b in range(B):
+        c, s_ = np.cos(ang[b]), np.sin(ang[b])
+        bda[b, :3, :3] = torch.tensor([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], dtype=torch.float32) * (1.0 if b == 0 else 1.05)
+    clouds = []
+    for b in range(B):
+        cand = np.concatenate([rng.uniform(-60, 60, (6000, 2)), rng.uniform(-3, 3, (6000, 1)),
+                               rng.uniform(0, 1, (6000, 2))], 1).astype(np.float32)
+        Rinv = np.linalg.inv(bda[b, :3, :3].double().numpy())
+        keep = np.ones(len(cand), bool)
+        seen = [set() for _ in range(N)]
+        for n in range(N):
+            q = cand[:, :3].astype(np.float64) @ Rinv.T
+            cam = (extr[b, n].double().numpy() @ np.concatenate([q, np.ones((len(q), 1))], 1).T)
+            pr = K[b, n].double().numpy() @ cam
+            depth, u, v = cam[2], pr[0] / pr[2], pr[1] / pr[2]
+            fr = lambda a: np.abs(a - np.round(a))
+            risky = (fr(u) < 0.02) | (fr(v) < 0.02) | (np.abs(depth - 1.0) < 1e-3) | (np.abs(pr[2]) < 1e-3)
+            g = (depth - (d_bound[0] - d_bound[2])) / d_bound[2]
+            risky |= fr(g) < 2e-3
+            inside = (depth > 1) & (u > 1) & (u < W - 1) & (v > 1) & (v < H - 1)
+            for i in np.nonzero(inside & keep)[0]:
+                key = (int(v[i]), int(u[i]))
+                if key in seen[n]:
+                    keep[i] = False
+                else:
+                    seen[n].add(key)
+            keep &= ~risky
+        clouds.append(torch.from_numpy(cand[keep]))
+    images = torch.zeros(B, 1, N, 3, H, W)
+    mats = {"extrinsics": extr.unsqueeze(1), "intrin_mats": K.unsqueeze(1), "bda_mat": bda}
+    self_ = types.SimpleNamespace(downsample_factor=ds, dbound=list(d_bound), depth_channels=D)
+    self_.get_depth_image = lambda *a: ns["get_depth_image"](self_, *a)
+    self_.get_downsampled_gt_depth = lambda *a: ns["get_downsampled_gt_depth"](self_, *a)
+    labels = ns["get_depth_labels"](self_, images, mats, clouds)          # [B*N*fH*fW, D] one-hot float
+    labels = labels.reshape(-1, D).numpy()
+    bins = labels.argmax(1).astype(np.int32)
+    assert labels.sum(1).min() == 1.0 and labels.sum(1).max() == 1.0
+    for pixel_last in (False, True):
+        ob, oh = oracle.depth_labels([c.numpy() for c in clouds], extr.numpy(), K.numpy(), bda.numpy(), (H, W), ds, d_bound,
+                                     pixel_last=pixel_last)
+        assert np.array_equal(ob, bins), (pixel_last, int((ob != bins).sum()))
+        assert np.array_equal(oh, labels)
+    np.savez_compressed(os.path.join(HERE, "depth_labels.npz"),
+                        points=np.concatenate([c.numpy() for c in clouds], 0),
+                        offsets=np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32),
+                        extrinsics=extr.numpy(), intrinsics=K.numpy(), bda=bda.numpy(),
+                        img_hw=np.array([H, W], np.int32), downsample=np.int32(ds), d_bound=np.array(d_bound, np.float32),
+                        bins=bins)
+    print("depth_labels: points", [len(c) for c in clouds], "labelled cells", int((bins > 0).sum()), "of", bins.size)
+
+
 def main():
     _install_stubs()
     oracle.build()
+    if "--only-depth-labels" in sys.argv:
+        return make_depth_labels()
     make_vp_ref_test()
     make_vp_edge()
     make_quant_and_geom()
+    make_depth_labels()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -152,3 +152,20 @@ def test_geometry_on_reference_nuscenes_calibration(oracle_mod, golden):
         lo = g["nusc_voxel_coord"] - g["nusc_voxel_size"] / 2
         frac = (ref[mism] - lo) / g["nusc_voxel_size"]
         assert np.abs(frac - np.round(frac)).min(1).max() < 2e-3
+
+
+def test_depth_labels_oracle_matches_reference_methods(oracle_mod, golden):
+    """bins produced by the reference's get_depth_labels / get_depth_image /
+    get_downsampled_gt_depth (exps/mm_training_aim.py:114-215, run by make_golden.py) vs the C
+    restatement, in both duplicate-pixel modes (the fixture has no duplicate pixels)."""
+    import numpy as np
+    g = golden["depth_labels"]
+    offs = g["offsets"]
+    clouds = [g["points"][offs[b]:offs[b + 1]] for b in range(len(offs) - 1)]
+    for pixel_last in (False, True):
+        bins, onehot = oracle_mod.depth_labels(clouds, g["extrinsics"], g["intrinsics"], g["bda"],
+                                               tuple(int(v) for v in g["img_hw"]), int(g["downsample"]),
+                                               [float(v) for v in g["d_bound"]], pixel_last=pixel_last)
+        assert np.array_equal(bins, g["bins"])
+        assert np.array_equal(onehot.argmax(1), g["bins"])
+    assert (g["bins"] > 0).sum() > 50
