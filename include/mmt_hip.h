@@ -268,6 +268,26 @@ int mmt_depth_labels(int batch_size, int num_cams, int point_features, int max_p
                      const float *intrinsics, const float *bda_inv, int32_t *workspace,
                      int64_t workspace_elems, int32_t *depth_bin, float *onehot, void *stream);
 
+/* CenterPoint training targets: replaces BEVDepthHead.get_targets_single,
+ * layers/heads/bev_depth_head.py:113-254 (Python loop over tasks and boxes around mmdet3d's
+ * gaussian_radius / draw_heatmap_gaussian).  HOST arrays: class_begin / class_count [num_tasks]
+ * (first label and number of classes of each task) and the four arrays of num_tasks DEVICE
+ * pointers.  Per task t (all FULLY written):
+ *   heatmaps[t]   fp32  [B, class_count[t], fy, fx]  max-combined Gaussians (:212)
+ *   anno_boxes[t] fp32  [B, max_objs, 10]  (dx, dy, z, log w, log l, log h, sin, cos, vx, vy) (:220-234)
+ *   inds[t]       int64 [B, max_objs]      y * fx + x of the centre cell (:218);  masks[t] uint8 [B, max_objs]
+ * boxes fp32 [sum K, 9] (x,y,z,w,l,h,yaw,vx,vy), labels int32 [sum K], box_offsets int32 [B+1]
+ * (DEVICE), max_boxes >= max K (host).  Box k of a sample fills slot k of the task owning its
+ * class (the reference packs each task's boxes densely; its loss only sums masked slots, so the
+ * slot order is immaterial); boxes beyond max_objs are ignored (:171). */
+int mmt_centerpoint_targets(int batch_size, int num_tasks, const int32_t *class_begin,
+                            const int32_t *class_count, int max_objs, int max_boxes, int fx, int fy,
+                            float range_x0, float range_y0, float voxel_x, float voxel_y,
+                            int out_size_factor, float gaussian_overlap, int min_radius, int norm_bbox,
+                            const float *boxes, const int32_t *labels, const int32_t *box_offsets,
+                            float *const *heatmaps, float *const *anno_boxes, int64_t *const *inds,
+                            uint8_t *const *masks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,3 +149,152 @@ extern "C" int mmt_depth_labels(int B, int num_cams, int F, int max_points, int 
     hipLaunchKernelGGL(depth_bins_kernel, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, st, a, ncells);
     return mmt::check_launch("depth_labels(bins)");
 }
+
+// ---------------------------------------------------------------------------
+// mmt_centerpoint_targets: CenterPoint training targets, layers/heads/bev_depth_head.py:113-254
+// (get_targets_single: a Python loop over tasks and boxes with per-box tensor construction and
+// mmdet3d's gaussian_radius / draw_heatmap_gaussian).  One workgroup per (box, sample): the box's
+// Gaussian window is max-combined into its class heat-map with an integer atomicMax on the float
+// bits (values are >= 0), lane 0 writes the regression target row.  Slot convention: box k of a
+// sample occupies slot k in the targets of the task that owns its class (the reference packs
+// each task's boxes densely; the loss sums over masked slots only, so the order is immaterial).
+namespace {
+
+constexpr int kMaxTasks = 8;
+
+struct CpArgs {
+    int B, T, max_objs, fx, fy, norm_bbox;
+    float x0, y0, vx, vy, osf, overlap;
+    int min_radius;
+    int cls_begin[kMaxTasks], cls_count[kMaxTasks];
+    const float *boxes;          // [sum K, 9] x,y,z,w,l,h,yaw,vx,vy
+    const int32_t *labels;       // [sum K]
+    const int32_t *offsets;      // [B+1]
+    float *heatmap[kMaxTasks];   // [B, cls_count, fy, fx]
+    float *anno[kMaxTasks];      // [B, max_objs, 10]
+    int64_t *ind[kMaxTasks];     // [B, max_objs]
+    uint8_t *mask[kMaxTasks];    // [B, max_objs]
+};
+
+__global__ __launch_bounds__(kBlock) void cp_clear_kernel(CpArgs a) {
+    const int t = blockIdx.y;
+    const int64_t nh = (int64_t)a.B * a.cls_count[t] * a.fy * a.fx, ns = (int64_t)a.B * a.max_objs;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nh; i += (int64_t)gridDim.x * kBlock) a.heatmap[t][i] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ns * 10; i += (int64_t)gridDim.x * kBlock) a.anno[t][i] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ns; i += (int64_t)gridDim.x * kBlock) {
+        a.ind[t][i] = 0;
+        a.mask[t][i] = 0;
+    }
+}
+
+// mmdet3d.core.gaussian_radius((height, width), min_overlap)
+__device__ __forceinline__ float cp_gaussian_radius(float h, float w, float o) {
+    const float b1 = h + w, c1 = w * h * (1.f - o) / (1.f + o);
+    const float r1 = (b1 + sqrtf(b1 * b1 - 4.f * c1)) / 2.f;
+    const float b2 = 2.f * (h + w), c2 = (1.f - o) * w * h;
+    const float r2 = (b2 + sqrtf(b2 * b2 - 16.f * c2)) / 2.f;
+    const float a3 = 4.f * o, b3 = -2.f * o * (h + w), c3 = (o - 1.f) * w * h;
+    const float r3 = (b3 + sqrtf(b3 * b3 - 4.f * a3 * c3)) / 2.f;
+    return fminf(fminf(r1, r2), r3);
+}
+
+__global__ __launch_bounds__(64) void cp_draw_kernel(CpArgs a) {
+    const int b = blockIdx.y, k = blockIdx.x;
+    const int beg = a.offsets[b];
+    int nk = a.offsets[b + 1] - beg;
+    if (nk > a.max_objs) nk = a.max_objs;                       // bev_depth_head.py:171
+    if (k >= nk) return;
+    const float *box = a.boxes + (int64_t)(beg + k) * 9;
+    const int label = a.labels[beg + k];
+    int t = -1;
+    for (int i = 0; i < a.T; ++i)
+        if (label >= a.cls_begin[i] && label < a.cls_begin[i] + a.cls_count[i]) t = i;
+    if (t < 0) return;
+    const int cls = label - a.cls_begin[t];
+    const float width = box[3] / a.vx / a.osf, length = box[4] / a.vy / a.osf;      // :176-181
+    if (!(width > 0.f && length > 0.f)) return;                                     // :183
+    float rf = cp_gaussian_radius(length, width, a.overlap);                        // :184-186
+    int radius = (rf == rf) ? (int)rf : 0;
+    if (radius < a.min_radius) radius = a.min_radius;                               // :187
+    const float cx = (box[0] - a.x0) / a.vx / a.osf, cy = (box[1] - a.y0) / a.vy / a.osf;   // :194-199
+    const int xi = (int)cx, yi = (int)cy;                                           // .to(torch.int32)
+    if (!(xi >= 0 && xi < a.fx && yi >= 0 && yi < a.fy)) return;                    // :208-210
+    // draw_heatmap_gaussian: sigma = diameter / 6, window clipped to the map, max-combine
+    const float sigma = (float)(2 * radius + 1) / 6.f;
+    const float inv = 1.f / (2.f * sigma * sigma);
+    const int left = min(xi, radius), right = min(a.fx - xi, radius + 1);
+    const int top = min(yi, radius), bottom = min(a.fy - yi, radius + 1);
+    const int ww = left + right, wh = top + bottom;
+    float *hm = a.heatmap[t] + (((int64_t)b * a.cls_count[t] + cls) * a.fy) * a.fx;
+    for (int i = threadIdx.x; i < ww * wh; i += 64) {
+        const int dy = i / ww - top, dx = i - (i / ww) * ww - left;
+        const float g = expf(-(float)(dx * dx + dy * dy) * inv);
+        atomicMax(reinterpret_cast<unsigned int *>(hm + (int64_t)(yi + dy) * a.fx + xi + dx), __float_as_uint(g));
+    }
+    if (threadIdx.x == 0) {
+        const int64_t slot = (int64_t)b * a.max_objs + k;
+        a.ind[t][slot] = (int64_t)yi * a.fx + xi;                                   // :218
+        a.mask[t][slot] = 1;
+        float *row = a.anno[t] + slot * 10;                                         // :220-234
+        row[0] = cx - (float)xi; row[1] = cy - (float)yi; row[2] = box[2];
+        row[3] = a.norm_bbox ? logf(box[3]) : box[3];
+        row[4] = a.norm_bbox ? logf(box[4]) : box[4];
+        row[5] = a.norm_bbox ? logf(box[5]) : box[5];
+        row[6] = sinf(box[6]); row[7] = cosf(box[6]); row[8] = box[7]; row[9] = box[8];
+    }
+}
+
+}  // namespace
+
+extern "C" int mmt_centerpoint_targets(int B, int num_tasks, const int32_t *class_begin, const int32_t *class_count,
+                                       int max_objs, int max_boxes, int fx, int fy, float x0, float y0, float vx,
+                                       float vy, int out_size_factor, float gaussian_overlap, int min_radius,
+                                       int norm_bbox, const float *boxes, const int32_t *labels,
+                                       const int32_t *box_offsets, float *const *heatmaps, float *const *anno_boxes,
+                                       int64_t *const *inds, uint8_t *const *masks, void *stream) {
+    MMT_REQUIRE_PTR(class_begin);
+    MMT_REQUIRE_PTR(class_count);
+    MMT_REQUIRE_PTR(box_offsets);
+    MMT_REQUIRE_PTR(heatmaps);
+    MMT_REQUIRE_PTR(anno_boxes);
+    MMT_REQUIRE_PTR(inds);
+    MMT_REQUIRE_PTR(masks);
+    if (B <= 0 || B > 65535 || num_tasks <= 0 || num_tasks > kMaxTasks || max_objs <= 0 || max_boxes < 0 || fx <= 0 ||
+        fy <= 0 || out_size_factor <= 0 || !(vx > 0.f) || !(vy > 0.f))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "centerpoint_targets: bad shape (B=%d tasks=%d max_objs=%d map=%dx%d)", B,
+                         num_tasks, max_objs, fx, fy);
+    if (max_boxes > 0) {
+        MMT_REQUIRE_PTR(boxes);
+        MMT_REQUIRE_PTR(labels);
+    }
+    CpArgs a;
+    a.B = B; a.T = num_tasks; a.max_objs = max_objs; a.fx = fx; a.fy = fy; a.norm_bbox = norm_bbox;
+    a.x0 = x0; a.y0 = y0; a.vx = vx; a.vy = vy; a.osf = (float)out_size_factor; a.overlap = gaussian_overlap;
+    a.min_radius = min_radius;
+    a.boxes = boxes; a.labels = labels; a.offsets = box_offsets;
+    int max_cls = 1;
+    for (int t = 0; t < kMaxTasks; ++t) {
+        const bool on = t < num_tasks;
+        a.cls_begin[t] = on ? class_begin[t] : 0;
+        a.cls_count[t] = on ? class_count[t] : 0;
+        a.heatmap[t] = on ? heatmaps[t] : nullptr;
+        a.anno[t] = on ? anno_boxes[t] : nullptr;
+        a.ind[t] = on ? inds[t] : nullptr;
+        a.mask[t] = on ? masks[t] : nullptr;
+        if (on) {
+            if (!heatmaps[t] || !anno_boxes[t] || !inds[t] || !masks[t] || class_count[t] <= 0)
+                return mmt::fail(MMT_ERR_NULL_POINTER, "centerpoint_targets: task %d has a NULL output or no classes", t);
+            if (class_count[t] > max_cls) max_cls = class_count[t];
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t biggest = (int64_t)B * max_cls * fy * fx;
+    hipLaunchKernelGGL(cp_clear_kernel, dim3(mmt::stream_grid(biggest, kBlock, 1024), num_tasks), dim3(kBlock), 0, st, a);
+    if (int rc = mmt::check_launch("centerpoint_targets(clear)")) return rc;
+    const int nb = max_boxes < max_objs ? max_boxes : max_objs;
+    if (nb > 0) {
+        hipLaunchKernelGGL(cp_draw_kernel, dim3(nb, B), dim3(64), 0, st, a);
+        return mmt::check_launch("centerpoint_targets(draw)");
+    }
+    return 0;
+}

@@ -14,6 +14,7 @@ import torch.distributed as dist
 from torch import nn
 
 from ..nets import ResNet, SECONDFPN
+from ...ops.train_targets import centerpoint_targets
 
 __all__ = ['BEVDepthHead']
 
@@ -104,7 +105,20 @@ class BEVDepthHead(nn.Module):
     @torch.no_grad()
     def get_targets(self, gt_bboxes_3d, gt_labels_3d):
         """list over samples of boxes [K,9] (x,y,z,w,l,h,yaw,vx,vy) and labels [K] ->
-        (heatmaps, anno_boxes, inds, masks): lists over tasks of batched tensors."""
+        (heatmaps, anno_boxes, inds, masks): lists over tasks of batched tensors.
+        One HIP op (ops/train_targets.py); CUDA tensors only."""
+        cfg = self.train_cfg
+        osf = cfg['out_size_factor']
+        return centerpoint_targets(
+            gt_bboxes_3d, gt_labels_3d, self.num_classes, cfg['max_objs'] * cfg['dense_reg'],
+            (int(cfg['grid_size'][0]) // osf, int(cfg['grid_size'][1]) // osf), cfg['point_cloud_range'],
+            cfg['voxel_size'], osf, cfg['gaussian_overlap'], cfg['min_radius'], self.norm_bbox)
+
+    @torch.no_grad()
+    def get_targets_torch(self, gt_bboxes_3d, gt_labels_3d):
+        """The same targets from vectorised torch ops: the cross-check of
+        tests/test_train_targets_gpu.py and what the CPU/gloo test of the data-parallel loss
+        normalisers (tests/test_dp_gloo.py) feeds the head with.  Not called by the training step."""
         per_sample = [self.get_targets_single(b, l) for b, l in zip(gt_bboxes_3d, gt_labels_3d)]
         out = []
         for field in range(4):

@@ -48,3 +48,49 @@ def depth_labels(pointclouds, extrinsics, intrinsics, bda_mat, img_hw, downsampl
                   bda_inv.data_ptr(), workspace.data_ptr(), n_ws, bins.data_ptr() if return_bins else None,
                   onehot.data_ptr(), torch.cuda.current_stream().cuda_stream)
     return (onehot, bins) if return_bins else onehot
+
+
+def centerpoint_targets(gt_boxes, gt_labels, class_counts, max_objs, feature_map_size, pc_range, voxel_size,
+                        out_size_factor, gaussian_overlap, min_radius, norm_bbox=True):
+    """BEVDepthHead.get_targets (layers/heads/bev_depth_head.py:86-254) in two launches.
+
+    gt_boxes: list of B CUDA tensors [K_b, 9]; gt_labels: list of B tensors [K_b]; class_counts:
+    number of classes per task (labels are task-major, as in the reference's class_names lists).
+    Returns (heatmaps, anno_boxes, inds, masks): lists over tasks of batched tensors
+    ([B, n_cls, fy, fx], [B, max_objs, 10], int64 [B, max_objs], uint8 [B, max_objs])."""
+    import ctypes
+    if not gt_boxes or not gt_boxes[0].is_cuda:
+        raise RuntimeError("gt_boxes must be a non-empty list of CUDAtensors ")
+    dev = gt_boxes[0].device
+    B, T = len(gt_boxes), len(class_counts)
+    fx, fy = int(feature_map_size[0]), int(feature_map_size[1])
+    counts = [int(b.shape[0]) for b in gt_boxes]
+    if sum(counts):
+        boxes = torch.cat([b.float().reshape(-1, 9) for b in gt_boxes], 0).contiguous()
+        labels = torch.cat([l.reshape(-1) for l in gt_labels], 0).to(torch.int32).contiguous()
+    else:
+        boxes, labels = torch.zeros((1, 9), device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    heatmaps = [torch.empty((B, int(n), fy, fx), dtype=torch.float32, device=dev) for n in class_counts]
+    annos = [torch.empty((B, max_objs, 10), dtype=torch.float32, device=dev) for _ in class_counts]
+    inds = [torch.empty((B, max_objs), dtype=torch.int64, device=dev) for _ in class_counts]
+    masks = [torch.empty((B, max_objs), dtype=torch.uint8, device=dev) for _ in class_counts]
+    begins, run = [], 0
+    for n in class_counts:
+        begins.append(run)
+        run += int(n)
+    i32 = ctypes.c_int32 * T
+    vp = ctypes.c_void_p * T
+    ptrs = lambda ts: vp(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(dev):
+        _lib.call("mmt_centerpoint_targets", B, T, ctypes.cast(i32(*begins), ctypes.c_void_p),
+                  ctypes.cast(i32(*[int(n) for n in class_counts]), ctypes.c_void_p), int(max_objs), max(counts), fx, fy,
+                  float(pc_range[0]), float(pc_range[1]), float(voxel_size[0]), float(voxel_size[1]), int(out_size_factor),
+                  float(gaussian_overlap), int(min_radius), int(bool(norm_bbox)), boxes.data_ptr(), labels.data_ptr(),
+                  offsets.data_ptr(), ctypes.cast(ptrs(heatmaps), ctypes.c_void_p), ctypes.cast(ptrs(annos), ctypes.c_void_p),
+                  ctypes.cast(ptrs(inds), ctypes.c_void_p), ctypes.cast(ptrs(masks), ctypes.c_void_p),
+                  torch.cuda.current_stream().cuda_stream)
+    return heatmaps, annos, inds, masks

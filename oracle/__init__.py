@@ -265,3 +265,20 @@ def depth_labels(points_list, extrinsics, intrinsics, bda_mats, img_hw, downsamp
                               _p(pts), _p(offs), _p(_f32(extrinsics)), _p(_f32(intrinsics)), _p(bda_inv),
                               int(bool(pixel_last)), _p(bins), _p(onehot) if want_onehot else None)
     return bins, onehot
+
+
+def centerpoint_targets_task(boxes, labels, cls_begin, n_cls, max_objs, fx, fy, pc_range, voxel_size, out_size_factor,
+                             gaussian_overlap, min_radius, norm_bbox=True):
+    """layers/heads/bev_depth_head.py:113-254 for one sample and one task (reference slot packing).
+    Returns (heatmap [n_cls, fy, fx], anno [max_objs, 10], ind int64 [max_objs], mask uint8 [max_objs])."""
+    boxes, labels = _f32(boxes).reshape(-1, 9), _i32(labels)
+    heatmap = np.empty((n_cls, fy, fx), np.float32)
+    anno = np.empty((max_objs, 10), np.float32)
+    ind = np.empty((max_objs,), np.int64)
+    mask = np.empty((max_objs,), np.uint8)
+    f = ctypes.c_float
+    lib().oracle_centerpoint_targets_task(len(labels), _p(boxes), _p(labels), int(cls_begin), int(n_cls), int(max_objs),
+                                          int(fx), int(fy), f(pc_range[0]), f(pc_range[1]), f(voxel_size[0]), f(voxel_size[1]),
+                                          int(out_size_factor), f(gaussian_overlap), int(min_radius), int(bool(norm_bbox)),
+                                          _p(heatmap), _p(anno), _p(ind), _p(mask))
+    return heatmap, anno, ind, mask

@@ -354,3 +354,65 @@ void oracle_depth_labels(int B, int N, int F, int H, int W, int ds, float d_lo, 
     free(cellmin);
     free(img);
 }
+
+/* ------------------------------------------------------------------ row f4: CenterPoint targets
+ * layers/heads/bev_depth_head.py:113-254 (get_targets_single) for ONE sample, sequential, with
+ * the reference's slot packing: the boxes of a task are gathered class by class (:142-163) and
+ * box j of that list fills slot j (:214-234).  gaussian_radius / draw_heatmap_gaussian /
+ * gaussian_2d are mmdet3d 1.0.0rc4 functions (un-vendored: PARITY UNPINNED, restated from their
+ * published definitions): radius in fp32 tensor arithmetic, the Gaussian window in float64
+ * numpy cast to fp32, max-combined.
+ *   heatmap [n_cls, fy, fx], anno [max_objs, 10], ind int64 [max_objs], mask uint8 [max_objs]
+ *   (all zero-filled here) for the task owning labels [cls_begin, cls_begin + n_cls). */
+static float oracle_gaussian_radius(float h, float w, float o) {
+    float b1 = h + w, c1 = w * h * (1.f - o) / (1.f + o);
+    float r1 = (b1 + sqrtf(b1 * b1 - 4.f * c1)) / 2.f;
+    float b2 = 2.f * (h + w), c2 = (1.f - o) * w * h;
+    float r2 = (b2 + sqrtf(b2 * b2 - 16.f * c2)) / 2.f;
+    float a3 = 4.f * o, b3 = -2.f * o * (h + w), c3 = (o - 1.f) * w * h;
+    float r3 = (b3 + sqrtf(b3 * b3 - 4.f * a3 * c3)) / 2.f;
+    return fminf(fminf(r1, r2), r3);
+}
+
+void oracle_centerpoint_targets_task(int K, const float *boxes, const int32_t *labels, int cls_begin,
+                                     int n_cls, int max_objs, int fx, int fy, float x0, float y0,
+                                     float vx, float vy, int osf, float overlap, int min_radius,
+                                     int norm_bbox, float *heatmap, float *anno, int64_t *ind,
+                                     uint8_t *mask) {
+    memset(heatmap, 0, sizeof(float) * (size_t)n_cls * fy * fx);
+    memset(anno, 0, sizeof(float) * (size_t)max_objs * 10);
+    memset(ind, 0, sizeof(int64_t) * (size_t)max_objs);
+    memset(mask, 0, (size_t)max_objs);
+    int slot = 0;
+    for (int c = 0; c < n_cls; ++c)                      /* class-major gathering, :142-163 */
+        for (int k = 0; k < K; ++k) {
+            if (labels[k] != cls_begin + c) continue;
+            const int j = slot++;
+            if (j >= max_objs) continue;                 /* num_objs = min(len, max_objs), :171 */
+            const float *box = boxes + (int64_t)k * 9;
+            const float width = box[3] / vx / (float)osf, length = box[4] / vy / (float)osf;
+            if (!(width > 0.f && length > 0.f)) continue;
+            float rf = oracle_gaussian_radius(length, width, overlap);
+            int radius = (rf == rf) ? (int)rf : 0;
+            if (radius < min_radius) radius = min_radius;
+            const float cx = (box[0] - x0) / vx / (float)osf, cy = (box[1] - y0) / vy / (float)osf;
+            const int xi = (int)cx, yi = (int)cy;
+            if (!(xi >= 0 && xi < fx && yi >= 0 && yi < fy)) continue;
+            const double sigma = (double)(2 * radius + 1) / 6.0;
+            const int left = xi < radius ? xi : radius, right = (fx - xi) < radius + 1 ? (fx - xi) : radius + 1;
+            const int top = yi < radius ? yi : radius, bottom = (fy - yi) < radius + 1 ? (fy - yi) : radius + 1;
+            float *hm = heatmap + (int64_t)c * fy * fx;
+            for (int dy = -top; dy < bottom; ++dy)
+                for (int dx = -left; dx < right; ++dx) {
+                    const float g = (float)exp(-(double)(dx * dx + dy * dy) / (2.0 * sigma * sigma));
+                    float *p = hm + (int64_t)(yi + dy) * fx + xi + dx;
+                    if (g > *p) *p = g;
+                }
+            ind[j] = (int64_t)yi * fx + xi;
+            mask[j] = 1;
+            float *row = anno + (int64_t)j * 10;
+            row[0] = cx - (float)xi; row[1] = cy - (float)yi; row[2] = box[2];
+            for (int d = 0; d < 3; ++d) row[3 + d] = norm_bbox ? logf(box[3 + d]) : box[3 + d];
+            row[6] = sinf(box[6]); row[7] = cosf(box[6]); row[8] = box[7]; row[9] = box[8];
+        }
+}

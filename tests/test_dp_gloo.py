@@ -47,7 +47,7 @@ def _data(cfg, n, seed=1):
 
 def _step(head, x, boxes, labels):
     preds = head(x)
-    targets = head.get_targets(boxes, labels)
+    targets = head.get_targets_torch(boxes, labels)   # torch restatement: the HIP op needs a GPU
     return head.loss(targets, preds)
 
 
@@ -60,7 +60,7 @@ def _worker(rank, world, port, out):
     x, boxes, labels = _data(cfg, 4)
     sl = slice(rank * 2, rank * 2 + 2)
     preds = ddp(x[sl])
-    loss = head.loss(head.get_targets(boxes[sl], labels[sl]), preds)
+    loss = head.loss(head.get_targets_torch(boxes[sl], labels[sl]), preds)
     loss.backward()
     if rank == 0:
         out["grads"] = {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}

@@ -103,3 +103,77 @@ def test_depth_labels_errors(mmt_lib):
         depth_labels([torch.zeros(4, 5)], eye, eye, eye[0], (64, 96), 16, (2.0, 58.0, 0.5), 112)
     with pytest.raises(RuntimeError):
         depth_labels(pc, eye, eye, eye[0], (60, 96), 16, (2.0, 58.0, 0.5), 112)     # H % downsample != 0
+
+
+def _sorted_rows(anno, ind, mask):
+    """Slot-order-invariant view of one sample's (anno, ind) rows of valid slots."""
+    m = mask.astype(bool)
+    rows = np.concatenate([ind[m, None].astype(np.float64), anno[m].astype(np.float64)], 1)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_centerpoint_targets_against_oracle(mmt_lib, oracle_mod, seed):
+    """Heat-maps (1e-6: fp32 expf vs the reference's float64 numpy window), centre indices, masks and
+    regression rows against the sequential restatement of bev_depth_head.py:113-254 -- compared
+    order-invariantly because the reference packs each task's boxes densely, class-major."""
+    from mm_training_amd.ops.train_targets import centerpoint_targets
+    rng = np.random.default_rng(900 + seed)
+    B = int(rng.integers(1, 5))
+    class_counts = [[1, 1, 1, 1], [2, 1, 3], [4]][seed % 3]
+    n_cls = sum(class_counts)
+    fx, fy, osf = [(128, 128, 4), (512, 64, 4), (40, 56, 2)][seed % 3]
+    vs = (0.2, 0.2, 8.0)
+    pc = (-vs[0] * osf * fx / 2, -vs[1] * osf * fy / 2, -5.0, vs[0] * osf * fx / 2, vs[1] * osf * fy / 2, 3.0)
+    max_objs = [500, 12, 40][seed % 3]
+    boxes, labels = [], []
+    for b in range(B):
+        k = int(rng.choice([0, 1, 7, 30]))
+        xy = rng.uniform([pc[0] - 3, pc[1] - 3], [pc[3] + 3, pc[4] + 3], (k, 2))          # some centres outside the map
+        dims = rng.uniform(0.3, 12.0, (k, 3))
+        if k > 3:
+            dims[0, 0] = 0.0                       # zero width: skipped (:183)
+            xy[1] = [pc[0] + 0.01, pc[1] + 0.01]   # window clipped at the map corner
+        bx = np.concatenate([xy, rng.uniform(-2, 1, (k, 1)), dims, rng.uniform(-3.2, 3.2, (k, 1)), rng.normal(size=(k, 2))], 1)
+        boxes.append(bx.astype(np.float32))
+        labels.append(rng.integers(0, n_cls, k).astype(np.int64))
+    if sum(len(b) for b in boxes) == 0:
+        boxes[0] = np.array([[0.5, 0.5, 0, 2, 4, 1.5, 0.3, 1, 0]], np.float32)
+        labels[0] = np.array([0])
+    hm, anno, ind, mask = centerpoint_targets([torch.from_numpy(b).cuda() for b in boxes], [torch.from_numpy(l).cuda() for l in labels],
+                                              class_counts, max_objs, (fx, fy), pc, vs, osf, 0.1, 2)
+    begin = 0
+    for t, n in enumerate(class_counts):
+        assert hm[t].shape == (B, n, fy, fx) and anno[t].shape == (B, max_objs, 10)
+        for b in range(B):
+            r_hm, r_anno, r_ind, r_mask = oracle_mod.centerpoint_targets_task(boxes[b][:max_objs], labels[b][:max_objs], begin, n,
+                                                                              max_objs, fx, fy, pc, vs, osf, 0.1, 2)
+            assert np.abs(hm[t][b].cpu().numpy() - r_hm).max() <= 1e-6
+            assert np.array_equal(hm[t][b].cpu().numpy() == 1.0, r_hm == 1.0)            # the loss's positive set
+            got = _sorted_rows(anno[t][b].cpu().numpy(), ind[t][b].cpu().numpy(), mask[t][b].cpu().numpy())
+            ref = _sorted_rows(r_anno, r_ind, r_mask)
+            assert got.shape == ref.shape
+            assert np.allclose(got, ref, rtol=0, atol=2e-6)
+            # invalid slots are zero
+            m = mask[t][b].cpu().numpy().astype(bool)
+            assert not anno[t][b].cpu().numpy()[~m].any() and not ind[t][b].cpu().numpy()[~m].any()
+        begin += n
+
+
+def test_centerpoint_targets_match_torch_cross_check(mmt_lib):
+    """HIP targets == the vectorised torch restatement slot by slot (same slot convention)."""
+    from mm_training_amd.dp import make_config, synthetic_batch
+    from mm_training_amd.layers.heads.bev_depth_head import BEVDepthHead
+    cfg = make_config("tiny")
+    dev = torch.device("cuda", 0)
+    head = BEVDepthHead(**cfg["head_conf"]).to(dev)
+    _, _, _, boxes, labels = synthetic_batch(cfg, dev, seed=11)
+    a = head.get_targets(boxes, labels)
+    b = head.get_targets_torch(boxes, labels)
+    for field in range(4):
+        for t in range(len(a[field])):
+            x, y = a[field][t], b[field][t]
+            assert x.shape == y.shape and x.dtype == y.dtype, (field, t, x.shape, y.shape, x.dtype, y.dtype)
+            # torch's GPU `tensor / python_scalar` multiplies by the rounded reciprocal, the kernel divides:
+            # the centre offsets (values up to fx) may differ in the last bit
+            assert torch.allclose(x.float(), y.float(), rtol=0, atol=2e-5 if field == 1 else 2e-6), (field, t)
