@@ -180,6 +180,21 @@ int mmt_voxel_pooling_forward_planned(int batch_size, int num_points, int num_ch
                                       float *output_features, int64_t out_row_stride, float *partial,
                                       int64_t partial_elems, void *stream);
 
+/* BEV-augmentation warp of the pooled camera map: replaces
+ * BEVDepth.bev_augment_image, models/bev_depth.py:69-84 (two kornia get_affine_matrix2d products
+ * around bda_mat[:3,:3] + kornia warp_affine: bilinear, zeros padding, align_corners=True):
+ *   y[b, v, u, :] = bilinear(x[b], M_b^-1 (u, v, 1)),  M_b = T(+c) bda_b[:3,:3] T(-c), c = ((W-1)/2, (H-1)/2)
+ * Channels-last maps: the row of cell (b,v,u) starts at base + ((b*H+v)*W+u) * row_stride (floats,
+ * >= C, multiple of 4), so input and output may be channel slices of wider buffers -- e.g. the
+ * output can be the camera part of the camera|LiDAR concat buffer (models/bev_depth.py:187-192).
+ * bda_mat fp32 [B, 4, 4] (last row (0,0,0,1)).  C % 4 == 0.
+ * The backward ACCUMULATES into grad_input (caller zero-fills). */
+int mmt_bev_warp_affine(int batch_size, int H, int W, int C, const float *bda_mat, const float *input,
+                        int64_t in_row_stride, float *output, int64_t out_row_stride, void *stream);
+int mmt_bev_warp_affine_backward(int batch_size, int H, int W, int C, const float *bda_mat,
+                                 const float *grad_output, int64_t grad_out_row_stride,
+                                 float *grad_input, int64_t grad_in_row_stride, void *stream);
+
 /* Deformable 3x3 convolution, the data-dependent halves: replaces
  * mmcv 'DCN' (DeformConv2dPack) inside DepthNet, layers/backbones/lss_fpn.py:189-197.
  * stride 1, pad 1, dilation 1, deform_groups 1.  All tensors channels-last fp32:

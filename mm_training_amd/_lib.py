@@ -36,6 +36,8 @@ SIGNATURES = {
     "mmt_depth_labels_workspace_elems": (_c_i64, [_c_int] * 5),
     "mmt_depth_labels": (_c_int, [_c_int] * 7 + [ctypes.c_float, ctypes.c_float, _c_int] + [_c_ptr] * 6 + [_c_i64, _c_ptr, _c_ptr, _c_ptr]),
     "mmt_centerpoint_targets": (_c_int, [_c_int, _c_int, _c_ptr, _c_ptr] + [_c_int] * 4 + [ctypes.c_float] * 4 + [_c_int, ctypes.c_float, _c_int, _c_int] + [_c_ptr] * 7 + [_c_ptr]),
+    "mmt_bev_warp_affine": (_c_int, [_c_int] * 4 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
+    "mmt_bev_warp_affine_backward": (_c_int, [_c_int] * 4 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "mmt_dcn_im2col": (_c_int, [_c_int] * 5 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_dcn_col2im": (_c_int, [_c_int] * 5 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr]),

@@ -1,0 +1,122 @@
+// BEV-augmentation warp of the pooled camera map:
+// models/bev_depth.py:69-84 (BEVDepth.bev_augment_image) =
+//   mat = T(+c) @ bda_mat[:3,:3] @ T(-c),  c = ((W-1)/2, (H-1)/2)      (kornia get_affine_matrix2d x2)
+//   y   = kornia.geometry.warp_affine(x, mat[:, :2, :3], dsize=(H, W))   bilinear, zeros, align_corners=True
+// i.e.  y[b, :, v, u] = bilinear(x[b], M^-1 (u, v, 1))  in pixel coordinates.
+// The reference builds the matrices with ~10 small tensor ops, inverts them with a batched LU
+// and calls grid_sample on an NCHW tensor.  Here the pooled map is channels-last already
+// ([B, H, W, C], one contiguous C-row per cell): one lane group per output cell gathers the four
+// neighbour rows as float4 columns; the 2x3 matrix and its inverse are formed in-kernel.  Input
+// and output rows may live inside wider channels-last buffers (row strides), so the warped map
+// can be written straight into the camera|LiDAR concat buffer (models/bev_depth.py:187-192).
+#include "mmt_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct WarpArgs {
+    int B, H, W, C;
+    int64_t in_stride, out_stride;     // floats between consecutive cells' rows
+    const float *bda;                  // [B, 4, 4]
+    const float *x;                    // forward: input;  backward: grad of the output
+    float *y;                          // forward: output; backward: grad of the input (accumulated into)
+};
+
+// inverse of the 2x3 affine map of bev_augment_image for sample b: src = A^-1 (dst - t).
+// Matrix algebra in double (a handful of flops per lane): source coordinates reach ~W, where an fp32
+// ulp is 3e-5 px, and the result is cast to fp32 only once -- the same as the oracle.
+__device__ __forceinline__ void inverse_affine(const float *bda, int H, int W, double (&m)[6]) {
+    const double cx = (W - 1) / 2.0, cy = (H - 1) / 2.0;
+    const double a = bda[0], b = bda[1], c = bda[4], d = bda[5];
+    // T(+c) R T(-c): translation column = R[:2,:2] (-c) + R[:2,2] + c   (R[2,:] = (0,0,1) for a BDA matrix)
+    const double tx = (a * -cx + b * -cy) + bda[2] + cx;
+    const double ty = (c * -cx + d * -cy) + bda[6] + cy;
+    const double det = a * d - b * c;
+    const double ia = d / det, ib = -b / det, ic = -c / det, id = a / det;
+    m[0] = ia; m[1] = ib; m[2] = -(ia * tx + ib * ty);
+    m[3] = ic; m[4] = id; m[5] = -(ic * tx + id * ty);
+}
+
+// one lane group of C/4 lanes per output cell
+template <bool BACKWARD>
+__global__ __launch_bounds__(kBlock) void bev_warp_kernel(WarpArgs a) {
+    const int C4 = a.C >> 2;
+    const int64_t cells = (int64_t)a.B * a.H * a.W;
+    const int64_t total = cells * C4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t cell = i / C4;
+        const int c4 = (int)(i - cell * C4);
+        const int b = (int)(cell / ((int64_t)a.H * a.W));
+        const int rem = (int)(cell - (int64_t)b * a.H * a.W);
+        const int v = rem / a.W, u = rem - v * a.W;
+        double m[6];
+        inverse_affine(a.bda + b * 16, a.H, a.W, m);
+        const float sx = (float)(m[0] * u + m[1] * v + m[2]);
+        const float sy = (float)(m[3] * u + m[4] * v + m[5]);
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const float w[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+        const int xs[4] = {x0, x0 + 1, x0, x0 + 1}, ys[4] = {y0, y0, y0 + 1, y0 + 1};
+        const float *img = a.x + (int64_t)b * a.H * a.W * a.in_stride;
+        if (!BACKWARD) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (xs[k] >= 0 && xs[k] < a.W && ys[k] >= 0 && ys[k] < a.H && sx == sx && sy == sy) {
+                    const float4 p = *reinterpret_cast<const float4 *>(img + ((int64_t)ys[k] * a.W + xs[k]) * a.in_stride + c4 * 4);
+                    acc.x += w[k] * p.x; acc.y += w[k] * p.y; acc.z += w[k] * p.z; acc.w += w[k] * p.w;
+                }
+            }
+            *reinterpret_cast<float4 *>(a.y + cell * a.out_stride + c4 * 4) = acc;
+        } else {
+            // a.x = grad of the warped map (row stride in_stride), a.y = grad of the source map
+            const float4 g = *reinterpret_cast<const float4 *>(a.x + cell * a.in_stride + c4 * 4);
+            float *gimg = a.y + (int64_t)b * a.H * a.W * a.out_stride;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (xs[k] >= 0 && xs[k] < a.W && ys[k] >= 0 && ys[k] < a.H && sx == sx && sy == sy && w[k] != 0.f) {
+                    float *p = gimg + ((int64_t)ys[k] * a.W + xs[k]) * a.out_stride + c4 * 4;
+                    atomicAdd(p, w[k] * g.x); atomicAdd(p + 1, w[k] * g.y);
+                    atomicAdd(p + 2, w[k] * g.z); atomicAdd(p + 3, w[k] * g.w);
+                }
+            }
+        }
+    }
+}
+
+int check(const char *who, int B, int H, int W, int C, const void *bda, const void *x, const void *y,
+          int64_t in_stride, int64_t out_stride) {
+    if (!bda || !x || !y) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: NULL pointer", who);
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || in_stride < C || out_stride < C || (in_stride & 3) ||
+        (out_stride & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: need C %% 4 == 0, row strides >= C and multiples of 4, 16-byte aligned "
+                                            "buffers (B=%d %dx%d C=%d)", who, B, H, W, C);
+    if ((int64_t)B * H * W * (in_stride > out_stride ? in_stride : out_stride) >= (1ll << 40))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: map too large", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mmt_bev_warp_affine(int B, int H, int W, int C, const float *bda_mat, const float *input,
+                                   int64_t in_row_stride, float *output, int64_t out_row_stride, void *stream) {
+    if (int rc = check("bev_warp_affine", B, H, W, C, bda_mat, input, output, in_row_stride, out_row_stride)) return rc;
+    WarpArgs a{B, H, W, C, in_row_stride, out_row_stride, bda_mat, input, output};
+    const int64_t work = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(bev_warp_kernel<false>, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    return mmt::check_launch("bev_warp_affine");
+}
+
+extern "C" int mmt_bev_warp_affine_backward(int B, int H, int W, int C, const float *bda_mat, const float *grad_output,
+                                            int64_t grad_out_row_stride, float *grad_input,
+                                            int64_t grad_in_row_stride, void *stream) {
+    if (int rc = check("bev_warp_affine_backward", B, H, W, C, bda_mat, grad_output, grad_input, grad_out_row_stride,
+                       grad_in_row_stride))
+        return rc;
+    WarpArgs a{B, H, W, C, grad_out_row_stride, grad_in_row_stride, bda_mat, grad_output, grad_input};
+    const int64_t work = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(bev_warp_kernel<true>, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    return mmt::check_launch("bev_warp_affine_backward");
+}

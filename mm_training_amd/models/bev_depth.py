@@ -12,6 +12,7 @@ from torch import nn
 from ..layers.backbones.lss_fpn import LSSFPN
 from ..layers.heads.bev_depth_head import BEVDepthHead
 from ..lidar import LidarEncoder
+from ..ops.bev_warp import bev_warp_affine, bev_warp_concat
 
 __all__ = ['BEVDepth', 'BEVFuseLayer', 'BEVDepthLiDAR']
 
@@ -43,7 +44,12 @@ class BEVDepth(nn.Module):
 
     def bev_augment_image(self, x, bda_mat):
         """models/bev_depth.py:69-84: rotate/flip the camera BEV by the BEV-aug matrix about
-        the map centre."""
+        the map centre -- one HIP launch (ops/bev_warp.py)."""
+        return bev_warp_affine(x, bda_mat)
+
+    def bev_augment_image_torch(self, x, bda_mat):
+        """The same warp from torch ops (matrix products, batched inverse, grid_sample): the
+        cross-check of tests/test_bev_warp_gpu.py, not used by forward."""
         b, _, h, w = x.shape
         h, w = h - 1, w - 1
         t_pos = torch.eye(3, device=x.device, dtype=x.dtype)
@@ -98,8 +104,9 @@ class BEVDepthLiDAR(BEVDepth):
         depth_pred, img_bev, lidar_bev, lidar_bev_ret, cam_bev_ret = None, None, None, None, None
         if self.use_cam:
             img_bev, depth_pred = self.backbone(img, mats_dict, lidar_oracle, timestamps, is_return_depth=True)
-            img_bev = self.bev_augment_image(img_bev, mats_dict['bda_mat'])
-            cam_bev_ret = img_bev
+            if not self.use_lidar:
+                img_bev = self.bev_augment_image(img_bev, mats_dict['bda_mat'])
+                cam_bev_ret = img_bev
         if self.use_lidar:
             batch_size = len(lidar)
             voxels, num_points, coors = self.lidar_encoder.voxelize(lidar)
@@ -109,7 +116,11 @@ class BEVDepthLiDAR(BEVDepth):
         if self.use_lidar and self.use_cam:
             if lidar_bev.shape[-2:] != img_bev.shape[-2:]:
                 lidar_bev = F.interpolate(lidar_bev, size=(img_bev.shape[2], img_bev.shape[3]))
-            bev_fused = self.bev_fuse(torch.cat([img_bev, lidar_bev], dim=1))
+            # warp (models/bev_depth.py:176) + concat (:189) in one pass: the warped camera map is
+            # written straight into the camera|LiDAR buffer
+            fused_in = bev_warp_concat(img_bev, mats_dict['bda_mat'], lidar_bev)
+            cam_bev_ret = fused_in[:, :img_bev.shape[1]]
+            bev_fused = self.bev_fuse(fused_in)
         elif self.use_cam:
             bev_fused = img_bev
         else:

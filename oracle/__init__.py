@@ -282,3 +282,12 @@ def centerpoint_targets_task(boxes, labels, cls_begin, n_cls, max_objs, fx, fy, 
                                           int(out_size_factor), f(gaussian_overlap), int(min_radius), int(bool(norm_bbox)),
                                           _p(heatmap), _p(anno), _p(ind), _p(mask))
     return heatmap, anno, ind, mask
+
+
+def bev_warp_affine(x_nhwc, bda_mat):
+    """models/bev_depth.py:69-84 on a channels-last map [B, H, W, C]; bda_mat [B, 4, 4]."""
+    x = _f32(x_nhwc)
+    B, H, W, C = x.shape
+    y = np.empty_like(x)
+    lib().oracle_bev_warp_affine(B, H, W, C, _p(_f32(bda_mat)), _p(x), _p(y))
+    return y

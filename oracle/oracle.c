@@ -416,3 +416,37 @@ void oracle_centerpoint_targets_task(int K, const float *boxes, const int32_t *l
             row[6] = sinf(box[6]); row[7] = cosf(box[6]); row[8] = box[7]; row[9] = box[8];
         }
 }
+
+/* ------------------------------------------------------------------ row f3: BEV-augmentation warp
+ * models/bev_depth.py:69-84 with kornia 0.6 semantics (un-vendored: PARITY UNPINNED): the matrix
+ * product T(+c) R T(-c), kornia.warp_affine = normalise to [-1,1], invert, affine_grid +
+ * grid_sample(bilinear, zeros, align_corners=True) -- which in pixel coordinates is
+ * y(u,v) = bilinear(x, M^-1 (u,v,1)).  Matrix algebra in double, sampling in fp32.
+ * x, y channels-last [B,H,W,C]. */
+void oracle_bev_warp_affine(int B, int H, int W, int C, const float *bda, const float *x, float *y) {
+    for (int b = 0; b < B; ++b) {
+        const float *R = bda + b * 16;
+        const double cx = (W - 1) / 2.0, cy = (H - 1) / 2.0;
+        const double a = R[0], bb = R[1], c = R[4], d = R[5];
+        const double tx = (a * -cx + bb * -cy) + R[2] + cx, ty = (c * -cx + d * -cy) + R[6] + cy;
+        const double det = a * d - bb * c;
+        const double ia = d / det, ib = -bb / det, ic = -c / det, id = a / det;
+        const double itx = -(ia * tx + ib * ty), ity = -(ic * tx + id * ty);
+        for (int v = 0; v < H; ++v)
+            for (int u = 0; u < W; ++u) {
+                const float sx = (float)(ia * u + ib * v + itx), sy = (float)(ic * u + id * v + ity);
+                const float fx0 = floorf(sx), fy0 = floorf(sy);
+                const int x0 = (int)fx0, y0 = (int)fy0;
+                const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                const float w[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+                const int xs[4] = {x0, x0 + 1, x0, x0 + 1}, ys[4] = {y0, y0, y0 + 1, y0 + 1};
+                float *out = y + (((int64_t)b * H + v) * W + u) * C;
+                for (int ch = 0; ch < C; ++ch) out[ch] = 0.f;
+                for (int k = 0; k < 4; ++k) {
+                    if (xs[k] < 0 || xs[k] >= W || ys[k] < 0 || ys[k] >= H) continue;
+                    const float *p = x + (((int64_t)b * H + ys[k]) * W + xs[k]) * C;
+                    for (int ch = 0; ch < C; ++ch) out[ch] += w[k] * p[ch];
+                }
+            }
+    }
+}

@@ -1,0 +1,92 @@
+"""GPU parity of the BEV-augmentation warp against the oracle and the
+torch (grid_sample) restatement of kornia.warp_affine; backward against torch autograd."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bda(B, rng, flip=True):
+    m = torch.eye(4).repeat(B, 1, 1)
+    for b in range(B):
+        a = float(rng.uniform(-0.4, 0.4))
+        s = float(rng.uniform(0.9, 1.1))
+        r = torch.tensor([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]], dtype=torch.float32) * s
+        if flip and b % 2:
+            r[:, 1] = -r[:, 1]
+        m[b, :2, :2] = r
+    return m
+
+
+@pytest.mark.parametrize("shape", [(2, 80, 128, 128), (3, 16, 40, 56), (1, 4, 7, 5), (2, 64, 64, 512)])
+def test_forward_against_oracle_and_torch(mmt_lib, oracle_mod, shape):
+    from mm_training_amd.models.bev_depth import BEVDepth
+    from mm_training_amd.ops.bev_warp import bev_warp_affine
+    B, C, H, W = shape
+    rng = np.random.default_rng(B * 100 + C)
+    x = torch.from_numpy(rng.standard_normal((B, H, W, C)).astype(np.float32)).cuda().permute(0, 3, 1, 2)   # channels-last view
+    bda = _bda(B, rng).cuda()
+    y = bev_warp_affine(x, bda)
+    assert y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last)
+    ref = oracle_mod.bev_warp_affine(x.permute(0, 2, 3, 1).cpu().numpy(), bda.cpu().numpy())
+    assert np.abs(y.permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= 1e-6      # same coordinates (double -> fp32 once), same fp32 sum order
+    t = BEVDepth.bev_augment_image_torch(None, x, bda)
+    # grid_sample goes through normalised [-1, 1] coordinates and an LU inverse: source coordinates agree to
+    # ~1e-4 px, which on white-noise input (neighbour differences of several units) is ~1e-3 in value
+    assert (y - t).abs().max().item() <= 3e-3 and (y - t).abs().mean().item() <= 1e-4
+    # identity matrix: exact copy
+    eye = torch.eye(4).repeat(B, 1, 1).cuda()
+    assert torch.equal(bev_warp_affine(x, eye), x.contiguous(memory_format=torch.channels_last))
+    # NCHW-contiguous input takes the same path after a layout change
+    assert torch.equal(bev_warp_affine(x.contiguous(), bda), y)
+
+
+def test_backward_against_torch_autograd(mmt_lib):
+    from mm_training_amd.models.bev_depth import BEVDepth
+    from mm_training_amd.ops.bev_warp import bev_warp_affine
+    rng = np.random.default_rng(3)
+    B, C, H, W = 2, 80, 128, 128
+    x0 = torch.from_numpy(rng.standard_normal((B, H, W, C)).astype(np.float32)).cuda().permute(0, 3, 1, 2)
+    bda = _bda(B, rng).cuda()
+    go = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).cuda()
+    xa = x0.clone().requires_grad_(True)
+    bev_warp_affine(xa, bda).backward(go)
+    xb = x0.clone().requires_grad_(True)
+    BEVDepth.bev_augment_image_torch(None, xb, bda).backward(go)
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-2 and (xa.grad - xb.grad).abs().mean().item() <= 5e-4
+    # adjoint identity <warp(x), g> == <x, warp^T(g)>
+    lhs = (bev_warp_affine(x0, bda).double() * go.double()).sum().item()
+    rhs = (x0.double() * xa.grad.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)) + 1e-2
+
+
+def test_concat_buffer(mmt_lib):
+    """The warped camera map lands in channels [0, C) of the camera|LiDAR buffer, the LiDAR map in
+    [C, C+C2) (models/bev_depth.py:187-192); gradients flow to both."""
+    from mm_training_amd.ops.bev_warp import bev_warp_affine, bev_warp_concat
+    rng = np.random.default_rng(4)
+    B, C, C2, H, W = 2, 80, 64, 128, 128
+    x = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).cuda().requires_grad_(True)
+    other = torch.from_numpy(rng.standard_normal((B, C2, H, W)).astype(np.float32)).cuda().requires_grad_(True)
+    bda = _bda(B, rng).cuda()
+    fused = bev_warp_concat(x, bda, other)
+    assert fused.shape == (B, C + C2, H, W) and fused.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.cat([bev_warp_affine(x.detach(), bda), other.detach()], 1)
+    assert torch.equal(fused, ref)
+    go = torch.from_numpy(rng.standard_normal((B, C + C2, H, W)).astype(np.float32)).cuda()
+    fused.backward(go)
+    x2 = x.detach().clone().requires_grad_(True)
+    bev_warp_affine(x2, bda).backward(go[:, :C].contiguous())
+    assert (x.grad - x2.grad).abs().max().item() <= 1e-5        # atomics: summation order differs run to run
+    assert torch.equal(other.grad, go[:, C:])
+
+
+def test_errors(mmt_lib):
+    from mm_training_amd import _lib
+    from mm_training_amd.ops.bev_warp import bev_warp_affine
+    bda = torch.eye(4).repeat(1, 1, 1).cuda()
+    with pytest.raises(RuntimeError, match="CUDA"):
+        bev_warp_affine(torch.zeros(1, 8, 4, 4), bda)
+    with pytest.raises(_lib.MmtError, match="C % 4"):
+        bev_warp_affine(torch.zeros(1, 6, 4, 4).cuda(), bda)
