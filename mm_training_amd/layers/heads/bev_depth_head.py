@@ -84,6 +84,9 @@ class BEVDepthHead(nn.Module):
         self.gaussian_overlap = gaussian_overlap
         self.min_radius = min_radius
         self.loss_bbox_weight = float(loss_bbox.get('loss_weight', 1.0))
+        # on-device once: building it inside loss() is a blocking pageable host->device copy every step
+        self.register_buffer('code_weights', torch.tensor((train_cfg or {}).get('code_weights', [1.0] * 10), dtype=torch.float32),
+                             persistent=False)
         bb = {k: v for k, v in dict(bev_backbone_conf).items() if k not in ('type', 'norm_eval')}
         self.trunk = ResNet(**bb)
         self.neck = SECONDFPN(**{k: v for k, v in dict(bev_neck_conf).items() if k != 'type'})
@@ -197,7 +200,7 @@ class BEVDepthHead(nn.Module):
             norm = norm / dist.get_world_size()
         cls_norm = norm[:n_task].clamp(min=1)
         box_norm = norm[n_task:].clamp(min=1e-4)
-        code_weights = torch.tensor(self.train_cfg['code_weights'], device=norm.device)
+        code_weights = self.code_weights
         total = 0
         for t, preds in enumerate(preds_dicts):
             p = preds[0]

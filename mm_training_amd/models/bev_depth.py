@@ -5,6 +5,8 @@ timestamps)`` -> ``(preds, depth_pred, lidar_bev, cam_bev)`` (models/bev_depth.p
 ``lidar_conf`` builds a mm_training_amd.lidar.LidarEncoder (the three calls at :181-183
 hit the HIP kernels) instead of an mmdet3d MVXFasterRCNN.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -94,6 +96,7 @@ class BEVDepthLiDAR(BEVDepth):
         super().__init__(backbone_conf, head_conf, is_train_depth=False, use_cam=use_cam)
         self.use_cam = use_cam
         self.use_lidar = use_lidar
+        self.sync_free_lidar = os.environ.get("MMT_LIDAR_SYNC_FREE", "1") != "0"
         if use_lidar:
             self.lidar_encoder = LidarEncoder(**{k: v for k, v in dict(lidar_conf).items() if k != 'type'})
         if use_cam and use_lidar:
@@ -108,10 +111,17 @@ class BEVDepthLiDAR(BEVDepth):
                 img_bev = self.bev_augment_image(img_bev, mats_dict['bda_mat'])
                 cam_bev_ret = img_bev
         if self.use_lidar:
-            batch_size = len(lidar)
-            voxels, num_points, coors = self.lidar_encoder.voxelize(lidar)
-            voxel_feats = self.lidar_encoder.pts_voxel_encoder(voxels, num_points, coors)
-            lidar_bev = self.lidar_encoder.pts_middle_encoder(voxel_feats, coors, batch_size)
+            if self.sync_free_lidar:
+                # same three stages in the voxelizer's fixed-capacity layout: no device->host copy of
+                # the voxel count in the middle of the step (LidarEncoder.forward_bev)
+                lidar_bev = self.lidar_encoder.forward_bev(lidar)
+            else:
+                # the reference's call sequence (models/bev_depth.py:180-183); voxelize() returns
+                # compacted [M, ...] tensors, i.e. M travels to the host
+                batch_size = len(lidar)
+                voxels, num_points, coors = self.lidar_encoder.voxelize(lidar)
+                voxel_feats = self.lidar_encoder.pts_voxel_encoder(voxels, num_points, coors)
+                lidar_bev = self.lidar_encoder.pts_middle_encoder(voxel_feats, coors, batch_size)
             lidar_bev_ret = lidar_bev
         if self.use_lidar and self.use_cam:
             if lidar_bev.shape[-2:] != img_bev.shape[-2:]:
