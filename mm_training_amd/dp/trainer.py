@@ -59,6 +59,26 @@ def synthetic_batch(cfg, device, seed=0, batch_size=None):
     return imgs.to(device), mats, pcs, boxes, labels
 
 
+def _batched_bn_counters(model):
+    """nn.BatchNorm2d bumps `num_batches_tracked` with one tiny kernel per layer and step (129 launches
+    at cfg2).  The counter only matters for momentum=None; keep the state identical but advance all
+    counters with ONE foreach launch per step: the modules' own increment is skipped by running
+    F.batch_norm directly in training mode."""
+    counters = []
+
+    def bn_forward(self, x):
+        if self.training and self.track_running_stats and self.momentum is not None:
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+        return nn.BatchNorm2d.forward(self, x)
+
+    import types
+    for m in model.modules():
+        if type(m) is nn.BatchNorm2d and m.track_running_stats and m.momentum is not None:
+            m.forward = types.MethodType(bn_forward, m)
+            counters.append(m.num_batches_tracked)
+    return counters
+
+
 class TrainStep(nn.Module):
     """Owns model + optimiser and runs one optimisation step per call."""
 
@@ -101,6 +121,7 @@ class TrainStep(nn.Module):
         self.register_buffer("mean", torch.tensor(IMG_MEAN).view(1, 1, 1, 3, 1, 1), persistent=False)
         self.register_buffer("std", torch.tensor(IMG_STD).view(1, 1, 1, 3, 1, 1), persistent=False)
         self.to(device)
+        self._bn_counters = _batched_bn_counters(self.model) if device.type == "cuda" else []
 
     # ---- exps/mm_training_aim.py:510-512
     def normalize_images(self, sweep_imgs):
@@ -166,6 +187,8 @@ class TrainStep(nn.Module):
         """One optimisation step; returns the (detached) loss tensors, no host sync."""
         self.optimizer.zero_grad(set_to_none=True)
         loss, det, dep = self.forward_loss(batch)
+        if self._bn_counters:
+            torch._foreach_add_(self._bn_counters, 1)      # see _batched_bn_counters
         loss.backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip, foreach=True)
         self.optimizer.step()

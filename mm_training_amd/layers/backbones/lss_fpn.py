@@ -56,7 +56,12 @@ class ASPP(nn.Module):
     def forward(self, x):
         # bilinear upsampling of a 1x1 map with align_corners=True (lss_fpn.py:96-99) is a broadcast
         x5 = self.global_avg_pool(x).expand(-1, -1, x.shape[2], x.shape[3])
-        x = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), x5), 1)
+        branches = (self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), x5)
+        if branches[0].is_contiguous(memory_format=torch.channels_last) and not branches[0].is_contiguous():
+            # the broadcast 1x1 branch has no memory format of its own and would make cat() pick NCHW,
+            # i.e. a 2560-channel layout conversion in front of the next convolution
+            branches = tuple(b.contiguous(memory_format=torch.channels_last) for b in branches)
+        x = torch.cat(branches, 1)
         return self.dropout(self.relu(self.bn1(self.conv1(x))))
 
 
