@@ -303,6 +303,26 @@ int mmt_centerpoint_targets(int batch_size, int num_tasks, const int32_t *class_
                             float *const *heatmaps, float *const *anno_boxes, int64_t *const *inds,
                             uint8_t *const *masks, void *stream);
 
+/* ------------------------------------------------- dense-net glue: BatchNorm + add + ReLU
+ * Training-mode BatchNorm2d fused with the optional residual add and ReLU that follow it in the
+ * ResNet / FPN / DepthNet blocks (mmcv / mmdet modules in the reference: layers/backbones/lss_fpn.py,
+ * layers/heads/bev_depth_head.py), for channels-last fp32 activations viewed as [R = N*H*W, C]:
+ *   y = relu?( (x - mean) * rstd * weight + bias  [+ residual] ),  batch statistics over R,
+ *   running_mean / running_var updated with `momentum` (unbiased variance), torch semantics.
+ * 3 + 5 streaming passes instead of 5 + 8 for MIOpen BN + ATen add / relu.
+ *   workspace fp32 [mmt_bn_workspace_elems(C)] scratch (per-workgroup partial sums; may be shared by
+ *             all layers that run on one stream)
+ *   save      fp32 [4*C]: mean | rstd | scale | shift, written by forward, read by backward
+ * C % 4 == 0 and (C <= 1024 or C == 2048).  Backward: grad_residual (if has_residual) is the
+ * ReLU-masked grad_y; y is needed only when relu && has_residual (the mask comes from the output). */
+int64_t mmt_bn_workspace_elems(int C);
+int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float *residual, const float *weight,
+                        const float *bias, float *running_mean, float *running_var, float momentum,
+                        float eps, int relu, float *workspace, float *save, float *y, void *stream);
+int mmt_bn_relu_backward(int64_t R, int C, const float *x, const float *y, const float *grad_y,
+                         const float *save, int relu, int has_residual, float *workspace, float *grad_x,
+                         float *grad_residual, float *grad_weight, float *grad_bias, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,373 @@
+// Training-mode BatchNorm2d fused with the residual add and the ReLU that follow it in the dense
+// nets (ResNet-50 / SECONDFPN / DepthNet / BEV trunk of layers/backbones/lss_fpn.py and
+// layers/heads/bev_depth_head.py -- mmcv/mmdet modules in the reference), for channels-last fp32
+// activations [R = N*H*W rows, C channels].
+//
+// These layers are pure HBM streaming (0.25 flop/byte).  Unfused (MIOpen BN + ATen add / relu) one
+// conv-bn-relu costs 5 passes over the activation forward and 8 backward; fused:
+//   forward : bn_stats (1 read)  ->  bn_finalize (C values)  ->  bn_apply (1 read [+ residual] , 1 write)
+//   backward: bn_bwd_reduce (dy, x [, y])  ->  bn_bwd_finalize  ->  bn_bwd_dx (dy, x [, y] -> dx [, dres])
+// i.e. 3 + 5 passes.  The ReLU mask is recomputed from x (plain variant) or read from the saved
+// output y (residual variant); nothing but mean / rstd is saved beyond what autograd keeps anyway.
+//
+// Layout: one float4 (4 channels) per lane, TPR = C/4 lanes per row (or 256 lanes looping over
+// C/1024 column blocks when C > 1024), 256/TPR rows per workgroup and trip; every thread keeps
+// its channels for the whole kernel, so per-channel statistics accumulate in registers and meet
+// in LDS once per workgroup and leave as one partial row per workgroup, summed (in double) by the
+// finalize kernel.  Loads in the row loops are
+// unconditional (clamped row index, zero weight) so several rows stay in flight per lane.
+#include "mmt_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRowsInFlight = 4;
+
+struct BnGeom {
+    int C4;        // float4 columns per row
+    int tpr;       // threads per row (<= 256)
+    int kc;        // column blocks per thread (C4 = tpr * kc)
+    int rpi;       // rows per workgroup and trip
+};
+
+struct BnArgs {
+    int64_t R;
+    int C;
+    BnGeom g;
+    int relu, has_res;
+    float momentum, eps;
+    const float *x, *res, *y_in, *dy;
+    const float *weight, *bias;
+    float *running_mean, *running_var;
+    float *acc;            // [blocks, 2*C] per-workgroup partial sums (scratch)
+    float *save_mean, *save_rstd;
+    float *scale, *shift;  // [C] each (workspace): y = x * scale + shift
+    float *y, *dx, *dres, *dweight, *dbias;
+    float *coef;           // [2*C] backward: mean(dy'), mean(dy' * xhat)
+};
+
+constexpr int kMaxKC = 2;  // C <= 2048
+
+// Sum of (a, b) per channel over this workgroup's rows -> partial[blockIdx][0:C], [C:2C] (plain stores:
+// 2*C same-address atomics per workgroup cost 150 us per launch, measured).
+// MODE 0: a = x, b = x*x.   MODE 1: a = dy', b = dy' * xhat  (dy' = relu-masked dy).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t rows_per_block) {
+    __shared__ float4 red[2][kBlock];
+    const BnGeom g = a.g;
+    const int tid = threadIdx.x;
+    const int rsub = tid / g.tpr, col = tid - rsub * g.tpr;
+    const bool live = rsub < g.rpi;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block) < a.R ? (r_begin + rows_per_block) : a.R;
+    float4 sa[kMaxKC], sb[kMaxKC];
+    float4 sc[kMaxKC], sh[kMaxKC], mean[kMaxKC], rstd[kMaxKC];
+#pragma unroll
+    for (int k = 0; k < kMaxKC; ++k) {
+        sa[k] = sb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1 && k < g.kc) {
+            const int c = (col + k * g.tpr) * 4;
+            sc[k] = *reinterpret_cast<const float4 *>(a.scale + c);
+            sh[k] = *reinterpret_cast<const float4 *>(a.shift + c);
+            mean[k] = *reinterpret_cast<const float4 *>(a.save_mean + c);
+            rstd[k] = *reinterpret_cast<const float4 *>(a.save_rstd + c);
+        }
+    }
+    if (live && r_begin < r_end) {
+        const int64_t last = r_end - 1;
+        for (int64_t r0 = r_begin + rsub; r0 < r_end; r0 += (int64_t)kRowsInFlight * g.rpi) {
+#pragma unroll
+            for (int k = 0; k < kMaxKC; ++k) {
+                if (k >= g.kc) break;
+                float4 vx[kRowsInFlight], vd[kRowsInFlight], vy[kRowsInFlight];
+                float wgt[kRowsInFlight];
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) {
+                    const int64_t r = r0 + (int64_t)u * g.rpi;
+                    wgt[u] = r < r_end ? 1.f : 0.f;
+                    const int64_t off = ((r < r_end ? r : last) * g.C4 + col + k * g.tpr) * 4;
+                    vx[u] = *reinterpret_cast<const float4 *>(a.x + off);
+                    if (MODE == 1) {
+                        vd[u] = *reinterpret_cast<const float4 *>(a.dy + off);
+                        if (a.has_res) vy[u] = *reinterpret_cast<const float4 *>(a.y_in + off);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) {
+                    if (MODE == 0) {
+                        const float w = wgt[u];
+                        sa[k].x += w * vx[u].x; sa[k].y += w * vx[u].y; sa[k].z += w * vx[u].z; sa[k].w += w * vx[u].w;
+                        sb[k].x += w * vx[u].x * vx[u].x; sb[k].y += w * vx[u].y * vx[u].y;
+                        sb[k].z += w * vx[u].z * vx[u].z; sb[k].w += w * vx[u].w * vx[u].w;
+                    } else {
+                        float4 d = vd[u];
+                        d.x *= wgt[u]; d.y *= wgt[u]; d.z *= wgt[u]; d.w *= wgt[u];
+                        if (a.relu) {
+                            if (a.has_res) {
+                                if (!(vy[u].x > 0.f)) d.x = 0.f;
+                                if (!(vy[u].y > 0.f)) d.y = 0.f;
+                                if (!(vy[u].z > 0.f)) d.z = 0.f;
+                                if (!(vy[u].w > 0.f)) d.w = 0.f;
+                            } else {
+                                if (!(vx[u].x * sc[k].x + sh[k].x > 0.f)) d.x = 0.f;
+                                if (!(vx[u].y * sc[k].y + sh[k].y > 0.f)) d.y = 0.f;
+                                if (!(vx[u].z * sc[k].z + sh[k].z > 0.f)) d.z = 0.f;
+                                if (!(vx[u].w * sc[k].w + sh[k].w > 0.f)) d.w = 0.f;
+                            }
+                        }
+                        sa[k].x += d.x; sa[k].y += d.y; sa[k].z += d.z; sa[k].w += d.w;
+                        sb[k].x += d.x * ((vx[u].x - mean[k].x) * rstd[k].x);
+                        sb[k].y += d.y * ((vx[u].y - mean[k].y) * rstd[k].y);
+                        sb[k].z += d.z * ((vx[u].z - mean[k].z) * rstd[k].z);
+                        sb[k].w += d.w * ((vx[u].w - mean[k].w) * rstd[k].w);
+                    }
+                }
+            }
+        }
+    }
+    // rows of the workgroup meet in LDS, then one partial row per workgroup
+#pragma unroll
+    for (int k = 0; k < kMaxKC; ++k) {
+        if (k >= g.kc) break;
+        __syncthreads();
+        red[0][tid] = sa[k];
+        red[1][tid] = sb[k];
+        __syncthreads();
+        if (rsub == 0) {
+            float4 ta = red[0][tid], tb = red[1][tid];
+            for (int j = 1; j < g.rpi; ++j) {
+                const float4 pa = red[0][tid + j * g.tpr], pb = red[1][tid + j * g.tpr];
+                ta.x += pa.x; ta.y += pa.y; ta.z += pa.z; ta.w += pa.w;
+                tb.x += pb.x; tb.y += pb.y; tb.z += pb.z; tb.w += pb.w;
+            }
+            const int c = (col + k * g.tpr) * 4;
+            float *p = a.acc + (int64_t)blockIdx.x * 2 * a.C;          // this workgroup's partial sums
+            *reinterpret_cast<float4 *>(p + c) = ta;
+            *reinterpret_cast<float4 *>(p + a.C + c) = tb;
+        }
+    }
+}
+
+// Sum of the workgroups' partial rows for 64 channels per workgroup: 16 waves take every 16th partial
+// row each (coalesced across channels, 8 independent loads in flight), double accumulation, LDS
+// combine.  Returns the totals to the threads of wave 0 (tid < 64).
+constexpr int kFinBlock = 1024;
+__device__ __forceinline__ bool bn_block_sums(const BnArgs &a, int nblocks, int *c_out, double *s0, double *s1) {
+    __shared__ double red[2][kFinBlock];
+    constexpr int NSEG = kFinBlock / 64;
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double t0 = 0.0, t1 = 0.0;
+    if (c < a.C) {
+        const int last = nblocks - 1;
+        for (int b0 = seg; b0 < nblocks; b0 += 8 * NSEG) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * NSEG;
+                const float *p = a.acc + (int64_t)(b < nblocks ? b : last) * 2 * a.C;
+                v0[u] = p[c];
+                v1[u] = p[a.C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b0 + u * NSEG < nblocks) { t0 += (double)v0[u]; t1 += (double)v1[u]; }
+        }
+    }
+    red[0][threadIdx.x] = t0;
+    red[1][threadIdx.x] = t1;
+    __syncthreads();
+    *c_out = c;
+    if (seg != 0 || c >= a.C) return false;
+    for (int j = 1; j < NSEG; ++j) { t0 += red[0][lane + 64 * j]; t1 += red[1][lane + 64 * j]; }
+    *s0 = t0; *s1 = t1;
+    return true;
+}
+
+// forward statistics -> mean / rstd / affine coefficients / running statistics (torch semantics:
+// biased variance for the normalisation, unbiased for running_var)
+__global__ __launch_bounds__(kFinBlock) void bn_finalize_kernel(BnArgs a, int nblocks) {
+    int c;
+    double sum, sumsq;
+    if (!bn_block_sums(a, nblocks, &c, &sum, &sumsq)) return;
+    const double n = (double)a.R;
+    const double mean = sum / n;
+    double var = sumsq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float w = a.weight ? a.weight[c] : 1.f, b = a.bias ? a.bias[c] : 0.f;
+    a.save_mean[c] = (float)mean;
+    a.save_rstd[c] = rstd;
+    a.scale[c] = w * rstd;
+    a.shift[c] = b - (float)mean * (w * rstd);
+    if (a.running_mean) {
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+}
+
+__global__ __launch_bounds__(kFinBlock) void bn_bwd_finalize_kernel(BnArgs a, int nblocks) {
+    int c;
+    double sdy, sdyx;
+    if (!bn_block_sums(a, nblocks, &c, &sdy, &sdyx)) return;
+    if (a.dbias) a.dbias[c] = (float)sdy;
+    if (a.dweight) a.dweight[c] = (float)sdyx;
+    a.coef[c] = (float)(sdy / (double)a.R);
+    a.coef[a.C + c] = (float)(sdyx / (double)a.R);
+}
+
+// MODE 0: y = relu(x * scale + shift [+ res]).   MODE 1: dx = scale * (dy' - c1 - xhat * c2) [, dres = dy'].
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
+    const int C4 = a.g.C4;
+    const int64_t total = a.R * C4;
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < total; i0 += U * stride) {
+        float4 vx[U], vr[U], vd[U];
+        int64_t idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            idx[u] = i < total ? i : total - 1;              // clamped: unconditional loads
+            vx[u] = reinterpret_cast<const float4 *>(a.x)[idx[u]];
+            if (MODE == 0) {
+                if (a.has_res) vr[u] = reinterpret_cast<const float4 *>(a.res)[idx[u]];
+            } else {
+                vd[u] = reinterpret_cast<const float4 *>(a.dy)[idx[u]];
+                if (a.has_res) vr[u] = reinterpret_cast<const float4 *>(a.y_in)[idx[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= total) break;
+            const int c = (total < (1ll << 31) ? (int)((unsigned)i % (unsigned)C4) : (int)(i % C4)) * 4;
+            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c);
+            const float4 sh = *reinterpret_cast<const float4 *>(a.shift + c);
+            if (MODE == 0) {
+                float4 y = make_float4(vx[u].x * sc.x + sh.x, vx[u].y * sc.y + sh.y, vx[u].z * sc.z + sh.z, vx[u].w * sc.w + sh.w);
+                if (a.has_res) { y.x += vr[u].x; y.y += vr[u].y; y.z += vr[u].z; y.w += vr[u].w; }
+                if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                reinterpret_cast<float4 *>(a.y)[i] = y;
+            } else {
+                const float4 mean = *reinterpret_cast<const float4 *>(a.save_mean + c);
+                const float4 rstd = *reinterpret_cast<const float4 *>(a.save_rstd + c);
+                const float4 c1 = *reinterpret_cast<const float4 *>(a.coef + c);
+                const float4 c2 = *reinterpret_cast<const float4 *>(a.coef + a.C + c);
+                float4 d = vd[u];
+                if (a.relu) {
+                    if (a.has_res) {
+                        if (!(vr[u].x > 0.f)) d.x = 0.f;
+                        if (!(vr[u].y > 0.f)) d.y = 0.f;
+                        if (!(vr[u].z > 0.f)) d.z = 0.f;
+                        if (!(vr[u].w > 0.f)) d.w = 0.f;
+                    } else {
+                        if (!(vx[u].x * sc.x + sh.x > 0.f)) d.x = 0.f;
+                        if (!(vx[u].y * sc.y + sh.y > 0.f)) d.y = 0.f;
+                        if (!(vx[u].z * sc.z + sh.z > 0.f)) d.z = 0.f;
+                        if (!(vx[u].w * sc.w + sh.w > 0.f)) d.w = 0.f;
+                    }
+                }
+                if (a.dres) reinterpret_cast<float4 *>(a.dres)[i] = d;
+                float4 o;
+                o.x = sc.x * (d.x - c1.x - (vx[u].x - mean.x) * rstd.x * c2.x);
+                o.y = sc.y * (d.y - c1.y - (vx[u].y - mean.y) * rstd.y * c2.y);
+                o.z = sc.z * (d.z - c1.z - (vx[u].z - mean.z) * rstd.z * c2.z);
+                o.w = sc.w * (d.w - c1.w - (vx[u].w - mean.w) * rstd.w * c2.w);
+                reinterpret_cast<float4 *>(a.dx)[i] = o;
+            }
+        }
+    }
+}
+
+int geometry(const char *who, int64_t R, int C, BnGeom *g) {
+    if (R <= 0 || C <= 0 || C % 4) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: need R > 0 and C %% 4 == 0 (R=%lld C=%d)", who, (long long)R, C);
+    const int C4 = C / 4;
+    g->C4 = C4;
+    if (C4 <= kBlock) { g->tpr = C4; g->kc = 1; }
+    else if (C4 % kBlock == 0 && C4 / kBlock <= kMaxKC) { g->tpr = kBlock; g->kc = C4 / kBlock; }
+    else return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: C=%d is not supported (C <= 1024, or a multiple of 1024 up to %d)", who, C, 1024 * kMaxKC);
+    g->rpi = kBlock / g->tpr;
+    if (R * C4 >= (1ll << 40)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: activation too large", who);
+    return 0;
+}
+
+constexpr int kMaxPartialBlocks = 512;
+
+void reduce_grid(const BnGeom &g, int64_t R, int *blocks, int64_t *rows_per_block) {
+    // every workgroup owns whole trips of rows and at least 64 rows, so the partial rows it writes
+    // (2*C floats) stay below ~6 % of what it reads; at most kMaxPartialBlocks workgroups
+    const int64_t trip = (int64_t)g.rpi * kRowsInFlight;
+    int64_t nb = R / 64;
+    if (nb < 1) nb = 1;
+    if (nb > kMaxPartialBlocks) nb = kMaxPartialBlocks;
+    const int64_t rpb = mmt::ceil_div(mmt::ceil_div(R, nb), trip) * trip;
+    *rows_per_block = rpb;
+    *blocks = (int)mmt::ceil_div(R, rpb);
+}
+
+}  // namespace
+
+extern "C" int64_t mmt_bn_workspace_elems(int C) { return C > 0 ? (2ll * kMaxPartialBlocks + 2) * C : -1; }
+
+extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float *residual, const float *weight,
+                                   const float *bias, float *running_mean, float *running_var, float momentum,
+                                   float eps, int relu, float *workspace, float *save, float *y, void *stream) {
+    MMT_REQUIRE_PTR(x);
+    MMT_REQUIRE_PTR(workspace);
+    MMT_REQUIRE_PTR(save);
+    MMT_REQUIRE_PTR(y);
+    float *save_mean = save, *save_rstd = save + C;
+    BnArgs a = {};
+    if (int rc = geometry("bn_relu_forward", R, C, &a.g)) return rc;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)workspace | (uintptr_t)save) & 15)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_forward: buffers must be 16-byte aligned");
+    a.R = R; a.C = C; a.relu = relu; a.has_res = residual != nullptr; a.momentum = momentum; a.eps = eps;
+    a.x = x; a.res = residual; a.weight = weight; a.bias = bias; a.running_mean = running_mean; a.running_var = running_var;
+    a.acc = workspace + 2 * C; a.coef = workspace; a.scale = save + 2 * C; a.shift = save + 3 * C;
+    a.save_mean = save_mean; a.save_rstd = save_rstd; a.y = y;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks; int64_t rpb;
+    reduce_grid(a.g, R, &blocks, &rpb);
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(blocks), dim3(kBlock), 0, st, a, rpb);
+    if (int rc = mmt::check_launch("bn_relu_forward(stats)")) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)mmt::ceil_div(C, 64)), dim3(kFinBlock), 0, st, a, blocks);
+    if (int rc = mmt::check_launch("bn_relu_forward(finalize)")) return rc;
+    hipLaunchKernelGGL(bn_map_kernel<0>, dim3(mmt::stream_grid(mmt::ceil_div(R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
+    return mmt::check_launch("bn_relu_forward(apply)");
+}
+
+extern "C" int mmt_bn_relu_backward(int64_t R, int C, const float *x, const float *y, const float *grad_y,
+                                    const float *save, int relu, int has_residual, float *workspace,
+                                    float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias,
+                                    void *stream) {
+    MMT_REQUIRE_PTR(x);
+    MMT_REQUIRE_PTR(grad_y);
+    MMT_REQUIRE_PTR(save);
+    MMT_REQUIRE_PTR(workspace);
+    const float *save_mean = save, *save_rstd = save + C;
+    MMT_REQUIRE_PTR(grad_x);
+    if (relu && has_residual) MMT_REQUIRE_PTR(y);
+    BnArgs a = {};
+    if (int rc = geometry("bn_relu_backward", R, C, &a.g)) return rc;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_residual | (uintptr_t)workspace |
+         (uintptr_t)save) & 15)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_backward: buffers must be 16-byte aligned");
+    a.R = R; a.C = C; a.relu = relu; a.has_res = (relu && has_residual) ? 1 : 0;
+    a.x = x; a.y_in = y; a.dy = grad_y;
+    a.acc = workspace + 2 * C; a.coef = workspace;
+    a.scale = const_cast<float *>(save) + 2 * C; a.shift = const_cast<float *>(save) + 3 * C;
+    a.save_mean = const_cast<float *>(save_mean); a.save_rstd = const_cast<float *>(save_rstd);
+    a.dx = grad_x; a.dres = has_residual ? grad_residual : nullptr; a.dweight = grad_weight; a.dbias = grad_bias;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks; int64_t rpb;
+    reduce_grid(a.g, R, &blocks, &rpb);
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(blocks), dim3(kBlock), 0, st, a, rpb);
+    if (int rc = mmt::check_launch("bn_relu_backward(reduce)")) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)mmt::ceil_div(C, 64)), dim3(kFinBlock), 0, st, a, blocks);
+    if (int rc = mmt::check_launch("bn_relu_backward(finalize)")) return rc;
+    hipLaunchKernelGGL(bn_map_kernel<1>, dim3(mmt::stream_grid(mmt::ceil_div(R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
+    return mmt::check_launch("bn_relu_backward(dx)");
+}

@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from ...ops.bev_geometry import frustum_geometry, lift_features, lift_splat
+from ...ops.bn_relu import ConvBNAct, bn_act
 from ...ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling, voxel_pooling_planned
 from ..nets import BasicBlock, DeformConv2dPack, ResNet, SECONDFPN
 
@@ -30,7 +31,7 @@ class _ASPPModule(nn.Module):
         nn.init.kaiming_normal_(self.atrous_conv.weight)
 
     def forward(self, x):
-        return self.relu(self.bn(self.atrous_conv(x)))
+        return bn_act(self.bn, self.atrous_conv(x))
 
 
 class ASPP(nn.Module):
@@ -62,7 +63,7 @@ class ASPP(nn.Module):
             # i.e. a 2560-channel layout conversion in front of the next convolution
             branches = tuple(b.contiguous(memory_format=torch.channels_last) for b in branches)
         x = torch.cat(branches, 1)
-        return self.dropout(self.relu(self.bn1(self.conv1(x))))
+        return self.dropout(bn_act(self.bn1, self.conv1(x)))
 
 
 class SELayer(nn.Module):
@@ -84,7 +85,7 @@ class DepthNet(nn.Module):
 
     def __init__(self, in_channels, mid_channels, context_channels, depth_channels):
         super().__init__()
-        self.reduce_conv = nn.Sequential(nn.Conv2d(in_channels, mid_channels, 3, 1, 1),
+        self.reduce_conv = ConvBNAct(nn.Conv2d(in_channels, mid_channels, 3, 1, 1),
                                          nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
         self.context_conv = nn.Conv2d(mid_channels, context_channels, 1)
         self.depth_se = nn.Identity()

@@ -14,6 +14,7 @@ import torch.distributed as dist
 from torch import nn
 
 from ..nets import ResNet, SECONDFPN
+from ...ops.bn_relu import ConvBNAct
 from ...ops.train_targets import centerpoint_targets
 
 __all__ = ['BEVDepthHead']
@@ -46,7 +47,7 @@ def gaussian_radius(height, width, min_overlap=0.5):
 
 
 def _conv_module(cin, cout, k):
-    return nn.Sequential(nn.Conv2d(cin, cout, k, 1, k // 2, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+    return ConvBNAct(nn.Conv2d(cin, cout, k, 1, k // 2, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
 
 
 class SeparateHead(nn.Module):

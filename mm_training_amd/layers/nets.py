@@ -12,6 +12,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..ops.bn_relu import ConvBNAct, bn_act
+
 
 class BasicBlock(nn.Module):
     expansion = 1
@@ -27,9 +29,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + identity)
+        out = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(out), residual=identity)
 
 
 class Bottleneck(nn.Module):
@@ -49,10 +50,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        out = bn_act(self.bn1, self.conv1(x))
+        out = bn_act(self.bn2, self.conv2(out))
+        return bn_act(self.bn3, self.conv3(out), residual=identity)
 
 
 class ResNet(nn.Module):
@@ -77,7 +77,7 @@ class ResNet(nn.Module):
                 s = stride if j == 0 else 1
                 down = None
                 if s != 1 or inplanes != planes * block.expansion:
-                    down = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, s, bias=False),
+                    down = ConvBNAct(nn.Conv2d(inplanes, planes * block.expansion, 1, s, bias=False),
                                          nn.BatchNorm2d(planes * block.expansion))
                 layers.append(block(inplanes, planes, s, down))
                 inplanes = planes * block.expansion
@@ -93,7 +93,7 @@ class ResNet(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         outs = []
         for i, stage in enumerate(self.stages):
             x = stage(x)
@@ -112,7 +112,7 @@ class SECONDFPN(nn.Module):
             else:
                 k = int(round(1 / s))
                 up = nn.Conv2d(cin, cout, k, k, bias=False)
-            blocks.append(nn.Sequential(up, nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)))
+            blocks.append(ConvBNAct(up, nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)))
         self.deblocks = nn.ModuleList(blocks)
         self.init_weights()
 

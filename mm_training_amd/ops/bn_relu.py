@@ -1,0 +1,110 @@
+"""Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) for the dense nets -- HIP
+(``mmt_bn_relu_forward/backward``, csrc/bn_relu.hip): 3 + 5 streaming passes over the
+activation instead of 5 + 8 with MIOpen BatchNorm + ATen add / relu.
+
+``bn_act(bn, x, residual=None, relu=True)`` takes a plain ``nn.BatchNorm2d`` (its parameters,
+running statistics, momentum and eps are used and updated exactly like ``bn(x)`` would) and
+returns ``relu(bn(x) + residual)``.  The fused path needs training mode, CUDA fp32
+channels-last activations and a supported channel count; everything else (eval mode, autocast
+to bf16, CPU tensors of the gloo unit tests, odd C) runs the ordinary torch modules -- these
+layers are PyTorch plumbing around the hot path, not part of it.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from .. import _lib
+
+ENABLED = os.environ.get("MMT_FUSED_BN", "1") != "0"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _supported(bn, x):
+    c = x.shape[1]
+    return (ENABLED and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and bn.track_running_stats and bn.momentum is not None and bn.affine
+            and c % 4 == 0 and (c <= 1024 or c == 2048)
+            and not torch.is_autocast_enabled()
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _BnAct(Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, workspace, momentum, eps, relu):
+        B, C, H, W = x.shape
+        R = B * H * W
+        y = torch.empty_like(x)                                   # preserves channels_last
+        save = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        res_ptr = 0
+        if residual is not None:
+            if not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            res_ptr = residual.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.call("mmt_bn_relu_forward", R, C, x.data_ptr(), res_ptr, weight.data_ptr(), bias.data_ptr(),
+                      running_mean.data_ptr(), running_var.data_ptr(), float(momentum), float(eps), int(relu),
+                      workspace.data_ptr(), save.data_ptr(), y.data_ptr(), _stream())
+        ctx.mark_non_differentiable(running_mean, running_var)
+        need_y = relu and residual is not None
+        ctx.save_for_backward(x, y if need_y else None, save, workspace)
+        ctx.cfg = (R, C, bool(relu), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, y, save, workspace = ctx.saved_tensors
+        R, C, relu, has_res = ctx.cfg
+        if not grad_y.is_contiguous(memory_format=torch.channels_last):
+            grad_y = grad_y.contiguous(memory_format=torch.channels_last)
+        grad_x = torch.empty_like(x)
+        grad_res = torch.empty_like(x) if has_res else None
+        grad_w = torch.empty(C, dtype=torch.float32, device=x.device)
+        grad_b = torch.empty(C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("mmt_bn_relu_backward", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
+                      save.data_ptr(), int(relu), int(has_res), workspace.data_ptr(), grad_x.data_ptr(),
+                      grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), _stream())
+        return grad_x, grad_res, grad_w, grad_b, None, None, None, None, None, None
+
+
+_SCRATCH = {}
+
+
+def _workspace(bn, device):
+    """Per-device scratch for the per-workgroup partial sums: consumed inside each call on the calling
+    stream, so one buffer sized for the widest layer serves every BatchNorm of the model."""
+    need = _lib.lib().mmt_bn_workspace_elems(max(2048, bn.num_features))
+    ws = _SCRATCH.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=device)
+        _SCRATCH[device] = ws
+    return ws
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """relu?(bn(x) [+ residual]) with ``bn`` an ``nn.BatchNorm2d`` (see module docstring)."""
+    if _supported(bn, x):
+        return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            _workspace(bn, x.device), bn.momentum, bn.eps, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out, inplace=True) if relu else out
+
+
+class ConvBNAct(torch.nn.Sequential):
+    """``nn.Sequential(conv, BatchNorm2d[, ReLU])`` with the same child indices (so state_dict keys
+    are those of the plain Sequential the reference's mmcv / mmdet modules produce) whose forward
+    runs the normalisation (+ ReLU) through ``bn_act``."""
+
+    def forward(self, x):
+        relu = len(self) > 2 and isinstance(self[2], torch.nn.ReLU)
+        out = bn_act(self[1], self[0](x), relu=relu)
+        for extra in list(self)[3 if relu else 2:]:
+            out = extra(out)
+        return out

@@ -1,0 +1,69 @@
+"""GPU numerics of the fused BatchNorm (+ residual) (+ ReLU) kernels against plain PyTorch fp32
+(nn.BatchNorm2d in training mode + add + relu, autograd for the gradients)."""
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(4, 64, 32, 44), (2, 256, 16, 22), (2, 2048, 4, 6), (3, 160, 9, 7), (2, 12, 5, 7), (1, 1024, 3, 3), (24, 64, 64, 176)]
+
+
+def _ref(bn, x, res, relu):
+    y = bn(x)
+    if res is not None:
+        y = y + res
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("use_res", [False, True])
+@pytest.mark.parametrize("relu", [True, False])
+def test_forward_backward_running_stats(mmt_lib, shape, use_res, relu):
+    from mm_training_amd.ops import bn_relu
+    from mm_training_amd.ops.bn_relu import bn_act
+    B, C, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(C * 7 + H)
+    x0 = (torch.randn(shape, device="cuda", generator=g) * 1.7 + 0.4).contiguous(memory_format=torch.channels_last)
+    r0 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last) if use_res else None
+    go = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    bn_a, bn_b = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(C, device="cuda", generator=g) + 0.5)
+        bn_a.bias.copy_(torch.randn(C, device="cuda", generator=g) * 0.3)
+        bn_b.load_state_dict(bn_a.state_dict())
+    assert bn_relu._supported(bn_a, x0), "this shape must take the fused path"
+    outs = []
+    for bn, fused in ((bn_a, True), (bn_b, False)):
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if use_res else None
+        for _ in range(2):                                   # two steps: running statistics accumulate
+            y = bn_act(bn, x, r, relu) if fused else _ref(bn, x, r, relu)
+        y.backward(go)
+        outs.append((y.detach(), x.grad, r.grad if use_res else None, bn.weight.grad, bn.bias.grad,
+                     bn.running_mean.clone(), bn.running_var.clone()))
+    names = ("y", "grad_x", "grad_res", "grad_weight", "grad_bias", "running_mean", "running_var")
+    for name, a, b in zip(names, outs[0], outs[1]):
+        if a is None:
+            continue
+        scale = max(1.0, b.abs().max().item())
+        # per-channel sums over up to 270 k fp32 terms (both sides): 2e-3 relative
+        tol = (2e-3 if name.startswith("grad_w") or name.startswith("grad_b") else 2e-5) * scale
+        # a ReLU mask decided on an activation within rounding of zero may differ: allow isolated outliers
+        bad = ((a - b).abs() > tol).float().mean().item()
+        assert bad <= (1e-5 if name in ("y", "grad_x", "grad_res") else 0.0), (name, bad, (a - b).abs().max().item())
+    assert outs[0][0].is_contiguous(memory_format=torch.channels_last)
+
+
+def test_fallback_paths(mmt_lib):
+    """eval mode, NCHW-contiguous input and unsupported C run the ordinary torch modules."""
+    from mm_training_amd.ops import bn_relu
+    from mm_training_amd.ops.bn_relu import bn_act
+    bn = nn.BatchNorm2d(6).cuda()
+    x = torch.randn(2, 6, 5, 5, device="cuda")
+    assert not bn_relu._supported(bn, x)
+    assert torch.allclose(bn_act(bn, x), torch.relu(nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True)), atol=1e-6)
+    bn8 = nn.BatchNorm2d(8).cuda().eval()
+    x8 = torch.randn(2, 8, 5, 5, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert not bn_relu._supported(bn8, x8)
+    assert torch.equal(bn_act(bn8, x8, relu=False), bn8(x8))
