@@ -6,7 +6,7 @@
 // These layers are pure HBM streaming (0.25 flop/byte).  Unfused (MIOpen BN + ATen add / relu) one
 // conv-bn-relu costs 5 passes over the activation forward and 8 backward; fused:
 //   forward : bn_stats (1 read)  ->  bn_finalize (C values)  ->  bn_apply (1 read [+ residual] , 1 write)
-//   backward: bn_bwd_reduce (dy, x [, y])  ->  bn_bwd_finalize  ->  bn_bwd_dx (dy, x [, y] -> dx [, dres])
+//   backward: bn_bwd_reduce (dy, x [, y -> dres])  ->  bn_bwd_finalize  ->  bn_bwd_dx (dy | dres, x -> dx)
 // i.e. 3 + 5 passes.  The ReLU mask is recomputed from x (plain variant) or read from the saved
 // output y (residual variant); nothing but mean / rstd is saved beyond what autograd keeps anyway.
 //
@@ -26,7 +26,7 @@ constexpr int kRowsInFlight = 4;
 struct BnGeom {
     int C4;        // float4 columns per row
     int tpr;       // threads per row (<= 256)
-    int kc;        // column blocks per thread (C4 = tpr * kc)
+    int kc;        // column blocks of tpr lanes per row (grid.y of the reduce kernels; C4 = tpr * kc)
     int rpi;       // rows per workgroup and trip
 };
 
@@ -46,7 +46,7 @@ struct BnArgs {
     float *coef;           // [2*C] backward: mean(dy'), mean(dy' * xhat)
 };
 
-constexpr int kMaxKC = 2;  // C <= 2048
+constexpr int kMaxKC = 8;  // C <= 8192
 
 // Sum of (a, b) per channel over this workgroup's rows -> partial[blockIdx][0:C], [C:2C] (plain stores:
 // 2*C same-address atomics per workgroup cost 150 us per launch, measured).
@@ -56,95 +56,85 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
     __shared__ float4 red[2][kBlock];
     const BnGeom g = a.g;
     const int tid = threadIdx.x;
-    const int rsub = tid / g.tpr, col = tid - rsub * g.tpr;
+    const int rsub = tid / g.tpr;
+    const int col = tid - rsub * g.tpr + blockIdx.y * g.tpr;      // grid.y = column block (C > 1024)
     const bool live = rsub < g.rpi;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = (r_begin + rows_per_block) < a.R ? (r_begin + rows_per_block) : a.R;
-    float4 sa[kMaxKC], sb[kMaxKC];
-    float4 sc[kMaxKC], sh[kMaxKC], mean[kMaxKC], rstd[kMaxKC];
-#pragma unroll
-    for (int k = 0; k < kMaxKC; ++k) {
-        sa[k] = sb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 1 && k < g.kc) {
-            const int c = (col + k * g.tpr) * 4;
-            sc[k] = *reinterpret_cast<const float4 *>(a.scale + c);
-            sh[k] = *reinterpret_cast<const float4 *>(a.shift + c);
-            mean[k] = *reinterpret_cast<const float4 *>(a.save_mean + c);
-            rstd[k] = *reinterpret_cast<const float4 *>(a.save_rstd + c);
-        }
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    float4 sc = sa, sh = sa, mean = sa, rstd = sa;
+    if (MODE == 1) {
+        sc = *reinterpret_cast<const float4 *>(a.scale + col * 4);
+        sh = *reinterpret_cast<const float4 *>(a.shift + col * 4);
+        mean = *reinterpret_cast<const float4 *>(a.save_mean + col * 4);
+        rstd = *reinterpret_cast<const float4 *>(a.save_rstd + col * 4);
     }
     if (live && r_begin < r_end) {
         const int64_t last = r_end - 1;
         for (int64_t r0 = r_begin + rsub; r0 < r_end; r0 += (int64_t)kRowsInFlight * g.rpi) {
+            float4 vx[kRowsInFlight], vd[kRowsInFlight], vy[kRowsInFlight];
+            float wgt[kRowsInFlight];
 #pragma unroll
-            for (int k = 0; k < kMaxKC; ++k) {
-                if (k >= g.kc) break;
-                float4 vx[kRowsInFlight], vd[kRowsInFlight], vy[kRowsInFlight];
-                float wgt[kRowsInFlight];
-#pragma unroll
-                for (int u = 0; u < kRowsInFlight; ++u) {
-                    const int64_t r = r0 + (int64_t)u * g.rpi;
-                    wgt[u] = r < r_end ? 1.f : 0.f;
-                    const int64_t off = ((r < r_end ? r : last) * g.C4 + col + k * g.tpr) * 4;
-                    vx[u] = *reinterpret_cast<const float4 *>(a.x + off);
-                    if (MODE == 1) {
-                        vd[u] = *reinterpret_cast<const float4 *>(a.dy + off);
-                        if (a.has_res) vy[u] = *reinterpret_cast<const float4 *>(a.y_in + off);
-                    }
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                const int64_t r = r0 + (int64_t)u * g.rpi;
+                wgt[u] = r < r_end ? 1.f : 0.f;
+                const int64_t off = ((r < r_end ? r : last) * g.C4 + col) * 4;
+                vx[u] = *reinterpret_cast<const float4 *>(a.x + off);
+                if (MODE == 1) {
+                    vd[u] = *reinterpret_cast<const float4 *>(a.dy + off);
+                    if (a.has_res) vy[u] = *reinterpret_cast<const float4 *>(a.y_in + off);
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < kRowsInFlight; ++u) {
-                    if (MODE == 0) {
-                        const float w = wgt[u];
-                        sa[k].x += w * vx[u].x; sa[k].y += w * vx[u].y; sa[k].z += w * vx[u].z; sa[k].w += w * vx[u].w;
-                        sb[k].x += w * vx[u].x * vx[u].x; sb[k].y += w * vx[u].y * vx[u].y;
-                        sb[k].z += w * vx[u].z * vx[u].z; sb[k].w += w * vx[u].w * vx[u].w;
-                    } else {
-                        float4 d = vd[u];
-                        d.x *= wgt[u]; d.y *= wgt[u]; d.z *= wgt[u]; d.w *= wgt[u];
-                        if (a.relu) {
-                            if (a.has_res) {
-                                if (!(vy[u].x > 0.f)) d.x = 0.f;
-                                if (!(vy[u].y > 0.f)) d.y = 0.f;
-                                if (!(vy[u].z > 0.f)) d.z = 0.f;
-                                if (!(vy[u].w > 0.f)) d.w = 0.f;
-                            } else {
-                                if (!(vx[u].x * sc[k].x + sh[k].x > 0.f)) d.x = 0.f;
-                                if (!(vx[u].y * sc[k].y + sh[k].y > 0.f)) d.y = 0.f;
-                                if (!(vx[u].z * sc[k].z + sh[k].z > 0.f)) d.z = 0.f;
-                                if (!(vx[u].w * sc[k].w + sh[k].w > 0.f)) d.w = 0.f;
-                            }
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                if (MODE == 0) {
+                    const float w = wgt[u];
+                    sa.x += w * vx[u].x; sa.y += w * vx[u].y; sa.z += w * vx[u].z; sa.w += w * vx[u].w;
+                    sb.x += w * vx[u].x * vx[u].x; sb.y += w * vx[u].y * vx[u].y;
+                    sb.z += w * vx[u].z * vx[u].z; sb.w += w * vx[u].w * vx[u].w;
+                } else {
+                    float4 d = vd[u];
+                    d.x *= wgt[u]; d.y *= wgt[u]; d.z *= wgt[u]; d.w *= wgt[u];
+                    if (a.relu) {
+                        if (a.has_res) {
+                            if (!(vy[u].x > 0.f)) d.x = 0.f;
+                            if (!(vy[u].y > 0.f)) d.y = 0.f;
+                            if (!(vy[u].z > 0.f)) d.z = 0.f;
+                            if (!(vy[u].w > 0.f)) d.w = 0.f;
+                        } else {
+                            if (!(vx[u].x * sc.x + sh.x > 0.f)) d.x = 0.f;
+                            if (!(vx[u].y * sc.y + sh.y > 0.f)) d.y = 0.f;
+                            if (!(vx[u].z * sc.z + sh.z > 0.f)) d.z = 0.f;
+                            if (!(vx[u].w * sc.w + sh.w > 0.f)) d.w = 0.f;
                         }
-                        sa[k].x += d.x; sa[k].y += d.y; sa[k].z += d.z; sa[k].w += d.w;
-                        sb[k].x += d.x * ((vx[u].x - mean[k].x) * rstd[k].x);
-                        sb[k].y += d.y * ((vx[u].y - mean[k].y) * rstd[k].y);
-                        sb[k].z += d.z * ((vx[u].z - mean[k].z) * rstd[k].z);
-                        sb[k].w += d.w * ((vx[u].w - mean[k].w) * rstd[k].w);
                     }
+                    if (a.dres && wgt[u] != 0.f) {      // residual variant: the masked gradient IS grad_residual
+                        const int64_t r = r0 + (int64_t)u * g.rpi;
+                        *reinterpret_cast<float4 *>(a.dres + (r * g.C4 + col) * 4) = d;
+                    }
+                    sa.x += d.x; sa.y += d.y; sa.z += d.z; sa.w += d.w;
+                    sb.x += d.x * ((vx[u].x - mean.x) * rstd.x);
+                    sb.y += d.y * ((vx[u].y - mean.y) * rstd.y);
+                    sb.z += d.z * ((vx[u].z - mean.z) * rstd.z);
+                    sb.w += d.w * ((vx[u].w - mean.w) * rstd.w);
                 }
             }
         }
     }
-    // rows of the workgroup meet in LDS, then one partial row per workgroup
-#pragma unroll
-    for (int k = 0; k < kMaxKC; ++k) {
-        if (k >= g.kc) break;
-        __syncthreads();
-        red[0][tid] = sa[k];
-        red[1][tid] = sb[k];
-        __syncthreads();
-        if (rsub == 0) {
-            float4 ta = red[0][tid], tb = red[1][tid];
-            for (int j = 1; j < g.rpi; ++j) {
-                const float4 pa = red[0][tid + j * g.tpr], pb = red[1][tid + j * g.tpr];
-                ta.x += pa.x; ta.y += pa.y; ta.z += pa.z; ta.w += pa.w;
-                tb.x += pb.x; tb.y += pb.y; tb.z += pb.z; tb.w += pb.w;
-            }
-            const int c = (col + k * g.tpr) * 4;
-            float *p = a.acc + (int64_t)blockIdx.x * 2 * a.C;          // this workgroup's partial sums
-            *reinterpret_cast<float4 *>(p + c) = ta;
-            *reinterpret_cast<float4 *>(p + a.C + c) = tb;
+    // rows of the workgroup meet in LDS, then one partial row (this column block of it) per workgroup
+    red[0][tid] = sa;
+    red[1][tid] = sb;
+    __syncthreads();
+    if (rsub == 0) {
+        float4 ta = red[0][tid], tb = red[1][tid];
+        for (int j = 1; j < g.rpi; ++j) {
+            const float4 pa = red[0][tid + j * g.tpr], pb = red[1][tid + j * g.tpr];
+            ta.x += pa.x; ta.y += pa.y; ta.z += pa.z; ta.w += pa.w;
+            tb.x += pb.x; tb.y += pb.y; tb.z += pb.z; tb.w += pb.w;
         }
+        float *p = a.acc + (int64_t)blockIdx.x * 2 * a.C;          // this workgroup's partial sums
+        *reinterpret_cast<float4 *>(p + col * 4) = ta;
+        *reinterpret_cast<float4 *>(p + a.C + col * 4) = tb;
     }
 }
 
@@ -331,7 +321,7 @@ extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float
     hipStream_t st = (hipStream_t)stream;
     int blocks; int64_t rpb;
     reduce_grid(a.g, R, &blocks, &rpb);
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(blocks), dim3(kBlock), 0, st, a, rpb);
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
     if (int rc = mmt::check_launch("bn_relu_forward(stats)")) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)mmt::ceil_div(C, 64)), dim3(kFinBlock), 0, st, a, blocks);
     if (int rc = mmt::check_launch("bn_relu_forward(finalize)")) return rc;
@@ -364,10 +354,15 @@ extern "C" int mmt_bn_relu_backward(int64_t R, int C, const float *x, const floa
     hipStream_t st = (hipStream_t)stream;
     int blocks; int64_t rpb;
     reduce_grid(a.g, R, &blocks, &rpb);
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(blocks), dim3(kBlock), 0, st, a, rpb);
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
     if (int rc = mmt::check_launch("bn_relu_backward(reduce)")) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)mmt::ceil_div(C, 64)), dim3(kFinBlock), 0, st, a, blocks);
     if (int rc = mmt::check_launch("bn_relu_backward(finalize)")) return rc;
+    if (a.dres) {
+        // the reduce pass has written grad_residual = masked grad_y: the dx pass reads that instead of
+        // grad_y + y (7 passes instead of 8 for the residual variant)
+        a.dy = a.dres; a.dres = nullptr; a.relu = 0; a.has_res = 0;
+    }
     hipLaunchKernelGGL(bn_map_kernel<1>, dim3(mmt::stream_grid(mmt::ceil_div(R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
     return mmt::check_launch("bn_relu_backward(dx)");
 }
