@@ -107,7 +107,10 @@ class TrainStep(nn.Module):
             self.net = nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[device.index] if device.type == "cuda" else None,
                 bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, find_unused_parameters=False,
-                static_graph=True)
+                static_graph=True,
+                # BatchNorm statistics are per rank (no SyncBN in the reference); re-broadcasting
+                # rank 0's ~390 buffers before every forward would be one more collective per step
+                broadcast_buffers=False)
         bs = cfg["batch_size"]
         self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr or 1e-3 / 64 * bs, weight_decay=1e-7,
                                            fused=(device.type == "cuda"))
