@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define MMT_ABI_VERSION 1
+/* 2: adds the cached-plan pooling, BEV warp, depth-label, CenterPoint-target and BatchNorm entry points
+ * (purely additive: every version-1 symbol keeps its signature and meaning) */
+#define MMT_ABI_VERSION 2
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
