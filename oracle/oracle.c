@@ -16,6 +16,11 @@
  *     mmdet3d 1.0.0rc4; pinned only by README.md:19-27).  The published sequential
  *     algorithm is restated here; PARITY UNPINNED (no reference test or fixture
  *     covers it; call sites models/bev_depth.py:181-183).
+ *   - depth labels (exps/mm_training_aim.py:114-215): PINNED against the reference's own
+ *     methods run in the build container (tests/golden/depth_labels.npz).
+ *   - CenterPoint targets (mmdet3d gaussian_radius / draw_heatmap_gaussian) and the BEV
+ *     augmentation warp (kornia get_affine_matrix2d / warp_affine): un-vendored third-party
+ *     functions restated from their published definitions; PARITY UNPINNED.
  *
  * Plain C99, single-threaded, no dependencies.
  */
