@@ -49,6 +49,41 @@ def test_host_side_argument_checks(mmt_lib):
         mmt_lib.call("mmt_quantize_geometry", 4, None, None, None, None, None)
 
 
+def test_host_side_argument_checks_of_the_additional_entry_points(mmt_lib):
+    """Cached plan, BEV warp, depth labels, CenterPoint targets, BatchNorm: refused on the host, no launch."""
+    lib = mmt_lib.lib()
+    buf = (ctypes.c_float * 256)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.mmt_voxel_pooling_plan_elems(0, 8, 2, 2) == -1
+    assert lib.mmt_voxel_pooling_plan_elems(2, 100, 4, 4) > 2 * 100
+    assert lib.mmt_voxel_pooling_plan_workspace_bytes(2, 100, 4, 4) > 3 * 4 * 200
+    assert lib.mmt_voxel_pooling_plan_build(1, 8, 2, 2, 1, None, None, p, 10, p, 10, None) == -1
+    assert lib.mmt_voxel_pooling_plan_build(1, 8, 2, 2, 1, p, None, p, 10, p, 1 << 20, None) == -5      # plan too small
+    assert lib.mmt_voxel_pooling_forward_planned(1, 8, 6, 2, 2, p, 4, 0, 0, p, p, 6, None, 0, None) == -2   # C % 4
+    assert lib.mmt_voxel_pooling_forward_planned(1, 8, 8, 2, 2, p, 3, 0, 0, p, p, 8, None, 0, None) == -2   # items < cells
+    assert lib.mmt_bev_warp_affine(1, 4, 4, 6, p, p, 6, p, 6, None) == -2
+    assert lib.mmt_bev_warp_affine(1, 4, 4, 8, p, None, 8, p, 8, None) == -1
+    assert lib.mmt_bev_warp_affine_backward(1, 4, 4, 8, p, p, 4, p, 8, None) == -2                      # stride < C
+    assert lib.mmt_depth_labels_workspace_elems(2, 6, 256, 704, 16) == 2 * 6 * 16 * 44
+    assert lib.mmt_depth_labels(1, 2, 5, 10, 60, 96, 16, 2.0, 0.5, 112, p, p, p, p, p, p, 1 << 20, p, p, None) == -2   # H % ds
+    assert lib.mmt_depth_labels(1, 2, 5, 10, 64, 96, 16, 2.0, 0.5, 112, p, p, p, p, p, p, 3, p, p, None) == -5       # workspace
+    assert lib.mmt_depth_labels(1, 2, 5, 10, 64, 96, 16, 2.0, 0.5, 112, p, p, p, p, p, p, 1 << 20, None, None, None) == -1
+    i32 = (ctypes.c_int32 * 2)(0, 1)
+    ptrs = (ctypes.c_void_p * 2)(p.value, p.value)
+    cp = lambda tasks, hm: lib.mmt_centerpoint_targets(
+        1, tasks, ctypes.cast(i32, ctypes.c_void_p), ctypes.cast(i32, ctypes.c_void_p), 8, 4, 16, 16, 0.0, 0.0, 0.2, 0.2,
+        4, 0.1, 2, 1, p, p, p, hm, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(ptrs, ctypes.c_void_p),
+        ctypes.cast(ptrs, ctypes.c_void_p), None)
+    assert cp(9, ctypes.cast(ptrs, ctypes.c_void_p)) == -2        # more than 8 tasks
+    assert cp(1, None) == -1
+    assert lib.mmt_bn_workspace_elems(64) >= 4 * 64 and lib.mmt_bn_workspace_elems(0) == -1
+    assert lib.mmt_bn_relu_forward(16, 6, p, None, p, p, p, p, 0.1, 1e-5, 1, p, p, p, None) == -2        # C % 4
+    assert lib.mmt_bn_relu_forward(16, 1028, p, None, p, p, p, p, 0.1, 1e-5, 1, p, p, p, None) == -2     # unsupported C
+    assert lib.mmt_bn_relu_forward(16, 8, None, None, p, p, p, p, 0.1, 1e-5, 1, p, p, p, None) == -1
+    assert lib.mmt_bn_relu_backward(16, 8, p, None, p, p, 1, 1, p, p, p, p, p, None) == -1                # y needed
+    assert b"y" in lib.mmt_last_error()
+
+
 def test_python_mirror_rejects_cpu_tensors(mmt_lib):
     import torch
     from mm_training_amd.ops.voxel_pooling import voxel_pooling
