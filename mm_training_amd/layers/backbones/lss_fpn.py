@@ -201,7 +201,7 @@ class LSSFPN(nn.Module):
                 if len(self._plan_cache) >= 8:          # a handful of rigs, not an unbounded map
                     self._plan_cache.pop(next(iter(self._plan_cache)))
                 self._plan_cache[key] = plan
-        else:
+        elif self.fused_lift_splat:
             geom_xyz = self.get_geometry_voxels(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
                                                 mats_dict['intrin_mats'][:, sweep_index, ...],
                                                 mats_dict.get('bda_mat', None))
@@ -214,6 +214,11 @@ class LSSFPN(nn.Module):
             # lift straight into [B, N, D, fH, fW, C], then the drop-in voxel_pooling
             feats = lift_features(depth_used.float(), context.float())
             feats = feats.view(batch_size, num_cams, *feats.shape[1:])
+            # geometry AFTER the lift: its small kernels give the 606 MB of non-temporal lift stores time
+            # to drain before the pooling kernel starts reading them (bench roofline.avg_ms: see DESIGN 3.1)
+            geom_xyz = self.get_geometry_voxels(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
+                                                mats_dict['intrin_mats'][:, sweep_index, ...],
+                                                mats_dict.get('bda_mat', None))
             feature_map = voxel_pooling(geom_xyz, feats, self._voxel_num_host)
         # the reference's `.contiguous()` (:467) would transpose to NCHW; the pooled map is
         # already a dense channels_last tensor, which the BEV convs consume directly
