@@ -262,6 +262,16 @@ int mmt_pillar_scatter_backward(int64_t num_voxels, int C, int batch_size, int n
                                 const float *grad_canvas, const int32_t *coors,
                                 const int32_t *workspace, float *grad_feats, void *stream);
 
+/* Channels-last variant of the pillar scatter: canvas fp32 [B, ny, nx, C] (the memory the channels_last BEV
+ * convolutions consume; returned to torch as a [B, C, ny, nx] view), same last-writer semantics, same
+ * workspace (cell -> row map).  A cell is one contiguous C-float row: the scatter writes and the backward
+ * gathers whole rows instead of C values ny*nx floats apart.  C % 4 == 0. */
+int mmt_pillar_scatter_nhwc(int64_t num_voxels, int C, int batch_size, int ny, int nx, const float *voxel_features,
+                            const int32_t *coors, float *canvas, int32_t *workspace, void *stream);
+int mmt_pillar_scatter_nhwc_backward(int64_t num_voxels, int C, int batch_size, int ny, int nx,
+                                     const float *grad_canvas, const int32_t *coors, const int32_t *workspace,
+                                     float *grad_feats, void *stream);
+
 /* --------------------------------------------------------- per-step label generation */
 
 /* LiDAR depth supervision of the camera branch: replaces

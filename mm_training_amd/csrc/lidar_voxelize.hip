@@ -394,6 +394,51 @@ extern "C" int mmt_simple_vfe(int64_t M, int T, int F, int nf, const float *voxe
     return mmt::check_launch("simple_vfe");
 }
 
+// Channels-last canvas [B, ny, nx, C] (what the channels_last BEV convolutions consume): a cell is one
+// contiguous C-float row, so the scatter writes and the backward gathers whole rows -- one lane group of
+// C/4 lanes per cell / voxel, 16 bytes per lane, no strided accesses (the NCHW backward gathers C values
+// with a stride of ny*nx floats per voxel).
+__global__ __launch_bounds__(256) void scatter_write_nhwc_kernel(int C4, int64_t cells, const float *feats,
+                                                                 const int32_t *map, float *canvas) {
+    // one lane group of C4 lanes per cell, kCells cells per group and trip: the map entries of a trip are
+    // loaded first (unconditional), the rare owner rows (5 % of the cells) are fetched per lane
+    constexpr int kCells = 4;
+    const int lane_in = threadIdx.x % C4;                 // C4 divides 256 or the tail lanes idle
+    const int groups_per_block = 256 / C4;
+    const int grp = threadIdx.x / C4;
+    if (grp >= groups_per_block) return;
+    const int64_t ngroups = (int64_t)gridDim.x * groups_per_block;
+    for (int64_t c0 = ((int64_t)blockIdx.x * groups_per_block + grp) * kCells; c0 < cells; c0 += ngroups * kCells) {
+        int m[kCells];
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) m[u] = map[(c0 + u) < cells ? (c0 + u) : (cells - 1)];
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) {
+            if (c0 + u >= cells) break;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m[u] >= 0) v = reinterpret_cast<const float4 *>(feats)[(int64_t)m[u] * C4 + lane_in];
+            mmt_nt_store4(v, reinterpret_cast<float4 *>(canvas) + (c0 + u) * C4 + lane_in);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_backward_nhwc_kernel(int64_t M, int C4, int B, int ny, int nx,
+                                                                    const float *grad_canvas, const int32_t *coors,
+                                                                    const int32_t *map, float *grad_feats) {
+    const int64_t total = M * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / C4;
+        const int c4 = (int)(i - m * C4);
+        const int b = coors[m * 4], y = coors[m * 4 + 2], x = coors[m * 4 + 3];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx)) {
+            const int64_t cell = ((int64_t)b * ny + y) * nx + x;
+            if (map[cell] == (int)m) v = reinterpret_cast<const float4 *>(grad_canvas)[cell * C4 + c4];
+        }
+        reinterpret_cast<float4 *>(grad_feats)[i] = v;
+    }
+}
+
 extern "C" int mmt_pillar_scatter(int64_t M, int C, int B, int ny, int nx, const float *feats,
                                   const int32_t *coors, float *canvas, int32_t *workspace,
                                   void *stream) {
@@ -429,4 +474,39 @@ extern "C" int mmt_pillar_scatter_backward(int64_t M, int C, int B, int ny, int 
     hipLaunchKernelGGL(scatter_backward_kernel, dim3(mmt::stream_grid(M * C, 256)), dim3(256), 0,
                        (hipStream_t)stream, M, C, B, ny, nx, grad_canvas, coors, workspace, grad_feats);
     return mmt::check_launch("pillar_scatter_backward");
+}
+
+extern "C" int mmt_pillar_scatter_nhwc(int64_t M, int C, int B, int ny, int nx, const float *feats,
+                                       const int32_t *coors, float *canvas, int32_t *workspace, void *stream) {
+    MMT_REQUIRE_PTR(canvas);
+    MMT_REQUIRE_PTR(workspace);
+    if (M > 0) { MMT_REQUIRE_PTR(feats); MMT_REQUIRE_PTR(coors); }
+    if (M < 0 || C <= 0 || C % 4 || C > 1024 || B <= 0 || ny <= 0 || nx <= 0 || M >= (1ll << 31) || ((uintptr_t)canvas & 15) ||
+        ((uintptr_t)feats & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc: bad sizes (C %% 4 == 0, C <= 1024, 16-byte aligned buffers)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t cells = (int64_t)B * ny * nx;
+    if (cells >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "pillar_scatter_nhwc: B*ny*nx exceeds int32");
+    hipError_t e = hipMemsetAsync(workspace, 0xff, sizeof(int32_t) * cells, st);
+    if (e != hipSuccess) return mmt::fail((int)e, "pillar_scatter_nhwc: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    if (M > 0)
+        hipLaunchKernelGGL(scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
+    hipLaunchKernelGGL(scatter_write_nhwc_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / (C / 4))) * 256, 256, 256 * 32)), dim3(256), 0, st,
+                       C / 4, cells, feats, workspace, canvas);
+    return mmt::check_launch("pillar_scatter_nhwc");
+}
+
+extern "C" int mmt_pillar_scatter_nhwc_backward(int64_t M, int C, int B, int ny, int nx, const float *grad_canvas,
+                                                const int32_t *coors, const int32_t *workspace, float *grad_feats,
+                                                void *stream) {
+    if (M == 0) return MMT_OK;
+    MMT_REQUIRE_PTR(grad_canvas);
+    MMT_REQUIRE_PTR(coors);
+    MMT_REQUIRE_PTR(workspace);
+    MMT_REQUIRE_PTR(grad_feats);
+    if (M < 0 || C <= 0 || C % 4 || B <= 0 || ny <= 0 || nx <= 0 || ((uintptr_t)grad_canvas & 15) || ((uintptr_t)grad_feats & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_backward: bad sizes");
+    hipLaunchKernelGGL(scatter_backward_nhwc_kernel, dim3(mmt::stream_grid(M * (C / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, M, C / 4, B, ny, nx, grad_canvas, coors, workspace, grad_feats);
+    return mmt::check_launch("pillar_scatter_nhwc_backward");
 }

@@ -103,7 +103,7 @@ def simple_vfe(voxels, num_points, num_features):
 
 class _PillarScatter(Function):
     @staticmethod
-    def forward(ctx, feats, coors, batch_size, ny, nx):
+    def forward(ctx, feats, coors, batch_size, ny, nx, channels_last):
         if not feats.is_cuda:
             raise RuntimeError("voxel_features must be a CUDAtensor ")
         feats = feats.contiguous()
@@ -111,31 +111,42 @@ class _PillarScatter(Function):
         if coors.dtype != torch.int32:
             coors = coors.int()
         M, C = feats.shape
-        canvas = torch.empty((batch_size, C, ny, nx), dtype=torch.float32, device=feats.device)
+        nhwc = bool(channels_last) and C % 4 == 0
+        if nhwc:   # same values, channels_last memory: the canvas is returned as a [B, C, ny, nx] view
+            canvas = torch.empty((batch_size, ny, nx, C), dtype=torch.float32, device=feats.device)
+        else:
+            canvas = torch.empty((batch_size, C, ny, nx), dtype=torch.float32, device=feats.device)
         cell_map = torch.empty((batch_size * ny * nx,), dtype=torch.int32, device=feats.device)
         with torch.cuda.device(feats.device):
-            _lib.call("mmt_pillar_scatter", M, C, batch_size, ny, nx, feats.data_ptr() if M else 0,
-                      coors.data_ptr() if M else 0, canvas.data_ptr(), cell_map.data_ptr(), _stream())
+            _lib.call("mmt_pillar_scatter_nhwc" if nhwc else "mmt_pillar_scatter", M, C, batch_size, ny, nx,
+                      feats.data_ptr() if M else 0, coors.data_ptr() if M else 0, canvas.data_ptr(),
+                      cell_map.data_ptr(), _stream())
         ctx.save_for_backward(coors, cell_map)
-        ctx.dims = (M, C, batch_size, ny, nx)
-        return canvas
+        ctx.dims = (M, C, batch_size, ny, nx, nhwc)
+        return canvas.permute(0, 3, 1, 2) if nhwc else canvas
 
     @staticmethod
     def backward(ctx, grad_canvas):
         coors, cell_map = ctx.saved_tensors
-        M, C, B, ny, nx = ctx.dims
+        M, C, B, ny, nx, nhwc = ctx.dims
         grad_feats = torch.empty((M, C), dtype=torch.float32, device=grad_canvas.device)
         if M:
-            grad_canvas = grad_canvas.contiguous()
+            if nhwc:
+                if not grad_canvas.is_contiguous(memory_format=torch.channels_last):
+                    grad_canvas = grad_canvas.contiguous(memory_format=torch.channels_last)
+            else:
+                grad_canvas = grad_canvas.contiguous()
             with torch.cuda.device(grad_canvas.device):
-                _lib.call("mmt_pillar_scatter_backward", M, C, B, ny, nx, grad_canvas.data_ptr(),
-                          coors.data_ptr(), cell_map.data_ptr(), grad_feats.data_ptr(), _stream())
-        return grad_feats, None, None, None, None
+                _lib.call("mmt_pillar_scatter_nhwc_backward" if nhwc else "mmt_pillar_scatter_backward", M, C, B, ny, nx,
+                          grad_canvas.data_ptr(), coors.data_ptr(), cell_map.data_ptr(), grad_feats.data_ptr(), _stream())
+        return grad_feats, None, None, None, None, None
 
 
-def pillar_scatter(voxel_features, coors, batch_size, ny, nx):
-    """PointPillarsScatter: dense [B, C, ny, nx] canvas from per-voxel features."""
-    return _PillarScatter.apply(voxel_features, coors, int(batch_size), int(ny), int(nx))
+def pillar_scatter(voxel_features, coors, batch_size, ny, nx, channels_last=False):
+    """PointPillarsScatter: dense [B, C, ny, nx] canvas from per-voxel features.  ``channels_last=True``
+    returns the same tensor in torch.channels_last memory (what channels_last convolutions consume:
+    no layout conversion in front of the BEV trunk, row-contiguous backward gather)."""
+    return _PillarScatter.apply(voxel_features, coors, int(batch_size), int(ny), int(nx), bool(channels_last))
 
 
 class LidarEncoder(nn.Module):
@@ -148,8 +159,10 @@ class LidarEncoder(nn.Module):
     `in_channels` before the scatter (PointPillars' PFN role)."""
 
     def __init__(self, pts_voxel_layer, pts_voxel_encoder=None, pts_middle_encoder=None,
-                 pillar_channels=None, **unused):
+                 pillar_channels=None, channels_last=True, **unused):
         super().__init__()
+        # memory format of the scattered canvas (values and logical [B, C, ny, nx] shape are the same)
+        self.channels_last = bool(channels_last)
         self.voxel_cfg = dict(pts_voxel_layer)
         mv = self.voxel_cfg.get("max_voxels", 25000)
         self.max_voxels = int(mv[0] if isinstance(mv, (tuple, list)) else mv)
@@ -183,7 +196,8 @@ class LidarEncoder(nn.Module):
     def pts_middle_encoder(self, voxel_features, coors, batch_size):
         if self.pillar_mlp is not None:
             voxel_features = self.pillar_mlp(voxel_features)
-        return pillar_scatter(voxel_features, coors, batch_size, self.output_shape[0], self.output_shape[1])
+        return pillar_scatter(voxel_features, coors, batch_size, self.output_shape[0], self.output_shape[1],
+                              channels_last=self.channels_last)
 
     def forward_bev(self, points):
         """voxelize -> mean -> (MLP) -> scatter with NO host synchronisation: stays in the
@@ -196,4 +210,5 @@ class LidarEncoder(nn.Module):
             feats = simple_vfe(voxels, num_points, self.num_features)
         if self.pillar_mlp is not None:
             feats = self.pillar_mlp(feats)
-        return pillar_scatter(feats, coors, len(points), self.output_shape[0], self.output_shape[1])
+        return pillar_scatter(feats, coors, len(points), self.output_shape[0], self.output_shape[1],
+                              channels_last=self.channels_last)

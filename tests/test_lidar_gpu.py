@@ -92,8 +92,11 @@ def test_voxelize_3d_grid(mmt_lib, oracle_mod):
     _check(oracle_mod, _frames([5000, 7000], rng_range=rng, seed=9), 5, 4000, vsize=[0.5, 0.5, 1.0], rng=rng)
 
 
-def test_pillar_scatter_forward_backward(mmt_lib, oracle_mod):
-    from mm_training_amd.lidar import pillar_scatter
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_pillar_scatter_forward_backward(mmt_lib, oracle_mod, channels_last):
+    import functools
+    from mm_training_amd.lidar import pillar_scatter as _ps
+    pillar_scatter = functools.partial(_ps, channels_last=channels_last)
     rv, rn, rc = oracle_mod.voxelize_batch([f.numpy() for f in _frames([20000, 15000], seed=5)], VSIZE, RANGE, 15, 25000)
     M = rc.shape[0]
     C = 64
@@ -104,6 +107,7 @@ def test_pillar_scatter_forward_backward(mmt_lib, oracle_mod):
     f = torch.from_numpy(feats).cuda().requires_grad_(True)
     canvas = pillar_scatter(f, torch.from_numpy(rc).cuda(), 2, ny, nx)
     assert canvas.shape == (2, C, ny, nx)
+    assert canvas.is_contiguous(memory_format=torch.channels_last) == channels_last
     assert np.array_equal(canvas.detach().cpu().numpy(), ref)
     g = rng.standard_normal(ref.shape).astype(np.float32)
     canvas.backward(torch.from_numpy(g).cuda())

@@ -52,6 +52,18 @@ def main():
     ms = timeit(lambda: pillar_scatter(feats, c, B, ny, nx))
     sb = 4 * C * M + 16 * M + 4 * C * B * ny * nx
     res["pillar_scatter"] = {"ms": ms, "canvas": [B, C, ny, nx], "algorithmic_MB": sb / 1e6, "GBps": sb / ms / 1e6}
+    # channels-last canvas (what the channels_last BEV trunk consumes) and the two backward variants
+    ms_cl = timeit(lambda: pillar_scatter(feats, c, B, ny, nx, channels_last=True))
+    res["pillar_scatter_channels_last"] = {"ms": ms_cl, "GBps": sb / ms_cl / 1e6}
+    for tag, cl in (("nchw", False), ("channels_last", True)):
+        fr = feats.detach().clone().requires_grad_(True)
+        cv = pillar_scatter(fr, c, B, ny, nx, channels_last=cl)
+        go = torch.randn(B, C, ny, nx, device="cuda")
+        if cl:
+            go = go.contiguous(memory_format=torch.channels_last)
+        ms_b = timeit(lambda: torch.autograd.grad(cv, fr, go, retain_graph=True))
+        bb = 4 * C * feats.shape[0] * 2 + 16 * feats.shape[0]        # gradient rows read + written, coors
+        res["pillar_scatter_backward_" + tag] = {"ms": ms_b, "algorithmic_MB": bb / 1e6, "GBps": bb / ms_b / 1e6}
     # camera-side producers at cfg2
     s2e, K = synthetic.camera_rig(4, 6, 704, 256, jitter=0.02)
     combine = (s2e @ torch.inverse(K)).cuda()
