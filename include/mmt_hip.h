@@ -70,6 +70,11 @@ int mmt_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
                                      per lane group), kept for A/B measurements */
 #define MMT_VP_WRITE_DROPPED 0x10 /* also write (-1,-1,-1) to pos_memo rows of dropped points,
                                      so the caller need not pre-fill pos_memo */
+#define MMT_VP_CHUNK_POINTS(n) ((((n) / 4) & 0xFF) << 8) /* SEG_GATHER: points per workgroup (multiple of 4,
+                                     64..512); 0 = sized by the library so that the grid is a whole number of
+                                     rounds of the resident workgroups.  A tuning knob: results do not depend on it
+                                     beyond the fp32 summation order. */
+#define MMT_VP_CHUNK_POINTS_MASK 0xFF00
 int mmt_voxel_pooling_forward_ex(int batch_size, int num_points, int num_channels,
                                  int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                  const int32_t *geom_xyz, const float *input_features,

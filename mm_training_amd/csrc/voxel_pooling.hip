@@ -285,6 +285,16 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     const int64_t base = (int64_t)blockIdx.x * cp;
     const int npts = (int)((a.BP - base) < cp ? (a.BP - base) : cp);
 
+    // all geom rows of the lane are requested up front, ahead of the LDS initialisation and its barrier, (clamped index, so the
+    // loads are unconditional): one memory round trip per workgroup instead of PPT serial ones
+    int gx[PPT], gy[PPT], gz[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int lp = tid + k * kBlock;
+        const int64_t t = base + (lp < npts ? lp : npts - 1);
+        gx[k] = a.geom[t * 3]; gy[k] = a.geom[t * 3 + 1]; gz[k] = a.geom[t * 3 + 2];
+    }
+
     for (int i = tid; i < HT; i += kBlock) tab_key[i] = kEmpty;
     for (int i = tid; i < CHUNK; i += kBlock) slot_cnt[i] = 0;
     if (tid == 0) { nslots = 0; next_slot = 0; next_long = 0; nlong = 0; }
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
                 pt_pix[lp] = (int)(cam * (unsigned)a.HW + rem % (unsigned)a.HW);
                 pt_depth[lp] = a.depth[t];
             }
-            const int x = a.geom[t * 3], y = a.geom[t * 3 + 1], z = a.geom[t * 3 + 2];
+            const int x = gx[k], y = gy[k], z = gz[k];
             if (in_grid(x, y, z, a.nx, a.ny, a.nz)) {
                 const int b = (int)((unsigned)t / (unsigned)a.P);
                 pm[k][0] = b; pm[k][1] = y; pm[k][2] = x;
@@ -827,23 +837,53 @@ struct VpBwdArgs {
 // although only 44 MB of its 650 MB are reads).  Pass 1 reads them while the memory
 // system is idle and leaves 4 B/point + the gradient rows in L2 / Infinity Cache.
 // Same XCD-contiguous partition as pass 2, so each XCD warms its own L2.
+//
+// The pass is a dependent chain pos_memo -> row touch on a small problem (44 MB), i.e. bound by
+// memory latency, not bandwidth: each lane therefore takes kPrepU points per trip and keeps all
+// of their loads in flight together -- 3*kPrepU pos_memo dwords (clamped index, unconditional),
+// then kPrepU*SECT row touches through a buffer descriptor (a dropped point uses an out-of-range
+// offset: the hardware returns zero without a memory access, so no branch separates the loads and
+// hipcc waits once per batch instead of once per point).  One point per trip (first version):
+// 19 us at cfg2, ~4 serial round trips per lane.
+constexpr int kPrepU = 4;
+
+template <int SECT_T>
 __global__ __launch_bounds__(kBlock) void vp_bwd_prepare(VpBwdArgs a, int rows_per_xcd) {
+    const int SECT = SECT_T > 0 ? SECT_T : (a.C + 15) >> 4;   // 64-byte sectors per gradient row
     const int xcd = blockIdx.x & 7;
     const int64_t r_begin = (int64_t)xcd * rows_per_xcd;
     const int64_t r_end = (r_begin + rows_per_xcd) < a.BP ? (r_begin + rows_per_xcd) : a.BP;
-    float sink = 0.f;
-    for (int64_t t = r_begin + (blockIdx.x >> 3) * kBlock + threadIdx.x; t < r_end;
-         t += (int64_t)(gridDim.x >> 3) * kBlock) {
-        const int b = a.pos_memo[t * 3];
-        const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
-        const unsigned o = (unsigned)(b * a.sb + y * a.sy + x * a.sx) * 4u;
-        a.row_off_out[t] = (b != -1) ? o : 0xFFFFFFF0u;
-        if (b != -1) {
-            const float *row = a.grad_out + (b * a.sb + y * a.sy + x * a.sx);
-            for (int c = 0; c < a.C; c += 16) sink += row[c];   // one dword per 64-byte sector
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.grad_out), 0, (int)a.span_bytes, 0x00020000);
+    const int64_t step = (int64_t)(gridDim.x >> 3) * kBlock * kPrepU;
+    unsigned sink = 0u;
+    for (int64_t t0 = r_begin + (int64_t)(blockIdx.x >> 3) * kBlock * kPrepU + threadIdx.x; t0 < r_end; t0 += step) {
+        int b[kPrepU], y[kPrepU], x[kPrepU];
+#pragma unroll
+        for (int u = 0; u < kPrepU; ++u) {
+            const int64_t t = t0 + (int64_t)u * kBlock;
+            const int64_t tc = t < r_end ? t : r_end - 1;     // clamped: every load is unconditional
+            b[u] = a.pos_memo[tc * 3];
+            y[u] = a.pos_memo[tc * 3 + 1];
+            x[u] = a.pos_memo[tc * 3 + 2];
+        }
+        unsigned off[kPrepU];
+#pragma unroll
+        for (int u = 0; u < kPrepU; ++u) {
+            const int64_t t = t0 + (int64_t)u * kBlock;
+            const int64_t tc = t < r_end ? t : r_end - 1;     // clamped lanes rewrite the last point's own value
+            const unsigned o = (unsigned)(b[u] * a.sb + y[u] * a.sy + x[u] * a.sx) * 4u;
+            off[u] = (b[u] != -1) ? o : 0xFFFFFFF0u;
+            a.row_off_out[tc] = off[u];
+        }
+#pragma unroll 5
+        for (int s = 0; s < SECT; ++s) {                      // one dword per 64-byte sector of the row
+#pragma unroll
+            for (int u = 0; u < kPrepU; ++u)
+                sink ^= __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[u] == 0xFFFFFFF0u ? off[u] : off[u] + s * 64u, 0, 0);
         }
     }
-    if (sink == 1.2345e-30f) a.row_off_out[0] = 0;  // never true: keeps the touches alive
+    if (sink == 0x9E3779B9u && a.BP < 0) a.row_off_out[0] = 0;  // never true: keeps the touches alive
 }
 
 // Software-pipelined: the dependent chain pos_memo -> BEV-gradient row -> store is
@@ -1113,8 +1153,11 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     int algo = flags & MMT_VP_ALGO_MASK;
     if (algo > MMT_VP_ALGO_STREAM)
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown algorithm %d", algo);
-    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024 | MMT_VP_WAVE_PER_SLOT))
+    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024 | MMT_VP_WAVE_PER_SLOT | MMT_VP_CHUNK_POINTS_MASK))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown flag bits 0x%x", flags);
+    const int chunk_points = ((flags & MMT_VP_CHUNK_POINTS_MASK) >> 8) * 4;
+    if (chunk_points != 0 && (chunk_points < 64 || chunk_points > 512 || (flags & MMT_VP_CHUNK_1024)))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: MMT_VP_CHUNK_POINTS must be 64..512 (got %d) and excludes MMT_VP_CHUNK_1024", chunk_points);
     hipStream_t st = (hipStream_t)stream;
 
     VpArgs a;
@@ -1133,7 +1176,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
         const bool fused = false;
         const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
         const bool wave_slots = (flags & MMT_VP_WAVE_PER_SLOT) != 0;
-        const int chunk = big ? 1024 : balanced_chunk_points(BP, 512);
+        const int chunk = big ? 1024 : (chunk_points ? chunk_points : balanced_chunk_points(BP, 512));
         a.nchunks = chunk;
         const int64_t nchunks = mmt::ceil_div(BP, chunk);
         const dim3 grid((unsigned)nchunks), block(kBlock);
@@ -1245,9 +1288,11 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
         // pass 1: row offsets + cache warm-up (see vp_bwd_prepare)
         a.row_off_out = reinterpret_cast<uint32_t *>(workspace + bev_elems);
         const int rows_per_xcd = (int)mmt::ceil_div(BP, 8);
-        int pgrid = mmt::stream_grid(BP, kBlock, 256 * 8);
+        int pgrid = mmt::stream_grid(mmt::ceil_div(BP, kPrepU), kBlock, 256 * 8);
         pgrid = (pgrid + 7) & ~7;
-        hipLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
+        if (C == 80) hipLaunchKernelGGL((vp_bwd_prepare<5>), dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
+        else if (C == 64) hipLaunchKernelGGL((vp_bwd_prepare<4>), dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
+        else hipLaunchKernelGGL((vp_bwd_prepare<0>), dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
         int rc = mmt::check_launch("voxel_pooling_backward(prepare)");
         if (rc) return rc;
         a.row_off = a.row_off_out;

@@ -40,7 +40,9 @@ def test_host_side_argument_checks(mmt_lib):
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.mmt_voxel_pooling_forward(0, 8, 4, 2, 2, 1, p, p, p, p, None) == -2
     assert lib.mmt_voxel_pooling_forward_ex(1, 8, 4, 2, 2, 1, p, p, p, p, 7, None) == -4
-    assert lib.mmt_voxel_pooling_forward_ex(1, 8, 4, 2, 2, 1, p, p, p, p, 0x100, None) == -4
+    assert lib.mmt_voxel_pooling_forward_ex(1, 8, 4, 2, 2, 1, p, p, p, p, 0x100, None) == -4          # chunk of 4 points: < 64
+    assert lib.mmt_voxel_pooling_forward_ex(1, 8, 4, 2, 2, 1, p, p, p, p, 3 | 0x20 | (58 << 8), None) == -4   # excludes CHUNK_1024
+    assert lib.mmt_voxel_pooling_forward_ex(1, 8, 4, 2, 2, 1, p, p, p, p, 0x10000, None) == -4        # unknown bit
     assert lib.mmt_voxel_pooling_forward(70000, 70000, 4, 2, 2, 1, p, p, p, p, None) == -3
     assert lib.mmt_voxel_pooling_backward(1, 8, 4, 2, 2, None, p, 1, 1, 1, 1, p, None, 0, None) == -1
     assert lib.mmt_voxel_pooling_backward_workspace_elems(2, 10, 4, 3, 5) == 2 * 5 * 3 * 4 + 20
