@@ -61,6 +61,38 @@ def main():
                                           gi.data_ptr(), ws.data_ptr(), ws_elems, st)
         assert rc == 0, h.mmt_last_error()
 
+    # the lift (producer of the feature matrix, lss_fpn.py:423-463) and its backward, same builds
+    N, D = sh["N"], int((sh["d_bound"][1] - sh["d_bound"][0]) / sh["d_bound"][2])
+    HW = P // (N * D)
+    depth = torch.rand(B * N, D, HW, device="cuda")
+    context = torch.randn(B * N, C, HW, device="cuda")
+    gd, gc = torch.empty_like(depth), torch.empty_like(context)
+
+    def lift(h):
+        rc = h.mmt_lift_features(B * N, D, HW, C, depth.data_ptr(), context.data_ptr(), gi.data_ptr(), st)
+        assert rc == 0, h.mmt_last_error()
+
+    def lift_bwd(h):
+        rc = h.mmt_lift_features_backward(B * N, D, HW, C, depth.data_ptr(), context.data_ptr(), gi.data_ptr(),
+                                          gd.data_ptr(), gc.data_ptr(), st)
+        assert rc == 0, h.mmt_last_error()
+
+    lift_res, lift_checks = [{"lift": [], "lift_bwd": []} for _ in libs], []
+    for h in libs:
+        lift(h); lift_bwd(h); torch.cuda.synchronize()
+        lift_checks.append((gd.clone(), gc.clone()))
+    for rnd in range(args.rounds + 2):
+        for k, h in enumerate(libs):
+            evs = []
+            for it in range(6):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                e[0].record(); lift(h); e[1].record(); e[2].record(); lift_bwd(h); e[3].record()
+                evs.append(e)
+            torch.cuda.synchronize()
+            if rnd >= 2:
+                lift_res[k]["lift"].append(sorted(e[0].elapsed_time(e[1]) for e in evs)[3])
+                lift_res[k]["lift_bwd"].append(sorted(e[2].elapsed_time(e[3]) for e in evs)[3])
+
     results, checks = [{"fwd": [], "bwd": []} for _ in libs], []
     for h in libs:
         out.zero_(); fwd(h); bwd(h); torch.cuda.synchronize()
@@ -82,6 +114,9 @@ def main():
         "shape": args.shape, "libs": args.libs,
         "fwd_us": [round(med(r["fwd"]) * 1e3, 2) for r in results],
         "bwd_us": [round(med(r["bwd"]) * 1e3, 2) for r in results],
+        "lift_us": [round(med(r["lift"]) * 1e3, 2) for r in lift_res],
+        "lift_bwd_us": [round(med(r["lift_bwd"]) * 1e3, 2) for r in lift_res],
+        "lift_bwd_max_rel_diff": [float(((lift_checks[0][i] - lift_checks[1][i]).abs().max() / lift_checks[0][i].abs().max())) for i in (0, 1)],
         "pos_memo_equal": bool(torch.equal(checks[0][1], checks[1][1])),
         "grad_in_equal": bool(torch.equal(checks[0][2], checks[1][2])),
         "bev_max_abs_diff": float((checks[0][0] - checks[1][0]).abs().max())}))
