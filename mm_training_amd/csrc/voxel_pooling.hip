@@ -830,33 +830,31 @@ struct VpBwdArgs {
 };
 
 // Backward, pass 1 (tiny): pos_memo -> per-point byte offset of its BEV-gradient row
-// (0xFFFFFFF0 = dropped), and touch that row so it is on-die before the write-heavy
-// pass starts.  Why a separate pass: with ~93 % of pass 2's HBM traffic being writes,
-// a read that misses the Infinity Cache queues behind the write drain (measured: the
-// same gather kernel runs 100 us with pos_memo / grad_out cache-warm and 170 us cold,
-// although only 44 MB of its 650 MB are reads).  Pass 1 reads them while the memory
-// system is idle and leaves 4 B/point + the gradient rows in L2 / Infinity Cache.
-// Same XCD-contiguous partition as pass 2, so each XCD warms its own L2.
+// (0xFFFFFFF0 = dropped), and pull the gradient on-die before the write-heavy pass starts.
+// Why a separate pass: with ~93 % of pass 2's HBM traffic being writes, a read that misses the
+// Infinity Cache queues behind the write drain (measured: the same gather kernel runs 100 us
+// with pos_memo / grad_out cache-warm and 170 us cold, although only 44 MB of its 650 MB are
+// reads).  Pass 1 reads them while the memory system is idle and leaves 4 B/point in L2 /
+// Infinity Cache.  Same XCD-contiguous partition of the points as pass 2.
 //
-// The pass is a dependent chain pos_memo -> row touch on a small problem (44 MB), i.e. bound by
-// memory latency, not bandwidth: each lane therefore takes kPrepU points per trip and keeps all
-// of their loads in flight together -- 3*kPrepU pos_memo dwords (clamped index, unconditional),
-// then kPrepU*SECT row touches through a buffer descriptor (a dropped point uses an out-of-range
-// offset: the hardware returns zero without a memory access, so no branch separates the loads and
-// hipcc waits once per batch instead of once per point).  One point per trip (first version):
-// 19 us at cfg2, ~4 serial round trips per lane.
+// The pass is a short dependent chain on a small problem, i.e. bound by memory latency: each lane
+// takes kPrepU points per trip and requests all of their pos_memo rows together (clamped index,
+// unconditional loads; one point per trip cost ~4 serial round trips per lane).
+// The gradient is warmed by a LINEAR sweep of its span (16 B per lane, coalesced), not by gathering
+// the rows the points use: the gather (5 sector touches per kept point, 5.7 M scattered L2 requests
+// at cfg2) cost 9 us and bought nothing -- pass 2 runs equally fast when its first touch of a row
+// is an Infinity-Cache hit instead of an L2 hit (interleaved A/B, us, gather touches / sweep / no
+// warm-up: cfg2 138.8 / 130.4 / 129.9, after a 1 GiB cache flush 138.3 / 133.5 / 130.9; cfg5 246.8 /
+// 234.8 / 233.1, flushed 245.8 / 233.0 / 240.2; inside the cfg-2 training step 137.9 / 131.5 / 130.0).
+// The sweep costs 1-3 us and covers the cold-gradient case; it is skipped when the view spans much more
+// memory than it uses (a thin channel slice of a wide buffer).
 constexpr int kPrepU = 4;
 
-template <int SECT_T>
-__global__ __launch_bounds__(kBlock) void vp_bwd_prepare(VpBwdArgs a, int rows_per_xcd) {
-    const int SECT = SECT_T > 0 ? SECT_T : (a.C + 15) >> 4;   // 64-byte sectors per gradient row
+__global__ __launch_bounds__(kBlock) void vp_bwd_prepare(VpBwdArgs a, int rows_per_xcd, int sweep) {
     const int xcd = blockIdx.x & 7;
     const int64_t r_begin = (int64_t)xcd * rows_per_xcd;
     const int64_t r_end = (r_begin + rows_per_xcd) < a.BP ? (r_begin + rows_per_xcd) : a.BP;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.grad_out), 0, (int)a.span_bytes, 0x00020000);
     const int64_t step = (int64_t)(gridDim.x >> 3) * kBlock * kPrepU;
-    unsigned sink = 0u;
     for (int64_t t0 = r_begin + (int64_t)(blockIdx.x >> 3) * kBlock * kPrepU + threadIdx.x; t0 < r_end; t0 += step) {
         int b[kPrepU], y[kPrepU], x[kPrepU];
 #pragma unroll
@@ -867,23 +865,32 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_prepare(VpBwdArgs a, int rows_p
             y[u] = a.pos_memo[tc * 3 + 1];
             x[u] = a.pos_memo[tc * 3 + 2];
         }
-        unsigned off[kPrepU];
 #pragma unroll
         for (int u = 0; u < kPrepU; ++u) {
             const int64_t t = t0 + (int64_t)u * kBlock;
             const int64_t tc = t < r_end ? t : r_end - 1;     // clamped lanes rewrite the last point's own value
             const unsigned o = (unsigned)(b[u] * a.sb + y[u] * a.sy + x[u] * a.sx) * 4u;
-            off[u] = (b[u] != -1) ? o : 0xFFFFFFF0u;
-            a.row_off_out[tc] = off[u];
-        }
-#pragma unroll 5
-        for (int s = 0; s < SECT; ++s) {                      // one dword per 64-byte sector of the row
-#pragma unroll
-            for (int u = 0; u < kPrepU; ++u)
-                sink ^= __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[u] == 0xFFFFFFF0u ? off[u] : off[u] + s * 64u, 0, 0);
+            a.row_off_out[tc] = (b[u] != -1) ? o : 0xFFFFFFF0u;
         }
     }
-    if (sink == 0x9E3779B9u && a.BP < 0) a.row_off_out[0] = 0;  // never true: keeps the touches alive
+    if (sweep) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.grad_out), 0, (int)a.span_bytes, 0x00020000);
+        const int64_t nvec = a.span_bytes >> 4;
+        const int64_t nthr = (int64_t)gridDim.x * kBlock;
+        unsigned sink = 0u;
+        for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < nvec; i0 += 4 * nthr) {
+            mmt_u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // past the end: out-of-range offset, the hardware returns zeros without an access
+                const int64_t i = i0 + u * nthr;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i < nvec ? (unsigned)(i << 4) : 0xFFFFFFF0u, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sink ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+        if (sink == 0x9E3779B9u && a.BP < 0) a.row_off_out[0] = 0;  // never true: keeps the sweep alive
+    }
 }
 
 // Software-pipelined: the dependent chain pos_memo -> BEV-gradient row -> store is
@@ -1290,9 +1297,8 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
         const int rows_per_xcd = (int)mmt::ceil_div(BP, 8);
         int pgrid = mmt::stream_grid(mmt::ceil_div(BP, kPrepU), kBlock, 256 * 8);
         pgrid = (pgrid + 7) & ~7;
-        if (C == 80) hipLaunchKernelGGL((vp_bwd_prepare<5>), dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
-        else if (C == 64) hipLaunchKernelGGL((vp_bwd_prepare<4>), dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
-        else hipLaunchKernelGGL((vp_bwd_prepare<0>), dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd);
+        const int sweep = span <= 4 * bev_elems;   // a thin slice of a much wider buffer: not worth reading the whole span
+        hipLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd, sweep);
         int rc = mmt::check_launch("voxel_pooling_backward(prepare)");
         if (rc) return rc;
         a.row_off = a.row_off_out;

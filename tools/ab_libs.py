@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--shape", default="cfg2")
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--flags", type=lambda v: int(v, 0), default=3 | 0x10)
+    ap.add_argument("--env-ab", default="", help="NAME=v1,v2,..: alternate this environment variable (a diagnostic switch read by "
+                                                 "the SECOND library per call) and time forward / backward for every value")
+    ap.add_argument("--flush", action="store_true", help="with --env-ab: a 1 GiB read before every backward (cold Infinity Cache)")
     args = ap.parse_args()
     sh = SHAPES[args.shape]
     B, C = sh["B"], sh["C"]
@@ -110,6 +113,33 @@ def main():
                 results[k]["fwd"].append(sorted(e[0].elapsed_time(e[1]) for e in evs)[3])
                 results[k]["bwd"].append(sorted(e[2].elapsed_time(e[3]) for e in evs)[3])
     med = lambda v: sorted(v)[len(v) // 2]
+    if args.env_ab:
+        name, vals = args.env_ab.split("=")
+        vals = vals.split(",")
+        flush = torch.empty(256 * 1024 * 1024, device="cuda") if args.flush else None
+        per = {m: {"fwd": [], "bwd": []} for m in vals}
+        h, ref_gi = libs[1], checks[1][2]
+        for rnd in range(args.rounds + 2):
+            for m in vals:
+                os.environ[name] = m
+                evs = []
+                for it in range(6):
+                    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    out.zero_()
+                    e[0].record(); fwd(h); e[1].record()
+                    if flush is not None:
+                        flush.sum()
+                    e[2].record(); bwd(h); e[3].record()
+                    evs.append(e)
+                torch.cuda.synchronize()
+                assert torch.equal(gi, ref_gi), (name, m)
+                if rnd >= 2:
+                    per[m]["fwd"].append(sorted(e[0].elapsed_time(e[1]) for e in evs)[3])
+                    per[m]["bwd"].append(sorted(e[2].elapsed_time(e[3]) for e in evs)[3])
+        os.environ.pop(name, None)
+        print(json.dumps({"shape": args.shape, "env": name, "flush": bool(args.flush),
+                          "values": {m: {"fwd_us": round(med(r["fwd"]) * 1e3, 2), "bwd_us": round(med(r["bwd"]) * 1e3, 2)} for m, r in per.items()}}))
+        return
     print(json.dumps({
         "shape": args.shape, "libs": args.libs,
         "fwd_us": [round(med(r["fwd"]) * 1e3, 2) for r in results],
