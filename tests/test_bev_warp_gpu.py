@@ -61,6 +61,45 @@ def test_backward_against_torch_autograd(mmt_lib):
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)) + 1e-2
 
 
+@pytest.mark.parametrize("kind", ["aug", "identity", "rot90", "zoom2", "shrink", "shear_shift"])
+def test_backward_is_the_exact_adjoint_of_the_forward(mmt_lib, kind):
+    """The backward gathers, for every source cell, the output cells whose bilinear footprint contains it.
+    Checked against the transpose of the forward's own matrix (forward applied to every one-hot map),
+    accumulated in float64: any missed or doubled candidate cell shows up as a full weight."""
+    from mm_training_amd.ops.bev_warp import bev_warp_affine
+    rng = np.random.default_rng(11)
+    B, C, H, W = 2, 8, 9, 13
+    bda = _bda(B, rng)
+    if kind == "identity":
+        bda = torch.eye(4).repeat(B, 1, 1)
+    elif kind == "rot90":
+        bda[:, :2, :2] = torch.tensor([[0.0, -1.0], [1.0, 0.0]])
+    elif kind == "zoom2":        # one source cell feeds ~16 output cells
+        bda[:, :2, :2] *= 2.0
+    elif kind == "shrink":       # most output cells sample outside the map
+        bda[:, :2, :2] *= 0.45
+    elif kind == "shear_shift":
+        bda[:, :2, :2] = torch.tensor([[1.0, 0.7], [-0.2, 1.1]])
+        bda[:, 0, 2], bda[:, 1, 2] = 2.3, -1.6
+    bda = bda.cuda()
+    # forward matrix per sample: column j = warp(one-hot map j), identical for every channel
+    basis = torch.eye(H * W, device="cuda").reshape(H * W, 1, H, W)
+    mats = []
+    for b in range(B):
+        cols = bev_warp_affine(basis.expand(H * W, 4, H, W).contiguous(), bda[b:b + 1].expand(H * W, 4, 4).contiguous())
+        mats.append(cols[:, 0].reshape(H * W, H * W).double())       # [source cell j, output cell]
+    go = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).cuda()
+    x = torch.zeros(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bev_warp_affine(x, bda).backward(go)
+    for b in range(B):
+        ref = (mats[b] @ go[b].reshape(C, H * W).double().T).T.reshape(C, H, W)
+        assert (x.grad[b].double() - ref).abs().max().item() <= 1e-5, kind
+    # bit-reproducible (no atomics)
+    x2 = torch.zeros_like(x).requires_grad_(True)
+    bev_warp_affine(x2, bda).backward(go)
+    assert torch.equal(x.grad, x2.grad)
+
+
 def test_concat_buffer(mmt_lib):
     """The warped camera map lands in channels [0, C) of the camera|LiDAR buffer, the LiDAR map in
     [C, C+C2) (models/bev_depth.py:187-192); gradients flow to both."""

@@ -133,6 +133,21 @@ def main():
     res["cpu_baseline_oracle_1core_ms"] = {"voxelize": t_vox * 1e3, "simple_vfe": t_vfe * 1e3, "pillar_scatter": t_sc * 1e3,
                                            "quantize_geometry": t_q * 1e3, "frustum_geometry_no_quantize": t_g * 1e3,
                                            "lift_forward": t_l * 1e3}
+    # BEV-augmentation warp of the pooled camera map at the cfg-2 shape: forward gather and
+    # atomics-free backward gather, each 2 x 21 MB of algorithmic traffic (+21 MB read-modify-write backward)
+    from mm_training_amd import _lib
+    Bw, Hw, Ww, Cw = 4, 128, 128, 80
+    xw = torch.randn(Bw, Hw, Ww, Cw, device="cuda")
+    yw, gw = torch.empty_like(xw), torch.zeros_like(xw)
+    bda = torch.eye(4).repeat(Bw, 1, 1)
+    bda[:, :2, :2] = torch.tensor([[0.96, -0.28], [0.28, 0.96]]) * 1.03
+    bda = bda.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    wb = 2 * xw.numel() * 4
+    ms = timeit(lambda: _lib.call("mmt_bev_warp_affine", Bw, Hw, Ww, Cw, bda.data_ptr(), xw.data_ptr(), Cw, yw.data_ptr(), Cw, st))
+    res["bev_warp_forward"] = {"ms": ms, "GBps": wb / ms / 1e6}
+    ms = timeit(lambda: _lib.call("mmt_bev_warp_affine_backward", Bw, Hw, Ww, Cw, bda.data_ptr(), yw.data_ptr(), Cw, gw.data_ptr(), Cw, st))
+    res["bev_warp_backward"] = {"ms": ms, "GBps": (wb + xw.numel() * 4) / ms / 1e6}
     res["hbm_peak_GBps"] = 8000.0
     for k in ("voxelize_fixed_capacity", "simple_vfe", "pillar_scatter", "lift_forward", "lift_backward", "frustum_geometry", "quantize_geometry"):
         res[k]["frac_of_peak"] = res[k]["GBps"] / 8000.0
