@@ -132,11 +132,8 @@ __global__ __launch_bounds__(kBlock) void lift_kernel(int D, int HW, int C, cons
 // together NG*C*4 contiguous bytes), keeps its grad_context float4 in registers over the
 // whole depth loop (4 rows in flight), and reduces the row's dot product with ctx across
 // its lanes by two DPP quad adds + one LDS float add per quad.
-// 6 waves per SIMD (<= 80 VGPRs): the grid is ONE round of workgroups that each walk every depth bin
-// (1416 workgroups = 5.5 waves per SIMD at cfg2), so a lower occupancy would leave a second, nearly
-// empty round that costs a whole workgroup lifetime.
 template <int C4T>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void lift_backward_vec4(int D, int HW, int C, const float *depth,
+__global__ __launch_bounds__(kBlock) void lift_backward_vec4(int D, int HW, int C, const float *depth,
                                                              const float *context, const float *g,
                                                              float *grad_depth, float *grad_context) {
     extern __shared__ __align__(16) float lds[];
@@ -165,43 +162,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     __syncthreads();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // Inactive lanes (tail lanes of the wave, positions past HW) read position s0 of the tile instead:
-    // every load below is unconditional, so the 4-row groups can be double-buffered -- the next group is
-    // requested before the current one is consumed and hipcc waits with counted vmcnt (the first version
-    // loaded 4 rows under `if (active && d < D)`, waited for all of them, computed, and only then asked
-    // for the next 4: one memory round trip per 4 depth bins and per lane group).
-    const int jl = active ? j : 0;
-    const float *src = g + (((int64_t)bn * D) * HW + s0 + jl) * C + li * 4;
+    const float *src = g + (((int64_t)bn * D) * HW + s0 + j) * C + li * 4;
     const int64_t dstride = (int64_t)HW * C;
-    const int Dfull = D & ~3;
-    auto load4 = [&](int d0, float4 (&v)[4]) {
-        d0 = d0 < Dfull ? d0 : 0;                 // past the end: re-read a valid group, never consumed
+    for (int d0 = 0; d0 < D; d0 += 4) {
+        float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (d0 + u) * dstride);
-    };
-    auto row = [&](int d, const float4 &v) {
-        const float dv = dep[d * NG + jl];
-        acc.x += v.x * dv; acc.y += v.y * dv; acc.z += v.z * dv; acc.w += v.w * dv;
-        float dot = v.x * cx.x + v.y * cx.y + v.z * cx.z + v.w * cx.w;
-        dot += __shfl_xor(dot, 1);       // quad reduction (lane groups start on multiples of 4
-        dot += __shfl_xor(dot, 2);       // when C/4 is a multiple of 4; otherwise see the host check)
-        if (active && (li & 3) == 0) atomicAdd(&gd[d * NG + j], dot);
-    };
-    if (Dfull > 0) {
-        float4 va[4], vb[4];
-        load4(0, va);
-        for (int d0 = 0; d0 < Dfull; d0 += 8) {
-            load4(d0 + 4, vb);
+        for (int u = 0; u < 4; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active && d0 + u < D) v[u] = *reinterpret_cast<const float4 *>(src + (d0 + u) * dstride);
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) row(d0 + u, va[u]);
-            if (d0 + 4 >= Dfull) break;
-            load4(d0 + 8, va);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) row(d0 + 4 + u, vb[u]);
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u;
+            if (d < D) {
+                const float dv = dep[d * NG + (active ? j : 0)];
+                acc.x += v[u].x * dv; acc.y += v[u].y * dv; acc.z += v[u].z * dv; acc.w += v[u].w * dv;
+                float dot = v[u].x * cx.x + v[u].y * cx.y + v[u].z * cx.z + v[u].w * cx.w;
+                dot += __shfl_xor(dot, 1);       // quad reduction (lane groups start on multiples of 4
+                dot += __shfl_xor(dot, 2);       // when C/4 is a multiple of 4; otherwise see the host check)
+                if (active && (li & 3) == 0) atomicAdd(&gd[d * NG + j], dot);
+            }
         }
     }
-    for (int d = Dfull; d < D; ++d)          // D % 4 remaining depth bins
-        row(d, *reinterpret_cast<const float4 *>(src + d * dstride));
     if (active) {
         float *gp = grad_context + ((int64_t)bn * C + li * 4) * HW + s0 + j;
         gp[0] = acc.x; gp[HW] = acc.y; gp[2 * (int64_t)HW] = acc.z; gp[3 * (int64_t)HW] = acc.w;
