@@ -78,16 +78,22 @@ def parse():
     return ap.parse_args()
 
 
+def choose_backend(world, local_rank, ndev, requested="nccl"):
+    """Backend and device index of a rank.  One GPU per rank -> RCCL ("nccl").  Fewer GPUs than ranks
+    (functional rehearsal of the N>1 path on a 1-GPU box only): ranks share devices, which RCCL refuses, so
+    EVERY rank falls back to gloo -- the decision depends on (world, ndev) alone, never on the rank, or
+    rank 0 would pick RCCL while the others pick gloo and the rendezvous would hang."""
+    if world > max(ndev, 1):
+        return "gloo", local_rank % max(ndev, 1)
+    return requested, local_rank
+
+
 def init_dist(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     ndev = torch.cuda.device_count()
-    backend = os.environ.get("MMT_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
-    if local_rank >= ndev:
-        # fewer GPUs than ranks (functional testing of the N>1 path on a 1-GPU box only):
-        # ranks share a device, which RCCL refuses, so fall back to gloo
-        local_rank, backend = local_rank % max(ndev, 1), "gloo"
+    backend, local_rank = choose_backend(world, local_rank, ndev, os.environ.get("MMT_DIST_BACKEND", "nccl"))   # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

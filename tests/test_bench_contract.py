@@ -39,3 +39,14 @@ def test_roofline_entry_and_pmc_summary():
 def test_help_and_defaults():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+def test_backend_choice_is_the_same_on_every_rank():
+    """One GPU per rank -> RCCL; fewer GPUs than ranks (rehearsal on a 1-GPU box) -> gloo on EVERY rank
+    (a per-rank decision made rank 0 pick RCCL and rank 1 gloo: the rendezvous hung)."""
+    import bench
+    assert [bench.choose_backend(8, r, 8) for r in range(8)] == [("nccl", r) for r in range(8)]
+    assert [bench.choose_backend(2, r, 1) for r in range(2)] == [("gloo", 0), ("gloo", 0)]
+    assert [bench.choose_backend(4, r, 2) for r in range(4)] == [("gloo", 0), ("gloo", 1), ("gloo", 0), ("gloo", 1)]
+    assert bench.choose_backend(1, 0, 1) == ("nccl", 0)
+    assert bench.choose_backend(2, 1, 8, "gloo") == ("gloo", 1)

@@ -107,6 +107,26 @@ def test_accumulates_into_output_like_reference(mmt_lib):
     assert (out - 2.0 - out0).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("widen", [1, 2, 7])
+def test_backward_gradient_as_channel_slice_of_a_wider_buffer(mmt_lib, oracle_mod, widen):
+    """grad_out handed over as the first C channels of a channels-last buffer `widen` times as wide (what
+    autograd gives when the pooled map was written into the camera|LiDAR concat buffer): the prepare pass
+    sweeps the whole span when it is at most 4x the dense size (widen 1, 2) and skips the sweep beyond (7)."""
+    from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext
+    rng = np.random.default_rng(widen)
+    B, P, C, nx, ny = 2, 3000, 80, 24, 20
+    geom = np.stack([rng.integers(-2, nx + 2, (B, P)), rng.integers(-2, ny + 2, (B, P)), np.zeros((B, P), np.int64)], -1).astype(np.int32)
+    feats = (rng.random((B, P, C), dtype=np.float32) - 0.5)
+    _, ref_pos = oracle_mod.voxel_pooling_forward(geom, feats, nx, ny, 1)
+    wide = torch.from_numpy(rng.standard_normal((B, ny, nx, C * widen)).astype(np.float32)).cuda()
+    grad = wide.permute(0, 3, 1, 2)[:, :C]                       # [B, C, ny, nx] view, channel stride 1, row stride C*widen
+    ref_gi = oracle_mod.voxel_pooling_backward(ref_pos, grad.contiguous().cpu().numpy())
+    gi = torch.empty(B, P, C, device="cuda")
+    ws = torch.empty(voxel_pooling_ext.backward_workspace_elems(B, P, C, nx, ny), device="cuda")
+    voxel_pooling_ext.voxel_pooling_backward_wrapper(B, P, C, nx, ny, _dev(ref_pos), grad, gi, ws)
+    assert np.array_equal(gi.cpu().numpy(), ref_gi)
+
+
 def test_error_behaviour(mmt_lib):
     from mm_training_amd.ops.voxel_pooling import voxel_pooling, voxel_pooling_ext
     geom = torch.zeros(1, 8, 3, dtype=torch.int32, device="cuda")
