@@ -27,8 +27,11 @@ extern "C" {
 #endif
 
 /* 2: adds the cached-plan pooling, BEV warp, depth-label, CenterPoint-target and BatchNorm entry points
- * (purely additive: every version-1 symbol keeps its signature and meaning) */
-#define MMT_ABI_VERSION 2
+ * (purely additive: every version-1 symbol keeps its signature and meaning)
+ * 3: adds the MMT_VP_CHUNK_POINTS field of the forward flags (bits 8-15, 0 = library default as before);
+ *    mmt_bev_warp_affine_backward is bit-reproducible (gather instead of atomics) and refuses a
+ *    grad_output that spans 2 GiB or more */
+#define MMT_ABI_VERSION 3
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
