@@ -71,7 +71,7 @@ def main():
     res = {"shape": args.shape, "geometry": args.geometry, "BP": BP, "kept": K / BP, "fwd_MB": fwd_bytes / 1e6, "bwd_MB": bwd_bytes / 1e6}
     ref = None
     for algo in [int(a) for a in args.algos.split(",")]:
-        flags = (algo & 0xF) | 0x10 | (algo & 0xFF60)  # e.g. 3, 35 = 3|0x20 (chunk 1024), 67 = 3|0x40 (wave per slot), 3|(58<<8) = 232-point chunks
+        flags = (algo & 0xF) | 0x10 | (algo & 0xFFE0)  # e.g. 3, 35 = 3|0x20 (chunk 1024), 67 = 3|0x40 (wave per slot), 3|(58<<8) = 232-point chunks
 
         def run():
             voxel_pooling_ext.voxel_pooling_forward_wrapper(B, P, C, nx, ny, nz, geom, feats, out, pos, flags=flags)
@@ -90,7 +90,7 @@ def main():
         per = {a_: [] for a_ in algos}
         for rnd in range(12):
             for a_ in algos:
-                fl_ = (a_ & 0xF) | 0x10 | (a_ & 0xFF60)
+                fl_ = (a_ & 0xF) | 0x10 | (a_ & 0xFFE0)
                 med_, _ = timeit(lambda: voxel_pooling_ext.voxel_pooling_forward_wrapper(
                     B, P, C, nx, ny, nz, geom, feats, out, pos, flags=fl_), 8, warm=1)
                 per[a_].append(med_)
