@@ -78,7 +78,6 @@ int mmt_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
                                      rounds of the resident workgroups.  A tuning knob: results do not depend on it
                                      beyond the fp32 summation order. */
 #define MMT_VP_CHUNK_POINTS_MASK 0xFF00
-#define MMT_VP_PREFETCH 0x80      /* SEG_GATHER (EXPERIMENT): first-round workgroups request rows ahead of their index pass */
 int mmt_voxel_pooling_forward_ex(int batch_size, int num_points, int num_channels,
                                  int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                  const int32_t *geom_xyz, const float *input_features,

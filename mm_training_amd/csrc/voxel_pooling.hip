@@ -37,7 +37,6 @@ struct VpArgs {
     const float *depth;    // [B*P] in point order (= [B*N, D, HW])
     const float *context;  // [B*N, HW, C] channels-last
     int DHW, HW;           // D*HW points per camera, HW pixels per camera
-    int prefetch_wgs;      // seg_gather: workgroups of the first round that request their rows ahead of the index pass
 };
 
 __device__ __forceinline__ bool in_grid(int x, int y, int z, int nx, int ny, int nz) {
@@ -307,22 +306,6 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     // cost a fetch-on-write: 23 MB of avoidable HBM reads at cfg2).
     int ent[PPT];
     int pm[PPT][3];
-    // Launch ramp: every resident workgroup of the FIRST round runs its index pass at the same time, ~6 us in
-    // which HBM has nothing to do.  Those workgroups therefore request the three 128-byte lines of their first
-    // kept row per lane as soon as geom has arrived; the values are only consumed (never) at the very end of the
-    // kernel, so nothing waits on them and the gather pass later finds the lines on-die.
-    float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
-    const bool prefetch = !FUSED && (int)blockIdx.x < a.prefetch_wgs;
-    if (!FUSED) {
-        const bool keep0 = tid < npts && in_grid(gx[0], gy[0], gz[0], a.nx, a.ny, a.nz);
-        // never true, but it makes the branch read the LAST geom row of the lane: every geom load has then landed
-        // before the row requests are issued, and no later wait on an older load has to sit out these requests
-        const bool all_geom_here = gz[PPT - 1] == (int)0x80000000 && a.BP < 0;
-        if (prefetch && (keep0 || all_geom_here)) {
-            const float *row = a.feats + (base + tid) * C;
-            pf0 = row[0]; pf1 = row[C > 32 ? 32 : C - 1]; pf2 = row[C > 64 ? 64 : C - 1];
-        }
-    }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int lp = tid + k * kBlock;
@@ -420,8 +403,8 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
         }
     }
     __syncthreads();
-    // (no global store happens before this point: a store ahead of a barrier makes the barrier's release fence
-    // wait for every outstanding memory operation, including the row requests of the launch ramp above)
+    // (pos_memo is written here and not in A1: a global store ahead of a barrier makes the barrier's release
+    // fence wait for every outstanding memory operation)
     if (!a.write_dropped) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
@@ -617,8 +600,6 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // the only consumer of the prefetched values (never true): keeps the early requests alive
-    if (prefetch && pf0 + pf1 + pf2 == 1.2345e-30f && a.BP < 0) a.out[0] = pf0;
 }
 
 
@@ -1185,7 +1166,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     int algo = flags & MMT_VP_ALGO_MASK;
     if (algo > MMT_VP_ALGO_STREAM)
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown algorithm %d", algo);
-    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024 | MMT_VP_WAVE_PER_SLOT | MMT_VP_CHUNK_POINTS_MASK | MMT_VP_PREFETCH))
+    if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024 | MMT_VP_WAVE_PER_SLOT | MMT_VP_CHUNK_POINTS_MASK))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown flag bits 0x%x", flags);
     const int chunk_points = ((flags & MMT_VP_CHUNK_POINTS_MASK) >> 8) * 4;
     if (chunk_points != 0 && (chunk_points < 64 || chunk_points > 512 || (flags & MMT_VP_CHUNK_1024)))
@@ -1198,7 +1179,6 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
     a.nslot = 0; a.nchunks = 0;
     a.depth = nullptr; a.context = nullptr; a.DHW = 1; a.HW = 1;
-    a.prefetch_wgs = (flags & MMT_VP_PREFETCH) ? 256 * 8 : 0;   // the resident workgroups of the first round
     // float4 paths need 16-byte aligned rows
     const bool vec4 = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0);
     const bool seg_ok = vec4 && C <= 256;
@@ -1363,7 +1343,7 @@ extern "C" int mmt_lift_splat_forward(int B, int N, int D, int HW, int C, int nx
     a.geom = geom; a.feats = nullptr; a.out = out; a.pos_memo = pos_memo;
     a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
     a.nslot = 0; a.nchunks = 0;
-    a.depth = depth; a.context = context; a.DHW = D * HW; a.HW = HW; a.prefetch_wgs = 0;
+    a.depth = depth; a.context = context; a.DHW = D * HW; a.HW = HW;
     hipStream_t st = (hipStream_t)stream;
     a.nchunks = balanced_chunk_points(BP, 512);
     const dim3 grid((unsigned)mmt::ceil_div(BP, a.nchunks)), block(kBlock);
