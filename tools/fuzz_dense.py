@@ -97,6 +97,21 @@ while time.time() < t_end:
     ref = oracle.bev_warp_affine(xw, bda)
     if np.abs(yw.permute(0, 2, 3, 1).cpu().numpy() - ref).max() > 1e-5:
         fail("warp", shape=(B, H, W, C), err=float(np.abs(yw.permute(0, 2, 3, 1).cpu().numpy() - ref).max()))
+    # backward (gather over the candidate output cells): adjoint identity <warp(x), g> == <x, warp^T(g)> in float64,
+    # any rotation / flip / scale 0.7-1.3, and bit-reproducibility
+    xg = torch.from_numpy(xw).cuda().permute(0, 3, 1, 2).requires_grad_(True)
+    gw_ = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).cuda()
+    yg = bev_warp_affine(xg, torch.from_numpy(bda).cuda())
+    yg.backward(gw_)
+    lhs = (yg.detach().double() * gw_.double()).sum().item()
+    rhs = (xg.detach().double() * xg.grad.double()).sum().item()
+    if abs(lhs - rhs) > 1e-6 * (yg.detach().abs().double() * gw_.abs().double()).sum().item() + 1e-6:
+        fail("warp_backward_adjoint", shape=(B, H, W, C), lhs=lhs, rhs=rhs)
+    g1 = xg.grad.clone()
+    xg.grad = None
+    bev_warp_affine(xg, torch.from_numpy(bda).cuda()).backward(gw_)
+    if not torch.equal(g1, xg.grad):
+        fail("warp_backward_not_reproducible", shape=(B, H, W, C))
     # ---- depth labels
     B, N = int(rng.integers(1, 4)), int(rng.integers(1, 7))
     H, W, ds = [(64, 96, 16), (256, 704, 16), (128, 352, 8), (32, 32, 4)][int(rng.integers(0, 4))]
