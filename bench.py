@@ -7,7 +7,7 @@
 One rank per GPU; pure data parallel over the batch axis ("weak" scaling: per-GPU
 batch is fixed).  Default (--mode train): a step = one full training step of BASELINE.json
 configs[1] (camera-only BEVDepth, bs=4/GPU) on synthetic frames resident in HBM; the
-voxel_pooling kernels inside the step are timed with HIP events for the roofline lines.
+voxel_pooling kernels inside the step are timed with HIP events attached to their dispatches for the roofline lines.
 --mode hotpath times only voxel_pooling forward+backward.  See DESIGN.md "Measurement".
 Rank 0 prints ONE JSON line.
 """

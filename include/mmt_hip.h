@@ -30,7 +30,7 @@ extern "C" {
  * (purely additive: every version-1 symbol keeps its signature and meaning)
  * 3: adds the MMT_VP_CHUNK_POINTS field of the forward flags (bits 8-15, 0 = library default as before);
  *    mmt_bev_warp_affine_backward is bit-reproducible (gather instead of atomics) and refuses a
- *    grad_output that spans 2 GiB or more */
+ *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support) */
 #define MMT_ABI_VERSION 3
 
 #define MMT_OK 0
@@ -42,6 +42,19 @@ extern "C" {
 
 int mmt_abi_version(void);
 const char *mmt_last_error(void);
+
+/* Measurement support (bench.py's live roofline figure; no counterpart in the reference).  The events are attached to
+ * the kernel dispatches themselves (hipExtLaunchKernel start / stop events), so the elapsed time is the kernels' own
+ * duration on the device -- what rocprofv3 --kernel-trace reports -- without the dispatch latency that events recorded
+ * around a launch include.  mmt_arm_kernel_timing(start, stop) applies to the NEXT call of this thread to
+ * mmt_voxel_pooling_forward[_ex] (used by the default SEG_GATHER launch only; the other algorithms consume and ignore
+ * it) or mmt_voxel_pooling_backward (start on the first kernel of the call, stop on the last) and is cleared by that
+ * call; other entry points leave it armed.
+ * Read the result with mmt_timing_elapsed_ms after synchronising the stream. */
+int mmt_timing_event_create(void **event);
+int mmt_timing_event_destroy(void *event);
+int mmt_timing_elapsed_ms(void *start, void *stop, float *ms);
+int mmt_arm_kernel_timing(void *start, void *stop);
 
 /* ------------------------------------------------------------------ camera half */
 

@@ -18,6 +18,10 @@ _c_ptr = ctypes.c_void_p
 SIGNATURES = {
     "mmt_abi_version": (_c_int, []),
     "mmt_last_error": (ctypes.c_char_p, []),
+    "mmt_timing_event_create": (_c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "mmt_timing_event_destroy": (_c_int, [_c_ptr]),
+    "mmt_timing_elapsed_ms": (_c_int, [_c_ptr, _c_ptr, ctypes.POINTER(ctypes.c_float)]),
+    "mmt_arm_kernel_timing": (_c_int, [_c_ptr, _c_ptr]),
     "mmt_voxel_pooling_forward": (_c_int, [_c_int] * 6 + [_c_ptr] * 4 + [_c_ptr]),
     "mmt_voxel_pooling_forward_ex": (_c_int, [_c_int] * 6 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
     "mmt_voxel_pooling_backward_workspace_elems": (_c_i64, [_c_int] * 5),

@@ -16,6 +16,10 @@ int fail(int code, const char *fmt, ...);
 // post-launch check: returns 0 or the hipError_t (recorded in the error buffer)
 int check_launch(const char *what);
 
+// Kernel timing for the bench (mmt_arm_kernel_timing): the events armed by the caller, handed to the NEXT
+// timed launch sequence of this thread and cleared.  Both are null when nothing is armed.
+void take_timing_events(hipEvent_t *start, hipEvent_t *stop);
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grid for streaming kernels: enough workgroups to fill 256 CUs several times over,

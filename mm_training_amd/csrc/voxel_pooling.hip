@@ -11,6 +11,8 @@
 //
 // HBM traffic per call (algorithmic): 12*BP geom + 12*BP pos_memo + 4*C*K features
 // of kept points + 4*C*B*ny*nx BEV rows.
+#include <hip/hip_ext.h>
+
 #include "mmt_common.h"
 
 namespace {
@@ -1172,6 +1174,9 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     if (chunk_points != 0 && (chunk_points < 64 || chunk_points > 512 || (flags & MMT_VP_CHUNK_1024)))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: MMT_VP_CHUNK_POINTS must be 64..512 (got %d) and excludes MMT_VP_CHUNK_1024", chunk_points);
     hipStream_t st = (hipStream_t)stream;
+    // armed by mmt_arm_kernel_timing (bench only); consumed by this call, used by the default SEG_GATHER launch
+    hipEvent_t t_start = nullptr, t_stop = nullptr;
+    mmt::take_timing_events(&t_start, &t_stop);
 
     VpArgs a;
     a.BP = BP; a.P = P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
@@ -1198,6 +1203,7 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
         if (fused) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, true>), grid, block, 0, st, a);          \
         else if (big) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 1024, false>), grid, block, 0, st, a);   \
         else if (wave_slots) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false, false>), grid, block, 0, st, a); \
+        else if (t_start && t_stop) hipExtLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false>), grid, block, 0, st, t_start, t_stop, 0, a); \
         else hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false>), grid, block, 0, st, a);               \
     } while (0)
         if (C == 80) MMT_LAUNCH_SEG(20);
@@ -1283,10 +1289,16 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
     a.pos_memo = pos_memo; a.grad_out = grad_out; a.grad_in = grad_in;
     a.sb = sb; a.sc = sc; a.sy = sy; a.sx = sx;
     a.row_off = nullptr; a.row_off_out = nullptr;
+    // armed by mmt_arm_kernel_timing (bench only): the start event rides on the first kernel of this call, the stop
+    // event on the last one
+    hipEvent_t t_start = nullptr, t_stop = nullptr;
+    mmt::take_timing_events(&t_start, &t_stop);
 
     if (sc != 1 && workspace_elems >= bev_elems) {
         dim3 grid((unsigned)mmt::ceil_div((int64_t)ny * nx, 32), (unsigned)mmt::ceil_div(C, 32), (unsigned)B);
-        hipLaunchKernelGGL(vp_to_channels_last, grid, dim3(kBlock), 0, st, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
+        if (t_start) hipExtLaunchKernelGGL(vp_to_channels_last, grid, dim3(kBlock), 0, st, t_start, nullptr, 0, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
+        else hipLaunchKernelGGL(vp_to_channels_last, grid, dim3(kBlock), 0, st, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
+        t_start = nullptr;
         int rc = mmt::check_launch("voxel_pooling_backward(to_channels_last)");
         if (rc) return rc;
         a.grad_out = workspace;
@@ -1304,7 +1316,9 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
         int pgrid = mmt::stream_grid(mmt::ceil_div(BP, kPrepU), kBlock, 256 * 8);
         pgrid = (pgrid + 7) & ~7;
         const int sweep = span <= 4 * bev_elems;   // a thin slice of a much wider buffer: not worth reading the whole span
-        hipLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd, sweep);
+        if (t_start) hipExtLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, t_start, nullptr, 0, a, rows_per_xcd, sweep);
+        else hipLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd, sweep);
+        t_start = nullptr;                         // the main pass below carries the stop event only
         int rc = mmt::check_launch("voxel_pooling_backward(prepare)");
         if (rc) return rc;
         a.row_off = a.row_off_out;
@@ -1312,13 +1326,18 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
     if (vec4) {
         int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock, 256 * 16);
         grid = (grid + 7) & ~7;  // whole groups of 8 (one workgroup per XCD)
-        if (C == 80) hipLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, a);
+        if (t_stop) {       // timed launch: start (if the prepare pass did not take it) and stop ride on this dispatch
+            if (C == 80) hipExtLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
+            else if (C == 64) hipExtLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
+            else hipExtLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
+        } else if (C == 80) hipLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, a);
         else if (C == 64) hipLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, a);
         else hipLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, a);
         return mmt::check_launch("voxel_pooling_backward(rows_vec4)");
     }
     const int grid = mmt::stream_grid(BP * C, kBlock);
-    hipLaunchKernelGGL(vp_bwd_strided, dim3(grid), dim3(kBlock), 0, st, a);
+    if (t_stop) hipExtLaunchKernelGGL(vp_bwd_strided, dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
+    else hipLaunchKernelGGL(vp_bwd_strided, dim3(grid), dim3(kBlock), 0, st, a);
     return mmt::check_launch("voxel_pooling_backward(strided)");
 }
 

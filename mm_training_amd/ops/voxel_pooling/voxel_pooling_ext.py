@@ -32,20 +32,53 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# Optional per-launch timing for bench.py's roofline figure: when set to a dict, every
-# kernel launch below is bracketed by HIP events recorded on the launch stream and the
-# (start, end) pairs are appended under "forward" / "backward".
+# Optional per-launch timing for bench.py's roofline figure: when set to a dict, every kernel launch below
+# carries a pair of HIP events ATTACHED TO ITS DISPATCHES (mmt_arm_kernel_timing -> hipExtLaunchKernel start /
+# stop events: the kernels' own duration on the device, what rocprofv3 --kernel-trace reports; events recorded
+# around the launch would add the dispatch latency), and the (start, end) pairs are appended under
+# "forward" / "backward".  `start.elapsed_time(end)` gives milliseconds after a stream synchronisation.
 TIMING = None
 
 
-def _timed_call(kind, *args):
+class KernelEvent:
+    """A HIP event owned by libmmt_hip (same `elapsed_time` call as torch.cuda.Event)."""
+
+    def __init__(self):
+        import ctypes
+        h = ctypes.c_void_p()
+        _lib.call("mmt_timing_event_create", ctypes.byref(h))
+        self.handle = h.value
+
+    def elapsed_time(self, end):
+        import ctypes
+        ms = ctypes.c_float()
+        _lib.call("mmt_timing_elapsed_ms", self.handle, end.handle, ctypes.byref(ms))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().mmt_timing_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _timed_call(kind, *args, dispatch_events=False):
     if TIMING is None:
         return _lib.call(*args)
-    start = torch.cuda.Event(enable_timing=True)
-    end = torch.cuda.Event(enable_timing=True)
-    start.record()
-    _lib.call(*args)
-    end.record()
+    if dispatch_events:
+        start, end = KernelEvent(), KernelEvent()
+        _lib.call("mmt_arm_kernel_timing", start.handle, end.handle)
+        try:
+            _lib.call(*args)
+        finally:
+            _lib.call("mmt_arm_kernel_timing", None, None)      # never leave it armed (the call consumes it anyway)
+    else:   # a launch path that does not take dispatch events: bracket it on the stream
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        _lib.call(*args)
+        end.record()
     TIMING.setdefault(kind, []).append((start, end))
 
 
@@ -69,11 +102,14 @@ def voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, num_voxe
         raise RuntimeError("output_features must be a contiguous [B, ny, nx, C] tensor")
     if pos_memo_tensor.numel() != B * P * 3 or not pos_memo_tensor.is_contiguous():
         raise RuntimeError("pos_memo must be a contiguous [B, P, 3] tensor")
+    # the default SEG_GATHER launch is the one that carries dispatch events (see mmt_arm_kernel_timing)
+    default_path = (int(flags) & 0xF) in (0, 3) and not (int(flags) & 0x60) and C % 4 == 0 and C <= 256 \
+        and input_features_tensor.data_ptr() % 16 == 0
     with torch.cuda.device(input_features_tensor.device):
         _timed_call("forward", "mmt_voxel_pooling_forward_ex", B, P, C, nx, ny, nz,
-                  geom_xyz_tensor.data_ptr(), input_features_tensor.data_ptr(),
-                  output_features_tensor.data_ptr(), pos_memo_tensor.data_ptr(),
-                  int(flags), _stream())
+                    geom_xyz_tensor.data_ptr(), input_features_tensor.data_ptr(),
+                    output_features_tensor.data_ptr(), pos_memo_tensor.data_ptr(),
+                    int(flags), _stream(), dispatch_events=default_path)
     return 1
 
 
@@ -109,5 +145,5 @@ def voxel_pooling_backward_wrapper(batch_size, num_points, num_channels, num_vox
     with torch.cuda.device(grad_input_tensor.device):
         _timed_call("backward", "mmt_voxel_pooling_backward", B, P, C, nx, ny, pos_memo_tensor.data_ptr(),
                   grad_output_tensor.data_ptr(), sb, sc, sy, sx, grad_input_tensor.data_ptr(),
-                  ws, ws_elems, _stream())
+                  ws, ws_elems, _stream(), dispatch_events=True)
     return 1

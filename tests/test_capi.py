@@ -46,6 +46,10 @@ def test_host_side_argument_checks(mmt_lib):
     assert lib.mmt_voxel_pooling_forward(70000, 70000, 4, 2, 2, 1, p, p, p, p, None) == -3
     assert lib.mmt_voxel_pooling_backward(1, 8, 4, 2, 2, None, p, 1, 1, 1, 1, p, None, 0, None) == -1
     assert lib.mmt_voxel_pooling_backward_workspace_elems(2, 10, 4, 3, 5) == 2 * 5 * 3 * 4 + 20
+    assert lib.mmt_arm_kernel_timing(p, None) == -1               # both events or none
+    assert lib.mmt_arm_kernel_timing(None, None) == 0
+    assert lib.mmt_timing_event_create(None) == -1
+    assert lib.mmt_timing_elapsed_ms(None, None, None) == -1
     assert lib.mmt_simple_vfe(5, 15, 5, 6, p, p, p, None) == -2
     with pytest.raises(mmt_lib.MmtError, match="NULL"):
         mmt_lib.call("mmt_quantize_geometry", 4, None, None, None, None, None)

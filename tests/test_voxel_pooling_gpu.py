@@ -127,6 +127,41 @@ def test_backward_gradient_as_channel_slice_of_a_wider_buffer(mmt_lib, oracle_mo
     assert np.array_equal(gi.cpu().numpy(), ref_gi)
 
 
+def test_dispatch_attached_kernel_timing(mmt_lib):
+    """bench.py's live roofline figure: with voxel_pooling_ext.TIMING set, forward and backward carry HIP events
+    attached to their kernel dispatches (mmt_arm_kernel_timing); results are unchanged, every pair yields a
+    positive duration, and nothing stays armed afterwards."""
+    from mm_training_amd.ops.voxel_pooling import voxel_pooling, voxel_pooling_ext
+    torch.manual_seed(1)
+    B, P, C, nx, ny = 2, 40000, 80, 64, 48
+    geom = torch.stack([torch.randint(-2, nx + 2, (B, P)), torch.randint(-2, ny + 2, (B, P)), torch.zeros(B, P, dtype=torch.long)], -1).int().cuda()
+    feats = torch.rand(B, P, C, device="cuda")
+    go = torch.randn(B, C, ny, nx, device="cuda")
+    f0 = feats.clone().requires_grad_(True)
+    ref = voxel_pooling(geom, f0, [nx, ny, 1])
+    ref.backward(go)
+    voxel_pooling_ext.TIMING = {}
+    try:
+        for grad in (go, go.contiguous(memory_format=torch.channels_last)):      # with and without the layout pass
+            f1 = feats.clone().requires_grad_(True)
+            out = voxel_pooling(geom, f1, [nx, ny, 1])
+            out.backward(grad)
+            assert (out - ref).abs().max().item() <= ATOL and torch.equal(f1.grad, f0.grad)
+        # a non-default algorithm is timed by events recorded around the launch instead
+        _run_ext(mmt_lib, geom, feats, nx, ny, 1, 1)
+        torch.cuda.synchronize()
+        timing = voxel_pooling_ext.TIMING
+    finally:
+        voxel_pooling_ext.TIMING = None
+    assert len(timing["forward"]) == 3 and len(timing["backward"]) == 2
+    for s_, e_ in timing["forward"] + timing["backward"]:
+        ms = s_.elapsed_time(e_)
+        assert 0.0 < ms < 50.0, ms
+    # nothing left armed: an untimed call runs as usual
+    out2, _ = _run_ext(mmt_lib, geom, feats, nx, ny, 1, 0)
+    assert (out2.permute(0, 3, 1, 2) - ref).abs().max().item() <= ATOL
+
+
 def test_error_behaviour(mmt_lib):
     from mm_training_amd.ops.voxel_pooling import voxel_pooling, voxel_pooling_ext
     geom = torch.zeros(1, 8, 3, dtype=torch.int32, device="cuda")
