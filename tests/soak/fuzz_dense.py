@@ -2,12 +2,12 @@
 """Soak test of the round-1 additions against their references (run on the GPU box):
 fused BatchNorm(+residual)(+ReLU) vs nn.BatchNorm2d + add + relu, the BEV warp vs the oracle,
 depth labels vs the oracle, CenterPoint targets vs the oracle.  Random shapes, exits non-zero on
-the first mismatch.   python tools/fuzz_dense.py [seconds] [seed]"""
+the first mismatch.   python tests/soak/fuzz_dense.py [seconds] [seed]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from torch import nn

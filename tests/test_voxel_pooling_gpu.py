@@ -280,7 +280,7 @@ def test_randomised_shapes_all_algorithms(mmt_lib, oracle_mod, seed):
 
 @pytest.mark.parametrize("algo", [0, 3, 4, 0x23, 3 | (16 << 8), 3 | (58 << 8)])
 def test_full_chunks_of_distinct_cells(mmt_lib, oracle_mod, algo):
-    """Regression (found by tools/fuzz_pooling.py): a chunk whose points are ALL kept and ALL in
+    """Regression (found by tests/soak/fuzz_pooling.py): a chunk whose points are ALL kept and ALL in
     different cells fills every slot of the chunk-local tables (ns == chunk size)."""
     B, P, C = 1, 4096, 256
     nx, ny, nz = 64, 64, 1

@@ -108,31 +108,11 @@ def main():
     o2 = unfused()
     ms = timeit(lambda: torch.autograd.grad(o2, (dep, ctx_cl), go2, retain_graph=True))
     res["unfused_lift_plus_pool_backward"] = {"ms": ms}
-    # CPU baseline beside it: the oracle's sequential C restatement (1 core) on the same frames
-    import time
-    import oracle
-    np_frames = [f.cpu().numpy() for f in frames]
-    t0 = time.perf_counter()
-    rv, rn, rc = oracle.voxelize_batch(np_frames, vs, rng, 15, 25000)
-    t_vox = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    rf = oracle.simple_vfe(rv, rn, 5)
-    t_vfe = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.pillar_scatter(feats.cpu().numpy()[:rc.shape[0]], rc, B, ny, nx)
-    t_sc = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.quantize(xyz_dev.cpu().numpy(), vc, vsz)
-    t_q = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.geometry(frustum.cpu().numpy(), combine.cpu().numpy())
-    t_g = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.lift(depth.detach().cpu().numpy(), ctx.detach().cpu().numpy())
-    t_l = time.perf_counter() - t0
-    res["cpu_baseline_oracle_1core_ms"] = {"voxelize": t_vox * 1e3, "simple_vfe": t_vfe * 1e3, "pillar_scatter": t_sc * 1e3,
-                                           "quantize_geometry": t_q * 1e3, "frustum_geometry_no_quantize": t_g * 1e3,
-                                           "lift_forward": t_l * 1e3}
+    # CPU baseline beside it: the oracle's sequential C restatement (1 core) on the same inputs
+    from tests.soak.oracle_checks import lidar_and_producer_cpu_timings
+    res["cpu_baseline_oracle_1core_ms"] = lidar_and_producer_cpu_timings(
+        [f.cpu().numpy() for f in frames], vs, rng, feats.cpu().numpy(), B, ny, nx, xyz_dev.cpu().numpy(), vc, vsz,
+        frustum.cpu().numpy(), combine.cpu().numpy(), depth.detach().cpu().numpy(), ctx.detach().cpu().numpy())
     # BEV-augmentation warp of the pooled camera map at the cfg-2 shape: forward gather and
     # atomics-free backward gather, each 2 x 21 MB of algorithmic traffic (+21 MB read-modify-write backward)
     from mm_training_amd import _lib
