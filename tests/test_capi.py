@@ -98,3 +98,28 @@ def test_python_mirror_rejects_cpu_tensors(mmt_lib):
     # same failure mode as CHECK_CUDA in voxel_pooling_forward.cpp:10-16; no CPU fallback
     with pytest.raises(RuntimeError, match="CUDA"):
         voxel_pooling(geom, feats, torch.tensor([2, 2, 1]))
+
+
+def test_missing_library_fails_loudly():
+    """No CPU fallback: without libmmt_hip.so the product path raises ImportError (it never routes
+    through the oracle or a torch restatement)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from mm_training_amd import _lib\n"
+            "try:\n"
+            "    _lib.lib()\n"
+            "except ImportError as e:\n"
+            "    assert 'no CPU fallback' in str(e); print('IMPORT_ERROR_OK')\n" % root)
+    env = dict(os.environ, MMT_HIP_LIB="/nonexistent/libmmt_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "IMPORT_ERROR_OK" in out.stdout, out.stdout + out.stderr
+    # and the product modules never import the oracle
+    import re
+    for dirpath, _, files in os.walk(os.path.join(root, "mm_training_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import oracle|from oracle)", text, re.M), os.path.join(dirpath, f)
