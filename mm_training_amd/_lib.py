@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# MMT_HIP_LIB: load another build of the same library (kernel experiments in tools/scratch)
+# MMT_HIP_LIB: load another build of the same library (interleaved A/B of two builds: tools/ab_libs.py)
 LIB_PATH = os.environ.get("MMT_HIP_LIB") or os.path.join(_PKG, "libmmt_hip.so")
 
 _c_int = ctypes.c_int

@@ -15,10 +15,10 @@ step() {   # step <seconds> <log> <cmd...>
 step 800 $out/pytest_gpu.log python -m pytest tests -m gpu -x -q --durations=12
 prc=$?
 tail -25 $out/pytest_gpu.log
-if [ "$1" = "ab" ] && [ -f tools/scratch/libmmt_base.so ]; then
-  step 150 $out/ab_cfg2.json python tools/ab_libs.py tools/scratch/libmmt_base.so mm_training_amd/libmmt_hip.so --rounds 12
+if [ "$1" = "ab" ] && [ -f mm_training_amd/libmmt_base.so ]; then
+  step 150 $out/ab_cfg2.json python tools/ab_libs.py mm_training_amd/libmmt_base.so mm_training_amd/libmmt_hip.so --rounds 12
   cat $out/ab_cfg2.json
-  step 150 $out/ab_cfg5.json python tools/ab_libs.py tools/scratch/libmmt_base.so mm_training_amd/libmmt_hip.so --rounds 8 --shape cfg5
+  step 150 $out/ab_cfg5.json python tools/ab_libs.py mm_training_amd/libmmt_base.so mm_training_amd/libmmt_hip.so --rounds 8 --shape cfg5
   cat $out/ab_cfg5.json
   # forward chunk sizes 232 / 312 / 400 / 464 (library default at cfg2) / 512: flags = 3 | (n/4 << 8)
   step 200 $out/kbench_chunks_cfg2.json python tools/kbench.py --shape cfg2 --algos 3,14851,19971,25603,29699,32771
