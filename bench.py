@@ -2,18 +2,27 @@
 """bench.py -- headline benchmark of the MI355X BEV-fusion hot path.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One rank per GPU; pure data parallel over the batch axis ("weak" scaling: per-GPU
-batch is fixed).  Default (--mode train): a step = one full training step of BASELINE.json
-configs[1] (camera-only BEVDepth, bs=4/GPU) on synthetic frames resident in HBM; the
-voxel_pooling kernels inside the step are timed with HIP events attached to their dispatches for the roofline lines.
---mode hotpath times only voxel_pooling forward+backward.  See DESIGN.md "Measurement".
-Rank 0 prints ONE JSON line.
+One rank per GPU, pure data parallel over the batch axis ("weak" scaling: the per-GPU batch is fixed).
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this script starts its own N rank
+processes BEFORE touching the GPU and relays rank 0's JSON line (what Lightning's launcher does for
+the reference, exps/mm_training_aim.py:595-612); under torchrun it is one of the ranks.
+
+Default (--mode train): a step = one full training step of BASELINE.json configs[3], the workload the
+metric is quoted on (camera + 40k-point LiDAR fusion, bs=4/GPU, fp32) on synthetic frames resident in
+HBM.  The hot-path kernels inside the timed steps carry HIP events attached to their dispatches:
+`roofline` / `roofline_backward` (the camera -> BEV pooling kernels the step runs), `roofline_lidar`
+(voxelize + mean + pillar scatter).  After the timed region rank 0 also times the DROP-IN
+voxel_pooling op at the same shape and geometry (`roofline_voxel_pooling[_backward]`,
+`hotpath_samples_per_s`) -- the like-for-like GPU figure beside `cpu_baseline`.
+--mode hotpath times only voxel_pooling forward+backward (any config's camera half, fp32 or bf16
+feature storage).  See DESIGN.md "Measurement".  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,12 +30,127 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide ("L2 (per XCD)")
+
+WORKLOADS = {
+    "cfg2": "BASELINE configs[1]: camera-only BEVDepth (ResNet-50, 6 cams 256x704, D=112, C=80, BEV 128x128) "
+            "full training step (fwd + det/depth loss + bwd + clip + AdamW)",
+    "cfg3": "BASELINE configs[2]: LiDAR-only pillar path, 40k pts, 0.2 m voxels, full training step",
+    "cfg4": "BASELINE configs[3]: LiDAR+camera fusion -- BEVDepth (ResNet-50, 6 cams 256x704, D=112, C=80, BEV 128x128) + "
+            "40k-point LiDAR frames (0.2 m pillars, 512x512 canvas) concatenated in BEV; full training step "
+            "(depth labels + fwd + det/depth loss + bwd + clip + AdamW)",
+    "cfg5": "BASELINE configs[4]: LiDAR+radar+camera, 6 cams 512x1408, 80k pts (8 columns); bf16 storage on the hot path",
+    "tiny": "tiny smoke configuration",
+}
+# camera halves for --mode hotpath (SURVEY.md section 8 shape table)
+HOTPATH_SHAPES = {
+    "cfg2": dict(batch=4, num_cams=6, final_dim=(256, 704), downsample=16, d_bound=(2.0, 58.0, 0.5), channels=80),
+    "cfg5": dict(batch=2, num_cams=6, final_dim=(512, 1408), downsample=16, d_bound=(2.0, 58.0, 0.5), channels=80),
+    "tiny": dict(batch=2, num_cams=2, final_dim=(64, 192), downsample=16, d_bound=(2.0, 58.0, 4.0), channels=16),
+}
+HOTPATH_SHAPES["cfg4"] = HOTPATH_SHAPES["cfg2"]
+BEV_BOUNDS = dict(x_bound=(-51.2, 51.2, 0.8), y_bound=(-51.2, 51.2, 0.8), z_bound=(-5.0, 3.0, 8.0))
+
+torch = None
+dist = None
+SHIPPED_MIOPEN_DB = False
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="train", choices=["train", "hotpath"],
+                    help="train: full data-parallel training step of the BASELINE config (default); "
+                         "hotpath: only voxel_pooling forward+backward at the config's camera shape")
+    ap.add_argument("--config", default="cfg4",
+                    help="cfg4 (BASELINE configs[3], camera+LiDAR fusion: the workload the metric is quoted on, default) | "
+                         "cfg2 | cfg3 | cfg5 | tiny")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="feature storage type of the hot-path ops (accumulation is always fp32); default f32, bf16 for cfg5")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: launcher rehearsal only (gloo, the dense detection head; the HIP hot path has no CPU form)")
+    ap.add_argument("--miopen-tune", action="store_true", help="exhaustive MIOpen search (minutes of warm-up)")
+    ap.add_argument("--cached-plan", action="store_true",
+                    help="train mode: pass a calibration id so the unfused voxel_pooling reuses a cached sort (SURVEY 8/f3)")
+    ap.add_argument("--unfused", action="store_true",
+                    help="camera branch runs the reference's op sequence lift -> drop-in voxel_pooling instead of the fused "
+                         "lift-splat kernels (SURVEY 8/f1, the default)")
+    ap.add_argument("--fused-lift-splat", action="store_true", help="(default since round 2; accepted for old command lines)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
+    ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag (hotpath mode)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# rank processes
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and wait.
+    The parent has made no GPU call (torch is not even imported yet); nothing is re-exec'd.  Rank 0's stdout is
+    relayed; the exit code is non-zero if any rank failed (the others are then terminated by PID)."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0:
+                    try:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif p.poll() is None:
+                    continue
+                pending.discard(r)
+                if p.returncode != 0:
+                    rc = rc or p.returncode or 1
+                    print(f"[bench] rank {r} exited with code {p.returncode}", file=sys.stderr)
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                if rc:
+                    p.terminate()
+                try:
+                    p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
 
 def use_shipped_miopen_db():
-    """MIOpen's per-shape solver choice for the dense nets: the repo ships the user find/perf
-    DB produced by one exhaustive search on an MI355X (mm_training_amd/miopen_db, ~100 KB of
-    text).  Each process works on a private copy (MIOpen rewrites the files), so a fresh box gets
-    the tuned solvers without the ~4 min search.  Must run before the first convolution."""
+    """MIOpen's per-shape solver choice for the dense nets: the repo ships the user find/perf DB produced by an
+    exhaustive search of the cfg2 and cfg4 steps on an MI355X (mm_training_amd/miopen_db, ~100 KB of text).  Each
+    process works on a private copy (MIOpen rewrites the files), so a fresh box gets the tuned solvers without the
+    minutes of search.  Must run before the first convolution."""
     src = os.path.join(ROOT, "mm_training_amd", "miopen_db")
     if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src):
         return False
@@ -36,46 +160,23 @@ def use_shipped_miopen_db():
     for f in os.listdir(src):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     os.environ["MIOPEN_USER_DB_PATH"] = dst
-    # HYBRID find mode: a find-DB hit returns the tuned solver without running anything, a miss
-    # times the applicable solvers once (seconds) instead of trusting the immediate-mode heuristic.
-    # The reference "naive" solvers (tens of ms per call, never chosen) are excluded from that
-    # timing: they alone cost ~15 s of warm-up per process (profiles/r01_miopen_find_modes.txt).
+    # HYBRID find mode: a find-DB hit returns the tuned solver without running anything, a miss times the
+    # applicable solvers once (seconds) instead of trusting the immediate-mode heuristic.  The reference "naive"
+    # solvers (tens of ms per call, never chosen) are excluded from that timing: they alone cost ~15 s of warm-up
+    # per process (profiles/r01_miopen_find_modes.txt).
     os.environ.setdefault("MIOPEN_FIND_MODE", "3")
     for d in ("FWD", "BWD", "WRW"):
         os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + d, "0")
     return True
 
 
-SHIPPED_MIOPEN_DB = use_shipped_miopen_db()
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
-
-# BASELINE.json configs[1]: camera-only BEVDepth, 6 cams 256x704, ds 16, D=112, C=80, BEV 128x128, bs=4
-CFG2 = dict(batch=4, num_cams=6, final_dim=(256, 704), downsample=16, d_bound=(2.0, 58.0, 0.5),
-            channels=80, x_bound=(-51.2, 51.2, 0.8), y_bound=(-51.2, 51.2, 0.8), z_bound=(-5.0, 3.0, 8.0))
-
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="train", choices=["train", "hotpath"],
-                    help="train: full data-parallel training step of the BASELINE config (default); "
-                         "hotpath: only voxel_pooling forward+backward at the cfg-2 shape")
-    ap.add_argument("--config", default="cfg2", help="cfg2 (BASELINE configs[1], default) | cfg3 | cfg4 | cfg5 | tiny")
-    ap.add_argument("--miopen-tune", action="store_true", help="exhaustive MIOpen search (minutes of warm-up)")
-    ap.add_argument("--cached-plan", action="store_true",
-                    help="train mode: pass a calibration id so voxel_pooling reuses a cached sort (SURVEY 8/f3)")
-    ap.add_argument("--fused-lift-splat", action="store_true",
-                    help="camera branch uses the fused lift-splat kernels (row f1) instead of lift -> voxel_pooling; "
-                         "the voxel_pooling roofline lines are then not produced")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag")
-    return ap.parse_args()
+def _late_imports(device):
+    global torch, dist, SHIPPED_MIOPEN_DB
+    if device == "cuda":
+        SHIPPED_MIOPEN_DB = use_shipped_miopen_db()
+    import torch as _torch
+    import torch.distributed as _dist
+    torch, dist = _torch, _dist
 
 
 def choose_backend(world, local_rank, ndev, requested="nccl"):
@@ -88,82 +189,79 @@ def choose_backend(world, local_rank, ndev, requested="nccl"):
     return requested, local_rank
 
 
-def init_dist(n_gpus):
+def init_dist(n_gpus, device="cuda"):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if device == "cpu":
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+        return rank, local_rank, world
     ndev = torch.cuda.device_count()
     backend, local_rank = choose_backend(world, local_rank, ndev, os.environ.get("MMT_DIST_BACKEND", "nccl"))   # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
     return rank, local_rank, world
 
 
-def barrier(world):
+def barrier(world, device="cuda"):
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if device == "cuda":
+        torch.cuda.synchronize()
 
 
-def algorithmic_bytes(BP, K, C, B, ny, nx):
-    """BASELINE.md section 2 / SURVEY.md section 8d."""
-    fwd = 12 * BP + 12 * BP + 4 * C * K + 4 * C * B * ny * nx
-    bwd = 12 * BP + 4 * C * B * ny * nx + 4 * C * BP
+def max_over_ranks(elapsed, world, device="cuda"):
+    if world == 1:
+        return elapsed
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithmic bytes (BASELINE.md section 2 / SURVEY.md section 8d) and roofline objects
+
+def algorithmic_bytes(BP, K, C, B, ny, nx, feat_bytes=4):
+    """Drop-in voxel_pooling: forward 12BP geom + 12BP pos_memo + fb*C*K kept rows + 4*C*B*ny*nx BEV;
+    backward 12BP pos_memo + 4*C*B*ny*nx grad_out + fb*C*BP grad_in.  fb = 4 (fp32) or 2 (bf16 storage)."""
+    fwd = 12 * BP + 12 * BP + feat_bytes * C * K + 4 * C * B * ny * nx
+    bwd = 12 * BP + 4 * C * B * ny * nx + feat_bytes * C * BP
     return fwd, bwd
 
 
-def cpu_baseline(geom, feats, vn, grad_out_nhwc, budget_s=20.0):
-    """The oracle's torch-CPU port of the reference semantics (BASELINE.md section 2:
-    scatter_add_ forward + masked gather backward) timed on this host's cores.  The thread
-    count is calibrated (all logical cores is pathologically slow for scatter_add_ on a
-    many-core host); `cores` reports the count actually used."""
-    import oracle
-    B, P, C = feats.shape
-    nx, ny, nz = vn
-
-    def one():
-        t0 = time.perf_counter()
-        out, pos = oracle.torch_forward_scatter_add(geom, feats, nx, ny, nz)
-        gi = oracle.torch_backward_gather(pos, grad_out_nhwc)
-        return time.perf_counter() - t0, out, pos, gi
-
-    ncpu = os.cpu_count() or 1
-    t_start = time.perf_counter()
-    best_threads, best_t = None, None
-    for th in sorted({min(ncpu, 16), min(ncpu, 64), ncpu}):
-        torch.set_num_threads(th)
-        if best_threads is None:
-            one()                                   # first-touch / allocator warm-up
-        t = one()[0]
-        if best_t is None or t < best_t:
-            best_threads, best_t = th, t
-        if time.perf_counter() - t_start > budget_s:
-            break
-    torch.set_num_threads(best_threads)
-    times = []
-    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 30):
-        t, out, pos, gi = one()
-        times.append(t)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": B / med, "unit": "samples/s", "cores": best_threads, "kind": "port",
-            "sample": f"{len(times)} reps of voxel_pooling fwd (torch scatter_add_) + bwd (masked gather) "
-                      f"on CPU at the full cfg-2 shape B={B} P={P} C={C}, median {med * 1e3:.1f} ms/step, "
-                      f"{best_threads} of {ncpu} logical cores (calibrated)"}, out, pos, gi
+def lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, feat_bytes=4):
+    """Fused lift-splat (row f1): the [BP, C] feature matrix does not exist.
+    forward  12BP geom + 12BP pos_memo + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx BEV
+    backward 12BP pos_memo + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx grad_out + fb*BP grad_depth + fb*C*BN*HW grad_context
+    The L2-side figure adds what the kernels gather from L2: one C-row (context / grad_out) + a depth value per kept point."""
+    fwd = 24 * BP + feat_bytes * BP + feat_bytes * C * BN_HW + 4 * C * B * ny * nx
+    bwd = 12 * BP + 2 * feat_bytes * BP + 2 * feat_bytes * C * BN_HW + 4 * C * B * ny * nx
+    l2_fwd = fwd + K * (feat_bytes * C)
+    l2_bwd = bwd + K * (4 * C)
+    return fwd, bwd, l2_fwd, l2_bwd
 
 
-def pmc_traffic(kernels):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
-    WRITE_SIZE passes with the gfx950 correction, profiles/r01_hotpath_cfg2_pmc.json).  PMC
-    collection cannot run inside this process; the figure belongs to the same kernel, shape
-    (cfg2) and geometry the roofline line is quoted on."""
-    path = os.path.join(ROOT, "profiles", "r01_hotpath_cfg2_pmc.json")
+def lidar_bytes(F, total_points, M, nf, C, B, ny, nx, voxels_T=0):
+    """voxelize+mean: 4*F*sum(Ni) points + 16*M coors + 4*M num_points + 4*nf*M means (+ 4*T*F*M when the padded voxel
+    tensor is materialised); scatter: 4*C*M + 16*M + 4*C*B*ny*nx; scatter backward: 8*C*M + 16*M."""
+    vox = 4 * F * total_points + 20 * M + 4 * nf * M + 4 * voxels_T * F * M
+    scat = 4 * C * M + 16 * M + 4 * C * B * ny * nx
+    scat_bwd = 8 * C * M + 16 * M
+    return vox, scat, scat_bwd
+
+
+def pmc_traffic(config, kernels):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary OF THIS CONFIGURATION (separate FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 correction; tools/collect_profiles.sh writes profiles/r02_pmc_<config>.json).
+    PMC collection cannot run inside this process; None when the shape has no summary."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_{config}.json")
     try:
         k = json.load(open(path))["kernels"]
         return float(sum(k[name]["traffic_bytes"] for name in kernels))
@@ -171,12 +269,250 @@ def pmc_traffic(kernels):
         return None
 
 
-def roofline_entry(kernel, nbytes, ms, pmc_kernels=()):
+def roofline_entry(kernel, nbytes, ms, traffic=None, l2_bytes=None, note=None):
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_kernels) if pmc_kernels else None,
-            "algorithmic_bytes": nbytes, "avg_ms": ms}
+    r = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": nbytes, "avg_ms": ms}
+    if l2_bytes is not None:
+        l2 = l2_bytes / (ms * 1e-3) / 1e9
+        r["l2_side"] = {"bytes": l2_bytes, "achieved": l2, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": l2 / L2_PEAK_GBS}
+    if note:
+        r["note"] = note
+    return r
 
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline
+
+def _cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1, len(phys) or None
+
+
+def cpu_baseline(geom, feats, vn, grad_out_nhwc, budget_s=25.0):
+    """The oracle's torch-CPU port of the reference semantics (scatter_add_ forward, and
+    index_add_ as a second line, + masked-gather backward) timed on this host's cores: 3 warm-up calls, then
+    >= 10 repetitions (fewer only if the time budget runs out) at the best of a few thread counts (all logical
+    cores is pathologically slow for scatter_add_ on a many-core host), median and best, plus a 1-thread figure.
+    A reported baseline beside `hotpath_samples_per_s`, not a target."""
+    import oracle
+    B, P, C = feats.shape
+    nx, ny, nz = vn
+    t_start = time.perf_counter()
+
+    def one(index_add=False):
+        t0 = time.perf_counter()
+        out, pos = oracle.torch_forward_scatter_add(geom, feats, nx, ny, nz, use_index_add=index_add)
+        t1 = time.perf_counter()
+        gi = oracle.torch_backward_gather(pos, grad_out_nhwc)
+        t2 = time.perf_counter()
+        return t2 - t0, t1 - t0, out, pos, gi
+
+    model, logical, physical = _cpu_info()
+    tried = {}
+    for th in sorted({min(logical, 16), min(logical, 32), min(logical, 64)}):
+        torch.set_num_threads(th)
+        if not tried:
+            for _ in range(2):
+                one()                               # first-touch / allocator warm-up
+        tried[th] = one()[0]
+        if time.perf_counter() - t_start > 0.3 * budget_s:
+            break
+    best_threads = min(tried, key=tried.get)
+    torch.set_num_threads(best_threads)
+    times, fwd_times = [], []
+    while len(times) < 3 or (time.perf_counter() - t_start < 0.6 * budget_s and len(times) < 10):
+        t, tf, out, pos, gi = one()
+        times.append(t)
+        fwd_times.append(tf)
+    ia = sorted(one(index_add=True)[1] for _ in range(3))
+    torch.set_num_threads(1)
+    t1s = []
+    while len(t1s) < 1 or (time.perf_counter() - t_start < budget_s and len(t1s) < 3):
+        t1s.append(one()[0])
+    torch.set_num_threads(best_threads)
+    times.sort()
+    fwd_times.sort()
+    med, best = times[len(times) // 2], times[0]
+    return {"value": B / med, "unit": "samples/s", "cores": best_threads, "kind": "port",
+            "sample": f"{len(times)} reps (after 3 warm-up calls) of voxel_pooling fwd (torch scatter_add_) + bwd (masked gather) on CPU "
+                      f"at the full camera shape B={B} P={P} C={C} grid {nx}x{ny}x{nz}: median {med * 1e3:.1f} ms, best {best * 1e3:.1f} ms "
+                      f"per fwd+bwd with {best_threads} threads; compare with hotpath_samples_per_s (same op, same shape), "
+                      f"NOT with the training-step value",
+            "cpu_model": model, "logical_cores": logical, "physical_cores": physical,
+            "median_ms": med * 1e3, "best_ms": best * 1e3, "forward_scatter_add_median_ms": fwd_times[len(fwd_times) // 2] * 1e3,
+            "forward_index_add_median_ms": ia[len(ia) // 2] * 1e3,
+            "threads_tried_ms": {str(k): v * 1e3 for k, v in tried.items()},
+            "one_thread": {"value": B / min(t1s), "ms": min(t1s) * 1e3, "reps": len(t1s)}}, out, pos, gi
+
+
+# ------------------------------------------------------------------------------------------------
+# the drop-in voxel_pooling op alone (hotpath mode, and the leg after the training steps)
+
+def kept_count(geom, vn):
+    nx, ny, nz = vn
+    g3 = geom.reshape(-1, 3)
+    kept = ((g3[:, 0] >= 0) & (g3[:, 0] < nx) & (g3[:, 1] >= 0) & (g3[:, 1] < ny) & (g3[:, 2] >= 0) & (g3[:, 2] < nz))
+    return int(kept.sum().item())
+
+
+def hotpath_leg(geom, vn, C, dtype, iters, warmup, seed=100, flags=None):
+    """voxel_pooling(geom, feats, vn) forward + backward, `iters` times, every launch carrying dispatch-attached
+    events.  Returns (fwd_ms, bwd_ms, feats_cpu, grad_out, out, feats) for the roofline entries and the parity check."""
+    from mm_training_amd import _lib, synthetic
+    from mm_training_amd.ops import voxel_pooling as vp_pkg
+    B = geom.shape[0]
+    P = geom[0].numel() // 3
+    nx, ny, nz = vn
+    feats_cpu = synthetic.features((B, P, C), seed=seed)
+    feats = feats_cpu.cuda()
+    if dtype == "bf16":
+        feats = feats.bfloat16()
+    feats.requires_grad_(True)
+    grad_out = torch.randn(B, ny, nx, C, generator=torch.Generator().manual_seed(1)).cuda().permute(0, 3, 1, 2)  # channels-last grad
+    op = vp_pkg.voxel_pooling_bf16 if dtype == "bf16" else vp_pkg.voxel_pooling
+
+    def step():
+        feats.grad = None
+        out = op(geom, feats, vn)
+        out.backward(grad_out)
+        return out
+
+    for _ in range(warmup):
+        step()
+    saved, _lib.TIMING = _lib.TIMING, {}
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = step()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        timing = _lib.TIMING
+    finally:
+        _lib.TIMING = saved
+    return _lib.mean_ms(timing["forward"]), _lib.mean_ms(timing["backward"]), wall, feats_cpu, grad_out, out, feats
+
+
+def hotpath_main(args, rank, local_rank, world):
+    from mm_training_amd import _lib, synthetic
+    _lib.lib()
+    shape = HOTPATH_SHAPES[args.config]
+    dtype = args.dtype or ("bf16" if args.config == "cfg5" else "f32")
+    B, C = shape["batch"], shape["channels"]
+    geom_cpu, vn = synthetic.rig_geometry(B, shape["num_cams"], shape["final_dim"], shape["downsample"], shape["d_bound"],
+                                          BEV_BOUNDS["x_bound"], BEV_BOUNDS["y_bound"], BEV_BOUNDS["z_bound"], seed=rank)
+    nx, ny, nz = vn
+    geom = geom_cpu.cuda()
+    P = geom_cpu[0].numel() // 3
+    barrier(world)
+    fwd_ms, bwd_ms, wall, feats_cpu, grad_out, out, feats = hotpath_leg(geom, vn, C, dtype, args.steps, args.warmup, seed=100 + rank)
+    barrier(world)
+    elapsed = max_over_ranks(wall, world)
+    if rank != 0:
+        return
+    K = kept_count(geom, vn)
+    fb = 2 if dtype == "bf16" else 4
+    fwd_bytes, bwd_bytes = algorithmic_bytes(B * P, K, C, B, ny, nx, fb)
+    fH, fW = shape["final_dim"][0] // shape["downsample"], shape["final_dim"][1] // shape["downsample"]
+    cfgname = args.config if dtype == "f32" else f"{args.config}_bf16"
+    fwd_kernel = "vp_fwd_seg_gather" + ("_bf16" if dtype == "bf16" else "")
+    bwd_kernels = ("vp_bwd_prepare", "vp_bwd_rows_bf16" if dtype == "bf16" else "vp_bwd_rows_vec4")
+    res = {
+        "metric": "training samples/sec at bs=%d/GPU (hot path only: voxel_pooling fwd+bwd); voxel_pooling HBM GB/s" % B,
+        "value": world * B * args.steps / elapsed, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"camera half of {WORKLOADS[args.config].split(':')[0]}: voxel_pooling forward+backward, "
+                               f"{shape['num_cams']} cams {shape['final_dim'][0]}x{shape['final_dim'][1]} ds{shape['downsample']} "
+                               f"D={int((shape['d_bound'][1] - shape['d_bound'][0]) / shape['d_bound'][2])} fH={fH} fW={fW} C={C}, "
+                               f"BEV {nx}x{ny}x{nz}, analytic 6-camera rig geometry, bs={B}/GPU, "
+                               f"{'bf16 feature storage, fp32 accumulate, fp32 BEV' if dtype == 'bf16' else 'fp32'}",
+                   "global_batch": world * B, "points_per_sample": P, "kept_fraction": K / (B * P),
+                   "parallelism": f"dp{world}", "mode": args.mode},
+        "roofline": roofline_entry(f"{fwd_kernel} (voxel_pooling forward)", fwd_bytes, fwd_ms, pmc_traffic(cfgname, (fwd_kernel,))),
+        "roofline_backward": roofline_entry(f"{' + '.join(bwd_kernels)} (voxel_pooling backward)", bwd_bytes, bwd_ms,
+                                            pmc_traffic(cfgname, bwd_kernels)),
+        "hotpath_samples_per_s": B / ((fwd_ms + bwd_ms) * 1e-3),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # the CPU port sees the same (for bf16: the same ROUNDED) feature values, up-cast to fp32
+        f_cpu = feats.detach().float().cpu().reshape(B, P, C)
+        base, ref_out, ref_pos, ref_gi = cpu_baseline(geom_cpu.reshape(B, P, 3), f_cpu, vn,
+                                                      grad_out.permute(0, 2, 3, 1).contiguous().cpu())
+        res["cpu_baseline"] = base
+        # same-run parity of the measured path against the CPU port
+        err = (out.detach().float().permute(0, 2, 3, 1).cpu() - ref_out).abs().max().item()
+        gi = feats.grad.reshape(B, P, C).cpu()
+        gi_equal = bool(torch.equal(gi, ref_gi.to(gi.dtype)))     # bf16: exact after rounding the fp32 gather
+        res["parity"] = {"bev_max_abs_err": err, "grad_in_bit_exact": gi_equal}
+    print(json.dumps(res), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher rehearsal on CPU
+
+def rehearsal_main(args, rank, world):
+    """--device cpu: the N>1 plumbing (rank spawn, rendezvous, DDP bucketed all-reduce, barrier, max over ranks,
+    rank 0's JSON line) on gloo with the part of the model that is plain PyTorch: the dense detection head on a
+    synthetic BEV map.  The HIP hot path has no CPU form and is NOT part of this mode; the line says so."""
+    from mm_training_amd.dp.configs import make_config
+    from mm_training_amd.layers.heads.bev_depth_head import BEVDepthHead
+    cfg = make_config(args.config)
+    torch.manual_seed(0)
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(world, 1) // 2))
+    head = BEVDepthHead(**cfg["head_conf"])
+    net = torch.nn.parallel.DistributedDataParallel(head) if world > 1 else head
+    opt = torch.optim.AdamW(head.parameters(), lr=1e-4)
+    B = cfg["batch_size"]
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(B, cfg["fuse_layer_in_channels"], 128, 128, generator=g)
+    boxes = [torch.cat([torch.rand(5, 2, generator=g) * 80 - 40, torch.tensor([[-1.0, 1.9, 4.6, 1.7, 0.3, 0.5, -0.2]]).repeat(5, 1)], 1)
+             for _ in range(B)]
+    labels = [torch.randint(0, 4, (5,), generator=g) for _ in range(B)]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = head.loss(head.get_targets_torch(boxes, labels), net(x))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world, "cpu")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier(world, "cpu")
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, "cpu")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "LAUNCHER REHEARSAL on CPU (not the benchmark): samples/s of the dense detection head", "value": world * B * args.steps / elapsed,
+            "unit": "samples/s", "n_gpus": 0, "ranks": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "launcher rehearsal: gloo ranks on CPU, dense detection head only (the HIP hot path needs a GPU)",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "mode": "rehearsal-cpu", "final_loss": float(loss)}}), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# training step
 
 def train_main(args, rank, local_rank, world):
     """Full training step of a BASELINE config: synthetic frames -> depth labels -> BEVDepth
@@ -184,17 +520,23 @@ def train_main(args, rank, local_rank, world):
     overlapped) -> grad clip -> AdamW.  Nothing is skipped inside the timed region."""
     from mm_training_amd import _lib
     from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
-    from mm_training_amd.ops.voxel_pooling import voxel_pooling_ext
     _lib.lib()
     # benchmark=True makes PyTorch ask MIOpen's find API, which is answered from the find DB
-    # (only for the configuration the DB was produced on: an unknown shape would start a search)
-    torch.backends.cudnn.benchmark = bool(args.miopen_tune) or (SHIPPED_MIOPEN_DB and args.config == "cfg2")
+    # (only for the configurations the DB was produced on: an unknown shape would start a search)
+    db_cfg = SHIPPED_MIOPEN_DB and args.config in ("cfg2", "cfg4")
+    torch.backends.cudnn.benchmark = bool(args.miopen_tune) or db_cfg
     dev = torch.device("cuda", local_rank)
     cfg = make_config(args.config)
+    # storage type of the hot-path operands (fp32 accumulate either way); the dense nets keep cfg["dtype"]
+    dtype = args.dtype or cfg["hot_path_dtype"]
+    cfg["hot_path_dtype"] = dtype
     torch.manual_seed(0)
     ts = TrainStep(cfg, dev, world_size=world)
-    if args.fused_lift_splat and cfg["use_cam"]:
-        ts.model.backbone.fused_lift_splat = True
+    fused = False
+    if cfg["use_cam"]:
+        if args.unfused or args.cached_plan:
+            ts.model.backbone.fused_lift_splat = False
+        fused = bool(ts.model.backbone.fused_lift_splat)
     B = cfg["batch_size"]
     # a small pool of distinct pre-generated batches resident in HBM (input is never the bottleneck)
     batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i) for i in range(2)]
@@ -205,19 +547,15 @@ def train_main(args, rank, local_rank, world):
             b[1]["calibration_id"] = ("synthetic", 1000 * rank + i)
     for i in range(args.warmup):
         ts(batches[i % len(batches)])
-    voxel_pooling_ext.TIMING = {}
+    _lib.TIMING = {}
     barrier(world)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, det, dep = ts(batches[i % len(batches)])
     barrier(world)
     elapsed = time.perf_counter() - t0
-    timing = voxel_pooling_ext.TIMING
-    voxel_pooling_ext.TIMING = None
-    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    timing, _lib.TIMING = _lib.TIMING, None
+    elapsed = max_over_ranks(elapsed, world)
     if rank != 0:
         return
     res = {
@@ -225,140 +563,117 @@ def train_main(args, rank, local_rank, world):
         "value": world * B * args.steps / elapsed, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if cfg["dtype"] == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": {
-            "cfg2": "BASELINE configs[1]: camera-only BEVDepth (ResNet-50, 6 cams 256x704, D=112, C=80, BEV 128x128) "
-                    "full training step (fwd + det/depth loss + bwd + clip + AdamW)",
-            "cfg3": "BASELINE configs[2]: LiDAR-only pillar path, 40k pts, 0.2 m voxels",
-            "cfg4": "BASELINE configs[3]: LiDAR+camera fusion (BEVDepth + pillar BEV concat)",
-            "cfg5": "BASELINE configs[4]: LiDAR+radar+camera, 6 cams 512x1408, 80k pts, bf16",
-            "tiny": "tiny smoke configuration"}[args.config],
-            "global_batch": world * B, "parallelism": f"dp{world}", "mode": "train",
-            "params_M": sum(p.numel() for p in ts.model.parameters()) / 1e6,
-            "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune),
-            "miopen_shipped_find_db": bool(SHIPPED_MIOPEN_DB and args.config == "cfg2"),
-            "fused_lift_splat": bool(args.fused_lift_splat), "cached_plan": bool(args.cached_plan)},
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": WORKLOADS[args.config],
+                   "global_batch": world * B, "parallelism": f"dp{world}", "mode": "train",
+                   "params_M": sum(p.numel() for p in ts.model.parameters()) / 1e6,
+                   "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune),
+                   "miopen_shipped_find_db": bool(db_cfg), "fused_lift_splat": fused, "cached_plan": bool(args.cached_plan),
+                   "dense_nets_dtype": "bf16 autocast" if ts.amp_dtype is not None else "f32",
+                   "hot_path_storage_dtype": dtype},
     }
-    if cfg["use_cam"] and timing.get("forward"):
-        fwd_ms = sum(s.elapsed_time(e) for s, e in timing["forward"]) / len(timing["forward"])
-        bwd_ms = sum(s.elapsed_time(e) for s, e in timing["backward"]) / len(timing["backward"])
+    fb = 2 if dtype == "bf16" else 4
+    geom = vn = None
+    if cfg["use_cam"]:
         lss = ts.model.backbone
         with torch.no_grad():
             m = batches[0][1]
             geom = lss.get_geometry_voxels(m["sensor2ego_mats"][:, 0], m["intrin_mats"][:, 0])
-        nx, ny, nz = lss._voxel_num_host
-        g3 = geom.reshape(-1, 3)
-        kept = ((g3[:, 0] >= 0) & (g3[:, 0] < nx) & (g3[:, 1] >= 0) & (g3[:, 1] < ny) & (g3[:, 2] >= 0) & (g3[:, 2] < nz))
-        K, BP, C = int(kept.sum()), g3.shape[0], lss.output_channels
-        fb, bb = algorithmic_bytes(BP, K, C, B, ny, nx)
-        cfg2 = args.config == "cfg2"
-        if args.cached_plan and lss._plan_cache:
-            plan = next(iter(lss._plan_cache.values()))
-            # cached sort: no geom read / pos_memo write per step; row ids + item descriptors instead
-            fb = 4 * C * K + 4 * K + 16 * plan.num_items + 4 * C * B * ny * nx
-            res["roofline"] = roofline_entry("vp_planned_items + vp_planned_fold (cached-plan voxel_pooling forward, "
-                                             "inside the training step)", fb, fwd_ms, ())
-        else:
-            res["roofline"] = roofline_entry("vp_fwd_seg_gather (voxel_pooling forward, inside the training step)", fb, fwd_ms,
-                                             ("vp_fwd_seg_gather",) if cfg2 else ())
-        res["roofline_backward"] = roofline_entry("vp_bwd_prepare + vp_bwd_rows_vec4 (voxel_pooling backward, inside the training step)",
-                                                  bb, bwd_ms, ("vp_bwd_prepare", "vp_bwd_rows_vec4") if cfg2 else ())
+        vn = list(lss._voxel_num_host)
+        nx, ny, nz = vn
+        K, BP, C = kept_count(geom, vn), geom.numel() // 3, lss.output_channels
+        BN_HW = BP // lss.depth_channels
         res["config"]["kept_fraction"] = K / BP
+        if fused and timing.get("lift_splat_forward"):
+            fwd_ms, bwd_ms = _lib.mean_ms(timing["lift_splat_forward"]), _lib.mean_ms(timing["lift_splat_backward"])
+            fbytes, bbytes, l2f, l2b = lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, fb)
+            note = ("fused lift + voxel_pooling (SURVEY 8/f1): the [B*P, C] feature matrix is never materialised, so the HBM-side "
+                    "algorithmic bytes are ~5x below the drop-in op's and the kernel is bound by L2 row gathers and its LDS sort, "
+                    "not by HBM; l2_side prices the gathered rows against the aggregate L2 bandwidth")
+            sfx = "_bf16" if dtype == "bf16" else ""
+            res["roofline"] = roofline_entry(f"vp_fwd_seg_gather<fused>{sfx} (lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
+                                             pmc_traffic(args.config, ("lift_splat_forward",)), l2f, note)
+            res["roofline_backward"] = roofline_entry(f"lift_splat_backward_kernel{sfx} (the step's voxel_pooling backward)", bbytes, bwd_ms,
+                                                      pmc_traffic(args.config, ("lift_splat_backward",)), l2b)
+        elif timing.get("forward"):
+            fwd_ms, bwd_ms = _lib.mean_ms(timing["forward"]), _lib.mean_ms(timing["backward"])
+            fbytes, bbytes = algorithmic_bytes(BP, K, C, B, ny, nx, fb)
+            if args.cached_plan and lss._plan_cache:
+                plan = next(iter(lss._plan_cache.values()))
+                # cached sort: no geom read / pos_memo write per step; row ids + item descriptors instead
+                fbytes = 4 * C * K + 4 * K + 16 * plan.num_items + 4 * C * B * ny * nx
+                res["roofline"] = roofline_entry("vp_planned_items + vp_planned_fold (cached-plan voxel_pooling forward, inside the training step)",
+                                                 fbytes, fwd_ms)
+            else:
+                res["roofline"] = roofline_entry("vp_fwd_seg_gather (voxel_pooling forward, inside the training step)", fbytes, fwd_ms,
+                                                 pmc_traffic(args.config + "_unfused", ("vp_fwd_seg_gather",)))
+            res["roofline_backward"] = roofline_entry("vp_bwd_prepare + vp_bwd_rows_vec4 (voxel_pooling backward, inside the training step)",
+                                                      bbytes, bwd_ms, pmc_traffic(args.config + "_unfused", ("vp_bwd_prepare", "vp_bwd_rows_vec4")))
+    if cfg["use_lidar"] and timing.get("voxelize") and timing.get("scatter"):
+        enc = ts.model.lidar_encoder
+        from mm_training_amd.lidar import hard_voxelize_mean_batch
+        with torch.no_grad():
+            _, _, _, cnt, _ = hard_voxelize_mean_batch([p.float() for p in batches[0][2]], enc.voxel_size, enc.point_cloud_range,
+                                                        enc.max_num_points, enc.max_voxels, enc.num_features, materialize_voxels=False)
+        M = int(cnt.sum().item())
+        total_pts = sum(int(p.shape[0]) for p in batches[0][2])
+        ny_l, nx_l = enc.output_shape
+        vox_b, scat_b, scat_bwd_b = lidar_bytes(cfg["point_features"], total_pts, M, enc.num_features, enc.in_channels, B, ny_l, nx_l)
+        t_vox, t_scat = _lib.mean_ms(timing["voxelize"]), _lib.mean_ms(timing["scatter"])
+        r = roofline_entry("vox_link + vox_heads + vox_emit (voxelize + mean) and fill + scatter_map + scatter_write_nhwc (pillar scatter), "
+                           "inside the training step", vox_b + scat_b, t_vox + t_scat,
+                           pmc_traffic(args.config, ("vox_link", "vox_heads", "vox_emit", "fill_i32_kernel", "scatter_map_kernel", "scatter_write_nhwc_kernel")))
+        r["parts"] = {"voxelize_mean": {"algorithmic_bytes": vox_b, "avg_ms": t_vox, "GBps": vox_b / t_vox / 1e6,
+                                        "note": "bound by one scattered device-scope atomic per point (~20 G/s), not by HBM"},
+                      "pillar_scatter": {"algorithmic_bytes": scat_b, "avg_ms": t_scat, "GBps": scat_b / t_scat / 1e6}}
+        r["voxels"] = M
+        res["roofline_lidar"] = r
+        if timing.get("scatter_backward"):
+            res["roofline_lidar_backward"] = roofline_entry("scatter_backward_nhwc_kernel (pillar scatter backward)", scat_bwd_b,
+                                                            _lib.mean_ms(timing["scatter_backward"]),
+                                                            pmc_traffic(args.config, ("scatter_backward_nhwc_kernel",)))
+    if cfg["use_cam"] and not args.no_hotpath_leg:
+        # the drop-in op at the same shape and geometry, right after the timed steps: the like-for-like figure
+        # beside cpu_baseline and the BASELINE metric's "voxel_pooling HBM GB/s"
+        gsh = geom.reshape(B, -1, 3).contiguous()
+        P = gsh.shape[1]
+        fwd_ms, bwd_ms, _, feats_cpu, grad_out, out, feats = hotpath_leg(gsh, vn, C, dtype, 20, 3)
+        fbytes, bbytes = algorithmic_bytes(BP, K, C, B, ny, nx, fb)
+        sfx = "_bf16" if dtype == "bf16" else ""
+        tag = (args.config if args.config != "cfg4" else "cfg2") + sfx      # cfg4's camera half IS the cfg2 shape
+        res["roofline_voxel_pooling"] = roofline_entry(f"vp_fwd_seg_gather{sfx} (drop-in voxel_pooling forward, same shape and geometry, "
+                                                       "timed after the steps)", fbytes, fwd_ms, pmc_traffic(tag, ("vp_fwd_seg_gather" + sfx,)))
+        bk = ("vp_bwd_prepare", "vp_bwd_rows_bf16" if dtype == "bf16" else "vp_bwd_rows_vec4")
+        res["roofline_voxel_pooling_backward"] = roofline_entry(f"{' + '.join(bk)} (drop-in voxel_pooling backward)", bbytes, bwd_ms,
+                                                                pmc_traffic(tag, bk))
+        res["hotpath_samples_per_s"] = B / ((fwd_ms + bwd_ms) * 1e-3)
         if world == 1 and not args.no_cpu_baseline:
-            from mm_training_amd import synthetic
-            P = BP // B
-            feats_cpu = synthetic.features((B, P, C), seed=100)
-            go = torch.randn(B, ny, nx, C, generator=torch.Generator().manual_seed(1))
-            base, _, _, _ = cpu_baseline(geom.reshape(B, P, 3).cpu(), feats_cpu, (nx, ny, nz), go)
+            f_cpu = feats.detach().float().cpu().reshape(B, P, C)
+            base, ref_out, ref_pos, ref_gi = cpu_baseline(gsh.cpu(), f_cpu, vn, grad_out.permute(0, 2, 3, 1).contiguous().cpu())
             res["cpu_baseline"] = base
+            err = (out.detach().float().permute(0, 2, 3, 1).cpu() - ref_out).abs().max().item()
+            gi = feats.grad.reshape(B, P, C).cpu()
+            res["parity"] = {"bev_max_abs_err": err, "grad_in_bit_exact": bool(torch.equal(gi, ref_gi.to(gi.dtype)))}
     print(json.dumps(res), flush=True)
 
 
-def main():
-    args = parse()
-    rank, local_rank, world = init_dist(args.gpus)
-    if args.mode == "train":
-        train_main(args, rank, local_rank, world)
-        if world > 1:
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, argv))
+    _late_imports(args.device)
+    rank, local_rank, world = init_dist(args.gpus, args.device)
+    try:
+        if args.device == "cpu":
+            rehearsal_main(args, rank, world)
+        elif args.mode == "train":
+            train_main(args, rank, local_rank, world)
+        else:
+            hotpath_main(args, rank, local_rank, world)
+    finally:
+        if world > 1 and dist.is_initialized():
             dist.destroy_process_group()
-        return
-    from mm_training_amd import _lib, synthetic
-    from mm_training_amd.ops.voxel_pooling import voxel_pooling, voxel_pooling_ext
-    _lib.lib()
-
-    cfg = CFG2
-    B, C = cfg["batch"], cfg["channels"]
-    geom_cpu, vn = synthetic.rig_geometry(B, cfg["num_cams"], cfg["final_dim"], cfg["downsample"],
-                                          cfg["d_bound"], cfg["x_bound"], cfg["y_bound"], cfg["z_bound"],
-                                          seed=rank)
-    feats_cpu = synthetic.features(tuple(geom_cpu.shape[:-1]) + (C,), seed=100 + rank)
-    nx, ny, nz = vn
-    P = feats_cpu[0].numel() // C
-    geom = geom_cpu.cuda()
-    feats = feats_cpu.cuda().requires_grad_(True)
-    g = torch.Generator().manual_seed(1)
-    grad_out = torch.randn(B, ny, nx, C, generator=g).cuda().permute(0, 3, 1, 2)  # channels-last grad
-
-    def step():
-        feats.grad = None
-        out = voxel_pooling(geom, feats, vn)
-        out.backward(grad_out)
-        return out
-
-    for _ in range(args.warmup):
-        step()
-    voxel_pooling_ext.TIMING = {}
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier(world)
-    elapsed = time.perf_counter() - t0
-    timing = voxel_pooling_ext.TIMING
-    voxel_pooling_ext.TIMING = None
-
-    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    fwd_ms = sum(s.elapsed_time(e) for s, e in timing["forward"]) / len(timing["forward"])
-    bwd_ms = sum(s.elapsed_time(e) for s, e in timing["backward"]) / len(timing["backward"])
-    g3 = geom.reshape(-1, 3)
-    kept = ((g3[:, 0] >= 0) & (g3[:, 0] < nx) & (g3[:, 1] >= 0) & (g3[:, 1] < ny)
-            & (g3[:, 2] >= 0) & (g3[:, 2] < nz))
-    K = int(kept.sum().item())
-    fwd_bytes, bwd_bytes = algorithmic_bytes(B * P, K, C, B, ny, nx)
-
-    if rank == 0:
-        res = {
-            "metric": "training samples/sec at bs=4/GPU (hot path: voxel_pooling fwd+bwd); voxel_pooling HBM GB/s",
-            "value": world * B * args.steps / elapsed,
-            "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] camera half: voxel_pooling forward+backward, "
-                                   "6 cams 256x704 ds16 D=112 fH=16 fW=44 C=80, BEV 128x128x1, "
-                                   "analytic 6-camera rig geometry, bs=4/GPU",
-                       "global_batch": world * B, "points_per_sample": P, "kept_fraction": K / (B * P),
-                       "parallelism": f"dp{world}", "mode": args.mode},
-            "roofline": roofline_entry("vp_fwd_seg_gather (voxel_pooling forward)", fwd_bytes, fwd_ms, ("vp_fwd_seg_gather",)),
-            "roofline_backward": roofline_entry("vp_bwd_prepare + vp_bwd_rows_vec4 (voxel_pooling backward)", bwd_bytes, bwd_ms,
-                                                ("vp_bwd_prepare", "vp_bwd_rows_vec4")),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            base, ref_out, ref_pos, ref_gi = cpu_baseline(geom_cpu.reshape(B, P, 3), feats_cpu.reshape(B, P, C),
-                                                          vn, grad_out.permute(0, 2, 3, 1).contiguous().cpu())
-            res["cpu_baseline"] = base
-            # same-run parity of the measured path against the CPU port
-            err = (out.detach().permute(0, 2, 3, 1).cpu() - ref_out).abs().max().item()
-            gi_equal = bool(torch.equal(feats.grad.reshape(B, P, C).cpu(), ref_gi))
-            res["parity"] = {"bev_max_abs_err": err, "grad_in_bit_exact": gi_equal}
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -30,8 +30,10 @@ extern "C" {
  * (purely additive: every version-1 symbol keeps its signature and meaning)
  * 3: adds the MMT_VP_CHUNK_POINTS field of the forward flags (bits 8-15, 0 = library default as before);
  *    mmt_bev_warp_affine_backward is bit-reproducible (gather instead of atomics) and refuses a
- *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support) */
-#define MMT_ABI_VERSION 3
+ *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
+ * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
+ *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
+#define MMT_ABI_VERSION 4
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -46,10 +48,11 @@ const char *mmt_last_error(void);
 /* Measurement support (bench.py's live roofline figure; no counterpart in the reference).  The events are attached to
  * the kernel dispatches themselves (hipExtLaunchKernel start / stop events), so the elapsed time is the kernels' own
  * duration on the device -- what rocprofv3 --kernel-trace reports -- without the dispatch latency that events recorded
- * around a launch include.  mmt_arm_kernel_timing(start, stop) applies to the NEXT call of this thread to
- * mmt_voxel_pooling_forward[_ex] (used by the default SEG_GATHER launch only; the other algorithms consume and ignore
- * it) or mmt_voxel_pooling_backward (start on the first kernel of the call, stop on the last) and is cleared by that
- * call; other entry points leave it armed.
+ * around a launch include.  mmt_arm_kernel_timing(start, stop) applies to the NEXT call of this thread to one of
+ * mmt_voxel_pooling_forward[_ex] (default SEG_GATHER launch only; the other algorithms consume and ignore it),
+ * mmt_voxel_pooling_backward, mmt_lift_splat_forward / _backward, mmt_hard_voxelize[_mean], mmt_simple_vfe,
+ * mmt_pillar_scatter[_nhwc][_backward] and their *_bf16 forms: start on the first kernel of the call, stop on the
+ * last; the call clears it.  Other entry points leave it armed.
  * Read the result with mmt_timing_elapsed_ms after synchronising the stream. */
 int mmt_timing_event_create(void **event);
 int mmt_timing_event_destroy(void *event);
@@ -246,7 +249,8 @@ int mmt_dcn_col2im(int B, int H, int W, int C, int groups, const float *x, const
  *   voxel_count  int32 [B]   number of voxels of each sample (M_b <= max_voxels)
  * Voxels are numbered in order of their first point; <= max_points points per voxel,
  * first come first kept; voxels beyond max_voxels (in first-point order) are dropped.
- * workspace: int32, at least mmt_voxelize_workspace_elems(...) elements (device). */
+ * workspace: int32, at least mmt_voxelize_workspace_elems(...) elements (device), any contents (this stateless
+ * form clears its per-cell table itself; mmt_hard_voxelize_mean below avoids that pass). */
 int64_t mmt_voxelize_workspace_elems(int batch_size, int64_t total_points, const int32_t *grid_host);
 int mmt_hard_voxelize(int batch_size, int64_t total_points, int num_features,
                       const float *points, const int32_t *point_offsets,
@@ -254,6 +258,29 @@ int mmt_hard_voxelize(int batch_size, int64_t total_points, int num_features,
                       const int32_t *grid_host, int max_points, int max_voxels, float *voxels,
                       int32_t *coors, int32_t *num_points, int32_t *voxel_count,
                       int32_t *workspace, void *stream);
+
+/* The same voxelization fused with the HardSimpleVFE mean (models/bev_depth.py:181-182 in one call; SURVEY
+ * section 8 row a10: "fuse into a9's epilogue") and WITHOUT any clearing pass:
+ *   table    int32 [mmt_voxelize_table_elems(B, grid)], 8-byte aligned, PERSISTENT: zero-filled ONCE by the
+ *            caller after allocation, then handed to every call unchanged.  Its per-cell entries carry a
+ *            generation stamp (a 40-bit counter kept in the table itself and advanced on the device by every
+ *            call, so a captured hipGraph can be replayed), entries of earlier calls read as empty.  One table
+ *            serves one stream at a time; after a failed call zero-fill it again.
+ *   scratch  int32 [mmt_voxelize_scratch_elems(B, total_points)], any contents.
+ *   voxels   may be NULL: the padded [B*max_voxels, max_points, F] tensor is then not materialised
+ *            (4*T*F bytes per voxel less traffic) -- what LidarEncoder.forward_bev does.
+ *   mean     fp32 [B*max_voxels, num_features] or NULL: sum over the voxel's points (slot order) of the first
+ *            num_features columns / num_points; rows past voxel_count[b] are written as zeros.
+ * Other arguments and outputs as mmt_hard_voxelize.  total_points < 2^24. */
+int64_t mmt_voxelize_table_elems(int batch_size, const int32_t *grid_host);
+int64_t mmt_voxelize_scratch_elems(int batch_size, int64_t total_points);
+int mmt_hard_voxelize_mean(int batch_size, int64_t total_points, int num_features,
+                           const float *points, const int32_t *point_offsets,
+                           const float *voxel_size_host, const float *range_min_host,
+                           const int32_t *grid_host, int max_points, int max_voxels,
+                           int vfe_num_features, float *voxels, int32_t *coors, int32_t *num_points,
+                           int32_t *voxel_count, float *mean, int32_t *table, int32_t *scratch,
+                           void *stream);
 
 /* Compacts the fixed-capacity outputs above into the dense (concatenated) tensors the
  * reference returns: rows [sum_{b'<b} M_b', ...) <- sample b's first M_b rows.

@@ -48,6 +48,9 @@ SIGNATURES = {
     "mmt_dcn_im2col": (_c_int, [_c_int] * 5 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_dcn_col2im": (_c_int, [_c_int] * 5 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr]),
+    "mmt_voxelize_table_elems": (_c_i64, [_c_int, _c_ptr]),
+    "mmt_voxelize_scratch_elems": (_c_i64, [_c_int, _c_i64]),
+    "mmt_hard_voxelize_mean": (_c_int, [_c_int, _c_i64, _c_int] + [_c_ptr] * 5 + [_c_int, _c_int, _c_int] + [_c_ptr] * 7 + [_c_ptr]),
     "mmt_hard_voxelize": (_c_int, [_c_int, _c_i64, _c_int] + [_c_ptr] * 5 + [_c_int, _c_int] + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_compact_voxels": (_c_int, [_c_int] * 3 + [_c_ptr] * 8 + [_c_ptr]),
     "mmt_simple_vfe": (_c_int, [_c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
@@ -98,6 +101,55 @@ def call(name, *args):
         msg = lib().mmt_last_error()
         raise MmtError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
     return rc
+
+
+# ---- measurement support (bench.py's live roofline figures) -------------------------------------------
+# When TIMING is a dict, every entry-point call made through timed_call() carries a pair of HIP events ATTACHED
+# TO ITS DISPATCHES (mmt_arm_kernel_timing -> hipExtLaunchKernel start / stop events: the kernels' own duration on
+# the device, what rocprofv3 --kernel-trace reports; events recorded around a launch would add the dispatch
+# latency), and the (start, end) pairs are appended under `kind`.  `start.elapsed_time(end)` gives milliseconds
+# after a stream synchronisation.  None (the default) = plain calls.
+TIMING = None
+
+
+class KernelEvent:
+    """A HIP event owned by libmmt_hip (same `elapsed_time` call as torch.cuda.Event)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        call("mmt_timing_event_create", ctypes.byref(h))
+        self.handle = h.value
+
+    def elapsed_time(self, end):
+        ms = ctypes.c_float()
+        call("mmt_timing_elapsed_ms", self.handle, end.handle, ctypes.byref(ms))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().mmt_timing_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def timed_call(kind, name, *args):
+    """call(name, *args); with TIMING enabled the call's kernels are bracketed by dispatch-attached events."""
+    if TIMING is None:
+        return call(name, *args)
+    start, end = KernelEvent(), KernelEvent()
+    call("mmt_arm_kernel_timing", start.handle, end.handle)
+    try:
+        rc = call(name, *args)
+    finally:
+        call("mmt_arm_kernel_timing", None, None)      # never leave it armed (a timed entry point consumes it anyway)
+    TIMING.setdefault(kind, []).append((start, end))
+    return rc
+
+
+def mean_ms(pairs):
+    """Average duration in ms of a list of (start, end) event pairs (after a synchronisation)."""
+    return sum(s.elapsed_time(e) for s, e in pairs) / len(pairs)
 
 
 def float3(values):

@@ -44,11 +44,41 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source into one shared library. Returns the .so path."""
-    if not force and not is_stale():
+def _obj_path(src):
+    return os.path.join(CSRC, "build", os.path.basename(src)[:-4] + ".o")
+
+
+def _obj_stale(src, headers_mtime):
+    obj = _obj_path(src)
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return os.path.getmtime(src) > t or headers_mtime > t
+
+
+def build(force=False, verbose=False, extra_flags=(), jobs=None):
+    """Compile every HIP source (one object per file, in parallel, rebuilt only when the file or a
+    header changed) and link them into one shared library. Returns the .so path."""
+    if not force and not is_stale() and not extra_flags:
         return LIB_PATH
-    cmd = [find_hipcc()] + HIPCC_FLAGS + list(extra_flags) + sources() + ["-o", LIB_PATH + ".tmp"]
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = find_hipcc()
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h")) + \
+        [os.path.abspath(__file__)]
+    hm = max(os.path.getmtime(h) for h in hdrs)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    todo = [src for src in sources() if force or extra_flags or _obj_stale(src, hm)]
+
+    def compile_one(src):
+        cmd = [hipcc] + cflags + ["-c", src, "-o", _obj_path(src)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + [_obj_path(s) for s in sources()] + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

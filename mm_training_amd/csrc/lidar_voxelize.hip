@@ -4,43 +4,55 @@
 // Replaces the third-party ops the reference reaches at models/bev_depth.py:181-183
 // (mmcv-full 1.7.0 ops.Voxelization, mmdet3d 1.0.0rc4 HardSimpleVFE and
 // PointPillarsScatter).  mmcv's deterministic GPU path compares every point with
-// every earlier point (O(N^2)) and numbers voxels in a single thread; here:
-//   1. claim : per point, cell id; atomicMin -> first point of each cell; atomicExch
-//              -> per-cell chain of its points (dense-grid claim, no hashing);
-//   2. count : per 1024-point tile, wave ballot + popcount of "is first point of its
-//              cell" flags -> tile head counts;
-//   3. number: per tile, offset = sum of preceding tile counts; voxel id of a head =
-//              offset + ballot/prefix-sum rank  ==> voxels numbered in order of their
-//              first point, exactly like the sequential algorithm; heads past
-//              max_voxels are dropped;
-//   4. fill  : per point, rank = number of earlier points in its cell (chain walk with
-//              early exit at max_points) -> voxels[v][rank][:] = point.
+// every earlier point (O(N^2)) and numbers voxels in a single thread; here three
+// kernels, no memset, ONE scattered atomic per point (the scattered device-scope
+// atomic -- ~20 G/s chip-wide, MI355X_MICROARCH.md "Global float atomics" -- is what
+// bounds the first kernel, so there is exactly one):
+//   1. link  : per point, cell id; one 64-bit atomicExch on the cell's entry of a dense
+//              per-sample table threads the point onto its cell's chain.  Entries carry a
+//              GENERATION stamp in their upper 40 bits: an entry of an older call reads as
+//              "empty", so the table is never cleared (the round-1 version spent three
+//              memsets of dense per-cell tables, 34 MB, on 6 MB of points);
+//   2. heads : per 256-point tile, "is this point the first of its cell" by a chain walk
+//              that stops at the first earlier point; wave ballot + popcount -> rank of the
+//              head inside its tile and the tile's head count;
+//   3. emit  : per tile, offset = sum of the preceding tiles' head counts; voxel id of a
+//              head = offset + rank  ==> voxels numbered in order of their first point,
+//              exactly like the sequential algorithm; heads past max_voxels are dropped.
+//              Each head walks its cell's chain once, keeps the max_points smallest point
+//              indices sorted (LDS) and the tile then writes its voxels' rows -- a
+//              CONTIGUOUS block of the output, voxel ids of a tile are consecutive -- the
+//              zero padding, coors, num_points and the HardSimpleVFE mean (summed in slot
+//              order) as flat coalesced stores.  Rows past a sample's voxel count are
+//              marked empty (coors -1, num_points 0, mean 0) by the same kernel.
 // All samples of the batch go through each kernel together (blockIdx.y = sample).
 #include "mmt_common.h"
 
 namespace {
 
-constexpr int kTileThreads = 1024;  // 16 waves
-constexpr int kWaves = kTileThreads / 64;
-constexpr int kFirstInit = 0x7f7f7f7f;  // hipMemset byte pattern 0x7f
+constexpr int kTile = 256;            // points per tile / threads per workgroup (4 waves)
+constexpr int kTileWaves = kTile / 64;
+constexpr int kIdxBits = 24;          // point index inside its sample (host checks N < 2^24)
+constexpr unsigned long long kIdxMask = (1ull << kIdxBits) - 1ull;
+constexpr int kMaxBatchLds = 255;     // sample offsets cached in LDS up to this batch size
 
 struct VoxArgs {
-    int F, max_points, max_voxels;
+    int F, max_points, max_voxels, nf;
     int gx, gy, gz;
     float vs[3], rmin[3];
     const float *points;
-    const int32_t *offsets;   // [B+1]
-    int32_t *first;           // [B*cells] min point index per cell
-    int32_t *head;            // [B*cells] chain head per cell
-    int32_t *vox_id;          // [B*cells] voxel number per cell (-1 = capped)
-    int32_t *cell_of_point;   // [N]
-    int32_t *next;            // [N]
-    int32_t *tile_counts;     // [B*ntiles]
+    const int32_t *offsets;        // [B+1]
+    unsigned long long *table;     // [2 + B*cells]: [0] generation counter, [1] pad, then one entry per cell
+    int32_t *cell_of_point;        // [N]
+    int32_t *next;                 // [N] chain link (point index inside the sample, -1 = end)
+    int32_t *hrank;                // [N] rank of a head point among the heads of its tile, -1 = not a head
+    int32_t *tile_counts;          // [B*ntiles]
     int ntiles;
-    float *voxels;
+    float *voxels;                 // may be NULL (only the mean is wanted)
     int32_t *coors;
     int32_t *num_points;
     int32_t *voxel_count;
+    float *mean;                   // may be NULL
 };
 
 __device__ __forceinline__ int cell_coord(float p, float rmin, float vs) {
@@ -48,143 +60,210 @@ __device__ __forceinline__ int cell_coord(float p, float rmin, float vs) {
     return (int)floorf(__fdiv_rn(__fsub_rn(p, rmin), vs));
 }
 
-__global__ __launch_bounds__(256) void vox_claim(VoxArgs a) {
-    const int b = blockIdx.y;
-    const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
+// sample of global point index g (offsets [B+1] ascending): B is small, a linear scan of the LDS copy
+__device__ __forceinline__ int sample_of_point(const int *offs, int B, int g) {
+    int b = 0;
+    while (b + 1 < B && g >= offs[b + 1]) ++b;
+    return b;
+}
+
+// (sample, tile) of a workgroup in the flattened tile space: sample b owns max(ceil(n_b / kTile), 1) consecutive
+// workgroups (an empty sample keeps one: its rows still have to be marked empty).  Returns false past the last tile.
+__device__ __forceinline__ bool locate_tile(const int32_t *offsets, int B, int wg, int *b_out, int *tile_out) {
+    int first = 0;
+    for (int b = 0; b < B; ++b) {
+        const int n = offsets[b + 1] - offsets[b];
+        int t = (n + kTile - 1) / kTile;
+        t = t > 0 ? t : 1;
+        if (wg < first + t) { *b_out = b; *tile_out = wg - first; return true; }
+        first += t;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(kTile) void vox_link(VoxArgs a, int B, int total) {
+    __shared__ int offs[kMaxBatchLds + 1];
+    for (int i = threadIdx.x; i <= B && i <= kMaxBatchLds; i += kTile) offs[i] = a.offsets[i];
+    __syncthreads();
     const int64_t cells = (int64_t)a.gx * a.gy * a.gz;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float *p = a.points + (int64_t)(beg + i) * a.F;
+    // every workgroup reads the same value: the counter is advanced by the NEXT kernel of the call
+    const unsigned long long gen = a.table[0] + 1ull;
+    for (int g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
+        int b, beg;
+        if (B <= kMaxBatchLds) { b = sample_of_point(offs, B, g); beg = offs[b]; }
+        else { b = 0; while (b + 1 < B && g >= a.offsets[b + 1]) ++b; beg = a.offsets[b]; }
+        const int i = g - beg;
+        const float *p = a.points + (int64_t)g * a.F;
         const int cx = cell_coord(p[0], a.rmin[0], a.vs[0]);
         const int cy = cell_coord(p[1], a.rmin[1], a.vs[1]);
         const int cz = cell_coord(p[2], a.rmin[2], a.vs[2]);
-        int cell = -1;
+        int cell = -1, nxt = -1;
         if (!(cx < 0 || cx >= a.gx || cy < 0 || cy >= a.gy || cz < 0 || cz >= a.gz)) {
             cell = (cz * a.gy + cy) * a.gx + cx;
-            atomicMin(&a.first[b * cells + cell], i);
-            a.next[beg + i] = atomicExch(&a.head[b * cells + cell], i);
+            const unsigned long long old = atomicExch(&a.table[2 + (int64_t)b * cells + cell], (gen << kIdxBits) | (unsigned long long)i);
+            if ((old >> kIdxBits) == gen) nxt = (int)(old & kIdxMask);
         }
-        a.cell_of_point[beg + i] = cell;
+        a.cell_of_point[g] = cell;
+        a.next[g] = nxt;
     }
 }
 
-__device__ __forceinline__ bool is_head(const VoxArgs &a, int b, int beg, int n, int i, int64_t cells, int *cell_out) {
-    int cell = -1;
-    bool h = false;
-    if (i < n) {
-        cell = a.cell_of_point[beg + i];
-        if (cell >= 0) h = (a.first[b * cells + cell] == i);
-    }
-    *cell_out = cell;
-    return h;
-}
-
-__global__ __launch_bounds__(kTileThreads) void vox_count(VoxArgs a) {
-    __shared__ int wc[kWaves];
-    const int b = blockIdx.y, tile = blockIdx.x;
+__global__ __launch_bounds__(kTile) void vox_heads(VoxArgs a, int B) {
+    __shared__ int wc[kTileWaves];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.table[0] += 1ull;     // vox_link of this call is done
+    int b, tile;
+    if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
     const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
-    if (tile * kTileThreads >= n) {
+    if (tile * kTile >= n) {
         if (threadIdx.x == 0) a.tile_counts[b * a.ntiles + tile] = 0;
         return;
     }
     const int64_t cells = (int64_t)a.gx * a.gy * a.gz;
-    int cell;
-    const bool h = is_head(a, b, beg, n, tile * kTileThreads + threadIdx.x, cells, &cell);
-    const unsigned long long m = __ballot(h);
-    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int s = 0;
-        for (int w = 0; w < kWaves; ++w) s += wc[w];
-        a.tile_counts[b * a.ntiles + tile] = s;
-    }
-}
-
-__global__ __launch_bounds__(kTileThreads) void vox_number(VoxArgs a) {
-    __shared__ int wc[kWaves];
-    __shared__ int tile_off;
-    const int b = blockIdx.y, tile = blockIdx.x;
-    const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
-    const int my_tiles = (n + kTileThreads - 1) / kTileThreads;
-    if (tile >= my_tiles && !(tile == 0 && my_tiles == 0)) return;
-    const int64_t cells = (int64_t)a.gx * a.gy * a.gz;
+    const unsigned long long *tab = a.table + 2 + (int64_t)b * cells;
+    const int i = tile * kTile + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    // offset of this tile = sum of the head counts of the preceding tiles (<= a few hundred)
-    if (wave == 0) {
-        int s = 0;
-        for (int t = lane; t < tile; t += 64) s += a.tile_counts[b * a.ntiles + t];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (lane == 0) tile_off = s;
+    bool h = false;
+    if (i < n) {
+        const int cell = a.cell_of_point[beg + i];
+        if (cell >= 0) {
+            // head <=> no point of the chain comes earlier in the cloud (the chain holds every point of the cell)
+            h = true;
+            for (int j = (int)(tab[cell] & kIdxMask); j >= 0; j = a.next[beg + j])
+                if (j < i) { h = false; break; }
+        }
     }
-    int cell;
-    const int i = tile * kTileThreads + threadIdx.x;
-    const bool h = is_head(a, b, beg, n, i, cells, &cell);
     const unsigned long long m = __ballot(h);
     if (lane == 0) wc[wave] = __popcll(m);
     __syncthreads();
     int woff = 0, total = 0;
-    for (int w = 0; w < kWaves; ++w) {
+#pragma unroll
+    for (int w = 0; w < kTileWaves; ++w) {
         const int c = wc[w];
         if (w < wave) woff += c;
         total += c;
     }
-    if (h) {
-        const int vid = tile_off + woff + __popcll(m & ((1ull << lane) - 1ull));
-        if (vid < a.max_voxels) {
-            a.vox_id[b * cells + cell] = vid;
-            const int cx = cell % a.gx, cy = (cell / a.gx) % a.gy, cz = cell / (a.gx * a.gy);
-            int32_t *co = a.coors + ((int64_t)b * a.max_voxels + vid) * 4;
-            co[0] = b; co[1] = cz; co[2] = cy; co[3] = cx;
-        } else {
-            a.vox_id[b * cells + cell] = -1;
-        }
-    }
-    if (tile == my_tiles - 1 || my_tiles == 0) {
-        if (threadIdx.x == 0) {
-            const int all = my_tiles == 0 ? 0 : tile_off + total;
-            a.voxel_count[b] = all < a.max_voxels ? all : a.max_voxels;
-        }
-    }
+    if (i < n) a.hrank[beg + i] = h ? woff + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    if (threadIdx.x == 0) a.tile_counts[b * a.ntiles + tile] = total;
 }
 
-__global__ __launch_bounds__(256) void vox_fill(VoxArgs a) {
-    const int b = blockIdx.y;
+// LDS: lists [kTile][T] sorted point indices | cnt [kTile] | cellv [kTile] | qmap [T*F] (slot, column) of a row element
+__global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
+    extern __shared__ __align__(16) int lds[];
+    __shared__ int s_off, s_total;
+    const int T = a.max_points, F = a.F, V = a.max_voxels;
+    const int TF = T * F;
+    int *lists = lds;
+    int *cnt = lists + kTile * T;
+    int *cellv = cnt + kTile;
+    int *qmap = cellv + kTile;
+    int b, tile;
+    if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
     const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
+    const int my_tiles = (n + kTile - 1) / kTile;
     const int64_t cells = (int64_t)a.gx * a.gy * a.gz;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int cell = a.cell_of_point[beg + i];
-        if (cell < 0) continue;
-        const int v = a.vox_id[b * cells + cell];
-        if (v < 0) continue;
-        // rank = number of points of this cell that come earlier in the cloud
-        int rank = 0;
-        for (int j = a.head[b * cells + cell]; j >= 0 && rank < a.max_points; j = a.next[beg + j])
-            rank += (j < i);
-        if (rank >= a.max_points) continue;
-        const int64_t row = (int64_t)b * a.max_voxels + v;
-        float *dst = a.voxels + (row * a.max_points + rank) * a.F;
-        const float *src = a.points + (int64_t)(beg + i) * a.F;
-        for (int k = 0; k < a.F; ++k) dst[k] = src[k];
-        atomicMax(&a.num_points[row], rank + 1);
-    }
-}
+    const unsigned long long *tab = a.table + 2 + (int64_t)b * cells;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-// zero the unused point slots of live voxels; mark rows past the sample's voxel count
-// as empty (coors = -1, num_points = 0) so the fixed-capacity layout is self-describing.
-__global__ __launch_bounds__(256) void vox_pad(VoxArgs a) {
-    const int b = blockIdx.y;
-    const int M = a.voxel_count[b];
-    const int slot_elems = a.max_points * a.F;
-    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < a.max_voxels; v += gridDim.x * 4) {
-        const int64_t row = (int64_t)b * a.max_voxels + v;
-        const int lane = threadIdx.x & 63;
-        if (v < M) {
-            const int np = a.num_points[row];
-            for (int e = np * a.F + lane; e < slot_elems; e += 64) a.voxels[row * slot_elems + e] = 0.f;
-        } else {
-            if (lane < 4) a.coors[row * 4 + lane] = -1;
-            if (lane == 4) a.num_points[row] = 0;
+    if (a.voxels)
+        for (int q = threadIdx.x; q < TF; q += kTile) qmap[q] = ((q / F) << 16) | (q % F);
+    // heads before this tile / in the whole sample (a few hundred tile counts at most)
+    if (wave == 0) {
+        int before = 0, all = 0;
+        for (int t = lane; t < my_tiles; t += 64) {
+            const int c = a.tile_counts[b * a.ntiles + t];
+            all += c;
+            if (t < tile) before += c;
         }
+        for (int o = 32; o > 0; o >>= 1) {
+            before += __shfl_down(before, o);
+            all += __shfl_down(all, o);
+        }
+        if (lane == 0) { s_off = before; s_total = all; }
+    }
+    __syncthreads();
+    const int off = s_off;
+    const int M = s_total < V ? s_total : V;            // voxels of this sample
+    if (tile == 0 && threadIdx.x == 0) a.voxel_count[b] = M;
+    const int nheads = my_tiles > 0 ? a.tile_counts[b * a.ntiles + tile] : 0;
+    const int nown = (off + nheads <= V) ? nheads : (V - off > 0 ? V - off : 0);   // heads of this tile below the cap
+
+    // ---- every owning head walks its chain once: the T smallest point indices, sorted, in LDS
+    const int i = tile * kTile + threadIdx.x;
+    if (i < n) {
+        const int r = a.hrank[beg + i];
+        if (r >= 0 && r < nown) {
+            const int cell = a.cell_of_point[beg + i];
+            int *L = lists + r * T;
+            int c = 0;
+            for (int j = (int)(tab[cell] & kIdxMask); j >= 0; j = a.next[beg + j]) {
+                if (c == T && j > L[T - 1]) continue;
+                int k = c < T ? c : T - 1;              // insertion position search from the top
+                while (k > 0 && L[k - 1] > j) { L[k] = L[k - 1]; --k; }
+                L[k] = j;
+                if (c < T) ++c;
+            }
+            cnt[r] = c;
+            cellv[r] = cell;
+        }
+    }
+    __syncthreads();
+
+    // ---- the tile's voxels are rows [off, off + nown) of the sample: flat, coalesced stores.  (row, element) of a
+    // flat index advance incrementally (no integer division per element: (slot, column) of an element come from qmap)
+    const int64_t row0 = (int64_t)b * V + off;
+    if (a.voxels) {
+        float *dst = a.voxels + row0 * TF;
+        const int total = nown * TF;
+        int r = threadIdx.x / TF, q = threadIdx.x - r * TF;
+        const int dr = kTile / TF, dq = kTile - dr * TF;
+        for (int e = threadIdx.x; e < total; e += kTile) {
+            const int tq = qmap[q];
+            const int t = tq >> 16, f = tq & 0xFFFF;
+            dst[e] = t < cnt[r] ? a.points[(int64_t)(beg + lists[r * T + t]) * F + f] : 0.f;
+            r += dr; q += dq;
+            if (q >= TF) { q -= TF; ++r; }
+        }
+    }
+    if (a.mean) {
+        const int nf = a.nf;
+        float *dst = a.mean + row0 * nf;
+        const int total = nown * nf;
+        int r = threadIdx.x / nf, k = threadIdx.x - r * nf;
+        const int dr = kTile / nf, dk = kTile - dr * nf;
+        for (int e = threadIdx.x; e < total; e += kTile) {
+            const int c = cnt[r];
+            const int *L = lists + r * T;
+            float sum = 0.f;
+            for (int t = 0; t < c; ++t) sum = __fadd_rn(sum, a.points[(int64_t)(beg + L[t]) * F + k]);
+            dst[e] = __fdiv_rn(sum, (float)c);          // zero-padded slots add nothing; c >= 1
+            r += dr; k += dk;
+            if (k >= nf) { k -= nf; ++r; }
+        }
+    }
+    for (int e = threadIdx.x; e < nown * 4; e += kTile) {
+        const int r = e >> 2, k = e & 3;
+        const int cell = cellv[r];
+        int v = b;
+        if (k == 1) v = cell / (a.gx * a.gy);
+        else if (k == 2) v = (cell / a.gx) % a.gy;
+        else if (k == 3) v = cell % a.gx;
+        a.coors[row0 * 4 + e] = v;
+    }
+    for (int e = threadIdx.x; e < nown; e += kTile) a.num_points[row0 + e] = cnt[e];
+
+    // ---- rows past the sample's voxel count: marked empty; each tile takes an equal share of them
+    const int tiles = my_tiles > 0 ? my_tiles : 1;
+    const int dead = V - M;
+    const int per = (dead + tiles - 1) / tiles;
+    const int d0 = M + tile * per;
+    const int d1 = (d0 + per) < V ? (d0 + per) : V;
+    if (d0 < d1) {
+        const int64_t r0 = (int64_t)b * V + d0;
+        const int nd = d1 - d0;
+        for (int e = threadIdx.x; e < nd * 4; e += kTile) a.coors[r0 * 4 + e] = -1;
+        for (int e = threadIdx.x; e < nd; e += kTile) a.num_points[r0 + e] = 0;
+        if (a.mean)
+            for (int e = threadIdx.x; e < nd * a.nf; e += kTile) a.mean[r0 * a.nf + e] = 0.f;
     }
 }
 
@@ -301,11 +380,90 @@ __global__ __launch_bounds__(256) void scatter_backward_kernel(int64_t M, int C,
 
 }  // namespace
 
+namespace {
+
+int64_t vox_tiles(int64_t N) { return mmt::ceil_div(N > 0 ? N : 1, kTile); }
+
+int vox_check(const char *what, int B, int64_t N, int F, const int32_t *grid_host, int max_points, int max_voxels, int nf) {
+    if (B <= 0 || B > 65535 || N < 0 || F < 3 || max_points <= 0 || max_voxels <= 0 || nf < 0 || nf > F)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: bad sizes (B=%d N=%lld F=%d T=%d max_voxels=%d nf=%d)", what, B, (long long)N, F, max_points, max_voxels, nf);
+    if (grid_host[0] <= 0 || grid_host[1] <= 0 || grid_host[2] <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive grid", what);
+    const int64_t cells = (int64_t)grid_host[0] * grid_host[1] * grid_host[2];
+    if (cells * B >= (1ll << 31) || cells >= (1ll << 31) || N >= (1ll << kIdxBits))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: B*cells exceeds int32 or N >= 2^24 points", what);
+    if ((size_t)(kTile * (int64_t)max_points + 2 * kTile + (int64_t)max_points * F) * 4 > 150 * 1024 || max_points >= 32768 || F >= 65536)
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: max_points=%d too large for the LDS index lists", what, max_points);
+    return 0;
+}
+
+// the three kernels of one voxelization (table: 8-byte aligned, generation-stamped; scratch: any contents)
+int vox_run(const char *what, int B, int64_t N, int F, const float *points, const int32_t *point_offsets,
+            const float *voxel_size_host, const float *range_min_host, const int32_t *grid_host, int max_points,
+            int max_voxels, int nf, float *voxels, int32_t *coors, int32_t *num_points, int32_t *voxel_count,
+            float *mean, unsigned long long *table, int32_t *scratch, hipStream_t st) {
+    VoxArgs a;
+    a.F = F; a.max_points = max_points; a.max_voxels = max_voxels; a.nf = nf;
+    a.gx = grid_host[0]; a.gy = grid_host[1]; a.gz = grid_host[2];
+    for (int k = 0; k < 3; ++k) { a.vs[k] = voxel_size_host[k]; a.rmin[k] = range_min_host[k]; }
+    a.points = points; a.offsets = point_offsets;
+    a.ntiles = (int)vox_tiles(N);
+    a.table = table;
+    a.cell_of_point = scratch;
+    a.next = a.cell_of_point + N;
+    a.hrank = a.next + N;
+    a.tile_counts = a.hrank + N;
+    a.voxels = voxels; a.coors = coors; a.num_points = num_points; a.voxel_count = voxel_count; a.mean = mean;
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    const unsigned gpts = (unsigned)mmt::stream_grid(N > 0 ? N : 1, kTile, 4096);
+    const unsigned gtiles = (unsigned)(vox_tiles(N) + B);       // flattened (sample, tile) space, see locate_tile
+    seq.launch(false, vox_link, dim3(gpts), dim3(kTile), 0, st, a, B, (int)N);
+    seq.launch(false, vox_heads, dim3(gtiles), dim3(kTile), 0, st, a, B);
+    const size_t lds = (size_t)(kTile * (int64_t)max_points + 2 * kTile + (int64_t)max_points * F) * 4;
+    seq.launch(true, vox_emit, dim3(gtiles), dim3(kTile), lds, st, a, B);
+    return mmt::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int64_t mmt_voxelize_table_elems(int B, const int32_t *grid) {
+    if (B <= 0 || grid == nullptr) return 0;
+    return 4 + 2 * (int64_t)B * grid[0] * grid[1] * grid[2];
+}
+
+extern "C" int64_t mmt_voxelize_scratch_elems(int B, int64_t total_points) {
+    if (B <= 0 || total_points < 0) return 0;
+    return 3 * total_points + (int64_t)B * vox_tiles(total_points) + 16;
+}
+
 extern "C" int64_t mmt_voxelize_workspace_elems(int B, int64_t total_points, const int32_t *grid) {
     if (B <= 0 || total_points < 0 || grid == nullptr) return 0;
-    const int64_t cells = (int64_t)grid[0] * grid[1] * grid[2];
-    const int64_t ntiles = mmt::ceil_div(total_points > 0 ? total_points : 1, kTileThreads) + 1;
-    return 3 * (int64_t)B * cells + 2 * total_points + (int64_t)B * ntiles + 64;
+    return mmt_voxelize_table_elems(B, grid) + mmt_voxelize_scratch_elems(B, total_points) + 2;
+}
+
+extern "C" int mmt_hard_voxelize_mean(int B, int64_t N, int F, const float *points,
+                                      const int32_t *point_offsets, const float *voxel_size_host,
+                                      const float *range_min_host, const int32_t *grid_host,
+                                      int max_points, int max_voxels, int num_features, float *voxels,
+                                      int32_t *coors, int32_t *num_points, int32_t *voxel_count,
+                                      float *mean, int32_t *table, int32_t *scratch, void *stream) {
+    MMT_REQUIRE_PTR(point_offsets);
+    MMT_REQUIRE_PTR(voxel_size_host);
+    MMT_REQUIRE_PTR(range_min_host);
+    MMT_REQUIRE_PTR(grid_host);
+    MMT_REQUIRE_PTR(coors);
+    MMT_REQUIRE_PTR(num_points);
+    MMT_REQUIRE_PTR(voxel_count);
+    MMT_REQUIRE_PTR(table);
+    MMT_REQUIRE_PTR(scratch);
+    if (N > 0) MMT_REQUIRE_PTR(points);
+    int rc = vox_check("hard_voxelize_mean", B, N, F, grid_host, max_points, max_voxels, num_features);
+    if (rc) return rc;
+    if (mean != nullptr && num_features <= 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "hard_voxelize_mean: mean requested with num_features=%d", num_features);
+    if ((uintptr_t)table & 7) return mmt::fail(MMT_ERR_WORKSPACE, "hard_voxelize_mean: table must be 8-byte aligned");
+    return vox_run("hard_voxelize_mean", B, N, F, points, point_offsets, voxel_size_host, range_min_host, grid_host,
+                   max_points, max_voxels, num_features, voxels, coors, num_points, voxel_count, mean,
+                   reinterpret_cast<unsigned long long *>(table), scratch, (hipStream_t)stream);
 }
 
 extern "C" int mmt_hard_voxelize(int B, int64_t N, int F, const float *points,
@@ -324,43 +482,18 @@ extern "C" int mmt_hard_voxelize(int B, int64_t N, int F, const float *points,
     MMT_REQUIRE_PTR(voxel_count);
     MMT_REQUIRE_PTR(workspace);
     if (N > 0) MMT_REQUIRE_PTR(points);
-    if (B <= 0 || B > 65535 || N < 0 || F < 3 || max_points <= 0 || max_voxels <= 0)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "hard_voxelize: bad sizes (B=%d N=%lld F=%d T=%d max_voxels=%d)", B, (long long)N, F, max_points, max_voxels);
-    if (grid_host[0] <= 0 || grid_host[1] <= 0 || grid_host[2] <= 0)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "hard_voxelize: non-positive grid");
-    const int64_t cells = (int64_t)grid_host[0] * grid_host[1] * grid_host[2];
-    if (cells * B >= (1ll << 31) || N >= (1ll << 31))
-        return mmt::fail(MMT_ERR_TOO_LARGE, "hard_voxelize: B*cells or N exceeds int32");
+    int rc = vox_check("hard_voxelize", B, N, F, grid_host, max_points, max_voxels, 0);
+    if (rc) return rc;
+    // stateless form: the table lives in the caller's scratch workspace (any contents), so it is cleared here;
+    // mmt_hard_voxelize_mean with a persistent table skips this memset
+    int32_t *tab = workspace + (((uintptr_t)workspace & 7) ? 1 : 0);
+    const int64_t tab_elems = mmt_voxelize_table_elems(B, grid_host);
     hipStream_t st = (hipStream_t)stream;
-
-    VoxArgs a;
-    a.F = F; a.max_points = max_points; a.max_voxels = max_voxels;
-    a.gx = grid_host[0]; a.gy = grid_host[1]; a.gz = grid_host[2];
-    for (int k = 0; k < 3; ++k) { a.vs[k] = voxel_size_host[k]; a.rmin[k] = range_min_host[k]; }
-    a.points = points; a.offsets = point_offsets;
-    a.ntiles = (int)mmt::ceil_div(N > 0 ? N : 1, kTileThreads) + 1;
-    a.first = workspace;
-    a.head = a.first + B * cells;
-    a.vox_id = a.head + B * cells;
-    a.cell_of_point = a.vox_id + B * cells;
-    a.next = a.cell_of_point + N;
-    a.tile_counts = a.next + N;
-    a.voxels = voxels; a.coors = coors; a.num_points = num_points; a.voxel_count = voxel_count;
-
-    hipError_t e;
-    e = hipMemsetAsync(a.first, 0x7f, sizeof(int32_t) * B * cells, st);
-    if (e == hipSuccess) e = hipMemsetAsync(a.head, 0xff, sizeof(int32_t) * B * cells, st);
-    if (e == hipSuccess) e = hipMemsetAsync(num_points, 0, sizeof(int32_t) * (size_t)B * max_voxels, st);
+    hipError_t e = hipMemsetAsync(tab, 0, sizeof(int32_t) * (size_t)tab_elems, st);
     if (e != hipSuccess) return mmt::fail((int)e, "hard_voxelize: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    static_assert(kFirstInit == 0x7f7f7f7f, "memset pattern");
-
-    const unsigned gpts = (unsigned)mmt::stream_grid(N > 0 ? N : 1, 256, 2048);
-    hipLaunchKernelGGL(vox_claim, dim3(gpts, B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(vox_count, dim3(a.ntiles, B), dim3(kTileThreads), 0, st, a);
-    hipLaunchKernelGGL(vox_number, dim3(a.ntiles, B), dim3(kTileThreads), 0, st, a);
-    hipLaunchKernelGGL(vox_fill, dim3(gpts, B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(vox_pad, dim3((unsigned)mmt::stream_grid(max_voxels, 4, 2048), B), dim3(256), 0, st, a);
-    return mmt::check_launch("hard_voxelize");
+    return vox_run("hard_voxelize", B, N, F, points, point_offsets, voxel_size_host, range_min_host, grid_host,
+                   max_points, max_voxels, 0, voxels, coors, num_points, voxel_count, nullptr,
+                   reinterpret_cast<unsigned long long *>(tab), tab + tab_elems, st);
 }
 
 extern "C" int mmt_compact_voxels(int B, int max_voxels, int row_elems, const int32_t *voxel_count,
@@ -389,8 +522,9 @@ extern "C" int mmt_simple_vfe(int64_t M, int T, int F, int nf, const float *voxe
     MMT_REQUIRE_PTR(out);
     if (M < 0 || T <= 0 || F <= 0 || nf <= 0 || nf > F)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "simple_vfe: bad sizes (M=%lld T=%d F=%d nf=%d)", (long long)M, T, F, nf);
-    hipLaunchKernelGGL(simple_vfe_kernel, dim3(mmt::stream_grid(M * nf, 256)), dim3(256), 0,
-                       (hipStream_t)stream, M, T, F, nf, voxels, num_points, out);
+    mmt::TimedSeq seq;
+    seq.launch(true, simple_vfe_kernel, dim3(mmt::stream_grid(M * nf, 256)), dim3(256), 0,
+               (hipStream_t)stream, M, T, F, nf, voxels, num_points, out);
     return mmt::check_launch("simple_vfe");
 }
 
@@ -422,9 +556,57 @@ __global__ __launch_bounds__(256) void scatter_write_nhwc_kernel(int C4, int64_t
     }
 }
 
+// fill of the cell -> row map (inside the timed kernel sequence, unlike a memset node)
+__global__ __launch_bounds__(256) void fill_i32_kernel(int64_t n, int32_t value, int32_t *dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = value;
+}
+
+// Backward of the channels-last scatter: grad_feats[m,:] = grad_canvas[cell(m),:] for rows that own their cell.
+// One lane group of C/4 lanes per voxel row, kRows rows in flight per group: the coors of the rows are loaded
+// first (one int4 each, clamped index), then their map entries, then the gradient rows through a range-checked
+// buffer descriptor (a row that owns nothing uses an out-of-range offset: zeros, no branch), so the three
+// dependent loads of a row overlap with those of its neighbours instead of forming one serial chain per lane.
+template <int kRows>
 __global__ __launch_bounds__(256) void scatter_backward_nhwc_kernel(int64_t M, int C4, int B, int ny, int nx,
                                                                     const float *grad_canvas, const int32_t *coors,
-                                                                    const int32_t *map, float *grad_feats) {
+                                                                    const int32_t *map, float *grad_feats,
+                                                                    unsigned span_bytes) {
+    const int gpb = 256 / C4;                       // lane groups per workgroup
+    const int grp = threadIdx.x / C4, li = threadIdx.x - grp * C4;
+    if (grp >= gpb) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(grad_canvas), 0, (int)span_bytes, 0x00020000);
+    const int4 *co4 = reinterpret_cast<const int4 *>(coors);
+    const int64_t step = (int64_t)gridDim.x * gpb * kRows;
+    for (int64_t m0 = ((int64_t)blockIdx.x * gpb + grp) * kRows; m0 < M; m0 += step) {
+        int4 co[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) co[u] = co4[(m0 + u) < M ? (m0 + u) : (M - 1)];
+        int64_t cell[kRows];
+        int own[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            const int b = co[u].x, y = co[u].z, x = co[u].w;
+            const bool ok = !(b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx);
+            cell[u] = ok ? ((int64_t)b * ny + y) * nx + x : 0;
+            own[u] = ok ? map[cell[u]] : -1;
+        }
+        mmt_u32x4 v[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            const bool mine = own[u] == (int)(m0 + u) && (m0 + u) < M;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, mine ? (unsigned)((cell[u] * C4 + li) << 4) : 0xFFFFFFF0u, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u)
+            if (m0 + u < M) reinterpret_cast<mmt_u32x4 *>(grad_feats)[(m0 + u) * C4 + li] = v[u];
+    }
+}
+
+// the same for a gradient of 4 GiB or more (beyond a buffer descriptor's range): plain loads
+__global__ __launch_bounds__(256) void scatter_backward_nhwc_big_kernel(int64_t M, int C4, int B, int ny, int nx,
+                                                                        const float *grad_canvas, const int32_t *coors,
+                                                                        const int32_t *map, float *grad_feats) {
     const int64_t total = M * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / C4;
@@ -450,14 +632,14 @@ extern "C" int mmt_pillar_scatter(int64_t M, int C, int B, int ny, int nx, const
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)ny * nx;
     if (HW * B >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "pillar_scatter: B*ny*nx exceeds int32");
-    hipError_t e = hipMemsetAsync(workspace, 0xff, sizeof(int32_t) * B * HW, st);
-    if (e != hipSuccess) return mmt::fail((int)e, "pillar_scatter: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    seq.launch(false, fill_i32_kernel, dim3(mmt::stream_grid(B * HW, 256, 2048)), dim3(256), 0, st, B * HW, (int32_t)-1, workspace);
     if (M > 0)
-        hipLaunchKernelGGL(scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
+        seq.launch(false, scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
     const bool vec4 = (HW % 4 == 0) && (((uintptr_t)canvas & 15) == 0) && (((uintptr_t)workspace & 15) == 0);
     const int64_t work = (int64_t)B * ((C + kChanBlock - 1) / kChanBlock) * (vec4 ? HW / 4 : HW);
-    if (vec4) hipLaunchKernelGGL((scatter_write_kernel<true>), dim3(mmt::stream_grid(work, 256, 256 * 32)), dim3(256), 0, st, C, B, (int)HW, feats, workspace, canvas);
-    else hipLaunchKernelGGL((scatter_write_kernel<false>), dim3(mmt::stream_grid(work, 256, 256 * 32)), dim3(256), 0, st, C, B, (int)HW, feats, workspace, canvas);
+    if (vec4) seq.launch(true, scatter_write_kernel<true>, dim3(mmt::stream_grid(work, 256, 256 * 32)), dim3(256), 0, st, C, B, (int)HW, feats, (const int32_t *)workspace, canvas);
+    else seq.launch(true, scatter_write_kernel<false>, dim3(mmt::stream_grid(work, 256, 256 * 32)), dim3(256), 0, st, C, B, (int)HW, feats, (const int32_t *)workspace, canvas);
     return mmt::check_launch("pillar_scatter");
 }
 
@@ -471,8 +653,9 @@ extern "C" int mmt_pillar_scatter_backward(int64_t M, int C, int B, int ny, int 
     MMT_REQUIRE_PTR(grad_feats);
     if (M < 0 || C <= 0 || B <= 0 || ny <= 0 || nx <= 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_backward: bad sizes");
-    hipLaunchKernelGGL(scatter_backward_kernel, dim3(mmt::stream_grid(M * C, 256)), dim3(256), 0,
-                       (hipStream_t)stream, M, C, B, ny, nx, grad_canvas, coors, workspace, grad_feats);
+    mmt::TimedSeq seq;
+    seq.launch(true, scatter_backward_kernel, dim3(mmt::stream_grid(M * C, 256)), dim3(256), 0,
+               (hipStream_t)stream, M, C, B, ny, nx, grad_canvas, coors, workspace, grad_feats);
     return mmt::check_launch("pillar_scatter_backward");
 }
 
@@ -487,12 +670,12 @@ extern "C" int mmt_pillar_scatter_nhwc(int64_t M, int C, int B, int ny, int nx, 
     hipStream_t st = (hipStream_t)stream;
     const int64_t cells = (int64_t)B * ny * nx;
     if (cells >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "pillar_scatter_nhwc: B*ny*nx exceeds int32");
-    hipError_t e = hipMemsetAsync(workspace, 0xff, sizeof(int32_t) * cells, st);
-    if (e != hipSuccess) return mmt::fail((int)e, "pillar_scatter_nhwc: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    seq.launch(false, fill_i32_kernel, dim3(mmt::stream_grid(cells, 256, 2048)), dim3(256), 0, st, cells, (int32_t)-1, workspace);
     if (M > 0)
-        hipLaunchKernelGGL(scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
-    hipLaunchKernelGGL(scatter_write_nhwc_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / (C / 4))) * 256, 256, 256 * 32)), dim3(256), 0, st,
-                       C / 4, cells, feats, workspace, canvas);
+        seq.launch(false, scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
+    seq.launch(true, scatter_write_nhwc_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / (C / 4))) * 256, 256, 256 * 32)), dim3(256), 0, st,
+               C / 4, cells, feats, (const int32_t *)workspace, canvas);
     return mmt::check_launch("pillar_scatter_nhwc");
 }
 
@@ -504,9 +687,21 @@ extern "C" int mmt_pillar_scatter_nhwc_backward(int64_t M, int C, int B, int ny,
     MMT_REQUIRE_PTR(coors);
     MMT_REQUIRE_PTR(workspace);
     MMT_REQUIRE_PTR(grad_feats);
-    if (M < 0 || C <= 0 || C % 4 || B <= 0 || ny <= 0 || nx <= 0 || ((uintptr_t)grad_canvas & 15) || ((uintptr_t)grad_feats & 15))
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_backward: bad sizes");
-    hipLaunchKernelGGL(scatter_backward_nhwc_kernel, dim3(mmt::stream_grid(M * (C / 4), 256)), dim3(256), 0,
-                       (hipStream_t)stream, M, C / 4, B, ny, nx, grad_canvas, coors, workspace, grad_feats);
+    if (M < 0 || C <= 0 || C % 4 || C > 1024 || B <= 0 || ny <= 0 || nx <= 0 || ((uintptr_t)grad_canvas & 15) || ((uintptr_t)grad_feats & 15) ||
+        ((uintptr_t)coors & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_backward: bad sizes (C %% 4 == 0, C <= 1024, 16-byte aligned buffers)");
+    const int C4 = C / 4;
+    const int64_t span = (int64_t)B * ny * nx * C * 4;
+    mmt::TimedSeq seq;
+    if (span < (1ll << 32) - 16) {
+        constexpr int kRows = 4;
+        const int gpb = 256 / C4;
+        const int grid = mmt::stream_grid(mmt::ceil_div(M, (int64_t)gpb * kRows) * 256, 256, 256 * 16);
+        seq.launch(true, scatter_backward_nhwc_kernel<kRows>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, C4, B, ny, nx,
+                   grad_canvas, coors, workspace, grad_feats, (unsigned)span);
+    } else {
+        seq.launch(true, scatter_backward_nhwc_big_kernel, dim3(mmt::stream_grid(M * C4, 256)), dim3(256), 0,
+                   (hipStream_t)stream, M, C4, B, ny, nx, grad_canvas, coors, workspace, grad_feats);
+    }
     return mmt::check_launch("pillar_scatter_nhwc_backward");
 }

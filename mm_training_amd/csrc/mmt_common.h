@@ -1,6 +1,7 @@
 // Shared host-side helpers for libmmt_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -21,6 +22,21 @@ int check_launch(const char *what);
 void take_timing_events(hipEvent_t *start, hipEvent_t *stop);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// The kernels of ONE C-ABI call as a timed sequence: takes whatever mmt_arm_kernel_timing armed (nothing, normally);
+// the start event rides on the first dispatch made through launch(), the stop event on the one marked `last`
+// (hipExtLaunchKernel start / stop events = the kernels' own duration on the device, no dispatch latency).
+struct TimedSeq {
+    hipEvent_t start = nullptr, stop = nullptr;
+    TimedSeq() { take_timing_events(&start, &stop); }
+    template <typename F, typename... Args>
+    void launch(bool last, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+        hipEvent_t s = start, e = last ? stop : nullptr;
+        start = nullptr;
+        if (s || e) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, s, e, 0, args...);
+        else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, args...);
+    }
+};
 
 // Grid for streaming kernels: enough workgroups to fill 256 CUs several times over,
 // capped so very large problems grid-stride instead of queueing >100k tiny blocks.

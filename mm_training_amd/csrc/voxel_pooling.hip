@@ -1366,9 +1366,10 @@ extern "C" int mmt_lift_splat_forward(int B, int N, int D, int HW, int C, int nx
     hipStream_t st = (hipStream_t)stream;
     a.nchunks = balanced_chunk_points(BP, 512);
     const dim3 grid((unsigned)mmt::ceil_div(BP, a.nchunks)), block(kBlock);
-    if (C == 80) hipLaunchKernelGGL((vp_fwd_seg_gather<20, 512, true>), grid, block, 0, st, a);
-    else if (C == 64) hipLaunchKernelGGL((vp_fwd_seg_gather<16, 512, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((vp_fwd_seg_gather<0, 512, true>), grid, block, 0, st, a);
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    if (C == 80) seq.launch(true, vp_fwd_seg_gather<20, 512, true>, grid, block, 0, st, a);
+    else if (C == 64) seq.launch(true, vp_fwd_seg_gather<16, 512, true>, grid, block, 0, st, a);
+    else seq.launch(true, vp_fwd_seg_gather<0, 512, true>, grid, block, 0, st, a);
     return mmt::check_launch("lift_splat_forward");
 }
 
@@ -1399,7 +1400,8 @@ extern "C" int mmt_lift_splat_backward(int B, int N, int D, int HW, int C, int n
     dim3 grid((unsigned)mmt::ceil_div(HW, NG), (unsigned)(B * N));
     hipStream_t st = (hipStream_t)stream;
     // pos_memo's batch index b is the SAMPLE index; cameras of one sample share it
-#define MMT_LSB(C4T) hipLaunchKernelGGL((lift_splat_backward_kernel<C4T>), grid, dim3(kBlock), lds, st, D, HW, C, pos_memo, depth, context, grad_out, sb, sy, sx, span * 4, grad_depth, grad_context)
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+#define MMT_LSB(C4T) seq.launch(true, lift_splat_backward_kernel<C4T>, grid, dim3(kBlock), lds, st, D, HW, C, pos_memo, depth, context, grad_out, sb, sy, sx, (int64_t)(span * 4), grad_depth, grad_context)
     if (C == 80) MMT_LSB(20);
     else if (C == 64) MMT_LSB(16);
     else MMT_LSB(0);

@@ -85,5 +85,9 @@ def make_config(name="cfg2"):
         # activations for this model (reproduced with the HIP ops of this repo taken out of the
         # picture: the individual ops and the whole fp32 model run clean at the cfg-5 shapes), so the
         # dense nets stay fp32 here; TrainStep(amp="bf16") opts in.  The hot-path ops are fp32 either way.
-        dtype="f32", num_boxes=20)
+        dtype="f32",
+        # storage type of the hot-path operands (depth / context / lifted features and their gradients); accumulation
+        # is fp32 either way.  BASELINE configs[4] names bf16: SURVEY 5.6 defines it as bf16 storage + fp32 accumulate.
+        hot_path_dtype="bf16" if name == "cfg5" else "f32",
+        num_boxes=20)
     return copy.deepcopy(cfg)

@@ -111,11 +111,11 @@ class LSSFPN(nn.Module):
         self.d_bound = d_bound
         self.final_dim = final_dim
         self.output_channels = output_channels
-        # False (default): the reference's op sequence (lift -> voxel_pooling) on the drop-in ops.
-        # True: lift + voxel_pooling run as ONE fused kernel pair (the
-        # [B,N,D,fH,fW,C] tensor of lss_fpn.py:441-463 is never materialised; needs C % 16 == 0).
-        # Same result up to fp32 summation order.
-        self.fused_lift_splat = False
+        # True (default whenever the kernels support the channel count): lift + voxel_pooling run as ONE fused
+        # kernel pair: the [B,N,D,fH,fW,C] tensor of lss_fpn.py:441-463 -- 606 MB
+        # written and read twice per step at cfg2 -- is never materialised.  Same result up to fp32 summation
+        # order.  False: the reference's op sequence (lift -> voxel_pooling) on the drop-in ops.
+        self.fused_lift_splat = output_channels % 16 == 0 and output_channels <= 256
         self._plan_cache = {}     # calibration_id -> VoxelPoolingPlan (see _forward_single_sweep)
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)

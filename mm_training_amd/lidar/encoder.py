@@ -30,14 +30,26 @@ def grid_size(point_cloud_range, voxel_size):
     return [int(x) for x in torch.round((r[3:] - r[:3]) / v).long()]
 
 
-def hard_voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
-                        compact=True):
-    """Batched hard voxelization (one kernel sequence for the whole batch).
+# Persistent per-cell tables of the voxelizer (mmt_hard_voxelize_mean): zero-filled once, then reused by every
+# call -- entries carry a generation stamp, nothing is cleared per step.  One table per (device, stream, size).
+_TABLES = {}
 
-    compact=True returns the reference layout (concatenated, M = sum of per-sample voxel
-    counts; costs ONE device->host copy of B ints).  compact=False returns the
-    fixed-capacity layout [B*max_voxels, ...] plus the per-sample counts, no host sync:
-    unused rows have coors = -1 and num_points = 0."""
+
+def _voxel_table(dev, elems):
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the table belongs to the graph: allocated (and zero-filled) by the graph itself
+        return torch.zeros((int(elems),), dtype=torch.int32, device=dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, int(elems))
+    t = _TABLES.get(key)
+    if t is None:
+        if len(_TABLES) >= 16:
+            _TABLES.pop(next(iter(_TABLES)))
+        t = torch.zeros((int(elems),), dtype=torch.int32, device=dev)
+        _TABLES[key] = t
+    return t
+
+
+def _batch_points(points_list):
     if len(points_list) == 0:
         raise ValueError("empty batch")
     dev = points_list[0].device
@@ -47,14 +59,52 @@ def hard_voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_poin
         if p.dtype != torch.float32 or p.dim() != 2:
             raise RuntimeError("each point cloud must be a float32 [N, F] tensor")
     B = len(points_list)
-    F = points_list[0].shape[1]
     sizes = [int(p.shape[0]) for p in points_list]
     points = torch.cat([p.contiguous() for p in points_list], 0) if B > 1 else points_list[0].contiguous()
     offs = [0]
     for n in sizes:
         offs.append(offs[-1] + n)
     offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
-    N = offs[-1]
+    return points, offsets, offs[-1]
+
+
+def hard_voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
+                             num_features, materialize_voxels=True):
+    """Batched hard voxelization fused with the HardSimpleVFE mean (mmt_hard_voxelize_mean: three kernels,
+    no clearing pass, no host sync).  Fixed-capacity layout: returns (voxels | None, num_points, coors,
+    voxel_count, mean [B*max_voxels, num_features]); unused rows have coors = -1, num_points = 0, mean = 0."""
+    points, offsets, N = _batch_points(points_list)
+    dev = points.device
+    B, F = len(points_list), points.shape[1]
+    grid = grid_size(point_cloud_range, voxel_size)
+    grid_c = _lib.int3(grid)
+    T, V = int(max_num_points), int(max_voxels)
+    voxels = torch.empty((B * V, T, F), dtype=torch.float32, device=dev) if materialize_voxels else None
+    coors = torch.empty((B * V, 4), dtype=torch.int32, device=dev)
+    num_points = torch.empty((B * V,), dtype=torch.int32, device=dev)
+    voxel_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    mean = torch.empty((B * V, int(num_features)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        table = _voxel_table(dev, _lib.lib().mmt_voxelize_table_elems(B, grid_c))
+        scratch = torch.empty((_lib.lib().mmt_voxelize_scratch_elems(B, N),), dtype=torch.int32, device=dev)
+        _lib.timed_call("voxelize", "mmt_hard_voxelize_mean", B, N, F, points.data_ptr(), offsets.data_ptr(),
+                        _lib.float3(voxel_size), _lib.float3(point_cloud_range[:3]), grid_c, T, V, int(num_features),
+                        voxels.data_ptr() if materialize_voxels else 0, coors.data_ptr(), num_points.data_ptr(),
+                        voxel_count.data_ptr(), mean.data_ptr(), table.data_ptr(), scratch.data_ptr(), _stream())
+    return voxels, num_points, coors, voxel_count, mean
+
+
+def hard_voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
+                        compact=True):
+    """Batched hard voxelization (one kernel sequence for the whole batch).
+
+    compact=True returns the reference layout (concatenated, M = sum of per-sample voxel
+    counts; costs ONE device->host copy of B ints).  compact=False returns the
+    fixed-capacity layout [B*max_voxels, ...] plus the per-sample counts, no host sync:
+    unused rows have coors = -1 and num_points = 0."""
+    points, offsets, N = _batch_points(points_list)
+    dev = points.device
+    B, F = len(points_list), points.shape[1]
     grid = grid_size(point_cloud_range, voxel_size)
     grid_c = _lib.int3(grid)
     T = int(max_num_points)
@@ -66,10 +116,10 @@ def hard_voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_poin
     ws_elems = _lib.lib().mmt_voxelize_workspace_elems(B, N, grid_c)
     workspace = torch.empty((ws_elems,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call("mmt_hard_voxelize", B, N, F, points.data_ptr(), offsets.data_ptr(),
-                  _lib.float3(voxel_size), _lib.float3(point_cloud_range[:3]), grid_c, T, V,
-                  voxels.data_ptr(), coors.data_ptr(), num_points.data_ptr(), voxel_count.data_ptr(),
-                  workspace.data_ptr(), _stream())
+        _lib.timed_call("voxelize", "mmt_hard_voxelize", B, N, F, points.data_ptr(), offsets.data_ptr(),
+                        _lib.float3(voxel_size), _lib.float3(point_cloud_range[:3]), grid_c, T, V,
+                        voxels.data_ptr(), coors.data_ptr(), num_points.data_ptr(), voxel_count.data_ptr(),
+                        workspace.data_ptr(), _stream())
     if not compact:
         return voxels, num_points, coors, voxel_count
     counts = voxel_count.cpu()                      # the one host sync of the drop-in path
@@ -96,7 +146,7 @@ def simple_vfe(voxels, num_points, num_features):
     out = torch.empty((M, num_features), dtype=torch.float32, device=voxels.device)
     if M:
         with torch.cuda.device(voxels.device):
-            _lib.call("mmt_simple_vfe", M, T, F, int(num_features), voxels.contiguous().data_ptr(),
+            _lib.timed_call("vfe", "mmt_simple_vfe", M, T, F, int(num_features), voxels.contiguous().data_ptr(),
                       num_points.contiguous().data_ptr(), out.data_ptr(), _stream())
     return out
 
@@ -118,7 +168,7 @@ class _PillarScatter(Function):
             canvas = torch.empty((batch_size, C, ny, nx), dtype=torch.float32, device=feats.device)
         cell_map = torch.empty((batch_size * ny * nx,), dtype=torch.int32, device=feats.device)
         with torch.cuda.device(feats.device):
-            _lib.call("mmt_pillar_scatter_nhwc" if nhwc else "mmt_pillar_scatter", M, C, batch_size, ny, nx,
+            _lib.timed_call("scatter", "mmt_pillar_scatter_nhwc" if nhwc else "mmt_pillar_scatter", M, C, batch_size, ny, nx,
                       feats.data_ptr() if M else 0, coors.data_ptr() if M else 0, canvas.data_ptr(),
                       cell_map.data_ptr(), _stream())
         ctx.save_for_backward(coors, cell_map)
@@ -137,7 +187,7 @@ class _PillarScatter(Function):
             else:
                 grad_canvas = grad_canvas.contiguous()
             with torch.cuda.device(grad_canvas.device):
-                _lib.call("mmt_pillar_scatter_nhwc_backward" if nhwc else "mmt_pillar_scatter_backward", M, C, B, ny, nx,
+                _lib.timed_call("scatter_backward", "mmt_pillar_scatter_nhwc_backward" if nhwc else "mmt_pillar_scatter_backward", M, C, B, ny, nx,
                           grad_canvas.data_ptr(), coors.data_ptr(), cell_map.data_ptr(), grad_feats.data_ptr(), _stream())
         return grad_feats, None, None, None, None, None
 
@@ -200,14 +250,14 @@ class LidarEncoder(nn.Module):
                               channels_last=self.channels_last)
 
     def forward_bev(self, points):
-        """voxelize -> mean -> (MLP) -> scatter with NO host synchronisation: stays in the
-        fixed-capacity layout; empty rows carry coors = -1 and are ignored by the scatter."""
+        """voxelize + mean (ONE fused call, the padded voxel tensor is not materialised) -> (MLP) -> scatter
+        with NO host synchronisation: stays in the fixed-capacity layout; empty rows carry coors = -1 and
+        are ignored by the scatter."""
         with torch.no_grad():
             pts = [p.float() for p in points]
-            voxels, num_points, coors, _ = hard_voxelize_batch(
+            _, _, coors, _, feats = hard_voxelize_mean_batch(
                 pts, self.voxel_size, self.point_cloud_range, self.max_num_points, self.max_voxels,
-                compact=False)
-            feats = simple_vfe(voxels, num_points, self.num_features)
+                self.num_features, materialize_voxels=False)
         if self.pillar_mlp is not None:
             feats = self.pillar_mlp(feats)
         return pillar_scatter(feats, coors, len(points), self.output_shape[0], self.output_shape[1],

@@ -119,7 +119,7 @@ class LiftSplat(Function):
         out = torch.zeros((B, ny, nx, C), dtype=torch.float32, device=depth.device)
         pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
         with torch.cuda.device(depth.device):
-            _lib.call("mmt_lift_splat_forward", B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(),
+            _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward", B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(),
                       depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), pos_memo.data_ptr(),
                       _lib.VP_WRITE_DROPPED, _stream())
         ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
@@ -136,7 +136,7 @@ class LiftSplat(Function):
         grad_depth = torch.empty_like(depth_c)
         grad_ctx = torch.empty_like(ctx_nhwc)
         with torch.cuda.device(depth_c.device):
-            _lib.call("mmt_lift_splat_backward", B, N, D, HW, C, nx, ny, pos_memo.data_ptr(),
+            _lib.timed_call("lift_splat_backward", "mmt_lift_splat_backward", B, N, D, HW, C, nx, ny, pos_memo.data_ptr(),
                       depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
                       grad_depth.data_ptr(), grad_ctx.data_ptr(), _stream())
         return None, grad_depth, grad_ctx.permute(0, 3, 1, 2), None

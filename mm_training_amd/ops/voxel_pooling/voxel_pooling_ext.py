@@ -32,54 +32,20 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# Optional per-launch timing for bench.py's roofline figure: when set to a dict, every kernel launch below
-# carries a pair of HIP events ATTACHED TO ITS DISPATCHES (mmt_arm_kernel_timing -> hipExtLaunchKernel start /
-# stop events: the kernels' own duration on the device, what rocprofv3 --kernel-trace reports; events recorded
-# around the launch would add the dispatch latency), and the (start, end) pairs are appended under
-# "forward" / "backward".  `start.elapsed_time(end)` gives milliseconds after a stream synchronisation.
-TIMING = None
-
-
-class KernelEvent:
-    """A HIP event owned by libmmt_hip (same `elapsed_time` call as torch.cuda.Event)."""
-
-    def __init__(self):
-        import ctypes
-        h = ctypes.c_void_p()
-        _lib.call("mmt_timing_event_create", ctypes.byref(h))
-        self.handle = h.value
-
-    def elapsed_time(self, end):
-        import ctypes
-        ms = ctypes.c_float()
-        _lib.call("mmt_timing_elapsed_ms", self.handle, end.handle, ctypes.byref(ms))
-        return float(ms.value)
-
-    def __del__(self):
-        try:
-            if self.handle:
-                _lib.lib().mmt_timing_event_destroy(self.handle)
-        except Exception:
-            pass
-
-
+# Per-launch timing for bench.py's roofline figures lives in mm_training_amd._lib (TIMING / timed_call):
+# the forward's default SEG_GATHER launch and every backward launch carry dispatch-attached events; the
+# non-default forward algorithms do not take them and are bracketed on the stream instead.
 def _timed_call(kind, *args, dispatch_events=False):
-    if TIMING is None:
+    if _lib.TIMING is None:
         return _lib.call(*args)
     if dispatch_events:
-        start, end = KernelEvent(), KernelEvent()
-        _lib.call("mmt_arm_kernel_timing", start.handle, end.handle)
-        try:
-            _lib.call(*args)
-        finally:
-            _lib.call("mmt_arm_kernel_timing", None, None)      # never leave it armed (the call consumes it anyway)
-    else:   # a launch path that does not take dispatch events: bracket it on the stream
-        start = torch.cuda.Event(enable_timing=True)
-        end = torch.cuda.Event(enable_timing=True)
-        start.record()
-        _lib.call(*args)
-        end.record()
-    TIMING.setdefault(kind, []).append((start, end))
+        return _lib.timed_call(kind, *args)
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    _lib.call(*args)
+    end.record()
+    _lib.TIMING.setdefault(kind, []).append((start, end))
 
 
 def voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, num_voxel_x,

@@ -125,3 +125,55 @@ def test_lidar_chain_replays_from_a_hip_graph(mmt_lib, oracle_mod):
     ref = oracle_mod.pillar_scatter(oracle_mod.simple_vfe(rv, rn, Cf), rc, B, 512, 512)
     assert int(cnt.sum()) == rc.shape[0]
     assert np.allclose(canvas.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_fused_voxelize_mean_replays_with_its_persistent_table(mmt_lib, oracle_mod):
+    """mmt_hard_voxelize_mean keeps its generation counter IN the table and advances it on the device, so a captured
+    graph can be replayed any number of times on the same (never cleared) table."""
+    from mm_training_amd import _lib, synthetic
+    L = _lib
+    dev = torch.device("cuda", 0)
+    rng, vsz = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.2, 0.2, 8.0]
+    B, Npts, F, T, V, nf = 2, 20000, 5, 15, 25000, 5
+    grid = L.int3([512, 512, 1])
+    points = torch.empty(B * Npts, F, device=dev)
+    offsets = torch.tensor([0, Npts, 2 * Npts], dtype=torch.int32, device=dev)
+    coors = torch.empty(B * V, 4, dtype=torch.int32, device=dev)
+    num = torch.empty(B * V, dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    mean = torch.empty(B * V, nf, device=dev)
+    table = torch.zeros(L.lib().mmt_voxelize_table_elems(B, grid), dtype=torch.int32, device=dev)     # zero-filled ONCE
+    scratch = torch.empty(L.lib().mmt_voxelize_scratch_elems(B, B * Npts), dtype=torch.int32, device=dev)
+
+    def launch():
+        st = torch.cuda.current_stream().cuda_stream
+        L.call("mmt_hard_voxelize_mean", B, B * Npts, F, points.data_ptr(), offsets.data_ptr(), L.float3(vsz), L.float3(rng[:3]),
+               grid, T, V, nf, 0, coors.data_ptr(), num.data_ptr(), cnt.data_ptr(), mean.data_ptr(), table.data_ptr(),
+               scratch.data_ptr(), st)
+
+    def fill(seed):
+        fr = [synthetic.lidar_frame(Npts, F, rng, seed=seed + i) for i in range(B)]
+        points.copy_(torch.cat(fr, 0))
+        return fr
+
+    fill(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch()
+    for seed in (7, 3, 7):
+        frames = fill(seed)
+        graph.replay()
+        torch.cuda.synchronize()
+        rv, rn, rc = oracle_mod.voxelize_batch([f.numpy() for f in frames], vsz, rng, T, V)
+        live = (coors[:, 0] >= 0).cpu().numpy()
+        assert int(cnt.sum()) == rc.shape[0] == int(live.sum())
+        assert np.array_equal(coors.cpu().numpy()[live], rc) and np.array_equal(num.cpu().numpy()[live], rn)
+        assert np.array_equal(mean.cpu().numpy()[live], oracle_mod.simple_vfe(rv, rn, nf))
+    # the generation counter advanced once per call: eager warm-up + capture (not executed) + 3 replays = 4
+    assert int(table[:2].view(torch.int64).item()) == 4

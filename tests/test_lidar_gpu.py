@@ -49,6 +49,25 @@ def _check(oracle_mod, frames, max_points, max_voxels, vsize=VSIZE, rng=RANGE):
         assert (c2[b * max_voxels + k:(b + 1) * max_voxels] == -1).all()
         assert (n2[b * max_voxels + k:(b + 1) * max_voxels] == 0).all()
         off += k
+    # fused voxelize + mean (mmt_hard_voxelize_mean): persistent generation-stamped table, no clearing pass;
+    # the second round runs on a table that still holds the first round's entries
+    from mm_training_amd.lidar import hard_voxelize_mean_batch
+    for materialize in (True, False, True):
+        v3, n3, c3, cnt3, m3 = hard_voxelize_mean_batch(dev, vsize, rng, max_points, max_voxels, nf, materialize_voxels=materialize)
+        assert np.array_equal(cnt3.cpu().numpy(), cnt)
+        assert (v3 is None) == (not materialize)
+        off = 0
+        for b in range(len(frames)):
+            k = int(cnt[b])
+            lo = b * max_voxels
+            assert np.array_equal(c3[lo:lo + k].cpu().numpy(), rc[off:off + k]) and (c3[lo + k:lo + max_voxels] == -1).all()
+            assert np.array_equal(n3[lo:lo + k].cpu().numpy(), rn[off:off + k]) and (n3[lo + k:lo + max_voxels] == 0).all()
+            if materialize:
+                assert np.array_equal(v3[lo:lo + k].cpu().numpy().view(np.int32), rv[off:off + k].view(np.int32))
+            # same fp32 sum in slot order and the same division as the oracle: exact
+            assert np.allclose(m3[lo:lo + k].cpu().numpy(), rm[off:off + k], rtol=0, atol=0, equal_nan=True), "fused mean"
+            assert float(m3[lo + k:lo + max_voxels].abs().sum()) == 0.0
+            off += k
     return rv, rn, rc
 
 
@@ -85,6 +104,25 @@ def test_voxelize_boundaries_and_nonfinite(mmt_lib, oracle_mod):
     pts[22, 2] = float("-inf")
     pts[23:, :3] = torch.rand(41, 3) * 10
     _check(oracle_mod, [pts], 15, 100)
+
+
+def test_voxelize_table_survives_other_clouds(mmt_lib, oracle_mod):
+    """The per-cell table is never cleared: alternating clouds (one of them much denser) on the same table must
+    each give their own result every time (entries of earlier calls read as empty)."""
+    from mm_training_amd.lidar import hard_voxelize_mean_batch
+    a = [f.cuda() for f in _frames([20000, 18000], seed=31)]
+    b = [f.cuda() for f in _frames([40000, 40000], seed=32, dense=True)]
+    ref = {}
+    for name, cloud in (("a", a), ("b", b)):
+        rv, rn, rc = oracle_mod.voxelize_batch([f.cpu().numpy() for f in cloud], VSIZE, RANGE, 15, 25000)
+        ref[name] = (rn, rc, oracle_mod.simple_vfe(rv, rn, 5))
+    for name, cloud in (("a", a), ("b", b), ("a", a), ("a", a), ("b", b)):
+        _, n, c, cnt, m = hard_voxelize_mean_batch(cloud, VSIZE, RANGE, 15, 25000, 5, materialize_voxels=False)
+        live = (c[:, 0] >= 0).cpu().numpy()
+        rn, rc, rm = ref[name]
+        assert int(cnt.sum()) == rc.shape[0] == int(live.sum())
+        assert np.array_equal(c.cpu().numpy()[live], rc) and np.array_equal(n.cpu().numpy()[live], rn)
+        assert np.array_equal(m.cpu().numpy()[live], rm)
 
 
 def test_voxelize_3d_grid(mmt_lib, oracle_mod):

@@ -18,9 +18,14 @@ def test_lssfpn_signature_and_hot_path(mmt_lib, oracle_mod):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     m = LSSFPN(**cfg["backbone_conf"]).to(dev).eval()
+    assert m.fused_lift_splat            # the default path (fused lift-splat, row f1) is the one checked against the oracle
     imgs, mats, pcs, boxes, labels = synthetic_batch(cfg, dev)
     with torch.no_grad():
         bev, depth = m(imgs[:, :, :, :3] / 255.0, mats, None, None, is_return_depth=True)
+        m.fused_lift_splat = False
+        bev_unfused = m(imgs[:, :, :, :3] / 255.0, mats, None, None, is_return_depth=False)
+        m.fused_lift_splat = True
+    assert (bev - bev_unfused).abs().max().item() <= 1e-4
     B, N = imgs.shape[0], imgs.shape[2]
     D, fH, fW = m.frustum.shape[:3]
     C = cfg["backbone_conf"]["output_channels"]
@@ -81,6 +86,8 @@ def test_lssfpn_cached_plan_matches_uncached(mmt_lib):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     m = LSSFPN(**cfg["backbone_conf"]).to(dev).train()
+    assert m.fused_lift_splat            # default: the fused kernels; the cached plan belongs to the unfused op sequence
+    m.fused_lift_splat = False
     imgs, mats, *_ = synthetic_batch(cfg, dev)
     x = imgs[:, :, :, :3] / 255.0
 

@@ -128,7 +128,7 @@ def test_backward_gradient_as_channel_slice_of_a_wider_buffer(mmt_lib, oracle_mo
 
 
 def test_dispatch_attached_kernel_timing(mmt_lib):
-    """bench.py's live roofline figure: with voxel_pooling_ext.TIMING set, forward and backward carry HIP events
+    """bench.py's live roofline figure: with mm_training_amd._lib.TIMING set, forward and backward carry HIP events
     attached to their kernel dispatches (mmt_arm_kernel_timing); results are unchanged, every pair yields a
     positive duration, and nothing stays armed afterwards."""
     from mm_training_amd.ops.voxel_pooling import voxel_pooling, voxel_pooling_ext
@@ -140,7 +140,7 @@ def test_dispatch_attached_kernel_timing(mmt_lib):
     f0 = feats.clone().requires_grad_(True)
     ref = voxel_pooling(geom, f0, [nx, ny, 1])
     ref.backward(go)
-    voxel_pooling_ext.TIMING = {}
+    mmt_lib.TIMING = {}
     try:
         for grad in (go, go.contiguous(memory_format=torch.channels_last)):      # with and without the layout pass
             f1 = feats.clone().requires_grad_(True)
@@ -150,9 +150,9 @@ def test_dispatch_attached_kernel_timing(mmt_lib):
         # a non-default algorithm is timed by events recorded around the launch instead
         _run_ext(mmt_lib, geom, feats, nx, ny, 1, 1)
         torch.cuda.synchronize()
-        timing = voxel_pooling_ext.TIMING
+        timing = mmt_lib.TIMING
     finally:
-        voxel_pooling_ext.TIMING = None
+        mmt_lib.TIMING = None
     assert len(timing["forward"]) == 3 and len(timing["backward"]) == 2
     for s_, e_ in timing["forward"] + timing["backward"]:
         ms = s_.elapsed_time(e_)

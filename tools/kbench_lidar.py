@@ -4,8 +4,8 @@ lift / geometry timings with HIP events + algorithmic GB/s (SURVEY.md section 8d
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from mm_training_amd import synthetic
-from mm_training_amd.lidar import hard_voxelize_batch, simple_vfe, pillar_scatter
+from mm_training_amd import _lib, synthetic
+from mm_training_amd.lidar import hard_voxelize_batch, hard_voxelize_mean_batch, simple_vfe, pillar_scatter
 from mm_training_amd.ops.bev_geometry import frustum_geometry, lift_features, quantize_geometry
 
 
@@ -21,6 +21,25 @@ def timeit(fn, reps=20, warm=3):
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     return ts[len(ts) // 2]
+
+
+def timeit_dispatch(fn, kinds, reps=20, warm=3):
+    """Median kernel-side duration (ms) of the timed entry points `kinds` inside fn: HIP events attached to the
+    dispatches (mmt_arm_kernel_timing), i.e. what rocprofv3 --kernel-trace reports, summed over the kinds."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    _lib.TIMING = {}
+    try:
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        t = _lib.TIMING
+    finally:
+        _lib.TIMING = None
+    per_rep = [sum(t[k][i][0].elapsed_time(t[k][i][1]) for k in kinds) for i in range(reps)]
+    per_rep.sort()
+    return per_rep[len(per_rep) // 2]
 
 
 def main():
@@ -40,6 +59,16 @@ def main():
     M = int(cnt.sum())
     vox_bytes = 4 * F * B * N + 16 * M + 4 * M + 4 * 15 * F * M
     res["voxelize_fixed_capacity"] = {"ms": ms, "voxels": M, "algorithmic_MB": vox_bytes / 1e6, "GBps": vox_bytes / ms / 1e6}
+    # fused voxelize + mean on the persistent generation-stamped table (three kernels, no clearing pass): what
+    # LidarEncoder.forward_bev runs.  Kernel-side durations (dispatch-attached events).
+    for tag, mat in (("voxelize_mean_fused_materialized", True), ("voxelize_mean_fused", False)):
+        kms = timeit_dispatch(lambda: hard_voxelize_mean_batch(frames, vs, rng, 15, 25000, 5, materialize_voxels=mat), ("voxelize",))
+        wms = timeit(lambda: hard_voxelize_mean_batch(frames, vs, rng, 15, 25000, 5, materialize_voxels=mat))
+        bts = 4 * F * B * N + 20 * M + 4 * 5 * M + (4 * 15 * F * M if mat else 0)
+        res[tag] = {"kernel_ms": kms, "stream_ms_with_launch_overheads": wms, "algorithmic_MB": bts / 1e6, "GBps": bts / kms / 1e6,
+                    "frac_of_peak": bts / kms / 1e6 / 8000.0}
+    kms = timeit_dispatch(lambda: hard_voxelize_batch(frames, vs, rng, 15, 25000, compact=False), ("voxelize",))
+    res["voxelize_fixed_capacity"]["kernel_ms_without_table_memset"] = kms
     ms = timeit(lambda: hard_voxelize_batch(frames, vs, rng, 15, 25000, compact=True))
     res["voxelize_compact_with_host_sync"] = {"ms": ms}
     v, n, c = hard_voxelize_batch(frames, vs, rng, 15, 25000, compact=True)
@@ -54,7 +83,8 @@ def main():
     res["pillar_scatter"] = {"ms": ms, "canvas": [B, C, ny, nx], "algorithmic_MB": sb / 1e6, "GBps": sb / ms / 1e6}
     # channels-last canvas (what the channels_last BEV trunk consumes) and the two backward variants
     ms_cl = timeit(lambda: pillar_scatter(feats, c, B, ny, nx, channels_last=True))
-    res["pillar_scatter_channels_last"] = {"ms": ms_cl, "GBps": sb / ms_cl / 1e6}
+    kms_cl = timeit_dispatch(lambda: pillar_scatter(feats, c, B, ny, nx, channels_last=True), ("scatter",))
+    res["pillar_scatter_channels_last"] = {"ms": ms_cl, "kernel_ms": kms_cl, "GBps": sb / kms_cl / 1e6, "frac_of_peak": sb / kms_cl / 1e6 / 8000.0}
     for tag, cl in (("nchw", False), ("channels_last", True)):
         fr = feats.detach().clone().requires_grad_(True)
         cv = pillar_scatter(fr, c, B, ny, nx, channels_last=cl)
@@ -62,8 +92,10 @@ def main():
         if cl:
             go = go.contiguous(memory_format=torch.channels_last)
         ms_b = timeit(lambda: torch.autograd.grad(cv, fr, go, retain_graph=True))
+        kms_b = timeit_dispatch(lambda: torch.autograd.grad(cv, fr, go, retain_graph=True), ("scatter_backward",))
         bb = 4 * C * feats.shape[0] * 2 + 16 * feats.shape[0]        # gradient rows read + written, coors
-        res["pillar_scatter_backward_" + tag] = {"ms": ms_b, "algorithmic_MB": bb / 1e6, "GBps": bb / ms_b / 1e6}
+        res["pillar_scatter_backward_" + tag] = {"ms": ms_b, "kernel_ms": kms_b, "algorithmic_MB": bb / 1e6, "GBps": bb / kms_b / 1e6,
+                                                 "frac_of_peak": bb / kms_b / 1e6 / 8000.0}
     # camera-side producers at cfg2
     s2e, K = synthetic.camera_rig(4, 6, 704, 256, jitter=0.02)
     combine = (s2e @ torch.inverse(K)).cuda()
