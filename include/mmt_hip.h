@@ -85,8 +85,8 @@ int mmt_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
 #define MMT_VP_ALGO_STREAM 4      /* chunk sorted by cell, balanced stream over the sorted list, LDS row buffer */
 #define MMT_VP_ALGO_MASK 0xF
 #define MMT_VP_CHUNK_1024 0x20    /* SEG_GATHER: 1024 points per workgroup instead of 512 */
-#define MMT_VP_WAVE_PER_SLOT 0x40 /* SEG_GATHER: previous gather schedule (one cell per wave instead of one
-                                     per lane group), kept for A/B measurements */
+#define MMT_VP_WAVE_PER_SLOT 0x40 /* (ABI <= 3: the previous gather schedule, kept for A/B measurements.)  Removed in
+                                     ABI 4: the bit is accepted and ignored */
 #define MMT_VP_WRITE_DROPPED 0x10 /* also write (-1,-1,-1) to pos_memo rows of dropped points,
                                      so the caller need not pre-fill pos_memo */
 #define MMT_VP_CHUNK_POINTS(n) ((((n) / 4) & 0xFF) << 8) /* SEG_GATHER: points per workgroup (multiple of 4,
@@ -233,6 +233,42 @@ int mmt_dcn_im2col(int B, int H, int W, int C, int groups, const float *x, const
                    float *col, void *stream);
 int mmt_dcn_col2im(int B, int H, int W, int C, int groups, const float *x, const float *offset,
                    const float *grad_col, float *grad_x, float *grad_offset, void *stream);
+
+/* ------------------------------------------------- bf16 feature storage
+ * BASELINE configs[4] names bf16.  The reference has no behaviour for it -- its extension takes data_ptr<float>()
+ * only (ops/voxel_pooling/src/voxel_pooling_forward.cpp:28-31; exps/conf_aim.py:30 "16 does not work yet") -- so
+ * SURVEY 5.6 defines it: bf16 STORAGE of the big operands, fp32 accumulation, parity against the fp32 oracle on the
+ * up-cast inputs.  uint16_t = raw bf16 bits.  Same argument meaning, ownership and flags as the fp32 entry points:
+ *   mmt_voxel_pooling_forward_bf16   input_features bf16 [B*P,C] (C % 8 == 0, C <= 512), output_features fp32
+ *                                    (accumulated into); flags: MMT_VP_WRITE_DROPPED / MMT_VP_CHUNK_POINTS only
+ *   mmt_voxel_pooling_backward_bf16  grad_output fp32 (any strides), grad_input bf16 [B*P,C]: the gathered fp32 row
+ *                                    rounded to nearest even (exact: the backward is a copy)
+ *   mmt_lift_features_bf16           depth / context fp32 (they come from the fp32 dense nets) -> feats bf16
+ *                                    [BN,D,HW,C] = bf16(depth * context); _backward_bf16: grad_feats bf16 ->
+ *                                    grad_depth / grad_context fp32 (fp32 sums)
+ *   mmt_lift_splat_forward_bf16      depth bf16 [B*N,D,HW], context bf16 [B*N,HW,C] -> BEV fp32 (products and sums
+ *                                    fp32); _backward_bf16: grad_out fp32 -> grad_depth / grad_context bf16 */
+int mmt_voxel_pooling_forward_bf16(int batch_size, int num_points, int num_channels, int num_voxel_x,
+                                   int num_voxel_y, int num_voxel_z, const int32_t *geom_xyz,
+                                   const uint16_t *input_features, float *output_features, int32_t *pos_memo,
+                                   int flags, void *stream);
+int mmt_voxel_pooling_backward_bf16(int batch_size, int num_points, int num_channels, int num_voxel_x,
+                                    int num_voxel_y, const int32_t *pos_memo, const float *grad_output,
+                                    int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                                    uint16_t *grad_input, float *workspace, int64_t workspace_elems, void *stream);
+int mmt_lift_features_bf16(int BN, int D, int HW, int C, const float *depth, const float *context,
+                           uint16_t *feats, void *stream);
+int mmt_lift_features_backward_bf16(int BN, int D, int HW, int C, const float *depth, const float *context,
+                                    const uint16_t *grad_feats, float *grad_depth, float *grad_context,
+                                    void *stream);
+int mmt_lift_splat_forward_bf16(int B, int N, int D, int HW, int C, int num_voxel_x, int num_voxel_y,
+                                int num_voxel_z, const int32_t *geom_xyz, const uint16_t *depth,
+                                const uint16_t *context, float *output_features, int32_t *pos_memo, int flags,
+                                void *stream);
+int mmt_lift_splat_backward_bf16(int B, int N, int D, int HW, int C, int num_voxel_x, int num_voxel_y,
+                                 const int32_t *pos_memo, const uint16_t *depth, const uint16_t *context,
+                                 const float *grad_output, int64_t stride_b, int64_t stride_c, int64_t stride_y,
+                                 int64_t stride_x, uint16_t *grad_depth, uint16_t *grad_context, void *stream);
 
 /* ------------------------------------------------------------------- LiDAR half */
 

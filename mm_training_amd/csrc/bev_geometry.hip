@@ -123,6 +123,47 @@ __global__ __launch_bounds__(kBlock) void lift_kernel(int D, int HW, int C, cons
     }
 }
 
+// bf16 storage of the lifted features: same tiling, the product is rounded once to bf16 (nearest even) and a lane
+// emits 8 channels = one 16-byte vector.  C % 8 == 0.
+template <int C8T>
+__global__ __launch_bounds__(kBlock) void lift_kernel_bf16(int D, int HW, int C, const float *depth,
+                                                           const float *context, bf16_t *feats) {
+    extern __shared__ __align__(16) float lds[];
+    const int CP = C + 4;
+    float *ctx = lds;                 // [kTile][CP]
+    float *dep = lds + kTile * CP;    // [kDRange][kTile]
+    const int bn = blockIdx.z;
+    const int s0 = blockIdx.x * kTile;
+    const int d0 = blockIdx.y * kDRange;
+    const int ns = (HW - s0) < kTile ? (HW - s0) : kTile;
+    const int nd = (D - d0) < kDRange ? (D - d0) : kDRange;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C * kTile; i += kBlock) {
+        const int c = i / kTile, j = i - c * kTile;
+        if (j < ns) ctx[j * CP + c] = context[((int64_t)bn * C + c) * HW + s0 + j];
+    }
+    for (int i = tid; i < nd * kTile; i += kBlock) {
+        const int dd = i / kTile, j = i - dd * kTile;
+        if (j < ns) dep[i] = depth[((int64_t)bn * D + d0 + dd) * HW + s0 + j];
+    }
+    __syncthreads();
+    const int C8 = C8T > 0 ? C8T : C >> 3;
+    const int nvec = ns * C8;
+    for (int dd = 0; dd < nd; ++dd) {
+        mmt_u32x4 *dst = reinterpret_cast<mmt_u32x4 *>(feats + (((int64_t)bn * D + d0 + dd) * HW + s0) * C);
+        for (int i = tid; i < nvec; i += kBlock) {
+            const int j = i / C8, c8 = i - j * C8;
+            const float dv = dep[dd * kTile + j];
+            const float4 a = *reinterpret_cast<const float4 *>(ctx + j * CP + c8 * 8);
+            const float4 b = *reinterpret_cast<const float4 *>(ctx + j * CP + c8 * 8 + 4);
+            mmt_u32x4 r;
+            r.x = pack_bf16x2(dv * a.x, dv * a.y); r.y = pack_bf16x2(dv * a.z, dv * a.w);
+            r.z = pack_bf16x2(dv * b.x, dv * b.y); r.w = pack_bf16x2(dv * b.z, dv * b.w);
+            __builtin_nontemporal_store(r, dst + i);
+        }
+    }
+}
+
 // Lift backward.  grad_depth[bn,d,s] = sum_c g[bn,d,s,c]*ctx[bn,c,s];
 //                 grad_context[bn,c,s] = sum_d g[bn,d,s,c]*depth[bn,d,s].
 // Workgroup = (camera, tile of NG consecutive positions) and walks ALL depth bins, so
@@ -132,9 +173,10 @@ __global__ __launch_bounds__(kBlock) void lift_kernel(int D, int HW, int C, cons
 // together NG*C*4 contiguous bytes), keeps its grad_context float4 in registers over the
 // whole depth loop (4 rows in flight), and reduces the row's dot product with ctx across
 // its lanes by two DPP quad adds + one LDS float add per quad.
-template <int C4T>
+// GT = float, or bf16_t for a bf16-stored gradient (a lane then reads its 4 channels as one 8-byte vector).
+template <typename GT, int C4T>
 __global__ __launch_bounds__(kBlock) void lift_backward_vec4(int D, int HW, int C, const float *depth,
-                                                             const float *context, const float *g,
+                                                             const float *context, const GT *g,
                                                              float *grad_depth, float *grad_context) {
     extern __shared__ __align__(16) float lds[];
     const int C4 = C4T > 0 ? C4T : C >> 2;
@@ -162,14 +204,21 @@ __global__ __launch_bounds__(kBlock) void lift_backward_vec4(int D, int HW, int 
     __syncthreads();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *src = g + (((int64_t)bn * D) * HW + s0 + j) * C + li * 4;
+    const GT *src = g + (((int64_t)bn * D) * HW + s0 + j) * C + li * 4;
     const int64_t dstride = (int64_t)HW * C;
     for (int d0 = 0; d0 < D; d0 += 4) {
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active && d0 + u < D) v[u] = *reinterpret_cast<const float4 *>(src + (d0 + u) * dstride);
+            if (active && d0 + u < D) {
+                if constexpr (sizeof(GT) == 2) {
+                    const uint2 r = *reinterpret_cast<const uint2 *>(src + (d0 + u) * dstride);
+                    v[u] = make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+                } else {
+                    v[u] = *reinterpret_cast<const float4 *>(src + (d0 + u) * dstride);
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -324,9 +373,9 @@ extern "C" int mmt_lift_features_backward(int BN, int D, int HW, int C, const fl
         const size_t lds = (size_t)2 * D * NG * 4;
         if (lds <= 64 * 1024) {
             dim3 grid((unsigned)mmt::ceil_div(HW, NG), (unsigned)BN);
-            if (C == 80) hipLaunchKernelGGL((lift_backward_vec4<20>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
-            else if (C == 64) hipLaunchKernelGGL((lift_backward_vec4<16>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
-            else hipLaunchKernelGGL((lift_backward_vec4<0>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+            if (C == 80) hipLaunchKernelGGL((lift_backward_vec4<float, 20>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+            else if (C == 64) hipLaunchKernelGGL((lift_backward_vec4<float, 16>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+            else hipLaunchKernelGGL((lift_backward_vec4<float, 0>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
             return mmt::check_launch("lift_features_backward(vec4)");
         }
     }
@@ -336,4 +385,47 @@ extern "C" int mmt_lift_features_backward(int BN, int D, int HW, int C, const fl
     hipLaunchKernelGGL(lift_backward_kernel, grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C,
                        depth, context, grad_feats, grad_depth, grad_context);
     return mmt::check_launch("lift_features_backward");
+}
+
+// ---- bf16 storage of the lifted feature matrix: depth / context and their gradients stay fp32 (they come
+// from and go back to the fp32 dense nets), feats [BN, D, HW, C] and its gradient are bf16.  C % 16 == 0, C <= 256.
+extern "C" int mmt_lift_features_bf16(int BN, int D, int HW, int C, const float *depth,
+                                      const float *context, uint16_t *feats, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(feats);
+    if (BN <= 0 || D <= 0 || HW <= 0 || C <= 0 || BN > 65535)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_features_bf16: bad sizes");
+    if (C % 8 != 0 || (((uintptr_t)feats & 15) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_features_bf16: needs C %% 8 == 0 and 16-byte aligned feats");
+    const size_t lds = ((size_t)kTile * (C + 4) + (size_t)kDRange * kTile) * 4;
+    if (lds > 160 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_features_bf16: C=%d too large for the LDS tile", C);
+    dim3 grid((unsigned)mmt::ceil_div(HW, kTile), (unsigned)mmt::ceil_div(D, kDRange), (unsigned)BN);
+    if (C == 80) hipLaunchKernelGGL((lift_kernel_bf16<10>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    else if (C == 64) hipLaunchKernelGGL((lift_kernel_bf16<8>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    else hipLaunchKernelGGL((lift_kernel_bf16<0>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, feats);
+    return mmt::check_launch("lift_features_bf16");
+}
+
+extern "C" int mmt_lift_features_backward_bf16(int BN, int D, int HW, int C, const float *depth,
+                                               const float *context, const uint16_t *grad_feats,
+                                               float *grad_depth, float *grad_context, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_feats);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    if (BN <= 0 || D <= 0 || HW <= 0 || C <= 0 || BN > 65535)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_features_backward_bf16: bad sizes");
+    if (C % 16 != 0 || C > 256 || (((uintptr_t)grad_feats & 7) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_features_backward_bf16: needs C %% 16 == 0, C <= 256, 8-byte aligned grad_feats");
+    const int C4 = C / 4;
+    const int NG = (kBlock / 64) * (64 / C4);
+    const size_t lds = (size_t)2 * D * NG * 4;
+    if (lds > 64 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_features_backward_bf16: D too large for the LDS tile");
+    dim3 grid((unsigned)mmt::ceil_div(HW, NG), (unsigned)BN);
+    if (C == 80) hipLaunchKernelGGL((lift_backward_vec4<bf16_t, 20>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+    else if (C == 64) hipLaunchKernelGGL((lift_backward_vec4<bf16_t, 16>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+    else hipLaunchKernelGGL((lift_backward_vec4<bf16_t, 0>), grid, dim3(kBlock), lds, (hipStream_t)stream, D, HW, C, depth, context, grad_feats, grad_depth, grad_context);
+    return mmt::check_launch("lift_features_backward_bf16");
 }

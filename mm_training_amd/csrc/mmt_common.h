@@ -57,6 +57,20 @@ __device__ __forceinline__ void mmt_nt_store4(float4 v, float4 *p) {
     __builtin_nontemporal_store(t, reinterpret_cast<mmt_f32x4 *>(p));
 }
 
+// bf16 storage (SURVEY 5.6 / BASELINE configs[4]: bf16 STORAGE, fp32 accumulate): raw bits + conversions
+typedef unsigned short bf16_t;
+// fp32 pair -> two bf16 in one dword (low half = first), round to nearest even, NaN stays NaN (the plain cast:
+// v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __bf16 mmt_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float mmt_f32x2 __attribute__((ext_vector_type(2)));
+    const mmt_f32x2 f = {lo, hi};
+    const mmt_bf16x2 h = __builtin_convertvector(f, mmt_bf16x2);
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float bf16_lo(unsigned pair) { return __uint_as_float(pair << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned pair) { return __uint_as_float(pair & 0xFFFF0000u); }
+
 #define MMT_REQUIRE_PTR(p)                                                        \
     do {                                                                          \
         if ((p) == nullptr) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: %s is NULL", __func__, #p); \

@@ -29,15 +29,15 @@ struct VpArgs {
     int64_t BP;  // B*P
     int P, C, nx, ny, nz;
     const int32_t *geom;
-    const float *feats;
+    const void *feats;     // fp32 or bf16 rows (the kernel's FT template argument says which)
     float *out;
     int32_t *pos_memo;
     int write_dropped;
     int nslot;    // LDS BEV rows per workgroup
     int nchunks;
     // fused lift-splat (feats == nullptr): row(t) = depth[t] * context[pix(t), :]
-    const float *depth;    // [B*P] in point order (= [B*N, D, HW])
-    const float *context;  // [B*N, HW, C] channels-last
+    const void *depth;     // [B*P] in point order (= [B*N, D, HW]), fp32 or bf16
+    const void *context;   // [B*N, HW, C] channels-last, fp32 or bf16
     int DHW, HW;           // D*HW points per camera, HW pixels per camera
 };
 
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_row_atomic(VpArgs a) {
         }
         if (!kept) continue;
         float *o = a.out + (((int64_t)b * a.ny + y) * a.nx + x) * a.C + cv * VEC;
-        const float *f = a.feats + t * a.C + cv * VEC;
+        const float *f = static_cast<const float *>(a.feats) + t * a.C + cv * VEC;
         if (VEC == 4) {
             const float4 v = *reinterpret_cast<const float4 *>(f);
             atomicAdd(o, v.x);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
         // ---- B: stream pass
         const int nvec = npts * CV;
         if (VEC == 4) {
-            const float4 *src = reinterpret_cast<const float4 *>(a.feats + base * C);
+            const float4 *src = reinterpret_cast<const float4 *>(static_cast<const float *>(a.feats) + base * C);
             constexpr int U = 4;
             for (int i0 = tid; i0 < nvec; i0 += kBlock * U) {
                 float4 v[U];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
                 }
             }
         } else {
-            const float *src = a.feats + base * C;
+            const float *src = static_cast<const float *>(a.feats) + base * C;
             for (int i = tid; i < nvec; i += kBlock) {
                 const int row = i / C;
                 const int c = i - row * C;
@@ -240,6 +240,35 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
 
 
 // ---------------------------------------------------------------------------
+// Feature storage types.  A lane owns one 16-byte vector of a feature row: 4 fp32 channels or 8 bf16 channels
+// (SURVEY 5.6 / BASELINE configs[4]: bf16 STORAGE, fp32 accumulate -- every sum below is fp32 either way).
+
+// A gathered row vector stays in its 16-byte load form (Raw) until it is added (bf16: still packed, so 8 rows in flight
+// cost 32 registers, not 64).
+template <typename FT> struct RowVec;
+template <> struct RowVec<float> {
+    static constexpr int VEC = 4;
+    typedef float4 Raw;
+    __device__ __forceinline__ static Raw zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ static Raw load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    __device__ __forceinline__ static void unpack(const Raw &r, float (&o)[4]) { o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+    __device__ __forceinline__ static float scalar(const float *p) { return *p; }
+};
+template <> struct RowVec<bf16_t> {
+    static constexpr int VEC = 8;
+    typedef uint4 Raw;
+    __device__ __forceinline__ static Raw zero() { return make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ static Raw load(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+    __device__ __forceinline__ static void unpack(const Raw &r, float (&o)[8]) {
+        o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xFFFF0000u);
+        o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xFFFF0000u);
+        o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xFFFF0000u);
+        o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xFFFF0000u);
+    }
+    __device__ __forceinline__ static float scalar(const bf16_t *p) { return __uint_as_float((unsigned)*p << 16); }
+};
+
+// ---------------------------------------------------------------------------
 // ALGO_AUTO: chunk-local sort by BEV cell + register accumulation.
 //
 // A workgroup owns one chunk of CHUNK consecutive points.
@@ -247,17 +276,20 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_lds_combine(VpArgs a) {
 //     (b*ny+y)*nx+x into an LDS hash table (the inserting lane numbers the cell:
 //     "slot"), count points per slot, wave-scan the counts, and scatter the local
 //     point ids into a per-slot list (a counting sort of the chunk by cell).
-//  B. gather pass: each wave takes one slot at a time; the wave is split into
-//     G = 64 / (C/4) lane groups, each lane owning one float4 column of the feature
-//     row.  Group g walks every G-th point of the slot's list, loads whole rows
-//     (C*4 contiguous, 64-byte aligned bytes; rows of dropped points are never
-//     fetched) and sums them in REGISTERS -- no LDS or global atomics in the loop.
-//  C. the G partial rows meet in a 1 KiB LDS staging row and leave the wave as one
-//     contiguous run of global fp32 atomics per touched cell.
+//  B. gather pass: the wave is split into G = 64 / (C/VEC) lane groups, each lane owning one
+//     16-byte column of the feature row (4 fp32 or 8 bf16 channels).  Every lane group takes ONE
+//     cell of the chunk at a time and walks its list alone, loading whole rows (C*sizeof(FT)
+//     contiguous bytes; rows of dropped points are never fetched) and summing them in fp32
+//     REGISTERS -- no LDS or global atomics in the loop; the few long lists are walked by a
+//     whole wave (every G-th row per group).
+//  C. the G partial rows meet in an LDS staging row and leave the wave as contiguous runs of
+//     global fp32 atomics, one run per (chunk, cell).
 // The BEV tile of the chunk therefore lives in registers + a staging row; HBM sees
 // each kept feature row once and one atomic row per (chunk, cell).
-template <int C4T, int CHUNK, bool FUSED, bool GROUPED = true>
+template <typename FT, int CVT, int CHUNK, bool FUSED>
 __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
+    using RV = RowVec<FT>;
+    constexpr int VEC = RV::VEC;
     constexpr int HT = CHUNK * 2;             // hash entries (load factor <= 0.5)
     constexpr int HT_LOG2 = (CHUNK == 512) ? 10 : 11;
     static_assert(CHUNK == 512 || CHUNK == 1024, "chunk size");
@@ -270,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     __shared__ int slot_cnt[CHUNK];
     __shared__ int slot_off[CHUNK + 1];
     __shared__ unsigned short sorted[CHUNK];
-    __shared__ __align__(16) float stage[NW][256];
+    __shared__ __align__(16) float stage[NW][64 * VEC];     // G*C <= 64*VEC floats per wave
     __shared__ int nslots, next_slot, next_long, nlong;
     __shared__ unsigned short long_list[CHUNK / kLongSlot + 1];
     // fused lift-splat: per point of the chunk its depth probability and its pixel's context row
@@ -278,8 +310,8 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
     __shared__ int pt_pix[FUSED ? CHUNK : 1];
 
     const int C = a.C;
-    const int C4 = C4T > 0 ? C4T : C >> 2;
-    const int G = 64 / C4;                    // lane groups per wave (C <= 256)
+    const int CV = CVT > 0 ? CVT : C / VEC;   // lanes per row
+    const int G = 64 / CV;                    // lane groups per wave (C <= 64*VEC)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // a.nchunks carries the points per workgroup (<= CHUNK, multiple of 4): the host sizes it so
     // that the grid is a whole number of rounds of the resident workgroup slots (no half-empty tail)
@@ -319,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
                 const unsigned cam = (unsigned)t / (unsigned)a.DHW;
                 const unsigned rem = (unsigned)t - cam * (unsigned)a.DHW;
                 pt_pix[lp] = (int)(cam * (unsigned)a.HW + rem % (unsigned)a.HW);
-                pt_depth[lp] = a.depth[t];
+                pt_depth[lp] = RV::scalar(reinterpret_cast<const FT *>(a.depth) + t);
             }
             const int x = gx[k], y = gy[k], z = gz[k];
             if (in_grid(x, y, z, a.nx, a.ny, a.nz)) {
@@ -424,183 +456,130 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_seg_gather(VpArgs a) {
         }
     }
 
-    if constexpr (!GROUPED) {
-        // ---- B/C: one slot per wave at a time, register accumulation, staged flush
-        const int g = lane / C4;
-        const int li = lane - g * C4;
-        const bool active = g < G;
-        const float *fbase = FUSED ? a.context + li * 4 : a.feats + base * C + li * 4;
-        float *st = stage[wave];
-        for (;;) {
-            int s = 0;
-            if (lane == 0) s = atomicAdd(&next_slot, 1);
-            s = __builtin_amdgcn_readfirstlane(s);
-            if (s >= ns) break;
-            const int beg = slot_off[s], end = slot_off[s + 1];
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active) {
-                // 4 rows in flight per lane group; short lists (the common far-range case)
-                // issue all their loads before the first add instead of one load per trip.
-                for (int j = beg + g; j < end; j += 4 * G) {
-                    float4 v[4];
-                    float dv[4];
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int jj = j + u * G;
-                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        dv[u] = 0.f;
-                        if (jj < end) {
-                            const int p = sorted[jj];
-                            if (FUSED) {
-                                dv[u] = pt_depth[p];
-                                v[u] = *reinterpret_cast<const float4 *>(fbase + (int64_t)pt_pix[p] * C);
-                            } else {
-                                v[u] = *reinterpret_cast<const float4 *>(fbase + p * C);
-                            }
-                        }
-                    }
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (FUSED) {   // product rounded to fp32 first (= the materialised lift), then added
-                            acc.x += __fmul_rn(dv[u], v[u].x); acc.y += __fmul_rn(dv[u], v[u].y);
-                            acc.z += __fmul_rn(dv[u], v[u].z); acc.w += __fmul_rn(dv[u], v[u].w);
-                        } else {
-                            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-                        }
+    // ---- B/C: register accumulation, staged flush.
+    // Pass 1: every lane group owns ONE cell (slot) at a time -- G cells per wave in flight, up to
+    // kRows rows each -- because the typical slot is short (36 slots / ~280 kept rows per chunk at
+    // cfg2): one slot per WAVE left two thirds of the load slots empty and paid the ticket /
+    // staging overhead per slot instead of per G slots.  Pass 2: the few long slots are walked by
+    // a whole wave (G groups, every G-th row) so no group serialises hundreds of rows.
+    constexpr int kRows = VEC == 8 ? 6 : 8;      // rows in flight per lane group (bf16: 6 keeps the kernel at 6 waves / SIMD)
+    const int g = lane / CV;
+    const int li = lane - g * CV;
+    const bool active = g < G;
+    const FT *fbase = (FUSED ? reinterpret_cast<const FT *>(a.context) : reinterpret_cast<const FT *>(a.feats) + base * C) + li * VEC;
+    float *st = stage[wave];
+    for (;;) {
+        int s0 = 0;
+        if (lane == 0) s0 = atomicAdd(&next_slot, G);
+        s0 = __builtin_amdgcn_readfirstlane(s0);
+        if (s0 >= ns) break;
+        const int s = s0 + g;
+        int beg = 0, end = 0;
+        if (active && s < ns) {
+            beg = slot_off[s];
+            end = slot_off[s + 1];
+            if (end - beg > kLongSlot) end = beg;      // left to pass 2
+        }
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        for (int j = beg; j < end; j += kRows) {
+            typename RV::Raw v[kRows];
+            float dv[kRows];
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {
+                v[u] = RV::zero();
+                dv[u] = 0.f;
+                if (j + u < end) {
+                    const int p = sorted[j + u];
+                    if (FUSED) {
+                        dv[u] = pt_depth[p];
+                        v[u] = RV::load(fbase + (int64_t)pt_pix[p] * C);
+                    } else {
+                        v[u] = RV::load(fbase + p * C);
                     }
                 }
-                *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float *orow = a.out + (int64_t)slot_key[s] * C;
-            for (int e = lane; e < C; e += 64) {
-                float sum = st[e];
-                for (int gg = 1; gg < G; ++gg) sum += st[gg * C + e];
-                atomicAdd(orow + e, sum);
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {
+                float f[VEC];
+                RV::unpack(v[u], f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)   // fused: product rounded to fp32 first (= the materialised lift), then added
+                    acc[e] += FUSED ? __fmul_rn(dv[u], f[e]) : f[e];
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-    } else {
-        // ---- B/C: register accumulation, staged flush.
-        // Pass 1: every lane group owns ONE cell (slot) at a time -- G cells per wave in flight, up to
-        // kRows rows each -- because the typical slot is short (36 slots / ~280 kept rows per chunk at
-        // cfg2): one slot per WAVE left two thirds of the load slots empty and paid the ticket /
-        // staging overhead per slot instead of per G slots.  Pass 2: the few long slots are walked by
-        // a whole wave (G groups, every G-th row) so no group serialises hundreds of rows.
-        constexpr int kRows = 8;
-        const int g = lane / C4;
-        const int li = lane - g * C4;
-        const bool active = g < G;
-        const float *fbase = FUSED ? a.context + li * 4 : a.feats + base * C + li * 4;
-        float *st = stage[wave];
-        for (;;) {
-            int s0 = 0;
-            if (lane == 0) s0 = atomicAdd(&next_slot, G);
-            s0 = __builtin_amdgcn_readfirstlane(s0);
-            if (s0 >= ns) break;
-            const int s = s0 + g;
-            int beg = 0, end = 0;
-            if (active && s < ns) {
-                beg = slot_off[s];
-                end = slot_off[s + 1];
-                if (end - beg > kLongSlot) end = beg;      // left to pass 2
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4)
+                *reinterpret_cast<float4 *>(st + g * C + li * VEC + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // G rows leave the wave as contiguous runs of global fp32 atomics
+        for (int e = lane; e < G * C; e += 64) {
+            const int gg = e / C;
+            const int ss = s0 + gg;
+            if (ss < ns) {
+                const int n = slot_off[ss + 1] - slot_off[ss];
+                if (n <= kLongSlot) atomicAdd(a.out + (int64_t)slot_key[ss] * C + (e - gg * C), st[e]);
             }
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int j = beg; j < end; j += kRows) {
-                float4 v[kRows];
-                float dv[kRows];
-    #pragma unroll
-                for (int u = 0; u < kRows; ++u) {
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int nl = nlong;
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&next_long, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= nl) break;
+        const int s = long_list[t];
+        const int beg = slot_off[s], end = slot_off[s + 1];
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        if (active) {
+            for (int j = beg + g; j < end; j += 4 * G) {
+                typename RV::Raw v[4];
+                float dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u * G;
+                    v[u] = RV::zero();
                     dv[u] = 0.f;
-                    if (j + u < end) {
-                        const int p = sorted[j + u];
+                    if (jj < end) {
+                        const int p = sorted[jj];
                         if (FUSED) {
                             dv[u] = pt_depth[p];
-                            v[u] = *reinterpret_cast<const float4 *>(fbase + (int64_t)pt_pix[p] * C);
+                            v[u] = RV::load(fbase + (int64_t)pt_pix[p] * C);
                         } else {
-                            v[u] = *reinterpret_cast<const float4 *>(fbase + p * C);
+                            v[u] = RV::load(fbase + p * C);
                         }
                     }
                 }
-    #pragma unroll
-                for (int u = 0; u < kRows; ++u) {
-                    if (FUSED) {   // product rounded to fp32 first (= the materialised lift), then added
-                        acc.x += __fmul_rn(dv[u], v[u].x); acc.y += __fmul_rn(dv[u], v[u].y);
-                        acc.z += __fmul_rn(dv[u], v[u].z); acc.w += __fmul_rn(dv[u], v[u].w);
-                    } else {
-                        acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[VEC];
+                    RV::unpack(v[u], f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += FUSED ? __fmul_rn(dv[u], f[e]) : f[e];
                 }
             }
-            if (active) *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // G rows leave the wave as contiguous runs of global fp32 atomics
-            for (int e = lane; e < G * C; e += 64) {
-                const int gg = e / C;
-                const int ss = s0 + gg;
-                if (ss < ns) {
-                    const int n = slot_off[ss + 1] - slot_off[ss];
-                    if (n <= kLongSlot) atomicAdd(a.out + (int64_t)slot_key[ss] * C + (e - gg * C), st[e]);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4)
+                *reinterpret_cast<float4 *>(st + g * C + li * VEC + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
         }
-        const int nl = nlong;
-        for (;;) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&next_long, 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= nl) break;
-            const int s = long_list[t];
-            const int beg = slot_off[s], end = slot_off[s + 1];
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active) {
-                for (int j = beg + g; j < end; j += 4 * G) {
-                    float4 v[4];
-                    float dv[4];
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int jj = j + u * G;
-                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        dv[u] = 0.f;
-                        if (jj < end) {
-                            const int p = sorted[jj];
-                            if (FUSED) {
-                                dv[u] = pt_depth[p];
-                                v[u] = *reinterpret_cast<const float4 *>(fbase + (int64_t)pt_pix[p] * C);
-                            } else {
-                                v[u] = *reinterpret_cast<const float4 *>(fbase + p * C);
-                            }
-                        }
-                    }
-    #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (FUSED) {
-                            acc.x += __fmul_rn(dv[u], v[u].x); acc.y += __fmul_rn(dv[u], v[u].y);
-                            acc.z += __fmul_rn(dv[u], v[u].z); acc.w += __fmul_rn(dv[u], v[u].w);
-                        } else {
-                            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-                        }
-                    }
-                }
-                *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float *orow = a.out + (int64_t)slot_key[s] * C;
-            for (int e = lane; e < C; e += 64) {
-                float sum = st[e];
-                for (int gg = 1; gg < G; ++gg) sum += st[gg * C + e];
-                atomicAdd(orow + e, sum);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float *orow = a.out + (int64_t)slot_key[s] * C;
+        for (int e = lane; e < C; e += 64) {
+            float sum = st[e];
+            for (int gg = 1; gg < G; ++gg) sum += st[gg * C + e];
+            atomicAdd(orow + e, sum);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -758,7 +737,7 @@ __global__ __launch_bounds__(kBlock) void vp_fwd_stream(VpArgs a) {
         const int L = (nkept + NG - 1) / NG;
         const int jb = gid * L;
         const int je = (jb + L) < nkept ? (jb + L) : nkept;
-        const float *fbase = a.feats + base * C + li * 4;
+        const float *fbase = static_cast<const float *>(a.feats) + base * C + li * 4;
         float *st = stage + wave * 256 + g * C;       // this group's private staging row
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int cur = jb < je ? (int)sorted_slot[jb] : -1;
@@ -831,7 +810,7 @@ struct VpBwdArgs {
     const int32_t *pos_memo;
     const float *grad_out;
     int64_t sb, sc, sy, sx;
-    float *grad_in;
+    void *grad_in;       // fp32 or bf16 [BP, C] (the kernel's OT template argument says which)
     int64_t span_bytes;  // bytes spanned by the grad_out view (buffer descriptor range)
     const uint32_t *row_off;  // optional [BP] byte offset of each point's BEV-gradient row (prepared), or NULL
     uint32_t *row_off_out;
@@ -907,11 +886,16 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_prepare(VpBwdArgs a, int rows_p
 // waits two full HBM read latencies behind a saturated write queue).  So each lane
 // keeps the row offsets of tile t+2 and the gathered vectors of tile t+1 in flight
 // while it stores tile t.
-template <int C4T>
-__global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
-    const int CV = C4T > 0 ? C4T : a.C / 4;
+// OT = float: grad_in fp32, a lane's 16-byte output vector is one float4 of the gradient row;
+// OT = bf16_t: grad_in bf16 (bf16 storage path), a lane's 16-byte output vector holds 8 channels = two float4
+// of the fp32 gradient row, rounded to nearest even on the way out.
+template <typename OT, int CVT>
+__global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec(VpBwdArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(OT);   // channels per lane vector
+    constexpr int NL = VEC / 4;                 // 16-byte gradient loads per lane vector
+    const int CV = CVT > 0 ? CVT : a.C / VEC;
     const int64_t total = a.BP * CV;
-    float4 *dst = reinterpret_cast<float4 *>(a.grad_in);
+    mmt_u32x4 *dst = reinterpret_cast<mmt_u32x4 *>(a.grad_in);
     constexpr int U = 4;
     constexpr int64_t kTileVecs = (int64_t)kBlock * U;
     // XCD-aware tile order: workgroups b, b+8, b+16.. share an XCD and its 4 MiB L2, so
@@ -938,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.grad_out), 0, (int)a.span_bytes, 0x00020000);
 
-    // BYTE offset of the lane's float4 inside grad_out, or 0xFFFFFFF0 (dropped point)
+    // BYTE offset of the lane's first float4 inside grad_out, or 0xFFFFFFF0 (dropped point)
     auto load_offsets = [&](int64_t tile, unsigned (&off)[U]) {
         tile = tile < my_end ? tile : t_first;  // prefetch past the end re-reads a valid tile
 #pragma unroll
@@ -948,35 +932,47 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
             const int cv = (int)(i - t * CV);
             if (a.row_off) {   // prepared by vp_bwd_prepare (wave-uniform branch)
                 const unsigned ro = a.row_off[t];
-                off[u] = ro == 0xFFFFFFF0u ? ro : ro + cv * 16u;
+                off[u] = ro == 0xFFFFFFF0u ? ro : ro + cv * (VEC * 4u);
             } else {
                 const int b = a.pos_memo[t * 3];
                 const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
-                const unsigned o = ((unsigned)(b * a.sb + y * a.sy + x * a.sx) + cv * 4) * 4u;
+                const unsigned o = ((unsigned)(b * a.sb + y * a.sy + x * a.sx) + cv * VEC) * 4u;
                 off[u] = (b != -1) ? o : 0xFFFFFFF0u;
             }
         }
     };
-    auto gather = [&](const unsigned (&off)[U], float4 (&v)[U]) {
+    auto gather = [&](const unsigned (&off)[U], mmt_u32x4 (&v)[U][NL]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const mmt_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[u], 0, 0);
-            v[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z),
-                               __uint_as_float(r.w));
+#pragma unroll
+            for (int l = 0; l < NL; ++l)   // the out-of-range marker must stay out of range (no wrap-around)
+                v[u][l] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (l == 0 || off[u] == 0xFFFFFFF0u) ? off[u] : off[u] + 16u * l, 0, 0);
+        }
+    };
+    auto pack = [&](const mmt_u32x4 (&v)[NL]) -> mmt_u32x4 {
+        if constexpr (NL == 1) {
+            return v[0];
+        } else {
+            mmt_u32x4 r;
+            r.x = pack_bf16x2(__uint_as_float(v[0].x), __uint_as_float(v[0].y));
+            r.y = pack_bf16x2(__uint_as_float(v[0].z), __uint_as_float(v[0].w));
+            r.z = pack_bf16x2(__uint_as_float(v[1].x), __uint_as_float(v[1].y));
+            r.w = pack_bf16x2(__uint_as_float(v[1].z), __uint_as_float(v[1].w));
+            return r;
         }
     };
 
     if (t_first < my_end) {
         unsigned off1[U], off2[U];
-        float4 g0[U], g1[U];
+        mmt_u32x4 g0[U][NL], g1[U][NL];
         load_offsets(t_first, off1);
         gather(off1, g0);
         load_offsets(t_first + t_step, off1);
-        auto store_tile = [&](int64_t tile, const float4 (&v)[U]) {
+        auto store_tile = [&](int64_t tile, const mmt_u32x4 (&v)[U][NL]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = tile * kTileVecs + threadIdx.x + (int64_t)u * kBlock;
-                mmt_nt_store4(v[u], dst + i);
+                __builtin_nontemporal_store(pack(v[u]), dst + i);
             }
         };
         // unrolled by two with the register sets swapping roles: no copies, so nothing
@@ -997,20 +993,26 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_rows_vec4(VpBwdArgs a) {
             const int64_t t = i / CV;
             const int cv = (int)(i - t * CV);
             const int b = a.pos_memo[t * 3];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            mmt_u32x4 v[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) v[l] = mmt_u32x4{0u, 0u, 0u, 0u};
             if (b != -1) {
                 const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
-                v = *reinterpret_cast<const float4 *>(a.grad_out + b * a.sb + y * a.sy + x * a.sx + cv * 4);
+                const mmt_u32x4 *src = reinterpret_cast<const mmt_u32x4 *>(a.grad_out + b * a.sb + y * a.sy + x * a.sx + cv * VEC);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) v[l] = src[l];
             }
-            dst[i] = v;
+            dst[i] = pack(v);
         }
     }
 }
 
 // any strides, any C (slow path: one element per lane)
+template <typename OT>
 __global__ __launch_bounds__(kBlock) void vp_bwd_strided(VpBwdArgs a) {
     const int64_t total = a.BP * a.C;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    OT *gi = reinterpret_cast<OT *>(a.grad_in);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
         const int64_t t = i / a.C;
         const int c = (int)(i - t * a.C);
@@ -1020,7 +1022,8 @@ __global__ __launch_bounds__(kBlock) void vp_bwd_strided(VpBwdArgs a) {
             const int y = a.pos_memo[t * 3 + 1], x = a.pos_memo[t * 3 + 2];
             v = a.grad_out[b * a.sb + c * a.sc + y * a.sy + x * a.sx];
         }
-        a.grad_in[i] = v;
+        if constexpr (sizeof(OT) == 4) gi[i] = v;
+        else gi[i] = (OT)(pack_bf16x2(v, 0.f) & 0xFFFFu);
     }
 }
 
@@ -1061,11 +1064,12 @@ __global__ __launch_bounds__(kBlock) void vp_to_channels_last(int C, int ny, int
 // One lane group (C/4 lanes, a float4 column each) owns one pixel and walks its D depth
 // bins; grad_out rows are L2 gathers through a range-checked buffer descriptor (dropped
 // points read zeros), 4 bins in flight.
-template <int C4T>
+template <typename FT, int C4T>
 __global__ __launch_bounds__(kBlock) void lift_splat_backward_kernel(
-    int D, int HW, int C, const int32_t *pos_memo, const float *depth, const float *context,
+    int D, int HW, int C, const int32_t *pos_memo, const FT *depth, const FT *context,
     const float *grad_out, int64_t sb, int64_t sy, int64_t sx, int64_t span_bytes,
-    float *grad_depth, float *grad_context) {
+    FT *grad_depth, FT *grad_context) {
+    constexpr bool kBf16 = sizeof(FT) == 2;
     extern __shared__ __align__(16) float lds[];
     const int C4 = C4T > 0 ? C4T : C >> 2;
     const int G = 64 / C4;
@@ -1082,7 +1086,15 @@ __global__ __launch_bounds__(kBlock) void lift_splat_backward_kernel(
     for (int i = tid; i < D * NG; i += kBlock) gd[i] = 0.f;
     const int64_t pix = (int64_t)bn * HW + s0 + (active ? j : 0);
     float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) cx = *reinterpret_cast<const float4 *>(context + pix * C + li * 4);
+    if (active) {
+        if constexpr (kBf16) {
+            const uint2 r = *reinterpret_cast<const uint2 *>(context + pix * C + li * 4);
+            cx = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u),
+                             __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
+        } else {
+            cx = *reinterpret_cast<const float4 *>(context + pix * C + li * 4);
+        }
+    }
     __syncthreads();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1100,7 +1112,7 @@ __global__ __launch_bounds__(kBlock) void lift_splat_backward_kernel(
                 const int b = pos_memo[t * 3];
                 const int y = pos_memo[t * 3 + 1], x = pos_memo[t * 3 + 2];
                 if (b != -1) off = ((unsigned)(b * sb + y * sy + x * sx) + li * 4) * 4u;
-                dv[u] = depth[t];
+                dv[u] = RowVec<FT>::scalar(depth + t);
             }
             v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         }
@@ -1118,11 +1130,23 @@ __global__ __launch_bounds__(kBlock) void lift_splat_backward_kernel(
             }
         }
     }
-    if (active) *reinterpret_cast<float4 *>(grad_context + pix * C + li * 4) = acc;
+    if (active) {
+        if constexpr (kBf16) {
+            uint2 r;
+            r.x = pack_bf16x2(acc.x, acc.y);
+            r.y = pack_bf16x2(acc.z, acc.w);
+            *reinterpret_cast<uint2 *>(grad_context + pix * C + li * 4) = r;
+        } else {
+            *reinterpret_cast<float4 *>(grad_context + pix * C + li * 4) = acc;
+        }
+    }
     __syncthreads();
     for (int i = tid; i < D * NG; i += kBlock) {
         const int d = i / NG, jj = i - d * NG;
-        if ((s0 + jj) < HW) grad_depth[((int64_t)bn * D + d) * HW + s0 + jj] = gd[i];
+        if ((s0 + jj) < HW) {
+            if constexpr (kBf16) grad_depth[((int64_t)bn * D + d) * HW + s0 + jj] = (FT)(pack_bf16x2(gd[i], 0.f) & 0xFFFFu);
+            else grad_depth[((int64_t)bn * D + d) * HW + s0 + jj] = gd[i];
+        }
     }
 }
 
@@ -1151,6 +1175,87 @@ int launch_lds_combine(const VpArgs &a, int grid, size_t lds, hipStream_t st) {
     return mmt::check_launch("voxel_pooling_forward(lds_combine)");
 }
 
+// SEG_GATHER launch for a storage type: compile-time lanes-per-row for the common channel counts
+template <typename FT>
+void launch_seg_gather(mmt::TimedSeq &seq, const VpArgs &a, bool big, bool fused, hipStream_t st) {
+    constexpr int VEC = RowVec<FT>::VEC;
+    const dim3 grid((unsigned)mmt::ceil_div(a.BP, a.nchunks)), block(kBlock);
+#define MMT_LAUNCH_SEG(CVT)                                                                         \
+    do {                                                                                            \
+        if (fused) seq.launch(true, vp_fwd_seg_gather<FT, CVT, 512, true>, grid, block, 0, st, a);  \
+        else if (big) seq.launch(true, vp_fwd_seg_gather<FT, CVT, 1024, false>, grid, block, 0, st, a); \
+        else seq.launch(true, vp_fwd_seg_gather<FT, CVT, 512, false>, grid, block, 0, st, a);       \
+    } while (0)
+    if (a.C == 80) MMT_LAUNCH_SEG(80 / VEC);
+    else if (a.C == 64) MMT_LAUNCH_SEG(64 / VEC);
+    else MMT_LAUNCH_SEG(0);
+#undef MMT_LAUNCH_SEG
+}
+
+// Backward for an output type (float / bf16_t): optional layout pass, optional prepare pass, main gather pass.
+template <typename OT>
+int backward_impl(const char *what, int B, int P, int C, int nx, int ny, const int32_t *pos_memo, const float *grad_out,
+                  int64_t sb, int64_t sc, int64_t sy, int64_t sx, void *grad_in, float *workspace,
+                  int64_t workspace_elems, hipStream_t st) {
+    constexpr int VEC = 16 / (int)sizeof(OT);
+    if (workspace == nullptr) workspace_elems = 0;
+    const int64_t bev_elems = (int64_t)B * ny * nx * C;
+    const int64_t BP = (int64_t)B * P;
+    VpBwdArgs a;
+    a.BP = BP; a.C = C; a.nx = nx; a.ny = ny;
+    a.pos_memo = pos_memo; a.grad_out = grad_out; a.grad_in = grad_in;
+    a.sb = sb; a.sc = sc; a.sy = sy; a.sx = sx;
+    a.row_off = nullptr; a.row_off_out = nullptr;
+    // armed by mmt_arm_kernel_timing (bench only): the start event rides on the first kernel of this call, the stop
+    // event on the last one
+    mmt::TimedSeq seq;
+    const bool can_vec = C % VEC == 0 && (((uintptr_t)grad_in & 15) == 0);
+
+    if (sc != 1 && can_vec && workspace_elems >= bev_elems) {
+        dim3 grid((unsigned)mmt::ceil_div((int64_t)ny * nx, 32), (unsigned)mmt::ceil_div(C, 32), (unsigned)B);
+        seq.launch(false, vp_to_channels_last, grid, dim3(kBlock), 0, st, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
+        int rc = mmt::check_launch(what);
+        if (rc) return rc;
+        a.grad_out = workspace;
+        a.sc = 1; a.sx = C; a.sy = (int64_t)nx * C; a.sb = (int64_t)ny * nx * C;
+    }
+    const int64_t span = (B - 1) * a.sb + (ny - 1) * a.sy + (nx - 1) * a.sx + C;
+    const bool vec = can_vec && a.sc == 1 && a.sb % 4 == 0 && a.sy % 4 == 0 && a.sx % 4 == 0 &&
+                     a.sb >= 0 && a.sy >= 0 && a.sx >= 0 && span < (1ll << 29) && (((uintptr_t)a.grad_out & 15) == 0);
+    a.span_bytes = span * 4;
+    if (vec && workspace_elems >= bev_elems + BP && (((uintptr_t)workspace & 3) == 0)) {
+        // pass 1: row offsets + cache warm-up (see vp_bwd_prepare)
+        a.row_off_out = reinterpret_cast<uint32_t *>(workspace + bev_elems);
+        const int rows_per_xcd = (int)mmt::ceil_div(BP, 8);
+        int pgrid = mmt::stream_grid(mmt::ceil_div(BP, kPrepU), kBlock, 256 * 8);
+        pgrid = (pgrid + 7) & ~7;
+        const int sweep = span <= 4 * bev_elems;   // a thin slice of a much wider buffer: not worth reading the whole span
+        seq.launch(false, vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd, sweep);
+        int rc = mmt::check_launch(what);
+        if (rc) return rc;
+        a.row_off = a.row_off_out;
+    }
+    if (vec) {
+        int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / VEC), 4), kBlock, 256 * 16);
+        grid = (grid + 7) & ~7;  // whole groups of 8 (one workgroup per XCD)
+        if (C == 80) seq.launch(true, vp_bwd_rows_vec<OT, 80 / VEC>, dim3(grid), dim3(kBlock), 0, st, a);
+        else if (C == 64) seq.launch(true, vp_bwd_rows_vec<OT, 64 / VEC>, dim3(grid), dim3(kBlock), 0, st, a);
+        else seq.launch(true, vp_bwd_rows_vec<OT, 0>, dim3(grid), dim3(kBlock), 0, st, a);
+        return mmt::check_launch(what);
+    }
+    const int grid = mmt::stream_grid(BP * C, kBlock);
+    seq.launch(true, vp_bwd_strided<OT>, dim3(grid), dim3(kBlock), 0, st, a);
+    return mmt::check_launch(what);
+}
+
+int forward_check(const char *what, int B, int P, int C, int nx, int ny, int nz) {
+    if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive size (B=%d P=%d C=%d grid=%dx%dx%d)", what, B, P, C, nx, ny, nz);
+    if ((int64_t)B * P >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: B*P or B*ny*nx exceeds int32", what);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny, int nz,
@@ -1160,23 +1265,18 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     MMT_REQUIRE_PTR(feats);
     MMT_REQUIRE_PTR(out);
     MMT_REQUIRE_PTR(pos_memo);
-    if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "voxel_pooling_forward: non-positive size (B=%d P=%d C=%d grid=%dx%dx%d)", B, P, C, nx, ny, nz);
+    if (int rc = forward_check("voxel_pooling_forward", B, P, C, nx, ny, nz)) return rc;
     const int64_t BP = (int64_t)B * P;
-    if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31))
-        return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_forward: B*P or B*ny*nx exceeds int32");
     int algo = flags & MMT_VP_ALGO_MASK;
     if (algo > MMT_VP_ALGO_STREAM)
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown algorithm %d", algo);
+    // MMT_VP_WAVE_PER_SLOT (the pre-ABI-3 gather schedule, kept for A/B runs until ABI 4) is accepted and ignored
     if (flags & ~(MMT_VP_ALGO_MASK | MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_1024 | MMT_VP_WAVE_PER_SLOT | MMT_VP_CHUNK_POINTS_MASK))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: unknown flag bits 0x%x", flags);
     const int chunk_points = ((flags & MMT_VP_CHUNK_POINTS_MASK) >> 8) * 4;
     if (chunk_points != 0 && (chunk_points < 64 || chunk_points > 512 || (flags & MMT_VP_CHUNK_1024)))
         return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward: MMT_VP_CHUNK_POINTS must be 64..512 (got %d) and excludes MMT_VP_CHUNK_1024", chunk_points);
     hipStream_t st = (hipStream_t)stream;
-    // armed by mmt_arm_kernel_timing (bench only); consumed by this call, used by the default SEG_GATHER launch
-    hipEvent_t t_start = nullptr, t_stop = nullptr;
-    mmt::take_timing_events(&t_start, &t_stop);
 
     VpArgs a;
     a.BP = BP; a.P = P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
@@ -1191,27 +1291,14 @@ extern "C" int mmt_voxel_pooling_forward_ex(int B, int P, int C, int nx, int ny,
     if ((algo == MMT_VP_ALGO_SEG_GATHER || algo == MMT_VP_ALGO_STREAM) && !seg_ok) algo = MMT_VP_ALGO_LDS_ATOMIC;
 
     if (algo == MMT_VP_ALGO_SEG_GATHER) {
-        const bool fused = false;
         const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
-        const bool wave_slots = (flags & MMT_VP_WAVE_PER_SLOT) != 0;
         const int chunk = big ? 1024 : (chunk_points ? chunk_points : balanced_chunk_points(BP, 512));
         a.nchunks = chunk;
-        const int64_t nchunks = mmt::ceil_div(BP, chunk);
-        const dim3 grid((unsigned)nchunks), block(kBlock);
-#define MMT_LAUNCH_SEG(C4T)                                                                     \
-    do {                                                                                        \
-        if (fused) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, true>), grid, block, 0, st, a);          \
-        else if (big) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 1024, false>), grid, block, 0, st, a);   \
-        else if (wave_slots) hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false, false>), grid, block, 0, st, a); \
-        else if (t_start && t_stop) hipExtLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false>), grid, block, 0, st, t_start, t_stop, 0, a); \
-        else hipLaunchKernelGGL((vp_fwd_seg_gather<C4T, 512, false>), grid, block, 0, st, a);               \
-    } while (0)
-        if (C == 80) MMT_LAUNCH_SEG(20);
-        else if (C == 64) MMT_LAUNCH_SEG(16);
-        else MMT_LAUNCH_SEG(0);
-#undef MMT_LAUNCH_SEG
+        mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+        launch_seg_gather<float>(seq, a, big, false, (hipStream_t)stream);
         return mmt::check_launch("voxel_pooling_forward(seg_gather)");
     }
+    { hipEvent_t t0, t1; mmt::take_timing_events(&t0, &t1); }   // the other algorithms consume and ignore an armed timing
 
     if (algo == MMT_VP_ALGO_STREAM) {
         const bool big = (flags & MMT_VP_CHUNK_1024) != 0;
@@ -1278,68 +1365,110 @@ extern "C" int mmt_voxel_pooling_backward(int B, int P, int C, int nx, int ny,
     MMT_REQUIRE_PTR(grad_in);
     if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "voxel_pooling_backward: non-positive size");
-    if (workspace == nullptr) workspace_elems = 0;
-    const int64_t bev_elems = (int64_t)B * ny * nx * C;
-    const int64_t BP = (int64_t)B * P;
-    if (BP >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_backward: B*P exceeds int32");
-    hipStream_t st = (hipStream_t)stream;
-
-    VpBwdArgs a;
-    a.BP = BP; a.C = C; a.nx = nx; a.ny = ny;
-    a.pos_memo = pos_memo; a.grad_out = grad_out; a.grad_in = grad_in;
-    a.sb = sb; a.sc = sc; a.sy = sy; a.sx = sx;
-    a.row_off = nullptr; a.row_off_out = nullptr;
-    // armed by mmt_arm_kernel_timing (bench only): the start event rides on the first kernel of this call, the stop
-    // event on the last one
-    hipEvent_t t_start = nullptr, t_stop = nullptr;
-    mmt::take_timing_events(&t_start, &t_stop);
-
-    if (sc != 1 && workspace_elems >= bev_elems) {
-        dim3 grid((unsigned)mmt::ceil_div((int64_t)ny * nx, 32), (unsigned)mmt::ceil_div(C, 32), (unsigned)B);
-        if (t_start) hipExtLaunchKernelGGL(vp_to_channels_last, grid, dim3(kBlock), 0, st, t_start, nullptr, 0, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
-        else hipLaunchKernelGGL(vp_to_channels_last, grid, dim3(kBlock), 0, st, C, ny, nx, grad_out, sb, sc, sy, sx, workspace);
-        t_start = nullptr;
-        int rc = mmt::check_launch("voxel_pooling_backward(to_channels_last)");
-        if (rc) return rc;
-        a.grad_out = workspace;
-        a.sc = 1; a.sx = C; a.sy = (int64_t)nx * C; a.sb = (int64_t)ny * nx * C;
-    }
-    const int64_t span = (B - 1) * a.sb + (ny - 1) * a.sy + (nx - 1) * a.sx + C;
-    const bool vec4 = a.sc == 1 && C % 4 == 0 && a.sb % 4 == 0 && a.sy % 4 == 0 && a.sx % 4 == 0 &&
-                      a.sb >= 0 && a.sy >= 0 && a.sx >= 0 && span < (1ll << 29) &&
-                      (((uintptr_t)a.grad_out & 15) == 0) && (((uintptr_t)grad_in & 15) == 0);
-    a.span_bytes = span * 4;
-    if (vec4 && workspace_elems >= bev_elems + BP && (((uintptr_t)workspace & 3) == 0)) {
-        // pass 1: row offsets + cache warm-up (see vp_bwd_prepare)
-        a.row_off_out = reinterpret_cast<uint32_t *>(workspace + bev_elems);
-        const int rows_per_xcd = (int)mmt::ceil_div(BP, 8);
-        int pgrid = mmt::stream_grid(mmt::ceil_div(BP, kPrepU), kBlock, 256 * 8);
-        pgrid = (pgrid + 7) & ~7;
-        const int sweep = span <= 4 * bev_elems;   // a thin slice of a much wider buffer: not worth reading the whole span
-        if (t_start) hipExtLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, t_start, nullptr, 0, a, rows_per_xcd, sweep);
-        else hipLaunchKernelGGL(vp_bwd_prepare, dim3(pgrid), dim3(kBlock), 0, st, a, rows_per_xcd, sweep);
-        t_start = nullptr;                         // the main pass below carries the stop event only
-        int rc = mmt::check_launch("voxel_pooling_backward(prepare)");
-        if (rc) return rc;
-        a.row_off = a.row_off_out;
-    }
-    if (vec4) {
-        int grid = mmt::stream_grid(mmt::ceil_div(BP * (C / 4), 4), kBlock, 256 * 16);
-        grid = (grid + 7) & ~7;  // whole groups of 8 (one workgroup per XCD)
-        if (t_stop) {       // timed launch: start (if the prepare pass did not take it) and stop ride on this dispatch
-            if (C == 80) hipExtLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
-            else if (C == 64) hipExtLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
-            else hipExtLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
-        } else if (C == 80) hipLaunchKernelGGL((vp_bwd_rows_vec4<20>), dim3(grid), dim3(kBlock), 0, st, a);
-        else if (C == 64) hipLaunchKernelGGL((vp_bwd_rows_vec4<16>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((vp_bwd_rows_vec4<0>), dim3(grid), dim3(kBlock), 0, st, a);
-        return mmt::check_launch("voxel_pooling_backward(rows_vec4)");
-    }
-    const int grid = mmt::stream_grid(BP * C, kBlock);
-    if (t_stop) hipExtLaunchKernelGGL(vp_bwd_strided, dim3(grid), dim3(kBlock), 0, st, t_start, t_stop, 0, a);
-    else hipLaunchKernelGGL(vp_bwd_strided, dim3(grid), dim3(kBlock), 0, st, a);
-    return mmt::check_launch("voxel_pooling_backward(strided)");
+    if ((int64_t)B * P >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_backward: B*P exceeds int32");
+    return backward_impl<float>("voxel_pooling_backward", B, P, C, nx, ny, pos_memo, grad_out, sb, sc, sy, sx, grad_in,
+                                workspace, workspace_elems, (hipStream_t)stream);
 }
+
+// ---- bf16 feature storage (SURVEY 5.6 / BASELINE configs[4]): bf16 rows in, fp32 accumulate, fp32 BEV out;
+// the backward rounds the gathered fp32 gradient rows to bf16 (nearest even) on the way out.
+extern "C" int mmt_voxel_pooling_forward_bf16(int B, int P, int C, int nx, int ny, int nz,
+                                              const int32_t *geom, const uint16_t *feats, float *out,
+                                              int32_t *pos_memo, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(feats);
+    MMT_REQUIRE_PTR(out);
+    MMT_REQUIRE_PTR(pos_memo);
+    if (int rc = forward_check("voxel_pooling_forward_bf16", B, P, C, nx, ny, nz)) return rc;
+    if (C % 8 != 0 || C > 512 || (((uintptr_t)feats & 15) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "voxel_pooling_forward_bf16: needs C %% 8 == 0, C <= 512 and 16-byte aligned rows (C=%d)", C);
+    if (flags & ~(MMT_VP_WRITE_DROPPED | MMT_VP_CHUNK_POINTS_MASK))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward_bf16: unknown flag bits 0x%x (only WRITE_DROPPED / CHUNK_POINTS)", flags);
+    const int chunk_points = ((flags & MMT_VP_CHUNK_POINTS_MASK) >> 8) * 4;
+    if (chunk_points != 0 && (chunk_points < 64 || chunk_points > 512))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "voxel_pooling_forward_bf16: MMT_VP_CHUNK_POINTS must be 64..512 (got %d)", chunk_points);
+    VpArgs a;
+    a.BP = (int64_t)B * P; a.P = P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
+    a.geom = geom; a.feats = feats; a.out = out; a.pos_memo = pos_memo;
+    a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
+    a.nslot = 0;
+    a.depth = nullptr; a.context = nullptr; a.DHW = 1; a.HW = 1;
+    a.nchunks = chunk_points ? chunk_points : balanced_chunk_points(a.BP, 512);
+    mmt::TimedSeq seq;
+    launch_seg_gather<bf16_t>(seq, a, false, false, (hipStream_t)stream);
+    return mmt::check_launch("voxel_pooling_forward_bf16");
+}
+
+extern "C" int mmt_voxel_pooling_backward_bf16(int B, int P, int C, int nx, int ny,
+                                               const int32_t *pos_memo, const float *grad_out,
+                                               int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                               uint16_t *grad_in, float *workspace,
+                                               int64_t workspace_elems, void *stream) {
+    MMT_REQUIRE_PTR(pos_memo);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_in);
+    if (B <= 0 || P <= 0 || C <= 0 || nx <= 0 || ny <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "voxel_pooling_backward_bf16: non-positive size");
+    if ((int64_t)B * P >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "voxel_pooling_backward_bf16: B*P exceeds int32");
+    return backward_impl<bf16_t>("voxel_pooling_backward_bf16", B, P, C, nx, ny, pos_memo, grad_out, sb, sc, sy, sx, grad_in,
+                                 workspace, workspace_elems, (hipStream_t)stream);
+}
+
+namespace {
+
+template <typename FT>
+int lift_splat_forward_impl(const char *what, int B, int N, int D, int HW, int C, int nx, int ny, int nz, const int32_t *geom,
+                            const FT *depth, const FT *context, float *out, int32_t *pos_memo, int flags, hipStream_t st) {
+    constexpr int VEC = RowVec<FT>::VEC;
+    if (B <= 0 || N <= 0 || D <= 0 || HW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive size", what);
+    if (C % VEC != 0 || C > 64 * VEC || (((uintptr_t)context & 15) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: needs C %% %d == 0, C <= %d and a 16-byte aligned context", what, VEC, 64 * VEC);
+    const int64_t P = (int64_t)N * D * HW, BP = (int64_t)B * P;
+    if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31) || (int64_t)B * N * HW * C >= (1ll << 31))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
+    if (flags & ~MMT_VP_WRITE_DROPPED) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    VpArgs a;
+    a.BP = BP; a.P = (int)P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
+    a.geom = geom; a.feats = nullptr; a.out = out; a.pos_memo = pos_memo;
+    a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
+    a.nslot = 0;
+    a.depth = depth; a.context = context; a.DHW = D * HW; a.HW = HW;
+    a.nchunks = balanced_chunk_points(BP, 512);
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    launch_seg_gather<FT>(seq, a, false, true, st);
+    return mmt::check_launch(what);
+}
+
+template <typename FT>
+int lift_splat_backward_impl(const char *what, int B, int N, int D, int HW, int C, int nx, int ny, const int32_t *pos_memo,
+                             const FT *depth, const FT *context, const float *grad_out, int64_t sb, int64_t sc, int64_t sy,
+                             int64_t sx, FT *grad_depth, FT *grad_context, hipStream_t st) {
+    if (B <= 0 || N <= 0 || D <= 0 || HW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || B * N > 65535)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: bad sizes", what);
+    if (C % 16 != 0 || C > 256)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: needs C %% 16 == 0 and C <= 256", what);
+    const int64_t span = (B - 1) * sb + (ny - 1) * sy + (nx - 1) * sx + C;
+    if (sc != 1 || sb % 4 || sy % 4 || sx % 4 || sb < 0 || sy < 0 || sx < 0 || span >= (1ll << 29) ||
+        (((uintptr_t)grad_out | (uintptr_t)context | (uintptr_t)grad_context) & 15) != 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: grad_out must be channels-last (stride_c == 1), 16-byte aligned", what);
+    if ((int64_t)B * N * D * HW >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: B*P exceeds int32", what);
+    const int C4 = C / 4;
+    const int NG = (kBlock / 64) * (64 / C4);
+    const size_t lds = (size_t)D * NG * 4;
+    if (lds > 64 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: D too large for the LDS tile", what);
+    dim3 grid((unsigned)mmt::ceil_div(HW, NG), (unsigned)(B * N));
+    // pos_memo's batch index b is the SAMPLE index; cameras of one sample share it
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+#define MMT_LSB(C4T) seq.launch(true, lift_splat_backward_kernel<FT, C4T>, grid, dim3(kBlock), lds, st, D, HW, C, pos_memo, depth, context, grad_out, sb, sy, sx, (int64_t)(span * 4), grad_depth, grad_context)
+    if (C == 80) MMT_LSB(20);
+    else if (C == 64) MMT_LSB(16);
+    else MMT_LSB(0);
+#undef MMT_LSB
+    return mmt::check_launch(what);
+}
+
+}  // namespace
 
 extern "C" int mmt_lift_splat_forward(int B, int N, int D, int HW, int C, int nx, int ny, int nz,
                                       const int32_t *geom, const float *depth, const float *context,
@@ -1349,28 +1478,20 @@ extern "C" int mmt_lift_splat_forward(int B, int N, int D, int HW, int C, int nx
     MMT_REQUIRE_PTR(context);
     MMT_REQUIRE_PTR(out);
     MMT_REQUIRE_PTR(pos_memo);
-    if (B <= 0 || N <= 0 || D <= 0 || HW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_forward: non-positive size");
-    if (C % 4 != 0 || C > 256 || (((uintptr_t)context & 15) != 0))
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_forward: needs C %% 4 == 0, C <= 256 and a 16-byte aligned context");
-    const int64_t P = (int64_t)N * D * HW, BP = (int64_t)B * P;
-    if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31) || (int64_t)B * N * HW * C >= (1ll << 31))
-        return mmt::fail(MMT_ERR_TOO_LARGE, "lift_splat_forward: index range exceeds int32");
-    if (flags & ~MMT_VP_WRITE_DROPPED) return mmt::fail(MMT_ERR_BAD_FLAG, "lift_splat_forward: unknown flag bits 0x%x", flags);
-    VpArgs a;
-    a.BP = BP; a.P = (int)P; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
-    a.geom = geom; a.feats = nullptr; a.out = out; a.pos_memo = pos_memo;
-    a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
-    a.nslot = 0; a.nchunks = 0;
-    a.depth = depth; a.context = context; a.DHW = D * HW; a.HW = HW;
-    hipStream_t st = (hipStream_t)stream;
-    a.nchunks = balanced_chunk_points(BP, 512);
-    const dim3 grid((unsigned)mmt::ceil_div(BP, a.nchunks)), block(kBlock);
-    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
-    if (C == 80) seq.launch(true, vp_fwd_seg_gather<20, 512, true>, grid, block, 0, st, a);
-    else if (C == 64) seq.launch(true, vp_fwd_seg_gather<16, 512, true>, grid, block, 0, st, a);
-    else seq.launch(true, vp_fwd_seg_gather<0, 512, true>, grid, block, 0, st, a);
-    return mmt::check_launch("lift_splat_forward");
+    return lift_splat_forward_impl<float>("lift_splat_forward", B, N, D, HW, C, nx, ny, nz, geom, depth, context, out, pos_memo,
+                                          flags, (hipStream_t)stream);
+}
+
+extern "C" int mmt_lift_splat_forward_bf16(int B, int N, int D, int HW, int C, int nx, int ny, int nz,
+                                           const int32_t *geom, const uint16_t *depth, const uint16_t *context,
+                                           float *out, int32_t *pos_memo, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    MMT_REQUIRE_PTR(pos_memo);
+    return lift_splat_forward_impl<bf16_t>("lift_splat_forward_bf16", B, N, D, HW, C, nx, ny, nz, geom, depth, context, out,
+                                           pos_memo, flags, (hipStream_t)stream);
 }
 
 extern "C" int mmt_lift_splat_backward(int B, int N, int D, int HW, int C, int nx, int ny,
@@ -1384,27 +1505,21 @@ extern "C" int mmt_lift_splat_backward(int B, int N, int D, int HW, int C, int n
     MMT_REQUIRE_PTR(grad_out);
     MMT_REQUIRE_PTR(grad_depth);
     MMT_REQUIRE_PTR(grad_context);
-    if (B <= 0 || N <= 0 || D <= 0 || HW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || B * N > 65535)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_backward: bad sizes");
-    if (C % 16 != 0 || C > 256)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_backward: needs C %% 16 == 0 and C <= 256");
-    const int64_t span = (B - 1) * sb + (ny - 1) * sy + (nx - 1) * sx + C;
-    if (sc != 1 || sb % 4 || sy % 4 || sx % 4 || sb < 0 || sy < 0 || sx < 0 || span >= (1ll << 29) ||
-        (((uintptr_t)grad_out | (uintptr_t)context | (uintptr_t)grad_context) & 15) != 0)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "lift_splat_backward: grad_out must be channels-last (stride_c == 1), 16-byte aligned");
-    if ((int64_t)B * N * D * HW >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_splat_backward: B*P exceeds int32");
-    const int C4 = C / 4;
-    const int NG = (kBlock / 64) * (64 / C4);
-    const size_t lds = (size_t)D * NG * 4;
-    if (lds > 64 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "lift_splat_backward: D too large for the LDS tile");
-    dim3 grid((unsigned)mmt::ceil_div(HW, NG), (unsigned)(B * N));
-    hipStream_t st = (hipStream_t)stream;
-    // pos_memo's batch index b is the SAMPLE index; cameras of one sample share it
-    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
-#define MMT_LSB(C4T) seq.launch(true, lift_splat_backward_kernel<C4T>, grid, dim3(kBlock), lds, st, D, HW, C, pos_memo, depth, context, grad_out, sb, sy, sx, (int64_t)(span * 4), grad_depth, grad_context)
-    if (C == 80) MMT_LSB(20);
-    else if (C == 64) MMT_LSB(16);
-    else MMT_LSB(0);
-#undef MMT_LSB
-    return mmt::check_launch("lift_splat_backward");
+    return lift_splat_backward_impl<float>("lift_splat_backward", B, N, D, HW, C, nx, ny, pos_memo, depth, context, grad_out,
+                                           sb, sc, sy, sx, grad_depth, grad_context, (hipStream_t)stream);
+}
+
+extern "C" int mmt_lift_splat_backward_bf16(int B, int N, int D, int HW, int C, int nx, int ny,
+                                            const int32_t *pos_memo, const uint16_t *depth,
+                                            const uint16_t *context, const float *grad_out, int64_t sb,
+                                            int64_t sc, int64_t sy, int64_t sx, uint16_t *grad_depth,
+                                            uint16_t *grad_context, void *stream) {
+    MMT_REQUIRE_PTR(pos_memo);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    return lift_splat_backward_impl<bf16_t>("lift_splat_backward_bf16", B, N, D, HW, C, nx, ny, pos_memo, depth, context,
+                                            grad_out, sb, sc, sy, sx, grad_depth, grad_context, (hipStream_t)stream);
 }

@@ -95,6 +95,8 @@ class TrainStep(nn.Module):
             for m in self.model.modules():
                 if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
                     m.to(memory_format=torch.channels_last)
+        if self.use_cam:
+            self.model.backbone.hot_path_dtype = cfg.get("hot_path_dtype", "f32")
         self.net = self.model
         if world_size > 1:
             # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183; the

@@ -16,7 +16,7 @@ from torch import nn
 
 from ...ops.bev_geometry import frustum_geometry, lift_features, lift_splat
 from ...ops.bn_relu import ConvBNAct, bn_act
-from ...ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling, voxel_pooling_planned
+from ...ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling, voxel_pooling_bf16, voxel_pooling_planned
 from ..nets import BasicBlock, DeformConv2dPack, ResNet, SECONDFPN
 
 __all__ = ['LSSFPN']
@@ -116,6 +116,9 @@ class LSSFPN(nn.Module):
         # written and read twice per step at cfg2 -- is never materialised.  Same result up to fp32 summation
         # order.  False: the reference's op sequence (lift -> voxel_pooling) on the drop-in ops.
         self.fused_lift_splat = output_channels % 16 == 0 and output_channels <= 256
+        # Storage type of the hot-path operands: "bf16" keeps depth / context (fused path) or the
+        # lifted feature matrix and its gradient (unfused path) in bf16; products and sums stay fp32, the BEV map is fp32.
+        self.hot_path_dtype = "f32"
         self._plan_cache = {}     # calibration_id -> VoxelPoolingPlan (see _forward_single_sweep)
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
@@ -209,17 +212,21 @@ class LSSFPN(nn.Module):
             feats = lift_features(depth_used.float(), context.float())
             feature_map = voxel_pooling_planned(plan, feats.view(batch_size, -1, feats.shape[-1]))
         elif self.fused_lift_splat:
-            feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host)
+            if self.hot_path_dtype == "bf16":
+                feature_map = lift_splat(geom_xyz, depth_used.bfloat16(), context.bfloat16(), self._voxel_num_host)
+            else:
+                feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host)
         else:
             # lift straight into [B, N, D, fH, fW, C], then the drop-in voxel_pooling
-            feats = lift_features(depth_used.float(), context.float())
+            bf16 = self.hot_path_dtype == "bf16" and self.output_channels % 16 == 0
+            feats = lift_features(depth_used.float(), context.float(), torch.bfloat16 if bf16 else torch.float32)
             feats = feats.view(batch_size, num_cams, *feats.shape[1:])
             # geometry AFTER the lift: its small kernels give the 606 MB of non-temporal lift stores time
             # to drain before the pooling kernel starts reading them (bench roofline.avg_ms: see DESIGN 3.1)
             geom_xyz = self.get_geometry_voxels(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
                                                 mats_dict['intrin_mats'][:, sweep_index, ...],
                                                 mats_dict.get('bda_mat', None))
-            feature_map = voxel_pooling(geom_xyz, feats, self._voxel_num_host)
+            feature_map = (voxel_pooling_bf16 if bf16 else voxel_pooling)(geom_xyz, feats, self._voxel_num_host)
         # the reference's `.contiguous()` (:467) would transpose to NCHW; the pooled map is
         # already a dense channels_last tensor, which the BEV convs consume directly
         if is_return_depth:

@@ -95,7 +95,42 @@ class LiftFeatures(Function):
         return grad_depth, grad_context
 
 
-def lift_features(depth, context):
+class LiftFeaturesBF16(Function):
+    """The same lift with the big tensor stored in bf16: depth / context fp32 in,
+    feats bf16 [BN, D, fH, fW, C] = bf16(depth * context) out; backward reads a bf16 gradient, sums in fp32."""
+
+    @staticmethod
+    def forward(ctx, depth, context):
+        _need_cuda(depth, "depth")
+        _need_cuda(context, "context")
+        BN, D, fH, fW = depth.shape
+        C = context.shape[1]
+        if context.shape != (BN, C, fH, fW):
+            raise RuntimeError("context must be [BN, C, fH, fW] matching depth [BN, D, fH, fW]")
+        feats = torch.empty((BN, D, fH, fW, C), dtype=torch.bfloat16, device=depth.device)
+        with torch.cuda.device(depth.device):
+            _lib.call("mmt_lift_features_bf16", BN, D, fH * fW, C, depth.data_ptr(), context.data_ptr(), feats.data_ptr(), _stream())
+        ctx.save_for_backward(depth, context)
+        return feats
+
+    @staticmethod
+    def backward(ctx, grad_feats):
+        depth, context = ctx.saved_tensors
+        BN, D, fH, fW = depth.shape
+        C = context.shape[1]
+        grad_feats = grad_feats.to(torch.bfloat16).contiguous()
+        grad_depth = torch.empty_like(depth)
+        grad_context = torch.empty_like(context)
+        with torch.cuda.device(depth.device):
+            _lib.call("mmt_lift_features_backward_bf16", BN, D, fH * fW, C, depth.data_ptr(), context.data_ptr(),
+                      grad_feats.data_ptr(), grad_depth.data_ptr(), grad_context.data_ptr(), _stream())
+        return grad_depth, grad_context
+
+
+def lift_features(depth, context, storage_dtype=torch.float32):
+    """depth [BN,D,fH,fW] x context [BN,C,fH,fW] (fp32) -> feats [BN,D,fH,fW,C] in `storage_dtype` (fp32 or bf16)."""
+    if storage_dtype == torch.bfloat16:
+        return LiftFeaturesBF16.apply(depth.contiguous(), context.contiguous())
     return LiftFeatures.apply(depth.contiguous(), context.contiguous())
 
 
@@ -113,17 +148,20 @@ class LiftSplat(Function):
             raise RuntimeError("lift_splat: depth must be [B*N, D, fH, fW] and context [B*N, C, fH, fW]")
         if not (depth.is_cuda and context.is_cuda):
             raise RuntimeError("depth / context must be a CUDAtensor ")
-        depth_c = depth.float().contiguous()                               # point order [BN, D, HW]
-        ctx_nhwc = context.float().permute(0, 2, 3, 1).contiguous()        # free for channels_last nets
+        bf16 = depth.dtype == torch.bfloat16 and context.dtype == torch.bfloat16   # bf16 storage of both operands (row g1)
+        sd = torch.bfloat16 if bf16 else torch.float32
+        depth_c = depth.to(sd).contiguous()                                # point order [BN, D, HW]
+        ctx_nhwc = context.to(sd).permute(0, 2, 3, 1).contiguous()         # free for channels_last nets
         nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
         out = torch.zeros((B, ny, nx, C), dtype=torch.float32, device=depth.device)
         pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
         with torch.cuda.device(depth.device):
-            _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward", B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(),
+            _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward_bf16" if bf16 else "mmt_lift_splat_forward", B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(),
                       depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), pos_memo.data_ptr(),
                       _lib.VP_WRITE_DROPPED, _stream())
         ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
         ctx.dims = (B, N, D, HW, C, nx, ny)
+        ctx.bf16 = bf16
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -136,12 +174,13 @@ class LiftSplat(Function):
         grad_depth = torch.empty_like(depth_c)
         grad_ctx = torch.empty_like(ctx_nhwc)
         with torch.cuda.device(depth_c.device):
-            _lib.timed_call("lift_splat_backward", "mmt_lift_splat_backward", B, N, D, HW, C, nx, ny, pos_memo.data_ptr(),
+            _lib.timed_call("lift_splat_backward", "mmt_lift_splat_backward_bf16" if ctx.bf16 else "mmt_lift_splat_backward", B, N, D, HW, C, nx, ny, pos_memo.data_ptr(),
                       depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
                       grad_depth.data_ptr(), grad_ctx.data_ptr(), _stream())
         return None, grad_depth, grad_ctx.permute(0, 3, 1, 2), None
 
 
 def lift_splat(geom_xyz, depth, context, voxel_num):
-    """geom int32 [B,N,D,fH,fW,3], depth [B*N,D,fH,fW], context [B*N,C,fH,fW] -> BEV [B,C,ny,nx]."""
+    """geom int32 [B,N,D,fH,fW,3], depth [B*N,D,fH,fW], context [B*N,C,fH,fW] -> BEV fp32 [B,C,ny,nx].
+    depth AND context in bf16 select the bf16-storage kernels (fp32 products and sums, bf16 gradients back)."""
     return LiftSplat.apply(geom_xyz.contiguous(), depth, context, voxel_num)

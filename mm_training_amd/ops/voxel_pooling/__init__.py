@@ -7,5 +7,6 @@ from . import voxel_pooling_ext  # noqa: F401  (importable like the reference's 
 from .plan import VoxelPoolingPlan, voxel_pooling_planned  # noqa: F401  (cached-sort variant)
 
 voxel_pooling = _op.voxel_pooling
+voxel_pooling_bf16 = _op.voxel_pooling_bf16      # bf16 feature storage, fp32 accumulate
 
-__all__ = ("voxel_pooling", "voxel_pooling_ext", "VoxelPoolingPlan", "voxel_pooling_planned")
+__all__ = ("voxel_pooling", "voxel_pooling_bf16", "voxel_pooling_ext", "VoxelPoolingPlan", "voxel_pooling_planned")

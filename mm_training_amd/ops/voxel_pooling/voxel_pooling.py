@@ -78,3 +78,48 @@ class VoxelPooling(Function):
 
 
 voxel_pooling = VoxelPooling.apply
+
+
+class VoxelPoolingBF16(Function):
+    """Same op with bf16 feature storage (SURVEY section 8 row g1 / BASELINE configs[4]): ``input_features`` bf16,
+    fp32 accumulation, fp32 ``[B, C, ny, nx]`` result; the gradient comes back as bf16 (the gathered fp32 BEV-gradient
+    row rounded to nearest even).  Not part of the reference's surface -- its extension rejects non-float32 tensors."""
+
+    @staticmethod
+    def forward(ctx, geom_xyz, input_features, voxel_num):
+        assert geom_xyz.is_contiguous()
+        assert input_features.is_contiguous()
+        ctx.mark_non_differentiable(geom_xyz)
+        feat_shape = input_features.shape
+        geom_xyz = geom_xyz.reshape(geom_xyz.shape[0], -1, geom_xyz.shape[-1])
+        input_features = input_features.reshape(geom_xyz.shape[0], -1, input_features.shape[-1])
+        assert geom_xyz.shape[1] == input_features.shape[1]
+        batch_size, num_points, num_channels = input_features.shape
+        nx, ny, nz = _voxel_num_to_ints(voxel_num)
+        output_features = torch.zeros((batch_size, ny, nx, num_channels), dtype=torch.float32, device=input_features.device)
+        pos_memo = torch.empty((batch_size, num_points, 3), dtype=torch.int32, device=input_features.device)
+        voxel_pooling_ext.voxel_pooling_forward_wrapper_bf16(
+            batch_size, num_points, num_channels, nx, ny, nz, geom_xyz, input_features, output_features, pos_memo,
+            flags=_lib.VP_WRITE_DROPPED)
+        ctx.save_for_backward(pos_memo)
+        ctx.feat_shape = feat_shape
+        ctx.grid = (nx, ny)
+        return output_features.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_output_features):
+        (pos_memo,) = ctx.saved_tensors
+        nx, ny = ctx.grid
+        batch_size, num_points, _ = pos_memo.shape
+        num_channels = ctx.feat_shape[-1]
+        grad_input_features = torch.empty(ctx.feat_shape, dtype=torch.bfloat16, device=pos_memo.device)
+        workspace = torch.empty(
+            voxel_pooling_ext.backward_workspace_elems(batch_size, num_points, num_channels, nx, ny),
+            dtype=torch.float32, device=pos_memo.device)
+        voxel_pooling_ext.voxel_pooling_backward_wrapper_bf16(
+            batch_size, num_points, num_channels, nx, ny, pos_memo, grad_output_features.float(),
+            grad_input_features, workspace)
+        return None, grad_input_features, None
+
+
+voxel_pooling_bf16 = VoxelPoolingBF16.apply

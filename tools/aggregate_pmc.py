@@ -1,32 +1,61 @@
 #!/usr/bin/env python3
-"""Average per launch of the rocprofv3 --pmc counters for the mmt kernels (argument: one output
-directory per counter pass) -> JSON on stdout (the layout bench.py's pmc_traffic() reads)."""
+"""Average per launch of the rocprofv3 --pmc counters for the libmmt_hip kernels (arguments: a label for the measured
+command, then one output directory per counter pass) -> JSON on stdout (the layout bench.py's pmc_traffic() reads:
+profiles/r02_pmc_<config>.json)."""
 import csv
 import glob
 import json
 import os
 import sys
 
-KERNELS = ("vp_fwd_seg_gather", "vp_bwd_prepare", "vp_bwd_rows_vec4", "vp_planned_items", "vp_planned_fold")
+# logical kernel name <- (substring of the demangled name, further substrings that must ALL be present)
+KERNELS = [
+    ("lift_splat_forward", ("vp_fwd_seg_gather<float", ", true>")),
+    ("lift_splat_forward_bf16", ("vp_fwd_seg_gather<unsigned short", ", true>")),
+    ("vp_fwd_seg_gather", ("vp_fwd_seg_gather<float", ", false>")),
+    ("vp_fwd_seg_gather_bf16", ("vp_fwd_seg_gather<unsigned short", ", false>")),
+    ("vp_bwd_prepare", ("vp_bwd_prepare",)),
+    ("vp_bwd_rows_vec4", ("vp_bwd_rows_vec<float",)),
+    ("vp_bwd_rows_bf16", ("vp_bwd_rows_vec<unsigned short",)),
+    ("lift_splat_backward", ("lift_splat_backward_kernel<float",)),
+    ("lift_splat_backward_bf16", ("lift_splat_backward_kernel<unsigned short",)),
+    ("vp_planned_items", ("vp_planned_items",)), ("vp_planned_fold", ("vp_planned_fold",)),
+    ("lift_kernel", ("lift_kernel<",)), ("lift_kernel_bf16", ("lift_kernel_bf16",)), ("lift_backward_vec4", ("lift_backward_vec4",)),
+    ("vox_link", ("vox_link",)), ("vox_heads", ("vox_heads",)), ("vox_emit", ("vox_emit",)),
+    ("fill_i32_kernel", ("fill_i32_kernel",)), ("scatter_map_kernel", ("scatter_map_kernel",)),
+    ("scatter_write_nhwc_kernel", ("scatter_write_nhwc_kernel",)), ("scatter_backward_nhwc_kernel", ("scatter_backward_nhwc_kernel",)),
+    ("dcn_col2im", ("dcn_col2im",)), ("dcn_im2col", ("dcn_im2col",)),
+    ("bev_warp_kernel", ("bev_warp_kernel",)), ("bev_warp_backward_gather", ("bev_warp_backward_gather",)),
+]
+
+
+def logical(name):
+    for key, subs in KERNELS:
+        if all(s in name for s in subs):
+            return key
+    return None
+
+
+label = sys.argv[1]
 acc = {}
-for d in sys.argv[1:]:
+for d in sys.argv[2:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         per_dispatch = {}
         for r in csv.DictReader(open(f)):
-            k = next((k for k in KERNELS if k in r["Kernel_Name"]), None)
+            k = logical(r["Kernel_Name"])
             if k is None:
                 continue
             key = (k, r["Dispatch_Id"], r["Counter_Name"])
             per_dispatch[key] = per_dispatch.get(key, 0.0) + float(r["Counter_Value"])   # sum over XCD rows
         for (k, _, c), v in per_dispatch.items():
             acc.setdefault(k, {}).setdefault(c, []).append(v)
-res = {"note": "rocprofv3 --pmc, one counter group per pass (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum "
-               "TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum), command: python bench.py --mode hotpath --steps 5 "
-               "--warmup 2 (cfg2, rig geometry, B=4); averages per launch (tools/collect_profiles.sh). FETCH_SIZE/"
-               "WRITE_SIZE are KiB. gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the "
-               "128-byte read requests of wide (16 B/lane) loads at 64 B, so traffic_bytes = (2*FETCH_SIZE + "
-               "WRITE_SIZE)*1024; cross-check: TCC_EA0_RDREQ_sum*128 B reads, TCC_EA0_WRREQ_sum*64 B writes+atomics.",
-       "kernels": {}}
+res = {"note": "rocprofv3 --pmc, one counter group per pass (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum "
+               "TCC_EA0_ATOMIC_sum TCC_HIT_sum); averages per launch (tools/collect_profiles.sh). FETCH_SIZE / WRITE_SIZE are KiB. "
+               "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128-byte read requests of wide "
+               "(16 B/lane) loads at 64 B, so traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; the guide calls other access widths "
+               "uncalibrated -- for the LiDAR kernels (4- and 8-byte scattered accesses, 64-bit atomics) read the figure as an upper "
+               "bound. Cross-check: TCC_EA0_RDREQ_sum*128 B reads, TCC_EA0_WRREQ_sum*64 B writes+atomics.",
+       "command": label, "kernels": {}}
 for k, ctrs in sorted(acc.items()):
     e = {c: sum(v) / len(v) for c, v in sorted(ctrs.items())}
     e["launches"] = max(len(v) for v in ctrs.values())
