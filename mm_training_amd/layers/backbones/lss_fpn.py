@@ -161,10 +161,10 @@ class LSSFPN(nn.Module):
         return frustum_geometry(self.frustum.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
 
     def get_cam_feats(self, imgs):
-        batch_size, num_sweeps, num_cams, num_channels, imH, imW = imgs.shape
-        imgs = imgs.flatten().view(batch_size * num_sweeps * num_cams, num_channels, imH, imW)
-        img_feats = self.img_neck(self.img_backbone(imgs))[0]
-        return img_feats.reshape(batch_size, num_sweeps, num_cams, *img_feats.shape[1:])
+        """[B, S, N, 3, H, W] images -> [B, S, N, C', fH, fW] neck features (lss_fpn.py:363-379)."""
+        lead = imgs.shape[:3]
+        feats = self.img_neck(self.img_backbone(imgs.reshape(-1, *imgs.shape[3:])))[0]
+        return feats.view(*lead, *feats.shape[1:])
 
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, depth_oracle, is_return_depth=False):
         batch_size, num_sweeps, num_cams = sweep_imgs.shape[:3]
@@ -234,18 +234,14 @@ class LSSFPN(nn.Module):
         return feature_map
 
     def forward(self, sweep_imgs, mats_dict, depth_oracle=None, timestamps=None, is_return_depth=False):
-        num_sweeps = sweep_imgs.shape[1]
-        key_frame_res = self._forward_single_sweep(0, sweep_imgs[:, 0:1, ...], mats_dict, depth_oracle,
-                                                   is_return_depth=is_return_depth)
-        if num_sweeps == 1:
-            return key_frame_res
-        key_frame_feature = key_frame_res[0] if is_return_depth else key_frame_res
-        ret_feature_list = [key_frame_feature]
-        for sweep_index in range(1, num_sweeps):
-            with torch.no_grad():
-                ret_feature_list.append(self._forward_single_sweep(
-                    sweep_index, sweep_imgs[:, sweep_index:sweep_index + 1, ...], mats_dict, depth_oracle,
-                    is_return_depth=False))
-        if is_return_depth:
-            return torch.cat(ret_feature_list, 1), key_frame_res[1]
-        return torch.cat(ret_feature_list, 1)
+        """Key frame with gradients, older sweeps (if any; the aiMotive loader feeds one) without, BEV maps stacked
+        on the channel axis (lss_fpn.py:469-529).  Returns the map, or (map, key-frame depth) if is_return_depth."""
+        first = self._forward_single_sweep(0, sweep_imgs[:, :1], mats_dict, depth_oracle, is_return_depth=is_return_depth)
+        sweeps = sweep_imgs.shape[1]
+        if sweeps == 1:
+            return first
+        bev0, depth0 = first if is_return_depth else (first, None)
+        with torch.no_grad():
+            older = [self._forward_single_sweep(k, sweep_imgs[:, k:k + 1], mats_dict, depth_oracle) for k in range(1, sweeps)]
+        stacked = torch.cat([bev0] + older, 1)
+        return (stacked, depth0) if is_return_depth else stacked

@@ -190,15 +190,26 @@ class BEVDepthHead(nn.Module):
         return heatmaps, anno_boxes, inds, masks
 
     # --------------------------------------------------------------------- loss
-    def loss(self, targets, preds_dicts, **kwargs):
+    def loss_normalisers(self, targets):
+        """[2 * n_task] tensor: per task the number of positive heatmap cells (bev_depth_head.py:273-276) and of masked
+        box slots (:300-301) -- the two quantities the reference mean-reduces across ranks."""
+        heatmaps, _, _, masks = targets
+        return torch.stack([h.eq(1).float().sum() for h in heatmaps] + [m.float().sum() for m in masks])
+
+    def loss(self, targets, preds_dicts, normalisers=None, **kwargs):
+        """`normalisers` (optional): use these instead of the (cross-rank mean of the) batch's own -- a single process
+        that accumulates the gradients of N micro-batches reproduces N data-parallel ranks by passing the mean of the
+        micro-batches' `loss_normalisers` (tests/test_dp_gpu.py)."""
         heatmaps, anno_boxes, inds, masks = targets
         n_task = len(preds_dicts)
-        # all normalisers in one tensor -> one all-reduce, no host sync
-        norm = torch.stack([heatmaps[t].eq(1).float().sum() for t in range(n_task)]
-                           + [masks[t].float().sum() for t in range(n_task)])
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(norm)
-            norm = norm / dist.get_world_size()
+        if normalisers is not None:
+            norm = normalisers
+        else:
+            # all normalisers in one tensor -> one all-reduce, no host sync
+            norm = self.loss_normalisers(targets)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(norm)
+                norm = norm / dist.get_world_size()
         cls_norm = norm[:n_task].clamp(min=1)
         box_norm = norm[n_task:].clamp(min=1e-4)
         code_weights = self.code_weights

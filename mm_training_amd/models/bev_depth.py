@@ -37,12 +37,16 @@ def warp_affine_bev(x, mat23):
 
 
 class BEVDepth(nn.Module):
+    """Camera-only detector: LSSFPN camera branch -> BEV augmentation warp -> BEVDepthHead.
+    Constructor arguments and the attribute names other code reaches for (`backbone`, `head`, `is_train_depth`,
+    `bev_augment_image`, `get_targets`, `loss`) are the reference's (models/bev_depth.py:13-130)."""
+
     def __init__(self, backbone_conf, head_conf, is_train_depth=False, use_cam=True):
         super().__init__()
+        self.is_train_depth = is_train_depth
+        self.head = BEVDepthHead(**head_conf)
         if use_cam:
             self.backbone = LSSFPN(**backbone_conf)
-        self.head = BEVDepthHead(**head_conf)
-        self.is_train_depth = is_train_depth
 
     def bev_augment_image(self, x, bda_mat):
         """models/bev_depth.py:69-84: rotate/flip the camera BEV by the BEV-aug matrix about
@@ -67,15 +71,18 @@ class BEVDepth(nn.Module):
     def loss(self, targets, preds_dicts):
         return self.head.loss(targets, preds_dicts)
 
+    def _camera_bev(self, images, mats_dict, depth_oracle, timestamps):
+        """(un-augmented camera BEV map, depth distribution) of the key frame."""
+        return self.backbone(images, mats_dict, depth_oracle, timestamps, is_return_depth=True)
+
     def forward(self, x, mats_dict, timestamps=None):
-        imgs, _ = x
-        imgs_bev, depth_pred = self.backbone(imgs, mats_dict, None, timestamps, is_return_depth=True)
-        imgs_bev = self.bev_augment_image(imgs_bev, mats_dict['bda_mat'])
-        return self.head(imgs_bev), depth_pred
+        cam_bev, depth = self._camera_bev(x[0], mats_dict, None, timestamps)
+        return self.head(self.bev_augment_image(cam_bev, mats_dict['bda_mat'])), depth
 
 
 class BEVFuseLayer(nn.Module):
-    """models/bev_depth.py:133-145."""
+    """models/bev_depth.py:133-145: 3x3 convolution of the camera|LiDAR stack, gated channel-wise by a squeeze
+    (global average -> 1x1 convolution -> sigmoid) of its own output."""
 
     def __init__(self, in_channels):
         super().__init__()
@@ -86,54 +93,47 @@ class BEVFuseLayer(nn.Module):
         self.activation = nn.Sigmoid()
 
     def forward(self, x):
-        x = self.conv_3(x)
-        return x * self.activation(self.conv_1(self.avg_pool(x)))
+        mixed = self.conv_3(x)
+        gate = self.activation(self.conv_1(self.avg_pool(mixed)))
+        return mixed * gate
 
 
 class BEVDepthLiDAR(BEVDepth):
+    """Camera + LiDAR/radar detector (models/bev_depth.py:148-200).  `forward((img, lidar), mats_dict, lidar_oracle,
+    timestamps)` -> `(preds, depth_pred, lidar_bev, cam_bev)`; a disabled modality contributes None."""
+
     def __init__(self, backbone_conf, head_conf, lidar_conf, is_train_depth=False, use_cam=True,
                  use_lidar=True, fuse_layer_in_channels=144):
         super().__init__(backbone_conf, head_conf, is_train_depth=False, use_cam=use_cam)
-        self.use_cam = use_cam
-        self.use_lidar = use_lidar
+        self.use_cam, self.use_lidar = use_cam, use_lidar
         self.sync_free_lidar = os.environ.get("MMT_LIDAR_SYNC_FREE", "1") != "0"
         if use_lidar:
             self.lidar_encoder = LidarEncoder(**{k: v for k, v in dict(lidar_conf).items() if k != 'type'})
         if use_cam and use_lidar:
             self.bev_fuse = BEVFuseLayer(in_channels=fuse_layer_in_channels)
 
+    def _lidar_bev(self, clouds):
+        if self.sync_free_lidar:
+            # voxelize + mean + scatter in the voxelizer's fixed-capacity layout: no device->host copy of the voxel
+            # count in the middle of the step (LidarEncoder.forward_bev)
+            return self.lidar_encoder.forward_bev(clouds)
+        # the reference's three calls (models/bev_depth.py:181-183); voxelize() returns compacted [M, ...]
+        # tensors, i.e. M travels to the host
+        enc = self.lidar_encoder
+        voxels, num_points, coors = enc.voxelize(clouds)
+        return enc.pts_middle_encoder(enc.pts_voxel_encoder(voxels, num_points, coors), coors, len(clouds))
+
     def forward(self, x, mats_dict, lidar_oracle=None, timestamps=None):
-        img, lidar = x
-        depth_pred, img_bev, lidar_bev, lidar_bev_ret, cam_bev_ret = None, None, None, None, None
-        if self.use_cam:
-            img_bev, depth_pred = self.backbone(img, mats_dict, lidar_oracle, timestamps, is_return_depth=True)
-            if not self.use_lidar:
-                img_bev = self.bev_augment_image(img_bev, mats_dict['bda_mat'])
-                cam_bev_ret = img_bev
-        if self.use_lidar:
-            if self.sync_free_lidar:
-                # same three stages in the voxelizer's fixed-capacity layout: no device->host copy of
-                # the voxel count in the middle of the step (LidarEncoder.forward_bev)
-                lidar_bev = self.lidar_encoder.forward_bev(lidar)
-            else:
-                # the reference's call sequence (models/bev_depth.py:180-183); voxelize() returns
-                # compacted [M, ...] tensors, i.e. M travels to the host
-                batch_size = len(lidar)
-                voxels, num_points, coors = self.lidar_encoder.voxelize(lidar)
-                voxel_feats = self.lidar_encoder.pts_voxel_encoder(voxels, num_points, coors)
-                lidar_bev = self.lidar_encoder.pts_middle_encoder(voxel_feats, coors, batch_size)
-            lidar_bev_ret = lidar_bev
-        if self.use_lidar and self.use_cam:
-            if lidar_bev.shape[-2:] != img_bev.shape[-2:]:
-                lidar_bev = F.interpolate(lidar_bev, size=(img_bev.shape[2], img_bev.shape[3]))
-            # warp (models/bev_depth.py:176) + concat (:189) in one pass: the warped camera map is
-            # written straight into the camera|LiDAR buffer
-            fused_in = bev_warp_concat(img_bev, mats_dict['bda_mat'], lidar_bev)
-            cam_bev_ret = fused_in[:, :img_bev.shape[1]]
-            bev_fused = self.bev_fuse(fused_in)
-        elif self.use_cam:
-            bev_fused = img_bev
-        else:
-            bev_fused = lidar_bev
-        preds = self.head(bev_fused)
-        return preds, depth_pred, lidar_bev_ret, cam_bev_ret
+        images, clouds = x
+        cam_map, depth = self._camera_bev(images, mats_dict, lidar_oracle, timestamps) if self.use_cam else (None, None)
+        lidar_map = self._lidar_bev(clouds) if self.use_lidar else None
+        if cam_map is None:
+            return self.head(lidar_map), depth, lidar_map, None
+        if lidar_map is None:
+            cam_aug = self.bev_augment_image(cam_map, mats_dict['bda_mat'])
+            return self.head(cam_aug), depth, None, cam_aug
+        # both: nearest-resize the pillar canvas onto the camera grid (:188-190), then BEV-aug warp (:176) and channel
+        # concat (:189) in one pass -- the warped camera map is written straight into the camera|LiDAR buffer
+        lidar_small = lidar_map if lidar_map.shape[-2:] == cam_map.shape[-2:] else F.interpolate(lidar_map, size=cam_map.shape[-2:])
+        stacked = bev_warp_concat(cam_map, mats_dict['bda_mat'], lidar_small)
+        return self.head(self.bev_fuse(stacked)), depth, lidar_map, stacked[:, :cam_map.shape[1]]

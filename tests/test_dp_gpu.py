@@ -1,8 +1,18 @@
-"""GPU, world_size 2 (two processes sharing cuda:0, gloo rendezvous on 127.0.0.1): the data-parallel
-step of the full tiny model through the HIP kernels.  SURVEY section 8e correctness check: two ranks
-with batch b each reproduce the detection-loss gradient of one process with batch 2b (eval-mode
-BatchNorm / dropout so that samples do not interact; the depth loss is normalised per rank in the
-reference and is left out)."""
+"""GPU, world_size 2 (two processes sharing cuda:0, gloo rendezvous on 127.0.0.1): the data-parallel step of the full
+tiny model through the HIP kernels.  SURVEY section 8e correctness check, both readings:
+
+  (B) N ranks x batch b  ==  ONE process accumulating the gradients of the same N micro-batches of b samples (each
+      micro-batch loss normalised by the mean of the micro-batches' normalisers, which is what the ranks' single
+      all-reduce computes; gradients averaged, which is what DDP does) -- detection AND depth loss;
+  (A) N ranks x batch b  ==  one process with batch N*b -- detection loss only (the reference normalises the depth
+      loss per rank, exps/mm_training_aim.py:165-178).
+
+Eval-mode BatchNorm / dropout so that samples do not interact.  The camera branch runs its DETERMINISTIC kernels (a
+`calibration_id` selects the cached-plan forward, atomics-free and bit-reproducible; the pooling backward is a pure
+gather), so what remains between the runs is fp32 summation order inside MIOpen's weight-gradient kernels and the DCN
+col2im atomics.  Bar: every gradient tensor within 1e-4 of the reference, measured against that tensor's own magnitude
+with a floor of 1e-3 of the largest gradient magnitude of the model (a tensor whose gradient is ~0 cannot be compared
+relative to itself).  A data-parallel bug (missing all-reduce, wrong loss normaliser, wrong shard) gives O(1) errors."""
 import os
 import socket
 
@@ -12,6 +22,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
 
 
 def _free_port():
@@ -29,49 +41,77 @@ def _slice(batch, lo, hi):
     return imgs[lo:hi], m, pcs[lo:hi], boxes[lo:hi], labels[lo:hi]
 
 
-def _grads(ts, batch):
+def _make(world):
+    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
+    dev = torch.device("cuda", 0)
+    cfg = make_config("tiny")
+    torch.manual_seed(0)
+    ts = TrainStep(cfg, dev, world_size=world)
     ts.model.eval()
-    ts.optimizer.zero_grad(set_to_none=True)
-    _, det, _ = ts.forward_loss(batch)
-    det.backward()
-    return {n: p.grad.detach().float().cpu().clone() for n, p in ts.model.named_parameters() if p.grad is not None}, float(det.detach())
+    ts.model.backbone.fused_lift_splat = False          # with a calibration id: cached-plan forward (no atomics)
+    full = synthetic_batch(cfg, dev, seed=7, batch_size=4)
+    return ts, full
+
+
+def _with_id(batch, tag):
+    imgs, mats, pcs, boxes, labels = batch
+    return imgs, dict(mats, calibration_id=("dp-test", tag)), pcs, boxes, labels
+
+
+def _grads(ts):
+    return {n: p.grad.detach().float().cpu().clone() for n, p in ts.model.named_parameters() if p.grad is not None}
 
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    cfg = make_config("tiny")
-    torch.manual_seed(0)
-    ts = TrainStep(cfg, dev, world_size=world)
-    full = synthetic_batch(cfg, dev, seed=7, batch_size=2 * world)
-    grads, det = _grads(ts, _slice(full, 2 * rank, 2 * rank + 2))
+    torch.cuda.set_device(0)
+    ts, full = _make(world)
+    shard = _with_id(_slice(full, 2 * rank, 2 * rank + 2), rank)
+    res = {}
+    for key, with_depth in (("det", False), ("full", True)):
+        ts.optimizer.zero_grad(set_to_none=True)
+        loss, det, dep = ts.forward_loss(shard)
+        (loss if with_depth else det).backward()
+        res[key] = _grads(ts)
     if rank == 0:
-        out["grads"], out["det"] = grads, det
+        out.update(res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_single_process_double_batch(mmt_lib):
+def _compare(got, ref):
+    assert set(got) == set(ref) and len(ref) > 50
+    scale = max(float(v.abs().max()) for v in ref.values())
+    worst = sorted(((float((got[n] - ref[n]).abs().max()) / (float(ref[n].abs().max()) + 1e-3 * scale), n) for n in ref), reverse=True)
+    return worst[:5]
+
+
+def test_two_ranks_equal_gradient_accumulation_and_double_batch(mmt_lib):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
-    dev = torch.device("cuda", 0)
-    cfg = make_config("tiny")
-    torch.manual_seed(0)
-    ts = TrainStep(cfg, dev, world_size=1)
-    ref, _ = _grads(ts, synthetic_batch(cfg, dev, seed=7, batch_size=4))
-    got = out["grads"]
-    assert set(got) == set(ref) and len(ref) > 50
-    rel = {}
-    for n in ref:
-        rel[n] = ((got[n] - ref[n]).norm() / ref[n].norm().clamp(min=1e-12)).item()
-    top = sorted(rel.items(), key=lambda kv: -kv[1])[:6]
-    vals = sorted(rel.values())
-    # A data-parallel bug (missing all-reduce, wrong loss normaliser, wrong shard) gives O(1) errors.  What is
-    # tolerated here: fp32 atomics of the pooling / DCN kernels, and MIOpen picking different convolution
-    # solvers in different processes on a box with a cold kernel cache (seen: 3 % on one head weight).
-    assert vals[len(vals) // 2] <= 2e-3 and top[0][1] <= 8e-2, top
+    ts, full = _make(1)
+    micro = [_with_id(_slice(full, 0, 2), 0), _with_id(_slice(full, 2, 4), 1)]
+    # (B) gradient accumulation over the two micro-batches, normalisers = their mean (the ranks' all-reduce)
+    targets = [ts.model.get_targets(m[3], m[4]) for m in micro]
+    norm = torch.stack([ts.model.head.loss_normalisers(t) for t in targets]).mean(0)
+    for key, with_depth in (("det", False), ("full", True)):
+        ts.optimizer.zero_grad(set_to_none=True)
+        for m, t in zip(micro, targets):
+            imgs, mats, pcs, _, _ = m
+            depth_labels = ts.get_depth_labels(imgs, mats, pcs)
+            preds, depth_preds, _, _ = ts.net((ts.normalize_images(imgs), pcs), mats, None)
+            loss = ts.model.head.loss(t, preds, normalisers=norm)
+            if with_depth:
+                loss = loss + ts.get_depth_loss(depth_labels, depth_preds)
+            (loss / len(micro)).backward()                # DDP averages the ranks' gradients
+        worst = _compare(out[key], _grads(ts))
+        assert worst[0][0] <= TOL, (key, worst)
+    # (A) one process, batch 4, detection loss (its normalisers are the global sums = N x the ranks' mean; the
+    # gradient of sum_r S_r / sum_r N_r equals the ranks' averaged gradient of S_r / mean(N))
+    ts.optimizer.zero_grad(set_to_none=True)
+    _, det, _ = ts.forward_loss(_with_id(full, "all"))
+    det.backward()
+    worst = _compare(out["det"], _grads(ts))
+    assert worst[0][0] <= TOL, ("batch-4", worst)

@@ -1,0 +1,82 @@
+"""INTEGRATION.md section B is executable: the code block a maintainer of the reference would drop in as
+`ops/voxel_pooling/voxel_pooling_ext.py` is extracted from the document, loaded as that extension module and driven
+exactly the way the reference's autograd function drives its pybind module (ops/voxel_pooling/voxel_pooling.py:37-52:
+caller zero-fills `output_features`, pre-fills `pos_memo` with -1, passes 0-dim `voxel_num[i]` tensors, plain
+`mmt_voxel_pooling_forward` with no flags), against the reference's own known-answer vectors and edge set."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_stub():
+    from mm_training_amd import _lib
+    _lib.lib()                                   # builds nothing; makes sure the library exists (and torch is loaded first)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## B. Replace only the native extension"):text.index("## C. Other entry points")]
+    code = sec[sec.index("```python\n") + len("```python\n"):]
+    code = code[:code.index("\n```")]
+    assert "/path/to/libmmt_hip.so" in code
+    mod = types.ModuleType("voxel_pooling_ext")
+    exec(compile(code.replace("/path/to/libmmt_hip.so", _lib.LIB_PATH), "INTEGRATION.md#B", "exec"), mod.__dict__)
+    return mod
+
+
+def test_stub_loads_binds_and_rejects_like_the_reference(mmt_lib):
+    """CPU: the block compiles, finds every symbol it binds, and raises the reference's CHECK_INPUT errors
+    (voxel_pooling_forward.cpp:10-16,26-27) before anything is launched."""
+    ext = _load_stub()
+    assert callable(ext.voxel_pooling_forward_wrapper) and callable(ext.voxel_pooling_backward_wrapper)
+    geom = torch.zeros(1, 8, 3, dtype=torch.int32)
+    feats = torch.zeros(1, 8, 4)
+    with pytest.raises(RuntimeError, match="must be a CUDAtensor"):
+        ext.voxel_pooling_forward_wrapper(1, 8, 4, 2, 2, 1, geom, feats, torch.zeros(1, 2, 2, 4), torch.zeros(1, 8, 3, dtype=torch.int32))
+
+
+def _reference_forward(ext, geom_xyz, input_features, voxel_num):
+    """The call sequence of VoxelPooling.forward (ops/voxel_pooling/voxel_pooling.py:30-55), restated."""
+    geom_xyz = geom_xyz.reshape(geom_xyz.shape[0], -1, geom_xyz.shape[-1])
+    input_features = input_features.reshape(geom_xyz.shape[0], -1, input_features.shape[-1])
+    batch_size, num_points, num_channels = input_features.shape[0], input_features.shape[1], input_features.shape[2]
+    output_features = input_features.new_zeros(batch_size, voxel_num[1], voxel_num[0], num_channels)
+    pos_memo = geom_xyz.new_ones(batch_size, num_points, 3) * -1
+    ext.voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, voxel_num[0], voxel_num[1], voxel_num[2],
+                                      geom_xyz, input_features, output_features, pos_memo)
+    return output_features, pos_memo
+
+
+@pytest.mark.gpu
+def test_stub_reproduces_the_reference_known_answer_test(mmt_lib, golden):
+    ext = _load_stub()
+    g = golden["vp_ref_test"]
+    voxel_num = torch.tensor([128, 128, 1], dtype=torch.int64, device="cuda")       # what lss_fpn.py:464 passes (`self.voxel_num.cuda()`)
+    out, pos = _reference_forward(ext, torch.from_numpy(g["geom"]).cuda(), torch.from_numpy(g["feats"]).cuda(), voxel_num)
+    assert np.array_equal(pos.cpu().numpy(), g["pos_memo"])
+    assert np.abs(out.cpu().numpy() - g["out_nhwc"]).max() <= 1e-4
+    assert torch.allclose(out.cpu(), torch.from_numpy(g["out_nhwc"]), 1e-3)          # the reference test's criterion
+    # the optional HIP backward of the stub against the gradient the reference's own ATen backward produced
+    go = torch.ones(2, 80, 128, 128, device="cuda")
+    gi = torch.zeros(2, 6000, 80, device="cuda")
+    ext.voxel_pooling_backward_wrapper(pos, go, gi)
+    kept = torch.from_numpy(g["pos_memo"][..., 0] != -1)
+    assert torch.equal(gi.cpu()[kept], torch.ones(int(kept.sum()), 80)) and float(gi.cpu()[~kept].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c1", "c3", "c64", "c80", "c81", "alldrop", "samecell"])
+def test_stub_on_the_edge_set(mmt_lib, golden, case):
+    """Every channel count (1, 3, 64, 80, 81), an all-dropped batch and 500 points in one cell through the PLAIN entry
+    point the stub binds (no flags, caller-prefilled pos_memo), plus the stub's backward vs the reference's gradient."""
+    ext = _load_stub()
+    g = golden["vp_edge"]
+    voxel_num = torch.from_numpy(g["grid"]).cuda()
+    out, pos = _reference_forward(ext, torch.from_numpy(g[case + "_geom"]).cuda(), torch.from_numpy(g[case + "_feats"]).cuda(), voxel_num)
+    assert np.array_equal(pos.cpu().numpy(), g[case + "_pos_memo"])
+    assert (out.permute(0, 3, 1, 2).cpu() - torch.from_numpy(g[case + "_out_nchw"])).abs().max().item() <= 1e-4
+    gi = torch.zeros(g[case + "_feats"].shape, device="cuda")
+    ext.voxel_pooling_backward_wrapper(pos, torch.from_numpy(g[case + "_grad_out"]).cuda(), gi)
+    assert np.array_equal(gi.cpu().numpy(), g[case + "_grad_in"])
