@@ -233,6 +233,15 @@ int mmt_dcn_im2col(int B, int H, int W, int C, int groups, const float *x, const
                    float *col, void *stream);
 int mmt_dcn_col2im(int B, int H, int W, int C, int groups, const float *x, const float *offset,
                    const float *grad_col, float *grad_x, float *grad_offset, void *stream);
+/* The same backward without global atomics (ABI 4): the bilinear-corner contributions are sorted by destination pixel
+ * (one LDS counting sort per image), grad_x is then a pure segmented gather -- OVERWRITTEN, the caller need not
+ * zero-fill it -- and grad_offset a streaming reduction.  workspace: int32 [mmt_dcn_col2im_workspace_elems(B,H,W)]
+ * (device, any contents).  Needs H*W <= 4096 and C/groups/4 a power of two <= 64; otherwise MMT_ERR_BAD_SHAPE and
+ * mmt_dcn_col2im is the general form.  The order of the fp32 sums may differ between runs (as with the atomics). */
+int64_t mmt_dcn_col2im_workspace_elems(int B, int H, int W);
+int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x, const float *offset,
+                          const float *grad_col, float *grad_x, float *grad_offset, int32_t *workspace,
+                          int64_t workspace_elems, void *stream);
 
 /* ------------------------------------------------- bf16 feature storage
  * BASELINE configs[4] names bf16.  The reference has no behaviour for it -- its extension takes data_ptr<float>()

@@ -53,6 +53,8 @@ SIGNATURES = {
     "mmt_bn_relu_backward": (_c_int, [_c_i64, _c_int] + [_c_ptr] * 4 + [_c_int, _c_int] + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_dcn_im2col": (_c_int, [_c_int] * 5 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_dcn_col2im": (_c_int, [_c_int] * 5 + [_c_ptr] * 5 + [_c_ptr]),
+    "mmt_dcn_col2im_workspace_elems": (_c_i64, [_c_int] * 3),
+    "mmt_dcn_col2im_sorted": (_c_int, [_c_int] * 5 + [_c_ptr] * 6 + [_c_i64, _c_ptr]),
     "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr]),
     "mmt_voxelize_table_elems": (_c_i64, [_c_int, _c_ptr]),
     "mmt_voxelize_scratch_elems": (_c_i64, [_c_int, _c_i64]),

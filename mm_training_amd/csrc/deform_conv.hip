@@ -134,6 +134,166 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(int B, int H, int W, in
     }
 }
 
+// ---------------------------------------------------------------------------
+// col2im WITHOUT global atomics (the kernel above moves 1.24 GB of fp32 atomics at the DepthNet shape: 870 us).
+// With free offsets the set of (position, tap) pairs that reach a pixel is not bounded by a neighbourhood, so a
+// plain gather needs the contributions sorted by destination first.  Three kernels:
+//   dcn_plan_kernel        one workgroup per image: every (position, tap) has up to 4 bilinear corners; the corners
+//                          with non-zero weight are binned by destination pixel in LDS (count -> scan -> counting
+//                          sort) and leave as a per-pixel list of (source position, tap, weight) entries;
+//   dcn_offset_grad_kernel grad_offset[pos, tap] = sum_c grad_col * d(sample)/d(py, px): a streaming read of grad_col
+//                          with the four x rows of the tap gathered from L2, channel reduction across the wave;
+//   dcn_col2im_gather      grad_x[pixel, group] = sum over the pixel's list of  weight * grad_col[source, tap, group]:
+//                          one lane group (Cg/4 lanes, a float4 column each) per (pixel, weight group), rows summed in
+//                          registers, ONE plain store per output row -- grad_x is overwritten (no zero-fill needed).
+// The order of a pixel's list is the LDS arrival order, so the fp32 sum order may differ between runs (as with the
+// atomics before).
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanMaxHW = 4096;     // destination bins held in LDS
+
+struct DcnEntry { int src_tap; float w; };    // (source position inside the image << 4) | tap
+
+__global__ __launch_bounds__(kPlanThreads) void dcn_plan_kernel(int H, int W, const float *offset, int32_t *bin_off,
+                                                                DcnEntry *entries) {
+    __shared__ int cnt[kPlanMaxHW];
+    __shared__ int off[kPlanMaxHW + 1];
+    __shared__ int wsum[kPlanThreads / 64];
+    const int HW = H * W;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *ob = offset + (int64_t)b * HW * 18;
+    for (int i = tid; i < HW; i += kPlanThreads) cnt[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < HW * 9; e += kPlanThreads) {
+        const int pos = e / 9, k = e - pos * 9;
+        const int h = pos / W, w = pos - h * W, ky = k / 3, kx = k - ky * 3;
+        const Tap t = make_tap((float)(h + ky - 1) + ob[e * 2], (float)(w + kx - 1) + ob[e * 2 + 1], H, W);
+        if (t.w1 != 0.f) atomicAdd(&cnt[t.o1], 1);
+        if (t.w2 != 0.f) atomicAdd(&cnt[t.o2], 1);
+        if (t.w3 != 0.f) atomicAdd(&cnt[t.o3], 1);
+        if (t.w4 != 0.f) atomicAdd(&cnt[t.o4], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the HW counts: kPer consecutive bins per thread, wave scan, then the wave totals
+    constexpr int kPer = kPlanMaxHW / kPlanThreads;
+    int loc[kPer], sum = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int idx = tid * kPer + i;
+        loc[i] = idx < HW ? cnt[idx] : 0;
+        sum += loc[i];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int run = base + incl - sum;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int idx = tid * kPer + i;
+        if (idx < HW) { off[idx] = run; cnt[idx] = 0; }
+        run += loc[i];
+    }
+    if (tid == kPlanThreads - 1) off[HW] = run;
+    __syncthreads();
+    for (int i = tid; i <= HW; i += kPlanThreads) bin_off[(int64_t)b * (HW + 1) + i] = off[i];
+    DcnEntry *eb = entries + (int64_t)b * HW * 36;
+    for (int e = tid; e < HW * 9; e += kPlanThreads) {
+        const int pos = e / 9, k = e - pos * 9;
+        const int h = pos / W, w = pos - h * W, ky = k / 3, kx = k - ky * 3;
+        const Tap t = make_tap((float)(h + ky - 1) + ob[e * 2], (float)(w + kx - 1) + ob[e * 2 + 1], H, W);
+        const int st = (pos << 4) | k;
+        if (t.w1 != 0.f) eb[off[t.o1] + atomicAdd(&cnt[t.o1], 1)] = DcnEntry{st, t.w1};
+        if (t.w2 != 0.f) eb[off[t.o2] + atomicAdd(&cnt[t.o2], 1)] = DcnEntry{st, t.w2};
+        if (t.w3 != 0.f) eb[off[t.o3] + atomicAdd(&cnt[t.o3], 1)] = DcnEntry{st, t.w3};
+        if (t.w4 != 0.f) eb[off[t.o4] + atomicAdd(&cnt[t.o4], 1)] = DcnEntry{st, t.w4};
+    }
+}
+
+// one wave per (position, tap): lanes own float4 columns of the C channels
+__global__ __launch_bounds__(256) void dcn_offset_grad_kernel(int B, int H, int W, int C, int groups, const float *x,
+                                                              const float *offset, const float *grad_col,
+                                                              float *grad_offset) {
+    const int lane = threadIdx.x & 63;
+    const int64_t npos = (int64_t)B * H * W;
+    const int64_t nitems = npos * 9;
+    const int Cg = C / groups, C4 = C >> 2;
+    for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < nitems; it += (int64_t)gridDim.x * 4) {
+        const int64_t pos = it / 9;
+        const int k = (int)(it - pos * 9);
+        const int b = (int)(pos / (H * W));
+        const int hw = (int)(pos - (int64_t)b * H * W);
+        const int h = hw / W, w = hw - h * W, ky = k / 3, kx = k - ky * 3;
+        const Tap t = make_tap((float)(h + ky - 1) + offset[it * 2], (float)(w + kx - 1) + offset[it * 2 + 1], H, W);
+        const float *xb = x + (int64_t)b * H * W * C;
+        const float *x1 = xb + (int64_t)t.o1 * C, *x2 = xb + (int64_t)t.o2 * C;
+        const float *x3 = xb + (int64_t)t.o3 * C, *x4 = xb + (int64_t)t.o4 * C;
+        float gy = 0.f, gx = 0.f;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const int c = c4 * 4;
+            const int g = c / Cg, cin = c - g * Cg;
+            const float4 gc = *reinterpret_cast<const float4 *>(grad_col + ((int64_t)g * npos + pos) * (9 * Cg) + k * Cg + cin);
+            const float4 v1 = *reinterpret_cast<const float4 *>(x1 + c), v2 = *reinterpret_cast<const float4 *>(x2 + c);
+            const float4 v3 = *reinterpret_cast<const float4 *>(x3 + c), v4 = *reinterpret_cast<const float4 *>(x4 + c);
+            gy += gc.x * (t.dy1 * v1.x + t.dy2 * v2.x + t.dy3 * v3.x + t.dy4 * v4.x) + gc.y * (t.dy1 * v1.y + t.dy2 * v2.y + t.dy3 * v3.y + t.dy4 * v4.y) +
+                  gc.z * (t.dy1 * v1.z + t.dy2 * v2.z + t.dy3 * v3.z + t.dy4 * v4.z) + gc.w * (t.dy1 * v1.w + t.dy2 * v2.w + t.dy3 * v3.w + t.dy4 * v4.w);
+            gx += gc.x * (t.dx1 * v1.x + t.dx2 * v2.x + t.dx3 * v3.x + t.dx4 * v4.x) + gc.y * (t.dx1 * v1.y + t.dx2 * v2.y + t.dx3 * v3.y + t.dx4 * v4.y) +
+                  gc.z * (t.dx1 * v1.z + t.dx2 * v2.z + t.dx3 * v3.z + t.dx4 * v4.z) + gc.w * (t.dx1 * v1.w + t.dx2 * v2.w + t.dx3 * v3.w + t.dx4 * v4.w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gy += __shfl_xor(gy, o);
+            gx += __shfl_xor(gx, o);
+        }
+        if (lane == 0) {
+            grad_offset[it * 2] = gy;
+            grad_offset[it * 2 + 1] = gx;
+        }
+    }
+}
+
+// LPG lanes (a float4 column each) per (destination pixel, weight group); kU list entries in flight
+template <int LPG>
+__global__ __launch_bounds__(256) void dcn_col2im_gather(int B, int HW, int C, int groups, const float *grad_col,
+                                                         const int32_t *bin_off, const DcnEntry *entries, float *grad_x) {
+    constexpr int kU = 4;
+    const int Cg = C / groups;
+    const int64_t npos = (int64_t)B * HW;
+    const int64_t nitems = npos * groups;
+    const int grp = threadIdx.x / LPG, li = threadIdx.x - grp * LPG;
+    constexpr int kGroups = 256 / LPG;
+    for (int64_t item = (int64_t)blockIdx.x * kGroups + grp; item < nitems; item += (int64_t)gridDim.x * kGroups) {
+        const int64_t pix = item / groups;             // b * HW + destination pixel
+        const int g = (int)(item - pix * groups);
+        const int b = (int)(pix / HW);
+        const int dest = (int)(pix - (int64_t)b * HW);
+        const int beg = bin_off[(int64_t)b * (HW + 1) + dest], end = bin_off[(int64_t)b * (HW + 1) + dest + 1];
+        const DcnEntry *eb = entries + (int64_t)b * HW * 36;
+        const float *gcb = grad_col + ((int64_t)g * npos + (int64_t)b * HW) * (9 * Cg) + li * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = beg; j < end; j += kU) {
+            DcnEntry en[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) en[u] = eb[(j + u) < end ? (j + u) : (end - 1)];
+            float4 v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                v[u] = *reinterpret_cast<const float4 *>(gcb + ((int64_t)(en[u].src_tap >> 4) * 9 + (en[u].src_tap & 15)) * Cg);
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const float w = (j + u) < end ? en[u].w : 0.f;
+                acc = fma4(w, v[u], acc);
+            }
+        }
+        *reinterpret_cast<float4 *>(grad_x + pix * C + g * Cg + li * 4) = acc;
+    }
+}
+
 int check_dcn(int B, int H, int W, int C, int groups, const char *what) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || (C / groups) % 4 != 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: need C %% groups == 0 and (C/groups) %% 4 == 0 (B=%d H=%d W=%d C=%d groups=%d)",
@@ -171,4 +331,56 @@ extern "C" int mmt_dcn_col2im(int B, int H, int W, int C, int groups, const floa
     hipLaunchKernelGGL(dcn_col2im_kernel, dim3(mmt::stream_grid(npos, 4, 256 * 32)), dim3(256), 0,
                        (hipStream_t)stream, B, H, W, C, groups, x, offset, grad_col, grad_x, grad_offset);
     return mmt::check_launch("dcn_col2im");
+}
+
+extern "C" int64_t mmt_dcn_col2im_workspace_elems(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t HW = (int64_t)H * W;
+    return (int64_t)B * (HW + 1) + 2 * (int64_t)B * HW * 36 + 4;
+}
+
+extern "C" int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x,
+                                     const float *offset, const float *grad_col, float *grad_x,
+                                     float *grad_offset, int32_t *workspace, int64_t workspace_elems, void *stream) {
+    MMT_REQUIRE_PTR(x);
+    MMT_REQUIRE_PTR(offset);
+    MMT_REQUIRE_PTR(grad_col);
+    MMT_REQUIRE_PTR(grad_x);
+    MMT_REQUIRE_PTR(grad_offset);
+    MMT_REQUIRE_PTR(workspace);
+    if (int rc = check_dcn(B, H, W, C, groups, "dcn_col2im_sorted")) return rc;
+    if ((((uintptr_t)x | (uintptr_t)grad_col | (uintptr_t)grad_x) & 15) != 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "dcn_col2im_sorted: x / grad_col / grad_x must be 16-byte aligned");
+    const int HW = H * W;
+    const int lpg = (C / groups) / 4;
+    if (HW > kPlanMaxHW || lpg > 64 || (lpg & (lpg - 1)) != 0 || B > 65535 || HW >= (1 << 27))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "dcn_col2im_sorted: needs H*W <= %d and C/groups/4 a power of two <= 64 (H*W=%d, C/groups=%d); "
+                                            "use mmt_dcn_col2im", kPlanMaxHW, HW, C / groups);
+    if (workspace_elems < mmt_dcn_col2im_workspace_elems(B, H, W))
+        return mmt::fail(MMT_ERR_WORKSPACE, "dcn_col2im_sorted: workspace too small (%lld < %lld elements)", (long long)workspace_elems,
+                         (long long)mmt_dcn_col2im_workspace_elems(B, H, W));
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *bin_off = workspace;
+    int64_t eoff = (int64_t)B * (HW + 1);
+    eoff += eoff & 1;                                      // 8-byte aligned entries
+    DcnEntry *entries = reinterpret_cast<DcnEntry *>(workspace + eoff);
+    const int64_t npos = (int64_t)B * HW;
+    hipLaunchKernelGGL(dcn_plan_kernel, dim3(B), dim3(kPlanThreads), 0, st, H, W, offset, bin_off, entries);
+    hipLaunchKernelGGL(dcn_offset_grad_kernel, dim3(mmt::stream_grid(npos * 9, 4, 256 * 64)), dim3(256), 0, st, B, H, W, C, groups, x,
+                       offset, grad_col, grad_offset);
+    const int64_t nitems = npos * groups;
+#define MMT_DCN_GATHER(L)                                                                                                 \
+    hipLaunchKernelGGL((dcn_col2im_gather<L>), dim3(mmt::stream_grid(nitems, 256 / L, 256 * 64)), dim3(256), 0, st, B, HW, C, \
+                       groups, grad_col, (const int32_t *)bin_off, (const DcnEntry *)entries, grad_x)
+    switch (lpg) {
+        case 1: MMT_DCN_GATHER(1); break;
+        case 2: MMT_DCN_GATHER(2); break;
+        case 4: MMT_DCN_GATHER(4); break;
+        case 8: MMT_DCN_GATHER(8); break;
+        case 16: MMT_DCN_GATHER(16); break;
+        case 32: MMT_DCN_GATHER(32); break;
+        default: MMT_DCN_GATHER(64); break;
+    }
+#undef MMT_DCN_GATHER
+    return mmt::check_launch("dcn_col2im_sorted");
 }

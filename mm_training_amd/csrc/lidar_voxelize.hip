@@ -146,16 +146,16 @@ __global__ __launch_bounds__(kTile) void vox_heads(VoxArgs a, int B) {
     if (threadIdx.x == 0) a.tile_counts[b * a.ntiles + tile] = total;
 }
 
-// LDS: lists [kTile][T] sorted point indices | cnt [kTile] | cellv [kTile] | qmap [T*F] (slot, column) of a row element
+// LDS: lists [kTile][T] sorted point indices | cnt [kTile] | cellv [kTile].  FT = compile-time F (0 = any)
+template <int FT>
 __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     extern __shared__ __align__(16) int lds[];
     __shared__ int s_off, s_total;
-    const int T = a.max_points, F = a.F, V = a.max_voxels;
+    const int T = a.max_points, F = FT > 0 ? FT : a.F, V = a.max_voxels;
     const int TF = T * F;
     int *lists = lds;
     int *cnt = lists + kTile * T;
     int *cellv = cnt + kTile;
-    int *qmap = cellv + kTile;
     int b, tile;
     if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
     const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
@@ -164,8 +164,6 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     const unsigned long long *tab = a.table + 2 + (int64_t)b * cells;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    if (a.voxels)
-        for (int q = threadIdx.x; q < TF; q += kTile) qmap[q] = ((q / F) << 16) | (q % F);
     // heads before this tile / in the whole sample (a few hundred tile counts at most)
     if (wave == 0) {
         int before = 0, all = 0;
@@ -212,16 +210,27 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     // flat index advance incrementally (no integer division per element: (slot, column) of an element come from qmap)
     const int64_t row0 = (int64_t)b * V + off;
     if (a.voxels) {
+        // one (voxel, slot) per thread and trip: the point's F floats are requested together and stored as one
+        // contiguous F*4-byte piece (the slots of a tile's voxels are one contiguous block of the output)
         float *dst = a.voxels + row0 * TF;
-        const int total = nown * TF;
-        int r = threadIdx.x / TF, q = threadIdx.x - r * TF;
-        const int dr = kTile / TF, dq = kTile - dr * TF;
+        const int total = nown * T;
+        int r = threadIdx.x / T, t = threadIdx.x - r * T;
+        const int dr = kTile / T, dt = kTile - dr * T;
         for (int e = threadIdx.x; e < total; e += kTile) {
-            const int tq = qmap[q];
-            const int t = tq >> 16, f = tq & 0xFFFF;
-            dst[e] = t < cnt[r] ? a.points[(int64_t)(beg + lists[r * T + t]) * F + f] : 0.f;
-            r += dr; q += dq;
-            if (q >= TF) { q -= TF; ++r; }
+            const bool live = t < cnt[r];
+            const float *src = a.points + (int64_t)(beg + (live ? lists[r * T + t] : 0)) * F;
+            float *d = dst + (int64_t)e * F;
+            if (FT > 0) {
+                float v[FT > 0 ? FT : 1];
+#pragma unroll
+                for (int f = 0; f < FT; ++f) v[f] = live ? src[f] : 0.f;
+#pragma unroll
+                for (int f = 0; f < FT; ++f) d[f] = v[f];
+            } else {
+                for (int f = 0; f < F; ++f) d[f] = live ? src[f] : 0.f;
+            }
+            r += dr; t += dt;
+            if (t >= T) { t -= T; ++r; }
         }
     }
     if (a.mean) {
@@ -392,7 +401,7 @@ int vox_check(const char *what, int B, int64_t N, int F, const int32_t *grid_hos
     const int64_t cells = (int64_t)grid_host[0] * grid_host[1] * grid_host[2];
     if (cells * B >= (1ll << 31) || cells >= (1ll << 31) || N >= (1ll << kIdxBits))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: B*cells exceeds int32 or N >= 2^24 points", what);
-    if ((size_t)(kTile * (int64_t)max_points + 2 * kTile + (int64_t)max_points * F) * 4 > 150 * 1024 || max_points >= 32768 || F >= 65536)
+    if ((size_t)(kTile * (int64_t)max_points + 2 * kTile) * 4 > 150 * 1024)
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: max_points=%d too large for the LDS index lists", what, max_points);
     return 0;
 }
@@ -419,8 +428,11 @@ int vox_run(const char *what, int B, int64_t N, int F, const float *points, cons
     const unsigned gtiles = (unsigned)(vox_tiles(N) + B);       // flattened (sample, tile) space, see locate_tile
     seq.launch(false, vox_link, dim3(gpts), dim3(kTile), 0, st, a, B, (int)N);
     seq.launch(false, vox_heads, dim3(gtiles), dim3(kTile), 0, st, a, B);
-    const size_t lds = (size_t)(kTile * (int64_t)max_points + 2 * kTile + (int64_t)max_points * F) * 4;
-    seq.launch(true, vox_emit, dim3(gtiles), dim3(kTile), lds, st, a, B);
+    const size_t lds = (size_t)(kTile * (int64_t)max_points + 2 * kTile) * 4;
+    if (F == 5) seq.launch(true, vox_emit<5>, dim3(gtiles), dim3(kTile), lds, st, a, B);
+    else if (F == 8) seq.launch(true, vox_emit<8>, dim3(gtiles), dim3(kTile), lds, st, a, B);
+    else if (F == 4) seq.launch(true, vox_emit<4>, dim3(gtiles), dim3(kTile), lds, st, a, B);
+    else seq.launch(true, vox_emit<0>, dim3(gtiles), dim3(kTile), lds, st, a, B);
     return mmt::check_launch(what);
 }
 

@@ -42,11 +42,20 @@ class _DeformConv3x3(Function):
         grad_wmat = torch.bmm(col.transpose(1, 2), go)              # [g, 9Cg, Og]
         grad_weight = grad_wmat.reshape(groups, 9, Cg, Og).permute(0, 3, 2, 1).reshape(O, Cg, 3, 3)
         grad_col = torch.bmm(go, wmat.transpose(1, 2)).contiguous()  # [g, N, 9Cg]
-        grad_x = torch.zeros_like(x_nhwc)
         grad_off = torch.empty_like(off_nhwc)
+        lpg = Cg // 4
+        sorted_ok = H * W <= 4096 and Cg % 4 == 0 and lpg <= 64 and (lpg & (lpg - 1)) == 0
         with torch.cuda.device(x_nhwc.device):
-            _lib.call("mmt_dcn_col2im", B, H, W, C, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(),
-                      grad_col.data_ptr(), grad_x.data_ptr(), grad_off.data_ptr(), _stream())
+            if sorted_ok:
+                # contributions sorted by destination pixel, then a pure gather: no global atomics, no zero-fill
+                grad_x = torch.empty_like(x_nhwc)
+                ws = torch.empty((_lib.lib().mmt_dcn_col2im_workspace_elems(B, H, W),), dtype=torch.int32, device=x_nhwc.device)
+                _lib.call("mmt_dcn_col2im_sorted", B, H, W, C, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(),
+                          grad_col.data_ptr(), grad_x.data_ptr(), grad_off.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+            else:
+                grad_x = torch.zeros_like(x_nhwc)
+                _lib.call("mmt_dcn_col2im", B, H, W, C, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(),
+                          grad_col.data_ptr(), grad_x.data_ptr(), grad_off.data_ptr(), _stream())
         return grad_x.permute(0, 3, 1, 2), grad_off.permute(0, 3, 1, 2), grad_weight, None
 
 

@@ -114,4 +114,6 @@ def test_two_ranks_equal_gradient_accumulation_and_double_batch(mmt_lib):
     _, det, _ = ts.forward_loss(_with_id(full, "all"))
     det.backward()
     worst = _compare(out["det"], _grads(ts))
-    assert worst[0][0] <= TOL, ("batch-4", worst)
+    # batch 4 runs through other MIOpen kernels (and another split of the batch reduction) than two batches of 2: the
+    # weight gradients of the transposed convolutions differ by up to ~1.3e-4 of their magnitude in fp32
+    assert worst[0][0] <= 5 * TOL, ("batch-4", worst)

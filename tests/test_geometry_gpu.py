@@ -85,8 +85,10 @@ def test_lift_forward_backward(mmt_lib, oracle_mod, shape):
 
 @pytest.mark.parametrize("shape", [(2, 16, 5, 7, 8, 4, 0.0), (2, 16, 5, 7, 8, 2, 0.4), (3, 64, 16, 44, 32, 4, 1.5), (24, 512, 16, 44, 512, 4, 0.7)])
 def test_deform_conv_matches_torch_reference(mmt_lib, shape):
-    """DCN (lss_fpn.py:189-197): HIP im2col/col2im + GEMM vs the torch fp32 grid_sample
-    restatement of the same operator (forward, grad_input, grad_offset, grad_weight)."""
+    """DCN (lss_fpn.py:189-197): HIP im2col / sorted col2im + GEMM vs the torch fp32 grid_sample restatement of the
+    same operator (forward, grad_input, grad_offset, grad_weight).  The checker is THIS REPOSITORY'S OWN restatement of
+    mmcv's DeformConv2dPack (layers/nets.py: tap order (dy, dx), deform_groups = 1, zero padding outside (-1, size)):
+    mmcv is not vendored and the reference has no test of it, so the semantics are PARITY UNPINNED upstream."""
     from mm_training_amd.layers.nets import DeformConv2dPack
     B, C, H, W, O, groups, off_scale = shape
     torch.manual_seed(0)
@@ -117,6 +119,35 @@ def test_deform_conv_matches_torch_reference(mmt_lib, shape):
     for a, b, name in ((xa.grad, xb.grad, "grad_x"), (ga, gb, "grad_offset"), (gw_a, gw_b, "grad_weight")):
         tol = 1e-4 * max(b.abs().max().item(), 1.0)
         assert (a - b).abs().max().item() <= tol, name
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 16, 4, 3.0), (24, 16, 44, 512, 4, 0.7), (3, 32, 88, 64, 2, 6.0)])
+def test_dcn_col2im_sorted_equals_the_atomic_form(mmt_lib, shape):
+    """mmt_dcn_col2im_sorted (contributions binned by destination pixel in LDS, then a gather: no global atomics,
+    overwrites grad_x) against mmt_dcn_col2im (fp32 atomics into a zero-filled grad_x), same inputs, through the C ABI;
+    offsets up to several pixels, some far outside the image."""
+    from mm_training_amd import _lib
+    B, H, W, C, groups, off_scale = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    offset = (torch.randn(B, H, W, 18, generator=g) * off_scale).cuda()
+    offset[0, 1, 1] = torch.tensor([-30.0, -30.0, 50.0, 50.0, -0.5, -0.5, 0.25, -1.25, 0.1, 0.1, 1.5, 1.5, -1.75, 2.25, 0.5, 0.5, 0.99, -0.99])
+    Cg, N = C // groups, B * H * W
+    grad_col = torch.randn(groups, N, 9 * Cg, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    gx_a, go_a = torch.zeros_like(x), torch.empty_like(offset)
+    _lib.call("mmt_dcn_col2im", B, H, W, C, groups, x.data_ptr(), offset.data_ptr(), grad_col.data_ptr(), gx_a.data_ptr(), go_a.data_ptr(), st)
+    gx_s, go_s = torch.full_like(x, float("nan")), torch.empty_like(offset)          # overwritten: no zero-fill needed
+    ws = torch.empty(_lib.lib().mmt_dcn_col2im_workspace_elems(B, H, W), dtype=torch.int32, device="cuda")
+    _lib.call("mmt_dcn_col2im_sorted", B, H, W, C, groups, x.data_ptr(), offset.data_ptr(), grad_col.data_ptr(), gx_s.data_ptr(),
+              go_s.data_ptr(), ws.data_ptr(), ws.numel(), st)
+    assert (gx_s - gx_a).abs().max().item() <= 1e-4 * max(gx_a.abs().max().item(), 1.0)
+    assert (go_s - go_a).abs().max().item() <= 1e-4 * max(go_a.abs().max().item(), 1.0)
+    # shapes the sorted form does not take are refused on the host (the atomic form is the general one)
+    assert _lib.lib().mmt_dcn_col2im_sorted(1, 80, 80, 16, 4, x.data_ptr(), offset.data_ptr(), grad_col.data_ptr(), gx_s.data_ptr(),
+                                            go_s.data_ptr(), ws.data_ptr(), ws.numel(), st) == -2
+    assert _lib.lib().mmt_dcn_col2im_sorted(B, H, W, C, groups, x.data_ptr(), offset.data_ptr(), grad_col.data_ptr(), gx_s.data_ptr(),
+                                            go_s.data_ptr(), ws.data_ptr(), 8, st) == -5
 
 
 @pytest.mark.parametrize("cfg", [(1, 2, 14, 4, 11, 16, "rig"), (4, 6, 112, 16, 44, 80, "rig"), (2, 6, 30, 16, 44, 64, "uniform")])
