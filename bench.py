@@ -588,10 +588,12 @@ def train_main(args, rank, local_rank, world):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["lift_splat_forward"]), _lib.mean_ms(timing["lift_splat_backward"])
             fbytes, bbytes, l2f, l2b = lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, fb)
             note = ("fused lift + voxel_pooling (SURVEY 8/f1): the [B*P, C] feature matrix is never materialised, so the HBM-side "
-                    "algorithmic bytes are ~5x below the drop-in op's and the kernel is bound by L2 row gathers and its LDS sort, "
-                    "not by HBM; l2_side prices the gathered rows against the aggregate L2 bandwidth")
+                    "algorithmic bytes are ~5x below the drop-in op's; the kernels are bound by the latency of their per-workgroup "
+                    "chain (load, LDS hash / sort, gather) and by L2 row gathers, not by HBM -- l2_side prices the rows a "
+                    "point-wise gather moves against the aggregate L2 bandwidth; the drop-in op's HBM roofline is "
+                    "roofline_voxel_pooling[_backward]")
             sfx = "_bf16" if dtype == "bf16" else ""
-            res["roofline"] = roofline_entry(f"vp_fwd_seg_gather<fused>{sfx} (lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
+            res["roofline"] = roofline_entry(f"lss_splat_fwd_tile{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
                                              pmc_traffic(args.config, ("lift_splat_forward",)), l2f, note)
             res["roofline_backward"] = roofline_entry(f"lift_splat_backward_kernel{sfx} (the step's voxel_pooling backward)", bbytes, bwd_ms,
                                                       pmc_traffic(args.config, ("lift_splat_backward",)), l2b)

@@ -243,6 +243,20 @@ int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x
                           const float *grad_col, float *grad_x, float *grad_offset, int32_t *workspace,
                           int64_t workspace_elems, void *stream);
 
+/* Fused lift-splat, frustum-tile form (ABI 4; SURVEY section 8 row f1, second generation): the same result as
+ * mmt_lift_splat_forward for a point set laid out as a camera frustum [B*N, D, fH, fW] -- a workgroup owns a tile of
+ * image columns x all fH rows x a range of depth bins, keeps the tile's context rows in LDS and emits one run of
+ * atomics per BEV cell the tile touches.  Correct for any geom values; fast when pixels of a column / neighbouring depth
+ * bins share cells (what a pinhole frustum gives).  pos_memo may be NULL (not written).  fH <= 512, C % 4 == 0, C <= 256.
+ * _bf16: depth and context stored as bf16 (C % 8 == 0), fp32 products and sums. */
+int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
+                          int num_voxel_z, const int32_t *geom_xyz, const float *depth, const float *context,
+                          float *output_features, int32_t *pos_memo, int flags, void *stream);
+int mmt_lss_splat_forward_bf16(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
+                               int num_voxel_z, const int32_t *geom_xyz, const uint16_t *depth,
+                               const uint16_t *context, float *output_features, int32_t *pos_memo, int flags,
+                               void *stream);
+
 /* ------------------------------------------------- bf16 feature storage
  * BASELINE configs[4] names bf16.  The reference has no behaviour for it -- its extension takes data_ptr<float>()
  * only (ops/voxel_pooling/src/voxel_pooling_forward.cpp:28-31; exps/conf_aim.py:30 "16 does not work yet") -- so

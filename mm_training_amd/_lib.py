@@ -32,6 +32,8 @@ SIGNATURES = {
     "mmt_lift_features_backward_bf16": (_c_int, [_c_int] * 4 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_lift_splat_forward_bf16": (_c_int, [_c_int] * 8 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_lift_splat_backward_bf16": (_c_int, [_c_int] * 7 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_ptr]),
+    "mmt_lss_splat_forward": (_c_int, [_c_int] * 9 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
+    "mmt_lss_splat_forward_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_quantize_geometry": (_c_int, [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     "mmt_frustum_geometry": (_c_int, [_c_int, _c_i64] + [_c_ptr] * 6 + [_c_ptr]),
     "mmt_lift_features": (_c_int, [_c_int] * 4 + [_c_ptr] * 3 + [_c_ptr]),

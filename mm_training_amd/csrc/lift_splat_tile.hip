@@ -1,0 +1,340 @@
+// Fused lift + voxel_pooling, frustum-tile form (second generation) for MI355X (gfx950).
+//
+//   out[b, cell(t), :] += depth[t] * context[pix(t), :]        (lss_fpn.py:441-464 in one pass)
+//
+// The first fused kernel (voxel_pooling.hip, vp_fwd_seg_gather<FUSED>) cuts the point list into chunks of CONSECUTIVE
+// points -- ten rows of 44 neighbouring pixels at one depth: 464 different context rows per chunk, which it has to gather
+// from L2 one by one (30 us of its 36 us per workgroup are that gather).  Here a workgroup owns a FRUSTUM TILE instead:
+// TPW image columns x all fH rows x Dt depth bins.  The pixels of one image column see the same ray in BEV, and
+// consecutive depth bins of a ray fall into the same or the next cell, so the tile's <= 512 points hit a dozen cells
+// and use only TPW*fH different context rows: the context tile is loaded ONCE into LDS (10-20 KB), the points are
+// sorted by cell in LDS exactly as before, every lane group sums one cell's rows out of LDS in registers, and the tile
+// leaves as one run of global fp32 atomics per touched cell (3x fewer atomic rows than the chunked kernel).
+// Correct for ANY geometry (the hash takes up to 512 distinct cells per tile); the frustum structure only makes it fast.
+//
+// Workgroups of one (camera, depth-group) are dealt to the same XCD (blockIdx & 7), so the geom / depth lines shared by
+// neighbouring column tiles and the camera's context rows are fetched into one L2 -- placement affects speed only.
+#include "mmt_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kPts = 512;          // points per workgroup (TP pixels x Dt depth bins)
+constexpr int kHT = 2 * kPts;      // hash entries (load factor <= 0.5)
+constexpr int kHTLog2 = 10;
+constexpr int kEmpty = -1;
+
+struct TileArgs {
+    int N, D, fH, fW, C, nx, ny, nz;
+    int TPW, TP, Dt;               // columns per tile, pixels per tile (TPW * fH), depth bins per tile
+    int wtiles, dtiles, dt_per_grp, ngrp_per_cam, NG;
+    const int32_t *geom;           // [B*N, D, fH, fW, 3]
+    const void *depth;             // [B*N, D, fH*fW]      fp32 or bf16
+    const void *context;           // [B*N, fH*fW, C]      fp32 or bf16, channels-last
+    float *out;                    // [B, ny, nx, C]       accumulated into
+    int32_t *pos_memo;             // [B*N*D*fH*fW, 3] or NULL
+    int write_dropped;
+};
+
+// which (camera, depth tile, column tile) a workgroup owns; false = nothing (grid padding)
+__device__ __forceinline__ bool locate(const TileArgs &a, int L, int *bn, int *dtile, int *wtile) {
+    const int x = L & 7, i = L >> 3;
+    const int per = a.dt_per_grp * a.wtiles;
+    const int gl = i / per, r = i - gl * per;
+    const int g = gl * 8 + x;
+    if (g >= a.NG) return false;
+    *bn = g / a.ngrp_per_cam;
+    const int dgrp = g - *bn * a.ngrp_per_cam;
+    *dtile = dgrp * a.dt_per_grp + r / a.wtiles;
+    *wtile = r % a.wtiles;
+    return *dtile < a.dtiles;
+}
+
+template <typename FT> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;       // channels per 16-byte lane vector
+    __device__ __forceinline__ static float scalar(const float *p) { return *p; }
+    __device__ __forceinline__ static void to_lds(const float *src, float *dst) {   // one 16-byte vector of a context row
+        *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+    }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ __forceinline__ static float scalar(const bf16_t *p) { return __uint_as_float((unsigned)*p << 16); }
+    __device__ __forceinline__ static void to_lds(const bf16_t *src, float *dst) {   // up-cast once, rows live in LDS as fp32
+        const uint4 r = *reinterpret_cast<const uint4 *>(src);
+        *reinterpret_cast<float4 *>(dst) = make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(bf16_lo(r.z), bf16_hi(r.z), bf16_lo(r.w), bf16_hi(r.w));
+    }
+};
+
+// LDS (dynamic): ctx [TP][C] fp32
+template <typename FT, int C4T>
+__global__ __launch_bounds__(kBlock) void lss_splat_fwd_tile(TileArgs a) {
+    extern __shared__ __align__(16) float ctx_lds[];
+    constexpr int PPT = kPts / kBlock;
+    constexpr int NW = kBlock / 64;
+    __shared__ __align__(16) int tab_key[kHT];           // hash keys; dead after the sort: reused as the flush staging rows
+    __shared__ unsigned short tab_slot[kHT];
+    __shared__ int slot_key[kPts];
+    __shared__ int slot_cnt[kPts];
+    __shared__ unsigned short slot_off[kPts + 2];
+    __shared__ __align__(8) int2 rec[kPts];              // cell-sorted point records: (depth bits, pixel)
+    __shared__ int nslots, next_slot;
+    static_assert(kHT * 4 >= NW * 256 * 4, "staging rows must fit in the dead hash table");
+
+    int bn, dtile, wtile;
+    if (!locate(a, blockIdx.x, &bn, &dtile, &wtile)) return;
+#ifdef LSS_STAMPS   // diagnostic build: pos_memo receives 8 s_memtime stamps per workgroup instead of its rows
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(a.pos_memo) + (int64_t)blockIdx.x * 8;
+    a.pos_memo = nullptr;
+#define LSS_STAMP(i) do { if (threadIdx.x == 0 && stamps) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LSS_STAMP(i) do { } while (0)
+#endif
+    LSS_STAMP(0);
+    const int C = a.C;
+    const int C4 = C4T > 0 ? C4T : C >> 2;
+    const int G = 64 / C4;                    // lane groups per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = a.fH * a.fW;
+    const int w0 = wtile * a.TPW, d0 = dtile * a.Dt;
+    const int b = bn / a.N;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+
+    // ---- requests first: geometry + depth of this thread's points
+    int gx[PPT], gy[PPT], gz[PPT], pix[PPT];
+    int64_t tg[PPT];
+    float dep[PPT];
+    bool valid[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int lp = tid + k * kBlock;
+        const int dd = lp / a.TP, pp = lp - dd * a.TP;
+        const int hh = pp / a.TPW, ww = pp - hh * a.TPW;
+        valid[k] = dd < a.Dt && (d0 + dd) < a.D && (w0 + ww) < a.fW;
+        pix[k] = pp;
+        const int64_t t = (((int64_t)bn * a.D + (valid[k] ? d0 + dd : d0)) * a.fH + hh) * a.fW + (valid[k] ? w0 + ww : w0);
+        tg[k] = t;
+        gx[k] = a.geom[t * 3]; gy[k] = a.geom[t * 3 + 1]; gz[k] = a.geom[t * 3 + 2];
+        dep[k] = Elem<FT>::scalar(depth + t);
+    }
+    for (int i = tid; i < kHT; i += kBlock) tab_key[i] = kEmpty;
+    for (int i = tid; i < kPts; i += kBlock) slot_cnt[i] = 0;
+    if (tid == 0) { nslots = 0; next_slot = 0; }
+    // context tile -> LDS (fp32): TP rows of C channels
+    {
+        constexpr int VEC = Elem<FT>::VEC;
+        const int CV = C / VEC;
+        for (int i = tid; i < a.TP * CV; i += kBlock) {
+            const int pp = i / CV, cv = i - pp * CV;
+            const int hh = pp / a.TPW, ww = pp - hh * a.TPW;
+            if (w0 + ww < a.fW)
+                Elem<FT>::to_lds(context + ((int64_t)bn * HW + hh * a.fW + w0 + ww) * C + cv * VEC, ctx_lds + pp * C + cv * VEC);
+        }
+    }
+    __syncthreads();
+    LSS_STAMP(1);
+
+    // ---- A1: bounds test, hash insert of the cell key; pos_memo straight from registers (optional output)
+    int ent[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        int e = -1;
+        if (valid[k]) {
+            const int x = gx[k], y = gy[k], z = gz[k];
+            const bool kept = !(x < 0 || x >= a.nx || y < 0 || y >= a.ny || z < 0 || z >= a.nz);
+            if (kept) {
+                const int key = (b * a.ny + y) * a.nx + x;
+                unsigned h = ((unsigned)key * 2654435761u) >> (32 - kHTLog2);
+                for (int probe = 0; probe < kHT; ++probe) {   // never fills: <= kPts keys in 2*kPts entries
+                    const int prev = atomicCAS(&tab_key[h], kEmpty, key);
+                    if (prev == kEmpty) {
+                        const int s = atomicAdd(&nslots, 1);
+                        tab_slot[h] = (unsigned short)s;
+                        slot_key[s] = key;
+                        e = (int)h;
+                        break;
+                    }
+                    if (prev == key) { e = (int)h; break; }
+                    h = (h + 1) & (kHT - 1);
+                }
+            }
+            if (a.pos_memo && (kept || a.write_dropped)) {
+                int32_t *pm = a.pos_memo + tg[k] * 3;
+                pm[0] = kept ? b : -1; pm[1] = kept ? y : -1; pm[2] = kept ? x : -1;
+            }
+        }
+        ent[k] = e;
+    }
+    __syncthreads();
+    LSS_STAMP(2);
+
+    // ---- A2: per-slot counts (rank of the point inside its cell's list)
+    int slot[PPT], rank[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        slot[k] = -1;
+        rank[k] = 0;
+        if (ent[k] >= 0) {
+            slot[k] = tab_slot[ent[k]];
+            rank[k] = atomicAdd(&slot_cnt[slot[k]], 1);
+        }
+    }
+    __syncthreads();
+
+    // ---- A3: exclusive scan of the counts by wave 0
+    const int ns = nslots;
+    if (wave == 0) {
+        constexpr int PER = kPts / 64;
+        int loc[PER];
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            loc[i] = idx < ns ? slot_cnt[idx] : 0;
+            sum += loc[i];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            if (idx <= ns) slot_off[idx] = (unsigned short)run;
+            run += loc[i];
+        }
+        if (lane == 63) slot_off[ns] = (unsigned short)incl;      // ns == kPts: idx never reaches it above
+    }
+    __syncthreads();
+    LSS_STAMP(3);
+
+    // ---- A4: every point writes its record (depth, pixel) at its place in the cell-sorted list
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (slot[k] >= 0) rec[slot_off[slot[k]] + rank[k]] = make_int2(__float_as_int(dep[k]), pix[k]);
+    __syncthreads();
+    LSS_STAMP(4);
+
+    // ---- B/C: every lane group sums ONE cell's rows (out of the LDS context tile) in registers; the G rows of a wave meet
+    // in a staging row (the dead hash table) and leave as contiguous runs of global fp32 atomics
+    constexpr int kRows = 4;
+    const int g = lane / C4;
+    const int li = lane - g * C4;
+    const bool active = g < G;
+    float *st = reinterpret_cast<float *>(tab_key) + wave * 256;
+    for (;;) {
+        int s0 = 0;
+        if (lane == 0) s0 = atomicAdd(&next_slot, G);
+        s0 = __builtin_amdgcn_readfirstlane(s0);
+        if (s0 >= ns) break;
+        const int s = s0 + g;
+        int beg = 0, end = 0;
+        if (active && s < ns) { beg = slot_off[s]; end = slot_off[s + 1]; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = beg; j < end; j += kRows) {
+            int2 r[kRows];
+            float4 v[kRows];
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) r[u] = rec[(j + u) < end ? (j + u) : (end - 1)];
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) v[u] = *reinterpret_cast<const float4 *>(ctx_lds + r[u].y * C + li * 4);
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {   // product rounded to fp32 first (= the materialised lift), then added
+                const float dv = (j + u) < end ? __int_as_float(r[u].x) : 0.f;
+                acc.x += __fmul_rn(dv, v[u].x); acc.y += __fmul_rn(dv, v[u].y);
+                acc.z += __fmul_rn(dv, v[u].z); acc.w += __fmul_rn(dv, v[u].w);
+            }
+        }
+        if (active) *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < G * C; e += 64) {
+            const int gg = e / C;
+            const int ss = s0 + gg;
+            if (ss < ns) atomicAdd(a.out + (int64_t)slot_key[ss] * C + (e - gg * C), st[e]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    LSS_STAMP(5);
+#undef LSS_STAMP
+}
+
+// tile shape for a feature map: whole image columns, about 32 pixels x 16 depth bins
+void pick_tile(int fH, int fW, int D, int BN, TileArgs *a) {
+    int tpw = 32 / fH;
+    if (tpw < 1) tpw = 1;
+    if (tpw > fW) tpw = fW;
+    a->TPW = tpw;
+    a->TP = tpw * fH;
+    int dt = kPts / a->TP;
+    if (dt > D) dt = D;
+    a->Dt = dt;
+    a->wtiles = (fW + tpw - 1) / tpw;
+    a->dtiles = (D + dt - 1) / dt;
+    // depth groups: enough (camera, depth-group) units to spread over the 8 XCDs evenly
+    int ngrp = 1;
+    while (BN * ngrp < 64 && ngrp < a->dtiles) ++ngrp;
+    a->dt_per_grp = (a->dtiles + ngrp - 1) / ngrp;
+    a->ngrp_per_cam = (a->dtiles + a->dt_per_grp - 1) / a->dt_per_grp;
+    a->NG = BN * a->ngrp_per_cam;
+}
+
+template <typename FT>
+int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
+                 const FT *depth, const FT *context, float *out, int32_t *pos_memo, int flags, hipStream_t st) {
+    if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive size", what);
+    constexpr int VEC = Elem<FT>::VEC;
+    if (C % VEC != 0 || C % 4 != 0 || C > 256 || (((uintptr_t)context & 15) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: needs C %% %d == 0, C <= 256 and a 16-byte aligned context", what, VEC);
+    if (fH > kPts) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: fH=%d exceeds the %d-point tile; use mmt_lift_splat_forward", what, fH, kPts);
+    const int64_t P = (int64_t)N * D * fH * fW, BP = (int64_t)B * P;
+    if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
+    if (flags & ~MMT_VP_WRITE_DROPPED) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    TileArgs a;
+    a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
+    pick_tile(fH, fW, D, B * N, &a);
+    a.geom = geom; a.depth = depth; a.context = context; a.out = out; a.pos_memo = pos_memo;
+    a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
+    const size_t lds = (size_t)a.TP * C * 4;
+    if (lds > 96 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: context tile of %d pixels x %d channels exceeds LDS", what, a.TP, C);
+    const int64_t grid = 8ll * ((a.NG + 7) / 8) * a.dt_per_grp * a.wtiles;
+    if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    if (C == 80) seq.launch(true, lss_splat_fwd_tile<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    else if (C == 64) seq.launch(true, lss_splat_fwd_tile<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    else seq.launch(true, lss_splat_fwd_tile<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    return mmt::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz,
+                                     const int32_t *geom, const float *depth, const float *context, float *out,
+                                     int32_t *pos_memo, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    return forward_impl<float>("lss_splat_forward", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, out, pos_memo, flags,
+                               (hipStream_t)stream);
+}
+
+extern "C" int mmt_lss_splat_forward_bf16(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz,
+                                          const int32_t *geom, const uint16_t *depth, const uint16_t *context, float *out,
+                                          int32_t *pos_memo, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    return forward_impl<bf16_t>("lss_splat_forward_bf16", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, out, pos_memo,
+                                flags, (hipStream_t)stream);
+}

@@ -6,6 +6,8 @@
 
 All take CUDA tensors, launch on the current stream and never fall back to torch ops.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -155,10 +157,16 @@ class LiftSplat(Function):
         nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
         out = torch.zeros((B, ny, nx, C), dtype=torch.float32, device=depth.device)
         pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
+        tiled = fH <= 512 and C <= 256 and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"
         with torch.cuda.device(depth.device):
-            _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward_bf16" if bf16 else "mmt_lift_splat_forward", B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(),
-                      depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), pos_memo.data_ptr(),
-                      _lib.VP_WRITE_DROPPED, _stream())
+            if tiled:   # frustum-tile kernel (context tile in LDS); the chunked first-generation kernel stays for A/B runs
+                _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward_bf16" if bf16 else "mmt_lss_splat_forward",
+                                B, N, D, fH, fW, C, nx, ny, nz, geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(),
+                                out.data_ptr(), pos_memo.data_ptr(), _lib.VP_WRITE_DROPPED, _stream())
+            else:
+                _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward_bf16" if bf16 else "mmt_lift_splat_forward",
+                                B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(),
+                                out.data_ptr(), pos_memo.data_ptr(), _lib.VP_WRITE_DROPPED, _stream())
         ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
         ctx.dims = (B, N, D, HW, C, nx, ny)
         ctx.bf16 = bf16

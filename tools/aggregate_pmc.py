@@ -10,8 +10,10 @@ import sys
 
 # logical kernel name <- (substring of the demangled name, further substrings that must ALL be present)
 KERNELS = [
-    ("lift_splat_forward", ("vp_fwd_seg_gather<float", ", true>")),
-    ("lift_splat_forward_bf16", ("vp_fwd_seg_gather<unsigned short", ", true>")),
+    ("lift_splat_forward", ("lss_splat_fwd_tile<float",)),
+    ("lift_splat_forward_bf16", ("lss_splat_fwd_tile<unsigned short",)),
+    ("lift_splat_forward_chunked", ("vp_fwd_seg_gather<float", ", true>")),
+    ("lift_splat_forward_chunked_bf16", ("vp_fwd_seg_gather<unsigned short", ", true>")),
     ("vp_fwd_seg_gather", ("vp_fwd_seg_gather<float", ", false>")),
     ("vp_fwd_seg_gather_bf16", ("vp_fwd_seg_gather<unsigned short", ", false>")),
     ("vp_bwd_prepare", ("vp_bwd_prepare",)),

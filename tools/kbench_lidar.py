@@ -127,11 +127,17 @@ def main():
     ctx_cl = ctx.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     dep = depth.detach().requires_grad_(True)
     ms = timeit(lambda: lift_splat(geom6, dep, ctx_cl, vn))
-    res["fused_lift_splat_forward"] = {"ms": ms}
+    kms = timeit_dispatch(lambda: lift_splat(geom6, dep, ctx_cl, vn), ("lift_splat_forward",))
+    res["fused_lift_splat_forward"] = {"ms": ms, "kernel_ms": kms, "kernel": "lss_splat_fwd_tile (frustum tiles, context tile in LDS)"}
+    os.environ["MMT_LIFT_SPLAT_V1"] = "1"
+    kms1 = timeit_dispatch(lambda: lift_splat(geom6, dep, ctx_cl, vn), ("lift_splat_forward",))
+    res["fused_lift_splat_forward_v1_chunked"] = {"kernel_ms": kms1}
+    os.environ["MMT_LIFT_SPLAT_V1"] = "0"
     o = lift_splat(geom6, dep, ctx_cl, vn)
     go2 = torch.randn(4, 128, 128, 80, device="cuda").permute(0, 3, 1, 2)
     ms = timeit(lambda: torch.autograd.grad(o, (dep, ctx_cl), go2, retain_graph=True))
-    res["fused_lift_splat_backward"] = {"ms": ms}
+    kms = timeit_dispatch(lambda: torch.autograd.grad(o, (dep, ctx_cl), go2, retain_graph=True), ("lift_splat_backward",))
+    res["fused_lift_splat_backward"] = {"ms": ms, "kernel_ms": kms}
     def unfused():
         f = lift_features(dep, ctx_cl).view(4, 6, 112, 16, 44, 80)
         return voxel_pooling(geom6, f, vn)
