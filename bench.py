@@ -557,6 +557,7 @@ def train_main(args, rank, local_rank, world):
     timing, _lib.TIMING = _lib.TIMING, None
     elapsed = max_over_ranks(elapsed, world)
     if rank != 0:
+        barrier(world)          # rank 0 adds its roofline legs below; everybody leaves together
         return
     res = {
         "metric": "training samples/sec at bs=%d/GPU; voxel_pooling HBM GB/s" % B,
@@ -657,6 +658,7 @@ def train_main(args, rank, local_rank, world):
             gi = feats.grad.reshape(B, P, C).cpu()
             res["parity"] = {"bev_max_abs_err": err, "grad_in_bit_exact": bool(torch.equal(gi, ref_gi.to(gi.dtype)))}
     print(json.dumps(res), flush=True)
+    barrier(world)
 
 
 def main(argv=None):

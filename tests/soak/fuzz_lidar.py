@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 import oracle
-from mm_training_amd.lidar import hard_voxelize_batch, pillar_scatter, simple_vfe
+from mm_training_amd.lidar import hard_voxelize_batch, hard_voxelize_mean_batch, pillar_scatter, simple_vfe
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -56,6 +56,19 @@ while time.time() < t_end:
     m = simple_vfe(v, n, nf).cpu().numpy()
     if M and not np.allclose(m, oracle.simple_vfe(rv, rn, nf), rtol=1e-6, atol=1e-7, equal_nan=True):
         print("MISMATCH vfe", cfg)
+        sys.exit(1)
+    # fused voxelize + mean on the persistent generation-stamped table (never cleared between the random configurations)
+    mat = bool(rng.integers(0, 2))
+    v3, n3, c3, cnt3, m3 = hard_voxelize_mean_batch(dev, vs, pcr, T, V, nf, materialize_voxels=mat)
+    live = (c3[:, 0] >= 0).cpu().numpy()
+    rm = oracle.simple_vfe(rv, rn, nf) if M else np.zeros((0, nf), np.float32)
+    if not (int(cnt3.sum()) == M == int(live.sum()) and np.array_equal(c3.cpu().numpy()[live], rc)
+            and np.array_equal(n3.cpu().numpy()[live], rn) and np.allclose(m3.cpu().numpy()[live], rm, rtol=0, atol=0, equal_nan=True)
+            and float(m3.cpu().numpy()[~live].__abs__().sum()) == 0.0 and (n3.cpu().numpy()[~live] == 0).all()):
+        print("MISMATCH fused voxelize+mean", cfg)
+        sys.exit(1)
+    if mat and not np.array_equal(v3.cpu().numpy()[live].view(np.int32), rv.view(np.int32)):
+        print("MISMATCH fused voxelize+mean (voxel rows)", cfg)
         sys.exit(1)
     g = oracle.grid_size(pcr, vs)
     nyy, nxx = int(g[1]), int(g[0])

@@ -45,7 +45,7 @@ while time.time() < t_end:
     _, ref_pos = oracle.voxel_pooling_forward(geom, np.zeros((B, P, 1), np.float32), nx, ny, nz)
     gd, fd = torch.from_numpy(geom).cuda(), torch.from_numpy(feats).cuda()
     verbose = os.environ.get("FUZZ_VERBOSE")
-    for algo in (0, 1, 2, 3, 4, 0x23, 0x43):
+    for algo in (0, 1, 2, 3, 4, 0x23):
         if verbose:
             print("cfg", dict(it=it, B=B, P=P, C=C, grid=(nx, ny, nz), mode=str(mode), algo=algo), flush=True)
         out = torch.zeros(B, ny, nx, C, device="cuda")
@@ -82,7 +82,25 @@ while time.time() < t_end:
             if not np.array_equal(gi.cpu().numpy(), ref_gi):
                 print("MISMATCH backward", dict(it=it, B=B, P=P, C=C, grid=(nx, ny, nz), mode=mode))
                 sys.exit(1)
-    # fused lift-splat on a factorised shape
+    # bf16 feature storage: fp32 accumulate vs the oracle on the rounded rows; grad_in = bf16(gather)
+    if C % 8 == 0 and C <= 512:
+        f16 = fd.bfloat16()
+        r16 = oracle.voxel_pooling_forward_f64(geom, f16.float().cpu().numpy(), nx, ny, nz)
+        out = torch.zeros(B, ny, nx, C, device="cuda")
+        pos = torch.empty(B, P, 3, dtype=torch.int32, device="cuda")
+        voxel_pooling_ext.voxel_pooling_forward_wrapper_bf16(B, P, C, nx, ny, nz, gd, f16, out, pos, flags=0x10)
+        err = np.abs(out.cpu().numpy() - r16).max()
+        if not np.array_equal(pos.cpu().numpy(), ref_pos) or err > tol:
+            print("MISMATCH bf16 forward", dict(it=it, B=B, P=P, C=C, grid=(nx, ny, nz), mode=mode, err=float(err)))
+            sys.exit(1)
+        ws = torch.empty(voxel_pooling_ext.backward_workspace_elems(B, P, C, nx, ny), device="cuda")
+        for grad in (god, god.contiguous()):
+            gi = torch.empty(B, P, C, dtype=torch.bfloat16, device="cuda")
+            voxel_pooling_ext.voxel_pooling_backward_wrapper_bf16(B, P, C, nx, ny, posd, grad, gi, ws)
+            if not torch.equal(gi.cpu(), torch.from_numpy(ref_gi).bfloat16()):
+                print("MISMATCH bf16 backward", dict(it=it, B=B, P=P, C=C, grid=(nx, ny, nz), mode=mode))
+                sys.exit(1)
+    # fused lift-splat on a factorised shape (frustum-tile forward; MMT_LIFT_SPLAT_V1=1 selects the chunked kernel)
     if C % 16 == 0 and C <= 256 and P % 6 == 0:
         N, HW = 2, 3
         D = P // (N * HW)
