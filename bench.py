@@ -236,12 +236,14 @@ def algorithmic_bytes(BP, K, C, B, ny, nx, feat_bytes=4):
     return fwd, bwd
 
 
-def lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, feat_bytes=4):
+def lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, feat_bytes=4, pos_memo=False):
     """Fused lift-splat (row f1): the [BP, C] feature matrix does not exist.
-    forward  12BP geom + 12BP pos_memo + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx BEV
-    backward 12BP pos_memo + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx grad_out + fb*BP grad_depth + fb*C*BN*HW grad_context
-    The L2-side figure adds what the kernels gather from L2: one C-row (context / grad_out) + a depth value per kept point."""
-    fwd = 24 * BP + feat_bytes * BP + feat_bytes * C * BN_HW + 4 * C * B * ny * nx
+    forward  12BP geom (+ 12BP pos_memo, first-generation kernels only) + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx BEV
+    backward 12BP geom (or pos_memo) + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx grad_out + fb*BP grad_depth
+             + fb*C*BN*HW grad_context
+    The frustum-tile kernels redo the kept test from geom, so no pos_memo is written or read.
+    The point-wise L2-side figure adds what a point-wise gather moves: one C-row (context / grad_out) per kept point."""
+    fwd = 12 * BP + (12 * BP if pos_memo else 0) + feat_bytes * BP + feat_bytes * C * BN_HW + 4 * C * B * ny * nx
     bwd = 12 * BP + 2 * feat_bytes * BP + 2 * feat_bytes * C * BN_HW + 4 * C * B * ny * nx
     l2_fwd = fwd + K * (feat_bytes * C)
     l2_bwd = bwd + K * (4 * C)
@@ -596,7 +598,7 @@ def train_main(args, rank, local_rank, world):
             sfx = "_bf16" if dtype == "bf16" else ""
             res["roofline"] = roofline_entry(f"lss_splat_fwd_tile{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
                                              pmc_traffic(args.config, ("lift_splat_forward",)), l2f, note)
-            res["roofline_backward"] = roofline_entry(f"lift_splat_backward_kernel{sfx} (the step's voxel_pooling backward)", bbytes, bwd_ms,
+            res["roofline_backward"] = roofline_entry(f"lss_splat_bwd_tile{sfx} (fused lift-splat backward = the step's voxel_pooling backward)", bbytes, bwd_ms,
                                                       pmc_traffic(args.config, ("lift_splat_backward",)), l2b)
         elif timing.get("forward"):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["forward"]), _lib.mean_ms(timing["backward"])

@@ -249,6 +249,13 @@ int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x
  * atomics per BEV cell the tile touches.  Correct for any geom values; fast when pixels of a column / neighbouring depth
  * bins share cells (what a pinhole frustum gives).  pos_memo may be NULL (not written).  fH <= 512, C % 4 == 0, C <= 256.
  * _bf16: depth and context stored as bf16 (C % 8 == 0), fp32 products and sums. */
+#define MMT_LSS_PIXEL_MAJOR 0x100 /* flags of the mmt_lss_splat_* entry points: geom_xyz / depth / grad_depth / pos_memo are laid
+                                     out PIXEL-major, [B*N, fH, fW, D(, 3)] -- the channels-last order the dense nets produce
+                                     the depth distribution in -- instead of the reference's frustum order
+                                     [B*N, D, fH, fW(, 3)]: a tile then reads whole 64- / 192-byte runs per pixel instead of
+                                     8- / 24-byte pieces (4x fewer memory transactions: the kernels are bound by those).
+                                     mmt_frustum_geometry yields that geom order when it is given the frustum permuted to
+                                     [fH, fW, D, 4]. */
 int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
                           int num_voxel_z, const int32_t *geom_xyz, const float *depth, const float *context,
                           float *output_features, int32_t *pos_memo, int flags, void *stream);
@@ -256,6 +263,20 @@ int mmt_lss_splat_forward_bf16(int B, int N, int D, int fH, int fW, int C, int n
                                int num_voxel_z, const int32_t *geom_xyz, const uint16_t *depth,
                                const uint16_t *context, float *output_features, int32_t *pos_memo, int flags,
                                void *stream);
+/* Backward on the same tiles: the kept test is redone from geom_xyz (no pos_memo), the BEV-gradient rows of a tile's cells
+ * are loaded once into LDS.  grad_output fp32 [B,C,ny,nx] addressed through element strides, stride_c must be 1
+ * (channels-last).  grad_depth [B*N, D, fH*fW] (fp32, or bf16 in the _bf16 form) is fully written; grad_context fp32
+ * [B*N, fH*fW, C] is ACCUMULATED INTO with fp32 atomics (one partial sum per pixel and depth tile): the caller zero-fills it
+ * (and rounds it to bf16 afterwards if it wants bf16).  C % 16 == 0, C <= 256, fH <= 512. */
+int mmt_lss_splat_backward(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
+                           int num_voxel_z, const int32_t *geom_xyz, const float *depth, const float *context,
+                           const float *grad_output, int64_t stride_b, int64_t stride_c, int64_t stride_y,
+                           int64_t stride_x, float *grad_depth, float *grad_context, int flags, void *stream);
+int mmt_lss_splat_backward_bf16(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
+                                int num_voxel_z, const int32_t *geom_xyz, const uint16_t *depth,
+                                const uint16_t *context, const float *grad_output, int64_t stride_b,
+                                int64_t stride_c, int64_t stride_y, int64_t stride_x, uint16_t *grad_depth,
+                                float *grad_context, int flags, void *stream);
 
 /* ------------------------------------------------- bf16 feature storage
  * BASELINE configs[4] names bf16.  The reference has no behaviour for it -- its extension takes data_ptr<float>()

@@ -34,6 +34,8 @@ SIGNATURES = {
     "mmt_lift_splat_backward_bf16": (_c_int, [_c_int] * 7 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_ptr]),
     "mmt_lss_splat_forward": (_c_int, [_c_int] * 9 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_lss_splat_forward_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
+    "mmt_lss_splat_backward": (_c_int, [_c_int] * 9 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_int, _c_ptr]),
+    "mmt_lss_splat_backward_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_int, _c_ptr]),
     "mmt_quantize_geometry": (_c_int, [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     "mmt_frustum_geometry": (_c_int, [_c_int, _c_i64] + [_c_ptr] * 6 + [_c_ptr]),
     "mmt_lift_features": (_c_int, [_c_int] * 4 + [_c_ptr] * 3 + [_c_ptr]),
@@ -74,6 +76,7 @@ SIGNATURES = {
 VP_ALGO_AUTO = 0
 VP_ALGO_ROW_ATOMIC = 1
 VP_WRITE_DROPPED = 0x10
+LSS_PIXEL_MAJOR = 0x100       # mmt_lss_splat_*: geom / depth / grad_depth in [B*N, fH, fW, D(, 3)] order
 
 _lib = None
 

@@ -32,8 +32,16 @@ struct TileArgs {
     const void *depth;             // [B*N, D, fH*fW]      fp32 or bf16
     const void *context;           // [B*N, fH*fW, C]      fp32 or bf16, channels-last
     float *out;                    // [B, ny, nx, C]       accumulated into
-    int32_t *pos_memo;             // [B*N*D*fH*fW, 3] or NULL
+    int32_t *pos_memo;             // [B*N*D*fH*fW, 3] or NULL (same point order as geom)
     int write_dropped;
+    int pm;                        // 1: geom / depth / grad_depth / pos_memo are PIXEL-major [B*N, fH, fW, D(, 3)] (the nets'
+                                   //    channels-last order: a tile reads Dt consecutive depth bins per pixel = whole
+                                   //    64- / 192-byte runs), 0: the reference's frustum order [B*N, D, fH, fW(, 3)]
+    // backward
+    const float *grad_out;         // [B, ny, nx, C] view: element strides sb, sy, sx (channel stride 1)
+    int64_t sb, sy, sx;
+    void *grad_depth;              // [B*N, D, fH*fW]  fp32 or bf16, every element written
+    float *grad_context;           // [B*N, fH*fW, C]  fp32, ACCUMULATED INTO with atomics (caller zero-fills)
 };
 
 // which (camera, depth tile, column tile) a workgroup owns; false = nothing (grid padding)
@@ -111,11 +119,14 @@ __global__ __launch_bounds__(kBlock) void lss_splat_fwd_tile(TileArgs a) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int lp = tid + k * kBlock;
-        const int dd = lp / a.TP, pp = lp - dd * a.TP;
+        int dd, pp;
+        if (a.pm) { pp = lp / a.Dt; dd = lp - pp * a.Dt; } else { dd = lp / a.TP; pp = lp - dd * a.TP; }
         const int hh = pp / a.TPW, ww = pp - hh * a.TPW;
-        valid[k] = dd < a.Dt && (d0 + dd) < a.D && (w0 + ww) < a.fW;
+        valid[k] = dd < a.Dt && pp < a.TP && (d0 + dd) < a.D && (w0 + ww) < a.fW;
         pix[k] = pp;
-        const int64_t t = (((int64_t)bn * a.D + (valid[k] ? d0 + dd : d0)) * a.fH + hh) * a.fW + (valid[k] ? w0 + ww : w0);
+        const int dc = valid[k] ? d0 + dd : d0, wc = valid[k] ? w0 + ww : w0, hc = pp < a.TP ? hh : 0;
+        const int64_t t = a.pm ? (((int64_t)bn * a.fH + hc) * a.fW + wc) * a.D + dc
+                               : (((int64_t)bn * a.D + dc) * a.fH + hc) * a.fW + wc;
         tg[k] = t;
         gx[k] = a.geom[t * 3]; gy[k] = a.geom[t * 3 + 1]; gz[k] = a.geom[t * 3 + 2];
         dep[k] = Elem<FT>::scalar(depth + t);
@@ -266,6 +277,180 @@ __global__ __launch_bounds__(kBlock) void lss_splat_fwd_tile(TileArgs a) {
 #undef LSS_STAMP
 }
 
+// ---------------------------------------------------------------------------
+// Backward on the same frustum tiles:
+//   grad_depth[t]        = < grad_out[cell(t), :], context[pix(t), :] >          (0 for dropped points)
+//   grad_context[pix, :] += sum over the tile's depth bins of depth[t] * grad_out[cell(t), :]
+// The first-generation kernel (voxel_pooling.hip, lift_splat_backward_kernel) gathers one 320-byte BEV-gradient row per
+// kept point from L2 (364 MB at cfg2).  A tile touches a dozen or two cells: their rows are loaded ONCE into LDS beside the
+// context tile, the kept test is redone from geom (no pos_memo), every lane group owns a pixel at a time and walks its
+// Dt depth bins out of LDS -- no sort is needed, only each point's row slot.  grad_depth is a plain store (a point
+// belongs to one tile); grad_context receives one run of fp32 atomics per (pixel, depth tile) -- D / Dt partial sums
+// per pixel, 38 MB of atomic traffic at cfg2 for a 5.4 MB tensor.
+constexpr int kGradRows = 24;      // BEV-gradient rows held in LDS per workgroup; further cells are read from L2
+
+// LDS (dynamic): ctx [TP][C] fp32 | rows [kGradRows][C] fp32
+template <typename FT, int C4T>
+__global__ __launch_bounds__(kBlock) void lss_splat_bwd_tile(TileArgs a) {
+    extern __shared__ __align__(16) float dyn_lds[];
+    constexpr int PPT = kPts / kBlock;
+    constexpr int NW = kBlock / 64;
+    __shared__ __align__(16) int tab_key[kHT];           // hash keys; dead after the slot lookup: reused as the flush staging rows
+    __shared__ unsigned short tab_slot[kHT];
+    __shared__ int slot_addr[kPts];                      // element offset of the slot's BEV-gradient row
+    __shared__ short pt_slot[kPts];                      // row slot of a point, -1 = dropped / outside the tile
+    __shared__ float pt_depth[kPts];
+    __shared__ float gd[kPts];
+    __shared__ int nslots;
+    static_assert(kHT * 4 >= NW * 256 * 4, "staging rows must fit in the dead hash table");
+
+    int bn, dtile, wtile;
+    if (!locate(a, blockIdx.x, &bn, &dtile, &wtile)) return;
+    const int C = a.C;
+    const int C4 = C4T > 0 ? C4T : C >> 2;
+    const int G = 64 / C4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = a.fH * a.fW;
+    const int w0 = wtile * a.TPW, d0 = dtile * a.Dt;
+    const int b = bn / a.N;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+    float *ctx_lds = dyn_lds;
+    float *rows = dyn_lds + a.TP * C;
+
+    int gx[PPT], gy[PPT], gz[PPT];
+    int64_t tg[PPT];
+    float dep[PPT];
+    bool valid[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int lp = tid + k * kBlock;
+        int dd, pp;
+        if (a.pm) { pp = lp / a.Dt; dd = lp - pp * a.Dt; } else { dd = lp / a.TP; pp = lp - dd * a.TP; }
+        const int hh = pp / a.TPW, ww = pp - hh * a.TPW;
+        valid[k] = dd < a.Dt && pp < a.TP && (d0 + dd) < a.D && (w0 + ww) < a.fW;
+        const int dc = valid[k] ? d0 + dd : d0, wc = valid[k] ? w0 + ww : w0, hc = pp < a.TP ? hh : 0;
+        const int64_t t = a.pm ? (((int64_t)bn * a.fH + hc) * a.fW + wc) * a.D + dc
+                               : (((int64_t)bn * a.D + dc) * a.fH + hc) * a.fW + wc;
+        tg[k] = t;
+        gx[k] = a.geom[t * 3]; gy[k] = a.geom[t * 3 + 1]; gz[k] = a.geom[t * 3 + 2];
+        dep[k] = Elem<FT>::scalar(depth + t);
+    }
+    for (int i = tid; i < kHT; i += kBlock) tab_key[i] = kEmpty;
+    if (tid == 0) nslots = 0;
+    {
+        constexpr int VEC = Elem<FT>::VEC;
+        const int CV = C / VEC;
+        for (int i = tid; i < a.TP * CV; i += kBlock) {
+            const int pp = i / CV, cv = i - pp * CV;
+            const int hh = pp / a.TPW, ww = pp - hh * a.TPW;
+            if (w0 + ww < a.fW)
+                Elem<FT>::to_lds(context + ((int64_t)bn * HW + hh * a.fW + w0 + ww) * C + cv * VEC, ctx_lds + pp * C + cv * VEC);
+        }
+    }
+    __syncthreads();
+
+    // ---- every kept point finds / creates the slot of its cell (slot = order of first insertion)
+    int ent[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int lp = tid + k * kBlock;
+        int e = -1;
+        pt_depth[lp] = dep[k];
+        if (valid[k]) {
+            const int x = gx[k], y = gy[k], z = gz[k];
+            if (!(x < 0 || x >= a.nx || y < 0 || y >= a.ny || z < 0 || z >= a.nz)) {
+                const int key = (b * a.ny + y) * a.nx + x;
+                unsigned h = ((unsigned)key * 2654435761u) >> (32 - kHTLog2);
+                for (int probe = 0; probe < kHT; ++probe) {   // never fills: <= kPts keys in 2*kPts entries
+                    const int prev = atomicCAS(&tab_key[h], kEmpty, key);
+                    if (prev == kEmpty) {
+                        const int s_ = atomicAdd(&nslots, 1);
+                        tab_slot[h] = (unsigned short)s_;
+                        slot_addr[s_] = (int)(b * a.sb + y * a.sy + x * a.sx);
+                        e = (int)h;
+                        break;
+                    }
+                    if (prev == key) { e = (int)h; break; }
+                    h = (h + 1) & (kHT - 1);
+                }
+            }
+        }
+        ent[k] = e;
+    }
+    __syncthreads();
+    const int ns = nslots;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) pt_slot[tid + k * kBlock] = ent[k] >= 0 ? (short)tab_slot[ent[k]] : (short)-1;
+    // the BEV-gradient rows of the tile's cells -> LDS, once
+    {
+        const int nrow = ns < kGradRows ? ns : kGradRows;
+        for (int i = tid; i < nrow * C4; i += kBlock) {
+            const int s_ = i / C4, c4 = i - s_ * C4;
+            *reinterpret_cast<float4 *>(rows + s_ * C + c4 * 4) = *reinterpret_cast<const float4 *>(a.grad_out + slot_addr[s_] + c4 * 4);
+        }
+    }
+    __syncthreads();
+
+    // ---- one lane group per pixel at a time: Dt depth bins out of LDS
+    const int g = lane / C4;
+    const int li = lane - g * C4;
+    float *st = reinterpret_cast<float *>(tab_key) + wave * 256;       // hash keys are dead now
+    const int NGR = NW * G;
+    for (int p0 = 0; p0 < a.TP; p0 += NGR) {            // uniform trip count for the whole workgroup (wave barriers inside)
+        const int pp = p0 + wave * G + g;
+        const bool act = g < G && pp < a.TP;
+        const int hh = act ? pp / a.TPW : 0, ww = act ? pp - hh * a.TPW : 0;
+        const bool inimg = act && (w0 + ww) < a.fW;
+        float4 cx = make_float4(0.f, 0.f, 0.f, 0.f), acc = cx;
+        if (inimg) cx = *reinterpret_cast<const float4 *>(ctx_lds + pp * C + li * 4);
+        if (inimg) {
+            for (int dd = 0; dd < a.Dt; ++dd) {
+                const int lp = a.pm ? pp * a.Dt + dd : dd * a.TP + pp;
+                const int s_ = pt_slot[lp];
+                float total = 0.f;
+                if (s_ >= 0) {
+                    const float dv = pt_depth[lp];
+                    const float4 gr = s_ < kGradRows ? *reinterpret_cast<const float4 *>(rows + s_ * C + li * 4)
+                                                     : *reinterpret_cast<const float4 *>(a.grad_out + slot_addr[s_] + li * 4);
+                    acc.x += gr.x * dv; acc.y += gr.y * dv; acc.z += gr.z * dv; acc.w += gr.w * dv;
+                    float q = gr.x * cx.x + gr.y * cx.y + gr.z * cx.z + gr.w * cx.w;
+                    q += __shfl_xor(q, 1);
+                    q += __shfl_xor(q, 2);                  // quad sum in all 4 lanes (lane groups start on quad boundaries)
+                    total = q;
+                    for (int o = 4; o < C4; o += 4) total += __shfl_down(q, o);   // lane li == 0: all C4/4 quads of the group
+                }
+                if (li == 0) gd[lp] = total;
+            }
+        }
+        // grad_context: the G rows of a wave meet in a staging row and leave as contiguous fp32 atomics
+        if (act) *reinterpret_cast<float4 *>(st + g * C + li * 4) = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < G * C; e += 64) {
+            const int gg = e / C;
+            const int pq = p0 + wave * G + gg;
+            if (pq < a.TP) {
+                const int h2 = pq / a.TPW, w2 = pq - h2 * a.TPW;
+                if (w0 + w2 < a.fW) atomicAdd(a.grad_context + ((int64_t)bn * HW + h2 * a.fW + w0 + w2) * C + (e - gg * C), st[e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // ---- grad_depth: a point belongs to exactly one tile
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        if (valid[k]) {
+            const float v = gd[tid + k * kBlock];
+            if constexpr (sizeof(FT) == 2) reinterpret_cast<bf16_t *>(a.grad_depth)[tg[k]] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu);
+            else reinterpret_cast<float *>(a.grad_depth)[tg[k]] = v;
+        }
+    }
+}
+
 // tile shape for a feature map: whole image columns, about 32 pixels x 16 depth bins
 void pick_tile(int fH, int fW, int D, int BN, TileArgs *a) {
     int tpw = 32 / fH;
@@ -298,12 +483,14 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     const int64_t P = (int64_t)N * D * fH * fW, BP = (int64_t)B * P;
     if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
-    if (flags & ~MMT_VP_WRITE_DROPPED) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (flags & ~(MMT_VP_WRITE_DROPPED | MMT_LSS_PIXEL_MAJOR)) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
     TileArgs a;
     a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
     pick_tile(fH, fW, D, B * N, &a);
     a.geom = geom; a.depth = depth; a.context = context; a.out = out; a.pos_memo = pos_memo;
     a.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
+    a.pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
+    a.grad_out = nullptr; a.sb = a.sy = a.sx = 0; a.grad_depth = nullptr; a.grad_context = nullptr;
     const size_t lds = (size_t)a.TP * C * 4;
     if (lds > 96 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: context tile of %d pixels x %d channels exceeds LDS", what, a.TP, C);
     const int64_t grid = 8ll * ((a.NG + 7) / 8) * a.dt_per_grp * a.wtiles;
@@ -315,7 +502,69 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     return mmt::check_launch(what);
 }
 
+template <typename FT>
+int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
+                  const FT *depth, const FT *context, const float *grad_out, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                  FT *grad_depth, float *grad_context, int flags, hipStream_t st) {
+    if (flags & ~MMT_LSS_PIXEL_MAJOR) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive size", what);
+    constexpr int VEC = Elem<FT>::VEC;
+    if (C % VEC != 0 || C % 16 != 0 || C > 256)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: needs C %% 16 == 0 and C <= 256 (C=%d)", what, C);
+    if (fH > kPts) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: fH=%d exceeds the %d-point tile; use mmt_lift_splat_backward", what, fH, kPts);
+    const int64_t span = (B - 1) * sb + (ny - 1) * sy + (nx - 1) * sx + C;
+    if (sc != 1 || sb % 4 || sy % 4 || sx % 4 || sb < 0 || sy < 0 || sx < 0 || span >= (1ll << 31) ||
+        (((uintptr_t)grad_out | (uintptr_t)context | (uintptr_t)grad_context) & 15) != 0)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: grad_out must be channels-last (stride_c == 1), 16-byte aligned, < 2^31 elements", what);
+    if ((int64_t)B * N * D * fH * fW >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
+    TileArgs a;
+    a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
+    pick_tile(fH, fW, D, B * N, &a);
+    a.geom = geom; a.depth = depth; a.context = context; a.out = nullptr; a.pos_memo = nullptr; a.write_dropped = 0;
+    a.pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
+    a.grad_out = grad_out; a.sb = sb; a.sy = sy; a.sx = sx; a.grad_depth = grad_depth; a.grad_context = grad_context;
+    const size_t lds = ((size_t)a.TP + kGradRows) * C * 4;
+    if (lds > 96 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: context tile of %d pixels x %d channels exceeds LDS", what, a.TP, C);
+    const int64_t grid = 8ll * ((a.NG + 7) / 8) * a.dt_per_grp * a.wtiles;
+    if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    if (C == 80) seq.launch(true, lss_splat_bwd_tile<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    else if (C == 64) seq.launch(true, lss_splat_bwd_tile<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    else seq.launch(true, lss_splat_bwd_tile<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    return mmt::check_launch(what);
+}
+
 }  // namespace
+
+extern "C" int mmt_lss_splat_backward(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz,
+                                      const int32_t *geom, const float *depth, const float *context,
+                                      const float *grad_out, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                      float *grad_depth, float *grad_context, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    return backward_impl<float>("lss_splat_backward", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sc, sy, sx,
+                                grad_depth, grad_context, flags, (hipStream_t)stream);
+}
+
+extern "C" int mmt_lss_splat_backward_bf16(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz,
+                                           const int32_t *geom, const uint16_t *depth, const uint16_t *context,
+                                           const float *grad_out, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                           uint16_t *grad_depth, float *grad_context, int flags, void *stream) {
+    MMT_REQUIRE_PTR(geom);
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    return backward_impl<bf16_t>("lss_splat_backward_bf16", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sc,
+                                 sy, sx, grad_depth, grad_context, flags, (hipStream_t)stream);
+}
 
 extern "C" int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz,
                                      const int32_t *geom, const float *depth, const float *context, float *out,

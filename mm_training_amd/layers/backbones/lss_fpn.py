@@ -126,6 +126,9 @@ class LSSFPN(nn.Module):
         self.register_buffer('voxel_coord', torch.Tensor([row[0] + row[2] / 2.0 for row in rows]))
         self.register_buffer('voxel_num', torch.LongTensor([(row[1] - row[0]) / row[2] for row in rows]))
         self.register_buffer('frustum', self.create_frustum())
+        # the same frustum in pixel-major order [fH, fW, D, 4]: the fused lift-splat kernels read geometry and depth per
+        # (pixel, depth range) -- the order a channels_last depth tensor has -- see ops/bev_geometry.py::lift_splat
+        self.register_buffer('frustum_pixel_major', self.frustum.permute(1, 2, 0, 3).contiguous(), persistent=False)
         self.depth_channels = self.frustum.shape[0]
         # host copies: no device->host sync per step (the reference indexes a CUDA tensor)
         self._voxel_num_host = [int(v) for v in self.voxel_num]
@@ -152,13 +155,14 @@ class LSSFPN(nn.Module):
         y_coords = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
         return torch.stack((x_coords, y_coords, d_coords, torch.ones_like(d_coords)), -1).contiguous()
 
-    def get_geometry_voxels(self, sensor2ego_mat, intrin_mat, bda_mat=None):
+    def get_geometry_voxels(self, sensor2ego_mat, intrin_mat, bda_mat=None, pixel_major=False):
         """get_geometry (lss_fpn.py:328-361) fused with the quantise (:461-462):
-        returns int32 voxel coordinates [B,N,D,fH,fW,3].  bda_mat is ignored like in
-        the reference (:355-360)."""
+        returns int32 voxel coordinates [B,N,D,fH,fW,3] ([B,N,fH,fW,D,3] with pixel_major: same values, the
+        order the fused kernels read).  bda_mat is ignored like in the reference (:355-360)."""
         with torch.autocast("cuda", enabled=False):   # the integer index path is fp32 whatever the AMP mode
             combine = sensor2ego_mat.float().matmul(torch.linalg.inv_ex(intrin_mat.float())[0]).contiguous()
-        return frustum_geometry(self.frustum.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
+        fr = self.frustum_pixel_major if pixel_major else self.frustum
+        return frustum_geometry(fr.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
 
     def get_cam_feats(self, imgs):
         """[B, S, N, 3, H, W] images -> [B, S, N, C', fH, fW] neck features (lss_fpn.py:363-379)."""
@@ -207,15 +211,15 @@ class LSSFPN(nn.Module):
         elif self.fused_lift_splat:
             geom_xyz = self.get_geometry_voxels(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
                                                 mats_dict['intrin_mats'][:, sweep_index, ...],
-                                                mats_dict.get('bda_mat', None))
+                                                mats_dict.get('bda_mat', None), pixel_major=True)
         if plan is not None:
             feats = lift_features(depth_used.float(), context.float())
             feature_map = voxel_pooling_planned(plan, feats.view(batch_size, -1, feats.shape[-1]))
         elif self.fused_lift_splat:
             if self.hot_path_dtype == "bf16":
-                feature_map = lift_splat(geom_xyz, depth_used.bfloat16(), context.bfloat16(), self._voxel_num_host)
+                feature_map = lift_splat(geom_xyz, depth_used.bfloat16(), context.bfloat16(), self._voxel_num_host, pixel_major=True)
             else:
-                feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host)
+                feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host, pixel_major=True)
         else:
             # lift straight into [B, N, D, fH, fW, C], then the drop-in voxel_pooling
             bf16 = self.hot_path_dtype == "bf16" and self.output_channels % 16 == 0

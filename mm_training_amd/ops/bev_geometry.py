@@ -139,12 +139,19 @@ def lift_features(depth, context, storage_dtype=torch.float32):
 class LiftSplat(Function):
     """Fused lift + voxel_pooling (lss_fpn.py:441-464 in one pass): the
     [B, N, D, fH, fW, C] feature tensor is never materialised.  Additional entry point beside
-    the drop-in ``voxel_pooling``; same result up to fp32 summation order."""
+    the drop-in ``voxel_pooling``; same result up to fp32 summation order.
+
+    Frustum-tile kernels (mmt_lss_splat_forward / _backward: a workgroup owns image columns x all rows x a depth range,
+    context tile and the tile's BEV-gradient rows in LDS) unless MMT_LIFT_SPLAT_V1=1 selects the first-generation pair
+    (chunks of consecutive points; pixel-major backward on pos_memo), kept for A/B runs and for fH > 512."""
 
     @staticmethod
-    def forward(ctx, geom_xyz, depth, context, voxel_num):
+    def forward(ctx, geom_xyz, depth, context, voxel_num, pixel_major=False):
         _need_cuda(geom_xyz, "geom_xyz", torch.int32)
-        B, N, D, fH, fW = geom_xyz.shape[:5]
+        if pixel_major:
+            B, N, fH, fW, D = geom_xyz.shape[:5]
+        else:
+            B, N, D, fH, fW = geom_xyz.shape[:5]
         BN, HW, C = B * N, fH * fW, context.shape[1]
         if tuple(depth.shape) != (BN, D, fH, fW) or tuple(context.shape) != (BN, C, fH, fW):
             raise RuntimeError("lift_splat: depth must be [B*N, D, fH, fW] and context [B*N, C, fH, fW]")
@@ -152,43 +159,62 @@ class LiftSplat(Function):
             raise RuntimeError("depth / context must be a CUDAtensor ")
         bf16 = depth.dtype == torch.bfloat16 and context.dtype == torch.bfloat16   # bf16 storage of both operands (row g1)
         sd = torch.bfloat16 if bf16 else torch.float32
-        depth_c = depth.to(sd).contiguous()                                # point order [BN, D, HW]
+        tiled = fH <= 512 and C <= 256 and C % 16 == 0 and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"
+        if pixel_major and not tiled:
+            raise RuntimeError("lift_splat: the pixel-major layout needs the frustum-tile kernels (C % 16 == 0, C <= 256, fH <= 512)")
+        # point order of depth: [BN, D, HW] (reference) or [BN, HW, D] (pixel-major: free for a channels_last depth tensor)
+        depth_c = (depth.to(sd).permute(0, 2, 3, 1) if pixel_major else depth.to(sd)).contiguous()
         ctx_nhwc = context.to(sd).permute(0, 2, 3, 1).contiguous()         # free for channels_last nets
         nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
         out = torch.zeros((B, ny, nx, C), dtype=torch.float32, device=depth.device)
-        pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
-        tiled = fH <= 512 and C <= 256 and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"
+        sfx = "_bf16" if bf16 else ""
         with torch.cuda.device(depth.device):
-            if tiled:   # frustum-tile kernel (context tile in LDS); the chunked first-generation kernel stays for A/B runs
-                _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward_bf16" if bf16 else "mmt_lss_splat_forward",
-                                B, N, D, fH, fW, C, nx, ny, nz, geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(),
-                                out.data_ptr(), pos_memo.data_ptr(), _lib.VP_WRITE_DROPPED, _stream())
+            if tiled:   # the backward redoes the kept test from geom: no pos_memo is written or kept
+                _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward" + sfx, B, N, D, fH, fW, C, nx, ny, nz,
+                                geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), 0,
+                                _lib.LSS_PIXEL_MAJOR if pixel_major else 0, _stream())
+                ctx.save_for_backward(geom_xyz, depth_c, ctx_nhwc)
             else:
-                _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward_bf16" if bf16 else "mmt_lift_splat_forward",
-                                B, N, D, HW, C, nx, ny, nz, geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(),
-                                out.data_ptr(), pos_memo.data_ptr(), _lib.VP_WRITE_DROPPED, _stream())
-        ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
-        ctx.dims = (B, N, D, HW, C, nx, ny)
-        ctx.bf16 = bf16
+                pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
+                _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward" + sfx, B, N, D, HW, C, nx, ny, nz,
+                                geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), pos_memo.data_ptr(),
+                                _lib.VP_WRITE_DROPPED, _stream())
+                ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
+        ctx.dims = (B, N, D, fH, fW, C, nx, ny, nz)
+        ctx.bf16, ctx.tiled, ctx.pixel_major = bf16, tiled, bool(pixel_major)
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, grad_out):
-        pos_memo, depth_c, ctx_nhwc = ctx.saved_tensors
-        B, N, D, HW, C, nx, ny = ctx.dims
+        index, depth_c, ctx_nhwc = ctx.saved_tensors          # index: geom (tiled) or pos_memo (first generation)
+        B, N, D, fH, fW, C, nx, ny, nz = ctx.dims
         if grad_out.stride(1) != 1 or grad_out.dtype != torch.float32:
             grad_out = grad_out.float().contiguous(memory_format=torch.channels_last)
         sb, sc, sy, sx = grad_out.stride()
         grad_depth = torch.empty_like(depth_c)
-        grad_ctx = torch.empty_like(ctx_nhwc)
+        sfx = "_bf16" if ctx.bf16 else ""
         with torch.cuda.device(depth_c.device):
-            _lib.timed_call("lift_splat_backward", "mmt_lift_splat_backward_bf16" if ctx.bf16 else "mmt_lift_splat_backward", B, N, D, HW, C, nx, ny, pos_memo.data_ptr(),
-                      depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
-                      grad_depth.data_ptr(), grad_ctx.data_ptr(), _stream())
-        return None, grad_depth, grad_ctx.permute(0, 3, 1, 2), None
+            if ctx.tiled:
+                grad_ctx = torch.zeros(ctx_nhwc.shape, dtype=torch.float32, device=depth_c.device)   # accumulated into (fp32 atomics)
+                _lib.timed_call("lift_splat_backward", "mmt_lss_splat_backward" + sfx, B, N, D, fH, fW, C, nx, ny, nz,
+                                index.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
+                                grad_depth.data_ptr(), grad_ctx.data_ptr(), _lib.LSS_PIXEL_MAJOR if ctx.pixel_major else 0, _stream())
+                if ctx.bf16:
+                    grad_ctx = grad_ctx.to(torch.bfloat16)
+            else:
+                grad_ctx = torch.empty_like(ctx_nhwc)
+                _lib.timed_call("lift_splat_backward", "mmt_lift_splat_backward" + sfx, B, N, D, fH * fW, C, nx, ny,
+                                index.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
+                                grad_depth.data_ptr(), grad_ctx.data_ptr(), _stream())
+        if ctx.pixel_major:      # [BN, fH, fW, D] storage = a channels_last [BN, D, fH, fW] gradient
+            grad_depth = grad_depth.permute(0, 3, 1, 2)
+        return None, grad_depth, grad_ctx.permute(0, 3, 1, 2), None, None
 
 
-def lift_splat(geom_xyz, depth, context, voxel_num):
+def lift_splat(geom_xyz, depth, context, voxel_num, pixel_major=False):
     """geom int32 [B,N,D,fH,fW,3], depth [B*N,D,fH,fW], context [B*N,C,fH,fW] -> BEV fp32 [B,C,ny,nx].
-    depth AND context in bf16 select the bf16-storage kernels (fp32 products and sums, bf16 gradients back)."""
-    return LiftSplat.apply(geom_xyz.contiguous(), depth, context, voxel_num)
+    depth AND context in bf16 select the bf16-storage kernels (fp32 products and sums, bf16 gradients back).
+    pixel_major=True: geom is [B,N,fH,fW,D,3] (frustum_geometry of the frustum permuted to [fH,fW,D,4]) and the kernels read
+    depth in [B*N,fH,fW,D] memory order -- what a channels_last depth tensor already is -- and return its gradient in that
+    order: whole 64- / 192-byte runs per pixel and tile instead of 8- / 24-byte pieces."""
+    return LiftSplat.apply(geom_xyz.contiguous(), depth, context, voxel_num, bool(pixel_major))

@@ -32,9 +32,11 @@ def test_lift_splat_and_lidar_bytes():
     b = _bench()
     BP, C, B, ny, nx = 1892352, 80, 4, 128, 128
     K, BN_HW = 1137000, 24 * 16 * 44
-    fwd, bwd, l2f, l2b = b.lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx)
+    fwd, bwd, l2f, l2b = b.lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, pos_memo=True)
     # 12BP geom + 12BP pos_memo + 4BP depth + 4*C*B*N*HW context + 4*C*B*ny*nx out
     assert fwd == 12 * BP + 12 * BP + 4 * BP + 4 * C * BN_HW + 4 * C * B * ny * nx
+    # the frustum-tile kernels write / read no pos_memo (the backward redoes the kept test from geom)
+    assert b.lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx)[0] == fwd - 12 * BP
     assert bwd == 12 * BP + 4 * BP + 4 * C * BN_HW + 4 * C * B * ny * nx + 4 * BP + 4 * C * BN_HW
     assert l2f - fwd == K * 4 * C and l2b - bwd == K * 4 * C
     vox, scat, scat_bwd = b.lidar_bytes(5, 160000, 90000, 5, 64, 4, 512, 512)

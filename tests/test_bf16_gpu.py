@@ -158,6 +158,13 @@ def test_fused_lift_splat_bf16(mmt_lib, oracle_mod, cfg):
     out2.backward(go)
     assert d1.grad.dtype == torch.bfloat16 and c1.grad.dtype == torch.bfloat16
     assert _close_bf16(d1.grad, d2.grad) and _close_bf16(c1.grad, c2.grad)
+    # pixel-major layout, bf16 operands
+    d3 = depth16.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    c3 = ctx16.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out3 = lift_splat(geom_d.permute(0, 1, 3, 4, 2, 5).contiguous(), d3, c3, vn, pixel_major=True)
+    assert np.abs(out3.detach().permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= ATOL
+    out3.backward(go)
+    assert _close_bf16(d3.grad, d2.grad) and _close_bf16(c3.grad, c2.grad)
 
 
 @pytest.mark.parametrize("fused", [True, False])

@@ -191,6 +191,28 @@ def test_fused_lift_splat_equals_lift_then_pool(mmt_lib, oracle_mod, cfg):
     c1.grad = None
     lift_splat(geom_d, d1, c1, vn).backward(go.contiguous())
     assert torch.allclose(d1.grad, d2.grad, rtol=1e-4, atol=1e-5)
+    # pixel-major layout (what LSSFPN runs): geom [B,N,fH,fW,D,3], depth read / its gradient written in channels_last order
+    geom_pm = geom_d.permute(0, 1, 3, 4, 2, 5).contiguous()
+    d3 = depth.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    c3 = ctx.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out3 = lift_splat(geom_pm, d3, c3, vn, pixel_major=True)
+    assert np.abs(out3.detach().permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= 1e-4
+    out3.backward(go)
+    assert d3.grad.shape == d2.grad.shape and c3.grad.shape == c2.grad.shape
+    assert torch.allclose(d3.grad, d2.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(c3.grad, c2.grad, rtol=1e-4, atol=1e-4)
+    # and the first-generation kernels (chunks of consecutive points, pixel-major backward on pos_memo) stay selectable
+    import os
+    os.environ["MMT_LIFT_SPLAT_V1"] = "1"
+    try:
+        d4 = depth.cuda().requires_grad_(True)
+        c4 = ctx.cuda().requires_grad_(True)
+        out4 = lift_splat(geom_d, d4, c4, vn)
+        out4.backward(go)
+    finally:
+        os.environ["MMT_LIFT_SPLAT_V1"] = "0"
+    assert np.abs(out4.detach().permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= 1e-4
+    assert torch.allclose(d4.grad, d2.grad, rtol=1e-4, atol=1e-5) and torch.allclose(c4.grad, c2.grad, rtol=1e-4, atol=1e-4)
 
 
 def test_fused_geometry_on_reference_nuscenes_calibration(mmt_lib, oracle_mod, golden):

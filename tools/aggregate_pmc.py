@@ -19,8 +19,10 @@ KERNELS = [
     ("vp_bwd_prepare", ("vp_bwd_prepare",)),
     ("vp_bwd_rows_vec4", ("vp_bwd_rows_vec<float",)),
     ("vp_bwd_rows_bf16", ("vp_bwd_rows_vec<unsigned short",)),
-    ("lift_splat_backward", ("lift_splat_backward_kernel<float",)),
-    ("lift_splat_backward_bf16", ("lift_splat_backward_kernel<unsigned short",)),
+    ("lift_splat_backward", ("lss_splat_bwd_tile<float",)),
+    ("lift_splat_backward_bf16", ("lss_splat_bwd_tile<unsigned short",)),
+    ("lift_splat_backward_pixel", ("lift_splat_backward_kernel<float",)),
+    ("lift_splat_backward_pixel_bf16", ("lift_splat_backward_kernel<unsigned short",)),
     ("vp_planned_items", ("vp_planned_items",)), ("vp_planned_fold", ("vp_planned_fold",)),
     ("lift_kernel", ("lift_kernel<",)), ("lift_kernel_bf16", ("lift_kernel_bf16",)), ("lift_backward_vec4", ("lift_backward_vec4",)),
     ("vox_link", ("vox_link",)), ("vox_heads", ("vox_heads",)), ("vox_emit", ("vox_emit",)),

@@ -62,6 +62,18 @@ def main():
         "chunk_fwd": lambda h: h.mmt_lift_splat_forward(B, N, D, HW, C, nx, ny, nz, geom.data_ptr(), depth.data_ptr(), ctx.data_ptr(), out.data_ptr(), pos.data_ptr(), 0x10, st),
         "pixel_bwd": lambda h: h.mmt_lift_splat_backward(B, N, D, HW, C, nx, ny, pos.data_ptr(), depth.data_ptr(), ctx.data_ptr(), go.data_ptr(), ny * nx * C, 1, nx * C, C, gd.data_ptr(), gc.data_ptr(), st),
     }
+    if all(hasattr(h, "mmt_lss_splat_backward") for h in hs):
+        geom_pm = geom.permute(0, 1, 3, 4, 2, 5).contiguous()
+        depth_pm = depth.permute(0, 2, 3, 1).contiguous()
+        gd_pm = torch.empty_like(depth_pm)
+
+        def tile_bwd(h, pm=0):
+            gc.zero_()
+            return h.mmt_lss_splat_backward(B, N, D, fH, fW, C, nx, ny, nz, (geom_pm if pm else geom).data_ptr(), (depth_pm if pm else depth).data_ptr(),
+                                            ctx.data_ptr(), go.data_ptr(), ny * nx * C, 1, nx * C, C, (gd_pm if pm else gd).data_ptr(), gc.data_ptr(), pm, st)
+        cases["tile_bwd"] = tile_bwd
+        cases["tile_bwd_pixel_major"] = lambda h: tile_bwd(h, 0x100)
+        cases["tile_fwd_pixel_major"] = lambda h: h.mmt_lss_splat_forward(B, N, D, fH, fW, C, nx, ny, nz, geom_pm.data_ptr(), depth_pm.data_ptr(), ctx.data_ptr(), out.data_ptr(), None, 0x100, st)
     for p_, h in zip(libs, hs):
         if "STAMPS" in p_:      # diagnostic build: pos_memo receives 8 s_memtime stamps per workgroup
             pos.zero_()
