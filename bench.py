@@ -510,7 +510,7 @@ def rehearsal_main(args, rank, world):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "launcher rehearsal: gloo ranks on CPU, dense detection head only (the HIP hot path needs a GPU)",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "mode": "rehearsal-cpu", "final_loss": float(loss)}}), flush=True)
+                       "global_batch": world * B, "parallelism": f"dp{world}", "mode": "rehearsal-cpu", "final_loss": float(loss.detach())}}), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -625,18 +625,18 @@ def train_main(args, rank, local_rank, world):
         ny_l, nx_l = enc.output_shape
         vox_b, scat_b, scat_bwd_b = lidar_bytes(cfg["point_features"], total_pts, M, enc.num_features, enc.in_channels, B, ny_l, nx_l)
         t_vox, t_scat = _lib.mean_ms(timing["voxelize"]), _lib.mean_ms(timing["scatter"])
-        r = roofline_entry("vox_link + vox_heads + vox_emit (voxelize + mean) and fill + scatter_map + scatter_write_nhwc (pillar scatter), "
-                           "inside the training step", vox_b + scat_b, t_vox + t_scat,
-                           pmc_traffic(args.config, ("vox_link", "vox_heads", "vox_emit", "fill_i32_kernel", "scatter_map_kernel", "scatter_write_nhwc_kernel")))
+        r = roofline_entry("vox_link + vox_heads + vox_emit (voxelize + mean) and scatter_write_nhwc_table (pillar scatter straight from the "
+                           "voxelizer's table), inside the training step", vox_b + scat_b, t_vox + t_scat,
+                           pmc_traffic(args.config, ("vox_link", "vox_heads", "vox_emit", "scatter_write_nhwc_table_kernel")))
         r["parts"] = {"voxelize_mean": {"algorithmic_bytes": vox_b, "avg_ms": t_vox, "GBps": vox_b / t_vox / 1e6,
                                         "note": "bound by one scattered device-scope atomic per point (~20 G/s), not by HBM"},
                       "pillar_scatter": {"algorithmic_bytes": scat_b, "avg_ms": t_scat, "GBps": scat_b / t_scat / 1e6}}
         r["voxels"] = M
         res["roofline_lidar"] = r
         if timing.get("scatter_backward"):
-            res["roofline_lidar_backward"] = roofline_entry("scatter_backward_nhwc_kernel (pillar scatter backward)", scat_bwd_b,
+            res["roofline_lidar_backward"] = roofline_entry("scatter_backward_nhwc_unique_kernel (pillar scatter backward)", scat_bwd_b,
                                                             _lib.mean_ms(timing["scatter_backward"]),
-                                                            pmc_traffic(args.config, ("scatter_backward_nhwc_kernel",)))
+                                                            pmc_traffic(args.config, ("scatter_backward_nhwc_unique_kernel",)))
     if cfg["use_cam"] and not args.no_hotpath_leg:
         # the drop-in op at the same shape and geometry, right after the timed steps: the like-for-like figure
         # beside cpu_baseline and the BASELINE metric's "voxel_pooling HBM GB/s"

@@ -400,6 +400,18 @@ int mmt_pillar_scatter_nhwc_backward(int64_t num_voxels, int C, int batch_size, 
                                      const float *grad_canvas, const int32_t *coors, const int32_t *workspace,
                                      float *grad_feats, void *stream);
 
+/* Pillar scatter straight from the voxelizer's table (ABI 4; what LidarEncoder.forward_bev runs): for the fixed-capacity
+ * rows of an mmt_hard_voxelize_mean call on `table` -- distinct cells by construction -- the canvas pass reads the table
+ * entries (the emit kernel leaves generation | owned | voxel id in them) instead of building a cell -> row map: one kernel,
+ * no fill, no atomics.  Must run on the same stream after that voxelization and before the next one on the table; needs a
+ * single z layer and (ny, nx) = the voxel grid's (y, x); feats fp32 [B*max_voxels, C], canvas fp32 [B, ny, nx, C] fully written.
+ * _unique_backward: grad_feats[m,:] = grad_canvas[cell(coors[m]),:] for rows whose coors are valid, 0 otherwise -- no map. */
+int mmt_pillar_scatter_nhwc_table(int C, int batch_size, int ny, int nx, int max_voxels, const float *voxel_features,
+                                  const int32_t *table, float *canvas, void *stream);
+int mmt_pillar_scatter_nhwc_unique_backward(int64_t num_voxels, int C, int batch_size, int ny, int nx,
+                                            const float *grad_canvas, const int32_t *coors, float *grad_feats,
+                                            void *stream);
+
 /* --------------------------------------------------------- per-step label generation */
 
 /* LiDAR depth supervision of the camera branch: replaces

@@ -34,6 +34,7 @@ constexpr int kTile = 256;            // points per tile / threads per workgroup
 constexpr int kTileWaves = kTile / 64;
 constexpr int kIdxBits = 24;          // point index inside its sample (host checks N < 2^24)
 constexpr unsigned long long kIdxMask = (1ull << kIdxBits) - 1ull;
+constexpr unsigned long long kOwnedBit = 1ull << (kIdxBits - 1);   // vox_emit: the entry now holds the cell's VOXEL ID (points < 2^23)
 constexpr int kMaxBatchLds = 255;     // sample offsets cached in LDS up to this batch size
 
 struct VoxArgs {
@@ -53,6 +54,7 @@ struct VoxArgs {
     int32_t *num_points;
     int32_t *voxel_count;
     float *mean;                   // may be NULL
+    int mark_owned;                // vox_emit leaves (generation | owned | voxel id) in the entries of the cells it emitted
 };
 
 __device__ __forceinline__ int cell_coord(float p, float rmin, float vs) {
@@ -202,6 +204,9 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
             }
             cnt[r] = c;
             cellv[r] = cell;
+            // the chain has been read: the cell's entry now names its voxel, (generation | owned | voxel id), for the pillar
+            // scatter that follows (mmt_pillar_scatter_nhwc_table reads the table instead of building a cell -> row map)
+            if (a.mark_owned) a.table[2 + (int64_t)b * cells + cell] = (a.table[0] << kIdxBits) | kOwnedBit | (unsigned long long)(off + r);
         }
     }
     __syncthreads();
@@ -423,6 +428,7 @@ int vox_run(const char *what, int B, int64_t N, int F, const float *points, cons
     a.hrank = a.next + N;
     a.tile_counts = a.hrank + N;
     a.voxels = voxels; a.coors = coors; a.num_points = num_points; a.voxel_count = voxel_count; a.mean = mean;
+    a.mark_owned = (N < (1ll << (kIdxBits - 1))) ? 1 : 0;
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
     const unsigned gpts = (unsigned)mmt::stream_grid(N > 0 ? N : 1, kTile, 4096);
     const unsigned gtiles = (unsigned)(vox_tiles(N) + B);       // flattened (sample, tile) space, see locate_tile
@@ -689,6 +695,103 @@ extern "C" int mmt_pillar_scatter_nhwc(int64_t M, int C, int B, int ny, int nx, 
     seq.launch(true, scatter_write_nhwc_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / (C / 4))) * 256, 256, 256 * 32)), dim3(256), 0, st,
                C / 4, cells, feats, (const int32_t *)workspace, canvas);
     return mmt::check_launch("pillar_scatter_nhwc");
+}
+
+// Pillar scatter straight from the voxelizer's table (the model path: LidarEncoder.forward_bev).  The rows of the
+// fixed-capacity layout own DISTINCT cells, and vox_emit has left (generation | owned | voxel id) in the table entry of every
+// cell it emitted, so the canvas pass needs neither the cell -> row map, nor its fill, nor the scatter_map kernel: an entry
+// of another generation (or a chain head that lost to the voxel cap) reads as an empty cell.
+__global__ __launch_bounds__(256) void scatter_write_nhwc_table_kernel(int C4, int B, int64_t cells_per_sample, int V,
+                                                                       const float *feats, const unsigned long long *table,
+                                                                       float *canvas) {
+    constexpr int kCells = 4;
+    const int lane_in = threadIdx.x % C4;
+    const int groups_per_block = 256 / C4;
+    const int grp = threadIdx.x / C4;
+    if (grp >= groups_per_block) return;
+    const unsigned long long gen = table[0];            // the voxelization that ran last on this table
+    const int64_t cells = (int64_t)B * cells_per_sample;
+    const int64_t ngroups = (int64_t)gridDim.x * groups_per_block;
+    for (int64_t c0 = ((int64_t)blockIdx.x * groups_per_block + grp) * kCells; c0 < cells; c0 += ngroups * kCells) {
+        unsigned long long e[kCells];
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) e[u] = table[2 + ((c0 + u) < cells ? (c0 + u) : (cells - 1))];
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) {
+            if (c0 + u >= cells) break;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((e[u] >> kIdxBits) == gen && (e[u] & kOwnedBit)) {
+                const int64_t row = (c0 + u) / cells_per_sample * V + (int64_t)(e[u] & (kOwnedBit - 1));
+                v = reinterpret_cast<const float4 *>(feats)[row * C4 + lane_in];
+            }
+            mmt_nt_store4(v, reinterpret_cast<float4 *>(canvas) + (c0 + u) * C4 + lane_in);
+        }
+    }
+}
+
+// backward for rows that own distinct cells: grad_feats[m,:] = grad_canvas[cell(m),:] (0 for rows without a cell)
+template <int kRows>
+__global__ __launch_bounds__(256) void scatter_backward_nhwc_unique_kernel(int64_t M, int C4, int B, int ny, int nx,
+                                                                           const float *grad_canvas, const int32_t *coors,
+                                                                           float *grad_feats, unsigned span_bytes) {
+    const int gpb = 256 / C4;
+    const int grp = threadIdx.x / C4, li = threadIdx.x - grp * C4;
+    if (grp >= gpb) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(grad_canvas), 0, (int)span_bytes, 0x00020000);
+    const int4 *co4 = reinterpret_cast<const int4 *>(coors);
+    const int64_t step = (int64_t)gridDim.x * gpb * kRows;
+    for (int64_t m0 = ((int64_t)blockIdx.x * gpb + grp) * kRows; m0 < M; m0 += step) {
+        int4 co[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) co[u] = co4[(m0 + u) < M ? (m0 + u) : (M - 1)];
+        mmt_u32x4 v[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            const int b = co[u].x, y = co[u].z, x = co[u].w;
+            const bool ok = !(b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx) && (m0 + u) < M;
+            const int64_t cell = ((int64_t)b * ny + y) * nx + x;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (unsigned)((cell * C4 + li) << 4) : 0xFFFFFFF0u, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u)
+            if (m0 + u < M) reinterpret_cast<mmt_u32x4 *>(grad_feats)[(m0 + u) * C4 + li] = v[u];
+    }
+}
+
+extern "C" int mmt_pillar_scatter_nhwc_table(int C, int B, int ny, int nx, int max_voxels, const float *feats,
+                                             const int32_t *table, float *canvas, void *stream) {
+    MMT_REQUIRE_PTR(feats);
+    MMT_REQUIRE_PTR(table);
+    MMT_REQUIRE_PTR(canvas);
+    if (C <= 0 || C % 4 || C > 1024 || B <= 0 || ny <= 0 || nx <= 0 || max_voxels <= 0 || max_voxels > (1 << (kIdxBits - 1)) ||
+        ((uintptr_t)canvas & 15) || ((uintptr_t)feats & 15) || ((uintptr_t)table & 7))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_table: bad sizes (C %% 4 == 0, C <= 1024, aligned buffers, max_voxels <= 2^23)");
+    const int64_t cells = (int64_t)B * ny * nx;
+    if (cells >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "pillar_scatter_nhwc_table: B*ny*nx exceeds int32");
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    seq.launch(true, scatter_write_nhwc_table_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / (C / 4))) * 256, 256, 256 * 32)),
+               dim3(256), 0, (hipStream_t)stream, C / 4, B, (int64_t)ny * nx, max_voxels, feats,
+               reinterpret_cast<const unsigned long long *>(table), canvas);
+    return mmt::check_launch("pillar_scatter_nhwc_table");
+}
+
+extern "C" int mmt_pillar_scatter_nhwc_unique_backward(int64_t M, int C, int B, int ny, int nx, const float *grad_canvas,
+                                                       const int32_t *coors, float *grad_feats, void *stream) {
+    if (M == 0) return MMT_OK;
+    MMT_REQUIRE_PTR(grad_canvas);
+    MMT_REQUIRE_PTR(coors);
+    MMT_REQUIRE_PTR(grad_feats);
+    const int64_t span = (int64_t)B * ny * nx * C * 4;
+    if (M < 0 || C <= 0 || C % 4 || C > 1024 || B <= 0 || ny <= 0 || nx <= 0 || ((uintptr_t)grad_canvas & 15) || ((uintptr_t)grad_feats & 15) ||
+        ((uintptr_t)coors & 15) || span >= (1ll << 32) - 16)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_unique_backward: bad sizes (C %% 4 == 0, C <= 1024, 16-byte aligned buffers, canvas < 4 GiB)");
+    constexpr int kRows = 4;
+    const int C4 = C / 4, gpb = 256 / C4;
+    mmt::TimedSeq seq;
+    seq.launch(true, scatter_backward_nhwc_unique_kernel<kRows>, dim3(mmt::stream_grid(mmt::ceil_div(M, (int64_t)gpb * kRows) * 256, 256, 256 * 16)),
+               dim3(256), 0, (hipStream_t)stream, M, C4, B, ny, nx, grad_canvas, coors, grad_feats, (unsigned)span);
+    return mmt::check_launch("pillar_scatter_nhwc_unique_backward");
 }
 
 extern "C" int mmt_pillar_scatter_nhwc_backward(int64_t M, int C, int B, int ny, int nx, const float *grad_canvas,

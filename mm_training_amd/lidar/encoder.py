@@ -69,7 +69,7 @@ def _batch_points(points_list):
 
 
 def hard_voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
-                             num_features, materialize_voxels=True):
+                             num_features, materialize_voxels=True, return_table=False):
     """Batched hard voxelization fused with the HardSimpleVFE mean (mmt_hard_voxelize_mean: three kernels,
     no clearing pass, no host sync).  Fixed-capacity layout: returns (voxels | None, num_points, coors,
     voxel_count, mean [B*max_voxels, num_features]); unused rows have coors = -1, num_points = 0, mean = 0."""
@@ -91,6 +91,8 @@ def hard_voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num
                         _lib.float3(voxel_size), _lib.float3(point_cloud_range[:3]), grid_c, T, V, int(num_features),
                         voxels.data_ptr() if materialize_voxels else 0, coors.data_ptr(), num_points.data_ptr(),
                         voxel_count.data_ptr(), mean.data_ptr(), table.data_ptr(), scratch.data_ptr(), _stream())
+    if return_table:     # for pillar_scatter_from_table: the scatter reads the voxel ids vox_emit left in the table
+        return voxels, num_points, coors, voxel_count, mean, table
     return voxels, num_points, coors, voxel_count, mean
 
 
@@ -192,6 +194,40 @@ class _PillarScatter(Function):
         return grad_feats, None, None, None, None, None
 
 
+class _PillarScatterTable(Function):
+    """Channels-last pillar scatter of the fixed-capacity rows of hard_voxelize_mean_batch straight from the voxelizer's
+    table (mmt_pillar_scatter_nhwc_table): the rows own distinct cells, no cell -> row map is built."""
+
+    @staticmethod
+    def forward(ctx, feats, coors, table, batch_size, ny, nx, max_voxels):
+        feats = feats.contiguous()
+        M, C = feats.shape
+        canvas = torch.empty((batch_size, ny, nx, C), dtype=torch.float32, device=feats.device)
+        with torch.cuda.device(feats.device):
+            _lib.timed_call("scatter", "mmt_pillar_scatter_nhwc_table", C, batch_size, ny, nx, max_voxels, feats.data_ptr(),
+                            table.data_ptr(), canvas.data_ptr(), _stream())
+        ctx.save_for_backward(coors)
+        ctx.dims = (M, C, batch_size, ny, nx)
+        return canvas.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_canvas):
+        (coors,) = ctx.saved_tensors
+        M, C, B, ny, nx = ctx.dims
+        grad_feats = torch.empty((M, C), dtype=torch.float32, device=grad_canvas.device)
+        if not grad_canvas.is_contiguous(memory_format=torch.channels_last):
+            grad_canvas = grad_canvas.contiguous(memory_format=torch.channels_last)
+        with torch.cuda.device(grad_canvas.device):
+            _lib.timed_call("scatter_backward", "mmt_pillar_scatter_nhwc_unique_backward", M, C, B, ny, nx, grad_canvas.data_ptr(),
+                            coors.data_ptr(), grad_feats.data_ptr(), _stream())
+        return grad_feats, None, None, None, None, None, None
+
+
+def pillar_scatter_from_table(voxel_features, coors, table, batch_size, ny, nx, max_voxels):
+    """[B*max_voxels, C] rows of the LAST hard_voxelize_mean_batch call on `table` -> channels_last [B, C, ny, nx] canvas."""
+    return _PillarScatterTable.apply(voxel_features, coors.contiguous(), table, int(batch_size), int(ny), int(nx), int(max_voxels))
+
+
 def pillar_scatter(voxel_features, coors, batch_size, ny, nx, channels_last=False):
     """PointPillarsScatter: dense [B, C, ny, nx] canvas from per-voxel features.  ``channels_last=True``
     returns the same tensor in torch.channels_last memory (what channels_last convolutions consume:
@@ -253,12 +289,17 @@ class LidarEncoder(nn.Module):
         """voxelize + mean (ONE fused call, the padded voxel tensor is not materialised) -> (MLP) -> scatter
         with NO host synchronisation: stays in the fixed-capacity layout; empty rows carry coors = -1 and
         are ignored by the scatter."""
+        # the scatter can read the voxelizer's own table when a canvas cell IS a voxel cell (one z layer, same y/x grid)
+        direct = (self.channels_last and self.grid[2] == 1 and self.output_shape == [self.grid[1], self.grid[0]]
+                  and self.in_channels % 4 == 0 and self.max_voxels <= (1 << 23))
         with torch.no_grad():
             pts = [p.float() for p in points]
-            _, _, coors, _, feats = hard_voxelize_mean_batch(
+            _, _, coors, _, feats, table = hard_voxelize_mean_batch(
                 pts, self.voxel_size, self.point_cloud_range, self.max_num_points, self.max_voxels,
-                self.num_features, materialize_voxels=False)
+                self.num_features, materialize_voxels=False, return_table=True)
         if self.pillar_mlp is not None:
             feats = self.pillar_mlp(feats)
+        if direct and sum(int(p.shape[0]) for p in points) < (1 << 23):
+            return pillar_scatter_from_table(feats, coors, table, len(points), self.output_shape[0], self.output_shape[1], self.max_voxels)
         return pillar_scatter(feats, coors, len(points), self.output_shape[0], self.output_shape[1],
                               channels_last=self.channels_last)

@@ -167,6 +167,34 @@ def test_pillar_scatter_forward_backward(mmt_lib, oracle_mod, channels_last):
     assert e.shape == (1, 4, 8, 8) and float(e.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("cfg", [([40000, 35000, 0, 1], 25000, 64), ([30000, 20000], 6000, 8)])
+def test_pillar_scatter_from_the_voxelizer_table(mmt_lib, oracle_mod, cfg):
+    """mmt_pillar_scatter_nhwc_table: the canvas written straight from the table entries vox_emit marks (no cell -> row map),
+    against the oracle's scatter of the oracle's voxels; gradient = the oracle's scatter backward; repeated on the same
+    (never cleared) table with other clouds in between, with the voxel cap hit (cells whose head lost to the cap stay empty)."""
+    from mm_training_amd.lidar import hard_voxelize_mean_batch, pillar_scatter_from_table
+    sizes, V, C = cfg
+    rng = np.random.default_rng(3)
+    ny, nx = 256, 2048
+    for seed in (41, 42, 41):
+        frames = _frames(sizes, seed=seed, dense=(V < 25000))
+        dev = [f.cuda() for f in frames]
+        _, n, c, cnt, m, table = hard_voxelize_mean_batch(dev, VSIZE, RANGE, 15, V, 5, materialize_voxels=False, return_table=True)
+        rv, rn, rc = oracle_mod.voxelize_batch([f.numpy() for f in frames], VSIZE, RANGE, 15, V)
+        B, M = len(frames), rc.shape[0]
+        live = (c[:, 0] >= 0).cpu().numpy()
+        assert int(live.sum()) == M
+        feats_full = torch.from_numpy(rng.standard_normal((B * V, C)).astype(np.float32)).cuda().requires_grad_(True)
+        canvas = pillar_scatter_from_table(feats_full, c, table, B, ny, nx, V)
+        assert canvas.shape == (B, C, ny, nx) and canvas.is_contiguous(memory_format=torch.channels_last)
+        ref = oracle_mod.pillar_scatter(feats_full.detach().cpu().numpy()[live], rc, B, ny, nx)
+        assert np.array_equal(canvas.detach().cpu().numpy(), ref)
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        canvas.backward(torch.from_numpy(g).cuda())
+        gf = feats_full.grad.cpu().numpy()
+        assert np.array_equal(gf[live], oracle_mod.pillar_scatter_backward(g, rc)) and float(np.abs(gf[~live]).sum()) == 0.0
+
+
 def test_lidar_encoder_three_calls(mmt_lib, oracle_mod):
     """The call sequence of models/bev_depth.py:181-183."""
     from mm_training_amd.lidar import LidarEncoder

@@ -28,6 +28,7 @@ KERNELS = [
     ("vox_link", ("vox_link",)), ("vox_heads", ("vox_heads",)), ("vox_emit", ("vox_emit",)),
     ("fill_i32_kernel", ("fill_i32_kernel",)), ("scatter_map_kernel", ("scatter_map_kernel",)),
     ("scatter_write_nhwc_kernel", ("scatter_write_nhwc_kernel",)), ("scatter_backward_nhwc_kernel", ("scatter_backward_nhwc_kernel",)),
+    ("scatter_write_nhwc_table_kernel", ("scatter_write_nhwc_table_kernel",)), ("scatter_backward_nhwc_unique_kernel", ("scatter_backward_nhwc_unique_kernel",)),
     ("dcn_col2im", ("dcn_col2im",)), ("dcn_im2col", ("dcn_im2col",)),
     ("bev_warp_kernel", ("bev_warp_kernel",)), ("bev_warp_backward_gather", ("bev_warp_backward_gather",)),
 ]
