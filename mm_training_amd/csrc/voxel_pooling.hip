@@ -4,10 +4,19 @@
 // launcher) and ops/voxel_pooling/voxel_pooling.py:58-69 (backward, pure ATen in the
 // reference).  Not a translation of the CUDA kernel: the reference maps one THREAD to
 // a point and loops over channels with strided loads + one contended fp32 atomic per
-// channel.  Here the [B*P, C] feature matrix is streamed as flat 16-byte vectors
-// (1 KiB contiguous per wave instruction), points of one chunk that fall into the
-// same BEV cell are summed in an LDS-resident tile of BEV rows (ds_add_f32), and each
-// touched cell leaves the workgroup as ONE coalesced row of global fp32 atomics.
+// channel.  The default forward (ALGO_AUTO = SEG_GATHER, vp_fwd_seg_gather) gives a
+// workgroup a chunk of consecutive points, sorts the chunk by BEV cell in LDS (hash ->
+// count -> wave scan -> counting sort), lets every lane group of a wave sum one cell's
+// feature rows (whole 16-byte-per-lane rows, rows of dropped points never fetched) in
+// fp32 REGISTERS, and sends one contiguous run of global fp32 atomics per (chunk, cell).
+// The backward is a two-pass gather (row offsets + cache warm-up, then a software-
+// pipelined, XCD-partitioned row gather through a range-checked buffer descriptor with
+// non-temporal 16-byte stores).  Feature storage is a template argument: fp32 (the
+// reference's type) or bf16 (SURVEY 5.6 / BASELINE configs[4]; fp32 accumulation).
+// ROW_ATOMIC / LDS_ATOMIC / STREAM are earlier algorithms kept selectable (odd channel
+// counts fall back to them) and as measured comparison points.
+// This file also holds the first-generation fused lift-splat pair (mmt_lift_splat_*);
+// the frustum-tile pair the model runs is in lift_splat_tile.hip.
 //
 // HBM traffic per call (algorithmic): 12*BP geom + 12*BP pos_memo + 4*C*K features
 // of kept points + 4*C*B*ny*nx BEV rows.
