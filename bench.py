@@ -590,16 +590,20 @@ def train_main(args, rank, local_rank, world):
         if fused and timing.get("lift_splat_forward"):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["lift_splat_forward"]), _lib.mean_ms(timing["lift_splat_backward"])
             fbytes, bbytes, l2f, l2b = lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, fb)
-            note = ("fused lift + voxel_pooling (SURVEY 8/f1): the [B*P, C] feature matrix is never materialised, so the HBM-side "
-                    "algorithmic bytes are ~5x below the drop-in op's; the kernels are bound by the latency of their per-workgroup "
-                    "chain (load, LDS hash / sort, gather) and by L2 row gathers, not by HBM -- l2_side prices the rows a "
-                    "point-wise gather moves against the aggregate L2 bandwidth; the drop-in op's HBM roofline is "
+            note = ("fused lift + voxel_pooling (SURVEY 8/f1), ray walks: the [B*P, C] feature matrix is never materialised, so the "
+                    "HBM-side algorithmic bytes are ~5x below the drop-in op's.  The forward is bound by the memory-side fp32 atomic "
+                    "units (about 1.2 TB/s of added bytes in whole 64-byte segments, tools/ubench/atomic_rows.hip: ~25 MB of BEV rows "
+                    "per launch at this shape), the backward by L1 row gathers and VALU issue, neither by HBM -- l2_side prices the "
+                    "rows a point-wise gather moves against the aggregate L2 bandwidth; the drop-in op's HBM roofline is "
                     "roofline_voxel_pooling[_backward]")
             sfx = "_bf16" if dtype == "bf16" else ""
-            res["roofline"] = roofline_entry(f"lss_splat_fwd_tile{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
-                                             pmc_traffic(args.config, ("lift_splat_forward",)), l2f, note)
-            res["roofline_backward"] = roofline_entry(f"lss_splat_bwd_tile{sfx} (fused lift-splat backward = the step's voxel_pooling backward)", bbytes, bwd_ms,
-                                                      pmc_traffic(args.config, ("lift_splat_backward",)), l2b)
+            tiles = os.environ.get("MMT_LIFT_SPLAT_TILES", "0") == "1"      # A/B switch: the second-generation frustum-tile kernels
+            kfwd, kbwd = ("lss_splat_fwd_tile", "lss_splat_bwd_tile") if tiles else ("lss_ray_fwd", "lss_ray_bwd")
+            res["config"]["lift_splat_kernels"] = "frustum tiles" if tiles else "ray walks"
+            res["roofline"] = roofline_entry(f"{kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
+                                             pmc_traffic(args.config, ("lift_splat_forward_tile" if tiles else "lift_splat_forward",)), l2f, note)
+            res["roofline_backward"] = roofline_entry(f"{kbwd}{sfx} (fused lift-splat backward = the step's voxel_pooling backward)", bbytes, bwd_ms,
+                                                      pmc_traffic(args.config, ("lift_splat_backward_tile" if tiles else "lift_splat_backward",)), l2b)
         elif timing.get("forward"):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["forward"]), _lib.mean_ms(timing["backward"])
             fbytes, bbytes = algorithmic_bytes(BP, K, C, B, ny, nx, fb)

@@ -33,7 +33,7 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 4
+#define MMT_ABI_VERSION 5
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -243,11 +243,13 @@ int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x
                           const float *grad_col, float *grad_x, float *grad_offset, int32_t *workspace,
                           int64_t workspace_elems, void *stream);
 
-/* Fused lift-splat, frustum-tile form (ABI 4; SURVEY section 8 row f1, second generation): the same result as
- * mmt_lift_splat_forward for a point set laid out as a camera frustum [B*N, D, fH, fW] -- a workgroup owns a tile of
- * image columns x all fH rows x a range of depth bins, keeps the tile's context rows in LDS and emits one run of
- * atomics per BEV cell the tile touches.  Correct for any geom values; fast when pixels of a column / neighbouring depth
- * bins share cells (what a pinhole frustum gives).  pos_memo may be NULL (not written).  fH <= 512, C % 4 == 0, C <= 256.
+/* Fused lift-splat on a camera frustum (ABI 4): the same result as mmt_lift_splat_forward for a
+ * point set laid out as a frustum [B*N, D, fH, fW].  Default kernels (ABI 5): RAY WALKS -- a workgroup owns one image
+ * column, its lane groups walk (depth bin, image row) and sum depth * context in registers for as long as the BEV cell
+ * stays the same, one run of fp32 atomics per change of cell.  MMT_LSS_TILE_KERNELS selects the second-generation
+ * frustum-tile kernels (hash + sort of a 512-point tile in LDS; less sensitive to unstructured geometry).  Either is
+ * correct for any geom values; both are fast when the pixels of a column / neighbouring depth bins share cells (what a
+ * pinhole frustum gives).  pos_memo may be NULL (not written).  fH <= 512, C % 4 == 0, C <= 256.
  * _bf16: depth and context stored as bf16 (C % 8 == 0), fp32 products and sums. */
 #define MMT_LSS_PIXEL_MAJOR 0x100 /* flags of the mmt_lss_splat_* entry points: geom_xyz / depth / grad_depth / pos_memo are laid
                                      out PIXEL-major, [B*N, fH, fW, D(, 3)] -- the channels-last order the dense nets produce
@@ -256,6 +258,7 @@ int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x
                                      8- / 24-byte pieces (4x fewer memory transactions: the kernels are bound by those).
                                      mmt_frustum_geometry yields that geom order when it is given the frustum permuted to
                                      [fH, fW, D, 4]. */
+#define MMT_LSS_TILE_KERNELS 0x200 /* mmt_lss_splat_*: the frustum-tile kernels instead of the ray walks (A/B runs) */
 int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
                           int num_voxel_z, const int32_t *geom_xyz, const float *depth, const float *context,
                           float *output_features, int32_t *pos_memo, int flags, void *stream);
@@ -263,11 +266,12 @@ int mmt_lss_splat_forward_bf16(int B, int N, int D, int fH, int fW, int C, int n
                                int num_voxel_z, const int32_t *geom_xyz, const uint16_t *depth,
                                const uint16_t *context, float *output_features, int32_t *pos_memo, int flags,
                                void *stream);
-/* Backward on the same tiles: the kept test is redone from geom_xyz (no pos_memo), the BEV-gradient rows of a tile's cells
- * are loaded once into LDS.  grad_output fp32 [B,C,ny,nx] addressed through element strides, stride_c must be 1
- * (channels-last).  grad_depth [B*N, D, fH*fW] (fp32, or bf16 in the _bf16 form) is fully written; grad_context fp32
- * [B*N, fH*fW, C] is ACCUMULATED INTO with fp32 atomics (one partial sum per pixel and depth tile): the caller zero-fills it
- * (and rounds it to bf16 afterwards if it wants bf16).  C % 16 == 0, C <= 256, fH <= 512. */
+/* Backward: the kept test is redone from geom_xyz (no pos_memo).  Ray walk: a lane group owns one pixel and walks its D
+ * depth bins, context row and grad_context sum in registers, BEV-gradient rows read from L2 -- no atomics.  (Tile
+ * kernels: the rows of a tile's cells in LDS, grad_context through fp32 atomics after an internal zero-fill.)
+ * grad_output fp32 [B,C,ny,nx] addressed through element strides, stride_c must be 1 (channels-last).  grad_depth
+ * [B*N, D, fH*fW] (fp32, or bf16 in the _bf16 form) and grad_context fp32 [B*N, fH*fW, C] are fully WRITTEN: the caller
+ * need not zero-fill (and rounds grad_context to bf16 afterwards if it wants bf16).  C % 16 == 0, C <= 256, fH <= 512. */
 int mmt_lss_splat_backward(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
                            int num_voxel_z, const int32_t *geom_xyz, const float *depth, const float *context,
                            const float *grad_output, int64_t stride_b, int64_t stride_c, int64_t stride_y,

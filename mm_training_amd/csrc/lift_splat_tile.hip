@@ -451,6 +451,366 @@ __global__ __launch_bounds__(kBlock) void lss_splat_bwd_tile(TileArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Third generation: RAY WALKS.  No hash, no sort, one workgroup barrier (forward) or none (backward).
+//
+// The points of one image column at one depth bin sit above each other in the world: for a (nearly) level camera they
+// fall into the same BEV cell, and the next depth bin of that ray falls into the same or the neighbouring cell.  A walk
+// over (depth bin, image row) of ONE column therefore sees the same cell dozens of times in a row, and a plain
+// run-length sum in registers already removes ~95 % of the atomic rows -- for any geometry the result is the same, an
+// unstructured one merely flushes more often.
+//
+// Forward: a workgroup owns one image column of one camera (optionally a depth slab of it).  Its geometry is reduced to
+// (cell, depth) records in LDS by all threads at once (coalesced in the pixel-major layout), the column's fH context
+// rows are staged in LDS as fp32, then every lane group walks `kd` consecutive depth bins x fH rows, summing
+// depth * context into 4 registers per lane (lane li holds channels li, li + C/4, li + 2C/4, li + 3C/4, so that a
+// flush is 4 atomic instructions of C/4 CONTIGUOUS floats each) and flushing when the cell changes.
+//
+// Backward: a lane group owns one PIXEL and walks its D depth bins: context row and grad_context sum in registers,
+// BEV-gradient rows straight from L2 through a range-checked buffer descriptor (dropped points read zeros), four rows
+// in flight; grad_depth = <g_row, ctx_row> by quad DPP sums whose C/16 partials meet in a small per-group LDS buffer
+// once per C/4 depth bins.  A pixel belongs to one lane group, so grad_context is a plain store: no atomics, no
+// zero-fill, no barrier.  The 4*G pixels of a workgroup are neighbours in one column (same ray => same BEV rows, L1 hits).
+struct RayArgs {
+    int BN, N, D, fH, fW, C, nx, ny, nz;
+    int pm, write_dropped;
+    int dsplit, dspan, kd;         // forward: depth slabs per ray, bins per slab, bins per lane group
+    int wpc;                       // backward: workgroups per camera
+    const int32_t *geom;
+    const void *depth;
+    const void *context;
+    float *out;
+    int32_t *pos_memo;
+    const float *grad_out;
+    int64_t sb, sy, sx;
+    int span_bytes;
+    void *grad_depth;
+    float *grad_context;
+};
+
+__device__ __forceinline__ int64_t ray_point(const RayArgs &a, int bn, int row, int col, int d) {
+    return a.pm ? (((int64_t)bn * a.fH + row) * a.fW + col) * a.D + d : (((int64_t)bn * a.D + d) * a.fH + row) * a.fW + col;
+}
+
+// LDS (dynamic): ctx [fH][C] fp32 | rec [fH][dspan] (cell or -1, depth bits)
+// S = C / 16: a lane group is 16 lanes, lane li holds channels li, li + 16, ... (S registers), so that one atomic
+// instruction of a group is one whole, aligned 64-byte segment of a BEV row -- the memory-side atomic units work in 64-byte
+// requests, and 80-byte pieces (C/4 lanes x 4 registers) or 16-byte lane strides cost 1.6x / 4x as many of them
+// (tools/ubench/atomic_rows.hip).  The 16 lane groups of a workgroup split the depth bins of the column among them.
+template <typename FT, int S>
+__global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
+    extern __shared__ __align__(16) float ray_lds[];
+    constexpr int C = 16 * S;
+    const int L = blockIdx.x, xcd = L & 7, i = L >> 3;
+    const int per = a.fW * a.dsplit;
+    const int q = i / per, r = i - q * per;
+    const int bn = q * 8 + xcd;                       // the columns of one camera share an XCD (context rows, geom lines)
+    if (bn >= a.BN) return;
+    const int col = r / a.dsplit, slab = r - col * a.dsplit;
+    const int d0 = slab * a.dspan;
+    const int dn = (a.D - d0) < a.dspan ? (a.D - d0) : a.dspan;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fH = a.fH, HW = a.fH * a.fW;
+    const int b = bn / a.N;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+    // padded row strides: the 4 lane groups of a wave read the same context row (broadcast) but records 2 * kd dwords apart
+    constexpr int CP = C + 4;
+    const int dnp = a.dspan | 1;
+    float *ctx = ray_lds;
+    int2 *rec = reinterpret_cast<int2 *>(ray_lds + fH * CP);
+
+    // ---- all threads: geometry -> (cell, depth) records
+    const int npts = fH * dn;
+    for (int p0 = tid; p0 < npts; p0 += kBlock * 4) {
+        int gx[4], gy[4], gz[4];
+        float dv[4];
+        int64_t t[4];
+        int row_of[4], dd_of[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * kBlock;
+            const int pc = p < npts ? p : 0;
+            const int row = pc / dn, dd = pc - row * dn;
+            row_of[u] = row; dd_of[u] = dd;
+            t[u] = ray_point(a, bn, row, col, d0 + dd);
+            gx[u] = a.geom[t[u] * 3]; gy[u] = a.geom[t[u] * 3 + 1]; gz[u] = a.geom[t[u] * 3 + 2];
+            dv[u] = Elem<FT>::scalar(depth + t[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * kBlock;
+            if (p < npts) {
+                const bool keep = !(gx[u] < 0 || gx[u] >= a.nx || gy[u] < 0 || gy[u] >= a.ny || gz[u] < 0 || gz[u] >= a.nz);
+                rec[row_of[u] * dnp + dd_of[u]] = make_int2(keep ? (b * a.ny + gy[u]) * a.nx + gx[u] : -1, keep ? __float_as_int(dv[u]) : 0);
+                if (a.pos_memo) {
+                    if (keep) {
+                        a.pos_memo[t[u] * 3] = b; a.pos_memo[t[u] * 3 + 1] = gy[u]; a.pos_memo[t[u] * 3 + 2] = gx[u];
+                    } else if (a.write_dropped) {
+                        a.pos_memo[t[u] * 3] = -1; a.pos_memo[t[u] * 3 + 1] = -1; a.pos_memo[t[u] * 3 + 2] = -1;
+                    }
+                }
+            }
+        }
+    }
+    {
+        constexpr int VEC = Elem<FT>::VEC;
+        constexpr int CV = C / VEC;
+        for (int e = tid; e < fH * CV; e += kBlock) {
+            const int row = e / CV, cv = e - row * CV;
+            Elem<FT>::to_lds(context + ((int64_t)bn * HW + row * a.fW + col) * C + cv * VEC, ctx + row * CP + cv * VEC);
+        }
+    }
+    __syncthreads();
+
+    // ---- 16 lane groups (4 per wave): kd depth bins x all fH rows each, run-length sums in registers (no barrier below)
+    const int g = lane >> 4, li = lane & 15;
+    const int ds = (wave * 4 + g) * a.kd;
+    const int de = (ds + a.kd) < dn ? (ds + a.kd) : dn;
+    float acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = 0.f;
+    int cur = -1;
+    const float *cl = ctx + li;
+    auto flush = [&]() __attribute__((always_inline)) {
+        float *o = a.out + (int64_t)cur * C + li;
+#pragma unroll
+        for (int j = 0; j < S; ++j) unsafeAtomicAdd(o + 16 * j, acc[j]);
+    };
+    for (int dd = ds; dd < de; ++dd) {
+        for (int r0 = 0; r0 < fH; r0 += 4) {
+            int2 kr[4];
+            float c[4][S];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = (r0 + u) < fH ? (r0 + u) : (fH - 1);
+                kr[u] = rec[row * dnp + dd];
+                if ((r0 + u) >= fH) kr[u] = make_int2(-1, 0);
+#pragma unroll
+                for (int j = 0; j < S; ++j) c[u][j] = cl[row * CP + 16 * j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = kr[u].x;
+                if (key >= 0 && key != cur) {
+                    if (cur >= 0) flush();
+                    cur = key;
+#pragma unroll
+                    for (int j = 0; j < S; ++j) acc[j] = 0.f;
+                }
+                const float dv = __int_as_float(kr[u].y);      // 0 for dropped points
+#pragma unroll
+                for (int j = 0; j < S; ++j) acc[j] = __builtin_fmaf(dv, c[u][j], acc[j]);
+            }
+        }
+    }
+    if (cur >= 0) flush();
+}
+
+__device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes of a quad, in all 4 (DPP quad_perm, no LDS)
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
+    return v;
+}
+
+constexpr int kRayBins = 16;        // depth bins per reduction batch of the backward walk (4 sub-batches of 4)
+
+// LDS (dynamic), per lane group: off [D] int (byte offset of the BEV-gradient row or an out-of-range value) | dep [D] fp32 |
+// part [kRayBins][C4/4] fp32
+template <typename FT, int C4T>
+__global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
+    extern __shared__ __align__(16) float ray_lds[];
+    const int L = blockIdx.x, xcd = L & 7, i = L >> 3;
+    const int q = i / a.wpc, w = i - q * a.wpc;
+    const int bn = q * 8 + xcd;
+    if (bn >= a.BN) return;
+    const int C = a.C, D = a.D;
+    const int C4 = C4T > 0 ? C4T : C >> 2;
+    const int G = 64 / C4, Q = C4 >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fH = a.fH, HW = a.fH * a.fW;
+    const int b = bn / a.N;
+    const int g = lane / C4, li = lane - g * C4;
+    const int slot = wave * G + (g < G ? g : 0);
+    const int pq = w * (kBlock / 64) * G + slot;                  // pixel, columns first: col * fH + row
+    const bool act = g < G && pq < HW;
+    const int col = act ? pq / fH : 0, row = act ? pq - col * fH : 0;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+    const int Dp = ((D + kRayBins - 1) & ~(kRayBins - 1)) + 8;    // bins the walk may ask for (it prefetches into the next batch)
+    const int stride = 2 * Dp + kRayBins * Q;
+    int *off = reinterpret_cast<int *>(ray_lds) + slot * stride;
+    float *dep = reinterpret_cast<float *>(off + Dp);
+    float *part = dep + Dp;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.grad_out), 0, a.span_bytes, 0x00020000);
+    const unsigned kOut = 0x80000000u;                            // beyond num_records (< 2^30): the load returns zeros
+
+#ifdef LSS_STAMPS   // diagnostic build: grad_context receives 4 s_memtime stamps per workgroup instead of its rows
+    unsigned long long *rstamps = reinterpret_cast<unsigned long long *>(a.grad_context) + (int64_t)blockIdx.x * 4;
+#define RAY_STAMP(i) do { if (threadIdx.x == 0) rstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RAY_STAMP(i) do { } while (0)
+#endif
+    RAY_STAMP(0);
+    // ---- the pixel's D points: kept test, row offset, depth (bins past D and the bins of an idle lane group: nothing)
+    const int64_t t0 = ray_point(a, bn, row, col, 0);              // the pixel's bin 0; bin d sits dstep points further
+    const int dstep = a.pm ? 1 : HW;
+    const int64_t pix = (int64_t)bn * HW + row * a.fW + col;
+    float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+        if constexpr (sizeof(FT) == 2) {
+            const uint2 rr = *reinterpret_cast<const uint2 *>(context + pix * C + li * 4);
+            cx = make_float4(bf16_lo(rr.x), bf16_hi(rr.x), bf16_lo(rr.y), bf16_hi(rr.y));
+        } else {
+            cx = *reinterpret_cast<const float4 *>(context + pix * C + li * 4);
+        }
+    }
+    if (g < G) {
+        constexpr int PA = 6;                                      // bins per lane in flight: the whole ray at D = 112, C = 80
+        for (int dbase = li; dbase < Dp; dbase += PA * C4) {
+            int gx[PA], gy[PA], gz[PA];
+            float dv[PA];
+#pragma unroll
+            for (int u = 0; u < PA; ++u) {
+                const int d = dbase + u * C4;
+                const int64_t t = t0 + (int64_t)((act && d < D) ? d : 0) * dstep;
+                gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2];
+                dv[u] = Elem<FT>::scalar(depth + t);
+            }
+#pragma unroll
+            for (int u = 0; u < PA; ++u) {
+                const int d = dbase + u * C4;
+                if (d < Dp) {
+                    const bool keep = act && d < D && !(gx[u] < 0 || gx[u] >= a.nx || gy[u] < 0 || gy[u] >= a.ny || gz[u] < 0 || gz[u] >= a.nz);
+                    off[d] = keep ? (int)((b * a.sb + gy[u] * a.sy + gx[u] * a.sx) * 4) : (int)kOut;
+                    dep[d] = (act && d < D) ? dv[u] : 0.f;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    RAY_STAMP(1);
+
+    const unsigned lane_off = g < G ? (unsigned)li * 16u : 0x40000000u;   // idle lanes: beyond the buffer whatever the bin
+    // four bins = four row loads per sub-batch, two sub-batches in flight (software pipeline: the loads of the next one are
+    // issued before the current one is consumed; the scheduling barriers keep the compiler from hoisting further loads and
+    // paying for them in registers -- 57 VGPRs with one sub-batch, 136 with five, and occupancy matters more here)
+    // The walk is VALU-bound (every wave-instruction occupies its SIMD for 4 cycles and a wave spends ~30 of them per bin in a
+    // naive form), so: packed fp32 FMAs, no per-bin selects (a dropped bin's offset lies beyond the buffer, adding the lane's
+    // 16 * li keeps it there), and a sub-batch in which no lane group of the wave has a kept bin skips its arithmetic.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 cxl = {cx.x, cx.y}, cxh = {cx.z, cx.w};
+    f32x2 accl = {0.f, 0.f}, acch = {0.f, 0.f};
+    auto load4 = [&](int dbase, mmt_u32x4 (&v)[4], float (&dv)[4], bool &any) __attribute__((always_inline)) {
+        const int4 o4 = *reinterpret_cast<const int4 *>(off + dbase);        // dbase is a multiple of 4: one 16-byte LDS read each
+        const float4 d4 = *reinterpret_cast<const float4 *>(dep + dbase);
+        const unsigned o[4] = {(unsigned)o4.x, (unsigned)o4.y, (unsigned)o4.z, (unsigned)o4.w};
+        dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+        any = __any((o[0] & o[1] & o[2] & o[3]) != kOut);                   // kOut is a single bit: all four dropped <=> the AND keeps it
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[u] + lane_off, 0, 0);
+    };
+    auto comp4 = [&](int u0, const mmt_u32x4 (&v)[4], const float (&dv)[4], bool any) __attribute__((always_inline)) {
+        float mine = 0.f;
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x2 gl = {__uint_as_float(v[u].x), __uint_as_float(v[u].y)}, gh = {__uint_as_float(v[u].z), __uint_as_float(v[u].w)};
+                const f32x2 dd = {dv[u], dv[u]};
+                accl = __builtin_elementwise_fma(gl, dd, accl);
+                acch = __builtin_elementwise_fma(gh, dd, acch);
+                const f32x2 t = __builtin_elementwise_fma(gh, cxh, gl * cxl);
+                const float qs = quad_sum(t.x + t.y);
+                if ((li & 3) == u) mine = qs;
+            }
+        }
+        if (g < G) part[(u0 + (li & 3)) * Q + (li >> 2)] = mine;      // partial of bin u0 + (li & 3), quad li >> 2
+        asm volatile("" : "+v"(accl), "+v"(acch));   // the sums are due HERE: without this the compiler sinks them to the end of the
+                                                     // batch and keeps 16 rows alive (150 VGPRs instead of 70)
+    };
+    mmt_u32x4 va[4], vb[4];
+    float da[4], db[4];
+    bool sa, sb_;
+    // The 4 waves of a workgroup (12 pixels of one column: the same BEV rows) start a quarter of the ray apart and wrap
+    // around: 4x as many DIFFERENT rows are in flight per workgroup, and a row that one wave had to wait for from HBM is in
+    // L2 when the next wave arrives there (cold grad_out inside the training step: 41 -> RAYROT us; warm: 28.6).
+    const int nb = (D + kRayBins - 1) / kRayBins;
+#ifdef RAY_NO_ROTATE
+    const int b0 = 0;
+#else
+    const int b0 = (wave * nb) / (kBlock / 64);
+#endif
+    int d0 = b0 * kRayBins;
+    __builtin_amdgcn_sched_barrier(0);
+    load4(d0, va, da, sa);
+    __builtin_amdgcn_sched_barrier(0);             // issue order = use order, or the first wait of the loop has to drain everything
+    load4(d0 + 4, vb, db, sb_);
+#pragma unroll 1
+    for (int it = 0; it < nb; ++it) {               // bins past D load nothing and count for nothing
+        int dn_ = d0 + kRayBins;                   // the batch after this one; after the last one: the padding (nothing)
+        if (dn_ >= nb * kRayBins) dn_ = 0;
+        if (it == nb - 1) dn_ = nb * kRayBins;
+        __builtin_amdgcn_sched_barrier(0);
+        comp4(0, va, da, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(d0 + 8, va, da, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        comp4(4, vb, db, sb_);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(d0 + 12, vb, db, sb_);
+        __builtin_amdgcn_sched_barrier(0);
+        comp4(8, va, da, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(dn_, va, da, sa);                             // the next batch is on its way while this one is reduced
+        __builtin_amdgcn_sched_barrier(0);
+        comp4(12, vb, db, sb_);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(dn_ + 4, vb, db, sb_);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int bin = li; bin < kRayBins; bin += C4) {
+            const int d = d0 + bin;
+            if (act && d < D) {
+                float s = 0.f;
+                for (int k = 0; k < Q; ++k) s += part[bin * Q + k];
+                const int64_t t = t0 + (int64_t)d * dstep;
+                if constexpr (sizeof(FT) == 2) reinterpret_cast<bf16_t *>(a.grad_depth)[t] = (bf16_t)(pack_bf16x2(s, 0.f) & 0xFFFFu);
+                else reinterpret_cast<float *>(a.grad_depth)[t] = s;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        d0 = dn_;
+    }
+    RAY_STAMP(2);
+#ifndef LSS_STAMPS
+    if (act) *reinterpret_cast<float4 *>(a.grad_context + pix * C + li * 4) = make_float4(accl.x, accl.y, acch.x, acch.y);
+#endif
+}
+
+// forward ray walk: depth slabs per ray (LDS within 64 KB; whole rays unless that leaves the chip short of workgroups) and
+// the depth bins of each of the 16 lane groups
+bool pick_ray_forward(RayArgs *r) {
+    int dsplit = 1;
+    static const char *env = getenv("MMT_RAY_DSPLIT");     // experiments only
+    if (env && atoi(env) > 0) dsplit = atoi(env);
+    else while ((int64_t)r->BN * r->fW * dsplit < 1024 && (r->D + dsplit) / (dsplit + 1) >= 16) ++dsplit;
+    if (dsplit > r->D) dsplit = r->D;
+    for (;; ++dsplit) {
+        const int dspan = (r->D + dsplit - 1) / dsplit;
+        const size_t lds = (size_t)r->fH * (r->C + 4) * 4 + (size_t)r->fH * (dspan | 1) * 8;
+        if (lds <= 64 * 1024) {
+            r->dspan = dspan;
+            r->dsplit = (r->D + dspan - 1) / dspan;
+            r->kd = (dspan + kBlock / 16 - 1) / (kBlock / 16);
+            return true;
+        }
+        if (dspan == 1) return false;
+    }
+}
+
 // tile shape for a feature map: whole image columns, about 32 pixels x 16 depth bins
 void pick_tile(int fH, int fW, int D, int BN, TileArgs *a) {
     int tpw = 32 / fH;
@@ -483,7 +843,25 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     const int64_t P = (int64_t)N * D * fH * fW, BP = (int64_t)B * P;
     if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
-    if (flags & ~(MMT_VP_WRITE_DROPPED | MMT_LSS_PIXEL_MAJOR)) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (flags & ~(MMT_VP_WRITE_DROPPED | MMT_LSS_PIXEL_MAJOR | MMT_LSS_TILE_KERNELS))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (!(flags & MMT_LSS_TILE_KERNELS) && (C == 64 || C == 80 || C == 128)) {   // other widths: the tile kernels
+        RayArgs r = {};
+        r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C; r.nx = nx; r.ny = ny; r.nz = nz;
+        r.pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
+        r.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
+        r.geom = geom; r.depth = depth; r.context = context; r.out = out; r.pos_memo = pos_memo;
+        if (pick_ray_forward(&r)) {
+            const size_t lds = (size_t)fH * (C + 4) * 4 + (size_t)fH * (r.dspan | 1) * 8;
+            const int64_t grid = 8ll * ((r.BN + 7) / 8) * fW * r.dsplit;
+            if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+            mmt::TimedSeq seq;
+            if (C == 80) seq.launch(true, lss_ray_fwd<FT, 5>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            else if (C == 64) seq.launch(true, lss_ray_fwd<FT, 4>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            else seq.launch(true, lss_ray_fwd<FT, 8>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            return mmt::check_launch(what);
+        }
+    }
     TileArgs a;
     a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
     pick_tile(fH, fW, D, B * N, &a);
@@ -506,7 +884,7 @@ template <typename FT>
 int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
                   const FT *depth, const FT *context, const float *grad_out, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
                   FT *grad_depth, float *grad_context, int flags, hipStream_t st) {
-    if (flags & ~MMT_LSS_PIXEL_MAJOR) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (flags & ~(MMT_LSS_PIXEL_MAJOR | MMT_LSS_TILE_KERNELS)) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
     if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive size", what);
     constexpr int VEC = Elem<FT>::VEC;
@@ -519,6 +897,29 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: grad_out must be channels-last (stride_c == 1), 16-byte aligned, < 2^31 elements", what);
     if ((int64_t)B * N * D * fH * fW >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
+    {
+        const int C4 = C / 4, NGR = (kBlock / 64) * (64 / C4);
+        const size_t lds = (size_t)NGR * (2 * (((D + kRayBins - 1) & ~(kRayBins - 1)) + 8) + kRayBins * (C4 / 4)) * 4;
+        if (!(flags & MMT_LSS_TILE_KERNELS) && lds <= 64 * 1024 && span * 4 < (1ll << 30)) {
+            RayArgs r = {};
+            r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C; r.nx = nx; r.ny = ny; r.nz = nz;
+            r.pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
+            r.geom = geom; r.depth = depth; r.context = context;
+            r.grad_out = grad_out; r.sb = sb; r.sy = sy; r.sx = sx; r.span_bytes = (int)(span * 4);
+            r.grad_depth = grad_depth; r.grad_context = grad_context;
+            r.wpc = (fH * fW + NGR - 1) / NGR;
+            const int64_t grid = 8ll * ((r.BN + 7) / 8) * r.wpc;
+            if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+            mmt::TimedSeq seq;
+            if (C == 80) seq.launch(true, lss_ray_bwd<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            else if (C == 64) seq.launch(true, lss_ray_bwd<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            else seq.launch(true, lss_ray_bwd<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            return mmt::check_launch(what);
+        }
+    }
+    // frustum-tile kernel: partial sums per depth tile meet in grad_context through fp32 atomics
+    if (const hipError_t e = hipMemsetAsync(grad_context, 0, (size_t)B * N * fH * fW * C * 4, st); e != hipSuccess)
+        return mmt::fail((int)e, "%s: zero-fill of grad_context: %s", what, hipGetErrorString(e));
     TileArgs a;
     a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
     pick_tile(fH, fW, D, B * N, &a);

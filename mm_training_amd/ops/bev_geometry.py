@@ -136,14 +136,19 @@ def lift_features(depth, context, storage_dtype=torch.float32):
     return LiftFeatures.apply(depth.contiguous(), context.contiguous())
 
 
+def _lss_flags(pixel_major):
+    return (_lib.LSS_PIXEL_MAJOR if pixel_major else 0) | (_lib.LSS_TILE_KERNELS if os.environ.get("MMT_LIFT_SPLAT_TILES", "0") == "1" else 0)
+
+
 class LiftSplat(Function):
     """Fused lift + voxel_pooling (lss_fpn.py:441-464 in one pass): the
     [B, N, D, fH, fW, C] feature tensor is never materialised.  Additional entry point beside
     the drop-in ``voxel_pooling``; same result up to fp32 summation order.
 
-    Frustum-tile kernels (mmt_lss_splat_forward / _backward: a workgroup owns image columns x all rows x a depth range,
-    context tile and the tile's BEV-gradient rows in LDS) unless MMT_LIFT_SPLAT_V1=1 selects the first-generation pair
-    (chunks of consecutive points; pixel-major backward on pos_memo), kept for A/B runs and for fH > 512."""
+    mmt_lss_splat_forward / _backward: ray walks (forward: a workgroup owns an image column and sums depth * context in
+    registers while the BEV cell stays the same; backward: a lane group owns a pixel, no atomics).  MMT_LIFT_SPLAT_TILES=1
+    selects the second-generation frustum-tile kernels, MMT_LIFT_SPLAT_V1=1 the first-generation pair (chunks of
+    consecutive points; pixel-major backward on pos_memo) -- both kept for A/B runs, the latter also for fH > 512."""
 
     @staticmethod
     def forward(ctx, geom_xyz, depth, context, voxel_num, pixel_major=False):
@@ -172,7 +177,7 @@ class LiftSplat(Function):
             if tiled:   # the backward redoes the kept test from geom: no pos_memo is written or kept
                 _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward" + sfx, B, N, D, fH, fW, C, nx, ny, nz,
                                 geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), 0,
-                                _lib.LSS_PIXEL_MAJOR if pixel_major else 0, _stream())
+                                _lss_flags(pixel_major), _stream())
                 ctx.save_for_backward(geom_xyz, depth_c, ctx_nhwc)
             else:
                 pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
@@ -195,10 +200,10 @@ class LiftSplat(Function):
         sfx = "_bf16" if ctx.bf16 else ""
         with torch.cuda.device(depth_c.device):
             if ctx.tiled:
-                grad_ctx = torch.zeros(ctx_nhwc.shape, dtype=torch.float32, device=depth_c.device)   # accumulated into (fp32 atomics)
+                grad_ctx = torch.empty(ctx_nhwc.shape, dtype=torch.float32, device=depth_c.device)    # every element is written
                 _lib.timed_call("lift_splat_backward", "mmt_lss_splat_backward" + sfx, B, N, D, fH, fW, C, nx, ny, nz,
                                 index.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
-                                grad_depth.data_ptr(), grad_ctx.data_ptr(), _lib.LSS_PIXEL_MAJOR if ctx.pixel_major else 0, _stream())
+                                grad_depth.data_ptr(), grad_ctx.data_ptr(), _lss_flags(ctx.pixel_major), _stream())
                 if ctx.bf16:
                     grad_ctx = grad_ctx.to(torch.bfloat16)
             else:

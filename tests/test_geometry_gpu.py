@@ -215,6 +215,51 @@ def test_fused_lift_splat_equals_lift_then_pool(mmt_lib, oracle_mod, cfg):
     assert torch.allclose(d4.grad, d2.grad, rtol=1e-4, atol=1e-5) and torch.allclose(c4.grad, c2.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kernels", ["ray", "tiles"])
+@pytest.mark.parametrize("cfg", [(1, 2, 13, 5, 7, 64, "rig"), (2, 3, 37, 16, 9, 80, "rig"), (1, 1, 112, 32, 10, 128, "rig"),
+                                 (1, 2, 21, 3, 5, 80, "uniform"), (2, 2, 16, 16, 6, 48, "rig")])
+def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, monkeypatch):
+    """mmt_lss_splat_forward / _backward, ray walks (default) and frustum tiles (MMT_LSS_TILE_KERNELS), both point orders, on
+    shapes that are not multiples of anything (fH % 4, D % 16, fW odd; C = 48 takes the tile forward + the ray backward):
+    forward vs the oracle composition (1e-4), gradients vs torch autograd of the same expression in fp64."""
+    from mm_training_amd import synthetic
+    from mm_training_amd.ops.bev_geometry import lift_splat
+    B, N, D, fH, fW, C, kind = cfg
+    monkeypatch.setenv("MMT_LIFT_SPLAT_TILES", "1" if kernels == "tiles" else "0")
+    if kind == "rig":
+        geom, vn = synthetic.rig_geometry(B, N, (fH * 16, fW * 16), 16, (2.0, 2.0 + 0.5 * D, 0.5))
+    else:
+        geom = synthetic.uniform_geometry(B, N * D * fH * fW, 128, 128).reshape(B, N, D, fH, fW, 3)
+        vn = [128, 128, 1]
+    nx, ny, nz = vn
+    g = torch.Generator().manual_seed(3)
+    depth = torch.rand(B * N, D, fH, fW, generator=g).softmax(1)
+    ctx = torch.randn(B * N, C, fH, fW, generator=g)
+    go = torch.randn(B, C, ny, nx, generator=g)
+    feats = oracle_mod.lift(depth.numpy(), ctx.numpy()).reshape(B, -1, C)
+    ref = oracle_mod.voxel_pooling_forward_f64(geom.reshape(B, -1, 3).numpy(), feats, *vn)
+    # fp64 autograd reference of out[b, :, y, x] += depth * context
+    gq = geom.reshape(B, N, D, fH, fW, 3).long()
+    keep = ((gq[..., 0] >= 0) & (gq[..., 0] < nx) & (gq[..., 1] >= 0) & (gq[..., 1] < ny) & (gq[..., 2] >= 0) & (gq[..., 2] < nz))
+    cell = (torch.arange(B).view(B, 1, 1, 1, 1) * ny + gq[..., 1]) * nx + gq[..., 0]
+    dd = depth.double().view(B, N, D, fH, fW).requires_grad_(True)
+    cc = ctx.double().view(B, N, C, fH, fW).requires_grad_(True)
+    rows = dd.unsqueeze(-1) * cc.permute(0, 1, 3, 4, 2).unsqueeze(2)                 # [B,N,D,fH,fW,C]
+    flat = torch.zeros(B * ny * nx, C, dtype=torch.float64).index_add(0, cell[keep], rows[keep])
+    (flat.view(B, ny, nx, C).permute(0, 3, 1, 2) * go.double()).sum().backward()
+    for pm in (False, True):
+        gm = geom.cuda()
+        if pm:
+            gm = gm.permute(0, 1, 3, 4, 2, 5).contiguous()
+        d1 = depth.cuda().requires_grad_(True)
+        c1 = ctx.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        out = lift_splat(gm, d1, c1, vn, pixel_major=pm)
+        assert np.abs(out.detach().permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= 1e-4
+        out.backward(go.cuda().contiguous(memory_format=torch.channels_last))
+        assert torch.allclose(d1.grad.cpu().double().view_as(dd), dd.grad, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(c1.grad.cpu().double().view_as(cc), cc.grad, rtol=1e-4, atol=1e-4)
+
+
 def test_fused_geometry_on_reference_nuscenes_calibration(mmt_lib, oracle_mod, golden):
     """HIP frustum geometry + quantise on the reference fixture's real calibration."""
     from mm_training_amd.ops.bev_geometry import frustum_geometry

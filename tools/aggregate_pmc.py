@@ -10,8 +10,10 @@ import sys
 
 # logical kernel name <- (substring of the demangled name, further substrings that must ALL be present)
 KERNELS = [
-    ("lift_splat_forward", ("lss_splat_fwd_tile<float",)),
-    ("lift_splat_forward_bf16", ("lss_splat_fwd_tile<unsigned short",)),
+    ("lift_splat_forward", ("lss_ray_fwd<float",)),
+    ("lift_splat_forward_bf16", ("lss_ray_fwd<unsigned short",)),
+    ("lift_splat_forward_tile", ("lss_splat_fwd_tile<float",)),
+    ("lift_splat_forward_tile_bf16", ("lss_splat_fwd_tile<unsigned short",)),
     ("lift_splat_forward_chunked", ("vp_fwd_seg_gather<float", ", true>")),
     ("lift_splat_forward_chunked_bf16", ("vp_fwd_seg_gather<unsigned short", ", true>")),
     ("vp_fwd_seg_gather", ("vp_fwd_seg_gather<float", ", false>")),
@@ -19,8 +21,10 @@ KERNELS = [
     ("vp_bwd_prepare", ("vp_bwd_prepare",)),
     ("vp_bwd_rows_vec4", ("vp_bwd_rows_vec<float",)),
     ("vp_bwd_rows_bf16", ("vp_bwd_rows_vec<unsigned short",)),
-    ("lift_splat_backward", ("lss_splat_bwd_tile<float",)),
-    ("lift_splat_backward_bf16", ("lss_splat_bwd_tile<unsigned short",)),
+    ("lift_splat_backward", ("lss_ray_bwd<float",)),
+    ("lift_splat_backward_bf16", ("lss_ray_bwd<unsigned short",)),
+    ("lift_splat_backward_tile", ("lss_splat_bwd_tile<float",)),
+    ("lift_splat_backward_tile_bf16", ("lss_splat_bwd_tile<unsigned short",)),
     ("lift_splat_backward_pixel", ("lift_splat_backward_kernel<float",)),
     ("lift_splat_backward_pixel_bf16", ("lift_splat_backward_kernel<unsigned short",)),
     ("vp_planned_items", ("vp_planned_items",)), ("vp_planned_fold", ("vp_planned_fold",)),
