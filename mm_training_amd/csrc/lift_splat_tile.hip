@@ -615,8 +615,8 @@ __device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes o
 
 constexpr int kRayBins = 16;        // depth bins per reduction batch of the backward walk (4 sub-batches of 4)
 
-// LDS (dynamic), per lane group: off [D] int (byte offset of the BEV-gradient row or an out-of-range value) | dep [D] fp32 |
-// part [kRayBins][C4/4] fp32
+// LDS (dynamic), per lane group: off [Dp] int (byte offset of the BEV-gradient row, or an out-of-range value in the padding) |
+// dep [Dp] fp32 | kbin [Dp] int | part [kRayBins][C4/4] fp32
 template <typename FT, int C4T>
 __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
     extern __shared__ __align__(16) float ray_lds[];
@@ -637,11 +637,12 @@ __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
     const int col = act ? pq / fH : 0, row = act ? pq - col * fH : 0;
     const FT *depth = reinterpret_cast<const FT *>(a.depth);
     const FT *context = reinterpret_cast<const FT *>(a.context);
-    const int Dp = ((D + kRayBins - 1) & ~(kRayBins - 1)) + 8;    // bins the walk may ask for (it prefetches into the next batch)
-    const int stride = 2 * Dp + kRayBins * Q;
-    int *off = reinterpret_cast<int *>(ray_lds) + slot * stride;
-    float *dep = reinterpret_cast<float *>(off + Dp);
-    float *part = dep + Dp;
+    const int Dp = ((D + kRayBins - 1) & ~(kRayBins - 1)) + 8;    // list entries the walk may ask for (it prefetches into the next batch)
+    const int stride = 3 * Dp + kRayBins * Q;
+    int *off = reinterpret_cast<int *>(ray_lds) + slot * stride;  // the pixel's KEPT bins, in depth order: row offset,
+    float *dep = reinterpret_cast<float *>(off + Dp);             // depth value,
+    int *kbin = reinterpret_cast<int *>(dep + Dp);                // bin number
+    float *part = reinterpret_cast<float *>(kbin + Dp);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.grad_out), 0, a.span_bytes, 0x00020000);
     const unsigned kOut = 0x80000000u;                            // beyond num_records (< 2^30): the load returns zeros
 
@@ -665,29 +666,48 @@ __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
             cx = *reinterpret_cast<const float4 *>(context + pix * C + li * 4);
         }
     }
-    if (g < G) {
+    // Dropped bins (40 % on the analytic rig: beyond the grid or outside the z range) get their zero gradient here and are
+    // left out of the walk: every row load of the walk, in or out of range, costs the texture path its 16 cycles.
+    int nk = 0;                                                    // kept bins of this lane group's pixel
+    {
         constexpr int PA = 6;                                      // bins per lane in flight: the whole ray at D = 112, C = 80
-        for (int dbase = li; dbase < Dp; dbase += PA * C4) {
+        const unsigned long long gmask = C4 >= 64 ? ~0ull : ((1ull << C4) - 1ull);
+        for (int dbase = 0; dbase < D; dbase += PA * C4) {
             int gx[PA], gy[PA], gz[PA];
             float dv[PA];
 #pragma unroll
             for (int u = 0; u < PA; ++u) {
-                const int d = dbase + u * C4;
+                const int d = dbase + u * C4 + li;
                 const int64_t t = t0 + (int64_t)((act && d < D) ? d : 0) * dstep;
                 gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2];
                 dv[u] = Elem<FT>::scalar(depth + t);
             }
 #pragma unroll
             for (int u = 0; u < PA; ++u) {
-                const int d = dbase + u * C4;
-                if (d < Dp) {
-                    const bool keep = act && d < D && !(gx[u] < 0 || gx[u] >= a.nx || gy[u] < 0 || gy[u] >= a.ny || gz[u] < 0 || gz[u] >= a.nz);
-                    off[d] = keep ? (int)((b * a.sb + gy[u] * a.sy + gx[u] * a.sx) * 4) : (int)kOut;
-                    dep[d] = (act && d < D) ? dv[u] : 0.f;
+                const int d = dbase + u * C4 + li;
+                const bool in = act && d < D;
+                const bool keep = in && !(gx[u] < 0 || gx[u] >= a.nx || gy[u] < 0 || gy[u] >= a.ny || gz[u] < 0 || gz[u] >= a.nz);
+                const unsigned long long seg = (__ballot(keep) >> (g < G ? g * C4 : 0)) & gmask;   // this group's lanes
+                if (keep) {
+                    const int pos = nk + __popcll(seg & ((1ull << li) - 1ull));
+                    off[pos] = (int)((b * a.sb + gy[u] * a.sy + gx[u] * a.sx) * 4);
+                    dep[pos] = dv[u];
+                    kbin[pos] = d;
+                } else if (in) {
+                    const int64_t t = t0 + (int64_t)d * dstep;
+                    if constexpr (sizeof(FT) == 2) reinterpret_cast<bf16_t *>(a.grad_depth)[t] = (bf16_t)0;
+                    else reinterpret_cast<float *>(a.grad_depth)[t] = 0.f;
                 }
+                nk += __popcll(seg);
             }
         }
+        if (g < G)
+            for (int i2 = nk + li; i2 < Dp; i2 += C4) { off[i2] = (int)kOut; dep[i2] = 0.f; }      // padding: loads nothing
     }
+    // batches of the longest list in the wave (the shorter ones run into their padding)
+    int nb = g < G ? (nk + kRayBins - 1) / kRayBins : 0;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o_ = __shfl_xor(nb, m); nb = o_ > nb ? o_ : nb; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     RAY_STAMP(1);
@@ -735,7 +755,6 @@ __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
     // The 4 waves of a workgroup (12 pixels of one column: the same BEV rows) start a quarter of the ray apart and wrap
     // around: 4x as many DIFFERENT rows are in flight per workgroup, and a row that one wave had to wait for from HBM is in
     // L2 when the next wave arrives there (cold grad_out inside the training step: 41 -> RAYROT us; warm: 28.6).
-    const int nb = (D + kRayBins - 1) / kRayBins;
 #ifdef RAY_NO_ROTATE
     const int b0 = 0;
 #else
@@ -771,11 +790,11 @@ __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int bin = li; bin < kRayBins; bin += C4) {
-            const int d = d0 + bin;
-            if (act && d < D) {
+            const int e = d0 + bin;                         // list entry
+            if (g < G && e < nk) {
                 float s = 0.f;
                 for (int k = 0; k < Q; ++k) s += part[bin * Q + k];
-                const int64_t t = t0 + (int64_t)d * dstep;
+                const int64_t t = t0 + (int64_t)kbin[e] * dstep;
                 if constexpr (sizeof(FT) == 2) reinterpret_cast<bf16_t *>(a.grad_depth)[t] = (bf16_t)(pack_bf16x2(s, 0.f) & 0xFFFFu);
                 else reinterpret_cast<float *>(a.grad_depth)[t] = s;
             }
@@ -899,7 +918,7 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
     {
         const int C4 = C / 4, NGR = (kBlock / 64) * (64 / C4);
-        const size_t lds = (size_t)NGR * (2 * (((D + kRayBins - 1) & ~(kRayBins - 1)) + 8) + kRayBins * (C4 / 4)) * 4;
+        const size_t lds = (size_t)NGR * (3 * (((D + kRayBins - 1) & ~(kRayBins - 1)) + 8) + kRayBins * (C4 / 4)) * 4;
         if (!(flags & MMT_LSS_TILE_KERNELS) && lds <= 64 * 1024 && span * 4 < (1ll << 30)) {
             RayArgs r = {};
             r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C; r.nx = nx; r.ny = ny; r.nz = nz;

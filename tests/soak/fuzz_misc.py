@@ -62,7 +62,7 @@ while time.time() < t_end:
     # ---- lift + fused lift-splat backward vs the unfused chain
     Bc, N, D = int(rng.integers(1, 3)), int(rng.integers(1, 4)), int(rng.integers(1, 30))
     fH, fW = int(rng.integers(1, 6)), int(rng.integers(1, 20))
-    Cc = int(rng.choice([16, 32, 64, 80, 96]))
+    Cc = int(rng.choice([16, 32, 64, 80, 96, 128]))
     cfg = dict(it=it, op="lift", B=Bc, N=N, D=D, fH=fH, fW=fW, C=Cc)
     if verbose:
         print(cfg, flush=True)
@@ -78,7 +78,12 @@ while time.time() < t_end:
     if not torch.equal(f, ref_f.contiguous()):
         fail("lift forward", cfg)
     o2 = voxel_pooling(geom, f.view(Bc, N, D, fH, fW, Cc), [nx, ny, 1])
-    o1 = lift_splat(geom, d1, c1, [nx, ny, 1])
+    # kernel family (ray walks / frustum tiles) and point order (reference / pixel-major) at random
+    os.environ["MMT_LIFT_SPLAT_TILES"] = "1" if rng.random() < 0.3 else "0"
+    if rng.random() < 0.5:
+        o1 = lift_splat(geom.permute(0, 1, 3, 4, 2, 5).contiguous(), d1, c1, [nx, ny, 1], pixel_major=True)
+    else:
+        o1 = lift_splat(geom, d1, c1, [nx, ny, 1])
     if (o1 - o2).abs().max().item() > 1e-4 * max(1.0, o2.abs().max().item()):
         fail("fused forward", cfg)
     go = torch.randn_like(o2)

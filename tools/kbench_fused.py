@@ -50,7 +50,14 @@ def main():
     ctx = torch.randn(B * N, fH, fW, C, generator=g).cuda()
     st = torch.cuda.current_stream().cuda_stream
     res = {}
-    for gname, (geom, vn) in {"rig": synthetic.rig_geometry(B), "roll5": rolled_rig_geometry(B, 5.0)}.items():
+    rig = synthetic.rig_geometry(B)
+    variants = {"rig": rig, "roll5": rolled_rig_geometry(B, 5.0)}
+    if os.environ.get("KBF_EXTRA"):      # every point dropped / every point kept (same cells, z forced into range): what do dropped bins cost?
+        variants["alldrop"] = (torch.full_like(rig[0], -1), rig[1])
+        allk = rig[0].clone()
+        allk[..., 0].clamp_(0, rig[1][0] - 1); allk[..., 1].clamp_(0, rig[1][1] - 1); allk[..., 2] = 0
+        variants["allkept"] = (allk, rig[1])
+    for gname, (geom, vn) in variants.items():
         nx, ny, nz = vn
         geom = geom.cuda()
         geom_pm = geom.permute(0, 1, 3, 4, 2, 5).contiguous()
