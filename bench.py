@@ -79,6 +79,8 @@ def parse(argv=None):
                     help="camera branch runs the reference's op sequence lift -> drop-in voxel_pooling instead of the fused "
                          "lift-splat kernels (SURVEY 8/f1, the default)")
     ap.add_argument("--fused-lift-splat", action="store_true", help="(default since round 2; accepted for old command lines)")
+    ap.add_argument("--lift-splat-backward", default="auto", choices=["auto", "ray", "column"],
+                    help="backward kernel of the fused camera path (auto: column on a level rig, decided once from the geometry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
     ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag (hotpath mode)")
@@ -539,6 +541,7 @@ def train_main(args, rank, local_rank, world):
         if args.unfused or args.cached_plan:
             ts.model.backbone.fused_lift_splat = False
         fused = bool(ts.model.backbone.fused_lift_splat)
+        ts.model.backbone.lift_splat_backward = args.lift_splat_backward
     B = cfg["batch_size"]
     # a small pool of distinct pre-generated batches resident in HBM (input is never the bottleneck)
     batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i) for i in range(2)]
@@ -593,17 +596,22 @@ def train_main(args, rank, local_rank, world):
             note = ("fused lift + voxel_pooling (SURVEY 8/f1), ray walks: the [B*P, C] feature matrix is never materialised, so the "
                     "HBM-side algorithmic bytes are ~5x below the drop-in op's.  The forward is bound by the memory-side fp32 atomic "
                     "units (about 1.2 TB/s of added bytes in whole 64-byte segments, tools/ubench/atomic_rows.hip: ~25 MB of BEV rows "
-                    "per launch at this shape), the backward by L1 row gathers and VALU issue, neither by HBM -- l2_side prices the "
+                    "per launch at this shape); the backward (matrix-core column kernel on a level rig, else a per-pixel ray walk) by "
+                    "its HBM-rate load phase followed by L2-latency-bound tile staging, neither by sustained HBM bandwidth -- l2_side prices the "
                     "rows a point-wise gather moves against the aggregate L2 bandwidth; the drop-in op's HBM roofline is "
                     "roofline_voxel_pooling[_backward]")
             sfx = "_bf16" if dtype == "bf16" else ""
             tiles = os.environ.get("MMT_LIFT_SPLAT_TILES", "0") == "1"      # A/B switch: the second-generation frustum-tile kernels
             kfwd, kbwd = ("lss_splat_fwd_tile", "lss_splat_bwd_tile") if tiles else ("lss_ray_fwd", "lss_ray_bwd")
-            res["config"]["lift_splat_kernels"] = "frustum tiles" if tiles else "ray walks"
+            column = (not tiles) and any(lss._column_backward_choice.values()) if lss.lift_splat_backward == "auto" else lss.lift_splat_backward == "column"
+            if column and not tiles:
+                kbwd = "lss_col_bwd"
+            res["config"]["lift_splat_kernels"] = "frustum tiles" if tiles else ("ray-walk forward, " + ("matrix-core column backward (chosen from the geometry: "
+                                                  "no pixel leaves its column's cell)" if column else "ray-walk backward"))
             res["roofline"] = roofline_entry(f"{kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
                                              pmc_traffic(args.config, ("lift_splat_forward_tile" if tiles else "lift_splat_forward",)), l2f, note)
             res["roofline_backward"] = roofline_entry(f"{kbwd}{sfx} (fused lift-splat backward = the step's voxel_pooling backward)", bbytes, bwd_ms,
-                                                      pmc_traffic(args.config, ("lift_splat_backward_tile" if tiles else "lift_splat_backward",)), l2b)
+                                                      pmc_traffic(args.config, ("lift_splat_backward_tile" if tiles else ("lift_splat_backward_column" if column else "lift_splat_backward"),)), l2b)
         elif timing.get("forward"):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["forward"]), _lib.mean_ms(timing["backward"])
             fbytes, bbytes = algorithmic_bytes(BP, K, C, B, ny, nx, fb)

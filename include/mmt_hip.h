@@ -259,6 +259,14 @@ int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x
                                      mmt_frustum_geometry yields that geom order when it is given the frustum permuted to
                                      [fH, fW, D, 4]. */
 #define MMT_LSS_TILE_KERNELS 0x200 /* mmt_lss_splat_*: the frustum-tile kernels instead of the ray walks (A/B runs) */
+#define MMT_LSS_COLUMN_BACKWARD 0x400 /* mmt_lss_splat_backward*: the COLUMN kernel on the matrix cores -- per image column and
+                                        16 image rows two fp32 GEMMs (v_mfma_f32_16x16x4_f32: exact fp32) against the
+                                        BEV-gradient rows of "the column's cell" per depth bin, read once per column; pixels
+                                        whose own cell differs are handled one by one afterwards.  The fastest form for a
+                                        level rig (every pixel of a column shares its cell: 23 us against 27 for the ray
+                                        walk, 28 against 37 inside the training step), slower than the walk once more than
+                                        a few per cent of the points differ (camera pitch / roll above ~1 degree).
+                                        C in {64, 80, 128}; other shapes fall back to the ray walk. */
 int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
                           int num_voxel_z, const int32_t *geom_xyz, const float *depth, const float *context,
                           float *output_features, int32_t *pos_memo, int flags, void *stream);

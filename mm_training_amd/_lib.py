@@ -80,6 +80,7 @@ VP_ALGO_ROW_ATOMIC = 1
 VP_WRITE_DROPPED = 0x10
 LSS_PIXEL_MAJOR = 0x100       # mmt_lss_splat_*: geom / depth / grad_depth in [B*N, fH, fW, D(, 3)] order
 LSS_TILE_KERNELS = 0x200      # mmt_lss_splat_*: frustum-tile kernels instead of the ray walks
+LSS_COLUMN_BACKWARD = 0x400   # mmt_lss_splat_backward*: matrix-core column kernel (level rigs)
 
 _lib = None
 

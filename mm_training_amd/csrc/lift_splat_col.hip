@@ -1,0 +1,359 @@
+// Fused lift-splat backward, COLUMN form on the matrix cores for MI355X (gfx950).
+//
+//   grad_depth[t]        = < grad_out[cell(t), :], context[pix(t), :] >
+//   grad_context[pix, :] = sum over the pixel's depth bins of depth[t] * grad_out[cell(t), :]
+//
+// The pixels of one image column at one depth bin lie above each other in the world: for a level camera they share their
+// BEV cell.  Take the column's 16 pixels x D bins and let G[d, :] be the BEV-gradient row of bin d's cell; then
+//   grad_depth  [16 x D] = Ctx [16 x C] * G^T [C x D]          grad_context [16 x C] = Dep [16 x D] * G [D x C]
+// two small fp32 GEMMs per column that read every gradient row ONCE per column (the ray walk reads it once per pixel,
+// 16 cycles of the texture path each) and need no cross-lane reductions.  v_mfma_f32_16x16x4_f32 is exact fp32 (a k-ordered
+// fmaf chain), so the result meets the same tolerance as the walk.
+//
+// Which cell "the column" has at a bin is decided from the data: ref[d] = the smallest row offset among the kept pixels of
+// the bin.  Pixels whose own cell differs (a camera that is not level, arbitrary geometry) are MISMATCHES: they are left out
+// of the GEMMs (depth 0, no grad_depth store) and handled one by one afterwards -- correct for any geometry, fast for a
+// frustum.  A workgroup = (camera, column, block of 16 image rows), 2 waves; a wave owns every other batch of 16 bins.
+#include "mmt_common.h"
+
+namespace {
+
+constexpr int kColBlock = 128;
+constexpr int kBins = 16;                       // bins per batch = N of the grad_depth tile = K of the grad_context product
+constexpr unsigned kOut = 0x80000000u;          // row offset of a dropped point: beyond num_records (< 2^30), loads zeros
+
+struct ColArgs {
+    int BN, N, D, fH, fW, C, nx, ny, nz;
+    int pm, rblocks;
+    const int32_t *geom;
+    const void *depth;
+    const void *context;
+    const float *grad_out;
+    int64_t sb, sy, sx;
+    int span_bytes;
+    void *grad_depth;
+    float *grad_context;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int64_t col_point(const ColArgs &a, int bn, int row, int col, int d) {
+    return a.pm ? (((int64_t)bn * a.fH + row) * a.fW + col) * a.D + d : (((int64_t)bn * a.D + d) * a.fH + row) * a.fW + col;
+}
+template <typename FT> __device__ __forceinline__ float ld_scalar(const FT *p);
+template <> __device__ __forceinline__ float ld_scalar<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ld_scalar<bf16_t>(const bf16_t *p) { return __uint_as_float((unsigned)*p << 16); }
+template <typename FT> __device__ __forceinline__ void st_scalar(FT *p, float v);
+template <> __device__ __forceinline__ void st_scalar<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_scalar<bf16_t>(bf16_t *p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu); }
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
+// LDS (dynamic): dep [16][Dp] fp32 | moff [16][Dp] int | ref [Dp] int | flag [16][Dp] bytes | G tiles of the 2 waves [2][16][CP] fp32
+// (CP = C + 4; after the products: the grad_context total and the lists / partial sums of the mismatch pass)
+// NT = C / 16 (N tiles of the grad_context product); C / 4 <= 64 lanes move one row.
+template <typename FT, int NT>
+__global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
+    extern __shared__ __align__(16) unsigned char col_lds[];
+    constexpr int C = 16 * NT, C4 = C / 4, CP = C + 4;
+    constexpr int NV = (16 * C4) / 64;                       // 16-byte vectors of a G tile per lane
+    const int L = blockIdx.x, xcd = L & 7, i0 = L >> 3;
+    const int per = a.fW * a.rblocks;
+    const int q = i0 / per, r = i0 - q * per;
+    const int bn = q * 8 + xcd;                              // the columns of one camera share an XCD
+    if (bn >= a.BN) return;
+    const int col = r / a.rblocks, rb = r - col * a.rblocks;
+    const int row0 = rb * 16;
+    const int nrow = (a.fH - row0) < 16 ? (a.fH - row0) : 16;
+    const int D = a.D, HW = a.fH * a.fW;
+    const int nb = (D + kBins - 1) / kBins, Dp = nb * kBins;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = bn / a.N;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+    FT *grad_depth = reinterpret_cast<FT *>(a.grad_depth);
+
+    float *dep = reinterpret_cast<float *>(col_lds);                   // [16][Dp] depth value (0 for dropped points)
+    int *moff = reinterpret_cast<int *>(dep + 16 * Dp);                // [16][Dp] byte offset of the point's own BEV-gradient row, or kOut
+    int *ref = moff + 16 * Dp;                                         // [Dp] byte offset of the COLUMN's row per bin, or kOut
+    unsigned char *flag = reinterpret_cast<unsigned char *>(ref + Dp); // [16][Dp] 0 dropped, 1 in the column's cell, 2 mismatch
+    float *gw0 = reinterpret_cast<float *>(flag + 16 * Dp);            // G tiles [16][CP], one per wave
+    float *gw1 = gw0 + 16 * CP;
+    float *gw = wave == 0 ? gw0 : gw1;
+    __shared__ int nmis;
+    if (tid == 0) nmis = 0;
+    __syncthreads();
+#ifdef LSS_STAMPS   // diagnostic build: grad_context receives 4 s_memtime stamps per workgroup instead of its rows
+    unsigned long long *cstamps = reinterpret_cast<unsigned long long *>(a.grad_context) + (int64_t)blockIdx.x * 4;
+#define COL_STAMP(i) do { if (threadIdx.x == 0) cstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define COL_STAMP(i) do { } while (0)
+#endif
+    COL_STAMP(0);
+
+    // ---- A operand of the grad_depth product, in registers for the whole kernel: Ctx[pixel = lane & 15][4 j + (lane >> 4)]
+    float ctxA[C4];
+    {
+        const int prow = lane & 15;
+        const int64_t pix = (int64_t)bn * HW + (row0 + (prow < nrow ? prow : 0)) * a.fW + col;
+#pragma unroll
+        for (int j = 0; j < C4; ++j) ctxA[j] = prow < nrow ? ld_scalar<FT>(context + pix * C + 4 * j + (lane >> 4)) : 0.f;
+    }
+
+    // ---- phase A: a thread takes one bin of all 16 rows (coalesced along the bins in the pixel-major order), all 32 loads in
+    // flight at once: kept test, the column's cell = the smallest row offset among the kept pixels, who shares it, who does not
+    const int64_t tcol = col_point(a, bn, row0, col, 0);               // point (row0, col, bin 0); rows / bins are strides away
+    const int64_t rstep = a.pm ? (int64_t)a.fW * D : a.fW;
+    const int64_t dstep = a.pm ? 1 : (int64_t)HW;
+    for (int bin = tid; bin < Dp; bin += kColBlock) {
+        int gx[16], gy[16], gz[16];
+        float dv[16];
+        const int64_t tb = tcol + (bin < D ? bin : 0) * dstep;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t t = tb + (u < nrow ? u : 0) * rstep;
+            gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2];
+            dv[u] = ld_scalar<FT>(depth + t);
+        }
+        unsigned o[16];
+        unsigned m = kOut;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            // in range <=> (unsigned)v < n for all three, one comparison each; no branches
+            const bool keep = (u < nrow) & (bin < D) & ((unsigned)gx[u] < (unsigned)a.nx) & ((unsigned)gy[u] < (unsigned)a.ny) & ((unsigned)gz[u] < (unsigned)a.nz);
+            o[u] = keep ? (unsigned)(((int)(b * a.sb) + gy[u] * (int)a.sy + gx[u] * (int)a.sx) * 4) : kOut;
+            m = o[u] < m ? o[u] : m;
+        }
+        ref[bin] = (int)m;
+        int mis = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int f = o[u] == kOut ? 0 : (o[u] == m ? 1 : 2);
+            flag[u * Dp + bin] = (unsigned char)f;
+            dep[u * Dp + bin] = f ? dv[u] : 0.f;
+            moff[u * Dp + bin] = (int)o[u];
+            mis += f == 2;
+        }
+        if (mis) atomicAdd(&nmis, mis);
+    }
+    __syncthreads();
+    COL_STAMP(1);
+
+    // ---- the two products, a batch of 16 bins at a time
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.grad_out), 0, a.span_bytes, 0x00020000);
+    f32x4 accC[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) accC[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mmt_u32x4 pre[NV];
+    auto fetch = [&](int bb) __attribute__((always_inline)) {           // the batch's 16 rows -> registers
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = lane + 64 * v;
+            const int rr = idx / C4, c4 = idx - rr * C4;
+            pre[v] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)ref[bb * kBins + rr] + c4 * 16, 0, 0);
+        }
+    };
+    if (wave < nb) fetch(wave);
+    for (int bb = wave; bb < nb; bb += kColBlock / 64) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = lane + 64 * v;
+            const int rr = idx / C4, c4 = idx - rr * C4;
+            *reinterpret_cast<mmt_u32x4 *>(gw + rr * CP + c4 * 4) = pre[v];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (bb + kColBlock / 64 < nb) fetch(bb + kColBlock / 64);       // the next batch's rows are on their way during the MFMAs
+        // grad_depth tile [16 pixels x 16 bins]: K = C.  B operands first (registers), then the MFMAs back to back
+        f32x4 accD = {0.f, 0.f, 0.f, 0.f}, accD2 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float *gB = gw + (lane & 15) * CP + (lane >> 4);
+            float bv[C4];
+#pragma unroll
+            for (int j = 0; j < C4; ++j) bv[j] = gB[4 * j];
+#pragma unroll
+            for (int j = 0; j < C4; j += 2) {
+                accD = __builtin_amdgcn_mfma_f32_16x16x4f32(ctxA[j], bv[j], accD, 0, 0, 0);
+                accD2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ctxA[j + 1], bv[j + 1], accD2, 0, 0, 0);
+            }
+        }
+        // grad_context partial [16 pixels x C]: K = the batch's 16 bins
+        {
+            const float *dA = dep + (lane & 15) * Dp + bb * kBins + (lane >> 4);
+            const unsigned char *fA = flag + (lane & 15) * Dp + bb * kBins + (lane >> 4);
+            const float *gC = gw + (lane >> 4) * CP + (lane & 15);
+            float av[4], cv[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                av[j] = fA[4 * j] == 1 ? dA[4 * j] : 0.f;              // mismatches are left to the pass below
+#pragma unroll
+                for (int n = 0; n < NT; ++n) cv[j][n] = gC[4 * j * CP + 16 * n];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) accC[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cv[j][n], accC[n], 0, 0, 0);
+        }
+        // store grad_depth: lane holds pixel 4 * (lane >> 4) + i, bin bb * 16 + (lane & 15)
+        const int bin = bb * kBins + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int prow = 4 * (lane >> 4) + i;
+            const int f = flag[prow * Dp + bin];
+            if (prow < nrow && bin < D && f != 2)
+                st_scalar<FT>(grad_depth + tcol + prow * rstep + bin * dstep, f == 1 ? accD[i] + accD2[i] : 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                 // the tile is rewritten by the next batch
+    }
+    COL_STAMP(2);
+    // ---- grad_context: the two waves' partial sums meet in LDS
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gw[(4 * (lane >> 4) + i) * CP + 16 * n + (lane & 15)] = accC[n][i];
+    __syncthreads();
+    float *sum = gw0;                                                    // wave 0's tile becomes the total
+    for (int e = tid; e < 16 * C4; e += kColBlock) {
+        const int prow = e / C4, c4 = e - prow * C4;
+        float4 s0 = *reinterpret_cast<const float4 *>(sum + prow * CP + c4 * 4);
+        const float4 s1 = *reinterpret_cast<const float4 *>(gw1 + prow * CP + c4 * 4);
+        s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+        *reinterpret_cast<float4 *>(sum + prow * CP + c4 * 4) = s0;
+    }
+    __syncthreads();
+
+    // ---- mismatches (3.8 % of the kept points on the reference's nuScenes calibration, none on a level rig): a lane group
+    // (C/4 lanes, a float4 column each) per pixel gathers the pixel's mismatching bins into a list and walks it, four
+    // BEV-gradient rows in flight -- the ray walk of lift_splat_tile.hip without its pipeline
+    if (nmis > 0) {
+        constexpr int G = 64 / C4, NGR = (kColBlock / 64) * G, Q = C4 / 4;
+        const int g = lane / C4, li = lane - g * C4;
+        const int grp = wave * G + (g < G ? g : 0);
+        int *klist = reinterpret_cast<int *>(gw1) + grp * Dp;            // bins of the pixel that need the pass
+        float *part = gw1 + NGR * Dp + grp * 4 * Q;                      // quad partials of 4 dot products
+        const unsigned long long gmask = C4 >= 64 ? ~0ull : ((1ull << C4) - 1ull);
+        for (int p0 = 0; p0 < 16; p0 += NGR) {
+            const int prow = p0 + wave * G + g;
+            const bool act = g < G && prow < nrow;
+            const int prc = act ? prow : 0;
+            const int64_t pix = (int64_t)bn * HW + (row0 + prc) * a.fW + col;
+            float4 cx = make_float4(0.f, 0.f, 0.f, 0.f), acc = cx;
+            if (act) {
+                if constexpr (sizeof(FT) == 2) {
+                    const uint2 rr = *reinterpret_cast<const uint2 *>(context + pix * C + li * 4);
+                    cx = make_float4(bf16_lo(rr.x), bf16_hi(rr.x), bf16_lo(rr.y), bf16_hi(rr.y));
+                } else {
+                    cx = *reinterpret_cast<const float4 *>(context + pix * C + li * 4);
+                }
+            }
+            int cnt = 0;
+            for (int d0 = 0; d0 < D; d0 += C4) {
+                const int bin = d0 + li;
+                const bool mm = act && bin < D && flag[prc * Dp + (bin < D ? bin : 0)] == 2;
+                const unsigned long long seg = (__ballot(mm) >> (g < G ? g * C4 : 0)) & gmask;
+                if (mm) klist[cnt + __popcll(seg & ((1ull << li) - 1ull))] = bin;
+                cnt += __popcll(seg);
+            }
+            int most = act ? cnt : 0;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) { const int o_ = __shfl_xor(most, m); most = o_ > most ? o_ : most; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int e0 = 0; e0 < most; e0 += 4) {
+                mmt_u32x4 v[4];
+                float dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = act && (e0 + u) < cnt;
+                    const int bin = on ? klist[e0 + u] : 0;
+                    const unsigned o = on ? (unsigned)moff[prc * Dp + bin] : kOut;
+                    dv[u] = on ? dep[prc * Dp + bin] : 0.f;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + (g < G ? (unsigned)li * 16u : 0x40000000u), 0, 0);
+                }
+                float mine = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float g0 = __uint_as_float(v[u].x), g1 = __uint_as_float(v[u].y), g2 = __uint_as_float(v[u].z), g3 = __uint_as_float(v[u].w);
+                    acc.x += g0 * dv[u]; acc.y += g1 * dv[u]; acc.z += g2 * dv[u]; acc.w += g3 * dv[u];
+                    const float qs = quad_sum(g0 * cx.x + g1 * cx.y + g2 * cx.z + g3 * cx.w);
+                    if ((li & 3) == u) mine = qs;
+                }
+                if (g < G) part[(li & 3) * Q + (li >> 2)] = mine;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (act && li < 4 && (e0 + li) < cnt) {
+                    float s2 = 0.f;
+                    for (int k = 0; k < Q; ++k) s2 += part[li * Q + k];
+                    st_scalar<FT>(grad_depth + tcol + prow * rstep + klist[e0 + li] * dstep, s2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (act) {
+                float4 s0 = *reinterpret_cast<const float4 *>(sum + prow * CP + li * 4);
+                s0.x += acc.x; s0.y += acc.y; s0.z += acc.z; s0.w += acc.w;
+                *reinterpret_cast<float4 *>(sum + prow * CP + li * 4) = s0;
+            }
+        }
+        __syncthreads();
+    }
+#ifndef LSS_STAMPS
+    for (int e = tid; e < 16 * C4; e += kColBlock) {
+        const int prow = e / C4, c4 = e - prow * C4;
+        if (prow < nrow) {
+            const int64_t pix = (int64_t)bn * HW + (row0 + prow) * a.fW + col;
+            *reinterpret_cast<float4 *>(a.grad_context + pix * C + c4 * 4) = *reinterpret_cast<const float4 *>(sum + prow * CP + c4 * 4);
+        }
+    }
+#endif
+}
+
+template <typename FT>
+int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom, const FT *depth,
+           const FT *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx, int64_t span, FT *grad_depth,
+           float *grad_context, int pm, hipStream_t st) {
+    ColArgs a;
+    a.BN = B * N; a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
+    a.pm = pm; a.rblocks = (fH + 15) / 16;
+    a.geom = geom; a.depth = depth; a.context = context; a.grad_out = grad_out; a.sb = sb; a.sy = sy; a.sx = sx;
+    a.span_bytes = (int)(span * 4);
+    a.grad_depth = grad_depth; a.grad_context = grad_context;
+    const int Dp = ((D + kBins - 1) / kBins) * kBins;
+    const size_t lds = (size_t)16 * Dp * 4 * 2 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
+    const int64_t grid = 8ll * ((a.BN + 7) / 8) * fW * a.rblocks;
+    mmt::TimedSeq seq;
+    if (C == 80) seq.launch(true, lss_col_bwd<FT, 5>, dim3((unsigned)grid), dim3(kColBlock), lds, st, a);
+    else if (C == 64) seq.launch(true, lss_col_bwd<FT, 4>, dim3((unsigned)grid), dim3(kColBlock), lds, st, a);
+    else seq.launch(true, lss_col_bwd<FT, 8>, dim3((unsigned)grid), dim3(kColBlock), lds, st, a);
+    return mmt::check_launch(what);
+}
+
+}  // namespace
+
+namespace mmt {
+
+// true when the column kernel takes this shape (C in {64, 80, 128}; LDS within 64 KB; a gradient map below 1 GiB)
+bool lss_col_backward_fits(int D, int fH, int fW, int C, int64_t span, int64_t grid_units) {
+    const int Dp = ((D + kBins - 1) / kBins) * kBins;
+    const size_t lds = (size_t)16 * Dp * 4 * 2 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
+    const int C4 = C / 4, NGR = (kColBlock / 64) * (64 / C4);
+    if (NGR * Dp + NGR * C4 > 16 * (C + 4)) return false;            // the lists of the mismatch pass live in wave 1's tile
+    return (C == 64 || C == 80 || C == 128) && lds <= 64 * 1024 && span * 4 < (1ll << 30) && grid_units < (1ll << 28);
+}
+int lss_col_backward_f32(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
+                         const float *depth, const float *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx,
+                         int64_t span, float *grad_depth, float *grad_context, int pm, hipStream_t st) {
+    return launch<float>(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+}
+int lss_col_backward_bf16(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
+                          const bf16_t *depth, const bf16_t *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx,
+                          int64_t span, bf16_t *grad_depth, float *grad_context, int pm, hipStream_t st) {
+    return launch<bf16_t>(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+}
+
+}  // namespace mmt

@@ -903,7 +903,8 @@ template <typename FT>
 int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
                   const FT *depth, const FT *context, const float *grad_out, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
                   FT *grad_depth, float *grad_context, int flags, hipStream_t st) {
-    if (flags & ~(MMT_LSS_PIXEL_MAJOR | MMT_LSS_TILE_KERNELS)) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (flags & ~(MMT_LSS_PIXEL_MAJOR | MMT_LSS_TILE_KERNELS | MMT_LSS_COLUMN_BACKWARD))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
     if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive size", what);
     constexpr int VEC = Elem<FT>::VEC;
@@ -917,6 +918,16 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
     if ((int64_t)B * N * D * fH * fW >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
     {
+        const bool want_col = (flags & MMT_LSS_COLUMN_BACKWARD) != 0;       // the matrix-core column kernel (lift_splat_col.hip)
+        if (want_col && !(flags & MMT_LSS_TILE_KERNELS) && mmt::lss_col_backward_fits(D, fH, fW, C, span, (int64_t)B * N * fW * ((fH + 15) / 16))) {
+            const int pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
+            if constexpr (sizeof(FT) == 2)
+                return mmt::lss_col_backward_bf16(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+            else
+                return mmt::lss_col_backward_f32(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+        }
+    }
+    {
         const int C4 = C / 4, NGR = (kBlock / 64) * (64 / C4);
         const size_t lds = (size_t)NGR * (3 * (((D + kRayBins - 1) & ~(kRayBins - 1)) + 8) + kRayBins * (C4 / 4)) * 4;
         if (!(flags & MMT_LSS_TILE_KERNELS) && lds <= 64 * 1024 && span * 4 < (1ll << 30)) {
@@ -929,10 +940,11 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
             r.wpc = (fH * fW + NGR - 1) / NGR;
             const int64_t grid = 8ll * ((r.BN + 7) / 8) * r.wpc;
             if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+            const size_t lds_req = lds;
             mmt::TimedSeq seq;
-            if (C == 80) seq.launch(true, lss_ray_bwd<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
-            else if (C == 64) seq.launch(true, lss_ray_bwd<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
-            else seq.launch(true, lss_ray_bwd<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            if (C == 80) seq.launch(true, lss_ray_bwd<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds_req, st, r);
+            else if (C == 64) seq.launch(true, lss_ray_bwd<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds_req, st, r);
+            else seq.launch(true, lss_ray_bwd<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds_req, st, r);
             return mmt::check_launch(what);
         }
     }

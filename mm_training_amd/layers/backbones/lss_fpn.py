@@ -119,6 +119,13 @@ class LSSFPN(nn.Module):
         # Storage type of the hot-path operands: "bf16" keeps depth / context (fused path) or the
         # lifted feature matrix and its gradient (unfused path) in bf16; products and sums stay fp32, the BEV map is fp32.
         self.hot_path_dtype = "f32"
+        # Backward kernel of the fused path: "ray" (per-pixel walk, any geometry at the same speed), "column" (matrix cores:
+        # two small GEMMs per image column, the faster one while the pixels of a column share their BEV cell) or "auto":
+        # measured ONCE per calibration (mats_dict['calibration_id'], or once per module without it) from the geometry itself
+        # -- column while fewer than 1 % of the kept points leave their column's cell.  That one measurement reads a scalar
+        # back (the only host sync of this module, never inside a graph capture).
+        self.lift_splat_backward = "auto"
+        self._column_backward_choice = {}
         self._plan_cache = {}     # calibration_id -> VoxelPoolingPlan (see _forward_single_sweep)
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
@@ -163,6 +170,21 @@ class LSSFPN(nn.Module):
             combine = sensor2ego_mat.float().matmul(torch.linalg.inv_ex(intrin_mat.float())[0]).contiguous()
         fr = self.frustum_pixel_major if pixel_major else self.frustum
         return frustum_geometry(fr.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
+
+    def _use_column_backward(self, geom_pixel_major, calib_id):
+        if self.lift_splat_backward != "auto":
+            return self.lift_splat_backward == "column"
+        key = calib_id if calib_id is not None else "_"
+        choice = self._column_backward_choice.get(key)
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled():
+                return False                                   # nothing to decide for (or no way to read a scalar back)
+            from mm_training_amd.ops.bev_geometry import column_mismatch_fraction
+            choice = bool(column_mismatch_fraction(geom_pixel_major, self._voxel_num_host, pixel_major=True).item() < 0.01)
+            if len(self._column_backward_choice) >= 64:
+                self._column_backward_choice.pop(next(iter(self._column_backward_choice)))
+            self._column_backward_choice[key] = choice
+        return choice
 
     def get_cam_feats(self, imgs):
         """[B, S, N, 3, H, W] images -> [B, S, N, C', fH, fW] neck features (lss_fpn.py:363-379)."""
@@ -216,10 +238,12 @@ class LSSFPN(nn.Module):
             feats = lift_features(depth_used.float(), context.float())
             feature_map = voxel_pooling_planned(plan, feats.view(batch_size, -1, feats.shape[-1]))
         elif self.fused_lift_splat:
+            col_bwd = self._use_column_backward(geom_xyz, calib_id)
             if self.hot_path_dtype == "bf16":
-                feature_map = lift_splat(geom_xyz, depth_used.bfloat16(), context.bfloat16(), self._voxel_num_host, pixel_major=True)
+                feature_map = lift_splat(geom_xyz, depth_used.bfloat16(), context.bfloat16(), self._voxel_num_host, pixel_major=True,
+                                         column_backward=col_bwd)
             else:
-                feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host, pixel_major=True)
+                feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host, pixel_major=True, column_backward=col_bwd)
         else:
             # lift straight into [B, N, D, fH, fW, C], then the drop-in voxel_pooling
             bf16 = self.hot_path_dtype == "bf16" and self.output_channels % 16 == 0

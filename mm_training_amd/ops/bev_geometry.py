@@ -136,8 +136,30 @@ def lift_features(depth, context, storage_dtype=torch.float32):
     return LiftFeatures.apply(depth.contiguous(), context.contiguous())
 
 
-def _lss_flags(pixel_major):
-    return (_lib.LSS_PIXEL_MAJOR if pixel_major else 0) | (_lib.LSS_TILE_KERNELS if os.environ.get("MMT_LIFT_SPLAT_TILES", "0") == "1" else 0)
+def _lss_flags(pixel_major, column_backward=False):
+    return ((_lib.LSS_PIXEL_MAJOR if pixel_major else 0) | (_lib.LSS_COLUMN_BACKWARD if column_backward else 0)
+            | (_lib.LSS_TILE_KERNELS if os.environ.get("MMT_LIFT_SPLAT_TILES", "0") == "1" else 0))
+
+
+def column_mismatch_fraction(geom_xyz, voxel_num, pixel_major=False):
+    """Share of the kept frustum points whose BEV cell differs from "their column's" cell (the smallest kept cell among the 16
+    image rows of their block at the same depth bin) -- what the column backward kernel (MMT_LSS_COLUMN_BACKWARD) has to handle
+    point by point.  0 for a level rig, ~0.04 for the reference's nuScenes calibration.  Returns a 0-dim tensor on the
+    device of geom (no host sync here).  geom int32 [B,N,D,fH,fW,3], or [B,N,fH,fW,D,3] with pixel_major."""
+    nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
+    g = geom_xyz if pixel_major else geom_xyz.permute(0, 1, 3, 4, 2, 5)          # [B,N,fH,fW,D,3]
+    x, y, z = g[..., 0].long(), g[..., 1].long(), g[..., 2].long()
+    kept = (x >= 0) & (x < nx) & (y >= 0) & (y < ny) & (z >= 0) & (z < nz)
+    big = torch.where(kept, y * nx + x, torch.full_like(x, 1 << 40))
+    B, N, fH, fW, D = big.shape
+    pad = (-fH) % 16
+    if pad:
+        big = torch.cat([big, big.new_full((B, N, pad, fW, D), 1 << 40)], 2)
+        kept = torch.cat([kept, kept.new_zeros((B, N, pad, fW, D))], 2)
+    blocks = big.view(B, N, -1, 16, fW, D)
+    ref = blocks.amin(3, keepdim=True)
+    mism = (kept.view(B, N, -1, 16, fW, D) & (blocks != ref)).sum()
+    return mism.float() / kept.sum().clamp(min=1).float()
 
 
 class LiftSplat(Function):
@@ -148,10 +170,11 @@ class LiftSplat(Function):
     mmt_lss_splat_forward / _backward: ray walks (forward: a workgroup owns an image column and sums depth * context in
     registers while the BEV cell stays the same; backward: a lane group owns a pixel, no atomics).  MMT_LIFT_SPLAT_TILES=1
     selects the second-generation frustum-tile kernels, MMT_LIFT_SPLAT_V1=1 the first-generation pair (chunks of
-    consecutive points; pixel-major backward on pos_memo) -- both kept for A/B runs, the latter also for fH > 512."""
+    consecutive points; pixel-major backward on pos_memo) -- both kept for A/B runs, the latter also for fH > 512.
+    column_backward=True: the backward of a (nearly) level rig on the matrix cores (MMT_LSS_COLUMN_BACKWARD, lift_splat_col.hip)."""
 
     @staticmethod
-    def forward(ctx, geom_xyz, depth, context, voxel_num, pixel_major=False):
+    def forward(ctx, geom_xyz, depth, context, voxel_num, pixel_major=False, column_backward=False):
         _need_cuda(geom_xyz, "geom_xyz", torch.int32)
         if pixel_major:
             B, N, fH, fW, D = geom_xyz.shape[:5]
@@ -186,7 +209,7 @@ class LiftSplat(Function):
                                 _lib.VP_WRITE_DROPPED, _stream())
                 ctx.save_for_backward(pos_memo, depth_c, ctx_nhwc)
         ctx.dims = (B, N, D, fH, fW, C, nx, ny, nz)
-        ctx.bf16, ctx.tiled, ctx.pixel_major = bf16, tiled, bool(pixel_major)
+        ctx.bf16, ctx.tiled, ctx.pixel_major, ctx.column_backward = bf16, tiled, bool(pixel_major), bool(column_backward)
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -203,7 +226,7 @@ class LiftSplat(Function):
                 grad_ctx = torch.empty(ctx_nhwc.shape, dtype=torch.float32, device=depth_c.device)    # every element is written
                 _lib.timed_call("lift_splat_backward", "mmt_lss_splat_backward" + sfx, B, N, D, fH, fW, C, nx, ny, nz,
                                 index.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), grad_out.data_ptr(), sb, sc, sy, sx,
-                                grad_depth.data_ptr(), grad_ctx.data_ptr(), _lss_flags(ctx.pixel_major), _stream())
+                                grad_depth.data_ptr(), grad_ctx.data_ptr(), _lss_flags(ctx.pixel_major, ctx.column_backward), _stream())
                 if ctx.bf16:
                     grad_ctx = grad_ctx.to(torch.bfloat16)
             else:
@@ -213,13 +236,13 @@ class LiftSplat(Function):
                                 grad_depth.data_ptr(), grad_ctx.data_ptr(), _stream())
         if ctx.pixel_major:      # [BN, fH, fW, D] storage = a channels_last [BN, D, fH, fW] gradient
             grad_depth = grad_depth.permute(0, 3, 1, 2)
-        return None, grad_depth, grad_ctx.permute(0, 3, 1, 2), None, None
+        return None, grad_depth, grad_ctx.permute(0, 3, 1, 2), None, None, None
 
 
-def lift_splat(geom_xyz, depth, context, voxel_num, pixel_major=False):
+def lift_splat(geom_xyz, depth, context, voxel_num, pixel_major=False, column_backward=False):
     """geom int32 [B,N,D,fH,fW,3], depth [B*N,D,fH,fW], context [B*N,C,fH,fW] -> BEV fp32 [B,C,ny,nx].
     depth AND context in bf16 select the bf16-storage kernels (fp32 products and sums, bf16 gradients back).
     pixel_major=True: geom is [B,N,fH,fW,D,3] (frustum_geometry of the frustum permuted to [fH,fW,D,4]) and the kernels read
     depth in [B*N,fH,fW,D] memory order -- what a channels_last depth tensor already is -- and return its gradient in that
     order: whole 64- / 192-byte runs per pixel and tile instead of 8- / 24-byte pieces."""
-    return LiftSplat.apply(geom_xyz.contiguous(), depth, context, voxel_num, bool(pixel_major))
+    return LiftSplat.apply(geom_xyz.contiguous(), depth, context, voxel_num, bool(pixel_major), bool(column_backward))

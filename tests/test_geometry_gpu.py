@@ -215,12 +215,13 @@ def test_fused_lift_splat_equals_lift_then_pool(mmt_lib, oracle_mod, cfg):
     assert torch.allclose(d4.grad, d2.grad, rtol=1e-4, atol=1e-5) and torch.allclose(c4.grad, c2.grad, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("kernels", ["ray", "tiles"])
+@pytest.mark.parametrize("kernels", ["ray", "tiles", "column"])
 @pytest.mark.parametrize("cfg", [(1, 2, 13, 5, 7, 64, "rig"), (2, 3, 37, 16, 9, 80, "rig"), (1, 1, 112, 32, 10, 128, "rig"),
-                                 (1, 2, 21, 3, 5, 80, "uniform"), (2, 2, 16, 16, 6, 48, "rig")])
+                                 (1, 2, 21, 3, 5, 80, "uniform"), (2, 2, 16, 16, 6, 48, "rig"), (1, 2, 40, 20, 5, 80, "pitched")])
 def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, monkeypatch):
-    """mmt_lss_splat_forward / _backward, ray walks (default) and frustum tiles (MMT_LSS_TILE_KERNELS), both point orders, on
-    shapes that are not multiples of anything (fH % 4, D % 16, fW odd; C = 48 takes the tile forward + the ray backward):
+    """mmt_lss_splat_forward / _backward, ray walks (default), frustum tiles (MMT_LSS_TILE_KERNELS) and the matrix-core column
+    backward (MMT_LSS_COLUMN_BACKWARD; "uniform" = every point a mismatch, "pitched" = a few per cent), both point orders, on
+    shapes that are not multiples of anything (fH % 4, fH % 16, D % 16, fW odd; C = 48 takes the tile forward + the ray backward):
     forward vs the oracle composition (1e-4), gradients vs torch autograd of the same expression in fp64."""
     from mm_training_amd import synthetic
     from mm_training_amd.ops.bev_geometry import lift_splat
@@ -228,6 +229,14 @@ def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, m
     monkeypatch.setenv("MMT_LIFT_SPLAT_TILES", "1" if kernels == "tiles" else "0")
     if kind == "rig":
         geom, vn = synthetic.rig_geometry(B, N, (fH * 16, fW * 16), 16, (2.0, 2.0 + 0.5 * D, 0.5))
+    elif kind == "pitched":      # cameras pitched by 2 degrees: the pixels of a column do not all share their cell
+        import math
+        s2e, K = synthetic.camera_rig(B, N, fW * 16, fH * 16, jitter=0.02, seed=0)
+        c_, s_ = math.cos(math.radians(2.0)), math.sin(math.radians(2.0))
+        rx = torch.tensor([[1, 0, 0, 0], [0, c_, -s_, 0], [0, s_, c_, 0], [0, 0, 0, 1]], dtype=torch.float32)
+        xyz = synthetic.frustum_geometry_xyz(s2e.matmul(rx), K, (fH * 16, fW * 16), 16, (2.0, 2.0 + 0.5 * D, 0.5))
+        geom, vn = synthetic.quantize_cpu(xyz, (-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8), (-5.0, 3.0, 8.0))
+        geom, vn = geom.contiguous(), [int(v) for v in vn]
     else:
         geom = synthetic.uniform_geometry(B, N * D * fH * fW, 128, 128).reshape(B, N, D, fH, fW, 3)
         vn = [128, 128, 1]
@@ -253,11 +262,16 @@ def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, m
             gm = gm.permute(0, 1, 3, 4, 2, 5).contiguous()
         d1 = depth.cuda().requires_grad_(True)
         c1 = ctx.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
-        out = lift_splat(gm, d1, c1, vn, pixel_major=pm)
+        out = lift_splat(gm, d1, c1, vn, pixel_major=pm, column_backward=kernels == "column")
         assert np.abs(out.detach().permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= 1e-4
         out.backward(go.cuda().contiguous(memory_format=torch.channels_last))
         assert torch.allclose(d1.grad.cpu().double().view_as(dd), dd.grad, rtol=1e-4, atol=1e-5)
         assert torch.allclose(c1.grad.cpu().double().view_as(cc), cc.grad, rtol=1e-4, atol=1e-4)
+    if kernels == "column":      # what LSSFPN's "auto" looks at
+        from mm_training_amd.ops.bev_geometry import column_mismatch_fraction
+        frac = float(column_mismatch_fraction(geom.cuda(), vn))
+        assert frac == float(column_mismatch_fraction(geom.cuda().permute(0, 1, 3, 4, 2, 5).contiguous(), vn, pixel_major=True))
+        assert (frac == 0.0) if kind == "rig" and fH <= 16 else (frac > 0.0 if kind != "rig" else True)
 
 
 def test_fused_geometry_on_reference_nuscenes_calibration(mmt_lib, oracle_mod, golden):

@@ -21,6 +21,8 @@ KERNELS = [
     ("vp_bwd_prepare", ("vp_bwd_prepare",)),
     ("vp_bwd_rows_vec4", ("vp_bwd_rows_vec<float",)),
     ("vp_bwd_rows_bf16", ("vp_bwd_rows_vec<unsigned short",)),
+    ("lift_splat_backward_column", ("lss_col_bwd<float",)),
+    ("lift_splat_backward_column_bf16", ("lss_col_bwd<unsigned short",)),
     ("lift_splat_backward", ("lss_ray_bwd<float",)),
     ("lift_splat_backward_bf16", ("lss_ray_bwd<unsigned short",)),
     ("lift_splat_backward_tile", ("lss_splat_bwd_tile<float",)),

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mm_training_amd import _lib, synthetic
 
-PM, TILE = 0x100, 0x200
+PM, TILE, COL = 0x100, 0x200, 0x400
 
 
 def load(path):
@@ -39,6 +39,17 @@ def rolled_rig_geometry(B, roll_deg, N=6, final_dim=(256, 704), ds=16, d_bound=(
     return geom.contiguous(), [int(v) for v in vn]
 
 
+def pitched_rig_geometry(B, pitch_deg, N=6, final_dim=(256, 704), ds=16, d_bound=(2.0, 58.0, 0.5)):
+    """rig geometry with every camera pitched about its own x axis (a mounting tolerance): the pixels of a column no longer
+    share their BEV cell exactly"""
+    s2e, K = synthetic.camera_rig(B, N, final_dim[1], final_dim[0], jitter=0.02, seed=0)
+    c, s = math.cos(math.radians(pitch_deg)), math.sin(math.radians(pitch_deg))
+    Rx = torch.tensor([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    xyz = synthetic.frustum_geometry_xyz(s2e.matmul(Rx), K, final_dim, ds, d_bound)
+    geom, vn = synthetic.quantize_cpu(xyz, (-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8), (-5.0, 3.0, 8.0))
+    return geom.contiguous(), [int(v) for v in vn]
+
+
 def main():
     libs = sys.argv[1:] or [_lib.LIB_PATH]
     _lib.lib()
@@ -53,6 +64,7 @@ def main():
     rig = synthetic.rig_geometry(B)
     variants = {"rig": rig, "roll5": rolled_rig_geometry(B, 5.0)}
     if os.environ.get("KBF_EXTRA"):      # every point dropped / every point kept (same cells, z forced into range): what do dropped bins cost?
+        variants["pitch1"] = pitched_rig_geometry(B, 1.0)
         variants["alldrop"] = (torch.full_like(rig[0], -1), rig[1])
         allk = rig[0].clone()
         allk[..., 0].clamp_(0, rig[1][0] - 1); allk[..., 1].clamp_(0, rig[1][1] - 1); allk[..., 2] = 0
@@ -70,7 +82,7 @@ def main():
         def fwd(h, flags):
             pm = flags & PM
             return h.mmt_lss_splat_forward(B, N, D, fH, fW, C, nx, ny, nz, (geom_pm if pm else geom).data_ptr(), (depth_pm if pm else depth).data_ptr(),
-                                           ctx.data_ptr(), out.data_ptr(), None, flags, st)
+                                           ctx.data_ptr(), out.data_ptr(), None, flags & ~COL, st)
 
         def bwd(h, flags):
             pm = flags & PM
@@ -102,7 +114,7 @@ def main():
         # agreement of the two kernel families (and of both point orders)
         h = hs[0]
         ref = {}
-        for name, flags in (("tile_pm", PM | TILE), ("ray_pm", PM), ("ray_frustum", 0)):
+        for name, flags in (("tile_pm", PM | TILE), ("ray_pm", PM), ("ray_frustum", 0), ("col_pm", PM | COL), ("col_frustum", COL)):
             out.zero_()
             assert fwd(h, flags) == 0, h.mmt_last_error()
             gc.fill_(float("nan")); gd.fill_(float("nan")); gd_pm.fill_(float("nan"))
@@ -119,7 +131,7 @@ def main():
                 gc.zero_()
                 if cold_:
                     torch.zeros(256 * 1024 * 1024, device="cuda").add_(1.0)
-                bwd(hh, PM)
+                bwd(hh, PM | COL if os.environ.get("KBF_STAMP_COL") else PM)
                 torch.cuda.synchronize()
                 s64 = gc.view(-1)[:8 * 2048].view(torch.int64).view(-1, 4).cpu()
                 s64 = s64[(s64[:, 0] != 0) & (s64[:, 2] != 0) & (s64[:, 1] != 0)]
@@ -128,13 +140,14 @@ def main():
                 print("RAY BWD STAMPS %s (s_memtime ticks, %d workgroups): phase A %.0f | walk %.0f ; first start to last end %.0f" % ("cold" if cold_ else "warm", len(s64), *d.mean(0).tolist(), span))
         flush = torch.zeros(256 * 1024 * 1024, device="cuda")
         cases = {"ray_fwd_pm": lambda h: fwd(h, PM), "tile_fwd_pm": lambda h: fwd(h, PM | TILE), "ray_fwd_frustum": lambda h: fwd(h, 0),
-                 "ray_bwd_pm": lambda h: bwd(h, PM), "tile_bwd_pm": lambda h: bwd(h, PM | TILE), "ray_bwd_frustum": lambda h: bwd(h, 0)}
+                 "ray_bwd_pm": lambda h: bwd(h, PM), "tile_bwd_pm": lambda h: bwd(h, PM | TILE), "ray_bwd_frustum": lambda h: bwd(h, 0),
+                 "col_bwd_pm": lambda h: bwd(h, PM | COL), "col_bwd_frustum": lambda h: bwd(h, COL)}
         for rnd in range(3):
             for name, fn in cases.items():
                 for p, h in zip(libs, hs):
                     out.zero_()
                     res.setdefault(gname + ":" + name, {}).setdefault(os.path.basename(p), []).append(round(timed(h, fn), 1))
-                    if name in ("ray_fwd_pm", "ray_bwd_pm", "tile_fwd_pm", "tile_bwd_pm") and gname == "rig":
+                    if name in ("ray_fwd_pm", "ray_bwd_pm", "tile_fwd_pm", "tile_bwd_pm", "col_bwd_pm") and gname == "rig":
                         out.zero_()
                         res.setdefault(gname + ":" + name + ":cold", {}).setdefault(os.path.basename(p), []).append(round(timed(h, fn, cold=True), 1))
     print(json.dumps(res, indent=1))
