@@ -77,6 +77,34 @@ def test_training_step_decreases_loss(mmt_lib, fused):
     assert ts.model.backbone.depth_net.context_se.conv_reduce.weight.grad is None
 
 
+def test_lssfpn_picks_the_backward_kernel_from_the_geometry(mmt_lib):
+    """LSSFPN.lift_splat_backward = "auto": the matrix-core column backward for a rig whose columns are level (no kept point
+    leaves its column's cell), the ray walk otherwise; decided once per calibration id; "ray" / "column" override it."""
+    import math
+    from mm_training_amd import synthetic
+    from mm_training_amd.dp import make_config
+    from mm_training_amd.layers.backbones import LSSFPN
+    cfg = make_config("tiny")
+    m = LSSFPN(**cfg["backbone_conf"]).cuda()
+    assert m.lift_splat_backward == "auto"
+    H, W = cfg["final_dim"]
+    s2e, K = synthetic.camera_rig(2, 2, W, H, jitter=0.02, seed=0)
+    level = m.get_geometry_voxels(s2e.cuda(), K.cuda(), pixel_major=True)
+    c_, s_ = math.cos(math.radians(3.0)), math.sin(math.radians(3.0))
+    rx = torch.tensor([[1, 0, 0, 0], [0, c_, -s_, 0], [0, s_, c_, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    pitched = m.get_geometry_voxels(s2e.matmul(rx).cuda(), K.cuda(), pixel_major=True)
+    with torch.no_grad():
+        assert m._use_column_backward(level, None) is False and not m._column_backward_choice     # nothing to decide without a backward
+    assert m._use_column_backward(level, "rig-a") is True
+    assert m._use_column_backward(pitched, "rig-b") is False
+    assert m._use_column_backward(pitched, "rig-a") is True                # remembered per calibration id, not re-measured
+    assert m._column_backward_choice == {"rig-a": True, "rig-b": False}
+    m.lift_splat_backward = "ray"
+    assert m._use_column_backward(level, "rig-a") is False
+    m.lift_splat_backward = "column"
+    assert m._use_column_backward(pitched, "rig-b") is True
+
+
 def test_lssfpn_cached_plan_matches_uncached(mmt_lib):
     """mats_dict['calibration_id']: the plan is built on the first call, reused on
     the next ones, and BEV map + gradients agree with the uncached drop-in path."""
