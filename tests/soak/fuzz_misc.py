@@ -71,6 +71,9 @@ while time.time() < t_end:
     nx, ny = int(rng.integers(1, 30)), int(rng.integers(1, 30))
     geom = torch.stack([torch.randint(-1, nx + 1, (Bc, N, D, fH, fW)), torch.randint(-1, ny + 1, (Bc, N, D, fH, fW)),
                         torch.zeros(Bc, N, D, fH, fW, dtype=torch.long)], -1).int().cuda()
+    if rng.random() < 0.5:      # frustum-like: the rows of a column share their cell, except a random 10 % of the points
+        coherent = geom[:, :, :, :1].expand_as(geom)
+        geom = torch.where(torch.rand(Bc, N, D, fH, fW, 1, device="cuda") < 0.1, geom, coherent).contiguous()
     d1, c1 = depth.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
     d2, c2 = depth.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
     f = lift_features(d2, c2)
@@ -80,10 +83,11 @@ while time.time() < t_end:
     o2 = voxel_pooling(geom, f.view(Bc, N, D, fH, fW, Cc), [nx, ny, 1])
     # kernel family (ray walks / frustum tiles) and point order (reference / pixel-major) at random
     os.environ["MMT_LIFT_SPLAT_TILES"] = "1" if rng.random() < 0.3 else "0"
+    col_bwd = bool(rng.random() < 0.5)          # matrix-core column backward (random cells: every point is a mismatch)
     if rng.random() < 0.5:
-        o1 = lift_splat(geom.permute(0, 1, 3, 4, 2, 5).contiguous(), d1, c1, [nx, ny, 1], pixel_major=True)
+        o1 = lift_splat(geom.permute(0, 1, 3, 4, 2, 5).contiguous(), d1, c1, [nx, ny, 1], pixel_major=True, column_backward=col_bwd)
     else:
-        o1 = lift_splat(geom, d1, c1, [nx, ny, 1])
+        o1 = lift_splat(geom, d1, c1, [nx, ny, 1], column_backward=col_bwd)
     if (o1 - o2).abs().max().item() > 1e-4 * max(1.0, o2.abs().max().item()):
         fail("fused forward", cfg)
     go = torch.randn_like(o2)
