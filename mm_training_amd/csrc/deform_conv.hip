@@ -48,7 +48,8 @@ __device__ __forceinline__ float4 fma4(float w, float4 v, float4 acc) {
     return make_float4(acc.x + w * v.x, acc.y + w * v.y, acc.z + w * v.z, acc.w + w * v.w);
 }
 
-// one wave per output position, 4 positions per workgroup
+// one wave per output position, 4 positions per workgroup; three taps = twelve 16-byte corner loads in flight per lane, no
+// branches (a corner outside the image is read at its clamped position and replaced by an exact 0, as mmcv's if does)
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(int B, int H, int W, int C, int groups,
                                                          const float *x, const float *offset, float *col) {
     const int lane = threadIdx.x & 63;
@@ -61,20 +62,34 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(int B, int H, int W, in
         const int h = hw / W, w = hw - h * W;
         const float *xb = x + (int64_t)b * H * W * C;
         const float *op = offset + pos * 18;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const int c = c4 * 4;
+            const int g = c / Cg, cin = c - g * Cg;
+            float *dst0 = col + ((int64_t)g * npos + pos) * (9 * Cg) + cin;
 #pragma unroll 1
-        for (int k = 0; k < 9; ++k) {
-            const int ky = k / 3, kx = k - ky * 3;
-            const Tap t = make_tap((float)(h + ky - 1) + op[2 * k], (float)(w + kx - 1) + op[2 * k + 1], H, W);
-            for (int c4 = lane; c4 < C4; c4 += 64) {
-                const int c = c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t.w1 != 0.f) v = fma4(t.w1, *reinterpret_cast<const float4 *>(xb + (int64_t)t.o1 * C + c), v);
-                if (t.w2 != 0.f) v = fma4(t.w2, *reinterpret_cast<const float4 *>(xb + (int64_t)t.o2 * C + c), v);
-                if (t.w3 != 0.f) v = fma4(t.w3, *reinterpret_cast<const float4 *>(xb + (int64_t)t.o3 * C + c), v);
-                if (t.w4 != 0.f) v = fma4(t.w4, *reinterpret_cast<const float4 *>(xb + (int64_t)t.o4 * C + c), v);
-                const int g = c / Cg, cin = c - g * Cg;
-                float *dst = col + ((int64_t)g * npos + pos) * (9 * Cg) + k * Cg + cin;
-                mmt_nt_store4(v, reinterpret_cast<float4 *>(dst));
+            for (int k0 = 0; k0 < 9; k0 += 3) {
+                Tap t[3];
+                float4 v[3][4];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int k = k0 + j;
+                    const int ky = k / 3, kx = k - ky * 3;
+                    t[j] = make_tap((float)(h + ky - 1) + op[2 * k], (float)(w + kx - 1) + op[2 * k + 1], H, W);
+                    v[j][0] = *reinterpret_cast<const float4 *>(xb + (int64_t)t[j].o1 * C + c);
+                    v[j][1] = *reinterpret_cast<const float4 *>(xb + (int64_t)t[j].o2 * C + c);
+                    v[j][2] = *reinterpret_cast<const float4 *>(xb + (int64_t)t[j].o3 * C + c);
+                    v[j][3] = *reinterpret_cast<const float4 *>(xb + (int64_t)t[j].o4 * C + c);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 r = z;
+                    r = fma4(t[j].w1, t[j].w1 != 0.f ? v[j][0] : z, r);
+                    r = fma4(t[j].w2, t[j].w2 != 0.f ? v[j][1] : z, r);
+                    r = fma4(t[j].w3, t[j].w3 != 0.f ? v[j][2] : z, r);
+                    r = fma4(t[j].w4, t[j].w4 != 0.f ? v[j][3] : z, r);
+                    mmt_nt_store4(r, reinterpret_cast<float4 *>(dst0 + (k0 + j) * Cg));
+                }
             }
         }
     }
@@ -240,10 +255,17 @@ __global__ __launch_bounds__(256) void dcn_offset_grad_kernel(int B, int H, int 
             const float4 gc = *reinterpret_cast<const float4 *>(grad_col + ((int64_t)g * npos + pos) * (9 * Cg) + k * Cg + cin);
             const float4 v1 = *reinterpret_cast<const float4 *>(x1 + c), v2 = *reinterpret_cast<const float4 *>(x2 + c);
             const float4 v3 = *reinterpret_cast<const float4 *>(x3 + c), v4 = *reinterpret_cast<const float4 *>(x4 + c);
-            gy += gc.x * (t.dy1 * v1.x + t.dy2 * v2.x + t.dy3 * v3.x + t.dy4 * v4.x) + gc.y * (t.dy1 * v1.y + t.dy2 * v2.y + t.dy3 * v3.y + t.dy4 * v4.y) +
-                  gc.z * (t.dy1 * v1.z + t.dy2 * v2.z + t.dy3 * v3.z + t.dy4 * v4.z) + gc.w * (t.dy1 * v1.w + t.dy2 * v2.w + t.dy3 * v3.w + t.dy4 * v4.w);
-            gx += gc.x * (t.dx1 * v1.x + t.dx2 * v2.x + t.dx3 * v3.x + t.dx4 * v4.x) + gc.y * (t.dx1 * v1.y + t.dx2 * v2.y + t.dx3 * v3.y + t.dx4 * v4.y) +
-                  gc.z * (t.dx1 * v1.z + t.dx2 * v2.z + t.dx3 * v3.z + t.dx4 * v4.z) + gc.w * (t.dx1 * v1.w + t.dx2 * v2.w + t.dx3 * v3.w + t.dx4 * v4.w);
+            // explicit FMAs (the library is built with -ffp-contract=off for the bit-exact geometry path)
+#define MMT_DOT4(d1, d2, d3, d4, comp) __builtin_fmaf(d1, v1.comp, __builtin_fmaf(d2, v2.comp, __builtin_fmaf(d3, v3.comp, d4 * v4.comp)))
+            gy = __builtin_fmaf(gc.x, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, x), gy);
+            gy = __builtin_fmaf(gc.y, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, y), gy);
+            gy = __builtin_fmaf(gc.z, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, z), gy);
+            gy = __builtin_fmaf(gc.w, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, w), gy);
+            gx = __builtin_fmaf(gc.x, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, x), gx);
+            gx = __builtin_fmaf(gc.y, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, y), gx);
+            gx = __builtin_fmaf(gc.z, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, z), gx);
+            gx = __builtin_fmaf(gc.w, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, w), gx);
+#undef MMT_DOT4
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -276,19 +298,25 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather(int B, int HW, int C, i
         const DcnEntry *eb = entries + (int64_t)b * HW * 36;
         const float *gcb = grad_col + ((int64_t)g * npos + (int64_t)b * HW) * (9 * Cg) + li * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = beg; j < end; j += kU) {
-            DcnEntry en[kU];
+        // the list entries of the NEXT kU rows are requested before the current rows are waited for: one dependent round
+        // trip per kU rows instead of two
+        DcnEntry en[kU], nx[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) en[u] = eb[(j + u) < end ? (j + u) : (end - 1)];
+        for (int u = 0; u < kU; ++u) en[u] = eb[(beg + u) < end ? (beg + u) : (end > beg ? end - 1 : beg)];
+        for (int j = beg; j < end; j += kU) {
             float4 v[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u)
                 v[u] = *reinterpret_cast<const float4 *>(gcb + ((int64_t)(en[u].src_tap >> 4) * 9 + (en[u].src_tap & 15)) * Cg);
 #pragma unroll
+            for (int u = 0; u < kU; ++u) nx[u] = eb[(j + kU + u) < end ? (j + kU + u) : (end - 1)];
+#pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const float w = (j + u) < end ? en[u].w : 0.f;
                 acc = fma4(w, v[u], acc);
             }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) en[u] = nx[u];
         }
         *reinterpret_cast<float4 *>(grad_x + pix * C + g * Cg + li * 4) = acc;
     }

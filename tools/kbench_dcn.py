@@ -40,9 +40,15 @@ def main():
         def srt():
             _lib.call("mmt_dcn_col2im_sorted", B, H, W, C, groups, x.data_ptr(), offset.data_ptr(), grad_col.data_ptr(), gx.data_ptr(),
                       go.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        col = torch.empty(groups, N, 9 * Cg, device="cuda")
+
+        def im2col():
+            _lib.call("mmt_dcn_im2col", B, H, W, C, groups, x.data_ptr(), offset.data_ptr(), col.data_ptr(), st)
         nbytes = grad_col.numel() * 4 + x.numel() * 4 * 2 + offset.numel() * 4 * 2       # grad_col + x read, grad_x + grad_offset written
-        ta, ts_ = timeit(atomic), timeit(srt)
+        ta, ts_, ti = timeit(atomic), timeit(srt), timeit(im2col)
+        fbytes = col.numel() * 4 + x.numel() * 4 + offset.numel() * 4
         res[f"B{B}_{H}x{W}_C{C}_offsets{scale}"] = {"atomic_ms_incl_zero_fill": ta, "sorted_ms": ts_, "algorithmic_MB": nbytes / 1e6,
+                                                   "im2col_ms": ti, "im2col_GBps": fbytes / ti / 1e6, "im2col_frac_of_peak": fbytes / ti / 1e6 / 8000.0,
                                                    "sorted_GBps": nbytes / ts_ / 1e6, "sorted_frac_of_peak": nbytes / ts_ / 1e6 / 8000.0}
     print(json.dumps(res, indent=1))
 
