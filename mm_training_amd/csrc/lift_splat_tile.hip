@@ -1,19 +1,24 @@
-// Fused lift + voxel_pooling, frustum-tile form (second generation) for MI355X (gfx950).
+// Fused lift + voxel_pooling over a camera frustum for MI355X (gfx950): the entry points
+// mmt_lss_splat_forward / _backward and two of their three kernel families.
 //
 //   out[b, cell(t), :] += depth[t] * context[pix(t), :]        (lss_fpn.py:441-464 in one pass)
 //
-// The first fused kernel (voxel_pooling.hip, vp_fwd_seg_gather<FUSED>) cuts the point list into chunks of CONSECUTIVE
-// points -- ten rows of 44 neighbouring pixels at one depth: 464 different context rows per chunk, which it has to gather
-// from L2 one by one (30 us of its 36 us per workgroup are that gather).  Here a workgroup owns a FRUSTUM TILE instead:
-// TPW image columns x all fH rows x Dt depth bins.  The pixels of one image column see the same ray in BEV, and
-// consecutive depth bins of a ray fall into the same or the next cell, so the tile's <= 512 points hit a dozen cells
-// and use only TPW*fH different context rows: the context tile is loaded ONCE into LDS (10-20 KB), the points are
-// sorted by cell in LDS exactly as before, every lane group sums one cell's rows out of LDS in registers, and the tile
-// leaves as one run of global fp32 atomics per touched cell (3x fewer atomic rows than the chunked kernel).
-// Correct for ANY geometry (the hash takes up to 512 distinct cells per tile); the frustum structure only makes it fast.
+// * RAY WALKS (default; second half of this file): no hash, no sort.  Forward: a workgroup owns one image column, its lane
+//   groups walk (depth bin, image row) and sum depth * context in registers while the BEV cell stays the same, flushing whole
+//   64-byte segments.  Backward: a lane group owns one pixel and walks its kept depth bins; no atomics.
+// * FRUSTUM TILES (MMT_LSS_TILE_KERNELS; first half): the second generation.  The first fused kernel (voxel_pooling.hip,
+//   vp_fwd_seg_gather<FUSED>) cuts the point list into chunks of CONSECUTIVE points -- ten rows of 44 neighbouring pixels at
+//   one depth: 464 different context rows per chunk, gathered from L2 one by one.  Here a workgroup owns a FRUSTUM TILE
+//   instead: TPW image columns x all fH rows x Dt depth bins.  The pixels of one image column see the same ray in BEV, and
+//   consecutive depth bins of a ray fall into the same or the next cell, so the tile's <= 512 points hit a dozen cells and
+//   use only TPW*fH different context rows: the context tile is loaded ONCE into LDS (10-20 KB), the points are sorted by
+//   cell in LDS, every lane group sums one cell's rows out of LDS in registers, and the tile leaves as one run of global
+//   fp32 atomics per touched cell.  Less sensitive to geometry whose columns are not level (the hash does not care).
+// * MATRIX CORES (MMT_LSS_COLUMN_BACKWARD): lift_splat_col.hip, backward only.
+// All are correct for ANY geometry; the frustum structure only makes them fast.
 //
-// Workgroups of one (camera, depth-group) are dealt to the same XCD (blockIdx & 7), so the geom / depth lines shared by
-// neighbouring column tiles and the camera's context rows are fetched into one L2 -- placement affects speed only.
+// Workgroups of one camera are dealt to the same XCD (blockIdx & 7), so the geom / depth lines shared by neighbouring
+// columns and the camera's context rows are fetched into one L2 -- placement affects speed only.
 #include "mmt_common.h"
 
 namespace {
