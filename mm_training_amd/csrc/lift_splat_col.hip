@@ -25,6 +25,7 @@ constexpr unsigned kOut = 0x80000000u;          // row offset of a dropped point
 struct ColArgs {
     int BN, N, D, fH, fW, C, nx, ny, nz;
     int pm, rblocks;
+    int vec;                      // grad_depth may leave as 16-byte (fp32) / 8-byte (bf16) vectors: pixel-major, D % 4 == 0, aligned
     const int32_t *geom;
     const void *depth;
     const void *context;
@@ -198,14 +199,43 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) accC[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cv[j][n], accC[n], 0, 0, 0);
         }
-        // store grad_depth: lane holds pixel 4 * (lane >> 4) + i, bin bb * 16 + (lane & 15)
-        const int bin = bb * kBins + (lane & 15);
+        // grad_depth: the lane holds pixel 4 * (lane >> 4) + i, bin bb * 16 + (lane & 15) -- a dword per lane.  4-byte stores cost
+        // the fabric ~6x as much per byte as 16-byte ones (8.5 of this kernel's 23 us in an ablation build), so in the pixel-major
+        // order the tile is turned through LDS (its own G tile: the products are done with it) and leaves as ONE 16-byte store
+        // per lane: pixel lane >> 2, bins 4 * (lane & 3) .. + 3.  Mismatching elements are written as they come and
+        // overwritten by the pass below (after a workgroup barrier).
+        if (a.vec && bb * kBins + kBins <= D) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                             // every lane is done reading the tile
+            const int bin = bb * kBins + (lane & 15);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int prow = 4 * (lane >> 4) + i;
-            const int f = flag[prow * Dp + bin];
-            if (prow < nrow && bin < D && f != 2)
-                st_scalar<FT>(grad_depth + tcol + prow * rstep + bin * dstep, f == 1 ? accD[i] + accD2[i] : 0.f);
+            for (int i = 0; i < 4; ++i) {
+                const int prow = 4 * (lane >> 4) + i;
+                gw[prow * 20 + (lane & 15)] = flag[prow * Dp + bin] == 1 ? accD[i] + accD2[i] : 0.f;     // rows padded to 20 floats
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int prow = lane >> 2, b4 = 4 * (lane & 3);
+            if (prow < nrow) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(gw + prow * 20 + b4);
+                FT *dst = grad_depth + tcol + prow * rstep + (bb * kBins + b4);
+                if constexpr (sizeof(FT) == 2) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v4.x, v4.y); pk.y = pack_bf16x2(v4.z, v4.w);
+                    *reinterpret_cast<uint2 *>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4 *>(dst) = v4;
+                }
+            }
+        } else {
+            const int bin = bb * kBins + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int prow = 4 * (lane >> 4) + i;
+                const int f = flag[prow * Dp + bin];
+                if (prow < nrow && bin < D && f != 2)
+                    st_scalar<FT>(grad_depth + tcol + prow * rstep + bin * dstep, f == 1 ? accD[i] + accD2[i] : 0.f);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                                 // the tile is rewritten by the next batch
@@ -320,6 +350,7 @@ int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx,
     ColArgs a;
     a.BN = B * N; a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
     a.pm = pm; a.rblocks = (fH + 15) / 16;
+    a.vec = pm && (D % 4) == 0 && (((uintptr_t)grad_depth) & 15) == 0;
     a.geom = geom; a.depth = depth; a.context = context; a.grad_out = grad_out; a.sb = sb; a.sy = sy; a.sx = sx;
     a.span_bytes = (int)(span * 4);
     a.grad_depth = grad_depth; a.grad_context = grad_context;

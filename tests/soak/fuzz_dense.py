@@ -29,7 +29,11 @@ def fail(what, **kw):
     sys.exit(1)
 
 
+_next_note = time.time() + 60.0     # a line a minute: a silent GPU job is taken to be hung
 while time.time() < t_end:
+    if time.time() > _next_note:
+        print("...", it, "configurations so far", flush=True)
+        _next_note = time.time() + 60.0
     it += 1
     VERB = os.environ.get("FUZZ_VERBOSE")
     # ---- fused BN

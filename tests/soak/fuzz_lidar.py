@@ -16,7 +16,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 it = 0
+_next_note = time.time() + 60.0     # a line a minute: a silent GPU job is taken to be hung
 while time.time() < t_end:
+    if time.time() > _next_note:
+        print("...", it, "configurations so far", flush=True)
+        _next_note = time.time() + 60.0
     it += 1
     B = int(rng.integers(1, 5))
     F = int(rng.choice([3, 4, 5, 8]))

@@ -29,7 +29,11 @@ def fail(what, cfg):
     sys.exit(1)
 
 
+_next_note = time.time() + 60.0     # a line a minute: a silent GPU job is taken to be hung
 while time.time() < t_end:
+    if time.time() > _next_note:
+        print("...", it, "configurations so far", flush=True)
+        _next_note = time.time() + 60.0
     it += 1
     # ---- DCN
     groups = int(rng.choice([1, 2, 4]))
