@@ -1,0 +1,58 @@
+"""CPU: host-side logic of the hot path that needs no GPU -- the measure LSSFPN uses to pick the backward kernel of the fused
+lift-splat, and the forward / backward algorithmic-byte formulas of bench.py against their closed forms."""
+import math
+
+import torch
+
+
+def _rig(pitch_deg=0.0, B=1, N=2, H=64, W=96, D=20):
+    from mm_training_amd import synthetic
+    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=0)
+    c, s = math.cos(math.radians(pitch_deg)), math.sin(math.radians(pitch_deg))
+    rx = torch.tensor([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    xyz = synthetic.frustum_geometry_xyz(s2e.matmul(rx), K, (H, W), 16, (2.0, 2.0 + 0.5 * D, 0.5))
+    geom, vn = synthetic.quantize_cpu(xyz, (-51.2, 51.2, 0.8), (-51.2, 51.2, 0.8), (-5.0, 3.0, 8.0))
+    return geom.contiguous(), [int(v) for v in vn]
+
+
+def test_column_mismatch_fraction_is_zero_for_a_level_rig_and_grows_with_pitch():
+    """What LSSFPN.lift_splat_backward = "auto" looks at (ops/bev_geometry.py): the share of kept frustum points whose BEV cell
+    differs from the smallest kept cell among the 16 image rows of their block at the same depth bin."""
+    from mm_training_amd.ops.bev_geometry import column_mismatch_fraction
+    level, vn = _rig(0.0)
+    assert float(column_mismatch_fraction(level, vn)) == 0.0
+    fracs = [float(column_mismatch_fraction(_rig(p)[0], vn)) for p in (1.0, 3.0, 8.0)]
+    assert 0.0 < fracs[0] < fracs[1] < fracs[2] < 1.0
+    # both point orders, and a brute-force count on a small case
+    g, vn = _rig(3.0, H=80, W=48, D=9)        # fH = 5: a single, padded 16-row block
+    pm = g.permute(0, 1, 3, 4, 2, 5).contiguous()
+    assert float(column_mismatch_fraction(g, vn)) == float(column_mismatch_fraction(pm, vn, pixel_major=True))
+    nx, ny, nz = vn
+    B, N, D, fH, fW, _ = g.shape
+    mism = kept = 0
+    for b in range(B):
+        for n in range(N):
+            for d in range(D):
+                for w in range(fW):
+                    cells = []
+                    for h in range(fH):
+                        x, y, z = g[b, n, d, h, w].tolist()
+                        if 0 <= x < nx and 0 <= y < ny and 0 <= z < nz:
+                            cells.append(y * nx + x)
+                    kept += len(cells)
+                    mism += sum(1 for c in cells if c != min(cells))
+    assert abs(float(column_mismatch_fraction(g, vn)) - mism / max(kept, 1)) < 1e-6
+
+
+def test_bench_algorithmic_byte_formulas():
+    """bench.py's roofline numerators are SURVEY 8(d)'s formulas; the cfg2 / cfg4 camera shape gives the figures DESIGN quotes."""
+    import bench
+    BP, C, B, ny, nx = 4 * 473088, 80, 4, 128, 128
+    K = int(0.601 * BP)
+    fwd, bwd = bench.algorithmic_bytes(BP, K, C, B, ny, nx)
+    assert fwd == 24 * BP + 4 * C * K + 4 * C * B * ny * nx and bwd == 12 * BP + 4 * C * B * ny * nx + 4 * C * BP
+    f, b_, l2f, l2b = bench.lift_splat_bytes(BP, K, C, B, 24 * 704, ny, nx)
+    assert f == 56655872 and b_ == 69632000                       # 56.7 MB / 69.6 MB
+    assert l2f == f + K * 4 * C and l2b == b_ + K * 4 * C
+    f16, b16, _, _ = bench.lift_splat_bytes(BP, K, C, B, 24 * 704, ny, nx, feat_bytes=2)
+    assert f16 < f and b16 < b_
