@@ -165,6 +165,19 @@ def test_fused_lift_splat_bf16(mmt_lib, oracle_mod, cfg):
     assert np.abs(out3.detach().permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= ATOL
     out3.backward(go)
     assert _close_bf16(d3.grad, d2.grad) and _close_bf16(c3.grad, c2.grad)
+    # the matrix-core column backward on bf16 operands (bf16 grad_depth leaves as 8-byte stores), both point orders; its fp32 sums
+    # are taken in another order than the walk's (1e-5 on gradients of magnitude 50), so near-zero elements get an absolute
+    # allowance scaled to the tensor instead of 1e-6
+    def _close_col(a, b):
+        a, b = a.float(), b.float()
+        return bool(((a - b).abs() <= BF16_ULP * b.abs() + 1e-6 * max(1.0, b.abs().max().item())).all())
+    d4 = depth16.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    c4 = ctx16.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    lift_splat(geom_d.permute(0, 1, 3, 4, 2, 5).contiguous(), d4, c4, vn, pixel_major=True, column_backward=True).backward(go)
+    assert _close_col(d4.grad, d2.grad) and _close_col(c4.grad, c2.grad)
+    d5, c5 = depth16.cuda().requires_grad_(True), ctx16.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    lift_splat(geom_d, d5, c5, vn, column_backward=True).backward(go)
+    assert _close_col(d5.grad, d2.grad) and _close_col(c5.grad, c2.grad)
 
 
 @pytest.mark.parametrize("fused", [True, False])
