@@ -55,6 +55,26 @@ def test_host_side_argument_checks(mmt_lib):
         mmt_lib.call("mmt_quantize_geometry", 4, None, None, None, None, None)
 
 
+def test_host_side_argument_checks_of_the_fused_lift_splat(mmt_lib):
+    """mmt_lss_splat_forward / _backward: shapes, flags and strides are refused on the host before any launch."""
+    lib = mmt_lib.lib()
+    buf = (ctypes.c_float * 1024)()
+    p = ctypes.cast(ctypes.addressof(buf) + (-ctypes.addressof(buf)) % 16, ctypes.c_void_p)       # 16-byte aligned
+    PM, TILES, COLUMN = 0x100, 0x200, 0x400
+    fwd = lambda C, flags: lib.mmt_lss_splat_forward(1, 1, 4, 2, 2, C, 4, 4, 1, p, p, p, p, None, flags, None)
+    assert fwd(6, 0) == -2                                   # C % 4
+    assert fwd(16, 0x800) == -4 and b"unknown flag" in lib.mmt_last_error()
+    assert fwd(16, COLUMN) == -4                             # the column kernel is a backward kernel
+    assert lib.mmt_lss_splat_forward(0, 1, 4, 2, 2, 16, 4, 4, 1, p, p, p, p, None, 0, None) == -2
+    assert lib.mmt_lss_splat_forward(1, 1, 4, 2, 2, 16, 4, 4, 1, None, p, p, p, None, PM, None) == -1
+    bwd = lambda C, sc, flags: lib.mmt_lss_splat_backward(1, 1, 4, 2, 2, C, 4, 4, 1, p, p, p, p, 16 * C, sc, 4 * C, C, p, p, flags, None)
+    assert bwd(24, 1, 0) == -2                               # C % 16
+    assert bwd(16, 2, 0) == -2 and b"channels-last" in lib.mmt_last_error()
+    assert bwd(16, 1, 0x1000) == -4
+    assert bwd(16, 1, PM | TILES | COLUMN | 0x800) == -4
+    assert lib.mmt_lss_splat_backward(1, 1, 4, 2, 2, 16, 4, 4, 1, p, p, p, None, 256, 1, 64, 16, p, p, COLUMN, None) == -1
+
+
 def test_host_side_argument_checks_of_the_additional_entry_points(mmt_lib):
     """Cached plan, BEV warp, depth labels, CenterPoint targets, BatchNorm: refused on the host, no launch."""
     lib = mmt_lib.lib()

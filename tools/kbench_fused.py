@@ -89,11 +89,13 @@ def main():
             return h.mmt_lss_splat_backward(B, N, D, fH, fW, C, nx, ny, nz, (geom_pm if pm else geom).data_ptr(), (depth_pm if pm else depth).data_ptr(),
                                             ctx.data_ptr(), go.data_ptr(), ny * nx * C, 1, nx * C, C, (gd_pm if pm else gd).data_ptr(), gc.data_ptr(), flags, st)
 
-        def timed(h, fn, reps=15, warm=3, cold=False):
+        def timed(h, fn, reps=15, warm=3, cold=False, zero_first=False):
             evs = []
             for i in range(warm + reps):
                 if cold:        # 1 GiB of writes between launches: nothing of the operands is left in L2 / the Infinity Cache
                     flush.add_(1.0)
+                if zero_first:  # as in the training step: the BEV map is zero-filled right before the forward's atomics
+                    out.zero_()
                 s, e = ctypes.c_void_p(), ctypes.c_void_p()
                 h.mmt_timing_event_create(ctypes.byref(s)); h.mmt_timing_event_create(ctypes.byref(e))
                 h.mmt_arm_kernel_timing(s, e)
@@ -147,6 +149,8 @@ def main():
                 for p, h in zip(libs, hs):
                     out.zero_()
                     res.setdefault(gname + ":" + name, {}).setdefault(os.path.basename(p), []).append(round(timed(h, fn), 1))
+                    if name == "ray_fwd_pm" and gname == "rig":
+                        res.setdefault(gname + ":" + name + ":after_zero_fill", {}).setdefault(os.path.basename(p), []).append(round(timed(h, fn, zero_first=True), 1))
                     if name in ("ray_fwd_pm", "ray_bwd_pm", "tile_fwd_pm", "tile_bwd_pm", "col_bwd_pm") and gname == "rig":
                         out.zero_()
                         res.setdefault(gname + ":" + name + ":cold", {}).setdefault(os.path.basename(p), []).append(round(timed(h, fn, cold=True), 1))
