@@ -267,6 +267,22 @@ def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, m
         out.backward(go.cuda().contiguous(memory_format=torch.channels_last))
         assert torch.allclose(d1.grad.cpu().double().view_as(dd), dd.grad, rtol=1e-4, atol=1e-5)
         assert torch.allclose(c1.grad.cpu().double().view_as(cc), cc.grad, rtol=1e-4, atol=1e-4)
+    if kernels != "column":      # the optional pos_memo output of the C entry point (the op passes NULL): exactly the drop-in op's
+        from mm_training_amd import _lib
+        _, ref_pos = oracle_mod.voxel_pooling_forward(geom.reshape(B, -1, 3).numpy(), np.zeros((B, N * D * fH * fW, 4), np.float32), *vn)
+        dcl = depth.cuda().contiguous()
+        ccl = ctx.cuda().permute(0, 2, 3, 1).contiguous()
+        for wd in (0, _lib.VP_WRITE_DROPPED):
+            pos = torch.full((B, N * D * fH * fW, 3), -7, dtype=torch.int32, device="cuda")
+            outp = torch.zeros((B, ny, nx, C), device="cuda")
+            flags = wd | (_lib.LSS_TILE_KERNELS if kernels == "tiles" else 0)
+            _lib.call("mmt_lss_splat_forward", B, N, D, fH, fW, C, nx, ny, nz, geom.cuda().data_ptr(), dcl.data_ptr(), ccl.data_ptr(),
+                      outp.data_ptr(), pos.data_ptr(), flags, torch.cuda.current_stream().cuda_stream)
+            got = pos.cpu().numpy()
+            kept_rows = ref_pos[..., 0] != -1
+            assert np.array_equal(got[kept_rows], ref_pos[kept_rows])
+            assert (got[~kept_rows] == (-1 if wd else -7)).all()          # dropped rows: written as -1 on request, else untouched
+            assert np.abs(outp.cpu().numpy() - ref).max() <= 1e-4
     if kernels == "column":      # what LSSFPN's "auto" looks at
         from mm_training_amd.ops.bev_geometry import column_mismatch_fraction
         frac = float(column_mismatch_fraction(geom.cuda(), vn))
