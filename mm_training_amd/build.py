@@ -44,12 +44,28 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _obj_path(src):
-    return os.path.join(CSRC, "build", os.path.basename(src)[:-4] + ".o")
+def _obj_dir(extra_flags=()):
+    """Objects of the regular build live in csrc/build; a build with extra flags (diagnostic variants such as
+    -DLSS_STAMPS) gets a directory of its own, named by a hash of the flags, so it can never be mistaken for -- or
+    overwrite -- the objects the product library is linked from."""
+    if not extra_flags:
+        return os.path.join(CSRC, "build")
+    import hashlib
+    tag = hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:10]
+    return os.path.join(CSRC, "build", "flags_" + tag)
 
 
-def _obj_stale(src, headers_mtime):
-    obj = _obj_path(src)
+def _obj_path(src, extra_flags=()):
+    return os.path.join(_obj_dir(extra_flags), os.path.basename(src)[:-4] + ".o")
+
+
+def variant_lib_path(extra_flags):
+    """Where build(extra_flags=...) writes its library (never LIB_PATH)."""
+    return os.path.join(_obj_dir(extra_flags), LIB_NAME)
+
+
+def _obj_stale(src, headers_mtime, extra_flags=()):
+    obj = _obj_path(src, extra_flags)
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
@@ -58,32 +74,36 @@ def _obj_stale(src, headers_mtime):
 
 def build(force=False, verbose=False, extra_flags=(), jobs=None):
     """Compile every HIP source (one object per file, in parallel, rebuilt only when the file or a
-    header changed) and link them into one shared library. Returns the .so path."""
-    if not force and not is_stale() and not extra_flags:
+    header changed) and link them into one shared library. Returns the .so path: LIB_PATH for the regular
+    build, variant_lib_path(extra_flags) for a build with extra flags (load it with MMT_HIP_LIB)."""
+    extra_flags = tuple(extra_flags)
+    out = variant_lib_path(extra_flags) if extra_flags else LIB_PATH
+    have_objs = all(os.path.exists(_obj_path(s, extra_flags)) for s in sources())
+    if not force and not extra_flags and not is_stale() and have_objs:
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     hipcc = find_hipcc()
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    os.makedirs(_obj_dir(extra_flags), exist_ok=True)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h")) + \
         [os.path.abspath(__file__)]
     hm = max(os.path.getmtime(h) for h in hdrs)
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
-    todo = [src for src in sources() if force or extra_flags or _obj_stale(src, hm)]
+    todo = [src for src in sources() if force or _obj_stale(src, hm, extra_flags)]
 
     def compile_one(src):
-        cmd = [hipcc] + cflags + ["-c", src, "-o", _obj_path(src)]
+        cmd = [hipcc] + cflags + ["-c", src, "-o", _obj_path(src, extra_flags)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_one, todo))
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + [_obj_path(s) for s in sources()] + ["-o", LIB_PATH + ".tmp"]
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + [_obj_path(s, extra_flags) for s in sources()] + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -35,17 +35,21 @@ def grid_size(point_cloud_range, voxel_size):
 _TABLES = {}
 
 
-def _voxel_table(dev, elems):
+def _voxel_table(dev, elems, tables=None):
+    """`tables`: the dict that owns the persistent tables -- a LidarEncoder passes its own, so that the table its scatter
+    reads (pillar_scatter_from_table) can only hold that encoder's last voxelization; the module-level dict serves
+    the function-style callers, which never read a table back later."""
     if torch.cuda.is_current_stream_capturing():
         # inside a hipGraph capture the table belongs to the graph: allocated (and zero-filled) by the graph itself
         return torch.zeros((int(elems),), dtype=torch.int32, device=dev)
+    tables = _TABLES if tables is None else tables
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, int(elems))
-    t = _TABLES.get(key)
+    t = tables.get(key)
     if t is None:
-        if len(_TABLES) >= 16:
-            _TABLES.pop(next(iter(_TABLES)))
+        if len(tables) >= 16:
+            tables.pop(next(iter(tables)))
         t = torch.zeros((int(elems),), dtype=torch.int32, device=dev)
-        _TABLES[key] = t
+        tables[key] = t
     return t
 
 
@@ -69,7 +73,7 @@ def _batch_points(points_list):
 
 
 def hard_voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
-                             num_features, materialize_voxels=True, return_table=False):
+                             num_features, materialize_voxels=True, return_table=False, tables=None):
     """Batched hard voxelization fused with the HardSimpleVFE mean (mmt_hard_voxelize_mean: three kernels,
     no clearing pass, no host sync).  Fixed-capacity layout: returns (voxels | None, num_points, coors,
     voxel_count, mean [B*max_voxels, num_features]); unused rows have coors = -1, num_points = 0, mean = 0."""
@@ -85,7 +89,7 @@ def hard_voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num
     voxel_count = torch.empty((B,), dtype=torch.int32, device=dev)
     mean = torch.empty((B * V, int(num_features)), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        table = _voxel_table(dev, _lib.lib().mmt_voxelize_table_elems(B, grid_c))
+        table = _voxel_table(dev, _lib.lib().mmt_voxelize_table_elems(B, grid_c), tables)
         scratch = torch.empty((_lib.lib().mmt_voxelize_scratch_elems(B, N),), dtype=torch.int32, device=dev)
         _lib.timed_call("voxelize", "mmt_hard_voxelize_mean", B, N, F, points.data_ptr(), offsets.data_ptr(),
                         _lib.float3(voxel_size), _lib.float3(point_cloud_range[:3]), grid_c, T, V, int(num_features),
@@ -268,6 +272,7 @@ class LidarEncoder(nn.Module):
             # must not influence live rows (forward_bev runs without compaction)
             self.pillar_mlp = nn.Sequential(nn.Linear(self.num_features, out_c), nn.ReLU(inplace=True))
             self.in_channels = out_c
+        self._tables = {}        # this encoder's persistent voxelizer tables (see _voxel_table)
 
     @torch.no_grad()
     def voxelize(self, points):
@@ -296,7 +301,7 @@ class LidarEncoder(nn.Module):
             pts = [p.float() for p in points]
             _, _, coors, _, feats, table = hard_voxelize_mean_batch(
                 pts, self.voxel_size, self.point_cloud_range, self.max_num_points, self.max_voxels,
-                self.num_features, materialize_voxels=False, return_table=True)
+                self.num_features, materialize_voxels=False, return_table=True, tables=self._tables)
         if self.pillar_mlp is not None:
             feats = self.pillar_mlp(feats)
         if direct and sum(int(p.shape[0]) for p in points) < (1 << 23):

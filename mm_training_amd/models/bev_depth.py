@@ -43,10 +43,12 @@ class BEVDepth(nn.Module):
 
     def __init__(self, backbone_conf, head_conf, is_train_depth=False, use_cam=True):
         super().__init__()
-        self.is_train_depth = is_train_depth
-        self.head = BEVDepthHead(**head_conf)
+        # registration order = models/bev_depth.py:26-29 (backbone, then head): `parameters()` order is what an optimizer
+        # state dict of a reference checkpoint is keyed by (tests/test_host_logic.py::test_parameter_registration_order)
         if use_cam:
             self.backbone = LSSFPN(**backbone_conf)
+        self.head = BEVDepthHead(**head_conf)
+        self.is_train_depth = is_train_depth
 
     def bev_augment_image(self, x, bda_mat):
         """models/bev_depth.py:69-84: rotate/flip the camera BEV by the BEV-aug matrix about

@@ -56,3 +56,40 @@ def test_bench_algorithmic_byte_formulas():
     assert l2f == f + K * 4 * C and l2b == b_ + K * 4 * C
     f16, b16, _, _ = bench.lift_splat_bytes(BP, K, C, B, 24 * 704, ny, nx, feat_bytes=2)
     assert f16 < f and b16 < b_
+
+
+def test_parameter_registration_order():
+    """`parameters()` order is what an optimizer state dict of a reference checkpoint is keyed by.  Recorded from the
+    reference's registration order (source order of the assignments): models/bev_depth.py:26-29 (backbone, head),
+    :153-161 (lidar_encoder, bev_fuse); layers/backbones/lss_fpn.py:293-295 (img_backbone, img_neck, depth_net),
+    :164-184 (reduce_conv, context_conv, depth_se, context_se, depth_conv), :53-90 (aspp1..4, global_avg_pool, conv1, bn1)."""
+    from mm_training_amd.dp.configs import make_config
+    from mm_training_amd.models.bev_depth import BEVDepth, BEVDepthLiDAR
+    cfg = make_config("tiny")
+
+    def first_seen(names, depth):
+        out = []
+        for n in names:
+            p = ".".join(n.split(".")[:depth])
+            if p not in out:
+                out.append(p)
+        return out
+
+    cam = BEVDepth(cfg["backbone_conf"], cfg["head_conf"], is_train_depth=True)
+    names = [n for n, _ in cam.named_parameters()]
+    assert first_seen(names, 1) == ["backbone", "head"]
+    assert first_seen([n for n in names if n.startswith("backbone.")], 2) == \
+        ["backbone.img_backbone", "backbone.img_neck", "backbone.depth_net"]
+    dn = [n[len("backbone.depth_net."):] for n in names if n.startswith("backbone.depth_net.")]
+    assert first_seen(dn, 1) == ["reduce_conv", "context_conv", "context_se", "depth_conv"]
+    aspp = [n[len("depth_conv.3."):] for n in dn if n.startswith("depth_conv.3.")]
+    assert first_seen(aspp, 1) == ["aspp1", "aspp2", "aspp3", "aspp4", "global_avg_pool", "conv1", "bn1"]
+    assert [n for n, _ in cam.named_buffers(recurse=True) if n.startswith("backbone.") and n.count(".") == 1][:4] == \
+        ["backbone.voxel_size", "backbone.voxel_coord", "backbone.voxel_num", "backbone.frustum"]
+
+    fusion = BEVDepthLiDAR(cfg["backbone_conf"], cfg["head_conf"], cfg["lidar_conf"],
+                           fuse_layer_in_channels=cfg["fuse_layer_in_channels"])
+    top = first_seen([n for n, _ in fusion.named_parameters()], 1)
+    assert top[:2] == ["backbone", "head"] and top[-1] == "bev_fuse"        # the pillar encoder has no parameters
+    assert [n for n, _ in fusion.named_children()] == ["backbone", "head", "lidar_encoder", "bev_fuse"]
+    assert [n for n, _ in fusion.bev_fuse.named_parameters()] == ["conv_3.weight", "conv_3.bias", "conv_1.weight", "conv_1.bias"]
