@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide ("L2 (per XCD)")
+ATOMIC_PEAK_GBS = 1300.0  # chip-wide memory-side fp32 atomic-add rate, same guide ("Global float atomics": 1.26-1.36 TB/s of added bytes)
 
 WORKLOADS = {
     "cfg2": "BASELINE configs[1]: camera-only BEVDepth (ResNet-50, 6 cams 256x704, D=112, C=80, BEV 128x128) "
@@ -81,6 +82,12 @@ def parse(argv=None):
     ap.add_argument("--fused-lift-splat", action="store_true", help="(default since round 2; accepted for old command lines)")
     ap.add_argument("--lift-splat-backward", default="auto", choices=["auto", "ray", "column"],
                     help="backward kernel of the fused camera path (auto: column on a level rig, decided once from the geometry)")
+    ap.add_argument("--geom-form", action="store_true",
+                    help="fused camera path: write a geom tensor with mmt_frustum_geometry every step and feed the geom form of the "
+                         "kernels (the round-2 path) instead of the camera form, whose kernels compute the cells themselves")
+    ap.add_argument("--calibration-ids", action="store_true",
+                    help="give every synthetic batch a mats_dict['calibration_id'] (a loader that knows its rig): camera matrices, "
+                         "the geometry's column summary and the backward-kernel choice are then cached per calibration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
     ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag (hotpath mode)")
@@ -238,15 +245,18 @@ def algorithmic_bytes(BP, K, C, B, ny, nx, feat_bytes=4):
     return fwd, bwd
 
 
-def lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, feat_bytes=4, pos_memo=False):
+def lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, feat_bytes=4, pos_memo=False, camera_form=False):
     """Fused lift-splat (row f1): the [BP, C] feature matrix does not exist.
     forward  12BP geom (+ 12BP pos_memo, first-generation kernels only) + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx BEV
     backward 12BP geom (or pos_memo) + fb*BP depth + fb*C*BN*HW context + 4*C*B*ny*nx grad_out + fb*BP grad_depth
              + fb*C*BN*HW grad_context
     The frustum-tile kernels redo the kept test from geom, so no pos_memo is written or read.
+    camera_form: no geom tensor at all -- the kernels compute the cells from B*N matrices; what replaces the 12BP is the
+    column summary, 8 bytes per block of 16 points (BP / 2), written by the forward and read by the backward.
     The point-wise L2-side figure adds what a point-wise gather moves: one C-row (context / grad_out) per kept point."""
-    fwd = 12 * BP + (12 * BP if pos_memo else 0) + feat_bytes * BP + feat_bytes * C * BN_HW + 4 * C * B * ny * nx
-    bwd = 12 * BP + 2 * feat_bytes * BP + 2 * feat_bytes * C * BN_HW + 4 * C * B * ny * nx
+    gbytes = BP // 2 if camera_form else 12 * BP
+    fwd = gbytes + (12 * BP if pos_memo else 0) + feat_bytes * BP + feat_bytes * C * BN_HW + 4 * C * B * ny * nx
+    bwd = gbytes + 2 * feat_bytes * BP + 2 * feat_bytes * C * BN_HW + 4 * C * B * ny * nx
     l2_fwd = fwd + K * (feat_bytes * C)
     l2_bwd = bwd + K * (4 * C)
     return fwd, bwd, l2_fwd, l2_bwd
@@ -265,12 +275,14 @@ def pmc_traffic(config, kernels):
     """HBM bytes per launch from a committed rocprofv3 --pmc summary OF THIS CONFIGURATION (separate FETCH_SIZE /
     WRITE_SIZE passes with the gfx950 correction; tools/collect_profiles.sh writes profiles/r02_pmc_<config>.json).
     PMC collection cannot run inside this process; None when the shape has no summary."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_{config}.json")
-    try:
-        k = json.load(open(path))["kernels"]
-        return float(sum(k[name]["traffic_bytes"] for name in kernels))
-    except Exception:
-        return None
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{config}.json")
+        try:
+            k = json.load(open(path))["kernels"]
+            return float(sum(k[name]["traffic_bytes"] for name in kernels))
+        except Exception:
+            continue
+    return None
 
 
 def roofline_entry(kernel, nbytes, ms, traffic=None, l2_bytes=None, note=None):
@@ -542,12 +554,15 @@ def train_main(args, rank, local_rank, world):
             ts.model.backbone.fused_lift_splat = False
         fused = bool(ts.model.backbone.fused_lift_splat)
         ts.model.backbone.lift_splat_backward = args.lift_splat_backward
+        if args.geom_form:
+            ts.model.backbone.camera_form = False
     B = cfg["batch_size"]
     # a small pool of distinct pre-generated batches resident in HBM (input is never the bottleneck)
     batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i) for i in range(2)]
-    if args.cached_plan:
-        # each synthetic batch has its own (jittered) rig; its id lets LSSFPN reuse the
-        # sort of the points by BEV cell instead of redoing geometry + sort every step
+    if args.cached_plan or args.calibration_ids:
+        # each synthetic batch has its own (jittered) rig; its id lets LSSFPN reuse what depends on the
+        # calibration alone (unfused path: the sort of the points by BEV cell; fused path: the camera matrices, the
+        # geometry's column summary and the choice of the backward kernel)
         for i, b in enumerate(batches):
             b[1]["calibration_id"] = ("synthetic", 1000 * rank + i)
     for i in range(args.warmup):
@@ -592,26 +607,46 @@ def train_main(args, rank, local_rank, world):
         res["config"]["kept_fraction"] = K / BP
         if fused and timing.get("lift_splat_forward"):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["lift_splat_forward"]), _lib.mean_ms(timing["lift_splat_backward"])
-            fbytes, bbytes, l2f, l2b = lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, fb)
-            note = ("fused lift + voxel_pooling (SURVEY 8/f1), ray walks: the [B*P, C] feature matrix is never materialised, so the "
-                    "HBM-side algorithmic bytes are ~5x below the drop-in op's.  The forward is bound by the memory-side fp32 atomic "
-                    "units (about 1.2 TB/s of added bytes in whole 64-byte segments, tools/ubench/atomic_rows.hip: ~25 MB of BEV rows "
-                    "per launch at this shape); the backward (matrix-core column kernel on a level rig, else a per-pixel ray walk) by "
-                    "its HBM-rate load phase followed by L2-latency-bound tile staging, neither by sustained HBM bandwidth -- l2_side prices the "
-                    "rows a point-wise gather moves against the aggregate L2 bandwidth; the drop-in op's HBM roofline is "
-                    "roofline_voxel_pooling[_backward]")
+            from mm_training_amd.ops.bev_geometry import last_kernel_family
+            fam_f, fam_b = last_kernel_family(), last_kernel_family(backward=True)
+            camera = fam_f.endswith("+camera")
+            fbytes, bbytes, l2f, l2b = lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, fb, camera_form=camera)
+            note = ("fused get_geometry + quantise + lift + voxel_pooling (SURVEY 8 rows f1 + f3): neither the [B*P, C] feature matrix nor "
+                    "(camera form) the geom tensor exists -- the kernels compute every point's cell from the B*N camera matrices with the "
+                    "arithmetic of mmt_frustum_geometry, so the HBM-side algorithmic bytes are ~13x below the drop-in op's (that also lowers "
+                    "this fraction: fewer bytes for the same atomic-bound time).  The forward is bound by the memory-side fp32 atomic units "
+                    "(about 1.25 TB/s of added bytes in whole 64-byte segments, tools/ubench/atomic_rows.hip: ~25 MB of BEV rows per launch at "
+                    "this shape = `atomic_side`); its zero-fill of the BEV map is part of the timed sequence (MMT_LSS_ZERO_OUTPUT).  The "
+                    "backward (matrix-core column kernel on a level rig, else a per-pixel ray walk) by its latency-bound load phase followed by "
+                    "tile staging, neither by sustained HBM bandwidth -- l2_side prices the rows a point-wise gather moves against the "
+                    "aggregate L2 bandwidth; the drop-in op's HBM roofline is roofline_voxel_pooling[_backward]")
             sfx = "_bf16" if dtype == "bf16" else ""
-            tiles = os.environ.get("MMT_LIFT_SPLAT_TILES", "0") == "1"      # A/B switch: the second-generation frustum-tile kernels
-            kfwd, kbwd = ("lss_splat_fwd_tile", "lss_splat_bwd_tile") if tiles else ("lss_ray_fwd", "lss_ray_bwd")
-            column = (not tiles) and any(lss._column_backward_choice.values()) if lss.lift_splat_backward == "auto" else lss.lift_splat_backward == "column"
-            if column and not tiles:
-                kbwd = "lss_col_bwd"
-            res["config"]["lift_splat_kernels"] = "frustum tiles" if tiles else ("ray-walk forward, " + ("matrix-core column backward (chosen from the geometry: "
-                                                  "no pixel leaves its column's cell)" if column else "ray-walk backward"))
-            res["roofline"] = roofline_entry(f"{kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
-                                             pmc_traffic(args.config, ("lift_splat_forward_tile" if tiles else "lift_splat_forward",)), l2f, note)
+            tiles = fam_f.startswith("tile")
+            kfwd = {"ray": "lss_ray_fwd", "tile": "lss_splat_fwd_tile"}.get(fam_f.split("+")[0], fam_f)
+            kbwd = {"ray": "lss_ray_bwd", "tile": "lss_splat_bwd_tile", "column": "lss_col_bwd"}.get(fam_b.split("+")[0], fam_b)
+            column = fam_b.startswith("column")
+            adaptive = lss._column_adaptive
+            res["config"]["lift_splat_kernels"] = {
+                "forward": fam_f, "backward": fam_b, "geometry": "computed in the kernels (camera form)" if camera else "geom tensor (mmt_frustum_geometry every step)",
+                "backward_choice": lss.lift_splat_backward if lss.lift_splat_backward != "auto" else (
+                    "auto: per calibration id, from the geometry" if args.calibration_ids else
+                    "auto: from the column kernel's own counters, read back lazily (share of kept points outside their column's cell: %s)"
+                    % (None if adaptive is None else adaptive["share"]))}
+            key_f = "lift_splat_forward_tile" if tiles else ("lift_splat_forward_camera" if camera else "lift_splat_forward")
+            key_b = "lift_splat_backward_tile" if tiles else (("lift_splat_backward_column" if column else "lift_splat_backward") + ("_camera" if camera else ""))
+            res["roofline"] = roofline_entry(f"{kfwd}{sfx} (+ lss_zero_fill; fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
+                                             pmc_traffic(args.config, (key_f,)), l2f, note)
+            atomic_bytes = None
+            try:
+                atomic_bytes = float(json.load(open(os.path.join(ROOT, "profiles", f"r03_pmc_{args.config}.json")))["kernels"][key_f]["atomic_bytes"])
+            except Exception:
+                pass
+            if atomic_bytes:
+                ab = atomic_bytes / (fwd_ms * 1e-3) / 1e9
+                res["roofline"]["atomic_side"] = {"bytes": atomic_bytes, "achieved": ab, "peak": ATOMIC_PEAK_GBS, "unit": "GB/s", "frac": ab / ATOMIC_PEAK_GBS,
+                                                  "note": "TCC_EA0_ATOMIC x 64 B per launch (PMC pass) against the chip-wide memory-side fp32 atomic rate"}
             res["roofline_backward"] = roofline_entry(f"{kbwd}{sfx} (fused lift-splat backward = the step's voxel_pooling backward)", bbytes, bwd_ms,
-                                                      pmc_traffic(args.config, ("lift_splat_backward_tile" if tiles else ("lift_splat_backward_column" if column else "lift_splat_backward"),)), l2b)
+                                                      pmc_traffic(args.config, (key_b,)), l2b)
         elif timing.get("forward"):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["forward"]), _lib.mean_ms(timing["backward"])
             fbytes, bbytes = algorithmic_bytes(BP, K, C, B, ny, nx, fb)

@@ -33,7 +33,7 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 5
+#define MMT_ABI_VERSION 6
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -289,6 +289,82 @@ int mmt_lss_splat_backward_bf16(int B, int N, int D, int fH, int fW, int C, int 
                                 const uint16_t *context, const float *grad_output, int64_t stride_b,
                                 int64_t stride_c, int64_t stride_y, int64_t stride_x, uint16_t *grad_depth,
                                 float *grad_context, int flags, void *stream);
+
+#define MMT_LSS_ZERO_OUTPUT 0x800 /* mmt_lss_splat_forward*: the entry point zero-fills output_features itself, in front of the
+                                     forward kernel, with write-through stores that leave no line in the XCD L2s (the
+                                     memory-side atomics that follow then do not wait for freshly written lines to be evicted,
+                                     which a caller-side memset right before the launch costs them).  The caller hands over an
+                                     uninitialised map; the fill is part of the call's timed kernel sequence. */
+
+/* CAMERA FORM of the fused lift-splat (ABI 6; SURVEY section 8 rows f1 + f3): what replaces layers/backbones/lss_fpn.py:328-361
+ * (get_geometry), :461-462 (quantise) and :441-464 (lift, voxel_pooling) in one kernel each way.  The geom tensor of the
+ * entry points above is a pure function of B*N camera matrices and the frustum, so these kernels compute the voxel index of
+ * a point themselves:
+ *   p = (u[w]*d[k], v[h]*d[k], d[k], 1);  xyz = (combine[bn] @ p)[:3];  index = ((xyz - (voxel_coord - voxel_size/2)) / voxel_size).int()
+ * with exactly the arithmetic of mmt_frustum_geometry (un-contracted k-ordered fp32 products and sums, correctly rounded
+ * divide, truncation; csrc/mmt_camera.h) -- cells are bit-identical to mmt_frustum_geometry + the geom form on the same
+ * inputs (tests/test_geometry_gpu.py::test_camera_form_*).  No geom tensor is written, read or kept: 12 bytes per point less
+ * in each direction and no geometry kernel in the step.
+ *   combine    device fp32 [B*N, 16]: sensor2ego @ inverse(intrin), row-major 4x4 (lss_fpn.py:339-352; rows 0..2 are used)
+ *   frustum_u  device fp32 [fW] = frustum[0, 0, :, 0] (lss_fpn.py:318-320), frustum_v [fH] = frustum[0, :, 0, 1] (:321-323),
+ *   frustum_d  device fp32 [D]  = frustum[:, 0, 0, 2] (:314-316); the frustum of create_frustum is the outer product of these
+ *              three axes with a constant 1 in its 4th component -- a caller with any other frustum uses the geom form
+ *   voxel_coord_host / voxel_size_host: 3 host floats each, as for mmt_quantize_geometry
+ * Point order of depth / grad_depth / pos_memo as in the geom form (MMT_LSS_PIXEL_MAJOR or the reference's frustum order).
+ * Kernels: the ray walks and the matrix-core column backward (MMT_LSS_COLUMN_BACKWARD); C in {64, 80, 128}; shapes those
+ * kernels do not take (and MMT_LSS_TILE_KERNELS) return MMT_ERR_BAD_SHAPE / MMT_ERR_BAD_FLAG -- use the geom form there.
+ * column_stats (backward, nullable): device uint64[2 * MMT_LSS_STATS_SLOTS], ACCUMULATED INTO by the column kernel: pair s
+ * (s = workgroup index mod MMT_LSS_STATS_SLOTS, so that no address is shared by more than a few dozen workgroups) receives
+ * [2s] += kept points whose cell differs from their column's (handled one by one), [2s + 1] += kept points, counted over a
+ * pseudo-random 1-in-8 SAMPLE of the kernel's workgroups (workgroup index * 0x9E3779B1 >> 29 == 0); the ratio of the sums
+ * over s estimates the share of points the column kernel could not take in its GEMMs.  A caller choosing between the column kernel and the ray walk reads them back lazily (no synchronisation in
+ * the step); never cleared by the library. */
+#define MMT_LSS_STATS_SLOTS 64
+/* column_summary (nullable; device int32 [B*N, ceil(fH/16), fW, D, 2], 8-byte aligned): what the geometry of a block of 16
+ * image rows of one column at one depth bin comes to -- for fixed (camera, column, bin) every coordinate is a monotone
+ * function of the image row, so a block whose first and last row share their (x, y) cell shares it throughout, and its kept
+ * rows are those whose z index is in range: [0] = (y << 16 | x) of that cell or -1 (outside the grid), [1] = bit i: row i's z
+ * index in range, bit 16: the block does share one cell.  8 bytes per block = 0.5 byte per point (a geom tensor: 12).
+ *   forward, flags without MMT_LSS_SUMMARY_CACHED: the kernel computes the geometry and WRITES the summary on the way;
+ *   forward with MMT_LSS_SUMMARY_CACHED: the summary was written by an earlier call with the SAME combine / frustum / grid
+ *            (an unchanged calibration): the kernel READS it instead of computing;
+ *   backward: READ when given (the forward's), otherwise the geometry is computed again.
+ * Blocks without bit 16 (a camera that is not level: some column straddles a cell border) are evaluated row by row from the
+ * matrices by whichever kernel meets them, so combine / frustum_* are always required.  Needs nx, ny < 32768. */
+#define MMT_LSS_SUMMARY_CACHED 0x1000
+int mmt_lss_splat_forward_cam(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                              const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,
+                              const float *voxel_coord_host, const float *voxel_size_host, const float *depth,
+                              const float *context, float *output_features, int32_t *pos_memo, int32_t *column_summary,
+                              int flags, void *stream);
+int mmt_lss_splat_forward_cam_bf16(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                   const float *combine, const float *frustum_u, const float *frustum_v,
+                                   const float *frustum_d, const float *voxel_coord_host, const float *voxel_size_host,
+                                   const uint16_t *depth, const uint16_t *context, float *output_features,
+                                   int32_t *pos_memo, int32_t *column_summary, int flags, void *stream);
+int mmt_lss_splat_backward_cam(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                               const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,
+                               const float *voxel_coord_host, const float *voxel_size_host, const float *depth,
+                               const float *context, const float *grad_output, int64_t stride_b, int64_t stride_c,
+                               int64_t stride_y, int64_t stride_x, float *grad_depth, float *grad_context,
+                               const int32_t *column_summary, uint64_t *column_stats, int flags, void *stream);
+int mmt_lss_splat_backward_cam_bf16(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
+                                    int num_voxel_z, const float *combine, const float *frustum_u, const float *frustum_v,
+                                    const float *frustum_d, const float *voxel_coord_host, const float *voxel_size_host,
+                                    const uint16_t *depth, const uint16_t *context, const float *grad_output,
+                                    int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                                    uint16_t *grad_depth, float *grad_context, const int32_t *column_summary,
+                                    uint64_t *column_stats, int flags, void *stream);
+/* Which kernel family the process's last mmt_lss_splat_forward* (backward = 0) / mmt_lss_splat_backward* (backward = 1)
+ * call launched (process-wide, not per thread: an autograd backward runs on the engine's thread): MMT_LSS_FAMILY_* below, ORed with MMT_LSS_FAMILY_CAMERA for the camera form; 0 before the first call.  The
+ * entry points pick a family from the shape (LDS budgets, channel count), so a fallback is visible here. */
+#define MMT_LSS_FAMILY_RAY 1
+#define MMT_LSS_FAMILY_TILE 2
+#define MMT_LSS_FAMILY_COLUMN 3
+#define MMT_LSS_FAMILY_CAMERA 0x10
+int mmt_lss_last_kernel_family(int backward);
+/* 1 when mmt_lss_splat_forward_cam AND mmt_lss_splat_backward_cam both take this shape, 0 otherwise (use the geom form). */
+int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW, int C);
 
 /* ------------------------------------------------- bf16 feature storage
  * BASELINE configs[4] names bf16.  The reference has no behaviour for it -- its extension takes data_ptr<float>()

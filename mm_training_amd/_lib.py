@@ -36,6 +36,12 @@ SIGNATURES = {
     "mmt_lss_splat_forward_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_lss_splat_backward": (_c_int, [_c_int] * 9 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_int, _c_ptr]),
     "mmt_lss_splat_backward_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_int, _c_ptr]),
+    "mmt_lss_splat_forward_cam": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_int, _c_ptr]),
+    "mmt_lss_splat_forward_cam_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_int, _c_ptr]),
+    "mmt_lss_splat_backward_cam": (_c_int, [_c_int] * 9 + [_c_ptr] * 9 + [_c_i64] * 4 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
+    "mmt_lss_splat_backward_cam_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 9 + [_c_i64] * 4 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
+    "mmt_lss_last_kernel_family": (_c_int, [_c_int]),
+    "mmt_lss_camera_form_supported": (_c_int, [_c_int] * 6),
     "mmt_quantize_geometry": (_c_int, [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     "mmt_frustum_geometry": (_c_int, [_c_int, _c_i64] + [_c_ptr] * 6 + [_c_ptr]),
     "mmt_lift_features": (_c_int, [_c_int] * 4 + [_c_ptr] * 3 + [_c_ptr]),
@@ -81,6 +87,10 @@ VP_WRITE_DROPPED = 0x10
 LSS_PIXEL_MAJOR = 0x100       # mmt_lss_splat_*: geom / depth / grad_depth in [B*N, fH, fW, D(, 3)] order
 LSS_TILE_KERNELS = 0x200      # mmt_lss_splat_*: frustum-tile kernels instead of the ray walks
 LSS_COLUMN_BACKWARD = 0x400   # mmt_lss_splat_backward*: matrix-core column kernel (level rigs)
+LSS_ZERO_OUTPUT = 0x800       # mmt_lss_splat_forward*: the call zero-fills the BEV map itself (write-through stores)
+LSS_SUMMARY_CACHED = 0x1000   # mmt_lss_splat_forward_cam*: read the column summary instead of computing the geometry
+LSS_STATS_SLOTS = 64          # column_stats of mmt_lss_splat_backward_cam*: int64 [2 * LSS_STATS_SLOTS], (mismatching, kept) pairs
+LSS_FAMILY = {0: "none", 1: "ray", 2: "tile", 3: "column"}     # mmt_lss_last_kernel_family() & 0xF; | 0x10 = camera form
 
 _lib = None
 

@@ -14,7 +14,7 @@
 // the bin.  Pixels whose own cell differs (a camera that is not level, arbitrary geometry) are MISMATCHES: they are left out
 // of the GEMMs (depth 0, no grad_depth store) and handled one by one afterwards -- correct for any geometry, fast for a
 // frustum.  A workgroup = (camera, column, block of 16 image rows), 2 waves; a wave owns every other batch of 16 bins.
-#include "mmt_common.h"
+#include "mmt_camera.h"
 
 namespace {
 
@@ -26,7 +26,11 @@ struct ColArgs {
     int BN, N, D, fH, fW, C, nx, ny, nz;
     int pm, rblocks;
     int vec;                      // grad_depth may leave as 16-byte (fp32) / 8-byte (bf16) vectors: pixel-major, D % 4 == 0, aligned
-    const int32_t *geom;
+    const int32_t *geom;          // geom form; camera form (template CAM): the cell comes from the matrix (mmt_camera.h)
+    const float *combine, *fu, *fv, *fd;
+    mmt::CamGrid q;
+    const int2 *summary;          // camera form, nullable: the forward's column summary (mmt_camera.h CamGeom::summary)
+    unsigned long long *stats;    // nullable: [0] += points handled by the mismatch pass, [1] += kept points (cumulative)
     const void *depth;
     const void *context;
     const float *grad_out;
@@ -57,7 +61,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 // LDS (dynamic): dep [16][Dp] fp32 | moff [16][Dp] int | ref [Dp] int | flag [16][Dp] bytes | G tiles of the 2 waves [2][16][CP] fp32
 // (CP = C + 4; after the products: the grad_context total and the lists / partial sums of the mismatch pass)
 // NT = C / 16 (N tiles of the grad_context product); C / 4 <= 64 lanes move one row.
-template <typename FT, int NT>
+template <typename FT, int NT, bool CAM>
 __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
     extern __shared__ __align__(16) unsigned char col_lds[];
     constexpr int C = 16 * NT, C4 = C / 4, CP = C + 4;
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
     float *gw0 = reinterpret_cast<float *>(flag + 16 * Dp);            // G tiles [16][CP], one per wave
     float *gw1 = gw0 + 16 * CP;
     float *gw = wave == 0 ? gw0 : gw1;
-    __shared__ int nmis;
-    if (tid == 0) nmis = 0;
+    __shared__ int nmis, nkept;
+    if (tid == 0) { nmis = 0; nkept = 0; }
     __syncthreads();
 #ifdef LSS_STAMPS   // diagnostic build: grad_context receives 4 s_memtime stamps per workgroup instead of its rows
     unsigned long long *cstamps = reinterpret_cast<unsigned long long *>(a.grad_context) + (int64_t)blockIdx.x * 4;
@@ -110,6 +114,17 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
     const int64_t tcol = col_point(a, bn, row0, col, 0);               // point (row0, col, bin 0); rows / bins are strides away
     const int64_t rstep = a.pm ? (int64_t)a.fW * D : a.fW;
     const int64_t dstep = a.pm ? 1 : (int64_t)HW;
+    float cm[12], cv[16];
+    float cu = 0.f;
+    bool cv_sorted = false;
+    if constexpr (CAM) {       // camera form: the column's cells from the matrix (mmt_camera.h: end-row shortcut, exact range thresholds)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cm[k] = a.combine[bn * 16 + k];
+        cu = a.fu[col];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cv[u] = a.fv[row0 + (u < nrow ? u : nrow - 1)];
+        cv_sorted = mmt_rows_sorted<16>(cv, nrow);
+    }
     for (int bin = tid; bin < Dp; bin += kColBlock) {
         int gx[16], gy[16], gz[16];
         float dv[16];
@@ -117,20 +132,50 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int64_t t = tb + (u < nrow ? u : 0) * rstep;
-            gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2];
+            if constexpr (!CAM) { gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2]; }
             dv[u] = ld_scalar<FT>(depth + t);
         }
         unsigned o[16];
         unsigned m = kOut;
+        if constexpr (CAM) {
+            const mmt_cam_column cc = mmt_cam_column_make(cm, cu, a.fd[bin < D ? bin : 0]);
+            bool uniform, in0;
+            int x0, y0;
+            unsigned zmask;
+            if (a.summary) {      // written by the forward: two dwords per bin instead of the geometry
+                const int2 sv = a.summary[(((int64_t)bn * a.rblocks + rb) * a.fW + col) * D + (bin < D ? bin : 0)];
+                in0 = sv.x >= 0; x0 = sv.x & 0xFFFF; y0 = sv.x >> 16;
+                zmask = (unsigned)sv.y & 0xFFFFu;
+                uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
+            } else {
+                zmask = mmt_cam_column_cells<16>(cc, cv, nrow, cv_sorted, a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
+            }
+            if (bin >= D) zmask = 0u;
+            if (uniform) {
+                const unsigned oc = in0 ? (unsigned)(((int)(b * a.sb) + y0 * (int)a.sy + x0 * (int)a.sx) * 4) : kOut;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            // in range <=> (unsigned)v < n for all three, one comparison each; no branches
-            const bool keep = (u < nrow) & (bin < D) & ((unsigned)gx[u] < (unsigned)a.nx) & ((unsigned)gy[u] < (unsigned)a.ny) & ((unsigned)gz[u] < (unsigned)a.nz);
-            o[u] = keep ? (unsigned)(((int)(b * a.sb) + gy[u] * (int)a.sy + gx[u] * (int)a.sx) * 4) : kOut;
-            m = o[u] < m ? o[u] : m;
+                for (int u = 0; u < 16; ++u) o[u] = ((zmask >> u) & 1u) ? oc : kOut;
+                m = zmask ? oc : kOut;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    int x, y;
+                    const bool in = mmt_cam_row_xy(cc, cv[u], a.q, a.nx, a.ny, x, y);
+                    o[u] = (in && ((zmask >> u) & 1u)) ? (unsigned)(((int)(b * a.sb) + y * (int)a.sy + x * (int)a.sx) * 4) : kOut;
+                    m = o[u] < m ? o[u] : m;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                // in range <=> (unsigned)v < n for all three, one comparison each; no branches
+                const bool keep = (u < nrow) & (bin < D) & ((unsigned)gx[u] < (unsigned)a.nx) & ((unsigned)gy[u] < (unsigned)a.ny) & ((unsigned)gz[u] < (unsigned)a.nz);
+                o[u] = keep ? (unsigned)(((int)(b * a.sb) + gy[u] * (int)a.sy + gx[u] * (int)a.sx) * 4) : kOut;
+                m = o[u] < m ? o[u] : m;
+            }
         }
         ref[bin] = (int)m;
-        int mis = 0;
+        int mis = 0, kept = 0;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int f = o[u] == kOut ? 0 : (o[u] == m ? 1 : 2);
@@ -138,8 +183,10 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
             dep[u * Dp + bin] = f ? dv[u] : 0.f;
             moff[u * Dp + bin] = (int)o[u];
             mis += f == 2;
+            kept += f != 0;
         }
         if (mis) atomicAdd(&nmis, mis);
+        if (a.stats && kept) atomicAdd(&nkept, kept);
     }
     __syncthreads();
     COL_STAMP(1);
@@ -341,26 +388,47 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
         }
     }
 #endif
+    // How well the geometry suits this kernel, for the caller's choice between it and the ray walk (read back lazily).  A
+    // pseudo-random 1-in-8 SAMPLE of the workgroups reports (same-address atomics retire one at a time at the memory side:
+    // with every workgroup reporting, the kernel's tail grew by 3 us inside the training step), spread over
+    // MMT_LSS_STATS_SLOTS pairs, as the last thing the workgroup does.
+    if (a.stats && tid == 0 && ((blockIdx.x * 0x9E3779B1u) >> 29) == 0u) {
+        unsigned long long *slot = a.stats + 2 * (blockIdx.x & (MMT_LSS_STATS_SLOTS - 1));
+        if (nmis) atomicAdd(slot, (unsigned long long)nmis);
+        if (nkept) atomicAdd(slot + 1, (unsigned long long)nkept);
+    }
 }
 
 template <typename FT>
-int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom, const FT *depth,
-           const FT *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx, int64_t span, FT *grad_depth,
-           float *grad_context, int pm, hipStream_t st) {
-    ColArgs a;
+int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom, const mmt::CamGeom *cam,
+           const FT *depth, const FT *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx, int64_t span, FT *grad_depth,
+           float *grad_context, unsigned long long *stats, int pm, hipStream_t st) {
+    ColArgs a = {};
     a.BN = B * N; a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
     a.pm = pm; a.rblocks = (fH + 15) / 16;
     a.vec = pm && (D % 4) == 0 && (((uintptr_t)grad_depth) & 15) == 0;
     a.geom = geom; a.depth = depth; a.context = context; a.grad_out = grad_out; a.sb = sb; a.sy = sy; a.sx = sx;
+    if (cam) {
+        a.combine = cam->combine; a.fu = cam->fu; a.fv = cam->fv; a.fd = cam->fd; a.q = cam->q;
+        a.summary = reinterpret_cast<const int2 *>(cam->summary);
+    }
+    a.stats = stats;
     a.span_bytes = (int)(span * 4);
     a.grad_depth = grad_depth; a.grad_context = grad_context;
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
     const size_t lds = (size_t)16 * Dp * 4 * 2 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
     const int64_t grid = 8ll * ((a.BN + 7) / 8) * fW * a.rblocks;
     mmt::TimedSeq seq;
-    if (C == 80) seq.launch(true, lss_col_bwd<FT, 5>, dim3((unsigned)grid), dim3(kColBlock), lds, st, a);
-    else if (C == 64) seq.launch(true, lss_col_bwd<FT, 4>, dim3((unsigned)grid), dim3(kColBlock), lds, st, a);
-    else seq.launch(true, lss_col_bwd<FT, 8>, dim3((unsigned)grid), dim3(kColBlock), lds, st, a);
+    const dim3 g((unsigned)grid), blk(kColBlock);
+    if (cam) {
+        if (C == 80) seq.launch(true, lss_col_bwd<FT, 5, true>, g, blk, lds, st, a);
+        else if (C == 64) seq.launch(true, lss_col_bwd<FT, 4, true>, g, blk, lds, st, a);
+        else seq.launch(true, lss_col_bwd<FT, 8, true>, g, blk, lds, st, a);
+    } else {
+        if (C == 80) seq.launch(true, lss_col_bwd<FT, 5, false>, g, blk, lds, st, a);
+        else if (C == 64) seq.launch(true, lss_col_bwd<FT, 4, false>, g, blk, lds, st, a);
+        else seq.launch(true, lss_col_bwd<FT, 8, false>, g, blk, lds, st, a);
+    }
     return mmt::check_launch(what);
 }
 
@@ -377,14 +445,14 @@ bool lss_col_backward_fits(int D, int fH, int fW, int C, int64_t span, int64_t g
     return (C == 64 || C == 80 || C == 128) && lds <= 64 * 1024 && span * 4 < (1ll << 30) && grid_units < (1ll << 28);
 }
 int lss_col_backward_f32(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
-                         const float *depth, const float *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx,
-                         int64_t span, float *grad_depth, float *grad_context, int pm, hipStream_t st) {
-    return launch<float>(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+                         const CamGeom *cam, const float *depth, const float *context, const float *grad_out, int64_t sb, int64_t sy,
+                         int64_t sx, int64_t span, float *grad_depth, float *grad_context, unsigned long long *stats, int pm, hipStream_t st) {
+    return launch<float>(what, B, N, D, fH, fW, C, nx, ny, nz, geom, cam, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, stats, pm, st);
 }
 int lss_col_backward_bf16(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
-                          const bf16_t *depth, const bf16_t *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx,
-                          int64_t span, bf16_t *grad_depth, float *grad_context, int pm, hipStream_t st) {
-    return launch<bf16_t>(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+                          const CamGeom *cam, const bf16_t *depth, const bf16_t *context, const float *grad_out, int64_t sb, int64_t sy,
+                          int64_t sx, int64_t span, bf16_t *grad_depth, float *grad_context, unsigned long long *stats, int pm, hipStream_t st) {
+    return launch<bf16_t>(what, B, N, D, fH, fW, C, nx, ny, nz, geom, cam, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, stats, pm, st);
 }
 
 }  // namespace mmt

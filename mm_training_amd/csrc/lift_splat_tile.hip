@@ -19,7 +19,7 @@
 //
 // Workgroups of one camera are dealt to the same XCD (blockIdx & 7), so the geom / depth lines shared by neighbouring
 // columns and the camera's context rows are fetched into one L2 -- placement affects speed only.
-#include "mmt_common.h"
+#include "mmt_camera.h"
 
 namespace {
 
@@ -481,7 +481,11 @@ struct RayArgs {
     int pm, write_dropped;
     int dsplit, dspan, kd;         // forward: depth slabs per ray, bins per slab, bins per lane group
     int wpc;                       // backward: workgroups per camera
-    const int32_t *geom;
+    const int32_t *geom;           // geom form: int32 voxel indices per point; camera form (template CAM): unused
+    const float *combine, *fu, *fv, *fd;   // camera form: [B*N, 16] matrices and the frustum's three axes (mmt_camera.h)
+    mmt::CamGrid q;
+    int2 *summary;                 // camera form, nullable: column summary (mmt_camera.h CamGeom::summary)
+    int summary_cached;            // forward: 1 = read the summary instead of computing (and writing) it
     const void *depth;
     const void *context;
     float *out;
@@ -502,7 +506,7 @@ __device__ __forceinline__ int64_t ray_point(const RayArgs &a, int bn, int row, 
 // instruction of a group is one whole, aligned 64-byte segment of a BEV row -- the memory-side atomic units work in 64-byte
 // requests, and 80-byte pieces (C/4 lanes x 4 registers) or 16-byte lane strides cost 1.6x / 4x as many of them
 // (tools/ubench/atomic_rows.hip).  The 16 lane groups of a workgroup split the depth bins of the column among them.
-template <typename FT, int S>
+template <typename FT, int S, bool CAM>
 __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
     extern __shared__ __align__(16) float ray_lds[];
     constexpr int C = 16 * S;
@@ -519,6 +523,14 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
     const int b = bn / a.N;
     const FT *depth = reinterpret_cast<const FT *>(a.depth);
     const FT *context = reinterpret_cast<const FT *>(a.context);
+#ifdef LSS_STAMPS   // diagnostic build: pos_memo receives 4 s_memtime stamps per workgroup (per wave 0 .. 3: stamp 2) instead of its rows
+    unsigned long long *fstamps = reinterpret_cast<unsigned long long *>(a.pos_memo) + (int64_t)blockIdx.x * 8;
+    a.pos_memo = nullptr;
+#define FWD_STAMP(i) do { if (threadIdx.x == 0 && fstamps) fstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FWD_STAMP(i) do { } while (0)
+#endif
+    FWD_STAMP(0);
     // padded row strides: the 4 lane groups of a wave read the same context row (broadcast) but records 2 * kd dwords apart
     constexpr int CP = C + 4;
     const int dnp = a.dspan | 1;
@@ -526,7 +538,63 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
     int2 *rec = reinterpret_cast<int2 *>(ray_lds + fH * CP);
 
     // ---- all threads: geometry -> (cell, depth) records
+    // camera form: the voxel index of a point is computed here from the camera's matrix and the frustum axes, with the
+    // arithmetic of mmt_frustum_geometry (mmt_camera.h) -- no geom tensor is read
     const int npts = fH * dn;
+    if constexpr (CAM) {
+        // a thread takes ONE depth bin of a block of 16 image rows: for a fixed (camera, column, bin) the coordinates are
+        // monotone in the row, so two (x, y) quantisations and 16 exact z range tests settle the block (mmt_camera.h)
+        float cm[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cm[k] = a.combine[bn * 16 + k];
+        const float cu = a.fu[col];
+        for (int r0 = 0; r0 < fH; r0 += 16) {
+            const int nr = (fH - r0) < 16 ? (fH - r0) : 16;
+            float cv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) cv[u] = a.fv[r0 + (u < nr ? u : nr - 1)];
+            const bool sorted = mmt_rows_sorted<16>(cv, nr);
+            const int64_t rstep = a.pm ? (int64_t)a.fW * a.D : a.fW;          // points between consecutive image rows
+            for (int dd = tid; dd < dn; dd += kBlock) {
+                const int64_t t0 = ray_point(a, bn, r0, col, d0 + dd);
+                float dv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) dv[u] = Elem<FT>::scalar(depth + t0 + (u < nr ? u : nr - 1) * rstep);
+                const mmt_cam_column cc = mmt_cam_column_make(cm, cu, a.fd[d0 + dd]);
+                bool uniform, in0;
+                int x0, y0;
+                unsigned zmask;
+                int2 *sum = a.summary ? a.summary + (((int64_t)bn * ((fH + 15) >> 4) + (r0 >> 4)) * a.fW + col) * a.D + d0 + dd : nullptr;
+                if (sum && a.summary_cached) {          // the calibration is the one the summary was written for
+                    const int2 sv = *sum;
+                    in0 = sv.x >= 0; x0 = sv.x & 0xFFFF; y0 = sv.x >> 16;
+                    zmask = (unsigned)sv.y & 0xFFFFu;
+                    uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
+                } else {
+                    zmask = mmt_cam_column_cells<16>(cc, cv, nr, sorted, a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
+                    if (sum) *sum = make_int2(in0 ? ((y0 << 16) | x0) : -1, (int)zmask | (uniform ? mmt::kSummaryUniform : 0));
+                }
+                const int cell0 = in0 ? (b * a.ny + y0) * a.nx + x0 : -1;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    if (u < nr) {
+                        int gx = x0, gy = y0, cell = cell0;
+                        if (!uniform) cell = mmt_cam_row_xy(cc, cv[u], a.q, a.nx, a.ny, gx, gy) ? (b * a.ny + gy) * a.nx + gx : -1;
+                        const bool keep = ((zmask >> u) & 1u) && cell >= 0;
+                        rec[(r0 + u) * dnp + dd] = make_int2(keep ? cell : -1, keep ? __float_as_int(dv[u]) : 0);
+                        if (a.pos_memo) {
+                            const int64_t t = t0 + u * rstep;
+                            if (keep) {
+                                a.pos_memo[t * 3] = b; a.pos_memo[t * 3 + 1] = gy; a.pos_memo[t * 3 + 2] = gx;
+                            } else if (a.write_dropped) {
+                                a.pos_memo[t * 3] = -1; a.pos_memo[t * 3 + 1] = -1; a.pos_memo[t * 3 + 2] = -1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    } else
     for (int p0 = tid; p0 < npts; p0 += kBlock * 4) {
         int gx[4], gy[4], gz[4];
         float dv[4];
@@ -567,6 +635,7 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
         }
     }
     __syncthreads();
+    FWD_STAMP(1);
 
     // ---- 16 lane groups (4 per wave): kd depth bins x all fH rows each, run-length sums in registers (no barrier below)
     const int g = lane >> 4, li = lane & 15;
@@ -610,6 +679,9 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
         }
     }
     if (cur >= 0) flush();
+#ifdef LSS_STAMPS
+    if (lane == 0 && fstamps) fstamps[2 + wave] = __builtin_amdgcn_s_memtime();      // end of the walk (atomics issued, not retired)
+#endif
 }
 
 __device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes of a quad, in all 4 (DPP quad_perm, no LDS)
@@ -622,7 +694,7 @@ constexpr int kRayBins = 16;        // depth bins per reduction batch of the bac
 
 // LDS (dynamic), per lane group: off [Dp] int (byte offset of the BEV-gradient row, or an out-of-range value in the padding) |
 // dep [Dp] fp32 | kbin [Dp] int | part [kRayBins][C4/4] fp32
-template <typename FT, int C4T>
+template <typename FT, int C4T, bool CAM>
 __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
     extern __shared__ __align__(16) float ray_lds[];
     const int L = blockIdx.x, xcd = L & 7, i = L >> 3;
@@ -677,15 +749,55 @@ __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
     {
         constexpr int PA = 6;                                      // bins per lane in flight: the whole ray at D = 112, C = 80
         const unsigned long long gmask = C4 >= 64 ? ~0ull : ((1ull << C4) - 1ull);
+        float cm[12];
+        float cu = 0.f, cv = 0.f;
+        if constexpr (CAM) {                                       // camera form: cells from the matrix (mmt_camera.h), no geom tensor
+#pragma unroll
+            for (int k = 0; k < 12; ++k) cm[k] = a.combine[bn * 16 + k];
+            cu = a.fu[col]; cv = a.fv[row];
+        }
         for (int dbase = 0; dbase < D; dbase += PA * C4) {
             int gx[PA], gy[PA], gz[PA];
             float dv[PA];
+            float fdd[PA];
 #pragma unroll
             for (int u = 0; u < PA; ++u) {
                 const int d = dbase + u * C4 + li;
-                const int64_t t = t0 + (int64_t)((act && d < D) ? d : 0) * dstep;
-                gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2];
+                const int dc = (act && d < D) ? d : 0;
+                const int64_t t = t0 + (int64_t)dc * dstep;
+                if constexpr (CAM) {
+                    fdd[u] = a.fd[dc];
+                } else {
+                    gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2];
+                }
                 dv[u] = Elem<FT>::scalar(depth + t);
+            }
+            if constexpr (CAM) {
+                if (a.summary) {       // the forward's column summary: the kept test and the cell cost two dwords per bin
+                    const int2 *sum = a.summary + (((int64_t)bn * ((fH + 15) >> 4) + (row >> 4)) * a.fW + col) * (int64_t)D;
+                    int2 sv[PA];
+#pragma unroll
+                    for (int u = 0; u < PA; ++u) {
+                        const int d = dbase + u * C4 + li;
+                        sv[u] = sum[(act && d < D) ? d : 0];
+                    }
+                    bool all_uniform = true;
+#pragma unroll
+                    for (int u = 0; u < PA; ++u) all_uniform = all_uniform && (sv[u].y & mmt::kSummaryUniform);
+                    if (__all(all_uniform)) {
+#pragma unroll
+                        for (int u = 0; u < PA; ++u) {
+                            const bool k = sv[u].x >= 0 && ((sv[u].y >> (row & 15)) & 1);
+                            gx[u] = k ? (sv[u].x & 0xFFFF) : -1; gy[u] = sv[u].x >> 16; gz[u] = 0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < PA; ++u) mmt_cam_cell(cm, cu, cv, fdd[u], a.q, gx[u], gy[u], gz[u]);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PA; ++u) mmt_cam_cell(cm, cu, cv, fdd[u], a.q, gx[u], gy[u], gz[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < PA; ++u) {
@@ -855,9 +967,24 @@ void pick_tile(int fH, int fW, int D, int BN, TileArgs *a) {
     a->NG = BN * a->ngrp_per_cam;
 }
 
+// which kernel family the process's last forward ([0]) / backward ([1]) call launched (mmt_lss_last_kernel_family); process-wide
+// on purpose: an autograd backward runs on the engine's thread, the caller asks from its own
+volatile int g_last_family[2] = {0, 0};
+
+// zero-fill of the BEV map in front of the forward (MMT_LSS_ZERO_OUTPUT): `sc1` stores leave no line behind in the XCD L2s,
+// so the memory-side atomics that follow do not wait for freshly written lines to be evicted (a torch.zeros right before
+// the launch cost the forward 2.2 us, tools/kbench_fused.py `after_zero_fill`)
+__global__ __launch_bounds__(kBlock) void lss_zero_fill(float4 *p, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7FFFFFFF, 0x00020000);
+    const mmt_u32x4 z = {0u, 0u, 0u, 0u};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride)
+        __builtin_amdgcn_raw_buffer_store_b128(z, rsrc, (unsigned)(i * 16), 0, 16);      // aux 16 = sc1
+}
+
 template <typename FT>
 int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
-                 const FT *depth, const FT *context, float *out, int32_t *pos_memo, int flags, hipStream_t st) {
+                 const mmt::CamGeom *cam, const FT *depth, const FT *context, float *out, int32_t *pos_memo, int flags, hipStream_t st) {
     if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive size", what);
     constexpr int VEC = Elem<FT>::VEC;
@@ -867,25 +994,51 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     const int64_t P = (int64_t)N * D * fH * fW, BP = (int64_t)B * P;
     if (BP >= (1ll << 31) || (int64_t)B * ny * nx >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
-    if (flags & ~(MMT_VP_WRITE_DROPPED | MMT_LSS_PIXEL_MAJOR | MMT_LSS_TILE_KERNELS))
+    if (flags & ~(MMT_VP_WRITE_DROPPED | MMT_LSS_PIXEL_MAJOR | MMT_LSS_TILE_KERNELS | MMT_LSS_ZERO_OUTPUT))
         return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (cam && (flags & MMT_LSS_TILE_KERNELS))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "%s: the camera form has no frustum-tile kernels (MMT_LSS_TILE_KERNELS)", what);
+    const int64_t out_elems = (int64_t)B * ny * nx * C;
+    if ((flags & MMT_LSS_ZERO_OUTPUT) && (((uintptr_t)out & 15) != 0 || out_elems * 4 >= (1ll << 31)))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: MMT_LSS_ZERO_OUTPUT needs a 16-byte aligned map below 2 GiB", what);
+    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    auto zero_fill = [&]() {
+        if (flags & MMT_LSS_ZERO_OUTPUT)
+            seq.launch(false, lss_zero_fill, dim3((unsigned)mmt::stream_grid(out_elems / 4, kBlock, 2048)), dim3(kBlock), 0, st,
+                       reinterpret_cast<float4 *>(out), out_elems / 4);
+    };
     if (!(flags & MMT_LSS_TILE_KERNELS) && (C == 64 || C == 80 || C == 128)) {   // other widths: the tile kernels
         RayArgs r = {};
         r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C; r.nx = nx; r.ny = ny; r.nz = nz;
         r.pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
         r.write_dropped = (flags & MMT_VP_WRITE_DROPPED) ? 1 : 0;
         r.geom = geom; r.depth = depth; r.context = context; r.out = out; r.pos_memo = pos_memo;
+        if (cam) {
+            r.combine = cam->combine; r.fu = cam->fu; r.fv = cam->fv; r.fd = cam->fd; r.q = cam->q;
+            r.summary = reinterpret_cast<int2 *>(cam->summary); r.summary_cached = cam->summary_cached;
+        }
         if (pick_ray_forward(&r)) {
             const size_t lds = (size_t)fH * (C + 4) * 4 + (size_t)fH * (r.dspan | 1) * 8;
             const int64_t grid = 8ll * ((r.BN + 7) / 8) * fW * r.dsplit;
             if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
-            mmt::TimedSeq seq;
-            if (C == 80) seq.launch(true, lss_ray_fwd<FT, 5>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
-            else if (C == 64) seq.launch(true, lss_ray_fwd<FT, 4>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
-            else seq.launch(true, lss_ray_fwd<FT, 8>, dim3((unsigned)grid), dim3(kBlock), lds, st, r);
+            zero_fill();
+            const dim3 g((unsigned)grid), blk(kBlock);
+            if (cam) {
+                if (C == 80) seq.launch(true, lss_ray_fwd<FT, 5, true>, g, blk, lds, st, r);
+                else if (C == 64) seq.launch(true, lss_ray_fwd<FT, 4, true>, g, blk, lds, st, r);
+                else seq.launch(true, lss_ray_fwd<FT, 8, true>, g, blk, lds, st, r);
+            } else {
+                if (C == 80) seq.launch(true, lss_ray_fwd<FT, 5, false>, g, blk, lds, st, r);
+                else if (C == 64) seq.launch(true, lss_ray_fwd<FT, 4, false>, g, blk, lds, st, r);
+                else seq.launch(true, lss_ray_fwd<FT, 8, false>, g, blk, lds, st, r);
+            }
+            g_last_family[0] = MMT_LSS_FAMILY_RAY | (cam ? MMT_LSS_FAMILY_CAMERA : 0);
             return mmt::check_launch(what);
         }
     }
+    if (cam)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the camera form needs C in {64, 80, 128} and a column of fH=%d rows within 64 KB of LDS; "
+                         "use the geom form (mmt_frustum_geometry + mmt_lss_splat_forward)", what, fH);
     TileArgs a;
     a.N = N; a.D = D; a.fH = fH; a.fW = fW; a.C = C; a.nx = nx; a.ny = ny; a.nz = nz;
     pick_tile(fH, fW, D, B * N, &a);
@@ -897,17 +1050,18 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     if (lds > 96 * 1024) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: context tile of %d pixels x %d channels exceeds LDS", what, a.TP, C);
     const int64_t grid = 8ll * ((a.NG + 7) / 8) * a.dt_per_grp * a.wtiles;
     if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
-    mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    zero_fill();
     if (C == 80) seq.launch(true, lss_splat_fwd_tile<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     else if (C == 64) seq.launch(true, lss_splat_fwd_tile<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     else seq.launch(true, lss_splat_fwd_tile<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    g_last_family[0] = MMT_LSS_FAMILY_TILE;
     return mmt::check_launch(what);
 }
 
 template <typename FT>
 int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
-                  const FT *depth, const FT *context, const float *grad_out, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
-                  FT *grad_depth, float *grad_context, int flags, hipStream_t st) {
+                  const mmt::CamGeom *cam, const FT *depth, const FT *context, const float *grad_out, int64_t sb, int64_t sc, int64_t sy,
+                  int64_t sx, FT *grad_depth, float *grad_context, unsigned long long *stats, int flags, hipStream_t st) {
     if (flags & ~(MMT_LSS_PIXEL_MAJOR | MMT_LSS_TILE_KERNELS | MMT_LSS_COLUMN_BACKWARD))
         return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
     if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
@@ -922,14 +1076,17 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: grad_out must be channels-last (stride_c == 1), 16-byte aligned, < 2^31 elements", what);
     if ((int64_t)B * N * D * fH * fW >= (1ll << 31) || (int64_t)B * N * fH * fW * C >= (1ll << 31))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: index range exceeds int32", what);
+    if (cam && (flags & MMT_LSS_TILE_KERNELS))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "%s: the camera form has no frustum-tile kernels (MMT_LSS_TILE_KERNELS)", what);
     {
         const bool want_col = (flags & MMT_LSS_COLUMN_BACKWARD) != 0;       // the matrix-core column kernel (lift_splat_col.hip)
         if (want_col && !(flags & MMT_LSS_TILE_KERNELS) && mmt::lss_col_backward_fits(D, fH, fW, C, span, (int64_t)B * N * fW * ((fH + 15) / 16))) {
             const int pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
+            g_last_family[1] = MMT_LSS_FAMILY_COLUMN | (cam ? MMT_LSS_FAMILY_CAMERA : 0);
             if constexpr (sizeof(FT) == 2)
-                return mmt::lss_col_backward_bf16(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+                return mmt::lss_col_backward_bf16(what, B, N, D, fH, fW, C, nx, ny, nz, geom, cam, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, stats, pm, st);
             else
-                return mmt::lss_col_backward_f32(what, B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, pm, st);
+                return mmt::lss_col_backward_f32(what, B, N, D, fH, fW, C, nx, ny, nz, geom, cam, depth, context, grad_out, sb, sy, sx, span, grad_depth, grad_context, stats, pm, st);
         }
     }
     {
@@ -940,19 +1097,33 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
             r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C; r.nx = nx; r.ny = ny; r.nz = nz;
             r.pm = (flags & MMT_LSS_PIXEL_MAJOR) ? 1 : 0;
             r.geom = geom; r.depth = depth; r.context = context;
+            if (cam) {
+                r.combine = cam->combine; r.fu = cam->fu; r.fv = cam->fv; r.fd = cam->fd; r.q = cam->q;
+                r.summary = reinterpret_cast<int2 *>(cam->summary);
+            }
             r.grad_out = grad_out; r.sb = sb; r.sy = sy; r.sx = sx; r.span_bytes = (int)(span * 4);
             r.grad_depth = grad_depth; r.grad_context = grad_context;
             r.wpc = (fH * fW + NGR - 1) / NGR;
             const int64_t grid = 8ll * ((r.BN + 7) / 8) * r.wpc;
             if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
             const size_t lds_req = lds;
+            const dim3 g((unsigned)grid), blk(kBlock);
             mmt::TimedSeq seq;
-            if (C == 80) seq.launch(true, lss_ray_bwd<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds_req, st, r);
-            else if (C == 64) seq.launch(true, lss_ray_bwd<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds_req, st, r);
-            else seq.launch(true, lss_ray_bwd<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds_req, st, r);
+            if (cam) {
+                if (C == 80) seq.launch(true, lss_ray_bwd<FT, 20, true>, g, blk, lds_req, st, r);
+                else if (C == 64) seq.launch(true, lss_ray_bwd<FT, 16, true>, g, blk, lds_req, st, r);
+                else seq.launch(true, lss_ray_bwd<FT, 0, true>, g, blk, lds_req, st, r);
+            } else {
+                if (C == 80) seq.launch(true, lss_ray_bwd<FT, 20, false>, g, blk, lds_req, st, r);
+                else if (C == 64) seq.launch(true, lss_ray_bwd<FT, 16, false>, g, blk, lds_req, st, r);
+                else seq.launch(true, lss_ray_bwd<FT, 0, false>, g, blk, lds_req, st, r);
+            }
+            g_last_family[1] = MMT_LSS_FAMILY_RAY | (cam ? MMT_LSS_FAMILY_CAMERA : 0);
             return mmt::check_launch(what);
         }
     }
+    if (cam)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the camera form needs a ray of D=%d bins within 64 KB of LDS per workgroup; use the geom form", what, D);
     // frustum-tile kernel: partial sums per depth tile meet in grad_context through fp32 atomics
     if (const hipError_t e = hipMemsetAsync(grad_context, 0, (size_t)B * N * fH * fW * C * 4, st); e != hipSuccess)
         return mmt::fail((int)e, "%s: zero-fill of grad_context: %s", what, hipGetErrorString(e));
@@ -970,6 +1141,7 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
     if (C == 80) seq.launch(true, lss_splat_bwd_tile<FT, 20>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     else if (C == 64) seq.launch(true, lss_splat_bwd_tile<FT, 16>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     else seq.launch(true, lss_splat_bwd_tile<FT, 0>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    g_last_family[1] = MMT_LSS_FAMILY_TILE;
     return mmt::check_launch(what);
 }
 
@@ -985,8 +1157,8 @@ extern "C" int mmt_lss_splat_backward(int B, int N, int D, int fH, int fW, int C
     MMT_REQUIRE_PTR(grad_out);
     MMT_REQUIRE_PTR(grad_depth);
     MMT_REQUIRE_PTR(grad_context);
-    return backward_impl<float>("lss_splat_backward", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sc, sy, sx,
-                                grad_depth, grad_context, flags, (hipStream_t)stream);
+    return backward_impl<float>("lss_splat_backward", B, N, D, fH, fW, C, nx, ny, nz, geom, nullptr, depth, context, grad_out, sb, sc, sy, sx,
+                                grad_depth, grad_context, nullptr, flags, (hipStream_t)stream);
 }
 
 extern "C" int mmt_lss_splat_backward_bf16(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz,
@@ -999,8 +1171,8 @@ extern "C" int mmt_lss_splat_backward_bf16(int B, int N, int D, int fH, int fW, 
     MMT_REQUIRE_PTR(grad_out);
     MMT_REQUIRE_PTR(grad_depth);
     MMT_REQUIRE_PTR(grad_context);
-    return backward_impl<bf16_t>("lss_splat_backward_bf16", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, grad_out, sb, sc,
-                                 sy, sx, grad_depth, grad_context, flags, (hipStream_t)stream);
+    return backward_impl<bf16_t>("lss_splat_backward_bf16", B, N, D, fH, fW, C, nx, ny, nz, geom, nullptr, depth, context, grad_out, sb, sc,
+                                 sy, sx, grad_depth, grad_context, nullptr, flags, (hipStream_t)stream);
 }
 
 extern "C" int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz,
@@ -1010,7 +1182,7 @@ extern "C" int mmt_lss_splat_forward(int B, int N, int D, int fH, int fW, int C,
     MMT_REQUIRE_PTR(depth);
     MMT_REQUIRE_PTR(context);
     MMT_REQUIRE_PTR(out);
-    return forward_impl<float>("lss_splat_forward", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, out, pos_memo, flags,
+    return forward_impl<float>("lss_splat_forward", B, N, D, fH, fW, C, nx, ny, nz, geom, nullptr, depth, context, out, pos_memo, flags,
                                (hipStream_t)stream);
 }
 
@@ -1021,6 +1193,97 @@ extern "C" int mmt_lss_splat_forward_bf16(int B, int N, int D, int fH, int fW, i
     MMT_REQUIRE_PTR(depth);
     MMT_REQUIRE_PTR(context);
     MMT_REQUIRE_PTR(out);
-    return forward_impl<bf16_t>("lss_splat_forward_bf16", B, N, D, fH, fW, C, nx, ny, nz, geom, depth, context, out, pos_memo,
+    return forward_impl<bf16_t>("lss_splat_forward_bf16", B, N, D, fH, fW, C, nx, ny, nz, geom, nullptr, depth, context, out, pos_memo,
                                 flags, (hipStream_t)stream);
+}
+
+// ---- camera form (ABI 6): the voxel index of a frustum point is computed inside the kernels (mmt_camera.h)
+namespace {
+int make_cam(const char *what, const float *combine, const float *fu, const float *fv, const float *fd, const float *vc, const float *vs,
+             int nx, int ny, int nz, int32_t *summary, int summary_cached, mmt::CamGeom *cam) {
+    if (!combine || !fu || !fv || !fd || !vc || !vs) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: a camera-geometry pointer is NULL", what);
+    if (summary_cached && !summary) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: MMT_LSS_SUMMARY_CACHED without a column summary", what);
+    if (summary && (nx > 32767 || ny > 32767 || ((uintptr_t)summary & 7) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the column summary needs an 8-byte aligned buffer and a grid below 32768 x 32768", what);
+    cam->combine = combine; cam->fu = fu; cam->fv = fv; cam->fd = fd;
+    cam->summary = summary; cam->summary_cached = summary_cached;
+    mmt::make_cam_grid(vc, vs, &cam->q);
+    if (nx > 0 && ny > 0 && nz > 0) mmt::make_cam_range(&cam->q, nx, ny, nz);      // (non-positive sizes are refused further down)
+    return MMT_OK;
+}
+}  // namespace
+
+extern "C" int mmt_lss_splat_forward_cam(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
+        const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
+        const float *voxel_size_host, const float *depth, const float *context, float *out, int32_t *pos_memo,
+        int32_t *column_summary, int flags, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    mmt::CamGeom cam;
+    if (const int rc = make_cam("lss_splat_forward_cam", combine, frustum_u, frustum_v, frustum_d, voxel_coord_host, voxel_size_host, nx, ny, nz,
+                                column_summary, (flags & MMT_LSS_SUMMARY_CACHED) ? 1 : 0, &cam)) return rc;
+    return forward_impl<float>("lss_splat_forward_cam", B, N, D, fH, fW, C, nx, ny, nz, nullptr, &cam, depth, context, out, pos_memo,
+                                flags & ~MMT_LSS_SUMMARY_CACHED, (hipStream_t)stream);
+}
+
+extern "C" int mmt_lss_splat_forward_cam_bf16(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
+        const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
+        const float *voxel_size_host, const uint16_t *depth, const uint16_t *context, float *out, int32_t *pos_memo,
+        int32_t *column_summary, int flags, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    mmt::CamGeom cam;
+    if (const int rc = make_cam("lss_splat_forward_cam_bf16", combine, frustum_u, frustum_v, frustum_d, voxel_coord_host, voxel_size_host, nx, ny, nz,
+                                column_summary, (flags & MMT_LSS_SUMMARY_CACHED) ? 1 : 0, &cam)) return rc;
+    return forward_impl<bf16_t>("lss_splat_forward_cam_bf16", B, N, D, fH, fW, C, nx, ny, nz, nullptr, &cam, depth, context, out, pos_memo,
+                                flags & ~MMT_LSS_SUMMARY_CACHED, (hipStream_t)stream);
+}
+
+extern "C" int mmt_lss_splat_backward_cam(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
+        const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
+        const float *voxel_size_host, const float *depth, const float *context, const float *grad_out, int64_t sb, int64_t sc,
+        int64_t sy, int64_t sx, float *grad_depth, float *grad_context, const int32_t *column_summary, uint64_t *column_stats,
+        int flags, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    mmt::CamGeom cam;
+    if (const int rc = make_cam("lss_splat_backward_cam", combine, frustum_u, frustum_v, frustum_d, voxel_coord_host, voxel_size_host, nx, ny, nz,
+                                const_cast<int32_t *>(column_summary), 0, &cam)) return rc;
+    return backward_impl<float>("lss_splat_backward_cam", B, N, D, fH, fW, C, nx, ny, nz, nullptr, &cam, depth, context, grad_out, sb, sc, sy, sx,
+                                 grad_depth, grad_context, reinterpret_cast<unsigned long long *>(column_stats), flags, (hipStream_t)stream);
+}
+
+extern "C" int mmt_lss_splat_backward_cam_bf16(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
+        const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
+        const float *voxel_size_host, const uint16_t *depth, const uint16_t *context, const float *grad_out, int64_t sb, int64_t sc,
+        int64_t sy, int64_t sx, uint16_t *grad_depth, float *grad_context, const int32_t *column_summary, uint64_t *column_stats,
+        int flags, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(grad_depth);
+    MMT_REQUIRE_PTR(grad_context);
+    mmt::CamGeom cam;
+    if (const int rc = make_cam("lss_splat_backward_cam_bf16", combine, frustum_u, frustum_v, frustum_d, voxel_coord_host, voxel_size_host, nx, ny, nz,
+                                const_cast<int32_t *>(column_summary), 0, &cam)) return rc;
+    return backward_impl<bf16_t>("lss_splat_backward_cam_bf16", B, N, D, fH, fW, C, nx, ny, nz, nullptr, &cam, depth, context, grad_out, sb, sc, sy, sx,
+                                 grad_depth, grad_context, reinterpret_cast<unsigned long long *>(column_stats), flags, (hipStream_t)stream);
+}
+
+extern "C" int mmt_lss_last_kernel_family(int backward) { return g_last_family[backward ? 1 : 0]; }
+
+// 1 when both directions have a camera-form kernel for this shape (the gates of forward_impl / backward_impl)
+extern "C" int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW, int C) {
+    if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || !(C == 64 || C == 80 || C == 128) || fH > kPts) return 0;
+    RayArgs r = {};
+    r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C;
+    if (!pick_ray_forward(&r)) return 0;
+    const int C4 = C / 4, NGR = (kBlock / 64) * (64 / C4);
+    const size_t lds = (size_t)NGR * (3 * (((D + kRayBins - 1) & ~(kRayBins - 1)) + 8) + kRayBins * (C4 / 4)) * 4;
+    return lds <= 64 * 1024 ? 1 : 0;
 }

@@ -71,15 +71,16 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16_lo(unsigned pair) { return __uint_as_float(pair << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned pair) { return __uint_as_float(pair & 0xFFFF0000u); }
 
-// fused lift-splat backward on the matrix cores (lift_splat_col.hip), called from mmt_lss_splat_backward
+// fused lift-splat backward on the matrix cores (lift_splat_col.hip), called from mmt_lss_splat_backward[_cam]
 namespace mmt {
+struct CamGeom;   // mmt_camera.h; NULL = geom form
 bool lss_col_backward_fits(int D, int fH, int fW, int C, int64_t span, int64_t grid_units);
 int lss_col_backward_f32(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
-                         const float *depth, const float *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx,
-                         int64_t span, float *grad_depth, float *grad_context, int pm, hipStream_t st);
+                         const CamGeom *cam, const float *depth, const float *context, const float *grad_out, int64_t sb, int64_t sy,
+                         int64_t sx, int64_t span, float *grad_depth, float *grad_context, unsigned long long *stats, int pm, hipStream_t st);
 int lss_col_backward_bf16(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
-                          const bf16_t *depth, const bf16_t *context, const float *grad_out, int64_t sb, int64_t sy, int64_t sx,
-                          int64_t span, bf16_t *grad_depth, float *grad_context, int pm, hipStream_t st);
+                          const CamGeom *cam, const bf16_t *depth, const bf16_t *context, const float *grad_out, int64_t sb, int64_t sy,
+                          int64_t sx, int64_t span, bf16_t *grad_depth, float *grad_context, unsigned long long *stats, int pm, hipStream_t st);
 }  // namespace mmt
 
 #define MMT_REQUIRE_PTR(p)                                                        \

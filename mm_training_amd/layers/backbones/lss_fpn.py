@@ -11,10 +11,13 @@ Reference quirks kept: voxel_num truncation (:286-289), depth softmax taken BEFO
 the per-camera un-flip of depth_feature (:423-425), BDA not applied in
 get_geometry (:355-360), context_se constructed but never called (:183, :240-248).
 """
+import os
+
 import torch
 from torch import nn
 
-from ...ops.bev_geometry import frustum_geometry, lift_features, lift_splat
+from ...ops.bev_geometry import (camera_form_supported, frustum_axes, frustum_geometry, lift_features, lift_splat,
+                                 lift_splat_camera, new_column_summary)
 from ...ops.bn_relu import ConvBNAct, bn_act
 from ...ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling, voxel_pooling_bf16, voxel_pooling_planned
 from ..nets import BasicBlock, DeformConv2dPack, ResNet, SECONDFPN
@@ -119,14 +122,26 @@ class LSSFPN(nn.Module):
         # Storage type of the hot-path operands: "bf16" keeps depth / context (fused path) or the
         # lifted feature matrix and its gradient (unfused path) in bf16; products and sums stay fp32, the BEV map is fp32.
         self.hot_path_dtype = "f32"
+        # True (default): the fused kernels compute every point's voxel index themselves from the camera matrices and the
+        # frustum axes (SURVEY section 8 rows f1 + f3: lss_fpn.py:328-361 and :461-462 folded into :441-464) -- no geom tensor
+        # is written or read and no geometry kernel runs in the step.  False (or a shape / frustum the camera-form kernels do
+        # not take): mmt_frustum_geometry writes geom and the geom form of the same kernels reads it.  Same cells bit for bit.
+        self.camera_form = os.environ.get("MMT_LSS_GEOM_FORM", "0") != "1"
         # Backward kernel of the fused path: "ray" (per-pixel walk, any geometry at the same speed), "column" (matrix cores:
         # two small GEMMs per image column, the faster one while the pixels of a column share their BEV cell) or "auto":
-        # measured ONCE per calibration (mats_dict['calibration_id'], or once per module without it) from the geometry itself
-        # -- column while fewer than 1 % of the kept points leave their column's cell.  That one measurement reads a scalar
-        # back (the only host sync of this module, never inside a graph capture).
+        # column while fewer than 1 % of the kept points leave their column's cell.  With a mats_dict['calibration_id'] that
+        # share is measured ONCE per calibration from the geometry (one scalar read back, never inside a graph capture, never
+        # in the steady state); without one the column kernel itself counts the points it had to handle one by one
+        # (`column_stats` of mmt_lss_splat_backward_cam) and the module reads the counters back LAZILY -- an asynchronous copy
+        # polled on later steps, no synchronisation -- falls back to the ray walk while the share is above 1 % and probes the
+        # column kernel again every `column_probe_period` steps, so a loader that switches rigs is followed.
         self.lift_splat_backward = "auto"
+        self.column_probe_period = 256
         self._column_backward_choice = {}
+        self._column_adaptive = None   # state of the lazy read-back (see _adaptive_column_choice)
         self._plan_cache = {}     # calibration_id -> VoxelPoolingPlan (see _forward_single_sweep)
+        self._combine_cache = {}  # calibration_id -> camera matrices sensor2ego @ inverse(intrin)
+        self._summary_cache = {}  # calibration_id -> column summary of the camera form (8 bytes per 16 points; ops/bev_geometry.py)
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
         self.register_buffer('voxel_size', torch.Tensor([row[2] for row in rows]))
@@ -136,6 +151,12 @@ class LSSFPN(nn.Module):
         # the same frustum in pixel-major order [fH, fW, D, 4]: the fused lift-splat kernels read geometry and depth per
         # (pixel, depth range) -- the order a channels_last depth tensor has -- see ops/bev_geometry.py::lift_splat
         self.register_buffer('frustum_pixel_major', self.frustum.permute(1, 2, 0, 3).contiguous(), persistent=False)
+        # the three axes the frustum is the outer product of (create_frustum: u per column, v per row, d per bin, w = 1):
+        # what the camera form of the fused kernels takes instead of a geom tensor
+        axes = frustum_axes(self.frustum)
+        self._has_frustum_axes = axes is not None
+        for name, t in zip(('frustum_u', 'frustum_v', 'frustum_d'), axes if axes is not None else (torch.zeros(1),) * 3):
+            self.register_buffer(name, t.clone(), persistent=False)
         self.depth_channels = self.frustum.shape[0]
         # host copies: no device->host sync per step (the reference indexes a CUDA tensor)
         self._voxel_num_host = [int(v) for v in self.voxel_num]
@@ -162,29 +183,81 @@ class LSSFPN(nn.Module):
         y_coords = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
         return torch.stack((x_coords, y_coords, d_coords, torch.ones_like(d_coords)), -1).contiguous()
 
-    def get_geometry_voxels(self, sensor2ego_mat, intrin_mat, bda_mat=None, pixel_major=False):
+    def camera_matrices(self, sensor2ego_mat, intrin_mat, cache_key=None):
+        """combine = sensor2ego @ inverse(intrin) [B, N, 4, 4] fp32 (lss_fpn.py:339-352), the only per-step geometry
+        operand of the hot path; reused while `cache_key` (from mats_dict['calibration_id']) repeats."""
+        if cache_key is not None:
+            hit = self._combine_cache.get(cache_key)
+            if hit is not None:
+                return hit
+        with torch.autocast("cuda", enabled=False):   # the integer index path is fp32 whatever the AMP mode
+            combine = sensor2ego_mat.float().matmul(torch.linalg.inv_ex(intrin_mat.float())[0]).contiguous()
+        if cache_key is not None and not torch.cuda.is_current_stream_capturing():
+            if len(self._combine_cache) >= 64:
+                self._combine_cache.pop(next(iter(self._combine_cache)))
+            self._combine_cache[cache_key] = combine
+        return combine
+
+    def get_geometry_voxels(self, sensor2ego_mat, intrin_mat, bda_mat=None, pixel_major=False, combine=None):
         """get_geometry (lss_fpn.py:328-361) fused with the quantise (:461-462):
         returns int32 voxel coordinates [B,N,D,fH,fW,3] ([B,N,fH,fW,D,3] with pixel_major: same values, the
         order the fused kernels read).  bda_mat is ignored like in the reference (:355-360)."""
-        with torch.autocast("cuda", enabled=False):   # the integer index path is fp32 whatever the AMP mode
-            combine = sensor2ego_mat.float().matmul(torch.linalg.inv_ex(intrin_mat.float())[0]).contiguous()
+        if combine is None:
+            combine = self.camera_matrices(sensor2ego_mat, intrin_mat)
         fr = self.frustum_pixel_major if pixel_major else self.frustum
         return frustum_geometry(fr.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
 
-    def _use_column_backward(self, geom_pixel_major, calib_id):
+    def _adaptive_column_choice(self, device):
+        """"auto" without a calibration id: (use the column kernel?, the counters it accumulates into)."""
+        st = self._column_adaptive
+        if st is None or st["stats"].device != device:
+            from mm_training_amd._lib import LSS_STATS_SLOTS
+            st = self._column_adaptive = dict(stats=torch.zeros(2 * LSS_STATS_SLOTS, dtype=torch.int64, device=device),
+                                              host=torch.zeros(2 * LSS_STATS_SLOTS, dtype=torch.int64).pin_memory(), event=torch.cuda.Event(),
+                                              pending=False, last=(0, 0), column=True, ray_left=0, calls=0, share=None)
+        if torch.cuda.is_current_stream_capturing():
+            return st["column"], st["stats"]              # a captured step keeps the choice it was captured with
+        if st["pending"] and st["event"].query():
+            mism, kept = int(st["host"][0::2].sum()), int(st["host"][1::2].sum())
+            dm, dk = mism - st["last"][0], kept - st["last"][1]
+            st["last"], st["pending"] = (mism, kept), False
+            if dk > 0:
+                st["share"] = dm / dk
+                if st["share"] >= 0.01:
+                    st["column"], st["ray_left"] = False, int(self.column_probe_period)
+        if not st["column"]:
+            st["ray_left"] -= 1
+            if st["ray_left"] <= 0:
+                st["column"] = True                       # probe again: the column kernel reports on the next backward
+        st["calls"] += 1
+        if st["column"] and not st["pending"] and st["calls"] % 4 == 0:
+            st["host"].copy_(st["stats"], non_blocking=True)     # sees every backward enqueued before this forward
+            st["event"].record()
+            st["pending"] = True
+        return st["column"], st["stats"]
+
+    def _use_column_backward(self, geom_pixel_major, calib_id, device=None):
+        """(column kernel?, column_stats tensor or None).  geom_pixel_major: the geometry, or a callable producing it (only
+        evaluated for the one measurement per calibration id)."""
         if self.lift_splat_backward != "auto":
-            return self.lift_splat_backward == "column"
-        key = calib_id if calib_id is not None else "_"
-        choice = self._column_backward_choice.get(key)
+            return self.lift_splat_backward == "column", None
+        if calib_id is None:
+            if not torch.is_grad_enabled():
+                return False, None                             # nothing to decide for
+            if device is None:
+                device = self.frustum.device
+            return self._adaptive_column_choice(device)
+        choice = self._column_backward_choice.get(calib_id)
         if choice is None:
             if torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled():
-                return False                                   # nothing to decide for (or no way to read a scalar back)
+                return False, None                             # nothing to decide for (or no way to read a scalar back)
             from mm_training_amd.ops.bev_geometry import column_mismatch_fraction
-            choice = bool(column_mismatch_fraction(geom_pixel_major, self._voxel_num_host, pixel_major=True).item() < 0.01)
+            geom = geom_pixel_major() if callable(geom_pixel_major) else geom_pixel_major
+            choice = bool(column_mismatch_fraction(geom, self._voxel_num_host, pixel_major=True).item() < 0.01)
             if len(self._column_backward_choice) >= 64:
                 self._column_backward_choice.pop(next(iter(self._column_backward_choice)))
-            self._column_backward_choice[key] = choice
-        return choice
+            self._column_backward_choice[calib_id] = choice
+        return choice, None
 
     def get_cam_feats(self, imgs):
         """[B, S, N, 3, H, W] images -> [B, S, N, C', fH, fW] neck features (lss_fpn.py:363-379)."""
@@ -230,20 +303,46 @@ class LSSFPN(nn.Module):
                 if len(self._plan_cache) >= 8:          # a handful of rigs, not an unbounded map
                     self._plan_cache.pop(next(iter(self._plan_cache)))
                 self._plan_cache[key] = plan
-        elif self.fused_lift_splat:
-            geom_xyz = self.get_geometry_voxels(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
-                                                mats_dict['intrin_mats'][:, sweep_index, ...],
-                                                mats_dict.get('bda_mat', None), pixel_major=True)
+        fused_kind = None
+        if plan is None and self.fused_lift_splat:
+            fH, fW = context.shape[-2:]
+            pixel_major_ok = fH <= 512 and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"
+            ckey = None if calib_id is None else (calib_id, sweep_index, batch_size, num_cams, str(context.device))
+            combine = self.camera_matrices(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
+                                           mats_dict['intrin_mats'][:, sweep_index, ...], ckey)
+            if (self.camera_form and self._has_frustum_axes and pixel_major_ok and os.environ.get("MMT_LIFT_SPLAT_TILES", "0") != "1"
+                    and camera_form_supported(batch_size, num_cams, self.depth_channels, fH, fW, self.output_channels)):
+                fused_kind = "camera"
+            else:
+                fused_kind = "geom_pm" if pixel_major_ok else "geom"     # fH > 512 / first-generation kernels: frustum order
+                geom_xyz = self.get_geometry_voxels(None, None, pixel_major=pixel_major_ok, combine=combine)
         if plan is not None:
             feats = lift_features(depth_used.float(), context.float())
             feature_map = voxel_pooling_planned(plan, feats.view(batch_size, -1, feats.shape[-1]))
-        elif self.fused_lift_splat:
-            col_bwd = self._use_column_backward(geom_xyz, calib_id)
-            if self.hot_path_dtype == "bf16":
-                feature_map = lift_splat(geom_xyz, depth_used.bfloat16(), context.bfloat16(), self._voxel_num_host, pixel_major=True,
-                                         column_backward=col_bwd)
+        elif fused_kind is not None:
+            bf16 = self.hot_path_dtype == "bf16"
+            dep_in, ctx_in = (depth_used.bfloat16(), context.bfloat16()) if bf16 else (depth_used, context)
+            if fused_kind == "camera":
+                col_bwd, stats = self._use_column_backward(
+                    lambda: self.get_geometry_voxels(None, None, pixel_major=True, combine=combine), calib_id, context.device)
+                # with a calibration id the geometry's column summary is kept too: later forwards read 0.5 byte per point
+                # instead of computing the cells (without one every forward writes a fresh summary for its backward)
+                summary, cached = None, False
+                if ckey is not None and not torch.cuda.is_current_stream_capturing():
+                    summary = self._summary_cache.get(ckey)
+                    cached = summary is not None
+                    if summary is None:
+                        if len(self._summary_cache) >= 64:
+                            self._summary_cache.pop(next(iter(self._summary_cache)))
+                        summary = self._summary_cache[ckey] = new_column_summary(batch_size, num_cams, self.depth_channels, fH, fW, context.device)
+                feature_map = lift_splat_camera(combine, (self.frustum_u, self.frustum_v, self.frustum_d), dep_in, ctx_in,
+                                                self._voxel_num_host, self._voxel_coord_host, self._voxel_size_host,
+                                                column_backward=col_bwd, column_stats=stats, summary=summary, summary_cached=cached)
+            elif fused_kind == "geom_pm":
+                col_bwd, _ = self._use_column_backward(geom_xyz, calib_id if calib_id is not None else "_", context.device)
+                feature_map = lift_splat(geom_xyz, dep_in, ctx_in, self._voxel_num_host, pixel_major=True, column_backward=col_bwd)
             else:
-                feature_map = lift_splat(geom_xyz, depth_used, context, self._voxel_num_host, pixel_major=True, column_backward=col_bwd)
+                feature_map = lift_splat(geom_xyz, dep_in, ctx_in, self._voxel_num_host, pixel_major=False)
         else:
             # lift straight into [B, N, D, fH, fW, C], then the drop-in voxel_pooling
             bf16 = self.hot_path_dtype == "bf16" and self.output_channels % 16 == 0

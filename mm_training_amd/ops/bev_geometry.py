@@ -194,15 +194,16 @@ class LiftSplat(Function):
         depth_c = (depth.to(sd).permute(0, 2, 3, 1) if pixel_major else depth.to(sd)).contiguous()
         ctx_nhwc = context.to(sd).permute(0, 2, 3, 1).contiguous()         # free for channels_last nets
         nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
-        out = torch.zeros((B, ny, nx, C), dtype=torch.float32, device=depth.device)
         sfx = "_bf16" if bf16 else ""
         with torch.cuda.device(depth.device):
             if tiled:   # the backward redoes the kept test from geom: no pos_memo is written or kept
+                out = torch.empty((B, ny, nx, C), dtype=torch.float32, device=depth.device)     # MMT_LSS_ZERO_OUTPUT fills it
                 _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward" + sfx, B, N, D, fH, fW, C, nx, ny, nz,
                                 geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), 0,
-                                _lss_flags(pixel_major), _stream())
+                                _lss_flags(pixel_major) | _lib.LSS_ZERO_OUTPUT, _stream())
                 ctx.save_for_backward(geom_xyz, depth_c, ctx_nhwc)
             else:
+                out = torch.zeros((B, ny, nx, C), dtype=torch.float32, device=depth.device)
                 pos_memo = torch.empty((B, N * D * HW, 3), dtype=torch.int32, device=depth.device)
                 _lib.timed_call("lift_splat_forward", "mmt_lift_splat_forward" + sfx, B, N, D, HW, C, nx, ny, nz,
                                 geom_xyz.data_ptr(), depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), pos_memo.data_ptr(),
@@ -246,3 +247,118 @@ def lift_splat(geom_xyz, depth, context, voxel_num, pixel_major=False, column_ba
     depth in [B*N,fH,fW,D] memory order -- what a channels_last depth tensor already is -- and return its gradient in that
     order: whole 64- / 192-byte runs per pixel and tile instead of 8- / 24-byte pieces."""
     return LiftSplat.apply(geom_xyz.contiguous(), depth, context, voxel_num, bool(pixel_major), bool(column_backward))
+
+
+def frustum_axes(frustum):
+    """The three axes of a create_frustum-style frustum [D, fH, fW, 4] (lss_fpn.py:308-326): (u [fW], v [fH], d [D]) with
+    frustum[k, h, w] == (u[w], v[h], d[k], 1) for every point -- what the camera form of the fused lift-splat takes instead
+    of a geom tensor.  Returns None when the frustum is not that outer product (then only the geom form applies)."""
+    u, v, d = frustum[0, 0, :, 0], frustum[0, :, 0, 1], frustum[:, 0, 0, 2]
+    D, fH, fW, _ = frustum.shape
+    same = (torch.equal(frustum[..., 0], u.view(1, 1, fW).expand(D, fH, fW)) and
+            torch.equal(frustum[..., 1], v.view(1, fH, 1).expand(D, fH, fW)) and
+            torch.equal(frustum[..., 2], d.view(D, 1, 1).expand(D, fH, fW)) and
+            bool((frustum[..., 3] == 1).all()))
+    return (u.contiguous(), v.contiguous(), d.contiguous()) if same else None
+
+
+def camera_form_supported(B, N, D, fH, fW, C):
+    """True when the camera-form kernels take this shape in both directions (mmt_lss_camera_form_supported)."""
+    return bool(_lib.lib().mmt_lss_camera_form_supported(int(B), int(N), int(D), int(fH), int(fW), int(C)))
+
+
+def last_kernel_family(backward=False):
+    """Kernel family the calling thread's last fused lift-splat forward / backward call launched:
+    "ray" | "tile" | "column" | "none", + "+camera" for the camera form (mmt_lss_last_kernel_family)."""
+    v = _lib.lib().mmt_lss_last_kernel_family(1 if backward else 0)
+    return _lib.LSS_FAMILY.get(v & 0xF, "?") + ("+camera" if v & 0x10 else "")
+
+
+class LiftSplatCamera(Function):
+    """Fused get_geometry + quantise + lift + voxel_pooling (lss_fpn.py:328-361, :461-462, :441-464): the camera form
+    of the fused op (mmt_lss_splat_forward_cam / _backward_cam).  The kernels compute every point's voxel index from
+    `combine` [B, N, 4, 4] (= sensor2ego @ inverse(intrin)) and the frustum axes with the arithmetic of
+    mmt_frustum_geometry, so no geom tensor exists in either direction.  depth / grad_depth in pixel-major
+    ([B*N, fH, fW, D] = channels_last) order; the BEV map is zero-filled by the forward call itself."""
+
+    @staticmethod
+    def forward(ctx, combine, axes, grid, depth, context, voxel_num, column_backward, column_stats, summary, summary_cached):
+        fu, fv, fd = axes
+        vc, vs = grid
+        B, N = combine.shape[:2]
+        D, fH, fW = fd.numel(), fv.numel(), fu.numel()
+        BN, C = B * N, context.shape[1]
+        _need_cuda(combine, "combine")
+        for t, name in ((fu, "frustum_u"), (fv, "frustum_v"), (fd, "frustum_d")):
+            _need_cuda(t, name)
+        if tuple(combine.shape[2:]) != (4, 4):
+            raise RuntimeError("lift_splat_camera: combine must be [B, N, 4, 4]")
+        if tuple(depth.shape) != (BN, D, fH, fW) or tuple(context.shape) != (BN, C, fH, fW):
+            raise RuntimeError("lift_splat_camera: depth must be [B*N, D, fH, fW] and context [B*N, C, fH, fW]")
+        if not (depth.is_cuda and context.is_cuda):
+            raise RuntimeError("depth / context must be a CUDAtensor ")
+        bf16 = depth.dtype == torch.bfloat16 and context.dtype == torch.bfloat16
+        sd = torch.bfloat16 if bf16 else torch.float32
+        depth_c = depth.to(sd).permute(0, 2, 3, 1).contiguous()            # free for channels_last nets
+        ctx_nhwc = context.to(sd).permute(0, 2, 3, 1).contiguous()
+        nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
+        out = torch.empty((B, ny, nx, C), dtype=torch.float32, device=depth.device)
+        vc_c, vs_c = _lib.float3(vc), _lib.float3(vs)
+        if summary is None:        # written by this forward, read by its backward
+            summary, summary_cached = new_column_summary(B, N, D, fH, fW, depth.device), False
+        elif tuple(summary.shape) != (BN, (fH + 15) // 16, fW, D, 2) or summary.dtype != torch.int32 or not summary.is_contiguous():
+            raise RuntimeError("lift_splat_camera: column summary must be a contiguous int32 [B*N, ceil(fH/16), fW, D, 2] tensor")
+        with torch.cuda.device(depth.device):
+            _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward_cam" + ("_bf16" if bf16 else ""), B, N, D, fH, fW, C,
+                            nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(), fd.data_ptr(), vc_c, vs_c,
+                            depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), 0, summary.data_ptr(),
+                            _lib.LSS_PIXEL_MAJOR | _lib.LSS_ZERO_OUTPUT | (_lib.LSS_SUMMARY_CACHED if summary_cached else 0), _stream())
+        ctx.save_for_backward(combine, fu, fv, fd, depth_c, ctx_nhwc, summary)
+        ctx.dims = (B, N, D, fH, fW, C, nx, ny, nz)
+        ctx.grid = (tuple(float(v) for v in vc), tuple(float(v) for v in vs))
+        ctx.bf16, ctx.column_backward, ctx.column_stats = bf16, bool(column_backward), column_stats
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        combine, fu, fv, fd, depth_c, ctx_nhwc, summary = ctx.saved_tensors
+        B, N, D, fH, fW, C, nx, ny, nz = ctx.dims
+        if grad_out.stride(1) != 1 or grad_out.dtype != torch.float32:
+            grad_out = grad_out.float().contiguous(memory_format=torch.channels_last)
+        sb, sc, sy, sx = grad_out.stride()
+        grad_depth = torch.empty_like(depth_c)
+        grad_ctx = torch.empty(ctx_nhwc.shape, dtype=torch.float32, device=depth_c.device)    # every element is written
+        stats = ctx.column_stats
+        flags = _lib.LSS_PIXEL_MAJOR | (_lib.LSS_COLUMN_BACKWARD if ctx.column_backward else 0)
+        with torch.cuda.device(depth_c.device):
+            _lib.timed_call("lift_splat_backward", "mmt_lss_splat_backward_cam" + ("_bf16" if ctx.bf16 else ""), B, N, D, fH, fW, C,
+                            nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(), fd.data_ptr(),
+                            _lib.float3(ctx.grid[0]), _lib.float3(ctx.grid[1]), depth_c.data_ptr(), ctx_nhwc.data_ptr(),
+                            grad_out.data_ptr(), sb, sc, sy, sx, grad_depth.data_ptr(), grad_ctx.data_ptr(), summary.data_ptr(),
+                            stats.data_ptr() if stats is not None else 0, flags, _stream())
+        if ctx.bf16:
+            grad_ctx = grad_ctx.to(torch.bfloat16)
+        return None, None, None, grad_depth.permute(0, 3, 1, 2), grad_ctx.permute(0, 3, 1, 2), None, None, None, None, None
+
+
+def new_column_summary(B, N, D, fH, fW, device):
+    """Uninitialised column summary of the camera form (include/mmt_hip.h `column_summary`): int32 [B*N, ceil(fH/16), fW, D, 2],
+    8 bytes per (16-row block of a column, depth bin) -- written by a forward, read by its backward and by later forwards
+    of the same calibration."""
+    return torch.empty((B * N, (fH + 15) // 16, fW, D, 2), dtype=torch.int32, device=device)
+
+
+def lift_splat_camera(combine, axes, depth, context, voxel_num, voxel_coord, voxel_size, column_backward=False, column_stats=None,
+                      summary=None, summary_cached=False):
+    """combine fp32 [B,N,4,4], axes = frustum_axes(frustum), depth [B*N,D,fH,fW], context [B*N,C,fH,fW] (fp32, or both bf16)
+    -> BEV fp32 [B,C,ny,nx] (channels_last memory).  voxel_coord / voxel_size: 3 host floats each (the module buffers
+    lss_fpn.py:278-285).  column_stats: optional int64 [2 * _lib.LSS_STATS_SLOTS] CUDA tensor the column backward
+    accumulates (mismatching, kept) point-count pairs into (sum over the pairs = the totals).
+    summary: None (a fresh column summary is written by the forward and read by the backward), or a tensor from
+    new_column_summary kept by the caller across steps: summary_cached=False writes it, summary_cached=True declares that an
+    earlier call wrote it for the SAME combine / axes / grid (unchanged calibration) and the forward reads it instead of
+    computing the geometry."""
+    vc = [float(v) for v in (voxel_coord.tolist() if isinstance(voxel_coord, torch.Tensor) else voxel_coord)]
+    vs = [float(v) for v in (voxel_size.tolist() if isinstance(voxel_size, torch.Tensor) else voxel_size)]
+    return LiftSplatCamera.apply(combine.contiguous(), tuple(axes), (vc, vs), depth, context, voxel_num, bool(column_backward),
+                                 column_stats, summary, bool(summary_cached))

@@ -94,15 +94,18 @@ def test_lssfpn_picks_the_backward_kernel_from_the_geometry(mmt_lib):
     rx = torch.tensor([[1, 0, 0, 0], [0, c_, -s_, 0], [0, s_, c_, 0], [0, 0, 0, 1]], dtype=torch.float32)
     pitched = m.get_geometry_voxels(s2e.matmul(rx).cuda(), K.cuda(), pixel_major=True)
     with torch.no_grad():
-        assert m._use_column_backward(level, None) is False and not m._column_backward_choice     # nothing to decide without a backward
-    assert m._use_column_backward(level, "rig-a") is True
-    assert m._use_column_backward(pitched, "rig-b") is False
-    assert m._use_column_backward(pitched, "rig-a") is True                # remembered per calibration id, not re-measured
+        assert m._use_column_backward(level, None) == (False, None) and not m._column_backward_choice     # nothing to decide without a backward
+    assert m._use_column_backward(level, "rig-a") == (True, None)
+    assert m._use_column_backward(lambda: pitched, "rig-b") == (False, None)      # a callable is evaluated for the one measurement
+    assert m._use_column_backward(pitched, "rig-a") == (True, None)        # remembered per calibration id, not re-measured
     assert m._column_backward_choice == {"rig-a": True, "rig-b": False}
+    # without an id: the column kernel's own counters decide, lazily (tests/test_camera_form_gpu.py); the first answer is "column"
+    col, stats = m._use_column_backward(None, None)
+    assert col is True and stats.dtype == torch.int64 and stats.numel() == 2 * mmt_lib.LSS_STATS_SLOTS and stats.is_cuda
     m.lift_splat_backward = "ray"
-    assert m._use_column_backward(level, "rig-a") is False
+    assert m._use_column_backward(level, "rig-a") == (False, None)
     m.lift_splat_backward = "column"
-    assert m._use_column_backward(pitched, "rig-b") is True
+    assert m._use_column_backward(pitched, "rig-b") == (True, None)
 
 
 def test_lssfpn_cached_plan_matches_uncached(mmt_lib):
