@@ -90,6 +90,9 @@ def parse(argv=None):
                          "the geometry's column summary and the backward-kernel choice are then cached per calibration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
+    ap.add_argument("--hotpath-leg", action="store_true",
+                    help="train mode with --gpus > 1: run rank 0's drop-in voxel_pooling timing after the steps anyway (by default only a "
+                         "1-GPU run does: the other ranks would sit in the final barrier for its seconds)")
     ap.add_argument("--algo", type=int, default=0, help="voxel_pooling forward algorithm flag (hotpath mode)")
     return ap.parse_args(argv)
 
@@ -567,6 +570,11 @@ def train_main(args, rank, local_rank, world):
             b[1]["calibration_id"] = ("synthetic", 1000 * rank + i)
     for i in range(args.warmup):
         ts(batches[i % len(batches)])
+    if os.environ.get("MMT_BENCH_FAIL_RANK") == str(rank):
+        # test hook (tests/test_bench_ranks_gpu.py): this rank dies after its warm-up; the launcher must report it and take
+        # the ranks waiting in the barrier down instead of hanging
+        print(f"[bench] rank {rank}: MMT_BENCH_FAIL_RANK set, exiting with code 3", file=sys.stderr, flush=True)
+        os._exit(3)
     _lib.TIMING = {}
     barrier(world)
     t0 = time.perf_counter()
@@ -684,7 +692,7 @@ def train_main(args, rank, local_rank, world):
             res["roofline_lidar_backward"] = roofline_entry("scatter_backward_nhwc_unique_kernel (pillar scatter backward)", scat_bwd_b,
                                                             _lib.mean_ms(timing["scatter_backward"]),
                                                             pmc_traffic(args.config, ("scatter_backward_nhwc_unique_kernel",)))
-    if cfg["use_cam"] and not args.no_hotpath_leg:
+    if cfg["use_cam"] and not args.no_hotpath_leg and (world == 1 or args.hotpath_leg):
         # the drop-in op at the same shape and geometry, right after the timed steps: the like-for-like figure
         # beside cpu_baseline and the BASELINE metric's "voxel_pooling HBM GB/s"
         gsh = geom.reshape(B, -1, 3).contiguous()

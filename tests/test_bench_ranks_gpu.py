@@ -1,0 +1,53 @@
+"""GPU box: the N > 1 launch path of bench.py with the HIP step -- what the driver's SCALE run starts, rehearsed with two
+ranks sharing the one card (gloo; RCCL refuses two ranks per device).  `python bench.py --gpus 2` is started as a child
+process: it spawns its own two rank processes before importing torch (the reference gets its ranks from Lightning,
+exps/mm_training_aim.py:595-612), they run warm-up + timed DDP steps of the tiny camera + LiDAR model through the HIP
+kernels, and rank 0 prints ONE JSON line."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env=None, *argv, timeout=420):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MMT_BENCH_FAIL_RANK")}
+    env.update(extra_env or {})
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, env=env, timeout=timeout)
+    return out, time.time() - t0
+
+
+def test_bench_two_ranks_on_the_gpu_box(mmt_lib):
+    out, _ = _run(None, "--gpus", "2", "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    c = d["config"]
+    assert c["parallelism"] == "dp2" and c["global_batch"] == 4 and c["mode"] == "train" and c["fused_lift_splat"] is True
+    assert c["final_loss"] == c["final_loss"] and abs(c["final_loss"]) < 1e6
+    assert abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    # the live roofline objects of the kernels inside the timed steps (dispatch-attached events on rank 0)
+    for key in ("roofline", "roofline_backward", "roofline_lidar"):
+        r = d[key]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["achieved"] > 0 and 0 < r["frac"] < 1 and r["avg_ms"] > 0
+    assert c["lift_splat_kernels"]["forward"] in ("tile", "ray", "ray+camera") and c["lift_splat_kernels"]["backward"]
+    # world > 1: rank 0 does not keep the other ranks parked in the final barrier for its own drop-in-op timing leg
+    assert "roofline_voxel_pooling" not in d and "cpu_baseline" not in d
+
+
+def test_bench_reports_a_rank_that_dies_instead_of_hanging(mmt_lib):
+    """rank 1 exits after its warm-up (test hook MMT_BENCH_FAIL_RANK): rank 0 is then blocked in the barrier in front of the
+    timed steps; the launcher must notice, terminate it and exit non-zero -- within seconds, not at a timeout."""
+    out, took = _run({"MMT_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "rank 1 exited with code 3" in out.stderr
+    assert took < 240

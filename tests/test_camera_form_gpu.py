@@ -150,7 +150,8 @@ def test_camera_form_cells_where_the_fast_quantise_must_fall_back(mmt_lib, oracl
 
 
 @pytest.mark.parametrize("cfg", [(2, 3, 37, 16, 9, 80, 0.0), (1, 2, 112, 32, 10, 128, 0.0), (1, 2, 40, 20, 5, 64, 2.0),
-                                 (4, 6, 112, 16, 44, 80, 0.0), (1, 1, 1, 1, 1, 64, 0.0), (3, 3, 17, 17, 2, 64, 5.0)])
+                                 (4, 6, 112, 16, 44, 80, 0.0), (1, 1, 1, 1, 1, 64, 0.0), (3, 3, 17, 17, 2, 64, 5.0),
+                                 (1, 2, 409, 44, 6, 80, 0.0)])          # the aiMotive-native frustum (D = 409, fH = 44) at a reduced width
 @pytest.mark.parametrize("bf16", [False, True])
 def test_camera_form_equals_geom_form(mmt_lib, cfg, bf16):
     """lift_splat_camera == lift_splat(frustum_geometry(...)): forward to fp32 summation order (atomics), both backward
@@ -191,10 +192,11 @@ def test_camera_form_equals_geom_form(mmt_lib, cfg, bf16):
         out_cam.backward(go)
         fam = last_kernel_family(backward=True)
         out_geo.backward(go)
-        assert fam == ("column+camera" if column else "ray+camera") and last_kernel_family(backward=True) == fam.split("+")[0]
+        col_fits = D <= 128                                          # the column kernel's mismatch lists need D <= ~200: D = 409 walks
+        assert fam == ("column+camera" if column and col_fits else "ray+camera") and last_kernel_family(backward=True) == fam.split("+")[0]
         assert torch.equal(d1.grad, d2.grad)
         assert torch.equal(c1.grad, c2.grad)
-        if column:
+        if column and D <= 128:
             gq = geom_pm.long()
             kept = ((gq[..., 0] >= 0) & (gq[..., 0] < vn[0]) & (gq[..., 1] >= 0) & (gq[..., 1] < vn[1])
                     & (gq[..., 2] >= 0) & (gq[..., 2] < vn[2])).sum().item()

@@ -218,7 +218,11 @@ def test_fused_lift_splat_equals_lift_then_pool(mmt_lib, oracle_mod, cfg):
 @pytest.mark.parametrize("kernels", ["ray", "tiles", "column"])
 @pytest.mark.parametrize("cfg", [(1, 2, 13, 5, 7, 64, "rig"), (2, 3, 37, 16, 9, 80, "rig"), (1, 1, 112, 32, 10, 128, "rig"),
                                  (1, 2, 21, 3, 5, 80, "uniform"), (2, 2, 16, 16, 6, 48, "rig"), (1, 2, 40, 20, 5, 80, "pitched"),
-                                 (1, 1, 1, 1, 1, 64, "uniform"), (1, 3, 2, 1, 3, 80, "uniform"), (3, 3, 17, 17, 2, 64, "rig")])
+                                 (1, 1, 1, 1, 1, 64, "uniform"), (1, 3, 2, 1, 3, 80, "uniform"), (3, 3, 17, 17, 2, 64, "rig"),
+                                 # the reference's native aiMotive frustum (exps/conf_aim.py:16-18,42-52: D = 409, fH = 44, C = 80, 512 x 64
+                                 # grid) at a reduced width: the forward splits the ray into depth slabs, the ray backward's LDS request
+                                 # is 64 896 of 65 536 bytes, the column kernel does not take D = 409 (its request falls back to the walk)
+                                 (1, 2, 409, 44, 6, 80, "aim")])
 def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, monkeypatch):
     """mmt_lss_splat_forward / _backward, ray walks (default), frustum tiles (MMT_LSS_TILE_KERNELS) and the matrix-core column
     backward (MMT_LSS_COLUMN_BACKWARD; "uniform" = every point a mismatch, "pitched" = a few per cent), both point orders, on
@@ -230,6 +234,10 @@ def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, m
     monkeypatch.setenv("MMT_LIFT_SPLAT_TILES", "1" if kernels == "tiles" else "0")
     if kind == "rig":
         geom, vn = synthetic.rig_geometry(B, N, (fH * 16, fW * 16), 16, (2.0, 2.0 + 0.5 * D, 0.5))
+    elif kind == "aim":
+        geom, vn = synthetic.rig_geometry(B, N, (fH * 16, fW * 16), 16, (1.0, 1.0 + 0.5 * D, 0.5), x_bound=(-204.8, 204.8, 0.8),
+                                          y_bound=(-25.6, 25.6, 0.8), z_bound=(-5.0, 3.0, 8.0))
+        assert vn == [512, 64, 1] and tuple(geom.shape) == (B, N, D, fH, fW, 3)
     elif kind == "pitched":      # cameras pitched by 2 degrees: the pixels of a column do not all share their cell
         import math
         s2e, K = synthetic.camera_rig(B, N, fW * 16, fH * 16, jitter=0.02, seed=0)
@@ -266,6 +274,12 @@ def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, m
         out = lift_splat(gm, d1, c1, vn, pixel_major=pm, column_backward=kernels == "column")
         assert np.abs(out.detach().permute(0, 2, 3, 1).cpu().numpy() - ref).max() <= 1e-4
         out.backward(go.cuda().contiguous(memory_format=torch.channels_last))
+        # which family ran is reported, so a fallback forced by an LDS budget or a channel count is visible (and asserted here)
+        from mm_training_amd.ops.bev_geometry import last_kernel_family
+        fits_ray = C in (64, 80, 128)
+        assert last_kernel_family() == ("tile" if kernels == "tiles" or not fits_ray else "ray")
+        want_b = "tile" if kernels == "tiles" else ("column" if kernels == "column" and fits_ray and D <= 128 else "ray")
+        assert last_kernel_family(backward=True) == want_b, (last_kernel_family(backward=True), want_b)
         assert torch.allclose(d1.grad.cpu().double().view_as(dd), dd.grad, rtol=1e-4, atol=1e-5)
         assert torch.allclose(c1.grad.cpu().double().view_as(cc), cc.grad, rtol=1e-4, atol=1e-4)
     if kernels != "column":      # the optional pos_memo output of the C entry point (the op passes NULL): exactly the drop-in op's
@@ -288,7 +302,7 @@ def test_lss_kernel_families_against_oracle(mmt_lib, oracle_mod, cfg, kernels, m
         from mm_training_amd.ops.bev_geometry import column_mismatch_fraction
         frac = float(column_mismatch_fraction(geom.cuda(), vn))
         assert frac == float(column_mismatch_fraction(geom.cuda().permute(0, 1, 3, 4, 2, 5).contiguous(), vn, pixel_major=True))
-        assert (frac == 0.0) if (kind == "rig" and fH <= 16) or fH == 1 else (frac > 0.0 if kind != "rig" else True)
+        assert (frac == 0.0) if (kind == "rig" and fH <= 16) or fH == 1 else (frac > 0.0 if kind not in ("rig", "aim") else True)
 
 
 def test_fused_geometry_on_reference_nuscenes_calibration(mmt_lib, oracle_mod, golden):
