@@ -19,6 +19,8 @@ What is executed from the reference:
   * layers/backbones/lss_fpn.py LSSFPN.__init__ buffers (:278-289), create_frustum
     (:308-326), get_geometry (:328-361) and the quantise expression (:461-462,
     evaluated from the module's source text at run time).
+  * layers/backbones/lss_fpn.py LSSFPN._forward_single_sweep / forward (:381-529) as a whole -- flipped cameras,
+    oracle depth, two sweeps -- with the conv nets replaced by the identity (lss_forward.npz).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -103,12 +105,65 @@ def _install_stubs():
     ext.voxel_pooling_forward_wrapper = voxel_pooling_forward_wrapper
     sys.modules["ops.voxel_pooling.voxel_pooling_ext"] = ext
     sys.path.insert(0, REF)
+    # `ops`, `layers`, `models` must be the REFERENCE's packages: this repository's root-level alias packages of the same
+    # names (regular packages) would otherwise win over the reference's `ops/` (a namespace package: no __init__.py)
+    for name in ("ops", "layers", "models"):
+        assert name not in sys.modules, name
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REF, name)]
+        sys.modules[name] = pkg
 
 
 def _ref_source_lines(relpath, lo, hi):
     with open(os.path.join(REF, relpath)) as f:
         lines = f.readlines()
     return textwrap.dedent("".join(lines[lo - 1:hi]))
+
+
+def _bounds_expression():
+    """The drop test of the reference's known-answer loop (test/test_ops/test_voxel_pooling.py:28, the `if` of the loop at
+    :23-30), read from the file at run time and turned into an elementwise numpy predicate over (x, y, z, nx, ny, nz)."""
+    cands = [l.strip() for l in _ref_source_lines("test/test_ops/test_voxel_pooling.py", 23, 30).splitlines() if l.strip().startswith("if ")]
+    assert len(cands) == 1, cands
+    mm = re.match(r"if (.+):$", cands[0])
+    assert mm, cands[0]
+    terms = [t.strip() for t in mm.group(1).split(" or ")]
+    assert len(terms) == 6, terms
+    expr = " | ".join("(" + t + ")" for t in terms)
+    expr = re.sub(r"\b128\b", "N_X_OR_Y", expr)       # the test's grid is 128 x 128 x 1: generalise the literals per coordinate
+    parts = expr.split(" | ")
+    out = []
+    for t in parts:
+        coord = t[1]
+        t = t.replace("N_X_OR_Y", {"x": "nx", "y": "ny"}.get(coord, "nz"))
+        if coord == "z":
+            t = re.sub(r">= 1\)", ">= nz)", t)
+        out.append(t)
+    return " | ".join(out)
+
+
+def independent_pos_memo(geom, nx, ny, nz):
+    """pos_memo WITHOUT the oracle: the reference test's own drop predicate on numpy arrays + the (b, y, x) row layout of
+    voxel_pooling_forward_cuda.cu:27-29; dropped rows keep the caller's -1 (voxel_pooling.py:40)."""
+    x, y, z = (geom[..., i].astype(np.int64) for i in range(3))
+    drop = eval(_bounds_expression(), {"x": x, "y": y, "z": z, "nx": nx, "ny": ny, "nz": nz})
+    pos = np.full(geom.shape, -1, np.int32)
+    b = np.broadcast_to(np.arange(geom.shape[0]).reshape(-1, *([1] * (geom.ndim - 2))), x.shape)
+    pos[..., 0] = np.where(drop, -1, b)
+    pos[..., 1] = np.where(drop, -1, y)
+    pos[..., 2] = np.where(drop, -1, x)
+    return pos
+
+
+def check_pos_memo_against_reference_backward(pos, grad_out_nchw, grad_in):
+    """The reference's OWN backward (voxel_pooling.py:58-69, pure ATen) consumed the pos_memo its forward stub wrote; its
+    grad_in must be exactly grad_out[b, :, y, x] on the rows the independent pos_memo keeps and 0 elsewhere."""
+    B, P, C = grad_in.shape
+    kept = pos[..., 0] != -1
+    want = np.zeros_like(grad_in)
+    bb, yy, xx = pos[..., 0][kept], pos[..., 1][kept], pos[..., 2][kept]
+    want[kept] = grad_out_nchw[bb, :, yy, xx]
+    assert np.array_equal(want, grad_in)
 
 
 # -------------------------------------------------------------------- fixtures
@@ -132,10 +187,13 @@ def make_vp_ref_test():
     out.backward(grad_out)
     grad_in = feats.grad.reshape(2, -1, 80)
 
-    # pos_memo is not returned by the reference op; recover it exactly as the
-    # reference computes it by running the same stub on fresh buffers
-    _, pos_memo = oracle.voxel_pooling_forward(geom_i.numpy(), features.reshape(2, -1, 80).numpy(),
-                                               128, 128, 1)
+    # pos_memo is not returned by the reference op.  It is derived here WITHOUT the oracle (the reference test's own drop
+    # predicate, evaluated with numpy), validated against the reference's own backward output, and only then compared with
+    # what the oracle writes -- so the stored array pins the oracle instead of being its output.
+    pos_memo = independent_pos_memo(geom_i.numpy(), 128, 128, 1)
+    check_pos_memo_against_reference_backward(pos_memo, grad_out.numpy(), grad_in.numpy())
+    _, pos_oracle = oracle.voxel_pooling_forward(geom_i.numpy(), features.reshape(2, -1, 80).numpy(), 128, 128, 1)
+    assert np.array_equal(pos_memo, pos_oracle)
     np.savez_compressed(
         os.path.join(HERE, "vp_ref_test.npz"),
         geom_float=geom_f.numpy(), geom=geom_i.numpy(),
@@ -175,7 +233,9 @@ def make_vp_edge():
         o = voxel_pooling(torch.from_numpy(geom), f, torch.tensor([nx, ny, nz]))
         go = torch.from_numpy(rng.standard_normal(tuple(o.shape)).astype(np.float32))
         o.backward(go)
-        _, pm = oracle.voxel_pooling_forward(geom, feats, nx, ny, nz)
+        pm = independent_pos_memo(geom, nx, ny, nz)                        # oracle-independent (see make_vp_ref_test)
+        check_pos_memo_against_reference_backward(pm, go.numpy(), f.grad.numpy())
+        assert np.array_equal(pm, oracle.voxel_pooling_forward(geom, feats, nx, ny, nz)[1])
         out[name + "_geom"] = geom
         out[name + "_feats"] = feats
         out[name + "_out_nchw"] = o.detach().numpy()
@@ -322,6 +382,73 @@ def make_quant_and_geom():
     return xyz.numpy(), q.numpy()
 
 
+def make_lss_forward():
+    """The caller's branches around the op, from the reference's own LSSFPN._forward_single_sweep / forward
+    (layers/backbones/lss_fpn.py:381-468, :469-529) run UNMODIFIED on CPU tensors: the softmax taken BEFORE the per-camera
+    un-flip of depth_feature (:423-425), the oracle-depth overwrite (:427-438), the lift (:441-443), get_geometry + quantise
+    + voxel_pooling (:455-465, the extension call answered by the C oracle), the older sweeps under no_grad and the channel
+    stacking (:516-529), plus the gradient the reference's autograd sends back to the network output.
+    Stand-ins, all outside the lines under test: get_cam_feats returns the "images" as they are (the fixture's images ARE
+    the neck features), the depth net is the identity (depth_feature = features: no arithmetic, so both sides see the same
+    bits), kornia's hflip is torch.flip(-1) (its documented definition; kornia is not vendored), Tensor.cuda is a no-op."""
+    import layers.backbones.lss_fpn as ref_lss
+    D_BOUND, DIM, DS, C = [2.0, 26.0, 2.0], (64, 96), 16, 64
+    bounds = ([-25.6, 25.6, 0.8], [-25.6, 25.6, 0.8], [-5, 3, 8])
+    ref_lss.LSSFPN._configure_depth_net = lambda self, conf: torch.nn.Identity()
+    ref_lss.build_backbone = lambda conf: _Dummy()
+    ref_lss.build_neck = lambda conf: _Dummy()
+    m = ref_lss.LSSFPN(*bounds, D_BOUND, DIM, DS, C, {}, {}, {})
+    m.get_cam_feats = lambda imgs: imgs
+    m._forward_depth_net = lambda feat, mats: feat
+    ref_lss.kornia = types.SimpleNamespace(geometry=types.SimpleNamespace(transform=types.SimpleNamespace(hflip=lambda t: t.flip(-1))))
+    D = m.depth_channels
+    fH, fW = DIM[0] // DS, DIM[1] // DS
+    B, S, N = 2, 2, 2
+    rng = np.random.default_rng(11)
+    s2e = np.zeros((B, S, N, 4, 4), np.float32)
+    K = np.zeros((B, S, N, 4, 4), np.float32)
+    for k in range(S):
+        a, b_ = _rig(B, N, DIM[1], DIM[0], seed=20 + k)
+        s2e[:, k], K[:, k] = a, b_
+        s2e[:, k, :, 0, 3] += 0.7 * k                         # the older sweep saw the scene from elsewhere
+    out = dict(d_bound=np.array(D_BOUND), final_dim=np.array(DIM, np.int32), ds=np.int32(DS), channels=np.int32(C),
+               bounds=np.array(bounds, np.float64), sensor2ego=s2e, intrin=K)
+    cuda_attr = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for case, (use_oracle, sweeps) in {"flip": (False, 2), "oracle": (True, 2), "single": (True, 1)}.items():
+            imgs = torch.from_numpy(rng.standard_normal((B, sweeps, N, D + C, fH, fW)).astype(np.float32)).requires_grad_(True)
+            flipped = np.array([True, False, False, True])[:B * N]
+            oracle_t = None
+            if use_oracle:
+                o = np.zeros((B * N, D, fH, fW), np.float32)
+                fg = rng.random((B * N, fH, fW)) < 0.5                               # foreground pixels carry a (soft) one-hot
+                hot = rng.integers(0, D, (B * N, fH, fW))
+                for idx in np.argwhere(fg):
+                    o[idx[0], hot[tuple(idx)], idx[1], idx[2]] = 0.75
+                    o[idx[0], (hot[tuple(idx)] + 1) % D, idx[1], idx[2]] = 0.25
+                oracle_t = torch.from_numpy(o)
+            mats = dict(sensor2ego_mats=torch.from_numpy(s2e[:, :sweeps]), intrin_mats=torch.from_numpy(K[:, :sweeps]),
+                        bda_mat=torch.eye(4).repeat(B, 1, 1), flipped=flipped.tolist())
+            bev, depth = m.forward(imgs, mats, oracle_t, None, is_return_depth=True)
+            assert tuple(bev.shape) == (B, sweeps * C, int(m.voxel_num[1]), int(m.voxel_num[0])) and tuple(depth.shape) == (B * N, D, fH, fW)
+            go = torch.from_numpy(hashed_f32(tuple(bev.shape), salt=31 + sweeps))
+            bev.backward(go)
+            assert imgs.grad[:, 1:].abs().max().item() == 0.0 if sweeps > 1 else True        # older sweeps: no_grad (:516-524)
+            out[case + "_imgs"] = imgs.detach().numpy()
+            out[case + "_flipped"] = flipped
+            if use_oracle:
+                out[case + "_depth_oracle"] = oracle_t.numpy()
+            out[case + "_bev"] = bev.detach().numpy()
+            out[case + "_depth"] = depth.detach().numpy()
+            out[case + "_grad_imgs"] = imgs.grad.numpy()
+            out[case + "_grad_out_salt"] = np.int32(31 + sweeps)
+            print("lss_forward", case, "bev", tuple(bev.shape), "nonzero cells", int((bev.detach().abs().sum(1) > 0).sum()))
+    finally:
+        torch.Tensor.cuda = cuda_attr
+    np.savez_compressed(os.path.join(HERE, "lss_forward.npz"), **out)
+
+
 def make_depth_labels():
     """Depth supervision labels from the reference's own methods:
     exps/mm_training_aim.py get_depth_labels (:114-140), get_depth_image (:142-163) and
@@ -398,9 +525,12 @@ def main():
     oracle.build()
     if "--only-depth-labels" in sys.argv:
         return make_depth_labels()
+    if "--only-lss-forward" in sys.argv:
+        return make_lss_forward()
     make_vp_ref_test()
     make_vp_edge()
     make_quant_and_geom()
+    make_lss_forward()
     make_depth_labels()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

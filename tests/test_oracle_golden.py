@@ -13,6 +13,8 @@ def test_forward_matches_reference_known_answer_test(oracle_mod, golden):
     out, pos = oracle_mod.voxel_pooling_forward(g["geom"], g["feats"], 128, 128, 1)
     # bit-exact: same sequential fp32 order as test/test_ops/test_voxel_pooling.py:23-30
     assert np.array_equal(out, g["out_nhwc"])
+    # the stored pos_memo is NOT the oracle's output: make_golden.py derives it with numpy from the reference test's own
+    # drop predicate and checks it against the reference's own backward before saving (independent_pos_memo)
     assert np.array_equal(pos, g["pos_memo"])
     # the reference's own acceptance criterion (test_voxel_pooling.py:35-37)
     assert torch.allclose(torch.from_numpy(out), torch.from_numpy(g["out_nhwc"]), rtol=1e-3)
