@@ -93,6 +93,26 @@ def test_voxelize_overfull_voxels_and_voxel_cap(mmt_lib, oracle_mod):
     _check(oracle_mod, _frames([3000], dense=True, seed=4), 3, 50)
 
 
+def test_voxelize_cells_spread_over_many_tiles(mmt_lib, oracle_mod):
+    """Every cell's points lie in DIFFERENT 256-point tiles, far apart: while the workgroup of a cell's first point is
+    already replacing the cell's table entry by (owned | voxel id), later tiles still start their walks from that entry
+    (the two used to be separate kernels; a walker reading the voxel id as a point index faulted).  Repeated on one table."""
+    g = torch.Generator().manual_seed(17)
+    clouds = []
+    for n, ncell in ((60000, 900), (33000, 5000)):
+        cx = torch.randint(0, 2048, (ncell,), generator=g).float() * 0.2 + RANGE[0] + 0.1
+        cy = torch.randint(0, 256, (ncell,), generator=g).float() * 0.2 + RANGE[1] + 0.1
+        pick = torch.arange(n) % ncell                       # point i and point i + ncell share a cell: ~3.5 / 20 tiles apart
+        pts = torch.rand(n, 5, generator=g)
+        pts[:, 0] = cx[pick] + (pts[:, 0] - 0.5) * 0.15
+        pts[:, 1] = cy[pick] + (pts[:, 1] - 0.5) * 0.15
+        pts[:, 2] = pts[:, 2] * 6 - 4
+        clouds.append(pts)
+    for _ in range(3):
+        _check(oracle_mod, clouds, 15, 25000)
+        _check(oracle_mod, clouds, 4, 700)                   # voxel cap hit: first points past it leave their entries unmarked
+
+
 def test_voxelize_boundaries_and_nonfinite(mmt_lib, oracle_mod):
     pts = torch.zeros(64, 5)
     edge = [RANGE[0], RANGE[0] - 1e-4, RANGE[3], RANGE[3] - 1e-4, 0.0, 0.2, 0.19999, -0.0]
