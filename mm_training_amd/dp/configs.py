@@ -80,12 +80,12 @@ def make_config(name="cfg2"):
         point_features=8 if use_radar else 5,
         point_cloud_range=pc_range, backbone_conf=backbone_conf, head_conf=head_conf, lidar_conf=lidar_conf,
         fuse_layer_in_channels=fuse_channels,
-        # BASELINE configs[4] asks for bf16; on this image (PyTorch 2.10+rocm7.0 / MIOpen) the bf16
-        # channels_last conv path intermittently raises "Memory access fault by GPU" and yields NaN
-        # activations for this model (reproduced with the HIP ops of this repo taken out of the
-        # picture: the individual ops and the whole fp32 model run clean at the cfg-5 shapes), so the
-        # dense nets stay fp32 here; TrainStep(amp="bf16") opts in.  The hot-path ops are fp32 either way.
-        dtype="f32",
+        # BASELINE configs[4] asks for bf16: cfg5 runs its dense nets under torch.autocast(bf16) (TrainStep.amp_dtype) and keeps
+        # the hot-path operands in bf16 (hot_path_dtype below); the other configurations train in fp32 like the reference
+        # (exps/conf_aim.py:30).  Round 2 had left cfg5's nets in fp32 because the autocast step died with "Memory access fault
+        # by GPU": tools/repro_bf16_fault.py bisected that to THIS repository's pillar scatter reading the bf16 output of the
+        # learned pillar MLP (nn.Linear under autocast) as fp32 rows, not to MIOpen -- fixed (lidar/encoder.py), 200 steps clean.
+        dtype="bf16" if name == "cfg5" else "f32",
         # storage type of the hot-path operands (depth / context / lifted features and their gradients); accumulation
         # is fp32 either way.  BASELINE configs[4] names bf16: SURVEY 5.6 defines it as bf16 storage + fp32 accumulate.
         hot_path_dtype="bf16" if name == "cfg5" else "f32",

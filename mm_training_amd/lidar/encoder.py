@@ -148,6 +148,8 @@ def simple_vfe(voxels, num_points, num_features):
     """HardSimpleVFE: voxels[:, :, :num_features].sum(1) / num_points -> [M, num_features]."""
     if not voxels.is_cuda:
         raise RuntimeError("voxels must be a CUDAtensor ")
+    if voxels.dtype != torch.float32 or num_points.dtype != torch.int32:
+        raise RuntimeError("simple_vfe: voxels must be float32 and num_points int32")
     M, T, F = voxels.shape
     out = torch.empty((M, num_features), dtype=torch.float32, device=voxels.device)
     if M:
@@ -157,12 +159,22 @@ def simple_vfe(voxels, num_points, num_features):
     return out
 
 
+def _fp32_rows(feats, name):
+    """The scatter kernels read fp32 rows.  Under autocast a learned pillar MLP hands over bf16 features (nn.Linear is on
+    autocast's cast list): torch.amp.custom_fwd casts them back, and this check turns any other way of getting a
+    non-fp32 tensor here into an exception instead of an out-of-bounds read on the device."""
+    if feats.dtype != torch.float32:
+        raise RuntimeError(f"expected scalar type Float but found {feats.dtype} for {name}")
+    return feats.contiguous()
+
+
 class _PillarScatter(Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, feats, coors, batch_size, ny, nx, channels_last):
         if not feats.is_cuda:
             raise RuntimeError("voxel_features must be a CUDAtensor ")
-        feats = feats.contiguous()
+        feats = _fp32_rows(feats, "voxel_features")
         coors = coors.contiguous()
         if coors.dtype != torch.int32:
             coors = coors.int()
@@ -182,9 +194,11 @@ class _PillarScatter(Function):
         return canvas.permute(0, 3, 1, 2) if nhwc else canvas
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_canvas):
         coors, cell_map = ctx.saved_tensors
         M, C, B, ny, nx, nhwc = ctx.dims
+        grad_canvas = grad_canvas.float()
         grad_feats = torch.empty((M, C), dtype=torch.float32, device=grad_canvas.device)
         if M:
             if nhwc:
@@ -203,8 +217,9 @@ class _PillarScatterTable(Function):
     table (mmt_pillar_scatter_nhwc_table): the rows own distinct cells, no cell -> row map is built."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, feats, coors, table, batch_size, ny, nx, max_voxels):
-        feats = feats.contiguous()
+        feats = _fp32_rows(feats, "voxel_features")
         M, C = feats.shape
         canvas = torch.empty((batch_size, ny, nx, C), dtype=torch.float32, device=feats.device)
         with torch.cuda.device(feats.device):
@@ -215,9 +230,11 @@ class _PillarScatterTable(Function):
         return canvas.permute(0, 3, 1, 2)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_canvas):
         (coors,) = ctx.saved_tensors
         M, C, B, ny, nx = ctx.dims
+        grad_canvas = grad_canvas.float()
         grad_feats = torch.empty((M, C), dtype=torch.float32, device=grad_canvas.device)
         if not grad_canvas.is_contiguous(memory_format=torch.channels_last):
             grad_canvas = grad_canvas.contiguous(memory_format=torch.channels_last)

@@ -77,6 +77,33 @@ def test_training_step_decreases_loss(mmt_lib, fused):
     assert ts.model.backbone.depth_net.context_se.conv_reduce.weight.grad is None
 
 
+def test_training_step_under_bf16_autocast(mmt_lib):
+    """BASELINE configs[4] names bf16: the whole model under torch.autocast(bf16).  Every op of this repository that reads
+    fp32 rows must survive what autocast hands it -- the learned pillar MLP (nn.Linear) returns bf16 features, which the
+    pillar scatter used to read as fp32 rows: an out-of-bounds read that took the process down with "Memory access fault by
+    GPU" (tools/repro_bf16_fault.py; round 2 blamed MIOpen for it)."""
+    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
+    from mm_training_amd.lidar import pillar_scatter
+    cfg = make_config("tiny")
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    ts = TrainStep(cfg, dev, lr=2e-4, amp="bf16")
+    assert ts.amp_dtype == torch.bfloat16 and ts.model.lidar_encoder.pillar_mlp is not None
+    batch = synthetic_batch(cfg, dev, seed=3)
+    losses = [float(ts(batch)[0]) for _ in range(6)]
+    assert all(l == l and abs(l) < 1e6 for l in losses) and losses[-1] < losses[0]
+    # the op itself: bf16 rows under autocast are cast, bf16 rows without autocast are refused (never read as fp32)
+    feats = torch.randn(50, 8, device=dev)
+    coors = torch.stack([torch.zeros(50), torch.zeros(50), torch.arange(50) // 10, torch.arange(50) % 10], 1).int().to(dev)
+    ref = pillar_scatter(feats, coors, 1, 8, 16, channels_last=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        got = pillar_scatter(feats.bfloat16(), coors, 1, 8, 16, channels_last=True)
+    assert got.dtype == torch.float32 and torch.equal(got, pillar_scatter(feats.bfloat16().float(), coors, 1, 8, 16, channels_last=True))
+    assert (got - ref).abs().max().item() < 0.05
+    with pytest.raises(RuntimeError, match="Float"):
+        pillar_scatter(feats.bfloat16(), coors, 1, 8, 16)
+
+
 def test_lssfpn_picks_the_backward_kernel_from_the_geometry(mmt_lib):
     """LSSFPN.lift_splat_backward = "auto": the matrix-core column backward for a rig whose columns are level (no kept point
     leaves its column's cell), the ray walk otherwise; decided once per calibration id; "ray" / "column" override it."""
