@@ -640,10 +640,11 @@ def train_main(args, rank, local_rank, world):
                     "auto: per calibration id, from the geometry" if args.calibration_ids else
                     "auto: from the column kernel's own counters, read back lazily (share of kept points outside their column's cell: %s)"
                     % (None if adaptive is None else adaptive["share"]))}
-            key_f = "lift_splat_forward_tile" if tiles else ("lift_splat_forward_camera" if camera else "lift_splat_forward")
-            key_b = "lift_splat_backward_tile" if tiles else (("lift_splat_backward_column" if column else "lift_splat_backward") + ("_camera" if camera else ""))
-            res["roofline"] = roofline_entry(f"{kfwd}{sfx} (+ lss_zero_fill; fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
-                                             pmc_traffic(args.config, (key_f,)), l2f, note)
+            key_f = ("lift_splat_forward_tile" if tiles else ("lift_splat_forward_camera" if camera else "lift_splat_forward")) + sfx
+            key_b = ("lift_splat_backward_tile" if tiles else (("lift_splat_backward_column" if column else "lift_splat_backward") + ("_camera" if camera else ""))) + sfx
+            # the timed sequence of the forward is the zero fill + the kernel: so is its traffic
+            res["roofline"] = roofline_entry(f"lss_zero_fill + {kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
+                                             pmc_traffic(args.config, (key_f, "lss_zero_fill")), l2f, note)
             atomic_bytes = None
             try:
                 atomic_bytes = float(json.load(open(os.path.join(ROOT, "profiles", f"r03_pmc_{args.config}.json")))["kernels"][key_f]["atomic_bytes"])

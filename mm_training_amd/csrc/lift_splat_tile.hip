@@ -19,6 +19,8 @@
 //
 // Workgroups of one camera are dealt to the same XCD (blockIdx & 7), so the geom / depth lines shared by neighbouring
 // columns and the camera's context rows are fetched into one L2 -- placement affects speed only.
+#include <type_traits>
+
 #include "mmt_camera.h"
 
 namespace {
@@ -480,6 +482,7 @@ struct RayArgs {
     int BN, N, D, fH, fW, C, nx, ny, nz;
     int pm, write_dropped;
     int dsplit, dspan, kd;         // forward: depth slabs per ray, bins per slab, bins per lane group
+    int compact;                   // forward: walk only the depth bins that hold a kept point (long rays: most far bins are empty)
     int wpc;                       // backward: workgroups per camera
     const int32_t *geom;           // geom form: int32 voxel indices per point; camera form (template CAM): unused
     const float *combine, *fu, *fv, *fd;   // camera form: [B*N, 16] matrices and the frustum's three axes (mmt_camera.h)
@@ -536,65 +539,91 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
     const int dnp = a.dspan | 1;
     float *ctx = ray_lds;
     int2 *rec = reinterpret_cast<int2 *>(ray_lds + fH * CP);
+    // which depth bins of this column hold a kept point at all (the walk skips the others: beyond the grid the far bins of a
+    // ray are empty in every row -- 84 % of all points at the reference's native 409-bin frustum), and their compacted list
+    int *binkept = reinterpret_cast<int *>(rec + (size_t)fH * dnp);
+    int *klist = binkept + a.dspan;
+    __shared__ int s_nkb;
 
     // ---- all threads: geometry -> (cell, depth) records
     // camera form: the voxel index of a point is computed here from the camera's matrix and the frustum axes, with the
     // arithmetic of mmt_frustum_geometry (mmt_camera.h) -- no geom tensor is read
     const int npts = fH * dn;
     if constexpr (CAM) {
-        // a thread takes ONE depth bin of a block of 16 image rows: for a fixed (camera, column, bin) the coordinates are
-        // monotone in the row, so two (x, y) quantisations and 16 exact z range tests settle the block (mmt_camera.h)
+        // a thread takes ONE depth bin of a block of 16 image rows, 8 rows at a time (two passes keep the register count at
+        // that of the walk): for a fixed (camera, column, bin) the coordinates are monotone in the row, so two (x, y)
+        // quantisations and 8 exact z range tests settle a pass (mmt_camera.h)
         float cm[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) cm[k] = a.combine[bn * 16 + k];
         const float cu = a.fu[col];
+        const int64_t rstep = a.pm ? (int64_t)a.fW * a.D : a.fW;              // points between consecutive image rows
+#pragma unroll 1
         for (int r0 = 0; r0 < fH; r0 += 16) {
             const int nr = (fH - r0) < 16 ? (fH - r0) : 16;
-            float cv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) cv[u] = a.fv[r0 + (u < nr ? u : nr - 1)];
-            const bool sorted = mmt_rows_sorted<16>(cv, nr);
-            const int64_t rstep = a.pm ? (int64_t)a.fW * a.D : a.fW;          // points between consecutive image rows
+#pragma unroll 1
             for (int dd = tid; dd < dn; dd += kBlock) {
-                const int64_t t0 = ray_point(a, bn, r0, col, d0 + dd);
-                float dv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) dv[u] = Elem<FT>::scalar(depth + t0 + (u < nr ? u : nr - 1) * rstep);
                 const mmt_cam_column cc = mmt_cam_column_make(cm, cu, a.fd[d0 + dd]);
-                bool uniform, in0;
-                int x0, y0;
-                unsigned zmask;
                 int2 *sum = a.summary ? a.summary + (((int64_t)bn * ((fH + 15) >> 4) + (r0 >> 4)) * a.fW + col) * a.D + d0 + dd : nullptr;
-                if (sum && a.summary_cached) {          // the calibration is the one the summary was written for
-                    const int2 sv = *sum;
-                    in0 = sv.x >= 0; x0 = sv.x & 0xFFFF; y0 = sv.x >> 16;
-                    zmask = (unsigned)sv.y & 0xFFFFu;
-                    uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
-                } else {
-                    zmask = mmt_cam_column_cells<16>(cc, cv, nr, sorted, a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
-                    if (sum) *sum = make_int2(in0 ? ((y0 << 16) | x0) : -1, (int)zmask | (uniform ? mmt::kSummaryUniform : 0));
-                }
-                const int cell0 = in0 ? (b * a.ny + y0) * a.nx + x0 : -1;
+                const bool cached = sum && a.summary_cached;                   // the calibration is the one the summary was written for
+                int2 sv = make_int2(-1, 0);
+                if (cached) sv = *sum;
+                unsigned zm16 = 0;
+                bool uni16 = true, in00 = false, any = false;
+                int x00 = 0, y00 = 0;
+#pragma unroll 1
+                for (int hb = 0; hb < 16; hb += 8) {
+                    if (hb >= nr) break;
+                    const int nh = (nr - hb) < 8 ? (nr - hb) : 8;
+                    const int64_t t0 = ray_point(a, bn, r0 + hb, col, d0 + dd);
+                    float dv[8], cv[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    if (u < nr) {
-                        int gx = x0, gy = y0, cell = cell0;
-                        if (!uniform) cell = mmt_cam_row_xy(cc, cv[u], a.q, a.nx, a.ny, gx, gy) ? (b * a.ny + gy) * a.nx + gx : -1;
-                        const bool keep = ((zmask >> u) & 1u) && cell >= 0;
-                        rec[(r0 + u) * dnp + dd] = make_int2(keep ? cell : -1, keep ? __float_as_int(dv[u]) : 0);
-                        if (a.pos_memo) {
-                            const int64_t t = t0 + u * rstep;
-                            if (keep) {
-                                a.pos_memo[t * 3] = b; a.pos_memo[t * 3 + 1] = gy; a.pos_memo[t * 3 + 2] = gx;
-                            } else if (a.write_dropped) {
-                                a.pos_memo[t * 3] = -1; a.pos_memo[t * 3 + 1] = -1; a.pos_memo[t * 3 + 2] = -1;
+                    for (int u = 0; u < 8; ++u) {
+                        dv[u] = Elem<FT>::scalar(depth + t0 + (u < nh ? u : nh - 1) * rstep);
+                        cv[u] = a.fv[r0 + hb + (u < nh ? u : nh - 1)];
+                    }
+                    bool uniform, in0;
+                    int x0, y0;
+                    unsigned zmask;
+                    if (cached) {
+                        in0 = sv.x >= 0; x0 = sv.x & 0xFFFF; y0 = sv.x >> 16;
+                        zmask = ((unsigned)sv.y >> hb) & 0xFFu;
+                        uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
+                    } else {
+                        zmask = mmt_cam_column_cells<8>(cc, cv, nh, mmt_rows_sorted<8>(cv, nh), a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
+                        zm16 |= zmask << hb;
+                        if (hb == 0) { uni16 = uniform; in00 = in0; x00 = x0; y00 = y0; }
+                        else uni16 = uni16 && uniform && in0 == in00 && x0 == x00 && y0 == y00;
+                    }
+                    const int cell0 = in0 ? (b * a.ny + y0) * a.nx + x0 : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < nh) {
+                            int gx = x0, gy = y0, cell = cell0;
+                            if (!uniform) cell = mmt_cam_row_xy(cc, cv[u], a.q, a.nx, a.ny, gx, gy) ? (b * a.ny + gy) * a.nx + gx : -1;
+                            const bool keep = ((zmask >> u) & 1u) && cell >= 0;
+                            any = any || keep;
+                            rec[(r0 + hb + u) * dnp + dd] = make_int2(keep ? cell : -1, keep ? __float_as_int(dv[u]) : 0);
+                            if (a.pos_memo) {
+                                const int64_t t = t0 + u * rstep;
+                                if (keep) {
+                                    a.pos_memo[t * 3] = b; a.pos_memo[t * 3 + 1] = gy; a.pos_memo[t * 3 + 2] = gx;
+                                } else if (a.write_dropped) {
+                                    a.pos_memo[t * 3] = -1; a.pos_memo[t * 3 + 1] = -1; a.pos_memo[t * 3 + 2] = -1;
+                                }
                             }
                         }
                     }
                 }
+                if (sum && !cached) *sum = make_int2(in00 ? ((y00 << 16) | x00) : -1, (int)zm16 | (uni16 ? mmt::kSummaryUniform : 0));
+                if (a.compact) binkept[dd] = (r0 == 0 ? 0 : binkept[dd]) | (any ? 1 : 0);     // this thread owns bin dd in every row block
             }
         }
-    } else
+    } else {
+    if (a.compact) {
+        for (int dd = tid; dd < dn; dd += kBlock) binkept[dd] = 0;
+        __syncthreads();
+    }
     for (int p0 = tid; p0 < npts; p0 += kBlock * 4) {
         int gx[4], gy[4], gz[4];
         float dv[4];
@@ -616,6 +645,7 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
             if (p < npts) {
                 const bool keep = !(gx[u] < 0 || gx[u] >= a.nx || gy[u] < 0 || gy[u] >= a.ny || gz[u] < 0 || gz[u] >= a.nz);
                 rec[row_of[u] * dnp + dd_of[u]] = make_int2(keep ? (b * a.ny + gy[u]) * a.nx + gx[u] : -1, keep ? __float_as_int(dv[u]) : 0);
+                if (keep && a.compact) binkept[dd_of[u]] = 1;  // (every writer writes the same value)
                 if (a.pos_memo) {
                     if (keep) {
                         a.pos_memo[t[u] * 3] = b; a.pos_memo[t[u] * 3 + 1] = gy[u]; a.pos_memo[t[u] * 3 + 2] = gx[u];
@@ -626,6 +656,7 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
             }
         }
     }
+    }
     {
         constexpr int VEC = Elem<FT>::VEC;
         constexpr int CV = C / VEC;
@@ -635,12 +666,32 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
         }
     }
     __syncthreads();
+    // long rays (a.compact; the reference's native 409-bin frustum: 84 % of the points lie beyond the grid): the bins with a
+    // kept point, in depth order (wave 0: ballot + popcount), so that the lane groups share the work that exists.  Short rays
+    // keep the plain split -- the extra barrier costs them more than the few empty bins (cfg4: +3 us).
+    int nkb = dn;
+    if (a.compact) {
+        if (wave == 0) {
+            int n = 0;
+            for (int base = 0; base < dn; base += 64) {
+                const bool k = (base + lane) < dn && binkept[base + lane] != 0;
+                const unsigned long long m = __ballot(k);
+                if (k) klist[n + __popcll(m & ((1ull << lane) - 1ull))] = base + lane;
+                n += __popcll(m);
+            }
+            if (lane == 0) s_nkb = n;
+        }
+        __syncthreads();
+        nkb = s_nkb;
+    }
     FWD_STAMP(1);
 
-    // ---- 16 lane groups (4 per wave): kd depth bins x all fH rows each, run-length sums in registers (no barrier below)
+    // ---- 16 lane groups (4 per wave): an equal share of the (kept) depth bins x all fH rows each, run-length sums in
+    // registers (no barrier below)
     const int g = lane >> 4, li = lane & 15;
-    const int ds = (wave * 4 + g) * a.kd;
-    const int de = (ds + a.kd) < dn ? (ds + a.kd) : dn;
+    const int share = a.compact ? (nkb + kBlock / 16 - 1) / (kBlock / 16) : a.kd;
+    const int ds = (wave * 4 + g) * share;
+    const int de = (ds + share) < nkb ? (ds + share) : nkb;
     float acc[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) acc[j] = 0.f;
@@ -651,33 +702,54 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
 #pragma unroll
         for (int j = 0; j < S; ++j) unsafeAtomicAdd(o + 16 * j, acc[j]);
     };
-    for (int dd = ds; dd < de; ++dd) {
-        for (int r0 = 0; r0 < fH; r0 += 4) {
-            int2 kr[4];
-            float c[4][S];
+    // SKIP (long rays only): four rows that are dropped in every lane group of the wave -- the rows above / below the z range
+    // at the far bins, 3/4 of a 44-row column at the reference's native frustum -- are passed over before their context rows
+    // are read.  The test sits between the record reads and the context reads, which costs a short ray more than it saves
+    // (cfg4: +3 us), so it is compiled only into the long-ray path.
+    auto walk = [&](auto skip) __attribute__((always_inline)) {
+        constexpr bool SKIP = decltype(skip)::value;
+        for (int e = ds; e < de; ++e) {
+            const int dd = SKIP ? klist[e] : e;
+            for (int r0 = 0; r0 < fH; r0 += 4) {
+                int2 kr[4];
+                float c[4][S];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = (r0 + u) < fH ? (r0 + u) : (fH - 1);
-                kr[u] = rec[row * dnp + dd];
-                if ((r0 + u) >= fH) kr[u] = make_int2(-1, 0);
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (r0 + u) < fH ? (r0 + u) : (fH - 1);
+                    kr[u] = rec[row * dnp + dd];
+                    if ((r0 + u) >= fH) kr[u] = make_int2(-1, 0);
+                    if constexpr (!SKIP) {
 #pragma unroll
-                for (int j = 0; j < S; ++j) c[u][j] = cl[row * CP + 16 * j];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int key = kr[u].x;
-                if (key >= 0 && key != cur) {
-                    if (cur >= 0) flush();
-                    cur = key;
-#pragma unroll
-                    for (int j = 0; j < S; ++j) acc[j] = 0.f;
+                        for (int j = 0; j < S; ++j) c[u][j] = cl[row * CP + 16 * j];
+                    }
                 }
-                const float dv = __int_as_float(kr[u].y);      // 0 for dropped points
+                if constexpr (SKIP) {
+                    if (!__any((kr[0].x & kr[1].x & kr[2].x & kr[3].x) >= 0)) continue;
 #pragma unroll
-                for (int j = 0; j < S; ++j) acc[j] = __builtin_fmaf(dv, c[u][j], acc[j]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int row = (r0 + u) < fH ? (r0 + u) : (fH - 1);
+#pragma unroll
+                        for (int j = 0; j < S; ++j) c[u][j] = cl[row * CP + 16 * j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int key = kr[u].x;
+                    if (key >= 0 && key != cur) {
+                        if (cur >= 0) flush();
+                        cur = key;
+#pragma unroll
+                        for (int j = 0; j < S; ++j) acc[j] = 0.f;
+                    }
+                    const float dv = __int_as_float(kr[u].y);      // 0 for dropped points
+#pragma unroll
+                    for (int j = 0; j < S; ++j) acc[j] = __builtin_fmaf(dv, c[u][j], acc[j]);
+                }
             }
         }
-    }
+    };
+    if (a.compact) walk(std::true_type{});
+    else walk(std::false_type{});
     if (cur >= 0) flush();
 #ifdef LSS_STAMPS
     if (lane == 0 && fstamps) fstamps[2 + wave] = __builtin_amdgcn_s_memtime();      // end of the walk (atomics issued, not retired)
@@ -936,11 +1008,12 @@ bool pick_ray_forward(RayArgs *r) {
     if (dsplit > r->D) dsplit = r->D;
     for (;; ++dsplit) {
         const int dspan = (r->D + dsplit - 1) / dsplit;
-        const size_t lds = (size_t)r->fH * (r->C + 4) * 4 + (size_t)r->fH * (dspan | 1) * 8;
+        const size_t lds = (size_t)r->fH * (r->C + 4) * 4 + (size_t)r->fH * (dspan | 1) * 8 + (size_t)dspan * 8;
         if (lds <= 64 * 1024) {
             r->dspan = dspan;
             r->dsplit = (r->D + dspan - 1) / dspan;
             r->kd = (dspan + kBlock / 16 - 1) / (kBlock / 16);
+            r->compact = (r->D >= 160 || r->fH > 32) ? 1 : 0;      // long rays / tall columns: most (bin, row) pairs lie outside the grid
             return true;
         }
         if (dspan == 1) return false;
@@ -1018,7 +1091,7 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
             r.summary = reinterpret_cast<int2 *>(cam->summary); r.summary_cached = cam->summary_cached;
         }
         if (pick_ray_forward(&r)) {
-            const size_t lds = (size_t)fH * (C + 4) * 4 + (size_t)fH * (r.dspan | 1) * 8;
+            const size_t lds = (size_t)fH * (C + 4) * 4 + (size_t)fH * (r.dspan | 1) * 8 + (size_t)r.dspan * 8;
             const int64_t grid = 8ll * ((r.BN + 7) / 8) * fW * r.dsplit;
             if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
             zero_fill();

@@ -80,3 +80,78 @@ def test_stub_on_the_edge_set(mmt_lib, golden, case):
     gi = torch.zeros(g[case + "_feats"].shape, device="cuda")
     ext.voxel_pooling_backward_wrapper(pos, torch.from_numpy(g[case + "_grad_out"]).cuda(), gi)
     assert np.array_equal(gi.cpu().numpy(), g[case + "_grad_in"])
+
+
+def _load_fused_stub():
+    from mm_training_amd import _lib
+    _lib.lib()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## D. The fused camera path"):text.index("## C. Other entry points")]
+    code = sec[sec.index("```python\n") + len("```python\n"):]
+    code = code[:code.index("\n```")]
+    assert "/path/to/libmmt_hip.so" in code and "lss_fpn.py:441-464" in code
+    mod = types.ModuleType("lss_fused")
+    exec(compile(code.replace("/path/to/libmmt_hip.so", _lib.LIB_PATH), "INTEGRATION.md#D", "exec"), mod.__dict__)
+    return mod
+
+
+def test_fused_stub_loads_and_binds(mmt_lib):
+    """CPU: the section-D block compiles and finds every symbol it binds."""
+    ext = _load_fused_stub()
+    assert callable(ext.fused_lift_splat) and issubclass(ext.FusedLiftSplat, torch.autograd.Function)
+    assert ext._lib.mmt_lss_camera_form_supported(4, 6, 112, 16, 44, 80) == 1
+
+
+@pytest.mark.gpu
+def test_fused_stub_equals_the_reference_op_sequence_through_the_extension_stub(mmt_lib):
+    """Section D (fused camera-form op via ctypes inside a torch.autograd.Function) against what it replaces,
+    lss_fpn.py:441-464: the lift in plain torch (:441-443), permute + contiguous (:460,:463) and `voxel_pooling` driven
+    through the SECTION-B extension stub the way voxel_pooling.py:37-52 does, its backward the reference's own ATen
+    expression (voxel_pooling.py:58-69) -- same inputs, map and both gradients.  The int32 geom the reference path needs
+    comes from mmt_frustum_geometry (the cells the reference's get_geometry + quantise give on this rig up to torch's
+    matmul order: tests/test_geometry_gpu.py)."""
+    from mm_training_amd import synthetic
+    from mm_training_amd.ops.bev_geometry import frustum_geometry
+    from tests.test_oracle_golden import _frustum_torch
+    fused, ext = _load_fused_stub(), _load_stub()
+    B, N, C, H, W = 2, 3, 64, 64, 80
+    fr = _frustum_torch((H, W), 16, (2.0, 22.0, 2.0)).cuda()                  # D = 10, fH = 4, fW = 5: 600 points per camera
+    D, fH, fW, _ = fr.shape
+    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=5)
+    lss = types.SimpleNamespace(frustum=fr, voxel_coord=torch.tensor([-50.8, -50.8, -1.0]), voxel_size=torch.tensor([0.8, 0.8, 8.0]),
+                                voxel_num=torch.tensor([128, 128, 1]))
+    g = torch.Generator().manual_seed(0)
+    depth = torch.rand(B * N, D, fH, fW, generator=g).softmax(1).cuda()
+    context = (torch.rand(B * N, C, fH, fW, generator=g) - 0.5).cuda()
+    go = torch.randn(B, C, 128, 128, generator=g).cuda()
+    # ---- section D
+    d1, c1 = depth.clone().requires_grad_(True), context.clone().requires_grad_(True)
+    bev = fused.fused_lift_splat(lss, d1, c1, s2e.cuda(), K.cuda())
+    assert tuple(bev.shape) == (B, C, 128, 128)
+    bev.backward(go)
+    # ---- the reference's op sequence on the section-B stub
+    class RefVoxelPooling(torch.autograd.Function):        # ops/voxel_pooling/voxel_pooling.py:10-69, restated around the stub
+        @staticmethod
+        def forward(ctx, geom_xyz, input_features, voxel_num):
+            out, pos = _reference_forward(ext, geom_xyz, input_features, voxel_num)
+            ctx.save_for_backward(pos)
+            ctx.shape = input_features.shape
+            return out.permute(0, 3, 1, 2)
+
+        @staticmethod
+        def backward(ctx, grad_output_features):
+            (pos_memo,) = ctx.saved_tensors
+            kept = (pos_memo != -1)[..., 0]
+            grad = torch.zeros(ctx.shape[0], pos_memo.shape[1], ctx.shape[-1], device=grad_output_features.device)
+            grad[kept] = grad_output_features[pos_memo[kept][..., 0].long(), :, pos_memo[kept][..., 1].long(), pos_memo[kept][..., 2].long()]
+            return None, grad.reshape(ctx.shape), None
+    combine = s2e.cuda().matmul(torch.inverse(K.cuda())).contiguous()
+    geom = frustum_geometry(fr, combine, lss.voxel_coord, lss.voxel_size)                      # [B, N, D, fH, fW, 3]
+    d2, c2 = depth.clone().requires_grad_(True), context.clone().requires_grad_(True)
+    lifted = (d2.unsqueeze(1) * c2.unsqueeze(2)).reshape(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2).contiguous()
+    ref = RefVoxelPooling.apply(geom, lifted, torch.tensor([128, 128, 1], device="cuda"))
+    ref.backward(go)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((bev - ref).abs().max()) <= 2e-5 * scale
+    assert torch.equal(bev.detach().abs().sum(1) > 0, ref.detach().abs().sum(1) > 0)
+    assert torch.allclose(d1.grad, d2.grad, rtol=1e-4, atol=1e-5) and torch.allclose(c1.grad, c2.grad, rtol=1e-4, atol=1e-5)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Average per launch of the rocprofv3 --pmc counters for the libmmt_hip kernels (arguments: a label for the measured
 command, then one output directory per counter pass) -> JSON on stdout (the layout bench.py's pmc_traffic() reads:
-profiles/r02_pmc_<config>.json)."""
+profiles/r03_pmc_<config>.json)."""
 import csv
 import glob
 import json
@@ -10,8 +10,12 @@ import sys
 
 # logical kernel name <- (substring of the demangled name, further substrings that must ALL be present)
 KERNELS = [
-    ("lift_splat_forward", ("lss_ray_fwd<float",)),
-    ("lift_splat_forward_bf16", ("lss_ray_fwd<unsigned short",)),
+    # camera form (round 3: the kernels compute the cells themselves; last template argument true) before the geom form
+    ("lift_splat_forward_camera", ("lss_ray_fwd<float", ", true>")),
+    ("lift_splat_forward_camera_bf16", ("lss_ray_fwd<unsigned short", ", true>")),
+    ("lift_splat_forward", ("lss_ray_fwd<float", ", false>")),
+    ("lift_splat_forward_bf16", ("lss_ray_fwd<unsigned short", ", false>")),
+    ("lss_zero_fill", ("lss_zero_fill",)),
     ("lift_splat_forward_tile", ("lss_splat_fwd_tile<float",)),
     ("lift_splat_forward_tile_bf16", ("lss_splat_fwd_tile<unsigned short",)),
     ("lift_splat_forward_chunked", ("vp_fwd_seg_gather<float", ", true>")),
@@ -21,10 +25,14 @@ KERNELS = [
     ("vp_bwd_prepare", ("vp_bwd_prepare",)),
     ("vp_bwd_rows_vec4", ("vp_bwd_rows_vec<float",)),
     ("vp_bwd_rows_bf16", ("vp_bwd_rows_vec<unsigned short",)),
-    ("lift_splat_backward_column", ("lss_col_bwd<float",)),
-    ("lift_splat_backward_column_bf16", ("lss_col_bwd<unsigned short",)),
-    ("lift_splat_backward", ("lss_ray_bwd<float",)),
-    ("lift_splat_backward_bf16", ("lss_ray_bwd<unsigned short",)),
+    ("lift_splat_backward_column_camera", ("lss_col_bwd<float", ", true>")),
+    ("lift_splat_backward_column_camera_bf16", ("lss_col_bwd<unsigned short", ", true>")),
+    ("lift_splat_backward_column", ("lss_col_bwd<float", ", false>")),
+    ("lift_splat_backward_column_bf16", ("lss_col_bwd<unsigned short", ", false>")),
+    ("lift_splat_backward_camera", ("lss_ray_bwd<float", ", true>")),
+    ("lift_splat_backward_camera_bf16", ("lss_ray_bwd<unsigned short", ", true>")),
+    ("lift_splat_backward", ("lss_ray_bwd<float", ", false>")),
+    ("lift_splat_backward_bf16", ("lss_ray_bwd<unsigned short", ", false>")),
     ("lift_splat_backward_tile", ("lss_splat_bwd_tile<float",)),
     ("lift_splat_backward_tile_bf16", ("lss_splat_bwd_tile<unsigned short",)),
     ("lift_splat_backward_pixel", ("lift_splat_backward_kernel<float",)),
@@ -35,6 +43,7 @@ KERNELS = [
     ("fill_i32_kernel", ("fill_i32_kernel",)), ("scatter_map_kernel", ("scatter_map_kernel",)),
     ("scatter_write_nhwc_kernel", ("scatter_write_nhwc_kernel",)), ("scatter_backward_nhwc_kernel", ("scatter_backward_nhwc_kernel",)),
     ("scatter_write_nhwc_table_kernel", ("scatter_write_nhwc_table_kernel",)), ("scatter_backward_nhwc_unique_kernel", ("scatter_backward_nhwc_unique_kernel",)),
+    ("dcn_col2im_gather", ("dcn_col2im_gather",)), ("dcn_offset_grad", ("dcn_offset_grad",)), ("dcn_plan", ("dcn_plan",)),
     ("dcn_col2im", ("dcn_col2im",)), ("dcn_im2col", ("dcn_im2col",)),
     ("bev_warp_kernel", ("bev_warp_kernel",)), ("bev_warp_backward_gather", ("bev_warp_backward_gather",)),
 ]
@@ -75,5 +84,7 @@ for k, ctrs in sorted(acc.items()):
     if "TCC_EA0_RDREQ_sum" in e:
         e["read_bytes_RDREQ_x128"] = e["TCC_EA0_RDREQ_sum"] * 128
         e["write_bytes_WRREQ_x64"] = e["TCC_EA0_WRREQ_sum"] * 64
+    if "TCC_EA0_ATOMIC_sum" in e:
+        e["atomic_bytes"] = e["TCC_EA0_ATOMIC_sum"] * 64        # memory-side atomic requests of 64 B (bench.py: roofline.atomic_side)
     res["kernels"][k] = e
 print(json.dumps(res, indent=1))

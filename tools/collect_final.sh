@@ -1,15 +1,21 @@
 #!/bin/bash
 # Run ON THE GPU BOX after tools/collect_profiles.sh: the bench lines (no profiler attached) of every BASELINE
-# config and the per-kernel micro-benchmarks whose JSON is committed under profiles/ (copy gpurun_out/final/* to profiles/r02_*).
+# config and the per-kernel micro-benchmarks whose JSON is committed under profiles/ (copy gpurun_out/final/* to profiles/r03_*).
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
 run() { local log=$1; shift; timeout -k 10 400 "$@" > "$log" 2> "$log.err"; local rc=$?; echo "[final] $* -> rc=$rc"; [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit $rc; return 0; }
 run $out/bench_train_cfg4.jsonl python bench.py
 run $out/bench_train_cfg4_ray_backward.jsonl python bench.py --lift-splat-backward ray --no-cpu-baseline --no-hotpath-leg
 run $out/bench_train_cfg4_unfused.jsonl python bench.py --unfused --no-cpu-baseline
+run $out/bench_train_cfg4_geom_form.jsonl python bench.py --geom-form --no-cpu-baseline --no-hotpath-leg
+run $out/bench_train_cfg4_calibration_ids.jsonl python bench.py --calibration-ids --no-cpu-baseline --no-hotpath-leg
 for c in cfg2 cfg3 cfg5; do run $out/bench_train_$c.jsonl python bench.py --config $c --no-cpu-baseline; done
 run $out/kbench_fused.txt env KBF_EXTRA=1 python tools/kbench_fused.py
+run $out/kbench_camera_cfg4.json python tools/kbench_camera.py --shape cfg4
+run $out/kbench_camera_cfg5_bf16.json python tools/kbench_camera.py --shape cfg5 --dtype bf16
+run $out/kbench_camera_aim.json python tools/kbench_camera.py --shape aim
 run $out/kbench_dcn.json python tools/kbench_dcn.py
 run $out/kbench_lidar_and_producers.json python tools/kbench_lidar.py
 run $out/ubench_atomic_rows.txt tools/ubench/atomic_rows
+run $out/ubench_atomic_scatter.txt tools/ubench/atomic_scatter
 grep -h '^{' $out/bench_*.jsonl | cut -c1-160

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'): rocprofv3 kernel statistics of the default bench
 # (train, BASELINE configs[3]) and of the isolated hot path (fp32 at the cfg2/cfg4 camera shape, bf16 at cfg5), plus the
 # three PMC passes behind bench.py's roofline.traffic for each of them.  Summaries land in gpurun_out/profiles_new/
-# (copy the ones to be judged into profiles/ as r02_*).  One counter group per pass; kernel-trace/stats only in their own
+# (copy the ones to be judged into profiles/ as r03_*).  One counter group per pass; kernel-trace/stats only in their own
 # runs.  The program itself follows `--` (python3 bench.py), never a wrapper.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -24,9 +24,11 @@ pmc() {    # pmc <tag> <bench args...>
   python3 tools/aggregate_pmc.py "python bench.py $*" $raw/pmc_${tag}_1 $raw/pmc_${tag}_2 $raw/pmc_${tag}_3 > $out/pmc_$tag.json
 }
 stats train_cfg4 --steps 20 --warmup 8 --no-cpu-baseline
+stats train_cfg5 --config cfg5 --steps 12 --warmup 6 --no-cpu-baseline --no-hotpath-leg
 stats hotpath_cfg2 --mode hotpath --config cfg2 --steps 50 --warmup 10 --no-cpu-baseline
 stats hotpath_cfg5_bf16 --mode hotpath --config cfg5 --dtype bf16 --steps 50 --warmup 10 --no-cpu-baseline
 pmc cfg4 --steps 3 --warmup 2 --no-cpu-baseline --no-hotpath-leg
+pmc cfg5 --config cfg5 --steps 3 --warmup 2 --no-cpu-baseline --no-hotpath-leg
 pmc cfg2 --mode hotpath --config cfg2 --steps 5 --warmup 2 --no-cpu-baseline
 pmc cfg5_bf16 --mode hotpath --config cfg5 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline
 grep -h '^{' $out/bench_*_under_rocprof.log | cut -c1-300
