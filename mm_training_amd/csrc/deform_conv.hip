@@ -153,20 +153,35 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(int B, int H, int W, in
 // col2im WITHOUT global atomics (the kernel above moves 1.24 GB of fp32 atomics at the DepthNet shape: 870 us).
 // With free offsets the set of (position, tap) pairs that reach a pixel is not bounded by a neighbourhood, so a
 // plain gather needs the contributions sorted by destination first.  Three kernels:
-//   dcn_plan_kernel        one workgroup per image: every (position, tap) has up to 4 bilinear corners; the corners
-//                          with non-zero weight are binned by destination pixel in LDS (count -> scan -> counting
-//                          sort) and leave as a per-pixel list of (source position, tap, weight) entries;
-//   dcn_offset_grad_kernel grad_offset[pos, tap] = sum_c grad_col * d(sample)/d(py, px): a streaming read of grad_col
-//                          with the four x rows of the tap gathered from L2, channel reduction across the wave;
-//   dcn_col2im_gather      grad_x[pixel, group] = sum over the pixel's list of  weight * grad_col[source, tap, group]:
-//                          one lane group (Cg/4 lanes, a float4 column each) per (pixel, weight group), rows summed in
-//                          registers, ONE plain store per output row -- grad_x is overwritten (no zero-fill needed).
+//   dcn_plan_kernel        one workgroup per image: every (position, tap) has up to 4 bilinear corners inside the image;
+//                          they are binned by destination pixel in LDS (count -> scan -> counting sort) and leave as a
+//                          per-pixel list of (source position, corner, tap, weight) entries.  Corners whose WEIGHT is zero
+//                          stay in the list when their coordinate derivative is not (at integer sampling positions -- zero
+//                          offsets, how training starts -- three of the four corners carry the offset gradient);
+//   dcn_col2im_gather      one lane group (Cg/4 lanes, a float4 column each) per (destination pixel, weight group) walks the
+//                          pixel's list and reads each grad_col row ONCE for both results:
+//                            grad_x[pixel, group]  = sum of  weight * grad_col[source, tap, group]  (registers, one plain
+//                                                    store per output row: grad_x is overwritten, no zero-fill needed);
+//                            dot[source, tap, corner, group] = < grad_col[source, tap, group], x[pixel, group] >  -- the
+//                                                    channel sums the offset gradient is made of (the pixel IS that corner);
+//   dcn_offset_reduce      grad_offset[pos, tap] = sum over the 4 corners of d(weight)/d(py, px) * (sum over groups of dot).
+// Round 2 computed the offset gradient in a kernel of its own that streamed grad_col a second time and pulled the four x
+// rows of every (position, tap) through L1 (1.25 GB): 107 of the 257 us.
 // The order of a pixel's list is the LDS arrival order, so the fp32 sum order may differ between runs (as with the
 // atomics before).
+constexpr int kDcnMaxGroups = 8;     // weight groups the workspace of the sorted backward is sized for
 constexpr int kPlanThreads = 1024;
 constexpr int kPlanMaxHW = 4096;     // destination bins held in LDS
 
-struct DcnEntry { int src_tap; float w; };    // (source position inside the image << 4) | tap
+struct DcnEntry { int src_tap; float w; };    // (source position inside the image << 6) | (corner << 4) | tap
+
+// corner i of a tap takes part in the backward: inside the image, and a non-zero weight or a non-zero derivative
+__device__ __forceinline__ bool tap_corner_live(const Tap &t, int i) {
+    const float w = i == 0 ? t.w1 : i == 1 ? t.w2 : i == 2 ? t.w3 : t.w4;
+    const float dy = i == 0 ? t.dy1 : i == 1 ? t.dy2 : i == 2 ? t.dy3 : t.dy4;
+    const float dx = i == 0 ? t.dx1 : i == 1 ? t.dx2 : i == 2 ? t.dx3 : t.dx4;
+    return w != 0.f || dy != 0.f || dx != 0.f;
+}
 
 __global__ __launch_bounds__(kPlanThreads) void dcn_plan_kernel(int H, int W, const float *offset, int32_t *bin_off,
                                                                 DcnEntry *entries) {
@@ -182,10 +197,10 @@ __global__ __launch_bounds__(kPlanThreads) void dcn_plan_kernel(int H, int W, co
         const int pos = e / 9, k = e - pos * 9;
         const int h = pos / W, w = pos - h * W, ky = k / 3, kx = k - ky * 3;
         const Tap t = make_tap((float)(h + ky - 1) + ob[e * 2], (float)(w + kx - 1) + ob[e * 2 + 1], H, W);
-        if (t.w1 != 0.f) atomicAdd(&cnt[t.o1], 1);
-        if (t.w2 != 0.f) atomicAdd(&cnt[t.o2], 1);
-        if (t.w3 != 0.f) atomicAdd(&cnt[t.o3], 1);
-        if (t.w4 != 0.f) atomicAdd(&cnt[t.o4], 1);
+        if (tap_corner_live(t, 0)) atomicAdd(&cnt[t.o1], 1);
+        if (tap_corner_live(t, 1)) atomicAdd(&cnt[t.o2], 1);
+        if (tap_corner_live(t, 2)) atomicAdd(&cnt[t.o3], 1);
+        if (tap_corner_live(t, 3)) atomicAdd(&cnt[t.o4], 1);
     }
     __syncthreads();
     // exclusive scan of the HW counts: kPer consecutive bins per thread, wave scan, then the wave totals
@@ -222,103 +237,143 @@ __global__ __launch_bounds__(kPlanThreads) void dcn_plan_kernel(int H, int W, co
         const int pos = e / 9, k = e - pos * 9;
         const int h = pos / W, w = pos - h * W, ky = k / 3, kx = k - ky * 3;
         const Tap t = make_tap((float)(h + ky - 1) + ob[e * 2], (float)(w + kx - 1) + ob[e * 2 + 1], H, W);
-        const int st = (pos << 4) | k;
-        if (t.w1 != 0.f) eb[off[t.o1] + atomicAdd(&cnt[t.o1], 1)] = DcnEntry{st, t.w1};
-        if (t.w2 != 0.f) eb[off[t.o2] + atomicAdd(&cnt[t.o2], 1)] = DcnEntry{st, t.w2};
-        if (t.w3 != 0.f) eb[off[t.o3] + atomicAdd(&cnt[t.o3], 1)] = DcnEntry{st, t.w3};
-        if (t.w4 != 0.f) eb[off[t.o4] + atomicAdd(&cnt[t.o4], 1)] = DcnEntry{st, t.w4};
+        const int st = (pos << 6) | k;
+        if (tap_corner_live(t, 0)) eb[off[t.o1] + atomicAdd(&cnt[t.o1], 1)] = DcnEntry{st, t.w1};
+        if (tap_corner_live(t, 1)) eb[off[t.o2] + atomicAdd(&cnt[t.o2], 1)] = DcnEntry{st | (1 << 4), t.w2};
+        if (tap_corner_live(t, 2)) eb[off[t.o3] + atomicAdd(&cnt[t.o3], 1)] = DcnEntry{st | (2 << 4), t.w3};
+        if (tap_corner_live(t, 3)) eb[off[t.o4] + atomicAdd(&cnt[t.o4], 1)] = DcnEntry{st | (3 << 4), t.w4};
     }
 }
 
-// one wave per (position, tap): lanes own float4 columns of the C channels
-__global__ __launch_bounds__(256) void dcn_offset_grad_kernel(int B, int H, int W, int C, int groups, const float *x,
-                                                              const float *offset, const float *grad_col,
-                                                              float *grad_offset) {
-    const int lane = threadIdx.x & 63;
-    const int64_t npos = (int64_t)B * H * W;
-    const int64_t nitems = npos * 9;
-    const int Cg = C / groups, C4 = C >> 2;
-    for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < nitems; it += (int64_t)gridDim.x * 4) {
-        const int64_t pos = it / 9;
-        const int k = (int)(it - pos * 9);
-        const int b = (int)(pos / (H * W));
-        const int hw = (int)(pos - (int64_t)b * H * W);
-        const int h = hw / W, w = hw - h * W, ky = k / 3, kx = k - ky * 3;
-        const Tap t = make_tap((float)(h + ky - 1) + offset[it * 2], (float)(w + kx - 1) + offset[it * 2 + 1], H, W);
-        const float *xb = x + (int64_t)b * H * W * C;
-        const float *x1 = xb + (int64_t)t.o1 * C, *x2 = xb + (int64_t)t.o2 * C;
-        const float *x3 = xb + (int64_t)t.o3 * C, *x4 = xb + (int64_t)t.o4 * C;
-        float gy = 0.f, gx = 0.f;
-        for (int c4 = lane; c4 < C4; c4 += 64) {
-            const int c = c4 * 4;
-            const int g = c / Cg, cin = c - g * Cg;
-            const float4 gc = *reinterpret_cast<const float4 *>(grad_col + ((int64_t)g * npos + pos) * (9 * Cg) + k * Cg + cin);
-            const float4 v1 = *reinterpret_cast<const float4 *>(x1 + c), v2 = *reinterpret_cast<const float4 *>(x2 + c);
-            const float4 v3 = *reinterpret_cast<const float4 *>(x3 + c), v4 = *reinterpret_cast<const float4 *>(x4 + c);
-            // explicit FMAs (the library is built with -ffp-contract=off for the bit-exact geometry path)
-#define MMT_DOT4(d1, d2, d3, d4, comp) __builtin_fmaf(d1, v1.comp, __builtin_fmaf(d2, v2.comp, __builtin_fmaf(d3, v3.comp, d4 * v4.comp)))
-            gy = __builtin_fmaf(gc.x, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, x), gy);
-            gy = __builtin_fmaf(gc.y, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, y), gy);
-            gy = __builtin_fmaf(gc.z, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, z), gy);
-            gy = __builtin_fmaf(gc.w, MMT_DOT4(t.dy1, t.dy2, t.dy3, t.dy4, w), gy);
-            gx = __builtin_fmaf(gc.x, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, x), gx);
-            gx = __builtin_fmaf(gc.y, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, y), gx);
-            gx = __builtin_fmaf(gc.z, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, z), gx);
-            gx = __builtin_fmaf(gc.w, MMT_DOT4(t.dx1, t.dx2, t.dx3, t.dx4, w), gx);
-#undef MMT_DOT4
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            gy += __shfl_xor(gy, o);
-            gx += __shfl_xor(gx, o);
-        }
-        if (lane == 0) {
-            grad_offset[it * 2] = gy;
-            grad_offset[it * 2 + 1] = gx;
-        }
-    }
-}
-
-// LPG lanes (a float4 column each) per (destination pixel, weight group); kU list entries in flight
+// LPG lanes (a float4 column each) per (destination pixel, weight group); kU = 4 list entries in flight.
+// dots [B*HW*9*4][groups]: < grad_col row, x row of the destination pixel > per (source position, tap, corner, group) -- the
+// four entries of a trip are reduced together: after two exchange steps lane (l & 3) of every quad holds the quad's sum for
+// entry l & 3, three more steps fold the quads of the lane group (LPG >= 4; smaller groups reduce entry by entry).
+// Placement: the up-to-four destination pixels of a (source, tap) are a 2 x 2 block of neighbours, and each of them reads the
+// same grad_col row.  All workgroups of one (image, 8-row band) run on ONE XCD (blockIdx & 7 selects the unit modulo 8), and
+// inside a band the items are ordered (row pair, x, row in pair, group), so the vertical neighbours sit in the same workgroup and the
+// horizontal ones in the next: the second to fourth read of a row is an L1 / L2 hit instead of a trip to another XCD's
+// share of the Infinity Cache (HBM-side traffic of this kernel: 820 MB for 311 MB of rows before, PMC).
 template <int LPG>
-__global__ __launch_bounds__(256) void dcn_col2im_gather(int B, int HW, int C, int groups, const float *grad_col,
-                                                         const int32_t *bin_off, const DcnEntry *entries, float *grad_x) {
+__global__ __launch_bounds__(256) void dcn_col2im_gather(int B, int H, int W, int C, int groups, int blocks_per_unit, const float *x,
+                                                         const float *grad_col, const int32_t *bin_off, const DcnEntry *entries,
+                                                         float *grad_x, float *dots) {
     constexpr int kU = 4;
-    const int Cg = C / groups;
+    const int Cg = C / groups, HW = H * W;
     const int64_t npos = (int64_t)B * HW;
-    const int64_t nitems = npos * groups;
     const int grp = threadIdx.x / LPG, li = threadIdx.x - grp * LPG;
     constexpr int kGroups = 256 / LPG;
-    for (int64_t item = (int64_t)blockIdx.x * kGroups + grp; item < nitems; item += (int64_t)gridDim.x * kGroups) {
-        const int64_t pix = item / groups;             // b * HW + destination pixel
-        const int g = (int)(item - pix * groups);
-        const int b = (int)(pix / HW);
-        const int dest = (int)(pix - (int64_t)b * HW);
-        const int beg = bin_off[(int64_t)b * (HW + 1) + dest], end = bin_off[(int64_t)b * (HW + 1) + dest + 1];
+    {
+        // unit = (image, band of kBand rows); the units are dealt to the XCDs round robin, all workgroups of a unit to one XCD
+        constexpr int kBand = 8;
+        const int bands = (H + kBand - 1) / kBand;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int unit = (idx / blocks_per_unit) * 8 + xcd;
+        if (unit >= B * bands) return;                        // whole workgroup (padding of the unit -> XCD deal)
+        const int b = unit / bands, band = unit - b * bands;
+        const int k = idx - (idx / blocks_per_unit) * blocks_per_unit;
+        const int64_t item = (int64_t)k * kGroups + grp;     // inside the band: ((y / 2 * W + x) * 2 + (y & 1)) * groups + g
+        const int g = (int)(item % groups);
+        const int64_t pp = item / groups;
+        const int ysub = (int)(pp & 1);
+        const int64_t q = pp >> 1;
+        const int xx = (int)(q % W), yb = (int)(q / W) * 2 + ysub;
+        const int y = yb < kBand ? band * kBand + yb : H;     // past the band: idle
+        const bool on = y < H;
+        const int dest = on ? y * W + xx : 0;
+        const int64_t pix = (int64_t)b * HW + dest;           // b * HW + destination pixel
+        const int beg = on ? bin_off[(int64_t)b * (HW + 1) + dest] : 0, end = on ? bin_off[(int64_t)b * (HW + 1) + dest + 1] : 0;
         const DcnEntry *eb = entries + (int64_t)b * HW * 36;
         const float *gcb = grad_col + ((int64_t)g * npos + (int64_t)b * HW) * (9 * Cg) + li * 4;
+        const float4 xd = *reinterpret_cast<const float4 *>(x + pix * C + g * Cg + li * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the longest list among the lane groups of the wave decides the trip count (shorter ones run on clamped entries)
+        int trips = (end - beg + kU - 1) / kU;
+#pragma unroll
+        for (int m = LPG; m < 64; m <<= 1) { const int o = __shfl_xor(trips, m); trips = o > trips ? o : trips; }
         // the list entries of the NEXT kU rows are requested before the current rows are waited for: one dependent round
         // trip per kU rows instead of two
         DcnEntry en[kU], nx[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) en[u] = eb[(beg + u) < end ? (beg + u) : (end > beg ? end - 1 : beg)];
-        for (int j = beg; j < end; j += kU) {
+        for (int tr = 0; tr < trips; ++tr) {
+            const int j = beg + tr * kU;
             float4 v[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u)
-                v[u] = *reinterpret_cast<const float4 *>(gcb + ((int64_t)(en[u].src_tap >> 4) * 9 + (en[u].src_tap & 15)) * Cg);
-#pragma unroll
-            for (int u = 0; u < kU; ++u) nx[u] = eb[(j + kU + u) < end ? (j + kU + u) : (end - 1)];
+            for (int u = 0; u < kU; ++u) {
+                // (a lane group whose list is shorter than the wave's trip count -- or empty -- runs on clamped or, past the
+                // image's last entry, unwritten entries: whatever they hold, the row address is forced inside grad_col)
+                const int src = min((unsigned)en[u].src_tap >> 6, (unsigned)(HW - 1)), tap = min(en[u].src_tap & 15, 8);
+                v[u] = *reinterpret_cast<const float4 *>(gcb + ((int64_t)src * 9 + tap) * Cg);
+            }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                const float w = (j + u) < end ? en[u].w : 0.f;
-                acc = fma4(w, v[u], acc);
+                const int jn = j + kU + u;
+                nx[u] = eb[jn < end ? jn : (end > beg ? end - 1 : beg)];
+            }
+            float d[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const bool live = (j + u) < end;
+                acc = fma4(live ? en[u].w : 0.f, v[u], acc);
+                d[u] = live ? __builtin_fmaf(v[u].x, xd.x, __builtin_fmaf(v[u].y, xd.y, __builtin_fmaf(v[u].z, xd.z, v[u].w * xd.w))) : 0.f;
+            }
+            if constexpr (LPG >= 4) {
+                // 4 values per lane -> 1: lane l keeps entry (l & 3)
+                float a0 = (li & 1) ? d[1] : d[0], b0 = (li & 1) ? d[0] : d[1];
+                float a1 = (li & 1) ? d[3] : d[2], b1 = (li & 1) ? d[2] : d[3];
+                a0 += __shfl_xor(b0, 1);
+                a1 += __shfl_xor(b1, 1);
+                float e0 = (li & 2) ? a1 : a0, f0 = (li & 2) ? a0 : a1;
+                e0 += __shfl_xor(f0, 2);
+#pragma unroll
+                for (int m = 4; m < LPG; m <<= 1) e0 += __shfl_xor(e0, m);
+                const int u = li & 3;
+                if (li < 4 && (j + u) < end) {
+                    const int st = u == 0 ? en[0].src_tap : u == 1 ? en[1].src_tap : u == 2 ? en[2].src_tap : en[3].src_tap;
+                    dots[((((int64_t)b * HW + (st >> 6)) * 9 + (st & 15)) * 4 + ((st >> 4) & 3)) * groups + g] = e0;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    float e0 = d[u];
+#pragma unroll
+                    for (int m = 1; m < LPG; m <<= 1) e0 += __shfl_xor(e0, m);
+                    if (li == 0 && (j + u) < end)
+                        dots[((((int64_t)b * HW + (en[u].src_tap >> 6)) * 9 + (en[u].src_tap & 15)) * 4 + ((en[u].src_tap >> 4) & 3)) * groups + g] = e0;
+                }
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) en[u] = nx[u];
         }
-        *reinterpret_cast<float4 *>(grad_x + pix * C + g * Cg + li * 4) = acc;
+        if (on) *reinterpret_cast<float4 *>(grad_x + pix * C + g * Cg + li * 4) = acc;
+    }
+}
+
+// grad_offset[pos, tap] = sum over the live corners of (d weight / d py, d weight / d px) * (sum over the groups of dots)
+__global__ __launch_bounds__(256) void dcn_offset_reduce(int B, int H, int W, int groups, const float *offset, const float *dots,
+                                                         float *grad_offset) {
+    const int64_t nitems = (int64_t)B * H * W * 9;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < nitems; it += (int64_t)gridDim.x * 256) {
+        const int64_t pos = it / 9;
+        const int k = (int)(it - pos * 9);
+        const int hw = (int)(pos % (H * W));
+        const int h = hw / W, w = hw - h * W, ky = k / 3, kx = k - ky * 3;
+        const Tap t = make_tap((float)(h + ky - 1) + offset[it * 2], (float)(w + kx - 1) + offset[it * 2 + 1], H, W);
+        float gy = 0.f, gx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (tap_corner_live(t, c)) {
+                float sum = 0.f;
+                for (int g = 0; g < groups; ++g) sum += dots[(it * 4 + c) * groups + g];
+                const float dy = c == 0 ? t.dy1 : c == 1 ? t.dy2 : c == 2 ? t.dy3 : t.dy4;
+                const float dx = c == 0 ? t.dx1 : c == 1 ? t.dx2 : c == 2 ? t.dx3 : t.dx4;
+                gy = __builtin_fmaf(dy, sum, gy);
+                gx = __builtin_fmaf(dx, sum, gx);
+            }
+        }
+        grad_offset[it * 2] = gy;
+        grad_offset[it * 2 + 1] = gx;
     }
 }
 
@@ -364,7 +419,8 @@ extern "C" int mmt_dcn_col2im(int B, int H, int W, int C, int groups, const floa
 extern "C" int64_t mmt_dcn_col2im_workspace_elems(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const int64_t HW = (int64_t)H * W;
-    return (int64_t)B * (HW + 1) + 2 * (int64_t)B * HW * 36 + 4;
+    // bin offsets + 8-byte entries (<= 36 per position) + the dot products [B*HW*36][groups <= kDcnMaxGroups]
+    return (int64_t)B * (HW + 1) + 2 * (int64_t)B * HW * 36 + (int64_t)B * HW * 36 * kDcnMaxGroups + 8;
 }
 
 extern "C" int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x,
@@ -381,9 +437,9 @@ extern "C" int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, con
         return mmt::fail(MMT_ERR_BAD_SHAPE, "dcn_col2im_sorted: x / grad_col / grad_x must be 16-byte aligned");
     const int HW = H * W;
     const int lpg = (C / groups) / 4;
-    if (HW > kPlanMaxHW || lpg > 64 || (lpg & (lpg - 1)) != 0 || B > 65535 || HW >= (1 << 27))
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "dcn_col2im_sorted: needs H*W <= %d and C/groups/4 a power of two <= 64 (H*W=%d, C/groups=%d); "
-                                            "use mmt_dcn_col2im", kPlanMaxHW, HW, C / groups);
+    if (HW > kPlanMaxHW || lpg > 64 || (lpg & (lpg - 1)) != 0 || B > 65535 || HW >= (1 << 25) || groups > kDcnMaxGroups)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "dcn_col2im_sorted: needs H*W <= %d, C/groups/4 a power of two <= 64 and groups <= %d (H*W=%d, C/groups=%d, "
+                                            "groups=%d); use mmt_dcn_col2im", kPlanMaxHW, kDcnMaxGroups, HW, C / groups, groups);
     if (workspace_elems < mmt_dcn_col2im_workspace_elems(B, H, W))
         return mmt::fail(MMT_ERR_WORKSPACE, "dcn_col2im_sorted: workspace too small (%lld < %lld elements)", (long long)workspace_elems,
                          (long long)mmt_dcn_col2im_workspace_elems(B, H, W));
@@ -392,14 +448,18 @@ extern "C" int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, con
     int64_t eoff = (int64_t)B * (HW + 1);
     eoff += eoff & 1;                                      // 8-byte aligned entries
     DcnEntry *entries = reinterpret_cast<DcnEntry *>(workspace + eoff);
+    float *dots = reinterpret_cast<float *>(workspace + eoff + 2 * (int64_t)B * HW * 36);
     const int64_t npos = (int64_t)B * HW;
     hipLaunchKernelGGL(dcn_plan_kernel, dim3(B), dim3(kPlanThreads), 0, st, H, W, offset, bin_off, entries);
-    hipLaunchKernelGGL(dcn_offset_grad_kernel, dim3(mmt::stream_grid(npos * 9, 4, 256 * 64)), dim3(256), 0, st, B, H, W, C, groups, x,
-                       offset, grad_col, grad_offset);
-    const int64_t nitems = npos * groups;
+    // items of one (image, 8-row band) unit: 4 row pairs x columns x 2 x groups
+    const int64_t items_per_unit = (int64_t)4 * W * 2 * groups;
+    const int units = B * ((H + 7) / 8);
 #define MMT_DCN_GATHER(L)                                                                                                 \
-    hipLaunchKernelGGL((dcn_col2im_gather<L>), dim3(mmt::stream_grid(nitems, 256 / L, 256 * 64)), dim3(256), 0, st, B, HW, C, \
-                       groups, grad_col, (const int32_t *)bin_off, (const DcnEntry *)entries, grad_x)
+    {                                                                                                                     \
+        const int bpi = (int)mmt::ceil_div(items_per_unit, 256 / L);                                                      \
+        hipLaunchKernelGGL((dcn_col2im_gather<L>), dim3((unsigned)(8 * ((units + 7) / 8) * bpi)), dim3(256), 0, st, B, H, W, C, \
+                           groups, bpi, x, grad_col, (const int32_t *)bin_off, (const DcnEntry *)entries, grad_x, dots);   \
+    }
     switch (lpg) {
         case 1: MMT_DCN_GATHER(1); break;
         case 2: MMT_DCN_GATHER(2); break;
@@ -410,5 +470,7 @@ extern "C" int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, con
         default: MMT_DCN_GATHER(64); break;
     }
 #undef MMT_DCN_GATHER
+    hipLaunchKernelGGL(dcn_offset_reduce, dim3(mmt::stream_grid(npos * 9, 256, 256 * 16)), dim3(256), 0, st, B, H, W, groups, offset,
+                       (const float *)dots, grad_offset);
     return mmt::check_launch("dcn_col2im_sorted");
 }

@@ -690,6 +690,8 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
     // registers (no barrier below)
     const int g = lane >> 4, li = lane & 15;
     const int share = a.compact ? (nkb + kBlock / 16 - 1) / (kBlock / 16) : a.kd;
+    // (Rotating the lane groups' shares by the column index -- so that the nearest bins of a camera's 44 columns, which fall
+    // into the same few cells, do not send their atomics together -- was measured: no difference, 34.5 us either way.)
     const int ds = (wave * 4 + g) * share;
     const int de = (ds + share) < nkb ? (ds + share) : nkb;
     float acc[S];
