@@ -33,7 +33,7 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 6
+#define MMT_ABI_VERSION 7
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -332,16 +332,32 @@ int mmt_lss_splat_backward_bf16(int B, int N, int D, int fH, int fW, int C, int 
  * Blocks without bit 16 (a camera that is not level: some column straddles a cell border) are evaluated row by row from the
  * matrices by whichever kernel meets them, so combine / frustum_* are always required.  Needs nx, ny < 32768. */
 #define MMT_LSS_SUMMARY_CACHED 0x1000
+/* exclusive_cache (ABI 7; forward, nullable; device int32, 16-byte aligned, exclusive_cache_bytes =
+ * mmt_lss_exclusive_cache_bytes(N, nx, ny, slots) bytes, ZERO-INITIALISED ONCE by the caller and then left to the library):
+ * a persistent per-calibration memory of which BEV cells receive ONE run of the forward only.  Such a cell (43 % of the runs
+ * on the cfg4 rig: far cells seen by one column of one camera) needs no atomic add -- the run is stored into the zero-filled
+ * row -- and the forward is bound by the memory-side atomic units.  The library learns them on the device, per sample, over
+ * the first two calls that present a sample's N matrices (MARK: every run stores its id into the cell's state; VERIFY: a run
+ * that finds another id stores -1); from the third call on runs into single-run cells leave as plain stores.  The lookup
+ * of a call's samples (64-bit hash of the matrices, then the matrices bit for bit; least-recently-used replacement) runs in
+ * one workgroup of the zero-fill kernel: no host involvement, no synchronisation, capturable in a graph.  A change of the
+ * launch shape, of the grid or of the frustum axes' contents empties the cache.  Used with MMT_LSS_ZERO_OUTPUT by the
+ * register-walk forward (fH <= 16, C <= 80, D < 160; mmt_lss_last_kernel_family reports MMT_LSS_FAMILY_REGISTER); ignored
+ * otherwise.  Results are those of the call without a cache up to the order of additions (a stored sum is a sum added to 0).
+ * Calls that share a cache must be ordered on one stream.  Limits: 1024 slots, samples of at most 8 cameras, the first 8
+ * samples of a call (further samples run without it). */
+int64_t mmt_lss_exclusive_cache_bytes(int N, int num_voxel_x, int num_voxel_y, int slots);   /* 0: bad arguments */
 int mmt_lss_splat_forward_cam(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
                               const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,
                               const float *voxel_coord_host, const float *voxel_size_host, const float *depth,
                               const float *context, float *output_features, int32_t *pos_memo, int32_t *column_summary,
-                              int flags, void *stream);
+                              int32_t *exclusive_cache, int64_t exclusive_cache_bytes, int flags, void *stream);
 int mmt_lss_splat_forward_cam_bf16(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                    const float *combine, const float *frustum_u, const float *frustum_v,
                                    const float *frustum_d, const float *voxel_coord_host, const float *voxel_size_host,
                                    const uint16_t *depth, const uint16_t *context, float *output_features,
-                                   int32_t *pos_memo, int32_t *column_summary, int flags, void *stream);
+                                   int32_t *pos_memo, int32_t *column_summary, int32_t *exclusive_cache,
+                                   int64_t exclusive_cache_bytes, int flags, void *stream);
 int mmt_lss_splat_backward_cam(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,
                                const float *voxel_coord_host, const float *voxel_size_host, const float *depth,
@@ -362,6 +378,8 @@ int mmt_lss_splat_backward_cam_bf16(int B, int N, int D, int fH, int fW, int C, 
 #define MMT_LSS_FAMILY_TILE 2
 #define MMT_LSS_FAMILY_COLUMN 3
 #define MMT_LSS_FAMILY_CAMERA 0x10
+#define MMT_LSS_FAMILY_REGISTER 0x20 /* forward, ORed to MMT_LSS_FAMILY_RAY: the register walk (columns of up to 16 rows, C <= 80, D < 160) */
+#define MMT_LSS_FAMILY_EXCLUSIVE 0x40 /* forward: the call used an exclusive-cell cache */
 int mmt_lss_last_kernel_family(int backward);
 /* 1 when mmt_lss_splat_forward_cam AND mmt_lss_splat_backward_cam both take this shape, 0 otherwise (use the geom form). */
 int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW, int C);

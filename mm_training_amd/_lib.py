@@ -36,8 +36,9 @@ SIGNATURES = {
     "mmt_lss_splat_forward_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_lss_splat_backward": (_c_int, [_c_int] * 9 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_int, _c_ptr]),
     "mmt_lss_splat_backward_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 4 + [_c_i64] * 4 + [_c_ptr, _c_ptr, _c_int, _c_ptr]),
-    "mmt_lss_splat_forward_cam": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_int, _c_ptr]),
-    "mmt_lss_splat_forward_cam_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_int, _c_ptr]),
+    "mmt_lss_splat_forward_cam": (_c_int, [_c_int] * 9 + [_c_ptr] * 12 + [_c_i64, _c_int, _c_ptr]),
+    "mmt_lss_splat_forward_cam_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 12 + [_c_i64, _c_int, _c_ptr]),
+    "mmt_lss_exclusive_cache_bytes": (_c_i64, [_c_int] * 4),
     "mmt_lss_splat_backward_cam": (_c_int, [_c_int] * 9 + [_c_ptr] * 9 + [_c_i64] * 4 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
     "mmt_lss_splat_backward_cam_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 9 + [_c_i64] * 4 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
     "mmt_lss_last_kernel_family": (_c_int, [_c_int]),
@@ -91,6 +92,7 @@ LSS_ZERO_OUTPUT = 0x800       # mmt_lss_splat_forward*: the call zero-fills the 
 LSS_SUMMARY_CACHED = 0x1000   # mmt_lss_splat_forward_cam*: read the column summary instead of computing the geometry
 LSS_STATS_SLOTS = 64          # column_stats of mmt_lss_splat_backward_cam*: int64 [2 * LSS_STATS_SLOTS], (mismatching, kept) pairs
 LSS_FAMILY = {0: "none", 1: "ray", 2: "tile", 3: "column"}     # mmt_lss_last_kernel_family() & 0xF; | 0x10 = camera form
+LSS_FAMILY_REGISTER, LSS_FAMILY_EXCLUSIVE = 0x20, 0x40           # forward: register walk / an exclusive-cell cache was used
 
 _lib = None
 

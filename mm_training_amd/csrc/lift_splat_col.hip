@@ -58,7 +58,9 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-// LDS (dynamic): dep [16][Dp] fp32 | moff [16][Dp] int | ref [Dp] int | flag [16][Dp] bytes | G tiles of the 2 waves [2][16][CP] fp32
+// LDS (dynamic): dep [16][Dp] fp32 | ref [Dp] int | flag [16][Dp] bytes | G tiles of the 2 waves [2][16][CP] fp32
+// (20 KB at D = 112, C = 80: eight workgroups per CU -- with <= 128 VGPRs every workgroup of the cfg4 launch is resident at
+// once; round 2 also kept every point's own row offset, 7 KB that only the mismatch pass reads: it recomputes them now)
 // (CP = C + 4; after the products: the grad_context total and the lists / partial sums of the mismatch pass)
 // NT = C / 16 (N tiles of the grad_context product); C / 4 <= 64 lanes move one row.
 template <typename FT, int NT, bool CAM>
@@ -83,8 +85,7 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
     FT *grad_depth = reinterpret_cast<FT *>(a.grad_depth);
 
     float *dep = reinterpret_cast<float *>(col_lds);                   // [16][Dp] depth value (0 for dropped points)
-    int *moff = reinterpret_cast<int *>(dep + 16 * Dp);                // [16][Dp] byte offset of the point's own BEV-gradient row, or kOut
-    int *ref = moff + 16 * Dp;                                         // [Dp] byte offset of the COLUMN's row per bin, or kOut
+    int *ref = reinterpret_cast<int *>(dep + 16 * Dp);                 // [Dp] byte offset of the COLUMN's row per bin, or kOut
     unsigned char *flag = reinterpret_cast<unsigned char *>(ref + Dp); // [16][Dp] 0 dropped, 1 in the column's cell, 2 mismatch
     float *gw0 = reinterpret_cast<float *>(flag + 16 * Dp);            // G tiles [16][CP], one per wave
     float *gw1 = gw0 + 16 * CP;
@@ -100,13 +101,22 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
 #endif
     COL_STAMP(0);
 
-    // ---- A operand of the grad_depth product, in registers for the whole kernel: Ctx[pixel = lane & 15][4 j + (lane >> 4)]
-    float ctxA[C4];
+    // ---- the block's 16 context rows -> wave 0's G tile (free until the products start), as whole 16-byte vectors; the A
+    // operand of the grad_depth product is read out of it after phase A's barrier (round 2: 20 strided dword loads per lane)
     {
-        const int prow = lane & 15;
-        const int64_t pix = (int64_t)bn * HW + (row0 + (prow < nrow ? prow : 0)) * a.fW + col;
-#pragma unroll
-        for (int j = 0; j < C4; ++j) ctxA[j] = prow < nrow ? ld_scalar<FT>(context + pix * C + 4 * j + (lane >> 4)) : 0.f;
+        constexpr int VEC = sizeof(FT) == 2 ? 8 : 4, CV = C / VEC;
+        for (int e = tid; e < 16 * CV; e += kColBlock) {
+            const int prow = e / CV, cvi = e - prow * CV;
+            const FT *src = context + ((int64_t)bn * HW + (row0 + (prow < nrow ? prow : 0)) * a.fW + col) * C + cvi * VEC;
+            float *dst = gw0 + prow * CP + cvi * VEC;
+            if constexpr (sizeof(FT) == 2) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(src);
+                *reinterpret_cast<float4 *>(dst) = make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+                *reinterpret_cast<float4 *>(dst + 4) = make_float4(bf16_lo(r.z), bf16_hi(r.z), bf16_lo(r.w), bf16_hi(r.w));
+            } else {
+                *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+            }
+        }
     }
 
     // ---- phase A: a thread takes one bin of all 16 rows (coalesced along the bins in the pixel-major order), all 32 loads in
@@ -181,7 +191,6 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
             const int f = o[u] == kOut ? 0 : (o[u] == m ? 1 : 2);
             flag[u * Dp + bin] = (unsigned char)f;
             dep[u * Dp + bin] = f ? dv[u] : 0.f;
-            moff[u * Dp + bin] = (int)o[u];
             mis += f == 2;
             kept += f != 0;
         }
@@ -189,6 +198,13 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
         if (a.stats && kept) atomicAdd(&nkept, kept);
     }
     __syncthreads();
+    float ctxA[C4];                       // Ctx[pixel = lane & 15][4 j + (lane >> 4)], in registers for the rest of the kernel
+    {
+        const int prow = lane & 15;
+#pragma unroll
+        for (int j = 0; j < C4; ++j) ctxA[j] = prow < nrow ? gw0[prow * CP + 4 * j + (lane >> 4)] : 0.f;
+    }
+    __syncthreads();                      // wave 0 stages its first G tile into gw0 next
     COL_STAMP(1);
 
     // ---- the two products, a batch of 16 bins at a time
@@ -348,7 +364,17 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     const bool on = act && (e0 + u) < cnt;
                     const int bin = on ? klist[e0 + u] : 0;
-                    const unsigned o = on ? (unsigned)moff[prc * Dp + bin] : kOut;
+                    unsigned o = kOut;                    // the point's OWN row (flag 2: kept, so its indices are in range)
+                    if constexpr (CAM) {
+                        int x_, y_;
+                        const mmt_cam_column cc_ = mmt_cam_column_make(cm, cu, a.fd[bin]);
+                        mmt_cam_row_xy(cc_, a.fv[row0 + prc], a.q, a.nx, a.ny, x_, y_);
+                        if (on) o = (unsigned)(((int)(b * a.sb) + y_ * (int)a.sy + x_ * (int)a.sx) * 4);
+                    } else {
+                        const int64_t t_ = tcol + prc * rstep + bin * dstep;
+                        const int x_ = a.geom[t_ * 3], y_ = a.geom[t_ * 3 + 1];
+                        if (on) o = (unsigned)(((int)(b * a.sb) + y_ * (int)a.sy + x_ * (int)a.sx) * 4);
+                    }
                     dv[u] = on ? dep[prc * Dp + bin] : 0.f;
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + (g < G ? (unsigned)li * 16u : 0x40000000u), 0, 0);
                 }
@@ -416,7 +442,7 @@ int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx,
     a.span_bytes = (int)(span * 4);
     a.grad_depth = grad_depth; a.grad_context = grad_context;
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
-    const size_t lds = (size_t)16 * Dp * 4 * 2 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
+    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
     const int64_t grid = 8ll * ((a.BN + 7) / 8) * fW * a.rblocks;
     mmt::TimedSeq seq;
     const dim3 g((unsigned)grid), blk(kColBlock);
@@ -439,7 +465,7 @@ namespace mmt {
 // true when the column kernel takes this shape (C in {64, 80, 128}; LDS within 64 KB; a gradient map below 1 GiB)
 bool lss_col_backward_fits(int D, int fH, int fW, int C, int64_t span, int64_t grid_units) {
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
-    const size_t lds = (size_t)16 * Dp * 4 * 2 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
+    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
     const int C4 = C / 4, NGR = (kColBlock / 64) * (64 / C4);
     if (NGR * Dp + NGR * C4 > 16 * (C + 4)) return false;            // the lists of the mismatch pass live in wave 1's tile
     return (C == 64 || C == 80 || C == 128) && lds <= 64 * 1024 && span * 4 < (1ll << 30) && grid_units < (1ll << 28);

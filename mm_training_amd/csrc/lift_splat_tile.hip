@@ -467,6 +467,196 @@ __global__ __launch_bounds__(kBlock) void lss_splat_bwd_tile(TileArgs a) {
 // run-length sum in registers already removes ~95 % of the atomic rows -- for any geometry the result is the same, an
 // unstructured one merely flushes more often.
 //
+// ---------------------------------------------------------------------------
+// EXCLUSIVE-CELL CACHE of the register-walk forward (camera form + MMT_LSS_ZERO_OUTPUT; nullable).  With the walk down to
+// 7 us the forward waits for the memory-side atomic units: 78 k runs x 320 B = 25 MB at ~1.25 TB/s.  But 43 % of the runs
+// (cfg4 rig) go to cells that NO other run of the launch touches -- far cells seen by one column of one camera -- and a cell
+// with a single contributor needs no atomic: a plain store into the zero-filled row does.  Which cells those are is a
+// function of a sample's camera matrices and of the launch shape alone, so it is learnt on the device, per SAMPLE (a
+// shuffled loader repeats rigs, not batches):
+//   * the cache holds `slots` calibrations: the sample's N matrices (+ a 64-bit hash of them) and one int32 STATE per BEV
+//     cell of a sample's map;
+//   * one extra workgroup of the zero-fill kernel looks every sample of the call up (hash, then the matrices bit for bit) and
+//     leaves a (slot, mode) pair per sample in the header; the forward reads it.  A new calibration takes the least recently
+//     used slot;
+//   * mode 1, MARK (the call that claims the slot): every run leaves its id -- (camera, column, slab, lane group, first bin,
+//     first row), the same in every launch of this shape -- in state[cell] with a plain store: some run's id survives;
+//   * mode 2, VERIFY (next call with these matrices): a run that finds another id than its own stores -1.  Afterwards
+//     state[cell] > 0 says "one run only";
+//   * mode 3, USE (from the third call on): the geometry phase tags the keys of such cells, and a tagged run leaves as plain
+//     stores.
+// Learning costs a 4-byte load or store per run (no same-address atomic chains: a counter per cell was measured at +14 us
+// per call), there is no host involvement and no synchronisation, so it works under graph capture; a loader with more rigs
+// than slots simply stays in modes 1/2.  Samples of one call that share their matrices learn through the first of them.
+// The header remembers the launch shape the states were learnt for (a host-side signature): another shape starts over.
+// One cache per stream: calls that share it must be stream-ordered.
+constexpr int kExclFlag = 1 << 30;       // in a key: the cell has a single contributing run
+constexpr int kExclMaxB = 8;             // samples per call that take part (the rest: mode 0)
+constexpr int kExclMaxN = 8;             // cameras per sample (more: the cache is not used)
+constexpr int kExclHeaderWords = 64;     // [0..1] shape signature, [2] clock, [3..4] hash of the frustum axes, [5] select done, [8 + b] slot of sample b, [24 + b] its mode
+constexpr int kExclMetaWords = 4;        // per slot: hash lo, hash hi, stage (0 free, 1 marked, 2 verified, 3 in use), stamp
+constexpr int kExclMaxSlots = 1024;
+struct ExclShape { int slots, N, cells; unsigned sig_lo, sig_hi; };      // cells = ny * nx of one sample
+struct ExclCall {                        // what the select step needs (zero-fill kernel argument)
+    int32_t *cache;                      // nullptr: no cache in this call
+    const float *combine, *fu, *fv, *fd;
+    int B, fW, fH, D;
+    ExclShape xs;
+};
+__host__ __device__ inline int64_t excl_slot_words(int N, int cells) { return (int64_t)kExclMetaWords + (int64_t)N * 16 + cells; }
+__device__ __forceinline__ int32_t *excl_meta(int32_t *c, int s) { return c + kExclHeaderWords + s * kExclMetaWords; }
+__device__ __forceinline__ int32_t *excl_mats(int32_t *c, const ExclShape &x, int s) {
+    return c + kExclHeaderWords + (int64_t)x.slots * kExclMetaWords + (int64_t)s * x.N * 16;
+}
+__device__ __forceinline__ int32_t *excl_state(int32_t *c, const ExclShape &x, int s) {
+    return c + kExclHeaderWords + (int64_t)x.slots * (kExclMetaWords + x.N * 16) + (int64_t)s * x.cells;
+}
+
+__device__ __forceinline__ unsigned excl_mix(unsigned v) {      // a 32-bit finaliser (murmur3)
+    v ^= v >> 16; v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;
+    return v;
+}
+
+// The select step: ONE extra workgroup (block 0) of the forward kernel, NT threads; the column workgroups wait for its verdict
+// only after their geometry phase (7 us; the select takes about 3), so it costs the call nothing.  (Riding on the zero-fill
+// kernel instead it took 11 us: its loads queue behind the fill's 21 MB of stores.)  Everything it needs is fetched in ONE
+// round of loads (header, frustum axes, the call's matrices, the metadata of all slots -> LDS); wave w then looks samples
+// w, w + NT/64, ... up (a second round of loads only to compare a candidate's matrices), and wave 0 settles claims and
+// duplicates in sample order on the LDS copy, writes the header and releases cache[5] (cleared by the zero-fill kernel in
+// front of every forward), which the other workgroups acquire.  Block 0 is dispatched first and waits for nobody.
+__host__ __device__ inline size_t excl_select_lds(int slots) {
+    return (size_t)slots * 12 + (size_t)((slots + 3) & ~3) + (size_t)kExclMaxB * kExclMaxN * 16 * 4 + (size_t)kExclMaxB * 16 + 64;      // (+ 64: axes, header copy)
+}
+template <int NT>
+__device__ void excl_select(const ExclCall &k, float *lds) {
+    const ExclShape x = k.xs;
+    unsigned *s_h0 = reinterpret_cast<unsigned *>(lds), *s_h1 = s_h0 + x.slots;
+    int *s_stamp = reinterpret_cast<int *>(s_h1 + x.slots);
+    unsigned (*s_mat)[kExclMaxN * 16] = reinterpret_cast<unsigned (*)[kExclMaxN * 16]>(s_stamp + x.slots);
+    unsigned (*s_hash)[2] = reinterpret_cast<unsigned (*)[2]>(s_mat + kExclMaxB);
+    int *s_slot = reinterpret_cast<int *>(s_hash + kExclMaxB), *s_stage = s_slot + kExclMaxB;
+    unsigned *s_axes = reinterpret_cast<unsigned *>(s_stage + kExclMaxB);      // [0..1] the hash, then a pair per wave
+    int *s_hdr = reinterpret_cast<int *>(s_axes + 10);
+    unsigned char *s_stg = reinterpret_cast<unsigned char *>(s_hdr + 6);
+    constexpr int kBlock = NT;               // (shadows the file's 256: this function runs with the forward's block size)
+    int32_t *cache = k.cache;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = k.B < kExclMaxB ? k.B : kExclMaxB, nw = x.N * 16;
+    if (tid < 5) s_hdr[tid] = cache[tid];
+    {
+        const unsigned *m = reinterpret_cast<const unsigned *>(k.combine);
+        for (int i = tid; i < nb * nw; i += kBlock) s_mat[i / nw][i % nw] = m[i];
+        for (int s = tid; s < x.slots; s += kBlock) {
+            const int4 mt = *reinterpret_cast<const int4 *>(excl_meta(cache, s));
+            s_h0[s] = (unsigned)mt.x; s_h1[s] = (unsigned)mt.y; s_stg[s] = (unsigned char)mt.z; s_stamp[s] = mt.w;
+        }
+        // the frustum axes' contents (a cache serves one frustum): per-wave partial hashes
+        unsigned a0 = 0, a1 = 0;
+        for (int i = tid; i < k.fW + k.fH + k.D; i += kBlock) {
+            const float *src = i < k.fW ? k.fu + i : (i < k.fW + k.fH ? k.fv + (i - k.fW) : k.fd + (i - k.fW - k.fH));
+            const unsigned w = __float_as_uint(*src);
+            a0 ^= excl_mix(w + 0x9E3779B9u * (unsigned)(i + 1));
+            a1 ^= excl_mix((w ^ 0x7F4A7C15u) + 0x85EBCA77u * (unsigned)(i + 1));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a0 ^= __shfl_xor(a0, o); a1 ^= __shfl_xor(a1, o); }
+        if (lane == 0) { s_axes[2 + wave * 2] = a0; s_axes[3 + wave * 2] = a1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned a0 = 0, a1 = 0;
+        for (int w = 0; w < NT / 64; ++w) { a0 ^= s_axes[2 + w * 2]; a1 ^= s_axes[3 + w * 2]; }
+        s_axes[0] = a0; s_axes[1] = a1;
+    }
+    __syncthreads();
+    // another launch shape, other frustum axes or a fresh cache: every slot is free again
+    const bool fresh = (unsigned)s_hdr[0] != x.sig_lo || (unsigned)s_hdr[1] != x.sig_hi || (unsigned)s_hdr[3] != s_axes[0] || (unsigned)s_hdr[4] != s_axes[1];
+    const int now = (fresh ? 0 : s_hdr[2]) + 1;
+    if (fresh) {
+        for (int i = tid; i < x.slots * kExclMetaWords; i += kBlock) cache[kExclHeaderWords + i] = 0;
+        for (int s = tid; s < x.slots; s += kBlock) { s_h0[s] = 0u; s_h1[s] = 0u; s_stg[s] = 0; s_stamp[s] = 0; }
+        __threadfence();                                             // (wave 0 writes some of these words again below)
+    }
+    __syncthreads();
+    for (int b = wave; b < nb; b += kBlock / 64) {
+        unsigned h0 = 0, h1 = 0;
+        for (int i = lane; i < nw; i += 64) {
+            const unsigned w = s_mat[b][i];
+            h0 ^= excl_mix(w + 0x9E3779B9u * (unsigned)(i + 1));
+            h1 ^= excl_mix((w ^ 0x7F4A7C15u) + 0x85EBCA77u * (unsigned)(i + 1));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { h0 ^= __shfl_xor(h0, o); h1 ^= __shfl_xor(h1, o); }
+        int found = -1;
+        for (int base = 0; base < x.slots && found < 0; base += 64) {
+            const int s = base + lane;
+            const bool cand = s < x.slots && s_stg[s] > 0 && s_h0[s] == h0 && s_h1[s] == h1;
+            unsigned long long mask = __ballot(cand);
+            while (mask != 0ull && found < 0) {                      // candidates of these 64 slots, lowest first: the matrices decide
+                const int c = base + __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const unsigned *sm = reinterpret_cast<const unsigned *>(excl_mats(cache, x, c));
+                bool same = true;
+                for (int i = lane; i < nw; i += 64) same = same && sm[i] == s_mat[b][i];
+                if (__all(same)) found = c;
+            }
+        }
+        if (lane == 0) { s_hash[b][0] = h0; s_hash[b][1] = h1; s_slot[b] = found; s_stage[b] = found >= 0 ? s_stg[found] : 0; }
+    }
+    __syncthreads();
+    if (wave != 0) return;                                           // (nothing below synchronises the workgroup)
+    // wave 0: samples in order.  mode: 0 none, 1 mark, 2 verify, 3 use
+    for (int b = 0; b < nb; ++b) {
+        int slot = s_slot[b], mode = 0;
+        int first = b;                                               // the first sample of the call with these matrices
+        for (int p = b - 1; p >= 0; --p) {
+            if (s_hash[p][0] != s_hash[b][0] || s_hash[p][1] != s_hash[b][1]) continue;
+            bool same = true;
+            for (int i = lane; i < nw; i += 64) same = same && s_mat[p][i] == s_mat[b][i];
+            if (__all(same)) first = p;
+        }
+        if (first != b) {                                            // a duplicate: uses what was learnt before this call, learns nothing
+            slot = s_slot[first];                                    // (s_stage 0: its first claimed the slot in this call)
+            mode = (slot >= 0 && s_stage[first] >= 2) ? 3 : 0;
+        } else if (slot >= 0) {                                      // known calibration: one stage further
+            mode = s_stage[b] >= 2 ? 3 : 2;
+            if (lane == 0) { int32_t *mt = excl_meta(cache, slot); mt[2] = mode; mt[3] = now; }
+        } else {                                                     // new calibration: the least recently used slot this call does not use
+            int best = 0x7FFFFFFF, arg = -1;
+            for (int s = lane; s < x.slots; s += 64) {
+                const int key = s_stg[s] > 0 ? s_stamp[s] : 0;
+                bool taken = false;
+                for (int p = 0; p < nb; ++p) taken = taken || s_slot[p] == s;
+                if (!taken && key < best) { best = key; arg = s; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ob = __shfl_xor(best, o), oa = __shfl_xor(arg, o);
+                if (oa >= 0 && (arg < 0 || ob < best || (ob == best && oa < arg))) { best = ob; arg = oa; }
+            }
+            if (arg >= 0) {
+                slot = arg; mode = 1;
+                unsigned *sm = reinterpret_cast<unsigned *>(excl_mats(cache, x, slot));
+                for (int i = lane; i < nw; i += 64) sm[i] = s_mat[b][i];
+                if (lane == 0) {
+                    int32_t *mt = excl_meta(cache, slot);
+                    mt[0] = (int)s_hash[b][0]; mt[1] = (int)s_hash[b][1]; mt[2] = 1; mt[3] = now;
+                }
+                s_slot[b] = slot; s_stage[b] = 0;                    // (every lane stores the same values)
+            }
+        }
+        if (lane == 0) {                                             // (device-scope stores: read by every XCD in this kernel)
+            __hip_atomic_store(cache + 8 + b, slot < 0 ? 0 : slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cache + 24 + b, slot < 0 ? 0 : mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (lane == 0) {
+        cache[2] = now;
+        if (fresh) { cache[0] = (int)x.sig_lo; cache[1] = (int)x.sig_hi; cache[3] = (int)s_axes[0]; cache[4] = (int)s_axes[1]; }
+    }
+    if (lane == 0) __hip_atomic_store(cache + 5, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);    // (orders the two stores above before it)
+}
+
 // Forward: a workgroup owns one image column of one camera (optionally a depth slab of it).  Its geometry is reduced to
 // (cell, depth) records in LDS by all threads at once (coalesced in the pixel-major layout), the column's fH context
 // rows are staged in LDS as fp32, then every lane group walks `kd` consecutive depth bins x fH rows, summing
@@ -483,6 +673,9 @@ struct RayArgs {
     int pm, write_dropped;
     int dsplit, dspan, kd;         // forward: depth slabs per ray, bins per slab, bins per lane group
     int compact;                   // forward: walk only the depth bins that hold a kept point (long rays: most far bins are empty)
+    int reg;                       // forward: the register walk (lss_ray_fwd_reg: fH <= 16, C <= 80, short rays)
+    int32_t *excl;                 // forward (register walk, camera form), nullable: the exclusive-cell cache
+    ExclShape xs;
     int wpc;                       // backward: workgroups per camera
     const int32_t *geom;           // geom form: int32 voxel indices per point; camera form (template CAM): unused
     const float *combine, *fu, *fv, *fd;   // camera form: [B*N, 16] matrices and the frustum's three axes (mmt_camera.h)
@@ -758,6 +951,338 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd(RayArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Forward for columns of up to 16 image rows (every BASELINE config but cfg5): the REGISTER walk.
+// The walk of lss_ray_fwd is bound by instruction issue, not by memory: a wave64 instruction holds its SIMD16 for four
+// cycles, and per point it spends ~17 of them (record read, key compare, S context reads, S multiply-adds, loop) --
+// 16 us of the kernel's 34 at cfg4 (measured with the walk compiled out / the flush compiled out).  Here
+//   * a lane group keeps the column's WHOLE context tile in registers (16 rows x S channels: loaded from LDS once, not once
+//     per depth bin), so a point costs its multiply-adds only -- two channels per v_pk_fma_f32;
+//   * the geometry phase, which knows it anyway, leaves ONE key per (depth bin): the cell shared by all kept rows of the bin
+//     (the rule on a level rig), "no kept row" (the bin is skipped) or "mixed" (the rows are walked one by one from LDS, as
+//     before); the 16 depths of a bin arrive as four 16-byte LDS reads;
+//   * 128 threads per column (8 lane groups): the geometry phase has one thread per depth bin and 112 bins -- the second
+//     half of a 256-thread workgroup idled through it -- and ~110 VGPRs x 2 waves leave room for every column of the
+//     launch to be resident at once.
+// The sums are formed in the order of lss_ray_fwd (bins ascending, rows ascending, one fused multiply-add per point).
+constexpr int kRegBlock = 128;
+constexpr int kBinStride = 20;      // LDS floats per depth bin: 16 rows + 4 of padding (16-byte vectors of neighbouring bins on different banks)
+typedef float mmt_v2f __attribute__((ext_vector_type(2)));
+
+__host__ __device__ inline size_t ray_fwd_reg_lds(int C, int dspan) { return (size_t)16 * (C + 4) * 4 + (size_t)dspan * (kBinStride * 8 + 4); }
+
+template <typename FT, int S, bool CAM>
+__global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
+    extern __shared__ __align__(16) float ray_lds[];
+    constexpr int C = 16 * S, CP = C + 4, NT = kRegBlock, BS = kBinStride, NP = S / 2;
+    int L = blockIdx.x;
+    if constexpr (CAM) {
+        if (a.excl) {                                 // exclusive-cell cache: block 0 looks the call's samples up, the columns follow
+            if (L == 0) {
+                ExclCall k;
+                k.cache = a.excl; k.combine = a.combine; k.fu = a.fu; k.fv = a.fv; k.fd = a.fd;
+                k.B = a.BN / a.N; k.fW = a.fW; k.fH = a.fH; k.D = a.D; k.xs = a.xs;
+                excl_select<NT>(k, ray_lds);
+                return;
+            }
+            --L;
+        }
+    }
+    const int xcd = L & 7, i = L >> 3;
+    const int per = a.fW * a.dsplit;
+    const int q = i / per, r = i - q * per;
+    const int bn = q * 8 + xcd;                       // the columns of one camera share an XCD (context rows, geom lines)
+    if (bn >= a.BN) return;
+    const int col = r / a.dsplit, slab = r - col * a.dsplit;
+    const int d0 = slab * a.dspan;
+    const int dn = (a.D - d0) < a.dspan ? (a.D - d0) : a.dspan;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fH = a.fH, HW = a.fH * a.fW;            // fH <= 16
+    const int b = bn / a.N;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+    float *ctx = ray_lds;                                             // [fH][CP] fp32 context rows
+    float *dep = ray_lds + 16 * CP;                                   // [dspan][BS]: depths of a bin's rows, 0 for a dropped or missing row
+    int *keyrow = reinterpret_cast<int *>(dep + (size_t)a.dspan * BS); // [dspan][BS]: cell (| kExclFlag) of a row, -1 dropped
+    int *bkey = keyrow + (size_t)a.dspan * BS;                        // [dspan]: the bin's key (see above): cell, -1 nothing kept, -2 mixed
+#ifdef LSS_STAMPS
+    unsigned long long *fstamps = reinterpret_cast<unsigned long long *>(a.pos_memo) + (int64_t)blockIdx.x * 8;
+    a.pos_memo = nullptr;
+#endif
+    FWD_STAMP(0);
+
+    // ---- geometry -> per-bin depths and keys
+    if constexpr (CAM) {
+        float cm[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cm[k] = a.combine[bn * 16 + k];
+        const float cu = a.fu[col];
+        const int64_t rstep = a.pm ? (int64_t)a.fW * a.D : a.fW;              // points between consecutive image rows
+#pragma unroll 1
+        for (int dd = tid; dd < dn; dd += NT) {
+            const mmt_cam_column cc = mmt_cam_column_make(cm, cu, a.fd[d0 + dd]);
+            int2 *sum = a.summary ? a.summary + ((int64_t)bn * a.fW + col) * a.D + d0 + dd : nullptr;      // one block of rows: fH <= 16
+            const bool cached = sum && a.summary_cached;
+            int2 sv = make_int2(-1, 0);
+            if (cached) sv = *sum;
+            unsigned zm16 = 0;
+            bool uni16 = cached ? (sv.y & mmt::kSummaryUniform) != 0 : true, in00 = false;
+            int x00 = 0, y00 = 0, ukey = -1;                                  // ukey: key of the first kept row
+#pragma unroll 1
+            for (int hb = 0; hb < 16; hb += 8) {
+                float dvs[8];
+                int ks[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { dvs[u] = 0.f; ks[u] = -1; }
+                if (hb < fH) {
+                    const int nh = (fH - hb) < 8 ? (fH - hb) : 8;
+                    const int64_t t0 = ray_point(a, bn, hb, col, d0 + dd);
+                    float dv[8], cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        dv[u] = Elem<FT>::scalar(depth + t0 + (u < nh ? u : nh - 1) * rstep);
+                        cv[u] = a.fv[hb + (u < nh ? u : nh - 1)];
+                    }
+                    bool uniform, in0;
+                    int x0, y0;
+                    unsigned zmask;
+                    if (cached) {
+                        in0 = sv.x >= 0; x0 = sv.x & 0xFFFF; y0 = sv.x >> 16;
+                        zmask = ((unsigned)sv.y >> hb) & 0xFFu;
+                        uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
+                    } else {
+                        zmask = mmt_cam_column_cells<8>(cc, cv, nh, mmt_rows_sorted<8>(cv, nh), a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
+                        zm16 |= zmask << hb;
+                        if (hb == 0) { uni16 = uniform; in00 = in0; x00 = x0; y00 = y0; }
+                        else uni16 = uni16 && uniform && in0 == in00 && x0 == x00 && y0 == y00;
+                    }
+                    const int cell0 = in0 ? (b * a.ny + y0) * a.nx + x0 : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < nh) {
+                            int gx = x0, gy = y0, cell = cell0;
+                            if (!uniform) cell = mmt_cam_row_xy(cc, cv[u], a.q, a.nx, a.ny, gx, gy) ? (b * a.ny + gy) * a.nx + gx : -1;
+                            const bool keep = ((zmask >> u) & 1u) && cell >= 0;
+                            if (keep) {
+                                dvs[u] = dv[u]; ks[u] = cell;
+                                if (ukey < 0) ukey = ks[u];
+                            }
+                            if (a.pos_memo) {
+                                const int64_t t = t0 + u * rstep;
+                                if (keep) {
+                                    a.pos_memo[t * 3] = b; a.pos_memo[t * 3 + 1] = gy; a.pos_memo[t * 3 + 2] = gx;
+                                } else if (a.write_dropped) {
+                                    a.pos_memo[t * 3] = -1; a.pos_memo[t * 3 + 1] = -1; a.pos_memo[t * 3 + 2] = -1;
+                                }
+                            }
+                        }
+                    }
+                }
+                float4 *dq = reinterpret_cast<float4 *>(dep + dd * BS + hb);
+                int4 *kq = reinterpret_cast<int4 *>(keyrow + dd * BS + hb);
+                dq[0] = make_float4(dvs[0], dvs[1], dvs[2], dvs[3]); dq[1] = make_float4(dvs[4], dvs[5], dvs[6], dvs[7]);
+                kq[0] = make_int4(ks[0], ks[1], ks[2], ks[3]); kq[1] = make_int4(ks[4], ks[5], ks[6], ks[7]);
+            }
+            if (sum && !cached) *sum = make_int2(in00 ? ((y00 << 16) | x00) : -1, (int)zm16 | (uni16 ? mmt::kSummaryUniform : 0));
+            bkey[dd] = ukey < 0 ? -1 : (uni16 ? ukey : -2);
+        }
+    } else {
+        const int npts = fH * dn;
+        for (int idx = tid; idx < dn * 16; idx += NT) {                       // rows past fH: nothing
+            const int dd = idx >> 4, row = idx & 15;
+            if (row >= fH) { dep[dd * BS + row] = 0.f; keyrow[dd * BS + row] = -1; }
+        }
+        for (int p0 = tid; p0 < npts; p0 += NT * 4) {
+            int gx[4], gy[4], gz[4];
+            float dv[4];
+            int64_t t[4];
+            int row_of[4], dd_of[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * NT;
+                const int pc = p < npts ? p : 0;
+                const int row = pc / dn, dd = pc - row * dn;
+                row_of[u] = row; dd_of[u] = dd;
+                t[u] = ray_point(a, bn, row, col, d0 + dd);
+                gx[u] = a.geom[t[u] * 3]; gy[u] = a.geom[t[u] * 3 + 1]; gz[u] = a.geom[t[u] * 3 + 2];
+                dv[u] = Elem<FT>::scalar(depth + t[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * NT;
+                if (p < npts) {
+                    const bool keep = !(gx[u] < 0 || gx[u] >= a.nx || gy[u] < 0 || gy[u] >= a.ny || gz[u] < 0 || gz[u] >= a.nz);
+                    dep[dd_of[u] * BS + row_of[u]] = keep ? dv[u] : 0.f;
+                    keyrow[dd_of[u] * BS + row_of[u]] = keep ? (b * a.ny + gy[u]) * a.nx + gx[u] : -1;
+                    if (a.pos_memo) {
+                        if (keep) {
+                            a.pos_memo[t[u] * 3] = b; a.pos_memo[t[u] * 3 + 1] = gy[u]; a.pos_memo[t[u] * 3 + 2] = gx[u];
+                        } else if (a.write_dropped) {
+                            a.pos_memo[t[u] * 3] = -1; a.pos_memo[t[u] * 3 + 1] = -1; a.pos_memo[t[u] * 3 + 2] = -1;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int dd = tid; dd < dn; dd += NT) {                              // the bin's key from its rows' keys
+            int ukey = -1;
+            bool same = true;
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int4 k4 = *reinterpret_cast<const int4 *>(keyrow + dd * BS + v4 * 4);
+                const int kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (kk[u] >= 0) {
+                        if (ukey < 0) ukey = kk[u];
+                        else same = same && kk[u] == ukey;
+                    }
+                }
+            }
+            bkey[dd] = ukey < 0 ? -1 : (same ? ukey : -2);
+        }
+    }
+    {
+        constexpr int VEC = Elem<FT>::VEC;
+        constexpr int CV = C / VEC;
+        for (int e = tid; e < fH * CV; e += NT) {
+            const int row = e / CV, cv = e - row * CV;
+            Elem<FT>::to_lds(context + ((int64_t)bn * HW + row * a.fW + col) * C + cv * VEC, ctx + row * CP + cv * VEC);
+        }
+    }
+    __syncthreads();
+    // ---- exclusive-cell cache: what block 0 decided for this sample (its verdict is long there: the select takes ~3 us, the
+    // geometry phase above 7).  mode 3: the keys of single-run cells get their tag; state = the slot's int32 per cell
+    int excl_mode = 0;
+    int32_t *excl_st = nullptr;
+    if constexpr (CAM) {
+        if (a.excl && b < kExclMaxB) {
+            __shared__ int s_verdict[2];
+            if (tid == 0) {
+                // relaxed device-scope loads (they bypass the XCD's non-coherent lines); NO acquire fence: an acquire invalidates
+                // the XCD's L2 per poll, and the only words read behind the flag are the two below, read the same way
+                while (__hip_atomic_load(a.excl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                s_verdict[0] = __hip_atomic_load(a.excl + 24 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_verdict[1] = __hip_atomic_load(a.excl + 8 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            excl_mode = s_verdict[0];
+            excl_st = excl_state(a.excl, a.xs, s_verdict[1]) - (int64_t)b * a.xs.cells;      // indexed by the call's cell id
+            if (excl_mode == 3) {
+                for (int dd = tid; dd < dn; dd += NT) {
+                    const int k = bkey[dd];
+                    if (k >= 0) {
+                        if (excl_st[k] > 0) bkey[dd] = k | kExclFlag;
+                    } else if (k == -2) {
+                        for (int row = 0; row < fH; ++row) {
+                            const int kk = keyrow[dd * BS + row];
+                            if (kk >= 0 && excl_st[kk] > 0) keyrow[dd * BS + row] = kk | kExclFlag;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    FWD_STAMP(1);
+#ifdef LSS_EXP_NOWALK
+    if (a.D != 12345) return;
+#endif
+
+    // ---- 8 lane groups: an equal share of the depth bins each; the context tile in registers
+    const int g = lane >> 4, li = lane & 15;
+    const int share = (dn + NT / 16 - 1) / (NT / 16);
+    const int ds = (wave * 4 + g) * share;
+    const int de = (ds + share) < dn ? (ds + share) : dn;
+    const float *cl = ctx + li;
+    mmt_v2f c2[16][NP > 0 ? NP : 1];
+    float c1[16];
+#pragma unroll
+    for (int row = 0; row < 16; ++row) {
+        const bool live = row < fH;
+        const float *cr = cl + (live ? row : 0) * CP;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float lo = cr[16 * (2 * p)], hi = cr[16 * (2 * p + 1)];
+            c2[row][p].x = live ? lo : 0.f; c2[row][p].y = live ? hi : 0.f;
+        }
+        if constexpr (S & 1) { const float v = cr[16 * (S - 1)]; c1[row] = live ? v : 0.f; }
+    }
+    mmt_v2f acc2[NP > 0 ? NP : 1];
+    float acc1 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc2[p] = mmt_v2f{0.f, 0.f};
+    int cur = -1, run_at = 0;                        // run_at: (bin, row) the current run began at
+    // a run's id: the same in every launch of this shape, whatever the sample's place in the batch
+    const int run_base = (((((bn - b * a.N) * a.fW + col) * a.dsplit + slab) * (NT / 16) + wave * 4 + g) * a.dspan) * 16 + 1;
+    auto flush = [&]() __attribute__((always_inline)) {
+#ifdef LSS_EXP_NOFLUSH
+        if (acc1 != 12345.f) return;
+#endif
+        const int cellid = cur & (kExclFlag - 1);
+        float *o = a.out + (int64_t)cellid * C + li;
+        if (cur & kExclFlag) {                      // the only run of the launch into this cell: the zero-filled row is simply written
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { o[16 * (2 * p)] = acc2[p].x; o[16 * (2 * p + 1)] = acc2[p].y; }
+            if constexpr (S & 1) o[16 * (S - 1)] = acc1;
+        } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { unsafeAtomicAdd(o + 16 * (2 * p), acc2[p].x); unsafeAtomicAdd(o + 16 * (2 * p + 1), acc2[p].y); }
+            if constexpr (S & 1) unsafeAtomicAdd(o + 16 * (S - 1), acc1);
+            if constexpr (CAM) {
+                if (li == 0 && (excl_mode == 1 || excl_mode == 2)) {
+                    const int id = run_base + run_at;
+                    if (excl_mode == 1) excl_st[cellid] = id;                       // MARK: some run's id survives
+                    else if (excl_st[cellid] != id) excl_st[cellid] = -1;           // VERIFY: the cell has another run
+                }
+            }
+        }
+    };
+    auto renew = [&](int key, int at) __attribute__((always_inline)) {
+        if (cur >= 0) flush();
+        cur = key; run_at = at;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc2[p] = mmt_v2f{0.f, 0.f};
+        acc1 = 0.f;
+    };
+#pragma unroll 1
+    for (int e = ds; e < de; ++e) {
+        const int k = bkey[e];
+        if (k == -1) continue;
+        if (k >= 0) {
+            if (k != cur) renew(k, e * 16);
+            const float4 *dp = reinterpret_cast<const float4 *>(dep + e * BS);
+            const float4 d0v = dp[0], d1v = dp[1], d2v = dp[2], d3v = dp[3];
+            const float dv[16] = {d0v.x, d0v.y, d0v.z, d0v.w, d1v.x, d1v.y, d1v.z, d1v.w, d2v.x, d2v.y, d2v.z, d2v.w, d3v.x, d3v.y, d3v.z, d3v.w};
+#pragma unroll
+            for (int row = 0; row < 16; ++row) {
+                const mmt_v2f d2 = {dv[row], dv[row]};
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc2[p] = __builtin_elementwise_fma(d2, c2[row][p], acc2[p]);
+                if constexpr (S & 1) acc1 = __builtin_fmaf(dv[row], c1[row], acc1);
+            }
+        } else {                                    // mixed bin (rare): row by row, context from LDS
+#pragma unroll 1
+            for (int row = 0; row < fH; ++row) {
+                const int key = keyrow[e * BS + row];
+                const float dv = dep[e * BS + row];
+                if (key >= 0 && key != cur) renew(key, e * 16 + row);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    acc2[p].x = __builtin_fmaf(dv, cl[row * CP + 16 * (2 * p)], acc2[p].x);
+                    acc2[p].y = __builtin_fmaf(dv, cl[row * CP + 16 * (2 * p + 1)], acc2[p].y);
+                }
+                if constexpr (S & 1) acc1 = __builtin_fmaf(dv, cl[row * CP + 16 * (S - 1)], acc1);
+            }
+        }
+    }
+    if (cur >= 0) flush();
+#ifdef LSS_STAMPS
+    if (lane == 0 && fstamps) fstamps[2 + wave] = __builtin_amdgcn_s_memtime();
+#endif
+}
+
 __device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes of a quad, in all 4 (DPP quad_perm, no LDS)
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
@@ -1002,20 +1527,27 @@ __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
 
 // forward ray walk: depth slabs per ray (LDS within 64 KB; whole rays unless that leaves the chip short of workgroups) and
 // the depth bins of each of the 16 lane groups
+size_t ray_fwd_lds(const RayArgs &r, int dspan) {
+    if (r.reg) return ray_fwd_reg_lds(r.C, dspan);
+    return (size_t)r.fH * (r.C + 4) * 4 + (size_t)r.fH * (dspan | 1) * 8 + (size_t)dspan * 8;
+}
+
 bool pick_ray_forward(RayArgs *r) {
     int dsplit = 1;
     static const char *env = getenv("MMT_RAY_DSPLIT");     // experiments only
     if (env && atoi(env) > 0) dsplit = atoi(env);
     else while ((int64_t)r->BN * r->fW * dsplit < 1024 && (r->D + dsplit) / (dsplit + 1) >= 16) ++dsplit;
     if (dsplit > r->D) dsplit = r->D;
+    r->compact = (r->D >= 160 || r->fH > 32) ? 1 : 0;              // long rays / tall columns: most (bin, row) pairs lie outside the grid
+    static const char *no_reg = getenv("MMT_RAY_NO_REG");          // experiments only
+    r->reg = (!r->compact && r->fH <= 16 && r->C <= 80 && !(no_reg && atoi(no_reg) > 0)) ? 1 : 0;
     for (;; ++dsplit) {
         const int dspan = (r->D + dsplit - 1) / dsplit;
-        const size_t lds = (size_t)r->fH * (r->C + 4) * 4 + (size_t)r->fH * (dspan | 1) * 8 + (size_t)dspan * 8;
+        const size_t lds = ray_fwd_lds(*r, dspan);
         if (lds <= 64 * 1024) {
             r->dspan = dspan;
             r->dsplit = (r->D + dspan - 1) / dspan;
             r->kd = (dspan + kBlock / 16 - 1) / (kBlock / 16);
-            r->compact = (r->D >= 160 || r->fH > 32) ? 1 : 0;      // long rays / tall columns: most (bin, row) pairs lie outside the grid
             return true;
         }
         if (dspan == 1) return false;
@@ -1049,7 +1581,8 @@ volatile int g_last_family[2] = {0, 0};
 // zero-fill of the BEV map in front of the forward (MMT_LSS_ZERO_OUTPUT): `sc1` stores leave no line behind in the XCD L2s,
 // so the memory-side atomics that follow do not wait for freshly written lines to be evicted (a torch.zeros right before
 // the launch cost the forward 2.2 us, tools/kbench_fused.py `after_zero_fill`)
-__global__ __launch_bounds__(kBlock) void lss_zero_fill(float4 *p, int64_t n4) {
+__global__ __launch_bounds__(kBlock) void lss_zero_fill(float4 *p, int64_t n4, int32_t *excl_ready) {
+    if (excl_ready != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *excl_ready = 0;      // the forward's select step sets it (see excl_select)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7FFFFFFF, 0x00020000);
     const mmt_u32x4 z = {0u, 0u, 0u, 0u};
@@ -1077,10 +1610,11 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     if ((flags & MMT_LSS_ZERO_OUTPUT) && (((uintptr_t)out & 15) != 0 || out_elems * 4 >= (1ll << 31)))
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: MMT_LSS_ZERO_OUTPUT needs a 16-byte aligned map below 2 GiB", what);
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
+    int32_t *excl_ready = nullptr;
     auto zero_fill = [&]() {
         if (flags & MMT_LSS_ZERO_OUTPUT)
             seq.launch(false, lss_zero_fill, dim3((unsigned)mmt::stream_grid(out_elems / 4, kBlock, 2048)), dim3(kBlock), 0, st,
-                       reinterpret_cast<float4 *>(out), out_elems / 4);
+                       reinterpret_cast<float4 *>(out), out_elems / 4, excl_ready);
     };
     if (!(flags & MMT_LSS_TILE_KERNELS) && (C == 64 || C == 80 || C == 128)) {   // other widths: the tile kernels
         RayArgs r = {};
@@ -1093,12 +1627,43 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
             r.summary = reinterpret_cast<int2 *>(cam->summary); r.summary_cached = cam->summary_cached;
         }
         if (pick_ray_forward(&r)) {
-            const size_t lds = (size_t)fH * (C + 4) * 4 + (size_t)fH * (r.dspan | 1) * 8 + (size_t)r.dspan * 8;
-            const int64_t grid = 8ll * ((r.BN + 7) / 8) * fW * r.dsplit;
-            if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+            size_t lds = ray_fwd_lds(r, r.dspan);
+            int64_t grid = 8ll * ((r.BN + 7) / 8) * fW * r.dsplit;
+            if (grid >= (1ll << 31) - 1) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+            // the exclusive-cell cache: register walk + in-library zero-fill only (the select step rides on the fill kernel);
+            // other shapes ignore it.  Run ids and tagged cell ids must fit 31 / 30 bits.
+            if (cam && cam->excl && r.reg && (flags & MMT_LSS_ZERO_OUTPUT) && N <= kExclMaxN && (int64_t)B * ny * nx < kExclFlag &&
+                (int64_t)N * fW * r.dsplit * (kRegBlock / 16) * r.dspan * 16 < (1ll << 31) - 2) {
+                ExclShape xs = {};
+                xs.N = N; xs.cells = ny * nx;
+                const int64_t fit = (cam->excl_bytes / 4 - kExclHeaderWords) / excl_slot_words(N, xs.cells);
+                if (fit < 1) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the exclusive-cell cache holds no slot (%lld bytes; mmt_lss_exclusive_cache_bytes)", what,
+                                              (long long)cam->excl_bytes);
+                xs.slots = fit > kExclMaxSlots ? kExclMaxSlots : (int)fit;
+                // the launch shape the learnt states depend on (run decomposition and cell numbering)
+                int words[17] = {N, D, fH, fW, nx, ny, nz, r.dsplit, r.dspan, kRegBlock, xs.slots};
+                memcpy(words + 11, cam->q.lo, 12);
+                memcpy(words + 14, cam->q.vs, 12);
+                uint64_t h = 0xCBF29CE484222325ull;
+                for (int w : words) { h ^= (uint32_t)w; h *= 0x100000001B3ull; h ^= h >> 29; }
+                xs.sig_lo = (unsigned)h | 1u; xs.sig_hi = (unsigned)(h >> 32);
+                r.excl = cam->excl; r.xs = xs;
+                excl_ready = cam->excl + 5;
+                grid += 1;                                                   // block 0: the select step
+                if (excl_select_lds(xs.slots) > lds) lds = excl_select_lds(xs.slots);
+            }
             zero_fill();
             const dim3 g((unsigned)grid), blk(kBlock);
-            if (cam) {
+            if (r.reg) {
+                const dim3 rb(kRegBlock);
+                if (cam) {
+                    if (C == 80) seq.launch(true, lss_ray_fwd_reg<FT, 5, true>, g, rb, lds, st, r);
+                    else seq.launch(true, lss_ray_fwd_reg<FT, 4, true>, g, rb, lds, st, r);
+                } else {
+                    if (C == 80) seq.launch(true, lss_ray_fwd_reg<FT, 5, false>, g, rb, lds, st, r);
+                    else seq.launch(true, lss_ray_fwd_reg<FT, 4, false>, g, rb, lds, st, r);
+                }
+            } else if (cam) {
                 if (C == 80) seq.launch(true, lss_ray_fwd<FT, 5, true>, g, blk, lds, st, r);
                 else if (C == 64) seq.launch(true, lss_ray_fwd<FT, 4, true>, g, blk, lds, st, r);
                 else seq.launch(true, lss_ray_fwd<FT, 8, true>, g, blk, lds, st, r);
@@ -1107,7 +1672,8 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
                 else if (C == 64) seq.launch(true, lss_ray_fwd<FT, 4, false>, g, blk, lds, st, r);
                 else seq.launch(true, lss_ray_fwd<FT, 8, false>, g, blk, lds, st, r);
             }
-            g_last_family[0] = MMT_LSS_FAMILY_RAY | (cam ? MMT_LSS_FAMILY_CAMERA : 0);
+            g_last_family[0] = MMT_LSS_FAMILY_RAY | (cam ? MMT_LSS_FAMILY_CAMERA : 0) | (r.reg ? MMT_LSS_FAMILY_REGISTER : 0) |
+                               (r.excl ? MMT_LSS_FAMILY_EXCLUSIVE : 0);
             return mmt::check_launch(what);
         }
     }
@@ -1282,22 +1848,38 @@ int make_cam(const char *what, const float *combine, const float *fu, const floa
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the column summary needs an 8-byte aligned buffer and a grid below 32768 x 32768", what);
     cam->combine = combine; cam->fu = fu; cam->fv = fv; cam->fd = fd;
     cam->summary = summary; cam->summary_cached = summary_cached;
+    cam->excl = nullptr; cam->excl_bytes = 0;
     mmt::make_cam_grid(vc, vs, &cam->q);
     if (nx > 0 && ny > 0 && nz > 0) mmt::make_cam_range(&cam->q, nx, ny, nz);      // (non-positive sizes are refused further down)
     return MMT_OK;
 }
+int attach_excl(const char *what, int32_t *cache, int64_t bytes, mmt::CamGeom *cam) {
+    if (!cache) return MMT_OK;
+    if (((uintptr_t)cache & 15) != 0 || bytes < kExclHeaderWords * 4)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the exclusive-cell cache needs a 16-byte aligned buffer of mmt_lss_exclusive_cache_bytes() bytes", what);
+    cam->excl = cache; cam->excl_bytes = bytes;
+    return MMT_OK;
+}
 }  // namespace
+
+// bytes of an exclusive-cell cache for `slots` calibrations of N cameras on an nx x ny map (int32 words, zero-initialised once)
+extern "C" int64_t mmt_lss_exclusive_cache_bytes(int N, int nx, int ny, int slots) {
+    if (N <= 0 || nx <= 0 || ny <= 0 || slots <= 0 || (int64_t)nx * ny >= kExclFlag) return 0;
+    if (slots > kExclMaxSlots) slots = kExclMaxSlots;
+    return 4 * ((int64_t)kExclHeaderWords + (int64_t)slots * excl_slot_words(N, nx * ny));
+}
 
 extern "C" int mmt_lss_splat_forward_cam(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
         const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
         const float *voxel_size_host, const float *depth, const float *context, float *out, int32_t *pos_memo,
-        int32_t *column_summary, int flags, void *stream) {
+        int32_t *column_summary, int32_t *exclusive_cache, int64_t exclusive_cache_bytes, int flags, void *stream) {
     MMT_REQUIRE_PTR(depth);
     MMT_REQUIRE_PTR(context);
     MMT_REQUIRE_PTR(out);
     mmt::CamGeom cam;
     if (const int rc = make_cam("lss_splat_forward_cam", combine, frustum_u, frustum_v, frustum_d, voxel_coord_host, voxel_size_host, nx, ny, nz,
                                 column_summary, (flags & MMT_LSS_SUMMARY_CACHED) ? 1 : 0, &cam)) return rc;
+    if (const int rc = attach_excl("lss_splat_forward_cam", exclusive_cache, exclusive_cache_bytes, &cam)) return rc;
     return forward_impl<float>("lss_splat_forward_cam", B, N, D, fH, fW, C, nx, ny, nz, nullptr, &cam, depth, context, out, pos_memo,
                                 flags & ~MMT_LSS_SUMMARY_CACHED, (hipStream_t)stream);
 }
@@ -1305,13 +1887,14 @@ extern "C" int mmt_lss_splat_forward_cam(int B, int N, int D, int fH, int fW, in
 extern "C" int mmt_lss_splat_forward_cam_bf16(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
         const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
         const float *voxel_size_host, const uint16_t *depth, const uint16_t *context, float *out, int32_t *pos_memo,
-        int32_t *column_summary, int flags, void *stream) {
+        int32_t *column_summary, int32_t *exclusive_cache, int64_t exclusive_cache_bytes, int flags, void *stream) {
     MMT_REQUIRE_PTR(depth);
     MMT_REQUIRE_PTR(context);
     MMT_REQUIRE_PTR(out);
     mmt::CamGeom cam;
     if (const int rc = make_cam("lss_splat_forward_cam_bf16", combine, frustum_u, frustum_v, frustum_d, voxel_coord_host, voxel_size_host, nx, ny, nz,
                                 column_summary, (flags & MMT_LSS_SUMMARY_CACHED) ? 1 : 0, &cam)) return rc;
+    if (const int rc = attach_excl("lss_splat_forward_cam_bf16", exclusive_cache, exclusive_cache_bytes, &cam)) return rc;
     return forward_impl<bf16_t>("lss_splat_forward_cam_bf16", B, N, D, fH, fW, C, nx, ny, nz, nullptr, &cam, depth, context, out, pos_memo,
                                 flags & ~MMT_LSS_SUMMARY_CACHED, (hipStream_t)stream);
 }

@@ -89,6 +89,8 @@ struct CamGeom {
     // dwords per block then.  Blocks without bit 16 are evaluated row by row from the matrices wherever they are met.
     int32_t *summary;
     int summary_cached;
+    int32_t *excl;           // nullable: exclusive-cell cache of the forward (lift_splat_tile.hip), persistent, zero-initialised once
+    int64_t excl_bytes;
 };
 constexpr int kSummaryUniform = 0x10000;
 

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from ...ops.bev_geometry import (camera_form_supported, frustum_axes, frustum_geometry, lift_features, lift_splat,
-                                 lift_splat_camera, new_column_summary)
+                                 lift_splat_camera, new_column_summary, new_exclusive_cache)
 from ...ops.bn_relu import ConvBNAct, bn_act
 from ...ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling, voxel_pooling_bf16, voxel_pooling_planned
 from ..nets import BasicBlock, DeformConv2dPack, ResNet, SECONDFPN
@@ -142,6 +142,11 @@ class LSSFPN(nn.Module):
         self._plan_cache = {}     # calibration_id -> VoxelPoolingPlan (see _forward_single_sweep)
         self._combine_cache = {}  # calibration_id -> camera matrices sensor2ego @ inverse(intrin)
         self._summary_cache = {}  # calibration_id -> column summary of the camera form (8 bytes per 16 points; ops/bev_geometry.py)
+        # exclusive-cell caches of the camera-form forward, (device, cameras, stream) -> int32 tensor: which BEV cells a single
+        # run reaches, learnt on the device per calibration (no id needed; include/mmt_hip.h `exclusive_cache`).
+        # MMT_LSS_EXCL_SLOTS calibrations (default 1024: 64 MiB on a 128 x 128 map), 0 switches it off.
+        self._excl_caches = {}
+        self.exclusive_slots = int(os.environ.get("MMT_LSS_EXCL_SLOTS", "1024"))
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
         self.register_buffer('voxel_size', torch.Tensor([row[2] for row in rows]))
@@ -206,6 +211,17 @@ class LSSFPN(nn.Module):
             combine = self.camera_matrices(sensor2ego_mat, intrin_mat)
         fr = self.frustum_pixel_major if pixel_major else self.frustum
         return frustum_geometry(fr.contiguous(), combine, self._voxel_coord_host, self._voxel_size_host)
+
+    def _exclusive_cache_for(self, num_cams, device):
+        if self.exclusive_slots <= 0:
+            return None
+        key = (str(device), int(num_cams), torch.cuda.current_stream(device).cuda_stream)      # calls sharing a cache are stream-ordered
+        cache = self._excl_caches.get(key)
+        if cache is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None                             # (allocate outside a capture: the cache must outlive the graph's pool)
+            cache = self._excl_caches[key] = new_exclusive_cache(num_cams, self._voxel_num_host, device, self.exclusive_slots)
+        return cache
 
     def _adaptive_column_choice(self, device):
         """"auto" without a calibration id: (use the column kernel?, the counters it accumulates into)."""
@@ -337,7 +353,8 @@ class LSSFPN(nn.Module):
                         summary = self._summary_cache[ckey] = new_column_summary(batch_size, num_cams, self.depth_channels, fH, fW, context.device)
                 feature_map = lift_splat_camera(combine, (self.frustum_u, self.frustum_v, self.frustum_d), dep_in, ctx_in,
                                                 self._voxel_num_host, self._voxel_coord_host, self._voxel_size_host,
-                                                column_backward=col_bwd, column_stats=stats, summary=summary, summary_cached=cached)
+                                                column_backward=col_bwd, column_stats=stats, summary=summary, summary_cached=cached,
+                                                exclusive_cache=self._exclusive_cache_for(num_cams, context.device))
             elif fused_kind == "geom_pm":
                 col_bwd, _ = self._use_column_backward(geom_xyz, calib_id if calib_id is not None else "_", context.device)
                 feature_map = lift_splat(geom_xyz, dep_in, ctx_in, self._voxel_num_host, pixel_major=True, column_backward=col_bwd)

@@ -267,11 +267,15 @@ def camera_form_supported(B, N, D, fH, fW, C):
     return bool(_lib.lib().mmt_lss_camera_form_supported(int(B), int(N), int(D), int(fH), int(fW), int(C)))
 
 
-def last_kernel_family(backward=False):
-    """Kernel family the calling thread's last fused lift-splat forward / backward call launched:
-    "ray" | "tile" | "column" | "none", + "+camera" for the camera form (mmt_lss_last_kernel_family)."""
+def last_kernel_family(backward=False, detail=False):
+    """Kernel family the process's last fused lift-splat forward / backward call launched:
+    "ray" | "tile" | "column" | "none", + "+camera" for the camera form (mmt_lss_last_kernel_family).
+    detail=True appends "+register" (the forward's register walk) and "+exclusive" (an exclusive-cell cache was used)."""
     v = _lib.lib().mmt_lss_last_kernel_family(1 if backward else 0)
-    return _lib.LSS_FAMILY.get(v & 0xF, "?") + ("+camera" if v & 0x10 else "")
+    name = _lib.LSS_FAMILY.get(v & 0xF, "?") + ("+camera" if v & 0x10 else "")
+    if detail:
+        name += ("+register" if v & _lib.LSS_FAMILY_REGISTER else "") + ("+exclusive" if v & _lib.LSS_FAMILY_EXCLUSIVE else "")
+    return name
 
 
 class LiftSplatCamera(Function):
@@ -282,7 +286,8 @@ class LiftSplatCamera(Function):
     ([B*N, fH, fW, D] = channels_last) order; the BEV map is zero-filled by the forward call itself."""
 
     @staticmethod
-    def forward(ctx, combine, axes, grid, depth, context, voxel_num, column_backward, column_stats, summary, summary_cached):
+    def forward(ctx, combine, axes, grid, depth, context, voxel_num, column_backward, column_stats, summary, summary_cached,
+                exclusive_cache=None):
         fu, fv, fd = axes
         vc, vs = grid
         B, N = combine.shape[:2]
@@ -308,10 +313,15 @@ class LiftSplatCamera(Function):
             summary, summary_cached = new_column_summary(B, N, D, fH, fW, depth.device), False
         elif tuple(summary.shape) != (BN, (fH + 15) // 16, fW, D, 2) or summary.dtype != torch.int32 or not summary.is_contiguous():
             raise RuntimeError("lift_splat_camera: column summary must be a contiguous int32 [B*N, ceil(fH/16), fW, D, 2] tensor")
+        if exclusive_cache is not None and (exclusive_cache.dtype != torch.int32 or not exclusive_cache.is_contiguous() or
+                                            exclusive_cache.device != depth.device):
+            raise RuntimeError("lift_splat_camera: the exclusive-cell cache must be a contiguous int32 tensor on the inputs' device")
         with torch.cuda.device(depth.device):
             _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward_cam" + ("_bf16" if bf16 else ""), B, N, D, fH, fW, C,
                             nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(), fd.data_ptr(), vc_c, vs_c,
                             depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), 0, summary.data_ptr(),
+                            exclusive_cache.data_ptr() if exclusive_cache is not None else 0,
+                            exclusive_cache.numel() * 4 if exclusive_cache is not None else 0,
                             _lib.LSS_PIXEL_MAJOR | _lib.LSS_ZERO_OUTPUT | (_lib.LSS_SUMMARY_CACHED if summary_cached else 0), _stream())
         ctx.save_for_backward(combine, fu, fv, fd, depth_c, ctx_nhwc, summary)
         ctx.dims = (B, N, D, fH, fW, C, nx, ny, nz)
@@ -338,7 +348,7 @@ class LiftSplatCamera(Function):
                             stats.data_ptr() if stats is not None else 0, flags, _stream())
         if ctx.bf16:
             grad_ctx = grad_ctx.to(torch.bfloat16)
-        return None, None, None, grad_depth.permute(0, 3, 1, 2), grad_ctx.permute(0, 3, 1, 2), None, None, None, None, None
+        return None, None, None, grad_depth.permute(0, 3, 1, 2), grad_ctx.permute(0, 3, 1, 2), None, None, None, None, None, None
 
 
 def new_column_summary(B, N, D, fH, fW, device):
@@ -348,8 +358,20 @@ def new_column_summary(B, N, D, fH, fW, device):
     return torch.empty((B * N, (fH + 15) // 16, fW, D, 2), dtype=torch.int32, device=device)
 
 
+def new_exclusive_cache(num_cams, voxel_num, device, slots=1024):
+    """Zero-initialised exclusive-cell cache of the camera-form forward (include/mmt_hip.h `exclusive_cache`): per
+    calibration (a sample's `num_cams` matrices) the BEV cells that a single run of the forward reaches; the library
+    learns them on the device and stores such runs instead of adding them atomically.  ~4 * nx * ny bytes per slot
+    (64 KiB on a 128 x 128 map).  One cache per module and stream; hand it to every lift_splat_camera call."""
+    nx, ny = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)][:2]
+    nbytes = int(_lib.lib().mmt_lss_exclusive_cache_bytes(int(num_cams), nx, ny, int(slots)))
+    if nbytes <= 0:
+        raise RuntimeError(f"new_exclusive_cache: bad arguments (N={num_cams}, nx={nx}, ny={ny}, slots={slots})")
+    return torch.zeros(nbytes // 4, dtype=torch.int32, device=device)
+
+
 def lift_splat_camera(combine, axes, depth, context, voxel_num, voxel_coord, voxel_size, column_backward=False, column_stats=None,
-                      summary=None, summary_cached=False):
+                      summary=None, summary_cached=False, exclusive_cache=None):
     """combine fp32 [B,N,4,4], axes = frustum_axes(frustum), depth [B*N,D,fH,fW], context [B*N,C,fH,fW] (fp32, or both bf16)
     -> BEV fp32 [B,C,ny,nx] (channels_last memory).  voxel_coord / voxel_size: 3 host floats each (the module buffers
     lss_fpn.py:278-285).  column_stats: optional int64 [2 * _lib.LSS_STATS_SLOTS] CUDA tensor the column backward
@@ -357,8 +379,8 @@ def lift_splat_camera(combine, axes, depth, context, voxel_num, voxel_coord, vox
     summary: None (a fresh column summary is written by the forward and read by the backward), or a tensor from
     new_column_summary kept by the caller across steps: summary_cached=False writes it, summary_cached=True declares that an
     earlier call wrote it for the SAME combine / axes / grid (unchanged calibration) and the forward reads it instead of
-    computing the geometry."""
+    computing the geometry.  exclusive_cache: None or the tensor of new_exclusive_cache (kept by the caller for good)."""
     vc = [float(v) for v in (voxel_coord.tolist() if isinstance(voxel_coord, torch.Tensor) else voxel_coord)]
     vs = [float(v) for v in (voxel_size.tolist() if isinstance(voxel_size, torch.Tensor) else voxel_size)]
     return LiftSplatCamera.apply(combine.contiguous(), tuple(axes), (vc, vs), depth, context, voxel_num, bool(column_backward),
-                                 column_stats, summary, bool(summary_cached))
+                                 column_stats, summary, bool(summary_cached), exclusive_cache)

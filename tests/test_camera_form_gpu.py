@@ -29,7 +29,7 @@ def _frustum(final_dim, ds, d_bound):
     return _frustum_torch(final_dim, ds, d_bound)
 
 
-def _run_forward_cam(combine, fr, vc, vs, vn, C=64, seed=0, pixel_major=True, bf16=False, summary=None, cached=False):
+def _run_forward_cam(combine, fr, vc, vs, vn, C=64, seed=0, pixel_major=True, bf16=False, summary=None, cached=False, excl=None):
     """-> (out [B,ny,nx,C] numpy, pos_memo [B, N*D*fH*fW, 3] numpy in the kernel's point order, depth, ctx (CPU tensors))"""
     from mm_training_amd import _lib
     from mm_training_amd.ops.bev_geometry import frustum_axes
@@ -51,9 +51,12 @@ def _run_forward_cam(combine, fr, vc, vs, vn, C=64, seed=0, pixel_major=True, bf
     cb = combine.contiguous().cuda()
     _lib.call("mmt_lss_splat_forward_cam" + ("_bf16" if bf16 else ""), B, N, D, fH, fW, C, nx, ny, nz, cb.data_ptr(), fu.data_ptr(),
               fv.data_ptr(), fd.data_ptr(), _lib.float3(vc), _lib.float3(vs), dep_dev.data_ptr(), ctx_dev.data_ptr(), out.data_ptr(),
-              pos.data_ptr(), summary.data_ptr() if summary is not None else 0, flags | (_lib.LSS_SUMMARY_CACHED if cached else 0),
+              pos.data_ptr(), summary.data_ptr() if summary is not None else 0, excl.data_ptr() if excl is not None else 0,
+              excl.numel() * 4 if excl is not None else 0, flags | (_lib.LSS_SUMMARY_CACHED if cached else 0),
               torch.cuda.current_stream().cuda_stream)
-    assert _lib.lib().mmt_lss_last_kernel_family(0) == 0x11          # ray walk, camera form
+    fam = _lib.lib().mmt_lss_last_kernel_family(0)
+    assert fam & 0x1F == 0x11                                        # ray walk, camera form
+    assert bool(fam & _lib.LSS_FAMILY_REGISTER) == (fH <= 16 and C <= 80 and D < 160)      # ... its register variant on short columns
     return out.cpu().numpy(), pos.cpu().numpy(), depth, ctx
 
 
@@ -235,12 +238,18 @@ def test_camera_form_argument_checks(mmt_lib):
     st = torch.cuda.current_stream().cuda_stream
     vc, vs = _lib.float3([0.4] * 3), _lib.float3([0.8] * 3)
     lib = _lib.lib()
-    args = [t.data_ptr()] * 4 + [vc, vs] + [t.data_ptr()] * 3 + [0, 0]
+    args = [t.data_ptr()] * 4 + [vc, vs] + [t.data_ptr()] * 3 + [0, 0, 0, 0]
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *args, _lib.LSS_TILE_KERNELS, st) == -4
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 48, 8, 8, 1, *args, 0, st) == -2
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, 0, *args[1:], 0, st) == -1
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *args, 0x4000, st) == -4
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *args, _lib.LSS_SUMMARY_CACHED, st) == -1      # cached, but no summary
+    xargs = args[:11] + [t.data_ptr() + 4, 4096]                        # a misaligned / an undersized exclusive-cell cache
+    assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *xargs, 0, st) == -2
+    xargs = args[:11] + [t.data_ptr(), 64]
+    assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *xargs, 0, st) == -2
+    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 4) == 4 * (64 + 4 * (4 + 96 + 128 * 128))
+    assert lib.mmt_lss_exclusive_cache_bytes(0, 128, 128, 4) == 0 and lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 0) == 0
     bargs = [t.data_ptr()] * 4 + [vc, vs] + [t.data_ptr()] * 3 + [64 * 64, 1, 8 * 64, 64] + [t.data_ptr()] * 2 + [0, 0]
     assert lib.mmt_lss_splat_backward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *bargs, _lib.LSS_TILE_KERNELS, st) == -4
     assert lib.mmt_lss_splat_backward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *bargs[:9], 64 * 64, 2, 8 * 64, 64, *bargs[13:], 0, st) == -2

@@ -75,13 +75,14 @@ def test_host_side_argument_checks_of_the_fused_lift_splat(mmt_lib):
     assert lib.mmt_lss_splat_backward(1, 1, 4, 2, 2, 16, 4, 4, 1, p, p, p, None, 256, 1, 64, 16, p, p, COLUMN, None) == -1
     # camera form (ABI 6): NULL geometry operands, the tile-kernel flag and unsupported widths are refused before any launch
     f3 = (ctypes.c_float * 3)(0.4, 0.4, 0.4)
-    cam = lambda C, flags, combine=p: lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, C, 4, 4, 1, combine, p, p, p, f3, f3, p, p, p, None, None, flags, None)
+    cam = lambda C, flags, combine=p: lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, C, 4, 4, 1, combine, p, p, p, f3, f3, p, p, p, None, None, None, 0, flags, None)
     assert cam(64, 0, None) == -1 and cam(64, TILES) == -4 and cam(48, 0) == -2 and cam(64, 0x2000) == -4
     assert cam(64, 0x1000) == -1                                  # MMT_LSS_SUMMARY_CACHED without a column summary
     assert lib.mmt_lss_splat_backward_cam(1, 1, 4, 2, 2, 64, 4, 4, 1, p, p, p, p, f3, None, p, p, p, 1024, 1, 256, 64, p, p, None, None, 0, None) == -1
     assert lib.mmt_lss_splat_backward_cam(1, 1, 4, 2, 2, 64, 4, 4, 1, p, p, p, p, f3, f3, p, p, p, 1024, 1, 256, 64, p, p, None, None, TILES, None) == -4
     assert lib.mmt_lss_camera_form_supported(4, 6, 112, 16, 44, 80) == 1 and lib.mmt_lss_camera_form_supported(1, 1, 8, 4, 4, 48) == 0
-    assert lib.mmt_lss_last_kernel_family(0) in (0, 1, 2, 0x11) and lib.mmt_lss_last_kernel_family(1) in (0, 1, 2, 3, 0x11, 0x13)
+    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 4) == 4 * (64 + 4 * (4 + 96 + 128 * 128)) and lib.mmt_lss_exclusive_cache_bytes(6, 128, 0, 4) == 0
+    assert lib.mmt_lss_last_kernel_family(0) & 0xF in (0, 1, 2) and lib.mmt_lss_last_kernel_family(1) in (0, 1, 2, 3, 0x11, 0x13)
 
 
 def test_host_side_argument_checks_of_the_additional_entry_points(mmt_lib):

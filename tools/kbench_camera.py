@@ -77,12 +77,13 @@ def main():
 
     summary = torch.empty(B * N, (fH + 15) // 16, fW, D, 2, dtype=torch.int32, device="cuda")
 
-    def fwd(h, cam, flags=PM, pos=None, sm=None):
+    def fwd(h, cam, flags=PM, pos=None, sm=None, xc=None):
         if cam:
             return getattr(h, "mmt_lss_splat_forward_cam" + sfx)(B, N, D, fH, fW, C, nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(),
                                                                 fd.data_ptr(), vc_c, vs_c, depth.data_ptr(), ctx.data_ptr(), out.data_ptr(),
                                                                 pos.data_ptr() if pos is not None else None,
-                                                                sm.data_ptr() if sm is not None else None, flags, st)
+                                                                sm.data_ptr() if sm is not None else None,
+                                                                xc.data_ptr() if xc is not None else None, xc.numel() * 4 if xc is not None else 0, flags, st)
         return getattr(h, "mmt_lss_splat_forward" + sfx)(B, N, D, fH, fW, C, nx, ny, nz, geom.data_ptr(), depth.data_ptr(), ctx.data_ptr(),
                                                         out.data_ptr(), pos.data_ptr() if pos is not None else None, flags, st)
 
@@ -200,8 +201,23 @@ def main():
         ts.sort()
         return round(ts[len(ts) // 2] * 1e3, 1)
 
+    # exclusive-cell cache (include/mmt_hip.h): three calls teach it this rig, then single-run cells are stored, not added
+    xbytes = h0.mmt_lss_exclusive_cache_bytes(N, nx, ny, 8)
+    xcache = {p: torch.zeros(xbytes // 4, dtype=torch.int32, device="cuda") for p in libs}
+    for p, h in zip(libs, hs):
+        for _ in range(3):
+            assert fwd(h, True, PM | ZERO, None, None, xcache[p]) == 0, h.mmt_last_error()
+    torch.cuda.synchronize()
+    xc0 = xcache[libs[0]]
+    st0 = xc0[64 + 8 * (4 + N * 16):].view(8, -1)[int(xc0[8])]               # the states of sample 0's slot
+    info["exclusive_cache"] = dict(modes=xc0[24:24 + B].tolist(), family=hex(h0.mmt_lss_last_kernel_family(0)),
+                                   cells_hit=int((st0 != 0).sum()), cells_single_run=int((st0 > 0).sum()))
+    by_handle = {id(h): xcache[p] for p, h in zip(libs, hs)}
     cases = {
         "frustum_geometry": (lambda h: geometry(h), {}),
+        "fwd_cam_exclusive_cache(fill+kernel)": (lambda h: fwd(h, True, PM | ZERO, None, None, by_handle[id(h)]), {}),
+        "fwd_cam_exclusive_cache_summary_cached(fill+kernel)": (lambda h: fwd(h, True, PM | ZERO | CACHED, None, summary, by_handle[id(h)]), {}),
+        "fwd_cam_exclusive_cache_cold(fill+kernel)": (lambda h: fwd(h, True, PM | ZERO, None, None, by_handle[id(h)]), dict(cold=True)),
         "fwd_geom": (lambda h: fwd(h, False), {}),
         "fwd_cam": (lambda h: fwd(h, True), {}),
         "fwd_cam_writes_summary": (lambda h: fwd(h, True, PM, None, summary), {}),
