@@ -617,6 +617,7 @@ def train_main(args, rank, local_rank, world):
             fwd_ms, bwd_ms = _lib.mean_ms(timing["lift_splat_forward"]), _lib.mean_ms(timing["lift_splat_backward"])
             from mm_training_amd.ops.bev_geometry import last_kernel_family
             fam_f, fam_b = last_kernel_family(), last_kernel_family(backward=True)
+            fam_f_detail = last_kernel_family(detail=True)
             camera = fam_f.endswith("+camera")
             fbytes, bbytes, l2f, l2b = lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, fb, camera_form=camera)
             note = ("fused get_geometry + quantise + lift + voxel_pooling (SURVEY 8 rows f1 + f3): neither the [B*P, C] feature matrix nor "
@@ -630,12 +631,15 @@ def train_main(args, rank, local_rank, world):
                     "aggregate L2 bandwidth; the drop-in op's HBM roofline is roofline_voxel_pooling[_backward]")
             sfx = "_bf16" if dtype == "bf16" else ""
             tiles = fam_f.startswith("tile")
-            kfwd = {"ray": "lss_ray_fwd", "tile": "lss_splat_fwd_tile"}.get(fam_f.split("+")[0], fam_f)
+            kfwd = {"ray": "lss_ray_fwd_reg" if "+register" in fam_f_detail else "lss_ray_fwd", "tile": "lss_splat_fwd_tile"}.get(fam_f.split("+")[0], fam_f)
             kbwd = {"ray": "lss_ray_bwd", "tile": "lss_splat_bwd_tile", "column": "lss_col_bwd"}.get(fam_b.split("+")[0], fam_b)
             column = fam_b.startswith("column")
             adaptive = lss._column_adaptive
             res["config"]["lift_splat_kernels"] = {
-                "forward": fam_f, "backward": fam_b, "geometry": "computed in the kernels (camera form)" if camera else "geom tensor (mmt_frustum_geometry every step)",
+                "forward": fam_f_detail, "backward": fam_b,
+                "exclusive_cell_cache": ("on: runs into single-run cells are stored, not added (learnt on the device per calibration; "
+                                         "the synthetic batch repeats, so every timed step uses it)") if "+exclusive" in fam_f_detail else "off",
+                "geometry": "computed in the kernels (camera form)" if camera else "geom tensor (mmt_frustum_geometry every step)",
                 "backward_choice": lss.lift_splat_backward if lss.lift_splat_backward != "auto" else (
                     "auto: per calibration id, from the geometry" if args.calibration_ids else
                     "auto: from the column kernel's own counters, read back lazily (share of kept points outside their column's cell: %s)"

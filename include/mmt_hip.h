@@ -336,16 +336,19 @@ int mmt_lss_splat_backward_bf16(int B, int N, int D, int fH, int fW, int C, int 
  * mmt_lss_exclusive_cache_bytes(N, nx, ny, slots) bytes, ZERO-INITIALISED ONCE by the caller and then left to the library):
  * a persistent per-calibration memory of which BEV cells receive ONE run of the forward only.  Such a cell (43 % of the runs
  * on the cfg4 rig: far cells seen by one column of one camera) needs no atomic add -- the run is stored into the zero-filled
- * row -- and the forward is bound by the memory-side atomic units.  The library learns them on the device, per sample, over
- * the first two calls that present a sample's N matrices (MARK: every run stores its id into the cell's state; VERIFY: a run
- * that finds another id stores -1); from the third call on runs into single-run cells leave as plain stores.  The lookup
- * of a call's samples (64-bit hash of the matrices, then the matrices bit for bit; least-recently-used replacement) runs in
- * one workgroup of the zero-fill kernel: no host involvement, no synchronisation, capturable in a graph.  A change of the
- * launch shape, of the grid or of the frustum axes' contents empties the cache.  Used with MMT_LSS_ZERO_OUTPUT by the
- * register-walk forward (fH <= 16, C <= 80, D < 160; mmt_lss_last_kernel_family reports MMT_LSS_FAMILY_REGISTER); ignored
- * otherwise.  Results are those of the call without a cache up to the order of additions (a stored sum is a sum added to 0).
- * Calls that share a cache must be ordered on one stream.  Limits: 1024 slots, samples of at most 8 cameras, the first 8
- * samples of a call (further samples run without it). */
+ * row -- and the forward is bound by the memory-side atomic units.  The library learns them on the device, per sample: the
+ * table is direct-mapped by a 64-bit hash of the sample's N matrices (compared bit for bit on a hit); the first call that
+ * presents a calibration claims its slot, the second MARKs (every run stores its id into the cell's state), the third
+ * VERIFIES (a run that finds another id stores -1), and from the fourth on runs into single-run cells leave as plain stores.
+ * Every workgroup of the forward looks its sample up itself (two rounds of loads behind its geometry phase); what a call
+ * decides for the next one is posted in a mailbox that the zero-fill kernel in front of the next forward commits: no host
+ * involvement, no synchronisation, no workgroup waits for another, capturable in a graph.  A change of the launch shape, of
+ * the grid or of the frustum axes' contents empties the table.  Used with MMT_LSS_ZERO_OUTPUT by the register-walk forward
+ * (fH <= 16, C <= 80, D < 160; mmt_lss_last_kernel_family reports MMT_LSS_FAMILY_REGISTER | _EXCLUSIVE); ignored otherwise.
+ * Results are those of the call without a cache up to the order of additions (a stored sum is a sum added to 0).
+ * Calls that share a cache must be ordered on one stream.  Limits: 65536 slots, samples of at most 8 cameras, the first 8
+ * samples of a call (further samples run without it).  Header words [8 + b] / [24 + b] tell what the last call found for
+ * sample b: its slot and the stage (0 miss, 1 mark, 2 verify, 3 use). */
 int64_t mmt_lss_exclusive_cache_bytes(int N, int num_voxel_x, int num_voxel_y, int slots);   /* 0: bad arguments */
 int mmt_lss_splat_forward_cam(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
                               const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,

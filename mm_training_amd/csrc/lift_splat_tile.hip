@@ -473,38 +473,42 @@ __global__ __launch_bounds__(kBlock) void lss_splat_bwd_tile(TileArgs a) {
 // (cfg4 rig) go to cells that NO other run of the launch touches -- far cells seen by one column of one camera -- and a cell
 // with a single contributor needs no atomic: a plain store into the zero-filled row does.  Which cells those are is a
 // function of a sample's camera matrices and of the launch shape alone, so it is learnt on the device, per SAMPLE (a
-// shuffled loader repeats rigs, not batches):
-//   * the cache holds `slots` calibrations: the sample's N matrices (+ a 64-bit hash of them) and one int32 STATE per BEV
-//     cell of a sample's map;
-//   * one extra workgroup of the zero-fill kernel looks every sample of the call up (hash, then the matrices bit for bit) and
-//     leaves a (slot, mode) pair per sample in the header; the forward reads it.  A new calibration takes the least recently
-//     used slot;
-//   * mode 1, MARK (the call that claims the slot): every run leaves its id -- (camera, column, slab, lane group, first bin,
-//     first row), the same in every launch of this shape -- in state[cell] with a plain store: some run's id survives;
-//   * mode 2, VERIFY (next call with these matrices): a run that finds another id than its own stores -1.  Afterwards
-//     state[cell] > 0 says "one run only";
-//   * mode 3, USE (from the third call on): the geometry phase tags the keys of such cells, and a tagged run leaves as plain
-//     stores.
+// shuffled loader repeats rigs, not batches), with no host involvement, no synchronisation and no workgroup waiting for
+// another:
+//   * the cache is a direct-mapped table of `slots` calibrations: a sample's N matrices, a 64-bit hash of them, a stage,
+//     and one int32 STATE per BEV cell of a sample's map;
+//   * every workgroup of the forward hashes its sample's matrices itself (96 words, one wave each), reads the slot the hash
+//     points at and compares the matrices bit for bit -- two rounds of loads behind which its geometry phase runs anyway.
+//     All workgroups of a sample read the same words, and nothing changes them during the launch, so they agree;
+//   * stage 1, MARK: every run leaves its id -- (camera, column, slab, lane group, first bin, first row), the same in every
+//     launch of this shape whatever the sample's place in the batch -- in state[cell] with a plain store: some id survives;
+//   * stage 2, VERIFY: a run that finds another id than its own stores -1.  Afterwards state[cell] > 0 says "one run only";
+//   * stage 3, USE: the geometry phase tags the keys of such cells, and a tagged run leaves as plain stores.
+//   * the first column workgroup of a sample posts what should happen next -- "claim this slot for my matrices" on a miss,
+//     "next stage" on a hit -- in a MAILBOX; the zero-fill kernel in front of the NEXT forward (one workgroup) commits the
+//     mail to the table.  A claim costs one call, so a calibration is used from its fourth call on.
 // Learning costs a 4-byte load or store per run (no same-address atomic chains: a counter per cell was measured at +14 us
-// per call), there is no host involvement and no synchronisation, so it works under graph capture; a loader with more rigs
-// than slots simply stays in modes 1/2.  Samples of one call that share their matrices learn through the first of them.
-// The header remembers the launch shape the states were learnt for (a host-side signature): another shape starts over.
-// One cache per stream: calls that share it must be stream-ordered.
+// per call).  Samples of one call that share their matrices post and learn the same things twice, harmlessly.  A
+// calibration whose slot another one takes starts over when it comes back.  The header remembers the launch shape (a
+// host-side signature) and a hash of the frustum axes' contents: a change empties the table.
+// One cache per stream: calls that share it must be stream-ordered (each forward is preceded by its zero-fill).
 constexpr int kExclFlag = 1 << 30;       // in a key: the cell has a single contributing run
-constexpr int kExclMaxB = 8;             // samples per call that take part (the rest: mode 0)
+constexpr int kExclMaxB = 8;             // samples per call that take part (the rest run without the cache)
 constexpr int kExclMaxN = 8;             // cameras per sample (more: the cache is not used)
-constexpr int kExclHeaderWords = 64;     // [0..1] shape signature, [2] clock, [3..4] hash of the frustum axes, [5] select done, [8 + b] slot of sample b, [24 + b] its mode
-constexpr int kExclMetaWords = 4;        // per slot: hash lo, hash hi, stage (0 free, 1 marked, 2 verified, 3 in use), stamp
-constexpr int kExclMaxSlots = 1024;
+constexpr int kExclMailWords = 8 + kExclMaxN * 16;     // per sample: [0] new stage (0 = no mail), [1] slot, [2..3] hash, [8..] matrices (claims)
+constexpr int kExclHeaderWords = 64 + kExclMaxB * kExclMailWords;    // [0..1] shape signature, [3..4] hash of the frustum axes, [64..] the mailbox
+constexpr int kExclMetaWords = 4;        // per slot: hash lo, hash hi, stage (0 free, 1 claimed: mark, 2 marked: verify, 3 verified: use), -
+constexpr int kExclMaxSlots = 1 << 16;
 struct ExclShape { int slots, N, cells; unsigned sig_lo, sig_hi; };      // cells = ny * nx of one sample
-struct ExclCall {                        // what the select step needs (zero-fill kernel argument)
+struct ExclCall {                        // what the commit step needs (zero-fill kernel argument)
     int32_t *cache;                      // nullptr: no cache in this call
-    const float *combine, *fu, *fv, *fd;
-    int B, fW, fH, D;
+    const float *fu, *fv, *fd;
+    int fW, fH, D;
     ExclShape xs;
 };
 __host__ __device__ inline int64_t excl_slot_words(int N, int cells) { return (int64_t)kExclMetaWords + (int64_t)N * 16 + cells; }
-__device__ __forceinline__ int32_t *excl_meta(int32_t *c, int s) { return c + kExclHeaderWords + s * kExclMetaWords; }
+__device__ __forceinline__ int32_t *excl_mail(int32_t *c, int b) { return c + 64 + b * kExclMailWords; }
+__device__ __forceinline__ int32_t *excl_meta(int32_t *c, int s) { return c + kExclHeaderWords + (int64_t)s * kExclMetaWords; }
 __device__ __forceinline__ int32_t *excl_mats(int32_t *c, const ExclShape &x, int s) {
     return c + kExclHeaderWords + (int64_t)x.slots * kExclMetaWords + (int64_t)s * x.N * 16;
 }
@@ -516,145 +520,110 @@ __device__ __forceinline__ unsigned excl_mix(unsigned v) {      // a 32-bit fina
     v ^= v >> 16; v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;
     return v;
 }
-
-// The select step: ONE extra workgroup (block 0) of the forward kernel, NT threads; the column workgroups wait for its verdict
-// only after their geometry phase (7 us; the select takes about 3), so it costs the call nothing.  (Riding on the zero-fill
-// kernel instead it took 11 us: its loads queue behind the fill's 21 MB of stores.)  Everything it needs is fetched in ONE
-// round of loads (header, frustum axes, the call's matrices, the metadata of all slots -> LDS); wave w then looks samples
-// w, w + NT/64, ... up (a second round of loads only to compare a candidate's matrices), and wave 0 settles claims and
-// duplicates in sample order on the LDS copy, writes the header and releases cache[5] (cleared by the zero-fill kernel in
-// front of every forward), which the other workgroups acquire.  Block 0 is dispatched first and waits for nobody.
-__host__ __device__ inline size_t excl_select_lds(int slots) {
-    return (size_t)slots * 12 + (size_t)((slots + 3) & ~3) + (size_t)kExclMaxB * kExclMaxN * 16 * 4 + (size_t)kExclMaxB * 16 + 64;      // (+ 64: axes, header copy)
+__device__ __forceinline__ void excl_hash_word(unsigned w, int i, unsigned &h0, unsigned &h1) {
+    h0 ^= excl_mix(w + 0x9E3779B9u * (unsigned)(i + 1));
+    h1 ^= excl_mix((w ^ 0x7F4A7C15u) + 0x85EBCA77u * (unsigned)(i + 1));
 }
-template <int NT>
-__device__ void excl_select(const ExclCall &k, float *lds) {
-    const ExclShape x = k.xs;
-    unsigned *s_h0 = reinterpret_cast<unsigned *>(lds), *s_h1 = s_h0 + x.slots;
-    int *s_stamp = reinterpret_cast<int *>(s_h1 + x.slots);
-    unsigned (*s_mat)[kExclMaxN * 16] = reinterpret_cast<unsigned (*)[kExclMaxN * 16]>(s_stamp + x.slots);
-    unsigned (*s_hash)[2] = reinterpret_cast<unsigned (*)[2]>(s_mat + kExclMaxB);
-    int *s_slot = reinterpret_cast<int *>(s_hash + kExclMaxB), *s_stage = s_slot + kExclMaxB;
-    unsigned *s_axes = reinterpret_cast<unsigned *>(s_stage + kExclMaxB);      // [0..1] the hash, then a pair per wave
-    int *s_hdr = reinterpret_cast<int *>(s_axes + 10);
-    unsigned char *s_stg = reinterpret_cast<unsigned char *>(s_hdr + 6);
-    constexpr int kBlock = NT;               // (shadows the file's 256: this function runs with the forward's block size)
+
+// What ONE WAVE of a forward workgroup finds out about its sample (every wave does it for itself: no barrier).  nw <= 128.
+// excl_probe_begin issues the loads (the matrices' words, then -- the slot follows from their hash -- the slot's metadata
+// and matrices); excl_probe_end, called after the geometry phase, compares.  In between the slot is known and its states can
+// be read speculatively.
+struct ExclProbe { int mode, slot; unsigned h0, h1, w0, w1, s0, s1; int4 mt; bool match; };
+__device__ __forceinline__ ExclProbe excl_probe_begin(int32_t *cache, const ExclShape &x, const float *combine, int b) {
+    const int lane = threadIdx.x & 63, nw = x.N * 16;
+    const unsigned *m = reinterpret_cast<const unsigned *>(combine) + (int64_t)b * nw;
+    ExclProbe p;
+    p.w0 = lane < nw ? m[lane] : 0u; p.w1 = lane + 64 < nw ? m[lane + 64] : 0u;
+    unsigned h0 = 0, h1 = 0;
+    if (lane < nw) excl_hash_word(p.w0, lane, h0, h1);
+    if (lane + 64 < nw) excl_hash_word(p.w1, lane + 64, h0, h1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h0 ^= __shfl_xor(h0, o); h1 ^= __shfl_xor(h1, o); }
+    p.h0 = h0; p.h1 = h1 | 1u;                                      // (a free slot's hash words are 0)
+    p.slot = (int)((h0 ^ (p.h1 * 0x9E3779B1u)) % (unsigned)x.slots);
+    p.mt = *reinterpret_cast<const int4 *>(excl_meta(cache, p.slot));
+    const unsigned *sm = reinterpret_cast<const unsigned *>(excl_mats(cache, x, p.slot));
+    p.s0 = lane < nw ? sm[lane] : 0u; p.s1 = lane + 64 < nw ? sm[lane + 64] : 0u;
+    p.match = false; p.mode = 0;
+    return p;
+}
+__device__ __forceinline__ void excl_probe_end(ExclProbe &p) {
+    p.match = __all(p.s0 == p.w0 && p.s1 == p.w1) && (unsigned)p.mt.x == p.h0 && (unsigned)p.mt.y == p.h1 && p.mt.z > 0;
+    p.mode = p.match ? p.mt.z : 0;
+}
+// The sample's first column workgroup (wave 0) posts the mail of this call.
+__device__ __forceinline__ void excl_post(int32_t *cache, const ExclShape &x, const float *combine, int b, const ExclProbe &p) {
+    const int lane = threadIdx.x & 63, nw = x.N * 16;
+    int32_t *mail = excl_mail(cache, b);
+    if (!p.match) {                                                  // claim the slot
+        const unsigned *m = reinterpret_cast<const unsigned *>(combine) + (int64_t)b * nw;
+        for (int i = lane; i < nw; i += 64) mail[8 + i] = (int)m[i];
+        if (lane == 0) { mail[1] = p.slot; mail[2] = (int)p.h0; mail[3] = (int)p.h1; mail[0] = 1; }
+    } else if (p.mode < 3) {                                         // this call marks (verifies): next stage
+        if (lane == 0) { mail[1] = p.slot; mail[2] = (int)p.h0; mail[3] = (int)p.h1; mail[0] = p.mode + 1; }
+    }
+    if (lane == 0) { cache[8 + b] = p.slot; cache[24 + b] = p.mode; }      // (for the curious: what this call did with sample b)
+}
+
+// The commit step: one workgroup (256 threads) of the zero-fill kernel in front of every forward.
+__device__ void excl_commit(const ExclCall &k) {
+    __shared__ unsigned s_axes[2 + 2 * (kBlock / 64)];
+    __shared__ int s_fresh;
     int32_t *cache = k.cache;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = k.B < kExclMaxB ? k.B : kExclMaxB, nw = x.N * 16;
-    if (tid < 5) s_hdr[tid] = cache[tid];
-    {
-        const unsigned *m = reinterpret_cast<const unsigned *>(k.combine);
-        for (int i = tid; i < nb * nw; i += kBlock) s_mat[i / nw][i % nw] = m[i];
-        for (int s = tid; s < x.slots; s += kBlock) {
-            const int4 mt = *reinterpret_cast<const int4 *>(excl_meta(cache, s));
-            s_h0[s] = (unsigned)mt.x; s_h1[s] = (unsigned)mt.y; s_stg[s] = (unsigned char)mt.z; s_stamp[s] = mt.w;
-        }
-        // the frustum axes' contents (a cache serves one frustum): per-wave partial hashes
+    const ExclShape x = k.xs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = x.N * 16;
+    // (everything the usual call needs in ONE round of loads: this workgroup runs beside the fill's 21 MB of stores)
+    int hdr = 0, stage_new = 0;
+    if (tid < 5) hdr = cache[tid];
+    if (tid < kExclMaxB) stage_new = excl_mail(cache, tid)[0];
+    {   // the frustum axes' contents (a cache serves one frustum)
         unsigned a0 = 0, a1 = 0;
         for (int i = tid; i < k.fW + k.fH + k.D; i += kBlock) {
             const float *src = i < k.fW ? k.fu + i : (i < k.fW + k.fH ? k.fv + (i - k.fW) : k.fd + (i - k.fW - k.fH));
-            const unsigned w = __float_as_uint(*src);
-            a0 ^= excl_mix(w + 0x9E3779B9u * (unsigned)(i + 1));
-            a1 ^= excl_mix((w ^ 0x7F4A7C15u) + 0x85EBCA77u * (unsigned)(i + 1));
+            excl_hash_word(__float_as_uint(*src), i, a0, a1);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a0 ^= __shfl_xor(a0, o); a1 ^= __shfl_xor(a1, o); }
         if (lane == 0) { s_axes[2 + wave * 2] = a0; s_axes[3 + wave * 2] = a1; }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {
         unsigned a0 = 0, a1 = 0;
-        for (int w = 0; w < NT / 64; ++w) { a0 ^= s_axes[2 + w * 2]; a1 ^= s_axes[3 + w * 2]; }
-        s_axes[0] = a0; s_axes[1] = a1;
+        for (int w = 0; w < kBlock / 64; ++w) { a0 ^= s_axes[2 + w * 2]; a1 ^= s_axes[3 + w * 2]; }
+        const unsigned want = lane == 0 ? x.sig_lo : (lane == 1 ? x.sig_hi : (lane == 3 ? a0 : a1));
+        const bool differs = (lane < 5 && lane != 2) && (unsigned)hdr != want;
+        const bool any = __any(differs);
+        if (lane == 0) { s_axes[0] = a0; s_axes[1] = a1; s_fresh = any ? 1 : 0; }
     }
     __syncthreads();
-    // another launch shape, other frustum axes or a fresh cache: every slot is free again
-    const bool fresh = (unsigned)s_hdr[0] != x.sig_lo || (unsigned)s_hdr[1] != x.sig_hi || (unsigned)s_hdr[3] != s_axes[0] || (unsigned)s_hdr[4] != s_axes[1];
-    const int now = (fresh ? 0 : s_hdr[2]) + 1;
-    if (fresh) {
-        for (int i = tid; i < x.slots * kExclMetaWords; i += kBlock) cache[kExclHeaderWords + i] = 0;
-        for (int s = tid; s < x.slots; s += kBlock) { s_h0[s] = 0u; s_h1[s] = 0u; s_stg[s] = 0; s_stamp[s] = 0; }
-        __threadfence();                                             // (wave 0 writes some of these words again below)
+    if (s_fresh) {                                                   // another launch shape, other axes, a new cache: empty table, mail dropped
+        for (int64_t i = tid; i < (int64_t)x.slots * kExclMetaWords; i += kBlock) cache[kExclHeaderWords + i] = 0;
+        if (tid < kExclMaxB) excl_mail(cache, tid)[0] = 0;
+        if (tid == 0) { cache[0] = (int)x.sig_lo; cache[1] = (int)x.sig_hi; cache[3] = (int)s_axes[0]; cache[4] = (int)s_axes[1]; }
+        return;
     }
-    __syncthreads();
-    for (int b = wave; b < nb; b += kBlock / 64) {
-        unsigned h0 = 0, h1 = 0;
-        for (int i = lane; i < nw; i += 64) {
-            const unsigned w = s_mat[b][i];
-            h0 ^= excl_mix(w + 0x9E3779B9u * (unsigned)(i + 1));
-            h1 ^= excl_mix((w ^ 0x7F4A7C15u) + 0x85EBCA77u * (unsigned)(i + 1));
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { h0 ^= __shfl_xor(h0, o); h1 ^= __shfl_xor(h1, o); }
-        int found = -1;
-        for (int base = 0; base < x.slots && found < 0; base += 64) {
-            const int s = base + lane;
-            const bool cand = s < x.slots && s_stg[s] > 0 && s_h0[s] == h0 && s_h1[s] == h1;
-            unsigned long long mask = __ballot(cand);
-            while (mask != 0ull && found < 0) {                      // candidates of these 64 slots, lowest first: the matrices decide
-                const int c = base + __builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                const unsigned *sm = reinterpret_cast<const unsigned *>(excl_mats(cache, x, c));
-                bool same = true;
-                for (int i = lane; i < nw; i += 64) same = same && sm[i] == s_mat[b][i];
-                if (__all(same)) found = c;
-            }
-        }
-        if (lane == 0) { s_hash[b][0] = h0; s_hash[b][1] = h1; s_slot[b] = found; s_stage[b] = found >= 0 ? s_stg[found] : 0; }
-    }
-    __syncthreads();
-    if (wave != 0) return;                                           // (nothing below synchronises the workgroup)
-    // wave 0: samples in order.  mode: 0 none, 1 mark, 2 verify, 3 use
-    for (int b = 0; b < nb; ++b) {
-        int slot = s_slot[b], mode = 0;
-        int first = b;                                               // the first sample of the call with these matrices
-        for (int p = b - 1; p >= 0; --p) {
-            if (s_hash[p][0] != s_hash[b][0] || s_hash[p][1] != s_hash[b][1]) continue;
-            bool same = true;
-            for (int i = lane; i < nw; i += 64) same = same && s_mat[p][i] == s_mat[b][i];
-            if (__all(same)) first = p;
-        }
-        if (first != b) {                                            // a duplicate: uses what was learnt before this call, learns nothing
-            slot = s_slot[first];                                    // (s_stage 0: its first claimed the slot in this call)
-            mode = (slot >= 0 && s_stage[first] >= 2) ? 3 : 0;
-        } else if (slot >= 0) {                                      // known calibration: one stage further
-            mode = s_stage[b] >= 2 ? 3 : 2;
-            if (lane == 0) { int32_t *mt = excl_meta(cache, slot); mt[2] = mode; mt[3] = now; }
-        } else {                                                     // new calibration: the least recently used slot this call does not use
-            int best = 0x7FFFFFFF, arg = -1;
-            for (int s = lane; s < x.slots; s += 64) {
-                const int key = s_stg[s] > 0 ? s_stamp[s] : 0;
-                bool taken = false;
-                for (int p = 0; p < nb; ++p) taken = taken || s_slot[p] == s;
-                if (!taken && key < best) { best = key; arg = s; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int ob = __shfl_xor(best, o), oa = __shfl_xor(arg, o);
-                if (oa >= 0 && (arg < 0 || ob < best || (ob == best && oa < arg))) { best = ob; arg = oa; }
-            }
-            if (arg >= 0) {
-                slot = arg; mode = 1;
+    if (wave != 0) return;
+    // wave 0: the mail in sample order (a later claim of a slot overrides an earlier letter about it)
+    for (int b = 0; b < kExclMaxB; ++b) {
+        const int sn = __shfl(stage_new, b);
+        if (sn == 0) continue;
+        int32_t *mail = excl_mail(cache, b);
+        const int slot = mail[1];
+        const unsigned h0 = (unsigned)mail[2], h1 = (unsigned)mail[3];
+        if (slot >= 0 && slot < x.slots) {
+            int32_t *mt = excl_meta(cache, slot);
+            if (sn == 1) {
                 unsigned *sm = reinterpret_cast<unsigned *>(excl_mats(cache, x, slot));
-                for (int i = lane; i < nw; i += 64) sm[i] = s_mat[b][i];
-                if (lane == 0) {
-                    int32_t *mt = excl_meta(cache, slot);
-                    mt[0] = (int)s_hash[b][0]; mt[1] = (int)s_hash[b][1]; mt[2] = 1; mt[3] = now;
-                }
-                s_slot[b] = slot; s_stage[b] = 0;                    // (every lane stores the same values)
+                for (int i = lane; i < nw; i += 64) sm[i] = (unsigned)mail[8 + i];
+                if (lane == 0) { mt[0] = (int)h0; mt[1] = (int)h1; mt[2] = 1; mt[3] = 0; }
+            } else {
+                const bool owner = (unsigned)mt[0] == h0 && (unsigned)mt[1] == h1 && mt[2] > 0;
+                if (lane == 0 && owner) mt[2] = sn;
             }
         }
-        if (lane == 0) {                                             // (device-scope stores: read by every XCD in this kernel)
-            __hip_atomic_store(cache + 8 + b, slot < 0 ? 0 : slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cache + 24 + b, slot < 0 ? 0 : mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (lane == 0) mail[0] = 0;
     }
-    if (lane == 0) {
-        cache[2] = now;
-        if (fresh) { cache[0] = (int)x.sig_lo; cache[1] = (int)x.sig_hi; cache[3] = (int)s_axes[0]; cache[4] = (int)s_axes[1]; }
-    }
-    if (lane == 0) __hip_atomic_store(cache + 5, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);    // (orders the two stores above before it)
 }
 
 // Forward: a workgroup owns one image column of one camera (optionally a depth slab of it).  Its geometry is reduced to
@@ -975,19 +944,7 @@ template <typename FT, int S, bool CAM>
 __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
     extern __shared__ __align__(16) float ray_lds[];
     constexpr int C = 16 * S, CP = C + 4, NT = kRegBlock, BS = kBinStride, NP = S / 2;
-    int L = blockIdx.x;
-    if constexpr (CAM) {
-        if (a.excl) {                                 // exclusive-cell cache: block 0 looks the call's samples up, the columns follow
-            if (L == 0) {
-                ExclCall k;
-                k.cache = a.excl; k.combine = a.combine; k.fu = a.fu; k.fv = a.fv; k.fd = a.fd;
-                k.B = a.BN / a.N; k.fW = a.fW; k.fH = a.fH; k.D = a.D; k.xs = a.xs;
-                excl_select<NT>(k, ray_lds);
-                return;
-            }
-            --L;
-        }
-    }
+    const int L = blockIdx.x;
     const int xcd = L & 7, i = L >> 3;
     const int per = a.fW * a.dsplit;
     const int q = i / per, r = i - q * per;
@@ -1010,6 +967,18 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
     a.pos_memo = nullptr;
 #endif
     FWD_STAMP(0);
+    // exclusive-cell cache: this wave looks its sample up (loads only; resolved behind the geometry phase).  The slot is
+    // known early, so the geometry phase reads its states SPECULATIVELY -- tags that turn out not to be ours are stripped
+    ExclProbe probe = {};
+    const int32_t *excl_st = nullptr;                 // the slot's int32 per cell, indexed by the call's cell id
+    bool excl_on = false;
+    if constexpr (CAM) {
+        excl_on = a.excl != nullptr && b < kExclMaxB;
+        if (excl_on) {
+            probe = excl_probe_begin(a.excl, a.xs, a.combine, b);
+            excl_st = excl_state(a.excl, a.xs, probe.slot) - (int64_t)b * a.xs.cells;
+        }
+    }
 
     // ---- geometry -> per-bin depths and keys
     if constexpr (CAM) {
@@ -1028,6 +997,8 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
             unsigned zm16 = 0;
             bool uni16 = cached ? (sv.y & mmt::kSummaryUniform) != 0 : true, in00 = false;
             int x00 = 0, y00 = 0, ukey = -1;                                  // ukey: key of the first kept row
+            int ustate = 0;                                                   // its cell's state (read as soon as the cell is known)
+            bool uasked = false;
 #pragma unroll 1
             for (int hb = 0; hb < 16; hb += 8) {
                 float dvs[8];
@@ -1078,13 +1049,20 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
                         }
                     }
                 }
+                if (excl_on && !uasked && ukey >= 0) { ustate = excl_st[ukey]; uasked = true; }      // (consumed behind the next pass)
                 float4 *dq = reinterpret_cast<float4 *>(dep + dd * BS + hb);
                 int4 *kq = reinterpret_cast<int4 *>(keyrow + dd * BS + hb);
                 dq[0] = make_float4(dvs[0], dvs[1], dvs[2], dvs[3]); dq[1] = make_float4(dvs[4], dvs[5], dvs[6], dvs[7]);
                 kq[0] = make_int4(ks[0], ks[1], ks[2], ks[3]); kq[1] = make_int4(ks[4], ks[5], ks[6], ks[7]);
             }
             if (sum && !cached) *sum = make_int2(in00 ? ((y00 << 16) | x00) : -1, (int)zm16 | (uni16 ? mmt::kSummaryUniform : 0));
-            bkey[dd] = ukey < 0 ? -1 : (uni16 ? ukey : -2);
+            if (excl_on && ukey >= 0 && !uni16) {                             // mixed bin (rare): the rows' tags one by one
+                for (int row = 0; row < fH; ++row) {
+                    const int kk = keyrow[dd * BS + row];
+                    if (kk >= 0 && excl_st[kk] > 0) keyrow[dd * BS + row] = kk | kExclFlag;
+                }
+            }
+            bkey[dd] = ukey < 0 ? -1 : (uni16 ? (ukey | (ustate > 0 ? kExclFlag : 0)) : -2);
         }
     } else {
         const int npts = fH * dn;
@@ -1152,34 +1130,20 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
         }
     }
     __syncthreads();
-    // ---- exclusive-cell cache: what block 0 decided for this sample (its verdict is long there: the select takes ~3 us, the
-    // geometry phase above 7).  mode 3: the keys of single-run cells get their tag; state = the slot's int32 per cell
+    // ---- exclusive-cell cache: the probe's answer.  Stage 3 (verified): the tags stand.  Anything else: they were read from
+    // another calibration's (or an unfinished) table -- strip them; stages 1 / 2 mark / verify in the flush below
     int excl_mode = 0;
-    int32_t *excl_st = nullptr;
     if constexpr (CAM) {
-        if (a.excl && b < kExclMaxB) {
-            __shared__ int s_verdict[2];
-            if (tid == 0) {
-                // relaxed device-scope loads (they bypass the XCD's non-coherent lines); NO acquire fence: an acquire invalidates
-                // the XCD's L2 per poll, and the only words read behind the flag are the two below, read the same way
-                while (__hip_atomic_load(a.excl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-                s_verdict[0] = __hip_atomic_load(a.excl + 24 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_verdict[1] = __hip_atomic_load(a.excl + 8 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            excl_mode = s_verdict[0];
-            excl_st = excl_state(a.excl, a.xs, s_verdict[1]) - (int64_t)b * a.xs.cells;      // indexed by the call's cell id
-            if (excl_mode == 3) {
+        if (excl_on) {
+            excl_probe_end(probe);
+            excl_mode = probe.mode;
+            if (wave == 0 && bn == b * a.N && col == 0 && slab == 0) excl_post(a.excl, a.xs, a.combine, b, probe);
+            if (excl_mode != 3) {
                 for (int dd = tid; dd < dn; dd += NT) {
                     const int k = bkey[dd];
-                    if (k >= 0) {
-                        if (excl_st[k] > 0) bkey[dd] = k | kExclFlag;
-                    } else if (k == -2) {
-                        for (int row = 0; row < fH; ++row) {
-                            const int kk = keyrow[dd * BS + row];
-                            if (kk >= 0 && excl_st[kk] > 0) keyrow[dd * BS + row] = kk | kExclFlag;
-                        }
-                    }
+                    if (k >= 0) bkey[dd] = k & (kExclFlag - 1);
+                    else if (k == -2)
+                        for (int row = 0; row < fH; ++row) { const int kk = keyrow[dd * BS + row]; if (kk >= 0) keyrow[dd * BS + row] = kk & (kExclFlag - 1); }
                 }
                 __syncthreads();
             }
@@ -1232,9 +1196,10 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
             if constexpr (S & 1) unsafeAtomicAdd(o + 16 * (S - 1), acc1);
             if constexpr (CAM) {
                 if (li == 0 && (excl_mode == 1 || excl_mode == 2)) {
+                    int32_t *st = const_cast<int32_t *>(excl_st) + cellid;
                     const int id = run_base + run_at;
-                    if (excl_mode == 1) excl_st[cellid] = id;                       // MARK: some run's id survives
-                    else if (excl_st[cellid] != id) excl_st[cellid] = -1;           // VERIFY: the cell has another run
+                    if (excl_mode == 1) *st = id;                                   // MARK: some run's id survives
+                    else if (*st != id) *st = -1;                                   // VERIFY: the cell has another run
                 }
             }
         }
@@ -1581,12 +1546,13 @@ volatile int g_last_family[2] = {0, 0};
 // zero-fill of the BEV map in front of the forward (MMT_LSS_ZERO_OUTPUT): `sc1` stores leave no line behind in the XCD L2s,
 // so the memory-side atomics that follow do not wait for freshly written lines to be evicted (a torch.zeros right before
 // the launch cost the forward 2.2 us, tools/kbench_fused.py `after_zero_fill`)
-__global__ __launch_bounds__(kBlock) void lss_zero_fill(float4 *p, int64_t n4, int32_t *excl_ready) {
-    if (excl_ready != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *excl_ready = 0;      // the forward's select step sets it (see excl_select)
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
+__global__ __launch_bounds__(kBlock) void lss_zero_fill(float4 *p, int64_t n4, ExclCall xc) {
+    const int extra = xc.cache != nullptr ? 1 : 0;           // the grid's FIRST workgroup commits the exclusive-cell cache's mail and fills nothing
+    if (extra && blockIdx.x == 0) { excl_commit(xc); return; }
+    const int64_t stride = (int64_t)(gridDim.x - extra) * kBlock;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7FFFFFFF, 0x00020000);
     const mmt_u32x4 z = {0u, 0u, 0u, 0u};
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride)
+    for (int64_t i = (int64_t)(blockIdx.x - extra) * kBlock + threadIdx.x; i < n4; i += stride)
         __builtin_amdgcn_raw_buffer_store_b128(z, rsrc, (unsigned)(i * 16), 0, 16);      // aux 16 = sc1
 }
 
@@ -1610,11 +1576,11 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     if ((flags & MMT_LSS_ZERO_OUTPUT) && (((uintptr_t)out & 15) != 0 || out_elems * 4 >= (1ll << 31)))
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: MMT_LSS_ZERO_OUTPUT needs a 16-byte aligned map below 2 GiB", what);
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
-    int32_t *excl_ready = nullptr;
+    ExclCall xc = {};
     auto zero_fill = [&]() {
         if (flags & MMT_LSS_ZERO_OUTPUT)
-            seq.launch(false, lss_zero_fill, dim3((unsigned)mmt::stream_grid(out_elems / 4, kBlock, 2048)), dim3(kBlock), 0, st,
-                       reinterpret_cast<float4 *>(out), out_elems / 4, excl_ready);
+            seq.launch(false, lss_zero_fill, dim3((unsigned)mmt::stream_grid(out_elems / 4, kBlock, 2048) + (xc.cache ? 1u : 0u)), dim3(kBlock), 0, st,
+                       reinterpret_cast<float4 *>(out), out_elems / 4, xc);
     };
     if (!(flags & MMT_LSS_TILE_KERNELS) && (C == 64 || C == 80 || C == 128)) {   // other widths: the tile kernels
         RayArgs r = {};
@@ -1627,10 +1593,10 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
             r.summary = reinterpret_cast<int2 *>(cam->summary); r.summary_cached = cam->summary_cached;
         }
         if (pick_ray_forward(&r)) {
-            size_t lds = ray_fwd_lds(r, r.dspan);
-            int64_t grid = 8ll * ((r.BN + 7) / 8) * fW * r.dsplit;
-            if (grid >= (1ll << 31) - 1) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
-            // the exclusive-cell cache: register walk + in-library zero-fill only (the select step rides on the fill kernel);
+            const size_t lds = ray_fwd_lds(r, r.dspan);
+            const int64_t grid = 8ll * ((r.BN + 7) / 8) * fW * r.dsplit;
+            if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
+            // the exclusive-cell cache: register walk + in-library zero-fill only (the fill kernel commits the cache's mail);
             // other shapes ignore it.  Run ids and tagged cell ids must fit 31 / 30 bits.
             if (cam && cam->excl && r.reg && (flags & MMT_LSS_ZERO_OUTPUT) && N <= kExclMaxN && (int64_t)B * ny * nx < kExclFlag &&
                 (int64_t)N * fW * r.dsplit * (kRegBlock / 16) * r.dspan * 16 < (1ll << 31) - 2) {
@@ -1648,9 +1614,7 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
                 for (int w : words) { h ^= (uint32_t)w; h *= 0x100000001B3ull; h ^= h >> 29; }
                 xs.sig_lo = (unsigned)h | 1u; xs.sig_hi = (unsigned)(h >> 32);
                 r.excl = cam->excl; r.xs = xs;
-                excl_ready = cam->excl + 5;
-                grid += 1;                                                   // block 0: the select step
-                if (excl_select_lds(xs.slots) > lds) lds = excl_select_lds(xs.slots);
+                xc.cache = cam->excl; xc.fu = cam->fu; xc.fv = cam->fv; xc.fd = cam->fd; xc.fW = fW; xc.fH = fH; xc.D = D; xc.xs = xs;
             }
             zero_fill();
             const dim3 g((unsigned)grid), blk(kBlock);
@@ -1855,7 +1819,7 @@ int make_cam(const char *what, const float *combine, const float *fu, const floa
 }
 int attach_excl(const char *what, int32_t *cache, int64_t bytes, mmt::CamGeom *cam) {
     if (!cache) return MMT_OK;
-    if (((uintptr_t)cache & 15) != 0 || bytes < kExclHeaderWords * 4)
+    if (((uintptr_t)cache & 15) != 0 || bytes < (kExclHeaderWords + 16) * 4)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the exclusive-cell cache needs a 16-byte aligned buffer of mmt_lss_exclusive_cache_bytes() bytes", what);
     cam->excl = cache; cam->excl_bytes = bytes;
     return MMT_OK;

@@ -3,7 +3,7 @@
 Random rigs (yaw jitter, pitch, roll), frustum shapes on both sides of every kernel choice (register walk: columns of up to
 16 rows, D < 160, C <= 80; the LDS-record walk otherwise; column / ray backward), random batches drawn from a small pool of
 calibrations -- repeated, reordered, duplicated inside a batch -- through ONE persistent exclusive-cell cache per shape with
-few slots (so it marks, verifies, uses, evicts and starts over all the time), each call against the geom form on
+few slots (so calibrations claim, mark, verify, use, collide and start over all the time), each call against the geom form on
 mmt_frustum_geometry's cells: same cells (bit for bit), same map and gradients (1e-4 of the largest value).  Exits non-zero
 on the first mismatch."""
 import math

@@ -38,7 +38,7 @@ def test_bench_two_ranks_on_the_gpu_box(mmt_lib):
     for key in ("roofline", "roofline_backward", "roofline_lidar"):
         r = d[key]
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["achieved"] > 0 and 0 < r["frac"] < 1 and r["avg_ms"] > 0
-    assert c["lift_splat_kernels"]["forward"] in ("tile", "ray", "ray+camera") and c["lift_splat_kernels"]["backward"]
+    assert c["lift_splat_kernels"]["forward"].split("+")[0] in ("tile", "ray") and c["lift_splat_kernels"]["backward"]
     # world > 1: rank 0 does not keep the other ranks parked in the final barrier for its own drop-in-op timing leg
     assert "roofline_voxel_pooling" not in d and "cpu_baseline" not in d
 

@@ -246,9 +246,9 @@ def test_camera_form_argument_checks(mmt_lib):
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *args, _lib.LSS_SUMMARY_CACHED, st) == -1      # cached, but no summary
     xargs = args[:11] + [t.data_ptr() + 4, 4096]                        # a misaligned / an undersized exclusive-cell cache
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *xargs, 0, st) == -2
-    xargs = args[:11] + [t.data_ptr(), 64]
+    xargs = args[:11] + [t.data_ptr(), 64 * 4]
     assert lib.mmt_lss_splat_forward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *xargs, 0, st) == -2
-    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 4) == 4 * (64 + 4 * (4 + 96 + 128 * 128))
+    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 4) == 4 * (64 + 8 * 136 + 4 * (4 + 96 + 128 * 128))
     assert lib.mmt_lss_exclusive_cache_bytes(0, 128, 128, 4) == 0 and lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 0) == 0
     bargs = [t.data_ptr()] * 4 + [vc, vs] + [t.data_ptr()] * 3 + [64 * 64, 1, 8 * 64, 64] + [t.data_ptr()] * 2 + [0, 0]
     assert lib.mmt_lss_splat_backward_cam(1, 1, 4, 2, 2, 64, 8, 8, 1, *bargs, _lib.LSS_TILE_KERNELS, st) == -4

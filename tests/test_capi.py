@@ -81,7 +81,7 @@ def test_host_side_argument_checks_of_the_fused_lift_splat(mmt_lib):
     assert lib.mmt_lss_splat_backward_cam(1, 1, 4, 2, 2, 64, 4, 4, 1, p, p, p, p, f3, None, p, p, p, 1024, 1, 256, 64, p, p, None, None, 0, None) == -1
     assert lib.mmt_lss_splat_backward_cam(1, 1, 4, 2, 2, 64, 4, 4, 1, p, p, p, p, f3, f3, p, p, p, 1024, 1, 256, 64, p, p, None, None, TILES, None) == -4
     assert lib.mmt_lss_camera_form_supported(4, 6, 112, 16, 44, 80) == 1 and lib.mmt_lss_camera_form_supported(1, 1, 8, 4, 4, 48) == 0
-    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 4) == 4 * (64 + 4 * (4 + 96 + 128 * 128)) and lib.mmt_lss_exclusive_cache_bytes(6, 128, 0, 4) == 0
+    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 4) == 4 * (64 + 8 * 136 + 4 * (4 + 96 + 128 * 128)) and lib.mmt_lss_exclusive_cache_bytes(6, 128, 0, 4) == 0
     assert lib.mmt_lss_last_kernel_family(0) & 0xF in (0, 1, 2) and lib.mmt_lss_last_kernel_family(1) in (0, 1, 2, 3, 0x11, 0x13)
 
 

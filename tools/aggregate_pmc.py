@@ -11,10 +11,11 @@ import sys
 # logical kernel name <- (substring of the demangled name, further substrings that must ALL be present)
 KERNELS = [
     # camera form (round 3: the kernels compute the cells themselves; last template argument true) before the geom form
-    ("lift_splat_forward_camera", ("lss_ray_fwd<float", ", true>")),
-    ("lift_splat_forward_camera_bf16", ("lss_ray_fwd<unsigned short", ", true>")),
-    ("lift_splat_forward", ("lss_ray_fwd<float", ", false>")),
-    ("lift_splat_forward_bf16", ("lss_ray_fwd<unsigned short", ", false>")),
+    # (lss_ray_fwd<...> and, for columns of up to 16 rows, lss_ray_fwd_reg<...>)
+    ("lift_splat_forward_camera", ("lss_ray_fwd", "<float, ", ", true>")),
+    ("lift_splat_forward_camera_bf16", ("lss_ray_fwd", "<unsigned short, ", ", true>")),
+    ("lift_splat_forward", ("lss_ray_fwd", "<float, ", ", false>")),
+    ("lift_splat_forward_bf16", ("lss_ray_fwd", "<unsigned short, ", ", false>")),
     ("lss_zero_fill", ("lss_zero_fill",)),
     ("lift_splat_forward_tile", ("lss_splat_fwd_tile<float",)),
     ("lift_splat_forward_tile_bf16", ("lss_splat_fwd_tile<unsigned short",)),

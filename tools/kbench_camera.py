@@ -201,15 +201,16 @@ def main():
         ts.sort()
         return round(ts[len(ts) // 2] * 1e3, 1)
 
-    # exclusive-cell cache (include/mmt_hip.h): three calls teach it this rig, then single-run cells are stored, not added
-    xbytes = h0.mmt_lss_exclusive_cache_bytes(N, nx, ny, 8)
+    # exclusive-cell cache (include/mmt_hip.h): four calls teach it this rig, then single-run cells are stored, not added
+    XS = 256
+    xbytes = h0.mmt_lss_exclusive_cache_bytes(N, nx, ny, XS)
     xcache = {p: torch.zeros(xbytes // 4, dtype=torch.int32, device="cuda") for p in libs}
     for p, h in zip(libs, hs):
-        for _ in range(3):
+        for _ in range(4):
             assert fwd(h, True, PM | ZERO, None, None, xcache[p]) == 0, h.mmt_last_error()
     torch.cuda.synchronize()
     xc0 = xcache[libs[0]]
-    st0 = xc0[64 + 8 * (4 + N * 16):].view(8, -1)[int(xc0[8])]               # the states of sample 0's slot
+    st0 = xc0[64 + 8 * 136 + XS * (4 + N * 16):].view(XS, -1)[int(xc0[8])]    # the states of sample 0's slot
     info["exclusive_cache"] = dict(modes=xc0[24:24 + B].tolist(), family=hex(h0.mmt_lss_last_kernel_family(0)),
                                    cells_hit=int((st0 != 0).sum()), cells_single_run=int((st0 > 0).sum()))
     by_handle = {id(h): xcache[p] for p, h in zip(libs, hs)}
