@@ -55,13 +55,20 @@ def test_roofline_entry_and_pmc_summaries():
     assert abs(r["l2_side"]["achieved"] - 2 * r["achieved"]) < 1e-6 and r["l2_side"]["peak"] == 34500.0
     # traffic is reported only for a configuration whose PMC summary is committed, never borrowed from another shape
     assert b.pmc_traffic("no_such_config", ("vp_fwd_seg_gather",)) is None
-    for name in os.listdir(os.path.join(ROOT, "profiles")):
-        if name.startswith("r02_pmc_") and name.endswith(".json"):
-            cfg = name[len("r02_pmc_"):-len(".json")]
+    seen = 0
+    for name in os.listdir(os.path.join(ROOT, "profiles")):            # this round's summaries are the ones bench.py quotes
+        if name.startswith("r03_pmc_") and name.endswith(".json"):
+            cfg = name[len("r03_pmc_"):-len(".json")]
             kernels = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
             for k, e in kernels.items():
                 if "traffic_bytes" in e:
                     assert b.pmc_traffic(cfg, (k,)) == e["traffic_bytes"] > 0
+                    seen += 1
+    assert seen > 10
+    # the headline configuration's summary holds the camera-form kernels of the step, in their steady state
+    k4 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_cfg4.json")))["kernels"]
+    assert {"lift_splat_forward_camera", "lss_zero_fill", "lift_splat_backward_column_camera", "vox_link", "vox_heads", "vox_emit"} <= set(k4)
+    assert k4["lift_splat_forward_camera"]["launches"] >= 12 and "first_half" in k4["lift_splat_forward_camera"]
 
 
 def test_help_and_defaults():

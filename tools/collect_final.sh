@@ -3,7 +3,7 @@
 # config and the per-kernel micro-benchmarks whose JSON is committed under profiles/ (copy gpurun_out/final/* to profiles/r03_*).
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
-run() { local log=$1; shift; timeout -k 10 400 "$@" > "$log" 2> "$log.err"; local rc=$?; echo "[final] $* -> rc=$rc"; [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit $rc; return 0; }
+run() { local log=$1; shift; timeout -k 10 300 "$@" > "$log" 2> "$log.err"; local rc=$?; echo "[final] $* -> rc=$rc ($(date +%T))"; [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit $rc; return 0; }
 run $out/bench_train_cfg4.jsonl python bench.py
 run $out/bench_train_cfg4_ray_backward.jsonl python bench.py --lift-splat-backward ray --no-cpu-baseline --no-hotpath-leg
 run $out/bench_train_cfg4_unfused.jsonl python bench.py --unfused --no-cpu-baseline

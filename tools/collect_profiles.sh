@@ -6,9 +6,13 @@
 # runs.  The program itself follows `--` (python3 bench.py), never a wrapper.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new; rm -rf $out; mkdir -p $out
+# Optional arguments pick groups (stats pmc4 pmc5 pmc2 pmc5bf16; default: all, into an emptied directory).
+out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new; [ $# -eq 0 ] && rm -rf $out; mkdir -p $out
+want() { [ -z "$GROUPS_WANTED" ] && return 0; case " $GROUPS_WANTED " in *" $1 "*) return 0;; esac; return 1; }
+GROUPS_WANTED="$*"
 raw=/tmp/mmt_prof; rm -rf $raw
-step() { local log=$1; shift; timeout -k 10 500 "$@" > "$log" 2>&1; local rc=$?; echo "[profiles] $(basename $log) rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then tail -5 "$log"; exit $rc; fi; }
+# (a pass that stops writing for 7 minutes gets the whole call killed: 200 s is several times what a pass takes)
+step() { local log=$1; shift; timeout -k 10 200 "$@" > "$log" 2>&1; local rc=$?; echo "[profiles] $(basename $log) rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then tail -5 "$log"; exit $rc; fi; }
 stats() {  # stats <tag> <bench args...>
   local tag=$1; shift
   step $out/bench_${tag}_under_rocprof.log rocprofv3 --kernel-trace --stats --output-format csv -d $raw/$tag -o $tag -- python3 bench.py "$@"
@@ -23,13 +27,16 @@ pmc() {    # pmc <tag> <bench args...>
   done
   python3 tools/aggregate_pmc.py "python bench.py $*" $raw/pmc_${tag}_1 $raw/pmc_${tag}_2 $raw/pmc_${tag}_3 > $out/pmc_$tag.json
 }
+if want stats; then
 stats train_cfg4 --steps 20 --warmup 8 --no-cpu-baseline
 stats train_cfg5 --config cfg5 --steps 12 --warmup 6 --no-cpu-baseline --no-hotpath-leg
 stats hotpath_cfg2 --mode hotpath --config cfg2 --steps 50 --warmup 10 --no-cpu-baseline
 stats hotpath_cfg5_bf16 --mode hotpath --config cfg5 --dtype bf16 --steps 50 --warmup 10 --no-cpu-baseline
-pmc cfg4 --steps 3 --warmup 2 --no-cpu-baseline --no-hotpath-leg
-pmc cfg5 --config cfg5 --steps 3 --warmup 2 --no-cpu-baseline --no-hotpath-leg
-pmc cfg2 --mode hotpath --config cfg2 --steps 5 --warmup 2 --no-cpu-baseline
-pmc cfg5_bf16 --mode hotpath --config cfg5 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline
+fi
+# (cfg4: 16 launches, the later 8 in the steady state of the exclusive-cell cache; cfg5's forward has no cache: 5 launches)
+want pmc4 && pmc cfg4 --steps 8 --warmup 8 --no-cpu-baseline --no-hotpath-leg
+want pmc5 && pmc cfg5 --config cfg5 --steps 3 --warmup 2 --no-cpu-baseline --no-hotpath-leg
+want pmc2 && pmc cfg2 --mode hotpath --config cfg2 --steps 5 --warmup 2 --no-cpu-baseline
+want pmc5bf16 && pmc cfg5_bf16 --mode hotpath --config cfg5 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline
 grep -h '^{' $out/bench_*_under_rocprof.log | cut -c1-300
 ls -la $out
