@@ -196,3 +196,33 @@ def test_cache_under_graph_replay_and_through_the_module(mmt_lib):
     torch.cuda.synchronize()
     assert float((static_out - ref2).abs().max()) <= 2e-5 * max(1.0, float(ref2.abs().max()))
     assert _lib.lib().mmt_lss_last_kernel_family(0) & _lib.LSS_FAMILY_REGISTER
+
+
+def test_cache_limits_more_samples_or_cameras_than_it_tracks(mmt_lib):
+    """The first 8 samples of a call take part, the rest run without the cache; a rig of more than 8 cameras, a column of
+    more than 16 rows or a long ray (the LDS-record walk) ignore it altogether -- the map is right in every case."""
+    from mm_training_amd import _lib
+    C = 80
+    fr = _frustum((64, 176), 16, (2.0, 58.0, 2.0))                 # D = 28, fH = 4, fW = 11
+    big = _rig(10, 2, 176, 64, seed=41)                            # 10 samples
+    ref, _ = _forward(big, fr, C, None)
+    cache = _cache(2, 256)
+    for want in (0, 1, 2, 3, 3):
+        out, _ = _forward(big, fr, C, cache)
+        assert _modes(cache, 8)[0] == [want] * 8
+        _same(out, ref)
+    wide = _rig(1, 9, 176, 64, seed=42)                            # 9 cameras
+    ref, _ = _forward(wide, fr, C, None)
+    cache9 = _cache(9, 4)
+    for _ in range(4):
+        out, _ = _forward(wide, fr, C, cache9)
+        assert not _lib.lib().mmt_lss_last_kernel_family(0) & _lib.LSS_FAMILY_EXCLUSIVE
+        _same(out, ref)
+    assert int(cache9.abs().sum()) == 0                            # never touched
+    tall = _frustum((272, 176), 16, (2.0, 58.0, 2.0))              # fH = 17
+    rig2 = _rig(2, 2, 176, 272, seed=43)
+    ref, _ = _forward(rig2, tall, C, None)
+    for _ in range(4):
+        out, _ = _forward(rig2, tall, C, cache)
+        assert not _lib.lib().mmt_lss_last_kernel_family(0) & (_lib.LSS_FAMILY_EXCLUSIVE | _lib.LSS_FAMILY_REGISTER)
+        _same(out, ref)
