@@ -126,8 +126,12 @@ def test_fused_stub_equals_the_reference_op_sequence_through_the_extension_stub(
     go = torch.randn(B, C, 128, 128, generator=g).cuda()
     # ---- section D
     d1, c1 = depth.clone().requires_grad_(True), context.clone().requires_grad_(True)
+    for _ in range(4):           # the stub keeps an exclusive-cell cache (ABI 7): through claim, mark and verify to its steady state
+        warm = fused.fused_lift_splat(lss, depth, context, s2e.cuda(), K.cuda())
     bev = fused.fused_lift_splat(lss, d1, c1, s2e.cuda(), K.cuda())
-    assert tuple(bev.shape) == (B, C, 128, 128)
+    assert tuple(bev.shape) == (B, C, 128, 128) and float((bev - warm).abs().max()) <= 2e-5 * max(1.0, float(warm.abs().max()))
+    (cache,) = fused._excl.values()
+    assert cache[24:24 + B].tolist() == [3] * B       # every sample's calibration is in use
     bev.backward(go)
     # ---- the reference's op sequence on the section-B stub
     class RefVoxelPooling(torch.autograd.Function):        # ops/voxel_pooling/voxel_pooling.py:10-69, restated around the stub

@@ -34,8 +34,9 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--pitch", type=float, default=0.0)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--stamps", action="store_true", help="the library is a -DLSS_STAMPS build (tools/build_variant.py): print the "
-                    "in-kernel s_memtime phase breakdown of the column / ray backward instead of timing")
+    ap.add_argument("--stamps", choices=["fwd", "col"], default=None, help="the library is a -DLSS_STAMPS build of lift_splat_tile.hip (fwd) "
+                    "or lift_splat_col.hip (col) (tools/build_variant.py): print that kernel's in-kernel s_memtime phase breakdown instead of "
+                    "timing.  The choice must match the build: a stamp build writes stamps where a plain one writes its results")
     ap.add_argument("libs", nargs="*")
     args = ap.parse_args()
     libs = args.libs or [_lib.LIB_PATH]
@@ -102,7 +103,8 @@ def main():
         flush = torch.zeros(256 * 1024 * 1024, device="cuda")
         # forward (lift_splat_tile.hip built with -DLSS_STAMPS): pos_memo receives 8 stamps per workgroup
         nwg_f = 8 * ((B * N + 7) // 8) * fW
-        for label, cam, flags, sm in (("geom form", False, PM, None), ("camera form", True, PM, None), ("camera form, summary cached", True, PM | CACHED, summary)):
+        for label, cam, flags, sm in ((("geom form", False, PM, None), ("camera form", True, PM, None), ("camera form, summary cached", True, PM | CACHED, summary))
+                                      if args.stamps == "fwd" else ()):
             for cold in (False, True):
                 stamp_buf = torch.zeros(nwg_f * 8 * 2 + 16, dtype=torch.int64, device="cuda")
                 for _ in range(3):
@@ -129,7 +131,7 @@ def main():
                 print("forward %s %s: %d workgroups; mean start +%.0f | phase 1 (records + context -> LDS) %.0f | walk %.0f | first start to last walk end, per XCD: %.0f cycles"
                       % (label, "cold" if cold else "warm", int(ok.sum()), sum(starts) / len(starts), (s8[ok, 1] - s8[ok, 0]).float().mean(),
                          (walk_end[ok] - s8[ok, 1]).float().mean(), sum(spans) / len(spans)))
-        for name, flags in (("column", PM | COL),):      # (lift_splat_col.hip built with -DLSS_STAMPS)
+        for name, flags in ((("column", PM | COL),) if args.stamps == "col" else ()):      # (lift_splat_col.hip built with -DLSS_STAMPS)
             for cam in (0, 1, 2):
                 for cold in (False, True):
                     for _ in range(3):
