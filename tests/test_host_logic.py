@@ -93,3 +93,24 @@ def test_parameter_registration_order():
     assert top[:2] == ["backbone", "head"] and top[-1] == "bev_fuse"        # the pillar encoder has no parameters
     assert [n for n, _ in fusion.named_children()] == ["backbone", "head", "lidar_encoder", "bev_fuse"]
     assert [n for n, _ in fusion.bev_fuse.named_parameters()] == ["conv_3.weight", "conv_3.bias", "conv_1.weight", "conv_1.bias"]
+
+
+def test_exclusive_cache_sizing_and_the_module_switch(monkeypatch):
+    """Host side of the exclusive-cell cache (include/mmt_hip.h `exclusive_cache`): its size, and that LSSFPN owns none
+    when MMT_LSS_EXCL_SLOTS=0 and keeps no state of it in the module's state dict."""
+    from mm_training_amd import _lib
+    from mm_training_amd.dp.configs import make_config
+    from mm_training_amd.layers.backbones.lss_fpn import LSSFPN
+    lib = _lib.lib()
+    header = 64 + 8 * (8 + 8 * 16)                                    # words: fixed part + the mailbox of 8 samples x 8 cameras
+    per_slot = 4 + 6 * 16 + 128 * 128
+    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 1024) == 4 * (header + 1024 * per_slot)
+    assert lib.mmt_lss_exclusive_cache_bytes(6, 128, 128, 1 << 20) == 4 * (header + (1 << 16) * per_slot)      # capped
+    assert lib.mmt_lss_exclusive_cache_bytes(6, 40000, 40000, 4) == 0                                         # cell ids need 30 bits
+    cfg = make_config("tiny")
+    monkeypatch.setenv("MMT_LSS_EXCL_SLOTS", "0")
+    off = LSSFPN(**cfg["backbone_conf"])
+    assert off.exclusive_slots == 0 and off._exclusive_cache_for(6, "cpu") is None
+    monkeypatch.setenv("MMT_LSS_EXCL_SLOTS", "32")
+    on = LSSFPN(**cfg["backbone_conf"])
+    assert on.exclusive_slots == 32 and not any("excl" in k for k in on.state_dict())
