@@ -126,3 +126,43 @@ def test_two_ranks_equal_gradient_accumulation_and_double_batch(mmt_lib):
     errs = sorted(float((out["det"][n] - ref4[n]).abs().max()) / (float(ref4[n].abs().max()) + 1e-3 * scale) for n in ref4)
     assert errs[len(errs) // 2] <= 5 * TOL, ("batch-4 median", errs[len(errs) // 2], worst)
     assert sum(e > 2e-3 for e in errs) <= 3 and errs[-1] <= 5e-2, ("batch-4", worst)
+
+
+def _rccl_worker(_index, port, out):
+    """One rank over RCCL (backend "nccl"), the way bench.py initialises it (init_dist: device_id given), with the step
+    wrapped in DistributedDataParallel exactly as for N > 1: bucketed all-reduce through RCCL, static graph, the fused
+    HIP kernels (camera form + exclusive-cell cache) and the LiDAR branch inside."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
+    dev = torch.device("cuda", 0)
+    cfg = make_config("tiny")
+    res = {}
+    for key, world in (("ddp", 2), ("plain", 1)):            # world_size > 1 only selects the DDP wrap; the group has one rank
+        torch.manual_seed(0)
+        ts = TrainStep(cfg, dev, world_size=world)
+        batch = synthetic_batch(cfg, dev, seed=7, batch_size=2)
+        losses = [float(ts(batch)[0]) for _ in range(5)]     # static_graph engages from the second iteration on
+        res[key] = losses
+        res[key + "_wrapped"] = isinstance(ts.net, torch.nn.parallel.DistributedDataParallel)
+    t = torch.ones(4, device=dev)
+    dist.all_reduce(t)
+    res["all_reduce"] = t.tolist()
+    res["backend"] = dist.get_backend()
+    out.update(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_ddp_step(mmt_lib):
+    """RCCL itself (one GPU per box here: the N > 1 tests above rendezvous over gloo): process group on the "nccl" backend,
+    DDP-wrapped training steps through it, same losses as the unwrapped step."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert out["backend"] == "nccl" and out["all_reduce"] == [1.0] * 4
+    assert out["ddp_wrapped"] and not out["plain_wrapped"]
+    for a, b in zip(out["ddp"], out["plain"]):
+        assert a == a and abs(a - b) <= 2e-3 * max(1.0, abs(b)), (out["ddp"], out["plain"])
+    assert out["ddp"][-1] < out["ddp"][0]                  # and it trains
