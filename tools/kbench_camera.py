@@ -215,7 +215,9 @@ def main():
     st0 = xc0[64 + 8 * 136 + XS * (4 + N * 16):].view(XS, -1)[int(xc0[8])]    # the states of sample 0's slot
     info["exclusive_cache"] = dict(modes=xc0[24:24 + B].tolist(), family=hex(h0.mmt_lss_last_kernel_family(0)),
                                    cells_hit=int((st0 != 0).sum()), cells_single_run=int((st0 > 0).sum()))
-    by_handle = {id(h): xcache[p] for p, h in zip(libs, hs)}
+    # (diagnostic builds -- tools/build_variant.py -DLSS_EXP_NOFLUSH / _NOWALK -- never teach a cache: they time the first
+    # library's, which stays in its steady state)
+    by_handle = {id(h): xcache[libs[0] if os.environ.get("KBC_SHARE_CACHE") else p] for p, h in zip(libs, hs)}
     cases = {
         "frustum_geometry": (lambda h: geometry(h), {}),
         "fwd_cam_exclusive_cache(fill+kernel)": (lambda h: fwd(h, True, PM | ZERO, None, None, by_handle[id(h)]), {}),
