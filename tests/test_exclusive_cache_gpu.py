@@ -53,7 +53,8 @@ def _forward(combine, fr, C, excl, **kw):
 def _same(out, ref):
     assert not np.isnan(out).any()
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
-    assert np.array_equal(out != 0, ref != 0)
+    # the same cells are touched (per cell, not per element: a channel sum may cancel to exactly 0 in one order of additions only)
+    assert np.array_equal((out != 0).any(-1), (ref != 0).any(-1))
 
 
 @pytest.mark.parametrize("C,bf16,pitch", [(80, False, 0.0), (64, False, 0.0), (80, True, 0.0), (80, False, 3.0)])
