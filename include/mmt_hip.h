@@ -383,6 +383,7 @@ int mmt_lss_splat_backward_cam_bf16(int B, int N, int D, int fH, int fW, int C, 
 #define MMT_LSS_FAMILY_CAMERA 0x10
 #define MMT_LSS_FAMILY_REGISTER 0x20 /* forward, ORed to MMT_LSS_FAMILY_RAY: the register walk (columns of up to 16 rows, C <= 80, D < 160) */
 #define MMT_LSS_FAMILY_EXCLUSIVE 0x40 /* forward: the call used an exclusive-cell cache */
+#define MMT_LSS_FAMILY_BLOCK 0x80 /* forward, camera form, ORed to MMT_LSS_FAMILY_RAY: the block walk (columns of more than 16 rows, long rays, C = 128) */
 int mmt_lss_last_kernel_family(int backward);
 /* 1 when mmt_lss_splat_forward_cam AND mmt_lss_splat_backward_cam both take this shape, 0 otherwise (use the geom form). */
 int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW, int C);

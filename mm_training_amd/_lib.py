@@ -92,7 +92,7 @@ LSS_ZERO_OUTPUT = 0x800       # mmt_lss_splat_forward*: the call zero-fills the 
 LSS_SUMMARY_CACHED = 0x1000   # mmt_lss_splat_forward_cam*: read the column summary instead of computing the geometry
 LSS_STATS_SLOTS = 64          # column_stats of mmt_lss_splat_backward_cam*: int64 [2 * LSS_STATS_SLOTS], (mismatching, kept) pairs
 LSS_FAMILY = {0: "none", 1: "ray", 2: "tile", 3: "column"}     # mmt_lss_last_kernel_family() & 0xF; | 0x10 = camera form
-LSS_FAMILY_REGISTER, LSS_FAMILY_EXCLUSIVE = 0x20, 0x40           # forward: register walk / an exclusive-cell cache was used
+LSS_FAMILY_REGISTER, LSS_FAMILY_EXCLUSIVE, LSS_FAMILY_BLOCK = 0x20, 0x40, 0x80      # forward: register walk / an exclusive-cell cache was used / block walk
 
 _lib = None
 

@@ -643,6 +643,7 @@ struct RayArgs {
     int dsplit, dspan, kd;         // forward: depth slabs per ray, bins per slab, bins per lane group
     int compact;                   // forward: walk only the depth bins that hold a kept point (long rays: most far bins are empty)
     int reg;                       // forward: the register walk (lss_ray_fwd_reg: fH <= 16, C <= 80, short rays)
+    int blk;                       // forward, camera form: the block walk (lss_ray_fwd_blk: every other shape)
     int32_t *excl;                 // forward (register walk, camera form), nullable: the exclusive-cell cache
     ExclShape xs;
     int wpc;                       // backward: workgroups per camera
@@ -1248,6 +1249,223 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Forward for the camera form's other shapes -- columns of more than 16 image rows (BASELINE configs[4]: 32) and long rays
+// (the reference's native frustum: 409 bins x 44 rows) -- the BLOCK walk.  The register walk's arithmetic with the context
+// rows read from LDS: the geometry phase leaves ONE key per (depth bin, block of 16 rows) -- the cell all kept rows of the
+// block share / nothing kept (the block costs the walk one LDS read; at the native frustum 84 % of the points lie beyond
+// the grid) / mixed (walked row by row: the rows' cells are computed again from the camera's matrix, rare) -- and a block's
+// 16 depths as four 16-byte LDS vectors; a point then costs its context reads and packed multiply-adds (~9 wave-
+// instructions against ~17 of lss_ray_fwd's record walk, which was bound by instruction issue).  Same order of additions
+// as lss_ray_fwd: bins ascending, rows ascending.  256 threads: 16 lane groups share the (kept) depth bins.
+constexpr int kBlkStride = 20;      // LDS floats per (bin, row block): 16 rows + padding
+
+__host__ __device__ inline size_t ray_fwd_blk_lds(int fH, int C, int dspan) {
+    const int RB = (fH + 15) / 16;
+    return (size_t)fH * (C + 4) * 4 + (size_t)dspan * RB * (kBlkStride * 4 + 4) + (size_t)dspan * 8;
+}
+
+template <typename FT, int S>
+__global__ __launch_bounds__(kBlock) void lss_ray_fwd_blk(RayArgs a) {
+    extern __shared__ __align__(16) float ray_lds[];
+    constexpr int C = 16 * S, CP = C + 4, BS = kBlkStride, NP = S / 2;
+    const int L = blockIdx.x, xcd = L & 7, i = L >> 3;
+    const int per = a.fW * a.dsplit;
+    const int q = i / per, r = i - q * per;
+    const int bn = q * 8 + xcd;                       // the columns of one camera share an XCD
+    if (bn >= a.BN) return;
+    const int col = r / a.dsplit, slab = r - col * a.dsplit;
+    const int d0 = slab * a.dspan;
+    const int dn = (a.D - d0) < a.dspan ? (a.D - d0) : a.dspan;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fH = a.fH, HW = a.fH * a.fW, RB = (fH + 15) >> 4;
+    const int b = bn / a.N;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+    float *ctx = ray_lds;                                              // [fH][CP] fp32 context rows
+    float *dep = ray_lds + fH * CP;                                    // [dspan][RB][BS]: depths of a block's rows, 0 for a dropped / missing row
+    int *bkey = reinterpret_cast<int *>(dep + (size_t)a.dspan * RB * BS);   // [dspan][RB]: cell, -1 nothing kept, -2 mixed
+    int *binkept = bkey + a.dspan * RB;                                // [dspan]: some block of the bin holds a kept row
+    int *klist = binkept + a.dspan;                                    // the kept bins in depth order (long rays)
+    __shared__ int s_nkb;
+    float cm[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) cm[k] = a.combine[bn * 16 + k];
+    const float cu = a.fu[col];
+    const int64_t rstep = a.pm ? (int64_t)a.fW * a.D : a.fW;              // points between consecutive image rows
+
+    // ---- geometry -> per-block depths and keys: a thread takes one (depth bin, row block) at a time, 8 rows per pass
+    for (int dd = tid; dd < dn; dd += kBlock) binkept[dd] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int it = tid; it < dn * RB; it += kBlock) {
+        const int rb = it / dn, dd = it - rb * dn;
+        const int r0 = rb * 16;
+        const int nr = (fH - r0) < 16 ? (fH - r0) : 16;
+        {
+            const mmt_cam_column cc = mmt_cam_column_make(cm, cu, a.fd[d0 + dd]);
+            int2 *sum = a.summary ? a.summary + (((int64_t)bn * RB + rb) * a.fW + col) * a.D + d0 + dd : nullptr;
+            const bool cached = sum && a.summary_cached;
+            int2 sv = make_int2(-1, 0);
+            if (cached) sv = *sum;
+            unsigned zm16 = 0;
+            bool uni16 = cached ? (sv.y & mmt::kSummaryUniform) != 0 : true, in00 = false;
+            int x00 = 0, y00 = 0, ukey = -1;
+#pragma unroll 1
+            for (int hb = 0; hb < 16; hb += 8) {
+                float dvs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dvs[u] = 0.f;
+                if (hb < nr) {
+                    const int nh = (nr - hb) < 8 ? (nr - hb) : 8;
+                    const int64_t t0 = ray_point(a, bn, r0 + hb, col, d0 + dd);
+                    float dv[8], cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        dv[u] = Elem<FT>::scalar(depth + t0 + (u < nh ? u : nh - 1) * rstep);
+                        cv[u] = a.fv[r0 + hb + (u < nh ? u : nh - 1)];
+                    }
+                    bool uniform, in0;
+                    int x0, y0;
+                    unsigned zmask;
+                    if (cached) {
+                        in0 = sv.x >= 0; x0 = sv.x & 0xFFFF; y0 = sv.x >> 16;
+                        zmask = ((unsigned)sv.y >> hb) & 0xFFu;
+                        uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
+                    } else {
+                        zmask = mmt_cam_column_cells<8>(cc, cv, nh, mmt_rows_sorted<8>(cv, nh), a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
+                        zm16 |= zmask << hb;
+                        if (hb == 0) { uni16 = uniform; in00 = in0; x00 = x0; y00 = y0; }
+                        else uni16 = uni16 && uniform && in0 == in00 && x0 == x00 && y0 == y00;
+                    }
+                    const int cell0 = in0 ? (b * a.ny + y0) * a.nx + x0 : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < nh) {
+                            int gx = x0, gy = y0, cell = cell0;
+                            if (!uniform) cell = mmt_cam_row_xy(cc, cv[u], a.q, a.nx, a.ny, gx, gy) ? (b * a.ny + gy) * a.nx + gx : -1;
+                            const bool keep = ((zmask >> u) & 1u) && cell >= 0;
+                            if (keep) {
+                                dvs[u] = dv[u];
+                                if (ukey < 0) ukey = cell;
+                            }
+                            if (a.pos_memo) {
+                                const int64_t t = t0 + u * rstep;
+                                if (keep) {
+                                    a.pos_memo[t * 3] = b; a.pos_memo[t * 3 + 1] = gy; a.pos_memo[t * 3 + 2] = gx;
+                                } else if (a.write_dropped) {
+                                    a.pos_memo[t * 3] = -1; a.pos_memo[t * 3 + 1] = -1; a.pos_memo[t * 3 + 2] = -1;
+                                }
+                            }
+                        }
+                    }
+                }
+                float4 *dq = reinterpret_cast<float4 *>(dep + ((size_t)dd * RB + rb) * BS + hb);
+                dq[0] = make_float4(dvs[0], dvs[1], dvs[2], dvs[3]); dq[1] = make_float4(dvs[4], dvs[5], dvs[6], dvs[7]);
+            }
+            if (sum && !cached) *sum = make_int2(in00 ? ((y00 << 16) | x00) : -1, (int)zm16 | (uni16 ? mmt::kSummaryUniform : 0));
+            bkey[dd * RB + rb] = ukey < 0 ? -1 : (uni16 ? ukey : -2);
+            if (ukey >= 0) binkept[dd] = 1;                                           // (every writer writes the same value)
+        }
+    }
+    {
+        constexpr int VEC = Elem<FT>::VEC;
+        constexpr int CV = C / VEC;
+        for (int e = tid; e < fH * CV; e += kBlock) {
+            const int row = e / CV, cv = e - row * CV;
+            Elem<FT>::to_lds(context + ((int64_t)bn * HW + row * a.fW + col) * C + cv * VEC, ctx + row * CP + cv * VEC);
+        }
+    }
+    __syncthreads();
+    // the bins with a kept point, in depth order (wave 0: ballot + popcount): the lane groups share the work that exists
+    if (wave == 0) {
+        int n = 0;
+        for (int base = 0; base < dn; base += 64) {
+            const bool k = (base + lane) < dn && binkept[base + lane] != 0;
+            const unsigned long long m = __ballot(k);
+            if (k) klist[n + __popcll(m & ((1ull << lane) - 1ull))] = base + lane;
+            n += __popcll(m);
+        }
+        if (lane == 0) s_nkb = n;
+    }
+    __syncthreads();
+    const int nkb = s_nkb;
+
+    // ---- 16 lane groups: an equal share of the kept bins x all row blocks each
+    const int g = lane >> 4, li = lane & 15;
+    const int share = (nkb + kBlock / 16 - 1) / (kBlock / 16);
+    const int ds = (wave * 4 + g) * share;
+    const int de = (ds + share) < nkb ? (ds + share) : nkb;
+    const float *cl = ctx + li;
+    mmt_v2f acc2[NP > 0 ? NP : 1];
+    float acc1 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc2[p] = mmt_v2f{0.f, 0.f};
+    int cur = -1;
+    auto flush = [&]() __attribute__((always_inline)) {
+        float *o = a.out + (int64_t)cur * C + li;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { unsafeAtomicAdd(o + 16 * (2 * p), acc2[p].x); unsafeAtomicAdd(o + 16 * (2 * p + 1), acc2[p].y); }
+        if constexpr (S & 1) unsafeAtomicAdd(o + 16 * (S - 1), acc1);
+    };
+    auto renew = [&](int key) __attribute__((always_inline)) {
+        if (cur >= 0) flush();
+        cur = key;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc2[p] = mmt_v2f{0.f, 0.f};
+        acc1 = 0.f;
+    };
+    auto add_row = [&](float dv, int row) __attribute__((always_inline)) {
+        const float *cr = cl + row * CP;
+        const mmt_v2f d2 = {dv, dv};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const mmt_v2f c2 = {cr[16 * (2 * p)], cr[16 * (2 * p + 1)]};
+            acc2[p] = __builtin_elementwise_fma(d2, c2, acc2[p]);
+        }
+        if constexpr (S & 1) acc1 = __builtin_fmaf(dv, cr[16 * (S - 1)], acc1);
+    };
+#pragma unroll 1
+    for (int e = ds; e < de; ++e) {
+        const int dd = klist[e];
+#pragma unroll 1
+        for (int rb = 0; rb < RB; ++rb) {
+            const int k = bkey[dd * RB + rb];
+            if (k == -1) continue;
+            const int r0 = rb * 16;
+            const int nr = (fH - r0) < 16 ? (fH - r0) : 16;
+            const float4 *dp = reinterpret_cast<const float4 *>(dep + ((size_t)dd * RB + rb) * BS);
+            const float4 d0v = dp[0], d1v = dp[1], d2v = dp[2], d3v = dp[3];
+            const float dv[16] = {d0v.x, d0v.y, d0v.z, d0v.w, d1v.x, d1v.y, d1v.z, d1v.w, d2v.x, d2v.y, d2v.z, d2v.w, d3v.x, d3v.y, d3v.z, d3v.w};
+            if (k >= 0) {
+                if (k != cur) renew(k);
+                if (nr == 16) {
+#pragma unroll
+                    for (int row = 0; row < 16; ++row) add_row(dv[row], r0 + row);
+                } else {
+#pragma unroll
+                    for (int row = 0; row < 16; ++row)
+                        if (row < nr) add_row(dv[row], r0 + row);
+                }
+            } else {                                    // mixed block (rare): the rows' cells again from the matrix.  A kept row whose
+                                                        // depth is exactly 0 adds nothing and is passed over
+                const mmt_cam_column cc = mmt_cam_column_make(cm, cu, a.fd[d0 + dd]);
+#pragma unroll
+                for (int row = 0; row < 16; ++row) {
+                    if (row < nr && dv[row] != 0.f) {
+                        int gx, gy;
+                        mmt_cam_row_xy(cc, a.fv[r0 + row], a.q, a.nx, a.ny, gx, gy);
+                        const int key = (b * a.ny + gy) * a.nx + gx;
+                        if (key != cur) renew(key);
+                        add_row(dv[row], r0 + row);
+                    }
+                }
+            }
+        }
+    }
+    if (cur >= 0) flush();
+}
+
 __device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes of a quad, in all 4 (DPP quad_perm, no LDS)
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
@@ -1494,6 +1712,7 @@ __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
 // the depth bins of each of the 16 lane groups
 size_t ray_fwd_lds(const RayArgs &r, int dspan) {
     if (r.reg) return ray_fwd_reg_lds(r.C, dspan);
+    if (r.blk) return ray_fwd_blk_lds(r.fH, r.C, dspan);
     return (size_t)r.fH * (r.C + 4) * 4 + (size_t)r.fH * (dspan | 1) * 8 + (size_t)dspan * 8;
 }
 
@@ -1506,6 +1725,8 @@ bool pick_ray_forward(RayArgs *r) {
     r->compact = (r->D >= 160 || r->fH > 32) ? 1 : 0;              // long rays / tall columns: most (bin, row) pairs lie outside the grid
     static const char *no_reg = getenv("MMT_RAY_NO_REG");          // experiments only
     r->reg = (!r->compact && r->fH <= 16 && r->C <= 80 && !(no_reg && atoi(no_reg) > 0)) ? 1 : 0;
+    static const char *no_blk = getenv("MMT_RAY_NO_BLK");          // experiments only
+    r->blk = (!r->reg && r->combine != nullptr && !(no_blk && atoi(no_blk) > 0)) ? 1 : 0;
     for (;; ++dsplit) {
         const int dspan = (r->D + dsplit - 1) / dsplit;
         const size_t lds = ray_fwd_lds(*r, dspan);
@@ -1627,6 +1848,10 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
                     if (C == 80) seq.launch(true, lss_ray_fwd_reg<FT, 5, false>, g, rb, lds, st, r);
                     else seq.launch(true, lss_ray_fwd_reg<FT, 4, false>, g, rb, lds, st, r);
                 }
+            } else if (r.blk) {
+                if (C == 80) seq.launch(true, lss_ray_fwd_blk<FT, 5>, g, blk, lds, st, r);
+                else if (C == 64) seq.launch(true, lss_ray_fwd_blk<FT, 4>, g, blk, lds, st, r);
+                else seq.launch(true, lss_ray_fwd_blk<FT, 8>, g, blk, lds, st, r);
             } else if (cam) {
                 if (C == 80) seq.launch(true, lss_ray_fwd<FT, 5, true>, g, blk, lds, st, r);
                 else if (C == 64) seq.launch(true, lss_ray_fwd<FT, 4, true>, g, blk, lds, st, r);
@@ -1637,7 +1862,7 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
                 else seq.launch(true, lss_ray_fwd<FT, 8, false>, g, blk, lds, st, r);
             }
             g_last_family[0] = MMT_LSS_FAMILY_RAY | (cam ? MMT_LSS_FAMILY_CAMERA : 0) | (r.reg ? MMT_LSS_FAMILY_REGISTER : 0) |
-                               (r.excl ? MMT_LSS_FAMILY_EXCLUSIVE : 0);
+                               (r.excl ? MMT_LSS_FAMILY_EXCLUSIVE : 0) | (r.blk ? MMT_LSS_FAMILY_BLOCK : 0);
             return mmt::check_launch(what);
         }
     }
@@ -1904,6 +2129,7 @@ extern "C" int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW
     if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || !(C == 64 || C == 80 || C == 128) || fH > kPts) return 0;
     RayArgs r = {};
     r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C;
+    r.combine = reinterpret_cast<const float *>(16);         // (camera form: the kernel choice of forward_impl)
     if (!pick_ray_forward(&r)) return 0;
     const int C4 = C / 4, NGR = (kBlock / 64) * (64 / C4);
     const size_t lds = (size_t)NGR * (3 * (((D + kRayBins - 1) & ~(kRayBins - 1)) + 8) + kRayBins * (C4 / 4)) * 4;

@@ -270,11 +270,13 @@ def camera_form_supported(B, N, D, fH, fW, C):
 def last_kernel_family(backward=False, detail=False):
     """Kernel family the process's last fused lift-splat forward / backward call launched:
     "ray" | "tile" | "column" | "none", + "+camera" for the camera form (mmt_lss_last_kernel_family).
-    detail=True appends "+register" (the forward's register walk) and "+exclusive" (an exclusive-cell cache was used)."""
+    detail=True appends "+register" / "+block" (the forward's register / block walk) and "+exclusive" (an exclusive-cell
+    cache was used)."""
     v = _lib.lib().mmt_lss_last_kernel_family(1 if backward else 0)
     name = _lib.LSS_FAMILY.get(v & 0xF, "?") + ("+camera" if v & 0x10 else "")
     if detail:
-        name += ("+register" if v & _lib.LSS_FAMILY_REGISTER else "") + ("+exclusive" if v & _lib.LSS_FAMILY_EXCLUSIVE else "")
+        name += (("+register" if v & _lib.LSS_FAMILY_REGISTER else "") + ("+block" if v & _lib.LSS_FAMILY_BLOCK else "") +
+                 ("+exclusive" if v & _lib.LSS_FAMILY_EXCLUSIVE else ""))
     return name
 
 

@@ -56,7 +56,8 @@ def _run_forward_cam(combine, fr, vc, vs, vn, C=64, seed=0, pixel_major=True, bf
               torch.cuda.current_stream().cuda_stream)
     fam = _lib.lib().mmt_lss_last_kernel_family(0)
     assert fam & 0x1F == 0x11                                        # ray walk, camera form
-    assert bool(fam & _lib.LSS_FAMILY_REGISTER) == (fH <= 16 and C <= 80 and D < 160)      # ... its register variant on short columns
+    reg = fH <= 16 and C <= 80 and D < 160
+    assert bool(fam & _lib.LSS_FAMILY_REGISTER) == reg and bool(fam & _lib.LSS_FAMILY_BLOCK) == (not reg)      # register walk on short columns, block walk otherwise
     return out.cpu().numpy(), pos.cpu().numpy(), depth, ctx
 
 
