@@ -631,7 +631,8 @@ def train_main(args, rank, local_rank, world):
                     "aggregate L2 bandwidth; the drop-in op's HBM roofline is roofline_voxel_pooling[_backward]")
             sfx = "_bf16" if dtype == "bf16" else ""
             tiles = fam_f.startswith("tile")
-            kfwd = {"ray": "lss_ray_fwd_reg" if "+register" in fam_f_detail else "lss_ray_fwd", "tile": "lss_splat_fwd_tile"}.get(fam_f.split("+")[0], fam_f)
+            kfwd = {"ray": "lss_ray_fwd_reg" if "+register" in fam_f_detail else ("lss_ray_fwd_blk" if "+block" in fam_f_detail else "lss_ray_fwd"),
+                    "tile": "lss_splat_fwd_tile"}.get(fam_f.split("+")[0], fam_f)
             kbwd = {"ray": "lss_ray_bwd", "tile": "lss_splat_bwd_tile", "column": "lss_col_bwd"}.get(fam_b.split("+")[0], fam_b)
             column = fam_b.startswith("column")
             adaptive = lss._column_adaptive

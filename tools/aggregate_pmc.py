@@ -11,7 +11,9 @@ import sys
 # logical kernel name <- (substring of the demangled name, further substrings that must ALL be present)
 KERNELS = [
     # camera form (round 3: the kernels compute the cells themselves; last template argument true) before the geom form
-    # (lss_ray_fwd<...> and, for columns of up to 16 rows, lss_ray_fwd_reg<...>)
+    # (lss_ray_fwd<...>; for columns of up to 16 rows lss_ray_fwd_reg<...>; the camera form's other shapes lss_ray_fwd_blk<...>)
+    ("lift_splat_forward_camera", ("lss_ray_fwd_blk<float, ",)),
+    ("lift_splat_forward_camera_bf16", ("lss_ray_fwd_blk<unsigned short, ",)),
     ("lift_splat_forward_camera", ("lss_ray_fwd", "<float, ", ", true>")),
     ("lift_splat_forward_camera_bf16", ("lss_ray_fwd", "<unsigned short, ", ", true>")),
     ("lift_splat_forward", ("lss_ray_fwd", "<float, ", ", false>")),
