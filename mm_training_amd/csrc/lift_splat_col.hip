@@ -59,8 +59,10 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 // LDS (dynamic): dep [16][Dp] fp32 | ref [Dp] int | flag [16][Dp] bytes | G tiles of the 2 waves [2][16][CP] fp32
-// (20 KB at D = 112, C = 80: eight workgroups per CU -- with <= 128 VGPRs every workgroup of the cfg4 launch is resident at
-// once; round 2 also kept every point's own row offset, 7 KB that only the mismatch pass reads: it recomputes them now)
+// (20 KB at D = 112, C = 80; the kernel takes 156 VGPRs -- the geometry phase's 16-row arrays -- so a CU holds six workgroups
+// of two waves: 1 536 slots, every workgroup of the cfg4 launch (1 056) is resident at once, the 2 112 of configs[4] take two
+// rounds.  Capping the registers at 128 spills and was slower; round 2 also kept every point's own row offset in LDS, 7 KB
+// that only the mismatch pass reads: it recomputes them now)
 // (CP = C + 4; after the products: the grad_context total and the lists / partial sums of the mismatch pass)
 // NT = C / 16 (N tiles of the grad_context product); C / 4 <= 64 lanes move one row.
 template <typename FT, int NT, bool CAM>
