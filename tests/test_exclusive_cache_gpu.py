@@ -227,3 +227,45 @@ def test_cache_limits_more_samples_or_cameras_than_it_tracks(mmt_lib):
         out, _ = _forward(rig2, tall, C, cache)
         assert not _lib.lib().mmt_lss_last_kernel_family(0) & (_lib.LSS_FAMILY_EXCLUSIVE | _lib.LSS_FAMILY_REGISTER)
         _same(out, ref)
+
+
+def test_training_lssfpn_with_and_without_the_cache(mmt_lib, monkeypatch):
+    """Through the module (camera form, 64 channels): three rigs in rotation under SGD, so that calibrations are claimed,
+    learnt and used while the weights move -- the loss curve is the one of the run without a cache to the noise of atomic
+    summation order, and the cache does get used."""
+    from mm_training_amd import synthetic
+    from mm_training_amd.dp import make_config
+    from mm_training_amd.layers.backbones import LSSFPN
+    from mm_training_amd.ops.bev_geometry import last_kernel_family
+    cfg = make_config("tiny")
+    bc = dict(cfg["backbone_conf"], output_channels=64)
+    H, W = cfg["final_dim"]
+    B, N = 2, cfg["num_cams"]
+    rigs = []
+    for seed in (0, 1, 2):
+        s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.05, seed=seed)
+        rigs.append(dict(sensor2ego_mats=s2e.view(B, 1, N, 4, 4).cuda(), intrin_mats=K.view(B, 1, N, 4, 4).cuda(),
+                         bda_mat=torch.eye(4).repeat(B, 1, 1).cuda()))
+    imgs = torch.rand(B, 1, N, 3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    curves, fams = {}, {}
+    for slots in ("64", "0"):
+        monkeypatch.setenv("MMT_LSS_EXCL_SLOTS", slots)
+        torch.manual_seed(0)
+        m = LSSFPN(**bc).cuda().train()
+        assert m.exclusive_slots == int(slots)
+        opt = torch.optim.SGD(m.parameters(), lr=1e-2)
+        losses = []
+        for step in range(15):
+            opt.zero_grad(set_to_none=True)
+            loss = m(imgs, rigs[step % 3]).square().mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        curves[slots], fams[slots] = losses, last_kernel_family(detail=True)
+        if slots == "64":
+            (cache,) = m._excl_caches.values()
+            torch.cuda.synchronize()
+            assert cache[24:24 + B].tolist() == [3] * B          # the fifth round of each rig: its calibrations are in use
+    assert "exclusive" in fams["64"] and "exclusive" not in fams["0"]
+    for a, b in zip(curves["64"], curves["0"]):
+        assert a == a and abs(a - b) <= 1e-3 * max(1e-6, abs(b)), (curves["64"], curves["0"])
