@@ -51,3 +51,20 @@ def test_bench_reports_a_rank_that_dies_instead_of_hanging(mmt_lib):
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "rank 1 exited with code 3" in out.stderr
     assert took < 240
+
+
+def test_bench_two_ranks_at_a_baseline_camera_shape(mmt_lib):
+    """BASELINE configs[1] (camera BEVDepth R50, 6 x 256 x 704, C = 80) with two ranks on the one card: each rank runs the
+    step's own kernels -- camera form, register walk, exclusive-cell cache (one cache per process) -- side by side with the
+    other's, long enough for both caches to reach their steady state."""
+    out, _ = _run(None, "--gpus", "2", "--config", "cfg2", "--steps", "4", "--warmup", "9", "--no-cpu-baseline", timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["parallelism"] == "dp2" and c["global_batch"] == 8
+    assert c["final_loss"] == c["final_loss"] and abs(c["final_loss"]) < 1e6
+    k = c["lift_splat_kernels"]
+    assert k["forward"] == "ray+camera+register+exclusive" and k["backward"].endswith("+camera") and k["exclusive_cell_cache"].startswith("on")
+    assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline"]["avg_ms"] < 5.0        # (two processes time-slice the card: no bound on speed here)
