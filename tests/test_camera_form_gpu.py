@@ -155,7 +155,8 @@ def test_camera_form_cells_where_the_fast_quantise_must_fall_back(mmt_lib, oracl
 
 @pytest.mark.parametrize("cfg", [(2, 3, 37, 16, 9, 80, 0.0), (1, 2, 112, 32, 10, 128, 0.0), (1, 2, 40, 20, 5, 64, 2.0),
                                  (4, 6, 112, 16, 44, 80, 0.0), (1, 1, 1, 1, 1, 64, 0.0), (3, 3, 17, 17, 2, 64, 5.0),
-                                 (1, 2, 409, 44, 6, 80, 0.0)])          # the aiMotive-native frustum (D = 409, fH = 44) at a reduced width
+                                 (1, 2, 409, 44, 6, 80, 0.0),           # the aiMotive-native frustum (D = 409, fH = 44) at a reduced width
+                                 (2, 6, 112, 32, 88, 80, 0.0)])         # BASELINE configs[4]'s camera shape in full (block walk, two row blocks)
 @pytest.mark.parametrize("bf16", [False, True])
 def test_camera_form_equals_geom_form(mmt_lib, cfg, bf16):
     """lift_splat_camera == lift_splat(frustum_geometry(...)): forward to fp32 summation order (atomics), both backward
