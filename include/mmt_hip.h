@@ -33,7 +33,7 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 7
+#define MMT_ABI_VERSION 8
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -521,6 +521,31 @@ int mmt_pillar_scatter_nhwc_table(int C, int batch_size, int ny, int nx, int max
 int mmt_pillar_scatter_nhwc_unique_backward(int64_t num_voxels, int C, int batch_size, int ny, int nx,
                                             const float *grad_canvas, const int32_t *coors, float *grad_feats,
                                             void *stream);
+
+/* Pillar scatter at the resolution the fusion layer consumes (ABI 8; replaces models/bev_depth.py:183 + :188-190 +
+ * the LiDAR half of the torch.cat at :192).  The reference scatters the full-resolution canvas [B, C, ny, nx] and
+ * nearest-resizes it onto the camera BEV grid: for an integer ratio (stride_y, stride_x) = (ny / out_h, nx / out_w) torch's
+ * 'nearest' reads canvas cell (i * stride_y, j * stride_x) for output cell (i, j) and nothing else.  These entry points
+ * write exactly those cells: out[b, i, j, 0:C] = canvas[b, :, i * stride_y, j * stride_x], rows `out_row_stride` floats
+ * apart (a channels-last [B, ny / stride_y, nx / stride_x, out_row_stride] buffer; `out` already points at the LiDAR
+ * channel offset of the camera|LiDAR concat buffer).  Bit-identical to mmt_pillar_scatter_nhwc[_table] followed by
+ * [..., ::stride_y, ::stride_x]; strides must divide the grid, C % 4 == 0, out_row_stride % 4 == 0, 16-byte aligned.
+ *   _table_strided   : the rows of the last mmt_hard_voxelize_mean call on `table` (see mmt_pillar_scatter_nhwc_table).
+ *   _strided         : any (feats, coors) rows, last-writer rule; workspace int32 [B * (ny/stride_y) * (nx/stride_x)].
+ *   _strided_backward: grad_feats[m,:] = grad_out[b, y / stride_y, x / stride_x, 0:C] for rows on a sampled cell
+ *                      (y % stride_y == 0 && x % stride_x == 0) that own it, zeros otherwise; `workspace` = the map the
+ *                      _strided forward left, or NULL when the rows own distinct cells (the table form).  grad_out rows are
+ *                      grad_row_stride floats apart (the gradient of the concat buffer, advanced to the channel offset). */
+int mmt_pillar_scatter_nhwc_table_strided(int C, int batch_size, int ny, int nx, int max_voxels, int stride_y, int stride_x,
+                                          const float *voxel_features, const int32_t *table, float *out,
+                                          int64_t out_row_stride, void *stream);
+int mmt_pillar_scatter_nhwc_strided(int64_t num_voxels, int C, int batch_size, int ny, int nx, int stride_y, int stride_x,
+                                    const float *voxel_features, const int32_t *coors, float *out, int64_t out_row_stride,
+                                    int32_t *workspace, void *stream);
+int mmt_pillar_scatter_nhwc_strided_backward(int64_t num_voxels, int C, int batch_size, int ny, int nx, int stride_y,
+                                             int stride_x, const float *grad_out, int64_t grad_row_stride,
+                                             const int32_t *coors, const int32_t *workspace, float *grad_feats,
+                                             void *stream);
 
 /* --------------------------------------------------------- per-step label generation */
 

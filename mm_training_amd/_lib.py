@@ -77,6 +77,9 @@ SIGNATURES = {
     "mmt_pillar_scatter_backward": (_c_int, [_c_i64] + [_c_int] * 4 + [_c_ptr] * 4 + [_c_ptr]),
     "mmt_pillar_scatter_nhwc_table": (_c_int, [_c_int] * 5 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_pillar_scatter_nhwc_unique_backward": (_c_int, [_c_i64] + [_c_int] * 4 + [_c_ptr] * 3 + [_c_ptr]),
+    "mmt_pillar_scatter_nhwc_table_strided": (_c_int, [_c_int] * 7 + [_c_ptr] * 3 + [_c_i64, _c_ptr]),
+    "mmt_pillar_scatter_nhwc_strided": (_c_int, [_c_i64] + [_c_int] * 6 + [_c_ptr] * 3 + [_c_i64, _c_ptr, _c_ptr]),
+    "mmt_pillar_scatter_nhwc_strided_backward": (_c_int, [_c_i64] + [_c_int] * 6 + [_c_ptr, _c_i64] + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_pillar_scatter_nhwc": (_c_int, [_c_i64] + [_c_int] * 4 + [_c_ptr] * 4 + [_c_ptr]),
     "mmt_pillar_scatter_nhwc_backward": (_c_int, [_c_i64] + [_c_int] * 4 + [_c_ptr] * 4 + [_c_ptr]),
 }

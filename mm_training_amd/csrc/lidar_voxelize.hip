@@ -337,12 +337,16 @@ __global__ __launch_bounds__(256) void simple_vfe_kernel(int64_t M, int T, int F
 }
 
 // cell -> row map: highest row index wins (sequential last-writer semantics)
-__global__ __launch_bounds__(256) void scatter_map_kernel(int64_t M, int B, int ny, int nx,
+// (sy, sx) > 1: the map of the canvas SAMPLED at cells (i * sy, j * sx) -- [B, ny / sy, nx / sx] entries; only the voxels
+// on sampled cells enter it (mmt_pillar_scatter_nhwc_strided)
+__global__ __launch_bounds__(256) void scatter_map_kernel(int64_t M, int B, int ny, int nx, int sy, int sx,
                                                           const int32_t *coors, int32_t *map) {
+    const int oh = ny / sy, ow = nx / sx;
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
         const int b = coors[m * 4], y = coors[m * 4 + 2], x = coors[m * 4 + 3];
         if (b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx) continue;
-        atomicMax(&map[((int64_t)b * ny + y) * nx + x], (int)m);
+        if (y % sy || x % sx) continue;
+        atomicMax(&map[((int64_t)b * oh + y / sy) * ow + x / sx], (int)m);
     }
 }
 
@@ -673,7 +677,7 @@ extern "C" int mmt_pillar_scatter(int64_t M, int C, int B, int ny, int nx, const
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
     seq.launch(false, fill_i32_kernel, dim3(mmt::stream_grid(B * HW, 256, 2048)), dim3(256), 0, st, B * HW, (int32_t)-1, workspace);
     if (M > 0)
-        seq.launch(false, scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
+        seq.launch(false, scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, 1, 1, coors, workspace);
     const bool vec4 = (HW % 4 == 0) && (((uintptr_t)canvas & 15) == 0) && (((uintptr_t)workspace & 15) == 0);
     const int64_t work = (int64_t)B * ((C + kChanBlock - 1) / kChanBlock) * (vec4 ? HW / 4 : HW);
     if (vec4) seq.launch(true, scatter_write_kernel<true>, dim3(mmt::stream_grid(work, 256, 256 * 32)), dim3(256), 0, st, C, B, (int)HW, feats, (const int32_t *)workspace, canvas);
@@ -711,7 +715,7 @@ extern "C" int mmt_pillar_scatter_nhwc(int64_t M, int C, int B, int ny, int nx, 
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
     seq.launch(false, fill_i32_kernel, dim3(mmt::stream_grid(cells, 256, 2048)), dim3(256), 0, st, cells, (int32_t)-1, workspace);
     if (M > 0)
-        seq.launch(false, scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, coors, workspace);
+        seq.launch(false, scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, 1, 1, coors, workspace);
     seq.launch(true, scatter_write_nhwc_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / (C / 4))) * 256, 256, 256 * 32)), dim3(256), 0, st,
                C / 4, cells, feats, (const int32_t *)workspace, canvas);
     return mmt::check_launch("pillar_scatter_nhwc");
@@ -844,4 +848,197 @@ extern "C" int mmt_pillar_scatter_nhwc_backward(int64_t M, int C, int B, int ny,
                    (hipStream_t)stream, M, C4, B, ny, nx, grad_canvas, coors, workspace, grad_feats);
     }
     return mmt::check_launch("pillar_scatter_nhwc_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pillar scatter AT THE RESOLUTION THE FUSION LAYER CONSUMES (round 4).  models/bev_depth.py:188-190 nearest-resizes the
+// pillar canvas onto the camera BEV grid before the channel concat (:189): with an integer ratio (sy, sx) -- 512 x 512
+// pillars of 0.2 m onto 128 x 128 cells of 0.8 m: 4 x 4 -- torch's 'nearest' samples canvas cell (i * sy, j * sx) for output
+// cell (i, j) and nothing else, so 15 / 16 of the canvas (268 MB at BASELINE configs[3]) was written, read once and thrown
+// away, and its gradient (another 268 MB, almost all zeros) was written by upsample_nearest2d_backward just to be gathered
+// from.  These entry points scatter only the sampled cells, straight into the camera|LiDAR concat buffer (rows of
+// `out_row_stride` floats, `out` already advanced to the LiDAR channel offset), and the backward gathers
+// grad[b, y / sy, x / sx, :] for the voxels on sampled cells (zeros for the others).  Bit-identical to the full-resolution
+// scatter followed by [..., ::sy, ::sx] (tests/test_lidar_strided_gpu.py).
+namespace {
+
+struct StridedDims {
+    int C4, B, ny, nx, sy, sx, oh, ow;
+    int64_t row_stride4;           // float4 units between consecutive output cells' rows
+};
+
+// table form: one lane group of C4 lanes per OUTPUT cell, kCells cells per group and trip (entries first, then rows)
+__global__ __launch_bounds__(256) void scatter_write_strided_table_kernel(StridedDims d, int V, const float *feats,
+                                                                          const unsigned long long *table, float *out) {
+    constexpr int kCells = 4;
+    const int lane_in = threadIdx.x % d.C4;
+    const int groups_per_block = 256 / d.C4;
+    const int grp = threadIdx.x / d.C4;
+    if (grp >= groups_per_block) return;
+    const unsigned long long gen = table[0];
+    const bool ids_valid = (table[1] >> 32) & 1ull;     // see scatter_write_nhwc_table_kernel
+    const int64_t per_b = (int64_t)d.oh * d.ow, cells = (int64_t)d.B * per_b;
+    const int64_t src_per_b = (int64_t)d.ny * d.nx;
+    const int64_t ngroups = (int64_t)gridDim.x * groups_per_block;
+    for (int64_t c0 = ((int64_t)blockIdx.x * groups_per_block + grp) * kCells; c0 < cells; c0 += ngroups * kCells) {
+        unsigned long long e[kCells];
+        int bb[kCells];
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) {
+            const int64_t oc = (c0 + u) < cells ? (c0 + u) : (cells - 1);
+            const int b = (int)(oc / per_b);
+            const int r = (int)(oc - (int64_t)b * per_b);
+            const int i = r / d.ow, j = r - i * d.ow;
+            bb[u] = b;
+            e[u] = table[2 + (int64_t)b * src_per_b + (int64_t)(i * d.sy) * d.nx + j * d.sx];
+        }
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) {
+            if (c0 + u >= cells) break;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((e[u] >> kIdxBits) == gen && (e[u] & kOwnedBit)) {
+                const int64_t row = (int64_t)bb[u] * V + (int64_t)(e[u] & (kOwnedBit - 1));
+                v = reinterpret_cast<const float4 *>(feats)[row * d.C4 + lane_in];
+            }
+            if (!ids_valid) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            reinterpret_cast<float4 *>(out)[(c0 + u) * d.row_stride4 + lane_in] = v;
+        }
+    }
+}
+
+// map form: the cell -> row map is already at the output resolution (scatter_map_kernel with strides)
+__global__ __launch_bounds__(256) void scatter_write_strided_kernel(int C4, int64_t cells, int64_t row_stride4, const float *feats,
+                                                                    const int32_t *map, float *out) {
+    constexpr int kCells = 4;
+    const int lane_in = threadIdx.x % C4;
+    const int groups_per_block = 256 / C4;
+    const int grp = threadIdx.x / C4;
+    if (grp >= groups_per_block) return;
+    const int64_t ngroups = (int64_t)gridDim.x * groups_per_block;
+    for (int64_t c0 = ((int64_t)blockIdx.x * groups_per_block + grp) * kCells; c0 < cells; c0 += ngroups * kCells) {
+        int m[kCells];
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) m[u] = map[(c0 + u) < cells ? (c0 + u) : (cells - 1)];
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) {
+            if (c0 + u >= cells) break;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m[u] >= 0) v = reinterpret_cast<const float4 *>(feats)[(int64_t)m[u] * C4 + lane_in];
+            reinterpret_cast<float4 *>(out)[(c0 + u) * row_stride4 + lane_in] = v;
+        }
+    }
+}
+
+// backward of both forms: grad_feats[m,:] = grad[b, y / sy, x / sx, :] for a row on a sampled cell (that owns it: `map`
+// non-NULL = the map form's last-writer rule; NULL = rows own distinct cells), zeros otherwise.  Same structure as
+// scatter_backward_nhwc_unique_kernel: coors of kRows rows first, then the gradient rows through a range-checked buffer
+// descriptor (a row that takes nothing uses an out-of-range offset -> zeros without a memory access, no branch).
+template <int kRows>
+__global__ __launch_bounds__(256) void scatter_backward_strided_kernel(int64_t M, StridedDims d, const float *grad, const int32_t *coors,
+                                                                       const int32_t *map, float *grad_feats, unsigned span_bytes) {
+    const int gpb = 256 / d.C4;
+    const int grp = threadIdx.x / d.C4, li = threadIdx.x - grp * d.C4;
+    if (grp >= gpb) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad), 0, (int)span_bytes, 0x00020000);
+    const int4 *co4 = reinterpret_cast<const int4 *>(coors);
+    const int64_t step = (int64_t)gridDim.x * gpb * kRows;
+    for (int64_t m0 = ((int64_t)blockIdx.x * gpb + grp) * kRows; m0 < M; m0 += step) {
+        int4 co[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) co[u] = co4[(m0 + u) < M ? (m0 + u) : (M - 1)];
+        int64_t ocell[kRows];
+        bool ok[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            const int b = co[u].x, y = co[u].z, x = co[u].w;
+            ok[u] = !(b < 0 || b >= d.B || y < 0 || y >= d.ny || x < 0 || x >= d.nx) && (m0 + u) < M && (y % d.sy == 0) && (x % d.sx == 0);
+            ocell[u] = ok[u] ? ((int64_t)b * d.oh + y / d.sy) * d.ow + x / d.sx : 0;
+        }
+        if (map != nullptr) {
+            int own[kRows];
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) own[u] = map[ocell[u]];
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) ok[u] = ok[u] && own[u] == (int)(m0 + u);
+        }
+        mmt_u32x4 v[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u)
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok[u] ? (unsigned)((ocell[u] * d.row_stride4 + li) << 4) : 0xFFFFFFF0u, 0, 0);
+#pragma unroll
+        for (int u = 0; u < kRows; ++u)
+            if (m0 + u < M) reinterpret_cast<mmt_u32x4 *>(grad_feats)[(m0 + u) * d.C4 + li] = v[u];
+    }
+}
+
+int strided_check(const char *who, int C, int B, int ny, int nx, int sy, int sx, int64_t row_stride, const void *buf, StridedDims *d) {
+    if (C <= 0 || C % 4 || C > 1024 || B <= 0 || ny <= 0 || nx <= 0 || sy <= 0 || sx <= 0 || ny % sy || nx % sx)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: bad sizes (C %% 4 == 0, C <= 1024, strides must divide the grid: C=%d B=%d %dx%d / %dx%d)",
+                         who, C, B, ny, nx, sy, sx);
+    if (row_stride < C || (row_stride & 3) || ((uintptr_t)buf & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the row stride must be >= C and a multiple of 4 floats, the buffer 16-byte aligned", who);
+    if ((int64_t)B * ny * nx >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: B*ny*nx exceeds int32", who);
+    d->C4 = C / 4; d->B = B; d->ny = ny; d->nx = nx; d->sy = sy; d->sx = sx; d->oh = ny / sy; d->ow = nx / sx;
+    d->row_stride4 = row_stride / 4;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mmt_pillar_scatter_nhwc_table_strided(int C, int B, int ny, int nx, int max_voxels, int stride_y, int stride_x,
+                                                     const float *feats, const int32_t *table, float *out,
+                                                     int64_t out_row_stride, void *stream) {
+    MMT_REQUIRE_PTR(feats);
+    MMT_REQUIRE_PTR(table);
+    MMT_REQUIRE_PTR(out);
+    StridedDims d;
+    if (int rc = strided_check("pillar_scatter_nhwc_table_strided", C, B, ny, nx, stride_y, stride_x, out_row_stride, out, &d)) return rc;
+    if (max_voxels <= 0 || max_voxels > (1 << (kIdxBits - 1)) || ((uintptr_t)feats & 15) || ((uintptr_t)table & 7))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_table_strided: max_voxels <= 2^23, aligned feats / table");
+    const int64_t cells = (int64_t)B * d.oh * d.ow;
+    mmt::TimedSeq seq;
+    seq.launch(true, scatter_write_strided_table_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / d.C4)) * 256, 256, 256 * 32)),
+               dim3(256), 0, (hipStream_t)stream, d, max_voxels, feats, reinterpret_cast<const unsigned long long *>(table), out);
+    return mmt::check_launch("pillar_scatter_nhwc_table_strided");
+}
+
+extern "C" int mmt_pillar_scatter_nhwc_strided(int64_t M, int C, int B, int ny, int nx, int stride_y, int stride_x, const float *feats,
+                                               const int32_t *coors, float *out, int64_t out_row_stride, int32_t *workspace,
+                                               void *stream) {
+    MMT_REQUIRE_PTR(out);
+    MMT_REQUIRE_PTR(workspace);
+    if (M > 0) { MMT_REQUIRE_PTR(feats); MMT_REQUIRE_PTR(coors); }
+    StridedDims d;
+    if (int rc = strided_check("pillar_scatter_nhwc_strided", C, B, ny, nx, stride_y, stride_x, out_row_stride, out, &d)) return rc;
+    if (M < 0 || M >= (1ll << 31) || ((uintptr_t)feats & 15)) return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_strided: bad M / unaligned feats");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t cells = (int64_t)B * d.oh * d.ow;
+    mmt::TimedSeq seq;
+    seq.launch(false, fill_i32_kernel, dim3(mmt::stream_grid(cells, 256, 2048)), dim3(256), 0, st, cells, (int32_t)-1, workspace);
+    if (M > 0)
+        seq.launch(false, scatter_map_kernel, dim3(mmt::stream_grid(M, 256)), dim3(256), 0, st, M, B, ny, nx, stride_y, stride_x, coors, workspace);
+    seq.launch(true, scatter_write_strided_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / d.C4)) * 256, 256, 256 * 32)), dim3(256), 0, st,
+               d.C4, cells, d.row_stride4, feats, (const int32_t *)workspace, out);
+    return mmt::check_launch("pillar_scatter_nhwc_strided");
+}
+
+extern "C" int mmt_pillar_scatter_nhwc_strided_backward(int64_t M, int C, int B, int ny, int nx, int stride_y, int stride_x,
+                                                        const float *grad_out, int64_t grad_row_stride, const int32_t *coors,
+                                                        const int32_t *workspace, float *grad_feats, void *stream) {
+    if (M == 0) return MMT_OK;
+    MMT_REQUIRE_PTR(grad_out);
+    MMT_REQUIRE_PTR(coors);
+    MMT_REQUIRE_PTR(grad_feats);
+    StridedDims d;
+    if (int rc = strided_check("pillar_scatter_nhwc_strided_backward", C, B, ny, nx, stride_y, stride_x, grad_row_stride, grad_out, &d)) return rc;
+    // bytes from grad_out to the end of the last sampled cell's C-float slice (the buffer descriptor's range)
+    const int64_t span = (((int64_t)B * d.oh * d.ow - 1) * grad_row_stride + C) * 4;
+    if (M < 0 || ((uintptr_t)grad_feats & 15) || ((uintptr_t)coors & 15) || span >= (1ll << 32) - 16)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_strided_backward: bad M, unaligned buffers or a gradient of 4 GiB or more");
+    constexpr int kRows = 4;
+    const int gpb = 256 / d.C4;
+    mmt::TimedSeq seq;
+    seq.launch(true, scatter_backward_strided_kernel<kRows>, dim3(mmt::stream_grid(mmt::ceil_div(M, (int64_t)gpb * kRows) * 256, 256, 256 * 16)),
+               dim3(256), 0, (hipStream_t)stream, M, d, grad_out, coors, workspace, grad_feats, (unsigned)span);
+    return mmt::check_launch("pillar_scatter_nhwc_strided_backward");
 }

@@ -244,6 +244,62 @@ class _PillarScatterTable(Function):
         return grad_feats, None, None, None, None, None, None
 
 
+class _PillarScatterStrided(Function):
+    """Pillar scatter of the canvas cells (i * sy, j * sx) only -- what a nearest resize by the integer ratio (sy, sx) reads
+    (models/bev_depth.py:188-190) -- as a channels_last [B, C, ny / sy, nx / sx] tensor.  table given: the fixed-capacity
+    rows of the last hard_voxelize_mean_batch call on it (mmt_pillar_scatter_nhwc_table_strided); None: any rows, last-writer
+    rule through a cell -> row map at the output resolution (mmt_pillar_scatter_nhwc_strided)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, feats, coors, table, batch_size, ny, nx, max_voxels, sy, sx):
+        if not feats.is_cuda:
+            raise RuntimeError("voxel_features must be a CUDAtensor ")
+        feats = _fp32_rows(feats, "voxel_features")
+        M, C = feats.shape
+        oh, ow = ny // sy, nx // sx
+        out = torch.empty((batch_size, oh, ow, C), dtype=torch.float32, device=feats.device)
+        cell_map = None
+        with torch.cuda.device(feats.device):
+            if table is not None:
+                _lib.timed_call("scatter", "mmt_pillar_scatter_nhwc_table_strided", C, batch_size, ny, nx, max_voxels, sy, sx,
+                                feats.data_ptr(), table.data_ptr(), out.data_ptr(), C, _stream())
+            else:
+                cell_map = torch.empty((batch_size * oh * ow,), dtype=torch.int32, device=feats.device)
+                _lib.timed_call("scatter", "mmt_pillar_scatter_nhwc_strided", M, C, batch_size, ny, nx, sy, sx,
+                                feats.data_ptr() if M else 0, coors.data_ptr() if M else 0, out.data_ptr(), C,
+                                cell_map.data_ptr(), _stream())
+        ctx.save_for_backward(coors, *([cell_map] if cell_map is not None else []))
+        ctx.dims = (M, C, batch_size, ny, nx, sy, sx)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        coors, *rest = ctx.saved_tensors
+        M, C, B, ny, nx, sy, sx = ctx.dims
+        grad_out = grad_out.float()
+        if not grad_out.is_contiguous(memory_format=torch.channels_last):
+            grad_out = grad_out.contiguous(memory_format=torch.channels_last)
+        grad_feats = torch.empty((M, C), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            _lib.timed_call("scatter_backward", "mmt_pillar_scatter_nhwc_strided_backward", M, C, B, ny, nx, sy, sx,
+                            grad_out.data_ptr(), C, coors.data_ptr(), rest[0].data_ptr() if rest else 0, grad_feats.data_ptr(), _stream())
+        return grad_feats, None, None, None, None, None, None, None, None
+
+
+def pillar_scatter_strided(voxel_features, coors, batch_size, ny, nx, stride_y, stride_x, table=None, max_voxels=0):
+    """The canvas of pillar_scatter sampled at [..., ::stride_y, ::stride_x] without the canvas: channels_last
+    [B, C, ny / stride_y, nx / stride_x].  `table`: see pillar_scatter_from_table."""
+    sy, sx = int(stride_y), int(stride_x)
+    if sy <= 0 or sx <= 0 or ny % sy or nx % sx:
+        raise ValueError(f"pillar_scatter_strided: strides ({sy}, {sx}) must divide the grid ({ny}, {nx})")
+    coors = coors.contiguous()
+    if coors.dtype != torch.int32:
+        coors = coors.int()
+    return _PillarScatterStrided.apply(voxel_features, coors, table, int(batch_size), int(ny), int(nx), int(max_voxels), sy, sx)
+
+
 def pillar_scatter_from_table(voxel_features, coors, table, batch_size, ny, nx, max_voxels):
     """[B*max_voxels, C] rows of the LAST hard_voxelize_mean_batch call on `table` -> channels_last [B, C, ny, nx] canvas."""
     return _PillarScatterTable.apply(voxel_features, coors.contiguous(), table, int(batch_size), int(ny), int(nx), int(max_voxels))
@@ -307,11 +363,11 @@ class LidarEncoder(nn.Module):
         return pillar_scatter(voxel_features, coors, batch_size, self.output_shape[0], self.output_shape[1],
                               channels_last=self.channels_last)
 
-    def forward_bev(self, points):
-        """voxelize + mean (ONE fused call, the padded voxel tensor is not materialised) -> (MLP) -> scatter
-        with NO host synchronisation: stays in the fixed-capacity layout; empty rows carry coors = -1 and
-        are ignored by the scatter."""
-        # the scatter can read the voxelizer's own table when a canvas cell IS a voxel cell (one z layer, same y/x grid)
+    def forward_rows(self, points):
+        """voxelize + mean (ONE fused call, the padded voxel tensor is not materialised) -> (MLP): the rows the scatter
+        consumes, in the voxelizer's fixed-capacity layout, with NO host synchronisation.  Returns (feats [B*max_voxels, C],
+        coors [B*max_voxels, 4], table or None): `table` is the voxelizer's own table when a canvas cell IS a voxel cell
+        (one z layer, same y/x grid), which lets the scatter read voxel ids straight from it; empty rows carry coors = -1."""
         direct = (self.channels_last and self.grid[2] == 1 and self.output_shape == [self.grid[1], self.grid[0]]
                   and self.in_channels % 4 == 0 and self.max_voxels <= (1 << 23))
         with torch.no_grad():
@@ -321,7 +377,21 @@ class LidarEncoder(nn.Module):
                 self.num_features, materialize_voxels=False, return_table=True, tables=self._tables)
         if self.pillar_mlp is not None:
             feats = self.pillar_mlp(feats)
-        if direct and sum(int(p.shape[0]) for p in points) < (1 << 23):
+        if not (direct and sum(int(p.shape[0]) for p in points) < (1 << 23)):
+            table = None
+        return feats, coors, table
+
+    def forward_bev(self, points):
+        """forward_rows -> scatter onto the full-resolution canvas (models/bev_depth.py:181-183 in three launches + one)."""
+        feats, coors, table = self.forward_rows(points)
+        if table is not None:
             return pillar_scatter_from_table(feats, coors, table, len(points), self.output_shape[0], self.output_shape[1], self.max_voxels)
         return pillar_scatter(feats, coors, len(points), self.output_shape[0], self.output_shape[1],
                               channels_last=self.channels_last)
+
+    def forward_bev_strided(self, points, stride_y, stride_x):
+        """forward_rows -> the canvas cells a nearest resize by (stride_y, stride_x) reads, nothing else
+        (models/bev_depth.py:181-183 + :188-190): channels_last [B, C, ny / stride_y, nx / stride_x]."""
+        feats, coors, table = self.forward_rows(points)
+        return pillar_scatter_strided(feats, coors, len(points), self.output_shape[0], self.output_shape[1], stride_y, stride_x,
+                                      table=table, max_voxels=self.max_voxels)

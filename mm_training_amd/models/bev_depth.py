@@ -14,7 +14,7 @@ from torch import nn
 from ..layers.backbones.lss_fpn import LSSFPN
 from ..layers.heads.bev_depth_head import BEVDepthHead
 from ..lidar import LidarEncoder
-from ..ops.bev_warp import bev_warp_affine, bev_warp_concat
+from ..ops.bev_warp import bev_warp_affine, bev_warp_concat, bev_warp_concat_pillars
 
 __all__ = ['BEVDepth', 'BEVFuseLayer', 'BEVDepthLiDAR']
 
@@ -109,6 +109,13 @@ class BEVDepthLiDAR(BEVDepth):
         super().__init__(backbone_conf, head_conf, is_train_depth=False, use_cam=use_cam)
         self.use_cam, self.use_lidar = use_cam, use_lidar
         self.sync_free_lidar = os.environ.get("MMT_LIDAR_SYNC_FREE", "1") != "0"
+        # The reference scatters the full-resolution pillar canvas and nearest-resizes it onto the camera grid
+        # (models/bev_depth.py:183 + :188-190); the canvas itself is only handed back as `lidar_bev_ret`, which nothing in
+        # the reference reads (exps/mm_training_aim.py:268 binds it and drops it).  False (default): with both modalities
+        # and an integer grid ratio only the canvas cells the resize samples are scattered, straight into the camera|LiDAR
+        # buffer, and the third return value is that LiDAR half [B, Cl, H, W].  True: the reference's op sequence and its
+        # full-resolution third return value.
+        self.full_lidar_canvas = os.environ.get("MMT_LIDAR_FULL_CANVAS", "0") == "1"
         if use_lidar:
             self.lidar_encoder = LidarEncoder(**{k: v for k, v in dict(lidar_conf).items() if k != 'type'})
         if use_cam and use_lidar:
@@ -128,14 +135,26 @@ class BEVDepthLiDAR(BEVDepth):
     def forward(self, x, mats_dict, lidar_oracle=None, timestamps=None):
         images, clouds = x
         cam_map, depth = self._camera_bev(images, mats_dict, lidar_oracle, timestamps) if self.use_cam else (None, None)
-        lidar_map = self._lidar_bev(clouds) if self.use_lidar else None
         if cam_map is None:
+            lidar_map = self._lidar_bev(clouds)
             return self.head(lidar_map), depth, lidar_map, None
-        if lidar_map is None:
+        if not self.use_lidar:
             cam_aug = self.bev_augment_image(cam_map, mats_dict['bda_mat'])
             return self.head(cam_aug), depth, None, cam_aug
+        enc = self.lidar_encoder
+        ny, nx = enc.output_shape
+        H, W = cam_map.shape[-2:]
+        if (self.sync_free_lidar and not self.full_lidar_canvas and enc.channels_last and enc.in_channels % 4 == 0
+                and cam_map.shape[1] % 4 == 0 and ny % H == 0 and nx % W == 0):
+            # both, integer ratio: BEV-aug warp of the camera map (:176) + the sampled pillar cells (:183 + :188-190), each
+            # written once, straight into the camera|LiDAR buffer (:192)
+            feats, coors, table = enc.forward_rows(clouds)
+            stacked = bev_warp_concat_pillars(cam_map, mats_dict['bda_mat'], feats, coors, table, ny, nx, enc.max_voxels)
+            c = cam_map.shape[1]
+            return self.head(self.bev_fuse(stacked)), depth, stacked[:, c:], stacked[:, :c]
         # both: nearest-resize the pillar canvas onto the camera grid (:188-190), then BEV-aug warp (:176) and channel
         # concat (:189) in one pass -- the warped camera map is written straight into the camera|LiDAR buffer
+        lidar_map = self._lidar_bev(clouds)
         lidar_small = lidar_map if lidar_map.shape[-2:] == cam_map.shape[-2:] else F.interpolate(lidar_map, size=cam_map.shape[-2:])
         stacked = bev_warp_concat(cam_map, mats_dict['bda_mat'], lidar_small)
         return self.head(self.bev_fuse(stacked)), depth, lidar_map, stacked[:, :cam_map.shape[1]]

@@ -153,3 +153,22 @@ def test_missing_library_fails_loudly():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import oracle|from oracle)", text, re.M), os.path.join(dirpath, f)
+
+
+def test_host_side_argument_checks_of_the_strided_pillar_scatter(mmt_lib):
+    """mmt_pillar_scatter_nhwc[_table]_strided[_backward] (ABI 8): strides that do not divide the grid, a row stride below C or
+    not a multiple of 4, NULL operands -- refused on the host before any launch."""
+    lib = mmt_lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 100, 4, 4, None, p, p, 8, None) == -1
+    assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 100, 3, 4, p, p, p, 8, None) == -2 and b"divide" in lib.mmt_last_error()
+    assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 100, 4, 4, p, p, p, 4, None) == -2      # row stride < C
+    assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 100, 4, 4, p, p, p, 10, None) == -2     # not a multiple of 4
+    assert lib.mmt_pillar_scatter_nhwc_table_strided(6, 1, 16, 16, 100, 4, 4, p, p, p, 8, None) == -2      # C % 4
+    assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 1 << 24, 4, 4, p, p, p, 8, None) == -2  # max_voxels > 2^23
+    assert lib.mmt_pillar_scatter_nhwc_strided(4, 8, 1, 16, 16, 4, 4, p, p, p, 8, None, None) == -1
+    assert lib.mmt_pillar_scatter_nhwc_strided(4, 8, 1, 16, 16, 0, 4, p, p, p, 8, p, None) == -2
+    assert lib.mmt_pillar_scatter_nhwc_strided_backward(0, 8, 1, 16, 16, 4, 4, None, 8, None, None, None, None) == 0   # nothing to do
+    assert lib.mmt_pillar_scatter_nhwc_strided_backward(4, 8, 1, 16, 16, 4, 4, p, 8, None, None, p, None) == -1
+    assert lib.mmt_pillar_scatter_nhwc_strided_backward(4, 8, 1, 16, 16, 5, 4, p, 8, p, None, p, None) == -2

@@ -1,0 +1,181 @@
+"""GPU parity of the pillar scatter at the resolution the fusion layer consumes (round 4): models/bev_depth.py:183 +
+:188-190 (PointPillarsScatter, then a nearest resize onto the camera grid) + the LiDAR half of the concat at :192.
+
+Forward bar: bit-identical to the oracle's full-resolution scatter sampled at [..., ::sy, ::sx] -- which is what
+torch's 'nearest' reads for an integer ratio (checked against F.interpolate itself below).  Backward bar: bit-identical
+to the gradient the existing path (full canvas -> F.interpolate -> autograd) gives the same rows.  PARITY UNPINNED
+upstream for the scatter itself (mmdet3d is not vendored, see oracle/oracle.c)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+NUSC = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]          # dp/configs.py: 512 x 512 pillars of 0.2 m
+VSIZE = [0.2, 0.2, 8.0]
+
+
+def _frames(sizes, F_=5, seed=0, dense=False):
+    from mm_training_amd import synthetic
+    out = []
+    for i, n in enumerate(sizes):
+        p = synthetic.lidar_frame(n, F_, NUSC, num_radar=min(n, 2000) if F_ == 8 else 0, seed=seed + i)
+        if dense and n:
+            k = n // 3
+            p[:k, 0] = 10.0 + (p[:k, 0] % 0.6)
+            p[:k, 1] = 2.0 + (p[:k, 1] % 0.4)
+        out.append(p)
+    return out
+
+
+def test_nearest_resize_by_an_integer_ratio_reads_the_strided_cells():
+    """The premise: F.interpolate(x, size) with in / out an integer s is x[..., ::s, ::s] (models/bev_depth.py:190 uses
+    torch.nn.functional.upsample's default mode 'nearest')."""
+    x = torch.randn(2, 3, 512, 256, device="cuda")
+    assert torch.equal(F.interpolate(x, size=(128, 64)), x[..., ::4, ::4])
+    assert torch.equal(F.interpolate(x, size=(256, 32)), x[..., ::2, ::8])
+
+
+# (point counts per sample, point columns, max_voxels, C, strides): BASELINE configs[3] (4 x 40 k points, 512 -> 128),
+# configs[4] (2 x 80 k points with the 8 radar columns), empty / one-point samples, the voxel cap hit, unequal strides
+CASES = [([40000] * 4, 5, 25000, 64, (4, 4)), ([80000, 80000], 8, 25000, 64, (4, 4)), ([40000, 0, 1, 30000], 5, 25000, 64, (4, 4)),
+         ([30000, 20000], 5, 6000, 8, (4, 4)), ([20000, 15000], 5, 25000, 16, (2, 8)), ([5000], 5, 25000, 4, (1, 1))]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_table_form_against_the_oracle_and_the_full_canvas_path(mmt_lib, oracle_mod, case):
+    from mm_training_amd.lidar import hard_voxelize_mean_batch, pillar_scatter_from_table, pillar_scatter_strided
+    sizes, Fcols, V, C, (sy, sx) = case
+    ny = nx = 512
+    rng = np.random.default_rng(7)
+    for seed in (51, 52, 51):                     # the persistent table holds the previous clouds' entries
+        frames = _frames(sizes, Fcols, seed=seed, dense=(V < 25000))
+        dev = [f.cuda() for f in frames]
+        B = len(frames)
+        _, n, c, cnt, m, table = hard_voxelize_mean_batch(dev, VSIZE, NUSC, 15, V, 5, materialize_voxels=False, return_table=True)
+        rv, rn, rc = oracle_mod.voxelize_batch([f.numpy() for f in frames], VSIZE, NUSC, 15, V)
+        live = (c[:, 0] >= 0).cpu().numpy()
+        assert int(live.sum()) == rc.shape[0]
+        feats_np = rng.standard_normal((B * V, C)).astype(np.float32)
+        ref_small = oracle_mod.pillar_scatter(feats_np[live], rc, B, ny, nx)[..., ::sy, ::sx]
+        f1 = torch.from_numpy(feats_np).cuda().requires_grad_(True)
+        small = pillar_scatter_strided(f1, c, B, ny, nx, sy, sx, table=table, max_voxels=V)
+        assert small.shape == (B, C, ny // sy, nx // sx) and small.is_contiguous(memory_format=torch.channels_last)
+        assert np.array_equal(small.detach().cpu().numpy(), ref_small)
+        g = torch.from_numpy(rng.standard_normal(ref_small.shape).astype(np.float32)).cuda()
+        small.backward(g)
+        # the existing path on the same rows: full canvas -> nearest resize -> autograd
+        f2 = torch.from_numpy(feats_np).cuda().requires_grad_(True)
+        full = pillar_scatter_from_table(f2, c, table, B, ny, nx, V)
+        resized = F.interpolate(full, size=(ny // sy, nx // sx))
+        assert torch.equal(resized, small.detach())
+        resized.backward(g)
+        assert torch.equal(f1.grad, f2.grad)
+        # and the oracle's backward of the zero-stuffed gradient
+        g_full = np.zeros((B, C, ny, nx), np.float32)
+        g_full[..., ::sy, ::sx] = g.cpu().numpy()
+        gf = f1.grad.cpu().numpy()
+        assert np.array_equal(gf[live], oracle_mod.pillar_scatter_backward(g_full, rc)) and float(np.abs(gf[~live]).sum()) == 0.0
+
+
+def test_map_form_with_duplicate_cells(mmt_lib, oracle_mod):
+    """Any (feats, coors) rows, last-writer rule (mmt_pillar_scatter_nhwc_strided): duplicates on sampled and unsampled
+    cells, out-of-range rows, an empty input."""
+    from mm_training_amd.lidar import pillar_scatter_strided
+    rng = np.random.default_rng(11)
+    B, ny, nx, C, M = 3, 64, 96, 12, 4000
+    co = np.stack([rng.integers(0, B, M), np.zeros(M, np.int64), rng.integers(0, ny, M), rng.integers(0, nx, M)], 1).astype(np.int32)
+    co[100:200] = co[0:100]                       # duplicates: the later row wins, the earlier one gets no gradient
+    co[300:310, 2] = -1                           # empty rows of the fixed-capacity layout
+    co[310:320, 0] = B                            # out of range
+    fe = rng.standard_normal((M, C)).astype(np.float32)
+    for sy, sx in ((4, 4), (2, 3), (1, 1), (64, 96)):
+        ft = torch.from_numpy(fe).cuda().requires_grad_(True)
+        out = pillar_scatter_strided(ft, torch.from_numpy(co).cuda(), B, ny, nx, sy, sx)
+        ok = (co[:, 0] >= 0) & (co[:, 0] < B) & (co[:, 2] >= 0)
+        ref = oracle_mod.pillar_scatter(fe[ok], co[ok], B, ny, nx)[..., ::sy, ::sx]
+        assert np.array_equal(out.detach().cpu().numpy(), ref)
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        out.backward(torch.from_numpy(g).cuda())
+        g_full = np.zeros((B, C, ny, nx), np.float32)
+        g_full[..., ::sy, ::sx] = g
+        want = np.zeros((M, C), np.float32)
+        want[ok] = oracle_mod.pillar_scatter_backward(g_full, co[ok])
+        assert np.array_equal(ft.grad.cpu().numpy(), want)
+    e = pillar_scatter_strided(torch.zeros(0, 4, device="cuda"), torch.zeros(0, 4, dtype=torch.int32, device="cuda"), 1, 8, 8, 2, 2)
+    assert e.shape == (1, 4, 4, 4) and float(e.abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        pillar_scatter_strided(torch.zeros(1, 4, device="cuda"), torch.zeros(1, 4, dtype=torch.int32, device="cuda"), 1, 8, 8, 3, 2)
+
+
+@pytest.mark.parametrize("table_form", [True, False])
+def test_warp_concat_pillars_equals_the_reference_op_sequence(mmt_lib, table_form):
+    """BevWarpConcatPillars (warp + sampled scatter into ONE buffer) against the sequence it replaces: full canvas ->
+    F.interpolate -> bev_warp_concat; outputs and all gradients bit-identical."""
+    from mm_training_amd.lidar import hard_voxelize_mean_batch, pillar_scatter, pillar_scatter_from_table
+    from mm_training_amd.ops.bev_warp import bev_warp_concat, bev_warp_concat_pillars
+    B, V, Cc, Cl, H = 4, 25000, 80, 64, 128
+    g = torch.Generator().manual_seed(3)
+    dev = [f.cuda() for f in _frames([40000] * B, seed=61)]
+    _, n, c, cnt, m, table = hard_voxelize_mean_batch(dev, VSIZE, NUSC, 15, V, 5, materialize_voxels=False, return_table=True)
+    feats = torch.randn(B * V, Cl, generator=g)
+    cam = torch.randn(B, Cc, H, H, generator=g).contiguous(memory_format=torch.channels_last)
+    bda = torch.eye(4).repeat(B, 1, 1)
+    bda[:, :2, :2] = torch.tensor([[0.96, -0.28], [0.28, 0.96]])
+    bda[1, 0, 0] *= -1
+    gout = torch.randn(B, Cc + Cl, H, H, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    res = []
+    for new in (True, False):
+        f = feats.cuda().requires_grad_(True)
+        x = cam.cuda().requires_grad_(True)
+        if new:
+            out = bev_warp_concat_pillars(x, bda.cuda(), f, c, table if table_form else None, 512, 512, V)
+        else:
+            full = pillar_scatter_from_table(f, c, table, B, 512, 512, V) if table_form else pillar_scatter(f, c, B, 512, 512, channels_last=True)
+            out = bev_warp_concat(x, bda.cuda(), F.interpolate(full, size=(H, H)))
+        assert out.is_contiguous(memory_format=torch.channels_last)
+        out.backward(gout)
+        res.append((out.detach(), x.grad, f.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][2].abs().sum()) > 0
+
+
+def test_model_forward_matches_the_full_canvas_path(mmt_lib):
+    """BEVDepthLiDAR with both modalities: the default (sampled scatter into the concat buffer) and
+    full_lidar_canvas=True (the reference's op sequence, models/bev_depth.py:181-192) give the same predictions, the same
+    camera half and -- after a backward -- the same parameter gradients; the third return value is the LiDAR half of the
+    fused input resp. the full-resolution canvas."""
+    from mm_training_amd.dp.configs import make_config
+    from mm_training_amd.dp.trainer import synthetic_batch
+    from mm_training_amd.models.bev_depth import BEVDepthLiDAR
+    cfg = make_config("tiny")
+    torch.manual_seed(0)
+    model = BEVDepthLiDAR(cfg["backbone_conf"], cfg["head_conf"], cfg["lidar_conf"], is_train_depth=True,
+                          fuse_layer_in_channels=cfg["fuse_layer_in_channels"]).cuda()
+    imgs, mats, pcs, _, _ = synthetic_batch(cfg, torch.device("cuda"), seed=2)
+    mats["bda_mat"][:, :2, :2] = torch.tensor([[0.96, -0.28], [0.28, 0.96]], device="cuda")
+    imgs = imgs / 255.0
+    model.eval()          # no dropout draw / BatchNorm batch statistics between the two passes; gradients still flow
+    outs = []
+    for full in (False, True):
+        model.full_lidar_canvas = full
+        model.zero_grad(set_to_none=True)
+        preds, depth, lidar_ret, cam_ret = model((imgs, pcs), mats)
+        loss = sum(v.float().square().mean() for p in preds for v in p[0].values())
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        outs.append((preds, lidar_ret, cam_ret, grads))
+    ny, nx = model.lidar_encoder.output_shape
+    H, W = outs[0][2].shape[-2:]
+    assert outs[0][1].shape[-2:] == (H, W) and outs[1][1].shape[-2:] == (ny, nx) and ny // H > 1
+    assert torch.equal(outs[0][1], outs[1][1][..., ::ny // H, ::nx // W])
+    # (the camera half sums its BEV cells with fp32 atomics: equal up to summation order between two passes)
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-6)
+    for pa, pb in zip(outs[0][0], outs[1][0]):
+        for k in pa[0]:
+            assert torch.allclose(pa[0][k], pb[0][k], rtol=1e-4, atol=1e-5), k
+    assert outs[0][3].keys() == outs[1][3].keys() and any("pillar_mlp" in k for k in outs[0][3])
+    for k in outs[0][3]:
+        assert torch.allclose(outs[0][3][k], outs[1][3][k], rtol=1e-3, atol=1e-6), k

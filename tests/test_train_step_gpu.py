@@ -55,8 +55,13 @@ def test_bevdepth_lidar_forward_contract(mmt_lib):
     preds, depth_pred, lidar_bev, cam_bev = model((imgs[:, :, :, :3] / 255.0, pcs), mats, None)
     assert len(preds) == 4 and set(preds[0][0]) == {"reg", "height", "dim", "rot", "vel", "heatmap"}
     assert preds[0][0]["heatmap"].shape == (2, 1, 128, 128)
-    assert cam_bev.shape == (2, 16, 128, 128) and lidar_bev.shape == (2, 8, 512, 512)
+    # default: only the pillar cells the nearest resize samples are scattered (straight into the fusion buffer), and the third
+    # return value -- bound and dropped by the reference, exps/mm_training_aim.py:268 -- is that LiDAR half
+    assert cam_bev.shape == (2, 16, 128, 128) and lidar_bev.shape == (2, 8, 128, 128)
     assert depth_pred.shape[1] == model.backbone.depth_channels
+    model.full_lidar_canvas = True          # the reference's op sequence and its full-resolution lidar_bev_ret
+    _, _, lidar_full, cam_bev2 = model((imgs[:, :, :, :3] / 255.0, pcs), mats, None)
+    assert lidar_full.shape == (2, 8, 512, 512) and cam_bev2.shape == cam_bev.shape
 
 
 @pytest.mark.parametrize("fused", [False, True])
