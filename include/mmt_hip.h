@@ -139,6 +139,32 @@ int mmt_frustum_geometry(int num_cams_total, int64_t frustum_points, const float
                          const float *voxel_size_host, int32_t *geom_xyz, float *xyz_out,
                          void *stream);
 
+/* Depth distribution (ABI 8).  Replaces layers/backbones/lss_fpn.py:423
+ *     depth = depth_feature[:, :self.depth_channels].softmax(1)
+ * and the oracle-depth overwrite of :427-438
+ *     fg_mask = torch.max(depth_oracle, dim=1).values > 0.0;  depth_updated[fg_mask] = depth_oracle_flattened[fg_mask]
+ * in pixel-major layout: one row of D values per pixel of the [B*N, fH, fW] feature maps -- the memory of a channels_last
+ * [B*N, D, fH, fW] tensor, which is how the depth net's last 1x1 convolution leaves its logits and how the fused lift-splat
+ * (MMT_LSS_PIXEL_MAJOR) reads the probabilities.
+ *   logits      [pixels] rows of D, logit_row_stride elements apart (>= D: the rows may sit inside the reference's
+ *               depth|context concatenation), fp32 or bf16 (logits_dtype; bf16 = the convolution ran under autocast)
+ *   probs       fp32 [pixels, D]: the plain softmax (max-subtracted, expf, IEEE division) -- what `is_return_depth` returns
+ *   oracle      nullable fp32 rows of D, oracle_row_stride apart: the depth labels (exps/mm_training_aim.py:259)
+ *   depth_used  nullable [pixels, D] fp32 or bf16 (used_dtype): the rows the lift multiplies the context with -- the label
+ *               row where it has a positive entry, the softmax elsewhere; required when oracle is given; without an oracle
+ *               it is a copy of probs in used_dtype (the bf16 operand of the bf16-storage lift-splat, row g1)
+ * backward: grad_logits[pix, :] = p * (g - <p, g>),  g = grad_probs + (foreground pixel ? 0 : grad_used); either gradient
+ * may be NULL (= zeros); grad_logits is [pixels, D] in logits_dtype.  16-byte accesses when D % 4 == 0 and every row is
+ * 16-byte aligned, element-wise otherwise; D <= 512. */
+#define MMT_DTYPE_F32 0
+#define MMT_DTYPE_BF16 1
+int mmt_depth_softmax_forward(int64_t pixels, int D, const void *logits, int64_t logit_row_stride, int logits_dtype,
+                              float *probs, const float *oracle, int64_t oracle_row_stride, void *depth_used, int used_dtype,
+                              void *stream);
+int mmt_depth_softmax_backward(int64_t pixels, int D, const float *probs, const float *grad_probs, const void *grad_used,
+                               int used_dtype, const float *oracle, int64_t oracle_row_stride, void *grad_logits,
+                               int logits_dtype, void *stream);
+
 /* Replaces the lift + layout step layers/backbones/lss_fpn.py:441-463:
  * feats[bn,d,h,w,c] = depth[bn,d,h,w] * context[bn,c,h,w]  (fp32), written directly in the
  * [B,N,D,fH,fW,C] channels-last layout voxel_pooling consumes (no permute+contiguous copy).

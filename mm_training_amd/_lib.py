@@ -45,6 +45,8 @@ SIGNATURES = {
     "mmt_lss_camera_form_supported": (_c_int, [_c_int] * 6),
     "mmt_quantize_geometry": (_c_int, [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     "mmt_frustum_geometry": (_c_int, [_c_int, _c_i64] + [_c_ptr] * 6 + [_c_ptr]),
+    "mmt_depth_softmax_forward": (_c_int, [_c_i64, _c_int, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr]),
+    "mmt_depth_softmax_backward": (_c_int, [_c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr]),
     "mmt_lift_features": (_c_int, [_c_int] * 4 + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_lift_features_backward": (_c_int, [_c_int] * 4 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_lift_splat_forward": (_c_int, [_c_int] * 8 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "mmt_pillar_scatter_nhwc_backward": (_c_int, [_c_i64] + [_c_int] * 4 + [_c_ptr] * 4 + [_c_ptr]),
 }
 
+DTYPE_F32, DTYPE_BF16 = 0, 1   # MMT_DTYPE_*
 # flags of mmt_voxel_pooling_forward_ex (include/mmt_hip.h)
 VP_ALGO_AUTO = 0
 VP_ALGO_ROW_ATOMIC = 1

@@ -16,7 +16,7 @@ import os
 import torch
 from torch import nn
 
-from ...ops.bev_geometry import (camera_form_supported, frustum_axes, frustum_geometry, lift_features, lift_splat,
+from ...ops.bev_geometry import (camera_form_supported, depth_softmax, frustum_axes, frustum_geometry, lift_features, lift_splat,
                                  lift_splat_camera, new_column_summary, new_exclusive_cache)
 from ...ops.bn_relu import ConvBNAct, bn_act
 from ...ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling, voxel_pooling_bf16, voxel_pooling_planned
@@ -99,11 +99,17 @@ class DepthNet(nn.Module):
             DeformConv2dPack(mid_channels, mid_channels, kernel_size=3, padding=1, groups=4),
             nn.Conv2d(mid_channels, depth_channels, 1))
 
-    def forward(self, x, mats_dict=None):
+    def forward_parts(self, x, mats_dict=None):
+        """(depth logits [BN, D, fH, fW], context [BN, C, fH, fW]): the two halves of forward()'s concatenation.  LSSFPN slices
+        the concatenation apart again two lines later (lss_fpn.py:423, :441-443), so the mirror asks for the halves and the
+        cat (two copies, and two slice-gradient copies in backward) never runs in the step."""
         x = self.reduce_conv(x)
         context = self.context_conv(x)
         depth = self.depth_conv(self.depth_se(x))
-        return torch.cat([depth, context], 1)
+        return depth, context
+
+    def forward(self, x, mats_dict=None):
+        return torch.cat(self.forward_parts(x, mats_dict), 1)
 
 
 class LSSFPN(nn.Module):
@@ -285,22 +291,31 @@ class LSSFPN(nn.Module):
         batch_size, num_sweeps, num_cams = sweep_imgs.shape[:3]
         img_feats = self.get_cam_feats(sweep_imgs)
         source_features = img_feats[:, 0, ...]
-        depth_feature = self.depth_net(source_features.reshape(batch_size * num_cams, *source_features.shape[2:]), mats_dict)
-        depth = depth_feature[:, :self.depth_channels].softmax(1)
+        feats_in = source_features.reshape(batch_size * num_cams, *source_features.shape[2:])
+        D, C = self.depth_channels, self.output_channels
+        if hasattr(self.depth_net, "forward_parts"):
+            depth_logits, context = self.depth_net.forward_parts(feats_in, mats_dict)
+        else:       # any depth net with the reference's output: depth | context on the channel axis
+            depth_feature = self.depth_net(feats_in, mats_dict)
+            depth_logits, context = depth_feature[:, :D], depth_feature[:, D:D + C]
+        # :423 + :427-438 as ONE launch, pixel-major (ops/bev_geometry.py::depth_softmax): `depth` is the plain softmax taken
+        # BEFORE the per-camera un-flip (reference quirk, :423-425), `depth_used` what the lift multiplies with -- the oracle's
+        # rows on foreground pixels (fg_mask = max over bins > 0), the softmax elsewhere.  bf16 storage (row g1): the fused
+        # kernels' bf16 operand comes out of the same launch.
+        used_bf16 = self.hot_path_dtype == "bf16" and self.fused_lift_splat
+        if D <= 512 and os.environ.get("MMT_ATEN_SOFTMAX", "0") != "1":
+            depth, depth_used = depth_softmax(depth_logits, depth_oracle, torch.bfloat16 if used_bf16 else torch.float32)
+        else:       # (more bins than the kernel takes; or the A/B switch of bench.py --aten-softmax)
+            depth = depth_logits.softmax(1)
+            depth_used = depth
+            if depth_oracle is not None:
+                fg_mask = (torch.max(depth_oracle, dim=1, keepdim=True).values > 0.0)
+                depth_used = torch.where(fg_mask, depth_oracle.to(depth.dtype), depth)
         flipped = mats_dict.get('flipped', None) if isinstance(mats_dict, dict) else None
         if flipped is not None:
-            fl = torch.as_tensor(flipped, device=depth_feature.device).view(-1, 1, 1, 1).bool()
-            depth_feature = torch.where(fl, depth_feature.flip(-1), depth_feature)      # hflip per camera (:425)
-        if depth_oracle is not None:   # :427-438
-            b, c, h, w = depth.shape
-            fg_mask = (torch.max(depth_oracle, dim=1).values > 0.0).view(-1)
-            depth_flat = depth.permute(0, 2, 3, 1).contiguous().view(-1, c)
-            oracle_flat = depth_oracle.permute(0, 2, 3, 1).contiguous().view(-1, c)
-            depth_flat = torch.where(fg_mask.view(-1, 1), oracle_flat, depth_flat)
-            depth_used = depth_flat.view(b, h, w, c).permute(0, 3, 1, 2)
-        else:
-            depth_used = depth
-        context = depth_feature[:, self.depth_channels:self.depth_channels + self.output_channels]
+            # hflip per camera (:425) -- after the softmax, so only the context half of depth_feature is still read
+            fl = torch.as_tensor(flipped, device=context.device).view(-1, 1, 1, 1).bool()
+            context = torch.where(fl, context.flip(-1), context)
         # SURVEY section 8 row f3 (cached sort): geometry, quantisation and the sort of the points by
         # BEV cell depend only on the calibration (BDA is not applied here, lss_fpn.py:355-360).  A data
         # pipeline that knows its calibration passes a hashable host-side mats_dict['calibration_id']
@@ -337,7 +352,7 @@ class LSSFPN(nn.Module):
             feature_map = voxel_pooling_planned(plan, feats.view(batch_size, -1, feats.shape[-1]))
         elif fused_kind is not None:
             bf16 = self.hot_path_dtype == "bf16"
-            dep_in, ctx_in = (depth_used.bfloat16(), context.bfloat16()) if bf16 else (depth_used, context)
+            dep_in, ctx_in = (depth_used.bfloat16(), context.bfloat16()) if bf16 else (depth_used.float(), context.float())
             if fused_kind == "camera":
                 col_bwd, stats = self._use_column_backward(
                     lambda: self.get_geometry_voxels(None, None, pixel_major=True, combine=combine), calib_id, context.device)

@@ -136,6 +136,88 @@ def lift_features(depth, context, storage_dtype=torch.float32):
     return LiftFeatures.apply(depth.contiguous(), context.contiguous())
 
 
+def _pixel_rows(t, D):
+    """(tensor, row stride in elements) with the D channel values of every pixel of t [BN, D, fH, fW] contiguous in memory and
+    the pixels' rows equally spaced in (bn, h, w) order -- true for a channels_last tensor and for a channel slice of one;
+    anything else is brought to channels_last first (one copy)."""
+    BN, _, fH, fW = t.shape
+    R = t.stride(3)
+    if not (t.stride(1) == 1 and R >= D and t.stride(2) == fW * R and t.stride(0) == fH * fW * R):
+        t = t.contiguous(memory_format=torch.channels_last)
+        if t.stride(1) != 1:                  # (a size-1 dimension can leave contiguous() with arbitrary strides)
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        R = D
+    return t, R
+
+
+class DepthSoftmax(Function):
+    """depth = logits.softmax(1) (lss_fpn.py:423) and the oracle-depth overwrite (:427-438) as one launch in the layout the fused
+    lift-splat reads (mmt_depth_softmax_forward / _backward).  Returns (probs, depth_used): probs = the plain softmax, a
+    channels_last [BN, D, fH, fW] fp32 tensor (what is_return_depth hands to the depth loss); depth_used = the tensor the
+    lift multiplies the context with -- None when it would equal probs (no oracle, fp32)."""
+
+    @staticmethod
+    def forward(ctx, logits, oracle, used_bf16):
+        if not logits.is_cuda:
+            raise RuntimeError("depth logits must be a CUDAtensor ")
+        if logits.dtype not in (torch.float32, torch.bfloat16) or logits.dim() != 4:
+            raise RuntimeError(f"depth logits must be a float32 / bfloat16 [B*N, D, fH, fW] tensor (found {logits.dtype})")
+        BN, D, fH, fW = logits.shape
+        logits, R = _pixel_rows(logits, D)
+        o_ptr, o_R = 0, 0
+        if oracle is not None:
+            if tuple(oracle.shape) != (BN, D, fH, fW):
+                raise RuntimeError("depth_softmax: the oracle must have the shape of the depth logits")
+            oracle, o_R = _pixel_rows(oracle.detach().float(), D)
+            o_ptr = oracle.data_ptr()
+        probs = torch.empty((BN, fH, fW, D), dtype=torch.float32, device=logits.device)
+        used = None
+        if oracle is not None or used_bf16:
+            used = torch.empty((BN, fH, fW, D), dtype=torch.bfloat16 if used_bf16 else torch.float32, device=logits.device)
+        lt = _lib.DTYPE_BF16 if logits.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        ut = _lib.DTYPE_BF16 if used_bf16 else _lib.DTYPE_F32
+        with torch.cuda.device(logits.device):
+            _lib.timed_call("softmax", "mmt_depth_softmax_forward", BN * fH * fW, D, logits.data_ptr(), R, lt, probs.data_ptr(),
+                            o_ptr, o_R, used.data_ptr() if used is not None else 0, ut, _stream())
+        ctx.save_for_backward(probs, *([oracle] if oracle is not None else []))
+        ctx.meta = (BN, D, fH, fW, lt, ut, o_R, logits.dtype)
+        return probs.permute(0, 3, 1, 2), (used.permute(0, 3, 1, 2) if used is not None else None)
+
+    @staticmethod
+    def backward(ctx, grad_probs, grad_used):
+        probs, *rest = ctx.saved_tensors
+        BN, D, fH, fW, lt, ut, o_R, ldtype = ctx.meta
+
+        def rows(g, dtype):
+            if g is None:
+                return None
+            if g.dtype != dtype:
+                g = g.to(dtype)
+            return g if g.is_contiguous(memory_format=torch.channels_last) and g.stride(1) == 1 else _pixel_rows(g, D)[0]
+
+        gp = rows(grad_probs, torch.float32)
+        gu = rows(grad_used, torch.bfloat16 if ut == _lib.DTYPE_BF16 else torch.float32)
+        if gp is not None and gp.stride(3) != D:
+            gp = gp.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        if gu is not None and gu.stride(3) != D:
+            gu = gu.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        grad_logits = torch.empty((BN, fH, fW, D), dtype=ldtype, device=probs.device)
+        with torch.cuda.device(probs.device):
+            _lib.timed_call("softmax_backward", "mmt_depth_softmax_backward", BN * fH * fW, D, probs.data_ptr(),
+                            gp.data_ptr() if gp is not None else 0, gu.data_ptr() if gu is not None else 0, ut,
+                            rest[0].data_ptr() if rest else 0, o_R, grad_logits.data_ptr(), lt, _stream())
+        return grad_logits.permute(0, 3, 1, 2), None, None
+
+
+def depth_softmax(logits, oracle=None, used_dtype=torch.float32):
+    """logits [B*N, D, fH, fW] (fp32 or bf16; free when channels_last or a channel slice of a channels_last tensor)
+    -> (probs, depth_used), both channels_last [B*N, D, fH, fW]: probs = softmax(logits, 1) in fp32; depth_used = probs with the
+    rows of foreground pixels (torch.max(oracle, 1).values > 0) replaced by the oracle's, in `used_dtype` (fp32 or bf16).
+    Without an oracle and with used_dtype fp32, depth_used IS probs."""
+    probs, used = DepthSoftmax.apply(logits, oracle, used_dtype == torch.bfloat16)
+    return probs, (probs if used is None else used)
+
+
 def _lss_flags(pixel_major, column_backward=False):
     return ((_lib.LSS_PIXEL_MAJOR if pixel_major else 0) | (_lib.LSS_COLUMN_BACKWARD if column_backward else 0)
             | (_lib.LSS_TILE_KERNELS if os.environ.get("MMT_LIFT_SPLAT_TILES", "0") == "1" else 0))
