@@ -88,6 +88,14 @@ def parse(argv=None):
     ap.add_argument("--calibration-ids", action="store_true",
                     help="give every synthetic batch a mats_dict['calibration_id'] (a loader that knows its rig): camera matrices, "
                          "the geometry's column summary and the backward-kernel choice are then cached per calibration")
+    ap.add_argument("--full-lidar-canvas", action="store_true",
+                    help="fusion configs: the reference's op sequence for the LiDAR half (full-resolution pillar canvas, nearest resize, "
+                         "slice copy) instead of scattering only the sampled cells straight into the camera|LiDAR buffer")
+    ap.add_argument("--aten-softmax", action="store_true",
+                    help="camera branch: ATen's softmax (+ torch.where for the depth oracle) instead of mmt_depth_softmax_* (A/B)")
+    ap.add_argument("--no-augment", action="store_true", help="skip augment_images (the reference's training_step always runs it)")
+    ap.add_argument("--no-depth-oracle", action="store_true",
+                    help="do not hand the depth labels to the model as its depth oracle (the reference does when use_depth_loss is set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
     ap.add_argument("--hotpath-leg", action="store_true",
@@ -108,6 +116,27 @@ def _free_port():
     return port
 
 
+def _visible_gpus():
+    """GPUs this launch can hand to ranks, WITHOUT initialising the GPU in the launcher (it must stay able to start rank
+    processes): the KFD topology lists one node per agent, GPUs are those with a non-zero simd_count; ROCR / HIP visibility
+    masks narrow it.  Falls back to "at least n" (= a real multi-GPU launch) when the topology cannot be read."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        count = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        count += 1
+        return count if count > 0 else 1 << 30
+    except OSError:
+        return 1 << 30
+
+
 def spawn_ranks(n, argv):
     """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and wait.
     The parent has made no GPU call (torch is not even imported yet); nothing is re-exec'd.  Rank 0's stdout is
@@ -115,7 +144,12 @@ def spawn_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("MASTER_PORT", str(_free_port()))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # HSA_ENABLE_IPC_MODE_LEGACY is NOT touched for a real multi-GPU launch: the image exports the value its host driver needs
+    # (dmabuf IPC, which RCCL's intra-node P2P rides on) and the ranks inherit it.  Only the rehearsal in which several ranks
+    # share ONE card (world > visible devices: gloo, see choose_backend) pins it to 0, because those ranks exchange CUDA
+    # tensors' IPC handles on one device (tests/test_bench_ranks_gpu.py) -- DESIGN section 6.
+    if n > _visible_gpus():
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
     procs = []
     for r in range(n):
@@ -219,7 +253,45 @@ def init_dist(n_gpus, device="cuda"):
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        if world <= ndev and "MMT_DIST_BACKEND" not in os.environ:
+            # one GPU per rank: the gradient all-reduce must ride RCCL (xGMI), never silently a host-staged backend
+            assert dist.get_backend() == "nccl", f"world {world} on {ndev} GPUs initialised backend {dist.get_backend()!r}, expected RCCL"
     return rank, local_rank, world
+
+
+def distributed_info(world, local_rank, ts=None):
+    """What the N > 1 path actually ran on, for the bench line (every rank calls this: it gathers): backend, world, each
+    rank's device and PCI bus id, the RCCL version, and DistributedDataParallel's bucket layout / gradient bytes."""
+    info = {"world": world, "backend": dist.get_backend() if world > 1 and dist.is_initialized() else None}
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": int(os.environ.get("RANK", "0")), "device": f"cuda:{local_rank}", "name": props.name,
+            "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        info["ranks"] = gathered
+        info["ranks_share_a_device"] = len({r["pci_bus_id"] for r in gathered}) < world
+    else:
+        info["ranks"] = [mine]
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        info["rccl_version"] = None
+    info["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if ts is not None:
+        params = [p for n, p in ts.model.named_parameters() if p.requires_grad and ".context_se." not in n]
+        info["gradient_bytes"] = int(sum(p.numel() * p.element_size() for p in params))
+        ddp = ts.net if isinstance(ts.net, torch.nn.parallel.DistributedDataParallel) else None
+        info["ddp"] = None
+        if ddp is not None:
+            cap = int(ddp.bucket_bytes_cap)
+            info["ddp"] = {"bucket_cap_mb": cap / (1024 * 1024), "static_graph": bool(getattr(ddp, "static_graph", False)),
+                           "gradient_as_bucket_view": bool(ddp.gradient_as_bucket_view), "broadcast_buffers": bool(ddp.broadcast_buffers),
+                           "find_unused_parameters": bool(ddp.find_unused_parameters),
+                           "buckets_estimate": max(1, -(-info["gradient_bytes"] // cap)),
+                           "ignored_parameters": sorted(getattr(ddp, "parameters_to_ignore", []))[:4]}
+    return info
 
 
 def barrier(world, device="cuda"):
@@ -265,10 +337,16 @@ def lift_splat_bytes(BP, K, C, B, BN_HW, ny, nx, feat_bytes=4, pos_memo=False, c
     return fwd, bwd, l2_fwd, l2_bwd
 
 
-def lidar_bytes(F, total_points, M, nf, C, B, ny, nx, voxels_T=0):
+def lidar_bytes(F, total_points, M, nf, C, B, ny, nx, voxels_T=0, sampled=None):
     """voxelize+mean: 4*F*sum(Ni) points + 16*M coors + 4*M num_points + 4*nf*M means (+ 4*T*F*M when the padded voxel
-    tensor is materialised); scatter: 4*C*M + 16*M + 4*C*B*ny*nx; scatter backward: 8*C*M + 16*M."""
+    tensor is materialised); scatter: 4*C*M + 16*M + 4*C*B*ny*nx; scatter backward: 8*C*M + 16*M.
+    sampled = (M_s, oh, ow): the scatter at the fusion layer's resolution (round 4) -- only the M_s voxels on sampled cells
+    are read, the output is [B, oh, ow, C] and the per-cell lookup is one 8-byte table entry per OUTPUT cell:
+    scatter 4*C*M_s + 8*B*oh*ow + 4*C*B*oh*ow; backward 16*M coors + 4*C*M_s gradient rows + 4*C*M rows written."""
     vox = 4 * F * total_points + 20 * M + 4 * nf * M + 4 * voxels_T * F * M
+    if sampled is not None:
+        ms, oh, ow = sampled
+        return vox, 4 * C * ms + 8 * B * oh * ow + 4 * C * B * oh * ow, 16 * M + 4 * C * ms + 4 * C * M
     scat = 4 * C * M + 16 * M + 4 * C * B * ny * nx
     scat_bwd = 8 * C * M + 16 * M
     return vox, scat, scat_bwd
@@ -278,13 +356,15 @@ def pmc_traffic(config, kernels):
     """HBM bytes per launch from a committed rocprofv3 --pmc summary OF THIS CONFIGURATION (separate FETCH_SIZE /
     WRITE_SIZE passes with the gfx950 correction; tools/collect_profiles.sh writes profiles/r02_pmc_<config>.json).
     PMC collection cannot run inside this process; None when the shape has no summary."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{config}.json")
+        if not os.path.exists(path):
+            continue                  # an older round's summary stands in only while this round has none for the configuration
         try:
             k = json.load(open(path))["kernels"]
             return float(sum(k[name]["traffic_bytes"] for name in kernels))
         except Exception:
-            continue
+            return None               # the newest summary lacks the kernel: it was not measured, not "as in an older round"
     return None
 
 
@@ -550,7 +630,17 @@ def train_main(args, rank, local_rank, world):
     dtype = args.dtype or cfg["hot_path_dtype"]
     cfg["hot_path_dtype"] = dtype
     torch.manual_seed(0)
+    import numpy as np
+    np.random.seed(0)            # augment_images draws its per-camera flags from numpy's global generator (like the reference)
+    if args.aten_softmax:
+        os.environ["MMT_ATEN_SOFTMAX"] = "1"
+    if args.no_augment:
+        cfg["augment_images"] = False
+    if args.no_depth_oracle:
+        cfg["use_depth_loss"] = False
     ts = TrainStep(cfg, dev, world_size=world)
+    if args.full_lidar_canvas and cfg["use_lidar"]:
+        ts.model.full_lidar_canvas = True
     fused = False
     if cfg["use_cam"]:
         if args.unfused or args.cached_plan:
@@ -584,6 +674,7 @@ def train_main(args, rank, local_rank, world):
     elapsed = time.perf_counter() - t0
     timing, _lib.TIMING = _lib.TIMING, None
     elapsed = max_over_ranks(elapsed, world)
+    dinfo = distributed_info(world, local_rank, ts)          # (gathers: every rank)
     if rank != 0:
         barrier(world)          # rank 0 adds its roofline legs below; everybody leaves together
         return
@@ -599,7 +690,10 @@ def train_main(args, rank, local_rank, world):
                    "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune),
                    "miopen_shipped_find_db": bool(db_cfg), "fused_lift_splat": fused, "cached_plan": bool(args.cached_plan),
                    "dense_nets_dtype": "bf16 autocast" if ts.amp_dtype is not None else "f32",
-                   "hot_path_storage_dtype": dtype},
+                   "hot_path_storage_dtype": dtype,
+                   # exps/mm_training_aim.py:258-259: both run inside every timed step
+                   "augment_images": bool(ts.augment and cfg["use_cam"]), "depth_oracle": bool(ts.pass_depth_labels and cfg["use_cam"]),
+                   "distributed": dinfo},
     }
     fb = 2 if dtype == "bf16" else 4
     geom = vn = None
@@ -652,7 +746,8 @@ def train_main(args, rank, local_rank, world):
                                              pmc_traffic(args.config, (key_f, "lss_zero_fill")), l2f, note)
             atomic_bytes = None
             try:
-                atomic_bytes = float(json.load(open(os.path.join(ROOT, "profiles", f"r03_pmc_{args.config}.json")))["kernels"][key_f]["atomic_bytes"])
+                newest = [r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_{args.config}.json"))][0]
+                atomic_bytes = float(json.load(open(os.path.join(ROOT, "profiles", f"{newest}_pmc_{args.config}.json")))["kernels"][key_f]["atomic_bytes"])
             except Exception:
                 pass
             if atomic_bytes:
@@ -675,29 +770,54 @@ def train_main(args, rank, local_rank, world):
                                                  pmc_traffic(args.config + "_unfused", ("vp_fwd_seg_gather",)))
             res["roofline_backward"] = roofline_entry("vp_bwd_prepare + vp_bwd_rows_vec4 (voxel_pooling backward, inside the training step)",
                                                       bbytes, bwd_ms, pmc_traffic(args.config + "_unfused", ("vp_bwd_prepare", "vp_bwd_rows_vec4")))
+    if cfg["use_cam"] and timing.get("softmax"):
+        # lss_fpn.py:423 (+ :427-438): logits read once, probabilities written once (+ the oracle rows read and the depth the
+        # lift uses written when the labels are passed in / the operand is bf16); backward: probabilities + the two consumers'
+        # gradients (+ the oracle rows for the foreground test) read, the logit gradient written
+        pix_d = BP                                     # pixels * D
+        lb = 2 if ts.amp_dtype is not None else 4      # bytes per logit (bf16 under autocast)
+        has_oracle, used_b = bool(ts.pass_depth_labels), fb
+        separate_used = has_oracle or dtype == "bf16"
+        sm_f = lb * pix_d + 4 * pix_d + (4 * pix_d if has_oracle else 0) + (used_b * pix_d if separate_used else 0)
+        sm_b = 4 * pix_d + 4 * pix_d + (used_b * pix_d if separate_used else 0) + (4 * pix_d if has_oracle else 0) + lb * pix_d
+        t_f, t_b = _lib.mean_ms(timing["softmax"]), _lib.mean_ms(timing["softmax_backward"])
+        res["roofline_softmax"] = roofline_entry("depth_softmax_fwd (depth distribution + oracle overwrite, pixel-major; lss_fpn.py:423-438)", sm_f, t_f,
+                                                 pmc_traffic(args.config, ("depth_softmax_fwd",)))
+        res["roofline_softmax"]["backward"] = roofline_entry("depth_softmax_bwd", sm_b, t_b, pmc_traffic(args.config, ("depth_softmax_bwd",)))
     if cfg["use_lidar"] and timing.get("voxelize") and timing.get("scatter"):
         enc = ts.model.lidar_encoder
         from mm_training_amd.lidar import hard_voxelize_mean_batch
         with torch.no_grad():
-            _, _, _, cnt, _ = hard_voxelize_mean_batch([p.float() for p in batches[0][2]], enc.voxel_size, enc.point_cloud_range,
-                                                        enc.max_num_points, enc.max_voxels, enc.num_features, materialize_voxels=False)
+            _, _, co, cnt, _ = hard_voxelize_mean_batch([p.float() for p in batches[0][2]], enc.voxel_size, enc.point_cloud_range,
+                                                         enc.max_num_points, enc.max_voxels, enc.num_features, materialize_voxels=False)
         M = int(cnt.sum().item())
         total_pts = sum(int(p.shape[0]) for p in batches[0][2])
         ny_l, nx_l = enc.output_shape
-        vox_b, scat_b, scat_bwd_b = lidar_bytes(cfg["point_features"], total_pts, M, enc.num_features, enc.in_channels, B, ny_l, nx_l)
+        sampled = None
+        if cfg["use_cam"] and not ts.model.full_lidar_canvas and vn is not None and ny_l % vn[1] == 0 and nx_l % vn[0] == 0:
+            sy, sx = ny_l // vn[1], nx_l // vn[0]
+            m_s = int(((co[:, 0] >= 0) & (co[:, 2] % sy == 0) & (co[:, 3] % sx == 0)).sum().item())
+            sampled = (m_s, vn[1], vn[0])
+        vox_b, scat_b, scat_bwd_b = lidar_bytes(cfg["point_features"], total_pts, M, enc.num_features, enc.in_channels, B, ny_l, nx_l,
+                                                sampled=sampled)
         t_vox, t_scat = _lib.mean_ms(timing["voxelize"]), _lib.mean_ms(timing["scatter"])
-        r = roofline_entry("vox_link + vox_heads + vox_emit (voxelize + mean) and scatter_write_nhwc_table (pillar scatter straight from the "
-                           "voxelizer's table), inside the training step", vox_b + scat_b, t_vox + t_scat,
-                           pmc_traffic(args.config, ("vox_link", "vox_heads", "vox_emit", "scatter_write_nhwc_table_kernel")))
+        k_scat = "scatter_write_strided_table_kernel" if sampled else "scatter_write_nhwc_table_kernel"
+        r = roofline_entry("vox_link + vox_heads + vox_emit (voxelize + mean) and " +
+                           ("scatter_write_strided_table (only the pillar cells the nearest resize samples, straight from the voxelizer's table "
+                            "into the camera|LiDAR buffer)" if sampled else
+                            "scatter_write_nhwc_table (pillar scatter straight from the voxelizer's table)") + ", inside the training step",
+                           vox_b + scat_b, t_vox + t_scat, pmc_traffic(args.config, ("vox_link", "vox_heads", "vox_emit", k_scat)))
+        if sampled:
+            r["sampled_scatter"] = {"stride": [ny_l // vn[1], nx_l // vn[0]], "voxels_on_sampled_cells": sampled[0], "output": [B, sampled[1], sampled[2], enc.in_channels]}
         r["parts"] = {"voxelize_mean": {"algorithmic_bytes": vox_b, "avg_ms": t_vox, "GBps": vox_b / t_vox / 1e6,
                                         "note": "bound by one scattered device-scope atomic per point (~20 G/s), not by HBM"},
                       "pillar_scatter": {"algorithmic_bytes": scat_b, "avg_ms": t_scat, "GBps": scat_b / t_scat / 1e6}}
         r["voxels"] = M
         res["roofline_lidar"] = r
         if timing.get("scatter_backward"):
-            res["roofline_lidar_backward"] = roofline_entry("scatter_backward_nhwc_unique_kernel (pillar scatter backward)", scat_bwd_b,
-                                                            _lib.mean_ms(timing["scatter_backward"]),
-                                                            pmc_traffic(args.config, ("scatter_backward_nhwc_unique_kernel",)))
+            k_sb = "scatter_backward_strided_kernel" if sampled else "scatter_backward_nhwc_unique_kernel"
+            res["roofline_lidar_backward"] = roofline_entry(f"{k_sb} (pillar scatter backward)", scat_bwd_b,
+                                                            _lib.mean_ms(timing["scatter_backward"]), pmc_traffic(args.config, (k_sb,)))
     if cfg["use_cam"] and not args.no_hotpath_leg and (world == 1 or args.hotpath_leg):
         # the drop-in op at the same shape and geometry, right after the timed steps: the like-for-like figure
         # beside cpu_baseline and the BASELINE metric's "voxel_pooling HBM GB/s"

@@ -596,6 +596,33 @@ int mmt_depth_labels(int batch_size, int num_cams, int point_features, int max_p
                      const float *intrinsics, const float *bda_inv, int32_t *workspace,
                      int64_t workspace_elems, int32_t *depth_bin, float *onehot, void *stream);
 
+/* The same with the per-camera horizontal flip of augment_images (exps/mm_training_aim.py:89-112) folded into the label
+ * write (ABI 8): flipped = device bytes [B*N], non-zero = this camera's label map is written mirrored along w (what
+ * kornia.hflip of the [D, fH, fW] label image gives); NULL = mmt_depth_labels. */
+int mmt_depth_labels_flipped(int batch_size, int num_cams, int point_features, int max_points, int img_h,
+                             int img_w, int downsample, float d_lo, float d_step, int depth_channels,
+                             const float *points, const int32_t *point_offsets, const float *extrinsics,
+                             const float *intrinsics, const float *bda_inv, int32_t *workspace,
+                             int64_t workspace_elems, int32_t *depth_bin, float *onehot, const uint8_t *flipped, void *stream);
+
+/* Image augmentation of the training step (ABI 8): exps/mm_training_aim.py:89-112
+ * (augment_images: per camera, with probability 1/2, kornia hflip of the image and of its depth-label map -- the reference
+ * stacks per-image Python lists) and :510-512 (normalize_images: torchvision Normalize((0.485, 0.456, 0.406), (0.229, 0.224,
+ * 0.225)) of sweep_imgs[:, :, :, :3] / 255).  The flags are one device byte per camera, drawn on the host like the reference
+ * draws them (np.random.uniform(size = b*s*n) > 0.5) and also handed to LSSFPN as mats['flipped'].
+ *   mmt_hflip: out[i, r, w, :] = in[i, r, flipped[i / group] ? W-1-w : w, :] for a contiguous fp32 [n, rows, W, elems]
+ *     tensor (label maps [B*N, fH, fW, D]: group 1; NCHW images viewed as [B*N*3, H, W, 1]: group 3).  Out of place.
+ *   mmt_normalize_flip_images: out[i, c, h, w] = (images[i, c, h, ws] * scale - mean[c]) / std[c], ws = W-1-w for a flipped
+ *     camera, c < 3 of channels_in >= 3 -- one pass instead of three element-wise kernels, a flip and a select; with
+ *     channels_last the result is stored as [n, H, W, 3] (the memory of a channels_last [n, 3, H, W] tensor, what the first
+ *     convolution reads).  `scale` multiplies (ATen evaluates `/ 255.` as a multiplication by the fp32 reciprocal on the GPU);
+ *     mean / std: 3 host floats each; flipped nullable. */
+int mmt_hflip(int64_t n, int group, int rows, int W, int elems, const float *in, const uint8_t *flipped, float *out,
+              void *stream);
+int mmt_normalize_flip_images(int64_t n_images, int channels_in, int H, int W, const float *images, float scale,
+                              const float *mean_host, const float *std_host, const uint8_t *flipped, float *out,
+                              int channels_last, void *stream);
+
 /* CenterPoint training targets: replaces BEVDepthHead.get_targets_single,
  * layers/heads/bev_depth_head.py:113-254 (Python loop over tasks and boxes around mmdet3d's
  * gaussian_radius / draw_heatmap_gaussian).  HOST arrays: class_begin / class_count [num_tasks]

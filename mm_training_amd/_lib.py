@@ -58,6 +58,9 @@ SIGNATURES = {
     "mmt_voxel_pooling_forward_planned": (_c_int, [_c_int] * 5 + [_c_ptr] + [_c_int] * 3 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "mmt_depth_labels_workspace_elems": (_c_i64, [_c_int] * 5),
     "mmt_depth_labels": (_c_int, [_c_int] * 7 + [ctypes.c_float, ctypes.c_float, _c_int] + [_c_ptr] * 6 + [_c_i64, _c_ptr, _c_ptr, _c_ptr]),
+    "mmt_depth_labels_flipped": (_c_int, [_c_int] * 7 + [ctypes.c_float, ctypes.c_float, _c_int] + [_c_ptr] * 6 + [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    "mmt_hflip": (_c_int, [_c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    "mmt_normalize_flip_images": (_c_int, [_c_i64, _c_int, _c_int, _c_int, _c_ptr, ctypes.c_float, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr]),
     "mmt_centerpoint_targets": (_c_int, [_c_int, _c_int, _c_ptr, _c_ptr] + [_c_int] * 4 + [ctypes.c_float] * 4 + [_c_int, ctypes.c_float, _c_int, _c_int] + [_c_ptr] * 7 + [_c_ptr]),
     "mmt_bev_warp_affine": (_c_int, [_c_int] * 4 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "mmt_bev_warp_affine_backward": (_c_int, [_c_int] * 4 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),

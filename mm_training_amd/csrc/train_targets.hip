@@ -29,6 +29,7 @@ struct DepthArgs {
     uint32_t *cell_min;         // [B*N, fH*fW] float bits
     int32_t *bin;               // [B*N*fH*fW] or NULL
     float *onehot;              // [B*N*fH*fW, D] or NULL
+    const uint8_t *flipped;     // [B*N] or NULL: cameras whose label map is written mirrored along w (augment_images, :89-112)
 };
 
 __global__ __launch_bounds__(kBlock) void depth_fill_kernel(uint32_t *cell_min, int64_t n) {
@@ -78,6 +79,15 @@ __global__ __launch_bounds__(kBlock) void depth_project_kernel(DepthArgs a) {
     }
 }
 
+// cell of the projected (unflipped) map that lands in OUTPUT cell `cell`: the same one, or its mirror image along w for a
+// camera augment_images flipped (exps/mm_training_aim.py:105-110: hflip of the [D, fH, fW] label image of that camera)
+__device__ __forceinline__ int64_t source_cell(const DepthArgs &a, int64_t cell) {
+    if (a.flipped == nullptr) return cell;
+    const int64_t row = cell / a.fW;                 // (camera, h)
+    const int w = (int)(cell - row * a.fW);
+    return a.flipped[row / a.fH] ? row * a.fW + (a.fW - 1 - w) : cell;
+}
+
 __global__ __launch_bounds__(kBlock) void depth_bins_kernel(DepthArgs a, int64_t ncells) {
     const int D = a.D;
     if (a.onehot) {
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void depth_bins_kernel(DepthArgs a, int64_t
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
             const int64_t cell = i / D;
             const int d = (int)(i - cell * D);
-            const float depth = __uint_as_float(a.cell_min[cell]);
+            const float depth = __uint_as_float(a.cell_min[source_cell(a, cell)]);
             // :207-212: (d - (lo - step)) / step, kept if in [0, D), else 0; .long() truncates
             const float g = __fdiv_rn(__fsub_rn(depth, __fsub_rn(a.d_lo, a.d_step)), a.d_step);
             const int bin = (g < (float)D && g >= 0.0f) ? (int)g : 0;
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void depth_bins_kernel(DepthArgs a, int64_t
         }
     } else {
         for (int64_t cell = (int64_t)blockIdx.x * kBlock + threadIdx.x; cell < ncells; cell += (int64_t)gridDim.x * kBlock) {
-            const float depth = __uint_as_float(a.cell_min[cell]);
+            const float depth = __uint_as_float(a.cell_min[source_cell(a, cell)]);
             const float g = __fdiv_rn(__fsub_rn(depth, __fsub_rn(a.d_lo, a.d_step)), a.d_step);
             a.bin[cell] = (g < (float)D && g >= 0.0f) ? (int)g : 0;
         }
@@ -113,6 +123,15 @@ extern "C" int mmt_depth_labels(int B, int num_cams, int F, int max_points, int 
                                 const int32_t *point_offsets, const float *extrinsics, const float *intrinsics,
                                 const float *bda_inv, int32_t *workspace, int64_t workspace_elems,
                                 int32_t *depth_bin, float *onehot, void *stream) {
+    return mmt_depth_labels_flipped(B, num_cams, F, max_points, H, W, downsample, d_lo, d_step, D, points, point_offsets, extrinsics,
+                                    intrinsics, bda_inv, workspace, workspace_elems, depth_bin, onehot, nullptr, stream);
+}
+
+extern "C" int mmt_depth_labels_flipped(int B, int num_cams, int F, int max_points, int H, int W, int downsample,
+                                        float d_lo, float d_step, int D, const float *points,
+                                        const int32_t *point_offsets, const float *extrinsics, const float *intrinsics,
+                                        const float *bda_inv, int32_t *workspace, int64_t workspace_elems,
+                                        int32_t *depth_bin, float *onehot, const uint8_t *flipped, void *stream) {
     MMT_REQUIRE_PTR(points);
     MMT_REQUIRE_PTR(point_offsets);
     MMT_REQUIRE_PTR(extrinsics);
@@ -136,7 +155,7 @@ extern "C" int mmt_depth_labels(int B, int num_cams, int F, int max_points, int 
     a.B = B; a.N = num_cams; a.F = F; a.H = H; a.W = W; a.ds = downsample; a.fH = fH; a.fW = fW; a.D = D;
     a.d_lo = d_lo; a.d_step = d_step;
     a.points = points; a.offsets = point_offsets; a.extr = extrinsics; a.intr = intrinsics; a.bda_inv = bda_inv;
-    a.cell_min = reinterpret_cast<uint32_t *>(workspace); a.bin = depth_bin; a.onehot = onehot;
+    a.cell_min = reinterpret_cast<uint32_t *>(workspace); a.bin = depth_bin; a.onehot = onehot; a.flipped = flipped;
     hipLaunchKernelGGL(depth_fill_kernel, dim3(mmt::stream_grid(ncells, kBlock)), dim3(kBlock), 0, st, a.cell_min, ncells);
     if (int rc = mmt::check_launch("depth_labels(fill)")) return rc;
     if (max_points > 0) {
@@ -148,6 +167,100 @@ extern "C" int mmt_depth_labels(int B, int num_cams, int F, int max_points, int 
     const int64_t work = onehot ? ncells * D : ncells;
     hipLaunchKernelGGL(depth_bins_kernel, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, st, a, ncells);
     return mmt::check_launch("depth_labels(bins)");
+}
+
+// ---------------------------------------------------------------------------
+// Image augmentation of the training step, exps/mm_training_aim.py:89-112 (augment_images: per camera, with probability 1/2,
+// kornia hflip of the image AND of its depth-label map; the flags go to mats['flipped']) and :510-512 (normalize_images:
+// torchvision Normalize of sweep_imgs[:, :, :, :3] / 255).  The reference stacks per-image Python lists; here the flags are
+// a device byte per camera and
+//   mmt_hflip                  out[i, r, w, :] = in[i, r, flipped[i / group] ? W-1-w : w, :]    (any [n, rows, W, E] tensor)
+//   mmt_normalize_flip_images  normalise + flip in ONE pass over the images, optionally straight into the channels-last
+//                              memory the first convolution reads (the NCHW -> NHWC conversion in front of it disappears)
+namespace {
+
+__global__ __launch_bounds__(kBlock) void hflip_kernel(int64_t n, int group, int rows, int W, int E, const float *in,
+                                                       const uint8_t *flipped, float *out) {
+    const int64_t per_img = (int64_t)rows * W * E, total = n * per_img;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t img = i / per_img;
+        int64_t src = i;
+        if (flipped[img / group]) {
+            const int64_t rem = i - img * per_img;
+            const int64_t row = rem / ((int64_t)W * E);
+            const int we = (int)(rem - row * W * E);
+            const int w = we / E, e = we - w * E;
+            src = img * per_img + row * W * E + (int64_t)(W - 1 - w) * E + e;
+        }
+        out[i] = in[src];
+    }
+}
+
+struct NormArgs {
+    int64_t n;
+    int c_in, H, W;
+    float scale, mean[3], stdv[3];
+    const float *in;             // [n, c_in, H, W]; the first 3 channels are read
+    const uint8_t *flipped;      // [n] or NULL
+    float *out;                  // [n, 3, H, W] or, channels-last, [n, H, W, 3]
+};
+
+// one thread per output pixel: three plane reads (coalesced along w, reversed for a flipped camera), three outputs
+template <bool NHWC>
+__global__ __launch_bounds__(kBlock) void normalize_flip_kernel(NormArgs a) {
+    const int64_t hw = (int64_t)a.H * a.W, total = a.n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t img = i / hw;
+        const int64_t rem = i - img * hw;
+        const int h = (int)(rem / a.W), w = (int)(rem - (int64_t)h * a.W);
+        const int ws = (a.flipped != nullptr && a.flipped[img]) ? a.W - 1 - w : w;
+        const float *src = a.in + (img * a.c_in) * hw + (int64_t)h * a.W + ws;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)      // (x * (1/255) - mean) / std: ATen's scalar division is a multiplication by the fp32 reciprocal
+            v[c] = __fdiv_rn(__fsub_rn(__fmul_rn(src[c * hw], a.scale), a.mean[c]), a.stdv[c]);
+        if (NHWC) {
+            float *dst = a.out + i * 3;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.out[(img * 3 + c) * hw + rem] = v[c];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mmt_hflip(int64_t n, int group, int rows, int W, int elems, const float *in, const uint8_t *flipped, float *out,
+                         void *stream) {
+    if (n < 0 || group <= 0 || rows <= 0 || W <= 0 || elems <= 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "hflip: bad sizes");
+    if (n == 0) return MMT_OK;
+    MMT_REQUIRE_PTR(in);
+    MMT_REQUIRE_PTR(flipped);
+    MMT_REQUIRE_PTR(out);
+    if (in == out) return mmt::fail(MMT_ERR_BAD_SHAPE, "hflip: in-place is not supported");
+    hipLaunchKernelGGL(hflip_kernel, dim3(mmt::stream_grid(n * rows * W * elems, kBlock, 256 * 32)), dim3(kBlock), 0, (hipStream_t)stream,
+                       n, group, rows, W, elems, in, flipped, out);
+    return mmt::check_launch("hflip");
+}
+
+extern "C" int mmt_normalize_flip_images(int64_t n_images, int channels_in, int H, int W, const float *images, float scale,
+                                         const float *mean_host, const float *std_host, const uint8_t *flipped, float *out,
+                                         int channels_last, void *stream) {
+    if (n_images < 0 || channels_in < 3 || H <= 0 || W <= 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "normalize_flip_images: bad sizes (>= 3 channels)");
+    if (n_images == 0) return MMT_OK;
+    MMT_REQUIRE_PTR(images);
+    MMT_REQUIRE_PTR(mean_host);
+    MMT_REQUIRE_PTR(std_host);
+    MMT_REQUIRE_PTR(out);
+    NormArgs a;
+    a.n = n_images; a.c_in = channels_in; a.H = H; a.W = W; a.scale = scale;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean_host[c]; a.stdv[c] = std_host[c]; }
+    a.in = images; a.flipped = flipped; a.out = out;
+    const dim3 grid(mmt::stream_grid(n_images * H * W, kBlock, 256 * 64)), block(kBlock);
+    if (channels_last) hipLaunchKernelGGL(normalize_flip_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(normalize_flip_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    return mmt::check_launch("normalize_flip_images");
 }
 
 // ---------------------------------------------------------------------------

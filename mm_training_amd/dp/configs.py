@@ -89,5 +89,8 @@ def make_config(name="cfg2"):
         # storage type of the hot-path operands (depth / context / lifted features and their gradients); accumulation
         # is fp32 either way.  BASELINE configs[4] names bf16: SURVEY 5.6 defines it as bf16 storage + fp32 accumulate.
         hot_path_dtype="bf16" if name == "cfg5" else "f32",
+        # exps/mm_training_aim.py:258 (augment_images runs in every training step) and exps/conf_aim.py:23 /
+        # exps/configs/lidar_cam.py:23 (use_depth_loss = True -> pass_depth_labels, :78: the labels are the model's depth oracle)
+        augment_images=True, use_depth_loss=True,
         num_boxes=20)
     return copy.deepcopy(cfg)

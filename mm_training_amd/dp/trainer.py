@@ -13,13 +13,14 @@ Host-side changes against the reference, none of which alter the arithmetic cont
 import math
 import os
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from .. import synthetic
 from ..models.bev_depth import BEVDepthLiDAR
-from ..ops.train_targets import depth_labels
+from ..ops.train_targets import camera_flags_to_device, depth_labels, hflip, normalize_flip_images
 
 IMG_MEAN = (0.485, 0.456, 0.406)
 IMG_STD = (0.229, 0.224, 0.225)
@@ -79,6 +80,23 @@ def _batched_bn_counters(model):
     return counters
 
 
+@torch.no_grad()
+def augment_images(images, depth_images, stage):
+    """exps/mm_training_aim.py:89-112.  Per camera, with probability 1/2 (np.random.uniform(size = b*s*n) > 0.5: the
+    reference's own draw from numpy's global generator), mirror the image [.., c, h, w] and its depth-label map
+    [b*s*n, fH, fW, D] along w.  Returns (images, depth_images, flips), flips = the host boolean array the reference stores
+    in mats['flipped'].  Two launches of mmt_hflip instead of two stacked Python lists of kornia.hflip results.  The
+    training step itself runs the fused form (TrainStep.forward_loss); this is the reference's function as a function."""
+    b, s, n, c, h, w = images.shape
+    if stage != 'train':
+        return images, depth_images, np.zeros((b * s * n), dtype=bool)
+    flips = np.random.uniform(size=(b * s * n)) > 0.5
+    fl = camera_flags_to_device(flips, images.device)
+    images = hflip(images.reshape(b * s * n * c, h, w, 1), fl, group=c).view(b, s, n, c, h, w)
+    depth_images = hflip(depth_images, fl)
+    return images, depth_images, flips
+
+
 class TrainStep(nn.Module):
     """Owns model + optimiser and runs one optimisation step per call."""
 
@@ -123,6 +141,11 @@ class TrainStep(nn.Module):
         self.downsample = cfg["backbone_conf"]["downsample_factor"]
         self.depth_channels = len(torch.arange(*db)) if self.use_cam else 0
         self.amp_dtype = torch.bfloat16 if (amp or cfg.get("dtype")) == "bf16" else None
+        # exps/mm_training_aim.py:258: training_step always runs augment_images(..., 'train'); :78 + :259: the depth labels are
+        # handed to the model as the depth oracle when use_depth_loss is set (True in exps/conf_aim.py:23 and in the reference's
+        # camera + LiDAR config exps/configs/lidar_cam.py:23)
+        self.augment = bool(cfg.get("augment_images", True))
+        self.pass_depth_labels = bool(cfg.get("use_depth_loss", True))
         self.register_buffer("mean", torch.tensor(IMG_MEAN).view(1, 1, 1, 3, 1, 1), persistent=False)
         self.register_buffer("std", torch.tensor(IMG_STD).view(1, 1, 1, 3, 1, 1), persistent=False)
         self.to(device)
@@ -173,19 +196,34 @@ class TrainStep(nn.Module):
         bce = F.binary_cross_entropy(depth_preds.clamp(0, 1), depth_labels, reduction="none").sum(1)
         return 3.0 * (bce * fg).sum() / fg.sum().clamp(min=1.0)
 
+    # ---- exps/mm_training_aim.py:89-112
+    def augment_images(self, images, depth_images, stage):
+        return augment_images(images, depth_images, stage)
+
     def forward_loss(self, batch):
         sweep_imgs, mats, pointclouds, gt_boxes, gt_labels = batch
-        depth_labels = None
+        depth_labels_flat = input_depth = None
         if self.use_cam:
-            depth_labels = self.get_depth_labels(sweep_imgs, mats, pointclouds)
-            sweep_imgs = self.normalize_images(sweep_imgs)
+            # training_step :256-259 in two launch sequences: the flags are drawn like augment_images draws them (:98), then
+            #   get_depth_labels + the label half of augment_images   -> mmt_depth_labels_flipped (mirrored label write)
+            #   normalize_images + the image half of augment_images   -> mmt_normalize_flip_images (one pass, channels_last out)
+            B, S, N, _, H, W = sweep_imgs.shape
+            flips = np.random.uniform(size=(B * S * N)) > 0.5 if self.augment else np.zeros((B * S * N), dtype=bool)
+            fl = camera_flags_to_device(flips, sweep_imgs.device)
+            depth_labels_flat = depth_labels(pointclouds, mats["extrinsics"][:, 0], mats["intrin_mats"][:, 0], mats["bda_mat"],
+                                             (H, W), self.downsample, self.dbound, self.depth_channels, flipped=fl)
+            sweep_imgs = normalize_flip_images(sweep_imgs, IMG_MEAN, IMG_STD, fl,
+                                               channels_last=os.environ.get("MMT_MEMORY_FORMAT", "channels_last") == "channels_last")
+            mats = dict(mats, flipped=fl)                    # :258 (the batch's own dict is left alone)
+            if self.pass_depth_labels:                       # :259: depth_labels.permute(0, 3, 1, 2)
+                input_depth = depth_labels_flat.view(B * S * N, H // self.downsample, W // self.downsample, -1).permute(0, 3, 1, 2)
         # targets do not depend on the network: build them first so nothing sits between the
         # forward and the backward kernels in the launch queue
         targets = self.model.get_targets(gt_boxes, gt_labels)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            preds, depth_preds, _, _ = self.net((sweep_imgs, pointclouds), mats, None)
+            preds, depth_preds, _, _ = self.net((sweep_imgs, pointclouds), mats, input_depth)
         detection_loss = self.model.loss(targets, preds)
-        depth_loss = self.get_depth_loss(depth_labels, depth_preds) if self.use_cam else detection_loss.new_zeros(())
+        depth_loss = self.get_depth_loss(depth_labels_flat, depth_preds) if self.use_cam else detection_loss.new_zeros(())
         return detection_loss + depth_loss, detection_loss, depth_loss
 
     def forward(self, batch):

@@ -10,13 +10,64 @@ import torch
 from .. import _lib
 
 
+def camera_flags_to_device(flags, device):
+    """Per-camera boolean flags drawn on the host (numpy / list / CPU tensor) -> uint8 CUDA tensor, through pinned memory and
+    an asynchronous copy: the step never waits for the device (exps/mm_training_aim.py:98 draws them with np.random)."""
+    if torch.is_tensor(flags) and flags.is_cuda:
+        return flags.to(torch.uint8).contiguous()
+    host = torch.as_tensor(flags).to(torch.uint8).contiguous()
+    return host.pin_memory().to(device, non_blocking=True)
+
+
+def hflip(t, flipped, group=1):
+    """out[i, r, w, :] = t[i, r, W-1-w, :] where flipped[i // group], else t[i, r, w, :] (mmt_hflip; kornia.hflip of the
+    selected images).  t: contiguous fp32 CUDA [n, rows, W, E]; flipped: uint8 CUDA [n / group]."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        raise RuntimeError("hflip: expected a float32 CUDAtensor [n, rows, W, E]")
+    t = t.contiguous()
+    n, rows, W, E = t.shape
+    if flipped.numel() * group != n or flipped.dtype != torch.uint8 or not flipped.is_cuda:
+        raise RuntimeError("hflip: flipped must be a uint8 CUDAtensor with n / group entries")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        _lib.call("mmt_hflip", n, int(group), rows, W, E, t.data_ptr(), flipped.data_ptr(), out.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def normalize_flip_images(sweep_imgs, mean, std, flipped=None, channels_last=True, divisor=255.0):
+    """normalize_images (exps/mm_training_aim.py:510-512) fused with the image half of augment_images (:100-104):
+    sweep_imgs fp32 CUDA [B, S, N, C>=3, H, W] in 0..255 -> ((x[:, :, :, :3] / divisor) - mean) / std (the division evaluated like
+    ATen evaluates a division by a Python scalar on the GPU: a multiplication by the fp32 reciprocal), camera i mirrored along w
+    where flipped[i] (uint8 CUDA [B*S*N] or None), as a [B, S, N, 3, H, W] tensor.  channels_last: its memory is
+    [B, S, N, H, W, 3], so `reshape(B*S*N, 3, H, W)` is a channels_last view -- what the image backbone's first convolution
+    reads (no layout conversion in front of it)."""
+    import ctypes
+    import numpy as np
+    if not sweep_imgs.is_cuda or sweep_imgs.dtype != torch.float32 or sweep_imgs.dim() != 6:
+        raise RuntimeError("normalize_flip_images: expected a float32 CUDAtensor [B, S, N, C, H, W]")
+    x = sweep_imgs.contiguous()
+    B, S, N, C, H, W = x.shape
+    n = B * S * N
+    if flipped is not None and (flipped.numel() != n or flipped.dtype != torch.uint8 or not flipped.is_cuda):
+        raise RuntimeError("normalize_flip_images: flipped must be a uint8 CUDAtensor [B*S*N]")
+    out = torch.empty((B, S, N, H, W, 3) if channels_last else (B, S, N, 3, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("mmt_normalize_flip_images", n, C, H, W, x.data_ptr(), ctypes.c_float(float(np.float32(1.0) / np.float32(divisor))),
+                  _lib.float3(mean), _lib.float3(std), flipped.data_ptr() if flipped is not None else 0, out.data_ptr(),
+                  1 if channels_last else 0, torch.cuda.current_stream().cuda_stream)
+    return out.permute(0, 1, 2, 5, 3, 4) if channels_last else out
+
+
 def depth_labels(pointclouds, extrinsics, intrinsics, bda_mat, img_hw, downsample, d_bound,
-                 depth_channels, return_bins=False):
+                 depth_channels, return_bins=False, flipped=None):
     """pointclouds: list of B CUDA tensors [Ni, F] (x, y, z first); extrinsics (ego -> camera) and
     intrinsics [B, N, 4, 4]; bda_mat [B, 4, 4]; img_hw = (H, W) of the network input.
 
     Returns the one-hot labels fp32 [B*N*fH*fW, depth_channels] (what get_downsampled_gt_depth
-    returns, :213-214) and, with ``return_bins``, also the int32 bin index per cell."""
+    returns, :213-214) and, with ``return_bins``, also the int32 bin index per cell.
+    flipped: optional uint8 CUDA [B*N]; the label maps of those cameras are written mirrored along w -- the label half of
+    augment_images (:105-110) folded into the label write (mmt_depth_labels_flipped)."""
     if not pointclouds or not pointclouds[0].is_cuda:
         raise RuntimeError("pointclouds must be a non-empty list of CUDAtensors ")
     dev = pointclouds[0].device
@@ -43,10 +94,12 @@ def depth_labels(pointclouds, extrinsics, intrinsics, bda_mat, img_hw, downsampl
     ext = extrinsics.float().contiguous()
     intr = intrinsics.float().contiguous()
     with torch.cuda.device(dev):
-        _lib.call("mmt_depth_labels", B, N, F, max(counts), H, W, int(downsample), float(d_bound[0]), float(d_bound[2]),
+        if flipped is not None and (flipped.numel() != B * N or flipped.dtype != torch.uint8 or not flipped.is_cuda):
+            raise RuntimeError("depth_labels: flipped must be a uint8 CUDAtensor [B*N]")
+        _lib.call("mmt_depth_labels_flipped", B, N, F, max(counts), H, W, int(downsample), float(d_bound[0]), float(d_bound[2]),
                   int(depth_channels), points.data_ptr(), offsets.data_ptr(), ext.data_ptr(), intr.data_ptr(),
                   bda_inv.data_ptr(), workspace.data_ptr(), n_ws, bins.data_ptr() if return_bins else None,
-                  onehot.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                  onehot.data_ptr(), flipped.data_ptr() if flipped is not None else None, torch.cuda.current_stream().cuda_stream)
     return (onehot, bins) if return_bins else onehot
 
 

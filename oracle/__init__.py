@@ -291,3 +291,32 @@ def bev_warp_affine(x_nhwc, bda_mat):
     y = np.empty_like(x)
     lib().oracle_bev_warp_affine(B, H, W, C, _p(_f32(bda_mat)), _p(x), _p(y))
     return y
+
+
+# ---- image augmentation of the training step (exps/mm_training_aim.py:88-112, :510-512); pinned by tests/golden/augment_images.npz
+IMG_MEAN = (0.485, 0.456, 0.406)
+IMG_STD = (0.229, 0.224, 0.225)
+
+
+def normalize_images(sweep_imgs, gpu_division=False):
+    """exps/mm_training_aim.py:510-512: torchvision Normalize(mean, std)(sweep_imgs[:, :, :, :3, ...] / 255.) in fp32.
+    gpu_division: evaluate `/ 255.` like ATen does on a GPU (multiplication by the fp32 reciprocal) instead of the CPU's
+    true division -- the two differ in the last bit of some values."""
+    x = np.asarray(sweep_imgs, np.float32)[:, :, :, :3]
+    x = x * (np.float32(1.0) / np.float32(255.0)) if gpu_division else x / np.float32(255.0)
+    mean = np.asarray(IMG_MEAN, np.float32).reshape(1, 1, 1, 3, 1, 1)
+    std = np.asarray(IMG_STD, np.float32).reshape(1, 1, 1, 3, 1, 1)
+    return ((x - mean) / std).astype(np.float32)
+
+
+def augment_images(images, depth_images, flips):
+    """exps/mm_training_aim.py:100-110 for given flags (the reference draws them at :98 with np.random.uniform(size=b*s*n) > 0.5):
+    camera i of images [b, s, n, c, h, w] and of the label maps [b*s*n, fH, fW, D] is mirrored along w where flips[i]."""
+    images = np.asarray(images)
+    b, s, n, c, h, w = images.shape
+    flips = np.asarray(flips, bool).reshape(b * s * n)
+    flat = images.reshape(b * s * n, c, h, w).copy()
+    flat[flips] = flat[flips][..., ::-1]
+    labels = np.asarray(depth_images).copy()
+    labels[flips] = labels[flips][:, :, ::-1, :]
+    return flat.reshape(b, s, n, c, h, w), labels

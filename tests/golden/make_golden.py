@@ -21,6 +21,8 @@ What is executed from the reference:
     evaluated from the module's source text at run time).
   * layers/backbones/lss_fpn.py LSSFPN._forward_single_sweep / forward (:381-529) as a whole -- flipped cameras,
     oracle depth, two sweeps -- with the conv nets replaced by the identity (lss_forward.npz).
+  * exps/mm_training_aim.py augment_images (:88-112) and normalize_images (:510-512), exec'd as plain functions with a
+    seeded numpy generator (augment_images.npz).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -520,6 +522,48 @@ def make_depth_labels():
     print("depth_labels: points", [len(c) for c in clouds], "labelled cells", int((bins > 0).sum()), "of", bins.size)
 
 
+def make_augment_images():
+    """The per-step image augmentation from the reference's own lines: exps/mm_training_aim.py:88-112 (augment_images:
+    flips = np.random.uniform(size = b*s*n) > 0.5, kornia hflip of the flagged images and label maps) and :510-512
+    (normalize_images), read from the file at run time and exec'd as plain functions.  Stand-ins for the two absent
+    third-party callables, by their documented definitions: kornia.geometry.transform.hflip(x) = x.flip(-1);
+    torchvision.transforms.Normalize(mean, std)(x) = (x - mean[:, None, None]) / std[:, None, None].  numpy's global generator
+    is seeded so that the test can draw the same flags.  Stored: the raw images (integer-valued, 4 channels so that the `:3`
+    slice of normalize_images matters), the label maps, the normalised images (CPU arithmetic: a true division by 255), the
+    flags and both augmented outputs, for the 'train' stage; the 'val' stage must hand everything back untouched."""
+    src = _ref_source_lines("exps/mm_training_aim.py", 88, 112) + "\n" + _ref_source_lines("exps/mm_training_aim.py", 510, 512)
+    hflip = lambda t: t.flip(-1)
+
+    class _Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    from typing import Tuple
+    ns = {"torch": torch, "np": np, "Tuple": Tuple,
+          "kornia": types.SimpleNamespace(geometry=types.SimpleNamespace(transform=types.SimpleNamespace(hflip=hflip))),
+          "torchvision": types.SimpleNamespace(transforms=types.SimpleNamespace(Normalize=_Normalize))}
+    exec(src, ns)
+    rng = np.random.default_rng(5)
+    B, S, N, H, W, fH, fW, D = 2, 1, 3, 32, 48, 2, 3, 5
+    raw = rng.integers(0, 256, (B, S, N, 4, H, W)).astype(np.float32)
+    hot = rng.integers(0, D, (B * S * N, fH, fW))
+    labels = np.eye(D, dtype=np.float32)[hot] * (rng.random((B * S * N, fH, fW, 1)) < 0.7)
+    norm = ns["normalize_images"](None, torch.from_numpy(raw))
+    assert tuple(norm.shape) == (B, S, N, 3, H, W)
+    seed = 20240
+    np.random.seed(seed)
+    imgs_t, labels_t, flips = ns["augment_images"](None, norm.clone(), torch.from_numpy(labels.astype(np.float32)), 'train')
+    assert flips.dtype == bool and flips.any() and not flips.all(), flips
+    iv, lv, fv = ns["augment_images"](None, norm, torch.from_numpy(labels.astype(np.float32)), 'val')
+    assert torch.equal(iv, norm) and torch.equal(lv, torch.from_numpy(labels.astype(np.float32))) and not fv.any()
+    np.savez_compressed(os.path.join(HERE, "augment_images.npz"), raw=raw, labels=labels.astype(np.float32), normalized=norm.numpy(),
+                        seed=np.int64(seed), flips=flips, aug_images=imgs_t.numpy(), aug_labels=labels_t.numpy())
+    print("augment_images: flips", flips.astype(int).tolist(), "images", tuple(imgs_t.shape), "labels", tuple(labels_t.shape))
+
+
 def main():
     _install_stubs()
     oracle.build()
@@ -527,11 +571,14 @@ def main():
         return make_depth_labels()
     if "--only-lss-forward" in sys.argv:
         return make_lss_forward()
+    if "--only-augment-images" in sys.argv:
+        return make_augment_images()
     make_vp_ref_test()
     make_vp_edge()
     make_quant_and_geom()
     make_lss_forward()
     make_depth_labels()
+    make_augment_images()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

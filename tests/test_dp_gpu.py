@@ -48,6 +48,7 @@ def _make(world):
     torch.manual_seed(0)
     ts = TrainStep(cfg, dev, world_size=world)
     ts.model.eval()
+    ts.augment = False                                  # no per-step random flips: the runs compared here must see the same inputs
     ts.model.backbone.fused_lift_splat = False          # with a calibration id: cached-plan forward (no atomics)
     full = synthetic_batch(cfg, dev, seed=7, batch_size=4)
     return ts, full
@@ -101,7 +102,10 @@ def test_two_ranks_equal_gradient_accumulation_and_double_batch(mmt_lib):
         for m, t in zip(micro, targets):
             imgs, mats, pcs, _, _ = m
             depth_labels = ts.get_depth_labels(imgs, mats, pcs)
-            preds, depth_preds, _, _ = ts.net((ts.normalize_images(imgs), pcs), mats, None)
+            # (the labels are the model's depth oracle, exps/mm_training_aim.py:259 -- what forward_loss passes in the ranks)
+            b_, s_, n_, _, h_, w_ = imgs.shape
+            oracle_depth = depth_labels.view(b_ * s_ * n_, h_ // ts.downsample, w_ // ts.downsample, -1).permute(0, 3, 1, 2)
+            preds, depth_preds, _, _ = ts.net((ts.normalize_images(imgs), pcs), mats, oracle_depth)
             loss = ts.model.head.loss(t, preds, normalisers=norm)
             if with_depth:
                 loss = loss + ts.get_depth_loss(depth_labels, depth_preds)
@@ -144,6 +148,8 @@ def _rccl_worker(_index, port, out):
     res = {}
     for key, world in (("ddp", 2), ("plain", 1)):            # world_size > 1 only selects the DDP wrap; the group has one rank
         torch.manual_seed(0)
+        import numpy as np
+        np.random.seed(0)                                    # augment_images draws its per-camera flags from numpy's global generator
         ts = TrainStep(cfg, dev, world_size=world)
         batch = synthetic_batch(cfg, dev, seed=7, batch_size=2)
         losses = [float(ts(batch)[0]) for _ in range(5)]     # static_graph engages from the second iteration on

@@ -171,3 +171,19 @@ def test_depth_labels_oracle_matches_reference_methods(oracle_mod, golden):
         assert np.array_equal(bins, g["bins"])
         assert np.array_equal(onehot.argmax(1), g["bins"])
     assert (g["bins"] > 0).sum() > 50
+
+
+def test_augment_and_normalize_against_the_reference(golden, oracle_mod):
+    """oracle.normalize_images / augment_images against the arrays the reference's own normalize_images (:510-512) and
+    augment_images (:88-112) produced (make_golden.py::make_augment_images): bit-exact (CPU arithmetic on both sides), and the
+    flags are what numpy's global generator gives for the stored seed."""
+    g = golden["augment_images"]
+    norm = oracle_mod.normalize_images(g["raw"])
+    assert np.array_equal(norm, g["normalized"])
+    imgs, labels = oracle_mod.augment_images(norm, g["labels"], g["flips"])
+    assert np.array_equal(imgs, g["aug_images"]) and np.array_equal(labels, g["aug_labels"])
+    np.random.seed(int(g["seed"]))
+    assert np.array_equal(np.random.uniform(size=g["flips"].shape) > 0.5, g["flips"])
+    # the GPU evaluation of `/ 255.` (reciprocal multiplication) stays within one ulp of the division
+    gpu = oracle_mod.normalize_images(g["raw"], gpu_division=True)
+    assert np.abs(gpu - norm).max() <= 1e-6 and not np.array_equal(gpu, norm)
