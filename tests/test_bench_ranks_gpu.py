@@ -41,6 +41,20 @@ def test_bench_two_ranks_on_the_gpu_box(mmt_lib):
     assert c["lift_splat_kernels"]["forward"].split("+")[0] in ("tile", "ray") and c["lift_splat_kernels"]["backward"]
     # world > 1: rank 0 does not keep the other ranks parked in the final barrier for its own drop-in-op timing leg
     assert "roofline_voxel_pooling" not in d and "cpu_baseline" not in d
+    # what the N > 1 path ran on (config.distributed): two ranks, both on the one card -> gloo (RCCL refuses two ranks per device),
+    # the shared-card rehearsal is the only launch for which bench.py pins HSA_ENABLE_IPC_MODE_LEGACY itself; DDP's layout
+    dd = c["distributed"]
+    assert dd["world"] == 2 and dd["backend"] == "gloo" and dd["ranks_share_a_device"] is True
+    assert [r["rank"] for r in dd["ranks"]] == [0, 1] and all(r["device"] == "cuda:0" for r in dd["ranks"])
+    assert len({r["pci_bus_id"] for r in dd["ranks"]}) == 1 and dd["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert dd["rccl_version"] and dd["gradient_bytes"] > 1e5
+    ddp = dd["ddp"]
+    assert ddp["static_graph"] is True and ddp["find_unused_parameters"] is False and ddp["gradient_as_bucket_view"] is True
+    assert ddp["broadcast_buffers"] is False and ddp["bucket_cap_mb"] == 64.0 and ddp["buckets_estimate"] >= 1
+    assert ddp["ignored_parameters"] and all(".context_se." in n for n in ddp["ignored_parameters"])
+    # the reference's training_step branches run inside the timed steps (exps/mm_training_aim.py:258-259)
+    assert c["augment_images"] is True and c["depth_oracle"] is True
+    assert "roofline_softmax" in d and d["roofline_softmax"]["backward"]["avg_ms"] > 0
 
 
 def test_bench_reports_a_rank_that_dies_instead_of_hanging(mmt_lib):

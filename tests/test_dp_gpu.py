@@ -159,6 +159,10 @@ def _rccl_worker(_index, port, out):
     dist.all_reduce(t)
     res["all_reduce"] = t.tolist()
     res["backend"] = dist.get_backend()
+    # bench.py's own initialisation + report at world 1 on RCCL (the N > 1 lines carry the same object, gathered over the ranks)
+    import bench
+    bench.torch, bench.dist = torch, dist
+    res["info"] = bench.distributed_info(1, 0, ts)
     out.update(res)
     dist.barrier()
     dist.destroy_process_group()
@@ -175,3 +179,6 @@ def test_rccl_backend_single_rank_ddp_step(mmt_lib):
     for a, b in zip(out["ddp"], out["plain"]):
         assert a == a and abs(a - b) <= 2e-3 * max(1.0, abs(b)), (out["ddp"], out["plain"])
     assert out["ddp"][-1] < out["ddp"][0]                  # and it trains
+    info = out["info"]
+    assert info["world"] == 1 and info["ranks"][0]["device"] == "cuda:0" and info["ranks"][0]["pci_bus_id"].count(":") == 2
+    assert info["rccl_version"] and info["gradient_bytes"] > 1e5 and info["ddp"] is None        # (the last TrainStep is the unwrapped one)
