@@ -413,6 +413,9 @@ int mmt_lss_splat_backward_cam_bf16(int B, int N, int D, int fH, int fW, int C, 
 int mmt_lss_last_kernel_family(int backward);
 /* 1 when mmt_lss_splat_forward_cam AND mmt_lss_splat_backward_cam both take this shape, 0 otherwise (use the geom form). */
 int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW, int C);
+/* 1 when mmt_lss_splat_forward_cam[_bf16] of this shape uses an exclusive_cache it is handed (ABI 8): a caller allocates the
+ * cache (mmt_lss_exclusive_cache_bytes) only for such shapes; every other shape ignores the argument. */
+int mmt_lss_exclusive_cache_used(int B, int N, int D, int fH, int fW, int C);
 
 /* ------------------------------------------------- bf16 feature storage
  * BASELINE configs[4] names bf16.  The reference has no behaviour for it -- its extension takes data_ptr<float>()

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mmt_lss_splat_backward_cam_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 9 + [_c_i64] * 4 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
     "mmt_lss_last_kernel_family": (_c_int, [_c_int]),
     "mmt_lss_camera_form_supported": (_c_int, [_c_int] * 6),
+    "mmt_lss_exclusive_cache_used": (_c_int, [_c_int] * 6),
     "mmt_quantize_geometry": (_c_int, [_c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     "mmt_frustum_geometry": (_c_int, [_c_int, _c_i64] + [_c_ptr] * 6 + [_c_ptr]),
     "mmt_depth_softmax_forward": (_c_int, [_c_i64, _c_int, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr]),

@@ -2124,6 +2124,17 @@ extern "C" int mmt_lss_splat_backward_cam_bf16(int B, int N, int D, int fH, int 
 
 extern "C" int mmt_lss_last_kernel_family(int backward) { return g_last_family[backward ? 1 : 0]; }
 
+// 1 when mmt_lss_splat_forward_cam* of this shape uses an exclusive-cell cache it is handed (with MMT_LSS_ZERO_OUTPUT): the
+// kernel choice of forward_impl -- today the register walk.  A caller allocates the cache only then.
+extern "C" int mmt_lss_exclusive_cache_used(int B, int N, int D, int fH, int fW, int C) {
+    if (B <= 0 || N <= 0 || N > kExclMaxN || D <= 0 || fH <= 0 || fW <= 0 || !(C == 64 || C == 80 || C == 128) || fH > kPts) return 0;
+    RayArgs r = {};
+    r.BN = B * N; r.N = N; r.D = D; r.fH = fH; r.fW = fW; r.C = C;
+    r.combine = reinterpret_cast<const float *>(16);
+    if (!pick_ray_forward(&r)) return 0;
+    return r.reg ? 1 : 0;
+}
+
 // 1 when both directions have a camera-form kernel for this shape (the gates of forward_impl / backward_impl)
 extern "C" int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW, int C) {
     if (B <= 0 || N <= 0 || D <= 0 || fH <= 0 || fW <= 0 || !(C == 64 || C == 80 || C == 128) || fH > kPts) return 0;

@@ -349,6 +349,11 @@ def camera_form_supported(B, N, D, fH, fW, C):
     return bool(_lib.lib().mmt_lss_camera_form_supported(int(B), int(N), int(D), int(fH), int(fW), int(C)))
 
 
+def exclusive_cache_used(B, N, D, fH, fW, C):
+    """True when the camera-form forward of this shape takes an exclusive-cell cache (mmt_lss_exclusive_cache_used)."""
+    return bool(_lib.lib().mmt_lss_exclusive_cache_used(int(B), int(N), int(D), int(fH), int(fW), int(C)))
+
+
 def last_kernel_family(backward=False, detail=False):
     """Kernel family the process's last fused lift-splat forward / backward call launched:
     "ray" | "tile" | "column" | "none", + "+camera" for the camera form (mmt_lss_last_kernel_family).

@@ -110,7 +110,31 @@ def test_exclusive_cache_sizing_and_the_module_switch(monkeypatch):
     cfg = make_config("tiny")
     monkeypatch.setenv("MMT_LSS_EXCL_SLOTS", "0")
     off = LSSFPN(**cfg["backbone_conf"])
-    assert off.exclusive_slots == 0 and off._exclusive_cache_for(6, "cpu") is None
+    assert off.exclusive_slots == 0 and off._exclusive_cache_for(4, 6, 16, 44, "cpu") is None
     monkeypatch.setenv("MMT_LSS_EXCL_SLOTS", "32")
     on = LSSFPN(**cfg["backbone_conf"])
     assert on.exclusive_slots == 32 and not any("excl" in k for k in on.state_dict())
+    # the module asks the library which shapes take a cache at all (mmt_lss_exclusive_cache_used) and allocates for no other:
+    # BASELINE configs[1] / [3] (16 rows, C = 80: register walk) do; the reference's native 409-bin frustum and more than
+    # 8 cameras per sample do not
+    assert lib.mmt_lss_exclusive_cache_used(4, 6, 112, 16, 44, 80) == 1
+    assert lib.mmt_lss_exclusive_cache_used(4, 2, 409, 44, 80, 80) == 0
+    assert lib.mmt_lss_exclusive_cache_used(1, 9, 112, 16, 44, 80) == 0 and lib.mmt_lss_exclusive_cache_used(1, 6, 112, 16, 44, 72) == 0
+
+
+def test_loaded_frustum_reaches_the_camera_form():
+    """`frustum` is a persistent buffer like the reference's (lss_fpn.py:291): after load_state_dict the camera form must read
+    the LOADED frustum's axes (and fall back to the geom form for a frustum that is no outer product of three axes)."""
+    import torch
+    from mm_training_amd.dp.configs import make_config
+    from mm_training_amd.layers.backbones.lss_fpn import LSSFPN
+    cfg = make_config("tiny")
+    m = LSSFPN(**cfg["backbone_conf"])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["frustum"][..., 2] += 0.25                       # other depth bins than the constructor's d_bound gives
+    m.load_state_dict(sd)
+    assert torch.equal(m.frustum_d, sd["frustum"][:, 0, 0, 2]) and m._has_frustum_axes
+    assert torch.equal(m.frustum_pixel_major, sd["frustum"].permute(1, 2, 0, 3))
+    sd["frustum"][3, 1, 2, 0] += 1.0                    # one point off the grid of axes: no camera form for this frustum
+    m.load_state_dict(sd)
+    assert not m._has_frustum_axes and torch.equal(m.frustum, sd["frustum"])
