@@ -198,3 +198,24 @@ def float3(values):
 
 def int3(values):
     return (ctypes.c_int32 * 3)(*[int(v) for v in values])
+
+
+# ---- small host-side integer arrays (per-sample row offsets) on the device ---------------------------------------------
+# The offsets depend on the point / box counts of the batch only.  `torch.tensor(list).to(device)` is a pageable host-to-device
+# copy: the host waits for it (and it shows up as a Memcpy HtoD in the middle of the launch queue).  Identical count patterns
+# reuse one read-only device tensor; a new pattern goes through pinned memory with an asynchronous copy.
+_INT_ARRAYS = {}
+
+
+def device_ints(values, device):
+    """int32 CUDA tensor holding `values` (a list of Python ints); cached per (device, values) -- treat it as read-only."""
+    import torch
+    key = (str(device), tuple(int(v) for v in values))
+    t = _INT_ARRAYS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.tensor(key[1], dtype=torch.int32).to(device, non_blocking=True)     # (a node of the graph, as before)
+        if len(_INT_ARRAYS) >= 256:
+            _INT_ARRAYS.pop(next(iter(_INT_ARRAYS)))
+        t = _INT_ARRAYS[key] = torch.tensor(key[1], dtype=torch.int32).pin_memory().to(device, non_blocking=True)
+    return t

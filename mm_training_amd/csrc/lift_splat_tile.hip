@@ -1158,8 +1158,22 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
     // ---- 8 lane groups: an equal share of the depth bins each; the context tile in registers
     const int g = lane >> 4, li = lane & 15;
     const int share = (dn + NT / 16 - 1) / (NT / 16);
-    const int ds = (wave * 4 + g) * share;
-    const int de = (ds + share) < dn ? (ds + share) : dn;
+    // Shares end where a run ends: a nominal boundary that falls inside a run (the bin before it has the same key) moves on to
+    // the run's last bin, so no cell's run is cut in two between neighbouring lane groups -- each cut was one more flush (one
+    // more atomic row, or a cell that could have been a plain store) per boundary: 7 of the ~52 flushes of a column at
+    // BASELINE configs[3].  The adjusted boundaries are a function of the keys alone: every group finds its own and its
+    // successor's without a barrier (a run is 1-3 bins).
+    auto run_start = [&](int p) __attribute__((always_inline)) {
+        if (p >= dn) return dn;
+        while (p > 0 && p < dn) {
+            const int k = bkey[p];
+            if (!(k >= 0 && k == bkey[p - 1])) break;
+            ++p;
+        }
+        return p;
+    };
+    const int ds = run_start((wave * 4 + g) * share);
+    const int de = run_start((wave * 4 + g + 1) * share);
     const float *cl = ctx + li;
     mmt_v2f c2[16][NP > 0 ? NP : 1];
     float c1[16];
@@ -1394,6 +1408,9 @@ __global__ __launch_bounds__(kBlock) void lss_ray_fwd_blk(RayArgs a) {
     // ---- 16 lane groups: an equal share of the kept bins x all row blocks each
     const int g = lane >> 4, li = lane & 15;
     const int share = (nkb + kBlock / 16 - 1) / (kBlock / 16);
+    // (Shares that end where a run ends -- lss_ray_fwd_reg's rule -- were measured here and dropped: +3 us at BASELINE
+    // configs[4] (44.0 -> 47.0 us, tools/kbench_camera.py interleaved).  70 kept bins over 16 lane groups are 4-5 bins each;
+    // moving a boundary to the next run end makes the longest share 6-7 bins, and the longest share is the kernel's walk time.)
     const int ds = (wave * 4 + g) * share;
     const int de = (ds + share) < nkb ? (ds + share) : nkb;
     const float *cl = ctx + li;
@@ -1828,7 +1845,7 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
                                               (long long)cam->excl_bytes);
                 xs.slots = fit > kExclMaxSlots ? kExclMaxSlots : (int)fit;
                 // the launch shape the learnt states depend on (run decomposition and cell numbering)
-                int words[17] = {N, D, fH, fW, nx, ny, nz, r.dsplit, r.dspan, kRegBlock, xs.slots};
+                int words[17] = {N, D, fH, fW, nx, ny, nz, r.dsplit, r.dspan, kRegBlock + (2 << 16) /* run decomposition v2: shares end at run ends */, xs.slots};
                 memcpy(words + 11, cam->q.lo, 12);
                 memcpy(words + 14, cam->q.vs, 12);
                 uint64_t h = 0xCBF29CE484222325ull;

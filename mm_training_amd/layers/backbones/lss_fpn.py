@@ -320,7 +320,10 @@ class LSSFPN(nn.Module):
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, depth_oracle, is_return_depth=False):
         batch_size, num_sweeps, num_cams = sweep_imgs.shape[:3]
         img_feats = self.get_cam_feats(sweep_imgs)
-        source_features = img_feats[:, 0, ...]
+        # the key frame (:389): every caller hands over ONE sweep here (forward slices sweep_imgs[:, k:k+1]); squeezing that axis is
+        # a view in both directions, while `img_feats[:, 0]` costs the backward a zero-fill + a strided copy of the whole neck
+        # output (select_backward: 16 + 47 us per step at BASELINE configs[3])
+        source_features = img_feats.squeeze(1) if img_feats.shape[1] == 1 else img_feats[:, 0, ...]
         feats_in = source_features.reshape(batch_size * num_cams, *source_features.shape[2:])
         D, C = self.depth_channels, self.output_channels
         if hasattr(self.depth_net, "forward_parts"):

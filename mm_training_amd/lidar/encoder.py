@@ -68,7 +68,7 @@ def _batch_points(points_list):
     offs = [0]
     for n in sizes:
         offs.append(offs[-1] + n)
-    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    offsets = _lib.device_ints(offs, dev)
     return points, offsets, offs[-1]
 
 

@@ -82,7 +82,7 @@ def depth_labels(pointclouds, extrinsics, intrinsics, bda_mat, img_hw, downsampl
     offs = [0]
     for c in counts:
         offs.append(offs[-1] + c)
-    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    offsets = _lib.device_ints(offs, dev)
     bda_inv = torch.linalg.inv_ex(bda_mat[:, :3, :3].float())[0].contiguous()       # inv_ex: no host sync
     n_ws = _lib.lib().mmt_depth_labels_workspace_elems(B, N, H, W, int(downsample))
     if n_ws < 0:
@@ -126,7 +126,7 @@ def centerpoint_targets(gt_boxes, gt_labels, class_counts, max_objs, feature_map
     offs = [0]
     for c in counts:
         offs.append(offs[-1] + c)
-    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    offsets = _lib.device_ints(offs, dev)
     heatmaps = [torch.empty((B, int(n), fy, fx), dtype=torch.float32, device=dev) for n in class_counts]
     annos = [torch.empty((B, max_objs, 10), dtype=torch.float32, device=dev) for _ in class_counts]
     inds = [torch.empty((B, max_objs), dtype=torch.int64, device=dev) for _ in class_counts]
