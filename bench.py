@@ -734,6 +734,7 @@ def train_main(args, rank, local_rank, world):
                 "forward": fam_f_detail, "backward": fam_b,
                 "exclusive_cell_cache": ("on: runs into single-run cells are stored, not added (learnt on the device per calibration; "
                                          "the synthetic batch repeats, so every timed step uses it)") if "+exclusive" in fam_f_detail else "off",
+                "exclusive_cell_cache_calls": lss.exclusive_cache_counters() if "+exclusive" in fam_f_detail else None,
                 "geometry": "computed in the kernels (camera form)" if camera else "geom tensor (mmt_frustum_geometry every step)",
                 "backward_choice": lss.lift_splat_backward if lss.lift_splat_backward != "auto" else (
                     "auto: per calibration id, from the geometry" if args.calibration_ids else

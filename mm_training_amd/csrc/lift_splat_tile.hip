@@ -529,7 +529,14 @@ __device__ __forceinline__ void excl_hash_word(unsigned w, int i, unsigned &h0, 
 // excl_probe_begin issues the loads (the matrices' words, then -- the slot follows from their hash -- the slot's metadata
 // and matrices); excl_probe_end, called after the geometry phase, compares.  In between the slot is known and its states can
 // be read speculatively.
-struct ExclProbe { int mode, slot; unsigned h0, h1, w0, w1, s0, s1; int4 mt; bool match; };
+// Round 4: the table is 2-WAY SET-ASSOCIATIVE (slots 2s and 2s + 1 form set s; a table of one slot stays direct-mapped): two
+// calibrations whose hashes meet in one set no longer take the slot from each other on every visit -- with a few hundred
+// calibrations in a shuffled loader and 1024 slots, dozens of pairs collided and never got past the claim.  A miss claims
+// the free way, else the way that has learnt less (ties: a hash bit).  Header words [32..34] count, per sample and call,
+// hits (stage 3: the cache was used), learning calls (stages 1 / 2) and misses -- mmt_lss_exclusive_cache_bytes' caller reads
+// them back (bench.py reports them).
+struct ExclProbe { int mode, slot, way_free; unsigned h0, h1, w0, w1, s0[2], s1[2]; int4 mt[2]; int base, ways; bool match; };
+__device__ __forceinline__ bool excl_meta_is(const int4 &mt, unsigned h0, unsigned h1) { return (unsigned)mt.x == h0 && (unsigned)mt.y == h1 && mt.z > 0; }
 __device__ __forceinline__ ExclProbe excl_probe_begin(int32_t *cache, const ExclShape &x, const float *combine, int b) {
     const int lane = threadIdx.x & 63, nw = x.N * 16;
     const unsigned *m = reinterpret_cast<const unsigned *>(combine) + (int64_t)b * nw;
@@ -541,29 +548,53 @@ __device__ __forceinline__ ExclProbe excl_probe_begin(int32_t *cache, const Excl
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { h0 ^= __shfl_xor(h0, o); h1 ^= __shfl_xor(h1, o); }
     p.h0 = h0; p.h1 = h1 | 1u;                                      // (a free slot's hash words are 0)
-    p.slot = (int)((h0 ^ (p.h1 * 0x9E3779B1u)) % (unsigned)x.slots);
-    p.mt = *reinterpret_cast<const int4 *>(excl_meta(cache, p.slot));
-    const unsigned *sm = reinterpret_cast<const unsigned *>(excl_mats(cache, x, p.slot));
-    p.s0 = lane < nw ? sm[lane] : 0u; p.s1 = lane + 64 < nw ? sm[lane + 64] : 0u;
+    p.ways = x.slots >= 2 ? 2 : 1;
+    p.base = (int)((h0 ^ (p.h1 * 0x9E3779B1u)) % (unsigned)(x.slots / p.ways)) * p.ways;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int sl = p.base + (w < p.ways ? w : 0);
+        p.mt[w] = *reinterpret_cast<const int4 *>(excl_meta(cache, sl));
+        const unsigned *sm = reinterpret_cast<const unsigned *>(excl_mats(cache, x, sl));
+        p.s0[w] = lane < nw ? sm[lane] : 0u; p.s1[w] = lane + 64 < nw ? sm[lane + 64] : 0u;
+    }
+    p.slot = p.base; p.way_free = 0;
     p.match = false; p.mode = 0;
     return p;
 }
+// the way whose metadata carries this sample's hash (known one round trip after excl_probe_begin: the states of that slot are
+// then read speculatively; whether its matrices really are the sample's is settled in excl_probe_end)
+__device__ __forceinline__ int excl_probe_slot(const ExclProbe &p) {
+    return (p.ways == 2 && !excl_meta_is(p.mt[0], p.h0, p.h1) && excl_meta_is(p.mt[1], p.h0, p.h1)) ? p.base + 1 : p.base;
+}
 __device__ __forceinline__ void excl_probe_end(ExclProbe &p) {
-    p.match = __all(p.s0 == p.w0 && p.s1 == p.w1) && (unsigned)p.mt.x == p.h0 && (unsigned)p.mt.y == p.h1 && p.mt.z > 0;
-    p.mode = p.match ? p.mt.z : 0;
+    const int w = excl_probe_slot(p) - p.base;
+    const bool same = w == 0 ? __all(p.s0[0] == p.w0 && p.s1[0] == p.w1) : __all(p.s0[1] == p.w0 && p.s1[1] == p.w1);
+    const int4 mt = w == 0 ? p.mt[0] : p.mt[1];
+    p.slot = p.base + w;
+    p.match = same && excl_meta_is(mt, p.h0, p.h1);
+    p.mode = p.match ? mt.z : 0;
+    // where a miss claims: a free way first, else the way that has learnt less, else a hash bit
+    if (p.ways == 2) {
+        const int st0 = p.mt[0].z, st1 = p.mt[1].z;
+        p.way_free = st0 <= 0 ? 0 : (st1 <= 0 ? 1 : (st0 != st1 ? (st1 < st0 ? 1 : 0) : (int)((p.h1 >> 1) & 1u)));
+    }
 }
 // The sample's first column workgroup (wave 0) posts the mail of this call.
 __device__ __forceinline__ void excl_post(int32_t *cache, const ExclShape &x, const float *combine, int b, const ExclProbe &p) {
     const int lane = threadIdx.x & 63, nw = x.N * 16;
     int32_t *mail = excl_mail(cache, b);
+    const int slot = p.match ? p.slot : p.base + p.way_free;
     if (!p.match) {                                                  // claim the slot
         const unsigned *m = reinterpret_cast<const unsigned *>(combine) + (int64_t)b * nw;
         for (int i = lane; i < nw; i += 64) mail[8 + i] = (int)m[i];
-        if (lane == 0) { mail[1] = p.slot; mail[2] = (int)p.h0; mail[3] = (int)p.h1; mail[0] = 1; }
+        if (lane == 0) { mail[1] = slot; mail[2] = (int)p.h0; mail[3] = (int)p.h1; mail[0] = 1; }
     } else if (p.mode < 3) {                                         // this call marks (verifies): next stage
-        if (lane == 0) { mail[1] = p.slot; mail[2] = (int)p.h0; mail[3] = (int)p.h1; mail[0] = p.mode + 1; }
+        if (lane == 0) { mail[1] = slot; mail[2] = (int)p.h0; mail[3] = (int)p.h1; mail[0] = p.mode + 1; }
     }
-    if (lane == 0) { cache[8 + b] = p.slot; cache[24 + b] = p.mode; }      // (for the curious: what this call did with sample b)
+    if (lane == 0) {
+        cache[8 + b] = slot; cache[24 + b] = p.mode;                 // (for the curious: what this call did with sample b)
+        atomicAdd(cache + (p.mode == 3 ? 32 : (p.mode > 0 ? 33 : 34)), 1);     // hits / learning calls / misses, cumulative
+    }
 }
 
 // The commit step: one workgroup (256 threads) of the zero-fill kernel in front of every forward.
@@ -975,10 +1006,7 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
     bool excl_on = false;
     if constexpr (CAM) {
         excl_on = a.excl != nullptr && b < kExclMaxB;
-        if (excl_on) {
-            probe = excl_probe_begin(a.excl, a.xs, a.combine, b);
-            excl_st = excl_state(a.excl, a.xs, probe.slot) - (int64_t)b * a.xs.cells;
-        }
+        if (excl_on) probe = excl_probe_begin(a.excl, a.xs, a.combine, b);      // (loads only; excl_st follows at its first use)
     }
 
     // ---- geometry -> per-bin depths and keys
@@ -1050,7 +1078,10 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
                         }
                     }
                 }
-                if (excl_on && !uasked && ukey >= 0) { ustate = excl_st[ukey]; uasked = true; }      // (consumed behind the next pass)
+                if (excl_on && !uasked && ukey >= 0) {                                                // (consumed behind the next pass)
+                    if (excl_st == nullptr) excl_st = excl_state(a.excl, a.xs, excl_probe_slot(probe)) - (int64_t)b * a.xs.cells;
+                    ustate = excl_st[ukey]; uasked = true;
+                }
                 float4 *dq = reinterpret_cast<float4 *>(dep + dd * BS + hb);
                 int4 *kq = reinterpret_cast<int4 *>(keyrow + dd * BS + hb);
                 dq[0] = make_float4(dvs[0], dvs[1], dvs[2], dvs[3]); dq[1] = make_float4(dvs[4], dvs[5], dvs[6], dvs[7]);
@@ -1058,6 +1089,7 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
             }
             if (sum && !cached) *sum = make_int2(in00 ? ((y00 << 16) | x00) : -1, (int)zm16 | (uni16 ? mmt::kSummaryUniform : 0));
             if (excl_on && ukey >= 0 && !uni16) {                             // mixed bin (rare): the rows' tags one by one
+                if (excl_st == nullptr) excl_st = excl_state(a.excl, a.xs, excl_probe_slot(probe)) - (int64_t)b * a.xs.cells;
                 for (int row = 0; row < fH; ++row) {
                     const int kk = keyrow[dd * BS + row];
                     if (kk >= 0 && excl_st[kk] > 0) keyrow[dd * BS + row] = kk | kExclFlag;
@@ -1138,6 +1170,7 @@ __global__ __launch_bounds__(kRegBlock, 4) void lss_ray_fwd_reg(RayArgs a) {
         if (excl_on) {
             excl_probe_end(probe);
             excl_mode = probe.mode;
+            excl_st = excl_state(a.excl, a.xs, probe.slot) - (int64_t)b * a.xs.cells;       // (the slot the mark / verify stores go to)
             if (wave == 0 && bn == b * a.N && col == 0 && slab == 0) excl_post(a.excl, a.xs, a.combine, b, probe);
             if (excl_mode != 3) {
                 for (int dd = tid; dd < dn; dd += NT) {
@@ -1845,7 +1878,7 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
                                               (long long)cam->excl_bytes);
                 xs.slots = fit > kExclMaxSlots ? kExclMaxSlots : (int)fit;
                 // the launch shape the learnt states depend on (run decomposition and cell numbering)
-                int words[17] = {N, D, fH, fW, nx, ny, nz, r.dsplit, r.dspan, kRegBlock + (2 << 16) /* run decomposition v2: shares end at run ends */, xs.slots};
+                int words[17] = {N, D, fH, fW, nx, ny, nz, r.dsplit, r.dspan, kRegBlock + (3 << 16) /* table layout v3: run decomposition with shares ending at run ends; 2-way sets */, xs.slots};
                 memcpy(words + 11, cam->q.lo, 12);
                 memcpy(words + 14, cam->q.vs, 12);
                 uint64_t h = 0xCBF29CE484222325ull;

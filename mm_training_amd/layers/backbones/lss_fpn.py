@@ -254,6 +254,16 @@ class LSSFPN(nn.Module):
             cache = self._excl_caches[key] = new_exclusive_cache(num_cams, self._voxel_num_host, device, slots)
         return cache
 
+    def exclusive_cache_counters(self):
+        """(hits, learning calls, misses) summed over this module's exclusive-cell caches: per sample and forward call, whether
+        the cache was used (the calibration is known: stage 3), still being learnt (stages 1 / 2) or not found (include/mmt_hip.h
+        `exclusive_cache`, header words 32..34).  Reads the device: call it outside the timed region."""
+        tot = [0, 0, 0]
+        for cache in self._excl_caches.values():
+            for i, v in enumerate(cache[32:35].tolist()):
+                tot[i] += int(v)
+        return dict(hit=tot[0], learning=tot[1], miss=tot[2])
+
     def _adaptive_column_choice(self, device):
         """"auto" without a calibration id: (use the column kernel?, the counters it accumulates into)."""
         st = self._column_adaptive

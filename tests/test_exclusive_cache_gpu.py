@@ -160,6 +160,39 @@ def test_calibrations_that_share_a_slot_and_a_change_of_shape_or_axes(mmt_lib):
     _same(out, refs[0])
 
 
+def test_two_way_sets_and_the_call_counters(mmt_lib):
+    """Round 4: slots 2s and 2s + 1 form a set.  Two calibrations that meet in one set (a table of two slots = one set) both
+    learn and are both used -- the direct-mapped table made them evict each other on every visit; a third one in the same set
+    takes a way from them in turn and everything stays correct.  Header words 32..34 count hits / learning calls / misses."""
+    N, C = 3, 80
+    fr = _frustum((128, 352), 16, (2.0, 58.0, 0.5))
+    rigs = [_rig(1, N, 352, 128, seed=s) for s in (41, 42, 43)]
+    refs = [_forward(r, fr, C, None)[0] for r in rigs]
+    cache = _cache(N, 2)
+    seen = {0: [], 1: []}
+    for rnd in range(5):
+        for i in (0, 1):
+            out, _ = _forward(rigs[i], fr, C, cache)
+            seen[i].append(_modes(cache, 1)[0][0])
+            _same(out, refs[i])
+    assert seen[0] == [0, 1, 2, 3, 3] and seen[1] == [0, 1, 2, 3, 3], seen
+    hit, learning, miss = cache[32:35].tolist()
+    assert (hit, learning, miss) == (4, 4, 2), (hit, learning, miss)
+    # a third calibration in the same set: correct throughout, and the two that keep coming back are found again after their
+    # way was taken
+    for rnd in range(4):
+        for i in (0, 1, 2):
+            out, _ = _forward(rigs[i], fr, C, cache)
+            _same(out, refs[i])
+    for want in (None, None, None, 3, 3):
+        out, _ = _forward(rigs[2], fr, C, cache)
+        _same(out, refs[2])
+        if want is not None:
+            assert _modes(cache, 1)[0] == [want]
+    h2, l2, m2 = cache[32:35].tolist()
+    assert h2 + l2 + m2 == 10 + 12 + 5 and m2 > miss
+
+
 def test_cache_under_graph_replay_and_through_the_module(mmt_lib):
     """A captured forward (zero-fill + select + walk) learns and uses the cache across replays; LSSFPN owns one cache per
     (device, cameras, stream) and reports it in the kernel family."""
