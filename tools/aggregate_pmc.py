@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Average per launch of the rocprofv3 --pmc counters for the libmmt_hip kernels (arguments: a label for the measured
 command, then one output directory per counter pass) -> JSON on stdout (the layout bench.py's pmc_traffic() reads:
-profiles/r03_pmc_<config>.json)."""
+profiles/rNN_pmc_<config>.json)."""
 import csv
 import glob
 import json
@@ -45,6 +45,11 @@ KERNELS = [
     ("vox_link", ("vox_link",)), ("vox_heads", ("vox_heads",)), ("vox_emit", ("vox_emit",)),
     ("fill_i32_kernel", ("fill_i32_kernel",)), ("scatter_map_kernel", ("scatter_map_kernel",)),
     ("scatter_write_nhwc_kernel", ("scatter_write_nhwc_kernel",)), ("scatter_backward_nhwc_kernel", ("scatter_backward_nhwc_kernel",)),
+    ("scatter_write_strided_table_kernel", ("scatter_write_strided_table_kernel",)), ("scatter_write_strided_kernel", ("scatter_write_strided_kernel",)),
+    ("scatter_backward_strided_kernel", ("scatter_backward_strided_kernel",)),
+    ("depth_softmax_fwd", ("depth_softmax_fwd",)), ("depth_softmax_bwd", ("depth_softmax_bwd",)),
+    ("normalize_flip_kernel", ("normalize_flip_kernel",)), ("hflip_kernel", ("hflip_kernel",)),
+    ("depth_project_kernel", ("depth_project_kernel",)), ("depth_bins_kernel", ("depth_bins_kernel",)),
     ("scatter_write_nhwc_table_kernel", ("scatter_write_nhwc_table_kernel",)), ("scatter_backward_nhwc_unique_kernel", ("scatter_backward_nhwc_unique_kernel",)),
     ("dcn_col2im_gather", ("dcn_col2im_gather",)), ("dcn_offset_grad", ("dcn_offset_grad",)), ("dcn_plan", ("dcn_plan",)),
     ("dcn_col2im", ("dcn_col2im",)), ("dcn_im2col", ("dcn_im2col",)),

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'): rocprofv3 kernel statistics of the default bench
 # (train, BASELINE configs[3]) and of the isolated hot path (fp32 at the cfg2/cfg4 camera shape, bf16 at cfg5), plus the
 # three PMC passes behind bench.py's roofline.traffic for each of them.  Summaries land in gpurun_out/profiles_new/
-# (copy the ones to be judged into profiles/ as r03_*).  One counter group per pass; kernel-trace/stats only in their own
+# (copy the ones to be judged into profiles/ as rNN_*: tools/adopt_profiles.sh).  One counter group per pass; kernel-trace/stats only in their own
 # runs.  The program itself follows `--` (python3 bench.py), never a wrapper.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
