@@ -535,7 +535,8 @@ __device__ __forceinline__ void excl_hash_word(unsigned w, int i, unsigned &h0, 
 // the free way, else the way that has learnt less (ties: a hash bit).  Header words [32..34] count, per sample and call,
 // hits (stage 3: the cache was used), learning calls (stages 1 / 2) and misses -- mmt_lss_exclusive_cache_bytes' caller reads
 // them back (bench.py reports them).
-struct ExclProbe { int mode, slot, way_free; unsigned h0, h1, w0, w1, s0[2], s1[2]; int4 mt[2]; int base, ways; bool match; };
+// (scalars, no arrays: an indexed member sends the whole struct to scratch memory -- 18 MB of private-segment traffic per launch)
+struct ExclProbe { int mode, slot, way_free; unsigned h0, h1, w0, w1, a0, a1, b0, b1; int4 mta, mtb; int base, ways; bool match; };
 __device__ __forceinline__ bool excl_meta_is(const int4 &mt, unsigned h0, unsigned h1) { return (unsigned)mt.x == h0 && (unsigned)mt.y == h1 && mt.z > 0; }
 __device__ __forceinline__ ExclProbe excl_probe_begin(int32_t *cache, const ExclShape &x, const float *combine, int b) {
     const int lane = threadIdx.x & 63, nw = x.N * 16;
@@ -550,13 +551,13 @@ __device__ __forceinline__ ExclProbe excl_probe_begin(int32_t *cache, const Excl
     p.h0 = h0; p.h1 = h1 | 1u;                                      // (a free slot's hash words are 0)
     p.ways = x.slots >= 2 ? 2 : 1;
     p.base = (int)((h0 ^ (p.h1 * 0x9E3779B1u)) % (unsigned)(x.slots / p.ways)) * p.ways;
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        const int sl = p.base + (w < p.ways ? w : 0);
-        p.mt[w] = *reinterpret_cast<const int4 *>(excl_meta(cache, sl));
-        const unsigned *sm = reinterpret_cast<const unsigned *>(excl_mats(cache, x, sl));
-        p.s0[w] = lane < nw ? sm[lane] : 0u; p.s1[w] = lane + 64 < nw ? sm[lane + 64] : 0u;
-    }
+    const int sla = p.base, slb = p.base + p.ways - 1;              // (one way: both name the same slot)
+    p.mta = *reinterpret_cast<const int4 *>(excl_meta(cache, sla));
+    p.mtb = *reinterpret_cast<const int4 *>(excl_meta(cache, slb));
+    const unsigned *sma = reinterpret_cast<const unsigned *>(excl_mats(cache, x, sla));
+    const unsigned *smb = reinterpret_cast<const unsigned *>(excl_mats(cache, x, slb));
+    p.a0 = lane < nw ? sma[lane] : 0u; p.a1 = lane + 64 < nw ? sma[lane + 64] : 0u;
+    p.b0 = lane < nw ? smb[lane] : 0u; p.b1 = lane + 64 < nw ? smb[lane + 64] : 0u;
     p.slot = p.base; p.way_free = 0;
     p.match = false; p.mode = 0;
     return p;
@@ -564,18 +565,18 @@ __device__ __forceinline__ ExclProbe excl_probe_begin(int32_t *cache, const Excl
 // the way whose metadata carries this sample's hash (known one round trip after excl_probe_begin: the states of that slot are
 // then read speculatively; whether its matrices really are the sample's is settled in excl_probe_end)
 __device__ __forceinline__ int excl_probe_slot(const ExclProbe &p) {
-    return (p.ways == 2 && !excl_meta_is(p.mt[0], p.h0, p.h1) && excl_meta_is(p.mt[1], p.h0, p.h1)) ? p.base + 1 : p.base;
+    return (p.ways == 2 && !excl_meta_is(p.mta, p.h0, p.h1) && excl_meta_is(p.mtb, p.h0, p.h1)) ? p.base + 1 : p.base;
 }
 __device__ __forceinline__ void excl_probe_end(ExclProbe &p) {
-    const int w = excl_probe_slot(p) - p.base;
-    const bool same = w == 0 ? __all(p.s0[0] == p.w0 && p.s1[0] == p.w1) : __all(p.s0[1] == p.w0 && p.s1[1] == p.w1);
-    const int4 mt = w == 0 ? p.mt[0] : p.mt[1];
-    p.slot = p.base + w;
-    p.match = same && excl_meta_is(mt, p.h0, p.h1);
-    p.mode = p.match ? mt.z : 0;
+    const bool second = excl_probe_slot(p) != p.base;
+    const bool same_a = __all(p.a0 == p.w0 && p.a1 == p.w1), same_b = __all(p.b0 == p.w0 && p.b1 == p.w1);
+    const bool is_a = excl_meta_is(p.mta, p.h0, p.h1), is_b = excl_meta_is(p.mtb, p.h0, p.h1);
+    p.slot = p.base + (second ? 1 : 0);
+    p.match = second ? (same_b && is_b) : (same_a && is_a);
+    p.mode = p.match ? (second ? p.mtb.z : p.mta.z) : 0;
     // where a miss claims: a free way first, else the way that has learnt less, else a hash bit
     if (p.ways == 2) {
-        const int st0 = p.mt[0].z, st1 = p.mt[1].z;
+        const int st0 = p.mta.z, st1 = p.mtb.z;
         p.way_free = st0 <= 0 ? 0 : (st1 <= 0 ? 1 : (st0 != st1 ? (st1 < st0 ? 1 : 0) : (int)((p.h1 >> 1) & 1u)));
     }
 }

@@ -27,8 +27,13 @@ class _DeformConv3x3(Function):
             _lib.call("mmt_dcn_im2col", B, H, W, C, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(),
                       col.data_ptr(), _stream())
         wmat = weight.float().reshape(groups, Og, Cg, 9).permute(0, 3, 2, 1).reshape(groups, 9 * Cg, Og)
-        out = torch.bmm(col, wmat)                                  # [g, N, Og]
-        out_nhwc = out.permute(1, 0, 2).reshape(B, H, W, O)
+        # one GEMM per weight group, each writing its Og columns of the channels-last result in place (leading dimension O):
+        # a batched GEMM leaves [g, N, Og] and the transposition to [N, g * Og] was a 35 MB copy per call (and one more for the
+        # gradient in backward)
+        out2d = torch.empty((N, O), dtype=torch.float32, device=x.device)
+        for g in range(groups):
+            torch.mm(col[g], wmat[g], out=out2d[:, g * Og:(g + 1) * Og])
+        out_nhwc = out2d.view(B, H, W, O)
         ctx.save_for_backward(x_nhwc, off_nhwc, col, wmat)
         ctx.dims = (B, H, W, C, O, groups)
         return out_nhwc.permute(0, 3, 1, 2)                         # channels_last view
@@ -38,10 +43,14 @@ class _DeformConv3x3(Function):
         x_nhwc, off_nhwc, col, wmat = ctx.saved_tensors
         B, H, W, C, O, groups = ctx.dims
         Cg, Og, N = C // groups, O // groups, B * H * W
-        go = grad_out.float().permute(0, 2, 3, 1).reshape(N, groups, Og).permute(1, 0, 2).contiguous()
-        grad_wmat = torch.bmm(col.transpose(1, 2), go)              # [g, 9Cg, Og]
+        go2d = grad_out.float().permute(0, 2, 3, 1).reshape(N, O)    # free for a channels_last gradient
+        grad_wmat = torch.empty((groups, 9 * Cg, Og), dtype=torch.float32, device=go2d.device)
+        grad_col = torch.empty((groups, N, 9 * Cg), dtype=torch.float32, device=go2d.device)
+        for g in range(groups):                                     # the group's Og gradient columns are read in place (leading dimension O)
+            go_g = go2d[:, g * Og:(g + 1) * Og]
+            torch.mm(col[g].t(), go_g, out=grad_wmat[g])
+            torch.mm(go_g, wmat[g].t(), out=grad_col[g])
         grad_weight = grad_wmat.reshape(groups, 9, Cg, Og).permute(0, 3, 2, 1).reshape(O, Cg, 3, 3)
-        grad_col = torch.bmm(go, wmat.transpose(1, 2)).contiguous()  # [g, N, 9Cg]
         grad_off = torch.empty_like(off_nhwc)
         lpg = Cg // 4
         sorted_ok = H * W <= 4096 and Cg % 4 == 0 and lpg <= 64 and (lpg & (lpg - 1)) == 0
