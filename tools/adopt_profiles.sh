@@ -1,19 +1,15 @@
 #!/bin/bash
-# Run HERE after `gpurun -- 'bash tools/collect_profiles.sh'` (and tools/collect_final.sh): copies the merged summaries from
-# gpurun_out/profiles_new/ and gpurun_out/final/ into profiles/ under the round prefix given as $1 (e.g. r04).
+# Run HERE after `gpurun -- 'bash tools/collect_profiles.sh'` and / or `gpurun -- 'bash tools/collect_final.sh'`: copies the
+# summaries those runs produced (their MANIFEST: the local gpurun_out/ may still hold files of earlier rounds) into profiles/
+# under the round prefix given as $1 (e.g. r04).
 set -e
 r=${1:?round prefix, e.g. r04}
 cd "$(dirname "$0")/.."
-for f in gpurun_out/profiles_new/bench_*_kernel_stats.csv gpurun_out/profiles_new/bench_*_under_rocprof.log gpurun_out/profiles_new/pmc_*.json; do
-  [ -f "$f" ] || continue
-  b=$(basename "$f")
-  case "$b" in pmc_*_[0-9].log) continue;; esac
-  cp "$f" "profiles/${r}_$b"
+for d in gpurun_out/profiles_new gpurun_out/final; do
+  [ -f "$d/MANIFEST" ] || { echo "no $d/MANIFEST: nothing adopted from $d"; continue; }
+  while read -r b; do
+    [ "$b" = MANIFEST ] && continue
+    [ -s "$d/$b" ] && cp "$d/$b" "profiles/${r}_$b"
+  done < "$d/MANIFEST"
 done
-if [ -d gpurun_out/final ]; then
-  for f in gpurun_out/final/*; do
-    case "$f" in *.err) continue;; esac
-    [ -s "$f" ] && cp "$f" "profiles/${r}_$(basename "$f")"
-  done
-fi
-ls profiles | grep "^${r}_" | wc -l
+ls profiles | grep -c "^${r}_"

@@ -19,3 +19,6 @@ run $out/kbench_lidar_and_producers.json python tools/kbench_lidar.py
 run $out/ubench_atomic_rows.txt tools/ubench/atomic_rows
 run $out/ubench_atomic_scatter.txt tools/ubench/atomic_scatter
 grep -h '^{' $out/bench_*.jsonl | cut -c1-160
+# what THIS run produced (gpurun merges into a local directory that may still hold files of earlier rounds: tools/adopt_profiles.sh
+# copies only the names listed here)
+ls $out | grep -v '\.err$' > $out/MANIFEST

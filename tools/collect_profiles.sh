@@ -38,5 +38,6 @@ want pmc4 && pmc cfg4 --steps 8 --warmup 8 --no-cpu-baseline --no-hotpath-leg
 want pmc5 && pmc cfg5 --config cfg5 --steps 3 --warmup 2 --no-cpu-baseline --no-hotpath-leg
 want pmc2 && pmc cfg2 --mode hotpath --config cfg2 --steps 5 --warmup 2 --no-cpu-baseline
 want pmc5bf16 && pmc cfg5_bf16 --mode hotpath --config cfg5 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline
+ls $out | grep -E '^(bench_.*(kernel_stats\.csv|under_rocprof\.log)|pmc_[a-z0-9_]*\.json)$' > $out/MANIFEST     # (see tools/adopt_profiles.sh)
 grep -h '^{' $out/bench_*_under_rocprof.log | cut -c1-300
 ls -la $out
