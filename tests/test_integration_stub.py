@@ -159,3 +159,87 @@ def test_fused_stub_equals_the_reference_op_sequence_through_the_extension_stub(
     assert float((bev - ref).abs().max()) <= 2e-5 * scale
     assert torch.equal(bev.detach().abs().sum(1) > 0, ref.detach().abs().sum(1) > 0)
     assert torch.allclose(d1.grad, d2.grad, rtol=1e-4, atol=1e-5) and torch.allclose(c1.grad, c2.grad, rtol=1e-4, atol=1e-5)
+
+
+def _load_glue_stub():
+    from mm_training_amd import _lib
+    _lib.lib()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## E. The callers either side of the op"):text.index("## C. Other entry points")]
+    code = sec[sec.index("```python\n") + len("```python\n"):]
+    code = code[:code.index("\n```")]
+    assert "/path/to/libmmt_hip.so" in code and "models/bev_depth.py:176" in code
+    mod = types.ModuleType("hip_glue")
+    exec(compile(code.replace("/path/to/libmmt_hip.so", _lib.LIB_PATH), "INTEGRATION.md#E", "exec"), mod.__dict__)
+    return mod
+
+
+def test_glue_stub_loads_and_binds(mmt_lib):
+    """CPU: the section-E block compiles and finds every symbol it binds."""
+    glue = _load_glue_stub()
+    assert callable(glue.depth_and_depth_updated) and callable(glue.fused_bev_inputs) and callable(glue.normalize_and_flip)
+
+
+@pytest.mark.gpu
+def test_glue_stub_equals_the_reference_lines(mmt_lib):
+    """Section E against the reference's own lines evaluated with torch ops on the same inputs: lss_fpn.py:423 + :427-438
+    (softmax, oracle overwrite), models/bev_depth.py:183 + :188-192 (scatter -> nearest resize -> cat; the warp of :176 with an
+    identity BDA matrix is the identity), exps/mm_training_aim.py:510-512 + :100-104 (normalise, flip) -- values and gradients."""
+    glue = _load_glue_stub()
+    g = torch.Generator().manual_seed(0)
+    # ---- depth softmax + oracle
+    BN, D, C, fH, fW = 6, 112, 80, 16, 44
+    feat = torch.randn(BN, D + C, fH, fW, generator=g).cuda()
+    hot = torch.randint(0, D, (BN, fH, fW), generator=g)
+    oracle = (torch.nn.functional.one_hot(hot, D).float() * (torch.rand(BN, fH, fW, 1, generator=g) < 0.4)).permute(0, 3, 1, 2).cuda()
+    g1, g2 = (torch.rand(BN, D, fH, fW, generator=g) - 0.5).cuda(), (torch.rand(BN, D, fH, fW, generator=g) - 0.5).cuda()
+    f1, f2 = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    depth, updated = glue.depth_and_depth_updated(f1, D, oracle)
+    ((depth * g1).sum() + (updated * g2).sum()).backward()
+    ref_depth = f2[:, :D].softmax(1)                                                        # :423
+    fg = (torch.max(oracle, dim=1).values > 0.0).view(-1)                                   # :429
+    flat = ref_depth.permute(0, 2, 3, 1).contiguous().view(-1, D)
+    ref_updated = torch.where(fg.view(-1, 1), oracle.permute(0, 2, 3, 1).contiguous().view(-1, D), flat).view(BN, fH, fW, D).permute(0, 3, 1, 2)
+    ((ref_depth * g1).sum() + (ref_updated * g2).sum()).backward()
+    assert float((depth - ref_depth).abs().max()) <= 1e-6 and float((updated - ref_updated).abs().max()) <= 1e-6
+    assert float((f1.grad - f2.grad).abs().max()) <= 1e-6
+    # ---- warp (identity BDA) + scatter + resize + cat
+    B, Cc, Cl, H, ny = 2, 16, 8, 32, 128
+    img_bev = torch.randn(B, Cc, H, H, generator=g).cuda()
+    M = 900
+    coors = torch.stack([torch.randint(0, B, (M,), generator=g), torch.zeros(M, dtype=torch.long), torch.randint(0, ny, (M,), generator=g),
+                         torch.randint(0, ny, (M,), generator=g)], 1).int()
+    lin = coors[:, 0].long() * ny * ny + coors[:, 2].long() * ny + coors[:, 3].long()
+    keep = torch.ones(M, dtype=torch.bool)
+    seen = set()
+    for i, v in enumerate(lin.tolist()):          # unique cells, like a voxelizer's output (PointPillarsScatter has no defined winner otherwise)
+        keep[i] = v not in seen
+        seen.add(v)
+    coors = coors[keep].cuda()
+    feats = torch.randn(int(keep.sum()), Cl, generator=g).cuda()
+    go = torch.randn(B, Cc + Cl, H, H, generator=g).cuda()
+    bda = torch.eye(4).repeat(B, 1, 1).cuda()
+    x1, v1 = img_bev.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    out = glue.fused_bev_inputs(x1, bda, v1, coors, B, (ny, ny))
+    out.backward(go)
+    x2, v2 = img_bev.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    canvas = torch.zeros(B, Cl, ny * ny, device="cuda")                                      # mmdet3d PointPillarsScatter
+    for b in range(B):
+        sel = coors[:, 0] == b
+        idx = (coors[sel, 2] * ny + coors[sel, 3]).long()
+        canvas[b][:, idx] = v2[sel].t()
+    lidar_bev = torch.nn.functional.interpolate(canvas.view(B, Cl, ny, ny), size=(H, H))     # :190
+    ref = torch.cat([x2, lidar_bev], dim=1)                                                  # :192
+    ref.backward(go)
+    assert float((out[:, :Cc] - ref[:, :Cc]).abs().max()) <= 1e-6 and torch.equal(out[:, Cc:], ref[:, Cc:])
+    assert torch.equal(v1.grad, v2.grad) and float((x1.grad - x2.grad).abs().max()) <= 1e-5
+    assert float(v1.grad.abs().sum()) > 0
+    # ---- normalise + flip
+    imgs = torch.randint(0, 256, (2, 1, 3, 4, 32, 48), generator=g).float().cuda()
+    flips = np.array([True, False, True, True, False, False])
+    got = glue.normalize_and_flip(imgs, flips)
+    mean = torch.tensor((0.485, 0.456, 0.406), device="cuda").view(1, 1, 1, 3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225), device="cuda").view(1, 1, 1, 3, 1, 1)
+    want = (imgs[:, :, :, :3] / 255.0 - mean) / std                                          # :510-512
+    want = torch.where(torch.from_numpy(flips).cuda().view(2, 1, 3, 1, 1, 1), want.flip(-1), want)   # :100-104
+    assert torch.equal(got, want)
