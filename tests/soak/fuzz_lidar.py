@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 import oracle
-from mm_training_amd.lidar import hard_voxelize_batch, hard_voxelize_mean_batch, pillar_scatter, simple_vfe
+from mm_training_amd.lidar import (hard_voxelize_batch, hard_voxelize_mean_batch, pillar_scatter, pillar_scatter_from_table,
+                                   pillar_scatter_strided, simple_vfe)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -88,4 +89,40 @@ while time.time() < t_end:
     if not np.array_equal(ft.grad.cpu().numpy(), oracle.pillar_scatter_backward(go, rc)):
         print("MISMATCH scatter backward", cfg)
         sys.exit(1)
+    # round 4: the scatter at a sampled resolution (what a nearest resize by an integer ratio reads), map form on the compact
+    # rows and, where the canvas is the voxel grid (one z layer), table form on the fixed-capacity rows -- against the oracle's
+    # full canvas sampled [..., ::sy, ::sx] and its backward of the zero-stuffed gradient
+    divs = lambda n: [d for d in (1, 2, 3, 4, 5, 8) if n % d == 0]
+    sy, sx = int(rng.choice(divs(nyy))), int(rng.choice(divs(nxx)))
+    C4 = int(rng.choice([4, 8, 64]))
+    feats4 = rng.standard_normal((M, C4)).astype(np.float32)
+    if gz == 1:      # (several z layers put several voxels into one canvas cell: the last-writer rule is the full scatter's test)
+        f4 = torch.from_numpy(feats4).cuda().requires_grad_(True)
+        small = pillar_scatter_strided(f4, c, B, nyy, nxx, sy, sx)
+        ref_small = oracle.pillar_scatter(feats4, rc, B, nyy, nxx)[..., ::sy, ::sx]
+        if not np.array_equal(small.detach().cpu().numpy(), ref_small):
+            print("MISMATCH strided scatter (map form)", cfg, sy, sx)
+            sys.exit(1)
+        go4 = rng.standard_normal(ref_small.shape).astype(np.float32)
+        small.backward(torch.from_numpy(go4).cuda())
+        g_full = np.zeros((B, C4, nyy, nxx), np.float32)
+        g_full[..., ::sy, ::sx] = go4
+        if not np.array_equal(f4.grad.cpu().numpy(), oracle.pillar_scatter_backward(g_full, rc)):
+            print("MISMATCH strided scatter backward (map form)", cfg, sy, sx)
+            sys.exit(1)
+        if sum(f.shape[0] for f in frames) < (1 << 23):
+            _, n5, c5, cnt5, m5, table = hard_voxelize_mean_batch(dev, vs, pcr, T, V, nf, materialize_voxels=False, return_table=True)
+            live5 = (c5[:, 0] >= 0).cpu().numpy()
+            full_rows = rng.standard_normal((B * V, C4)).astype(np.float32)
+            f5 = torch.from_numpy(full_rows).cuda().requires_grad_(True)
+            small5 = pillar_scatter_strided(f5, c5, B, nyy, nxx, sy, sx, table=table, max_voxels=V)
+            ref5 = oracle.pillar_scatter(full_rows[live5], rc, B, nyy, nxx)[..., ::sy, ::sx]
+            if not np.array_equal(small5.detach().cpu().numpy(), ref5):
+                print("MISMATCH strided scatter (table form)", cfg, sy, sx)
+                sys.exit(1)
+            small5.backward(torch.from_numpy(go4).cuda())
+            gf5 = f5.grad.cpu().numpy()
+            if not (np.array_equal(gf5[live5], oracle.pillar_scatter_backward(g_full, rc)) and float(np.abs(gf5[~live5]).sum()) == 0.0):
+                print("MISMATCH strided scatter backward (table form)", cfg, sy, sx)
+                sys.exit(1)
 print("fuzz ok:", it, "random LiDAR configurations")

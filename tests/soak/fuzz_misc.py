@@ -117,4 +117,43 @@ while time.time() < t_end:
     rx = oracle.geometry(fr, cb[None])[0]
     if not (np.array_equal(gx.cpu().numpy(), rx) and np.array_equal(gq.cpu().numpy(), oracle.quantize(rx, vc, vs))):
         fail("frustum geometry", dict(it=it, D=Dg, gh=gh, gw=gw, BN=BN))
-print("fuzz ok:", it, "random configurations of DCN / lift / fused lift-splat / quantise / geometry")
+    # ---- round 4: depth softmax + oracle overwrite (lss_fpn.py:423-438) vs the torch expression in fp64: any bin count up to
+    # 512 (16-byte and element-wise instantiations), fp32 / bf16 logits, fp32 / bf16 depth_used, channels_last / NCHW / slices
+    # of a wider channels_last tensor at aligned and unaligned offsets, with and without the oracle, one or both consumers
+    from mm_training_amd.ops.bev_geometry import depth_softmax
+    BNs, Ds = int(rng.integers(1, 7)), int(rng.choice([1, 3, 10, 36, 59, 112, 113, 128, 260, 409, 512]))
+    hs, ws = int(rng.integers(1, 9)), int(rng.integers(1, 12))
+    pad, offc = int(rng.choice([0, 4, 7, 80])), 0
+    wide = torch.randn(BNs, Ds + pad, hs, ws, device="cuda") * float(rng.choice([0.5, 3.0, 20.0]))
+    if pad:
+        offc = int(rng.integers(0, pad + 1))
+    layout = rng.choice(["cl", "nchw", "slice"])
+    src = wide.contiguous(memory_format=torch.channels_last) if layout != "nchw" else wide
+    src = src[:, offc:offc + Ds] if layout == "slice" or pad else src
+    lg_bf16, used_bf16 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    if lg_bf16:
+        src = src.bfloat16()
+    x1 = src.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+    orc = None
+    if rng.integers(0, 2):
+        hot = torch.randint(0, Ds, (BNs, hs, ws), device="cuda")
+        orc = (torch.nn.functional.one_hot(hot, Ds).float() * (torch.rand(BNs, hs, ws, 1, device="cuda") < 0.5)).permute(0, 3, 1, 2)
+    pr, us = depth_softmax(x1, orc, torch.bfloat16 if used_bf16 else torch.float32)
+    x64 = src.detach().double().requires_grad_(True)
+    p64 = x64.softmax(1)
+    u64 = p64 if orc is None else torch.where(orc.max(1, keepdim=True).values > 0, orc.double(), p64)
+    scfg = dict(it=it, BN=BNs, D=Ds, h=hs, w=ws, layout=str(layout), offc=offc, pad=pad, lg_bf16=lg_bf16, used_bf16=used_bf16, oracle=orc is not None)
+    if float((pr.detach().double() - p64.detach()).abs().max()) > 1e-6:
+        fail("depth softmax probs", scfg)
+    if float((us.detach().double() - u64.detach()).abs().max()) > (4e-3 if used_bf16 else 1e-6):
+        fail("depth softmax depth_used", scfg)
+    ga, gb = (torch.rand_like(p64) - 0.5), (torch.rand_like(p64) - 0.5)
+    which = int(rng.integers(0, 3))
+    loss = (pr.double() * ga).sum() * (which != 1) + (us.double() * gb).sum() * (which != 0)
+    l64 = (p64 * ga).sum() * (which != 1) + (u64 * gb).sum() * (which != 0)
+    loss.backward()
+    l64.backward()
+    tol = 1e-2 if (lg_bf16 or used_bf16) else 2e-6
+    if x1.grad.dtype != src.dtype or float((x1.grad.double() - x64.grad).abs().max()) > tol:
+        fail("depth softmax gradient", scfg)
+print("fuzz ok:", it, "random configurations of DCN / lift / fused lift-splat / quantise / geometry / depth softmax")
