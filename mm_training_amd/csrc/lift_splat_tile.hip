@@ -1828,6 +1828,11 @@ __global__ __launch_bounds__(kBlock) void lss_zero_fill(float4 *p, int64_t n4, E
         __builtin_amdgcn_raw_buffer_store_b128(z, rsrc, (unsigned)(i * 16), 0, 16);      // aux 16 = sc1
 }
 
+static int fill_blocks() {
+    static const char *env = getenv("MMT_FILL_BLOCKS");        // experiments only
+    return (env && atoi(env) > 0) ? atoi(env) : 2048;
+}
+
 template <typename FT>
 int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
                  const mmt::CamGeom *cam, const FT *depth, const FT *context, float *out, int32_t *pos_memo, int flags, hipStream_t st) {
@@ -1851,7 +1856,7 @@ int forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, i
     ExclCall xc = {};
     auto zero_fill = [&]() {
         if (flags & MMT_LSS_ZERO_OUTPUT)
-            seq.launch(false, lss_zero_fill, dim3((unsigned)mmt::stream_grid(out_elems / 4, kBlock, 2048) + (xc.cache ? 1u : 0u)), dim3(kBlock), 0, st,
+            seq.launch(false, lss_zero_fill, dim3((unsigned)mmt::stream_grid(out_elems / 4, kBlock, fill_blocks()) + (xc.cache ? 1u : 0u)), dim3(kBlock), 0, st,
                        reinterpret_cast<float4 *>(out), out_elems / 4, xc);
     };
     if (!(flags & MMT_LSS_TILE_KERNELS) && (C == 64 || C == 80 || C == 128)) {   // other widths: the tile kernels
