@@ -188,7 +188,6 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     int *lists = lds;
     int *cnt = lists + kTile * T;
     int *cellv = cnt + kTile;
-    float *tpts = reinterpret_cast<float *>(cellv + kTile);      // [kTile][F]: this tile's own point rows (see below)
     int b, tile;
     if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
     const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
@@ -202,15 +201,6 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     const int i = tile * kTile + threadIdx.x;
     int hr = -1, my_cell = -1;
     if (i < n) { hr = a.hrank[beg + i]; my_cell = a.cell_of_point[beg + i]; }
-    // The tile's own 256 point rows are ONE contiguous block of the cloud: staged in LDS with coalesced loads (requested here,
-    // ahead of the prefix barrier).  93 % of the voxels hold their head point only, and that point is in this tile: their mean
-    // then needs no scattered 20-byte read of a 128-byte line (12.8 MB of the kernel's 14.4 MB of traffic at 4 x 40 k points)
-    // and no second memory round trip behind the lists.
-    {
-        const int tile_pts = (n - tile * kTile) < kTile ? (n - tile * kTile) : kTile;
-        const float *src = a.points + (int64_t)(beg + tile * kTile) * F;
-        for (int e = threadIdx.x; e < tile_pts * F; e += kTile) tpts[e] = src[e];
-    }
     // heads before this tile / in the whole sample (a few hundred tile counts at most)
     if (wave == 0) {
         int before = 0, all = 0, mine = 0;
@@ -299,11 +289,7 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
             const int c = cnt[r];
             const int *L = lists + r * T;
             float sum = 0.f;
-            for (int t = 0; t < c; ++t) {
-                const int local = L[t] - tile * kTile;            // a member of this tile: from LDS
-                const float v = ((unsigned)local < (unsigned)kTile) ? tpts[local * F + k] : a.points[(int64_t)(beg + L[t]) * F + k];
-                sum = __fadd_rn(sum, v);
-            }
+            for (int t = 0; t < c; ++t) sum = __fadd_rn(sum, a.points[(int64_t)(beg + L[t]) * F + k]);
             dst[e] = __fdiv_rn(sum, (float)c);          // zero-padded slots add nothing; c >= 1
             r += dr; k += dk;
             if (k >= nf) { k -= nf; ++r; }
@@ -465,7 +451,7 @@ int vox_check(const char *what, int B, int64_t N, int F, const int32_t *grid_hos
     const int64_t cells = (int64_t)grid_host[0] * grid_host[1] * grid_host[2];
     if (cells * B >= (1ll << 31) || cells >= (1ll << 31) || N >= (1ll << kIdxBits))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: B*cells exceeds int32 or N >= 2^24 points", what);
-    if ((size_t)(kTile * (int64_t)max_points + 2 * kTile + (int64_t)kTile * F) * 4 > 150 * 1024)
+    if ((size_t)(kTile * (int64_t)max_points + 2 * kTile) * 4 > 150 * 1024)
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: max_points=%d too large for the LDS index lists", what, max_points);
     return 0;
 }
@@ -494,7 +480,7 @@ int vox_run(const char *what, int B, int64_t N, int F, const float *points, cons
     const unsigned gtiles = (unsigned)(vox_tiles(N) + B);       // flattened (sample, tile) space, see locate_tile
     seq.launch(false, vox_link, dim3(gpts), dim3(kTile), 0, st, a, B, (int)N);
     seq.launch(false, vox_heads, dim3(gtiles), dim3(kTile), 0, st, a, B);
-    const size_t lds = (size_t)(kTile * (int64_t)max_points + 2 * kTile + (int64_t)kTile * F) * 4;
+    const size_t lds = (size_t)(kTile * (int64_t)max_points + 2 * kTile) * 4;
     if (F == 5) seq.launch(true, vox_emit<5>, dim3(gtiles), dim3(kTile), lds, st, a, B);
     else if (F == 8) seq.launch(true, vox_emit<8>, dim3(gtiles), dim3(kTile), lds, st, a, B);
     else if (F == 4) seq.launch(true, vox_emit<4>, dim3(gtiles), dim3(kTile), lds, st, a, B);
