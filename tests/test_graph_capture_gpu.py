@@ -245,3 +245,107 @@ def test_fused_voxelize_mean_replays_with_its_persistent_table(mmt_lib, oracle_m
         assert np.array_equal(mean.cpu().numpy()[live], oracle_mod.simple_vfe(rv, rn, nf))
     # the generation counter advanced once per call: eager warm-up + capture (not executed) + 3 replays = 4
     assert int(table[:2].view(torch.int64).item()) == 4
+
+
+def test_round4_entry_points_replay_from_a_hip_graph(mmt_lib):
+    """The round-4 entry points -- normalise + flip, depth labels with the flip, depth softmax forward / backward with the oracle
+    rows, BEV warp + sampled pillar scatter into ONE buffer and their backwards -- captured once through the C ABI (fixed
+    buffers, no allocation inside) and replayed on new inputs, against the torch expressions on the same inputs."""
+    import torch.nn.functional as F
+    from mm_training_amd import _lib, synthetic
+    from mm_training_amd.lidar import hard_voxelize_mean_batch
+    L = _lib
+    dev = torch.device("cuda", 0)
+    B, N, H, W, ds, D, Cc, Cl, V = 2, 3, 64, 96, 16, 28, 16, 8, 6000
+    fH, fW, BN = H // ds, W // ds, 2 * 3
+    RANGE, VSIZE, ny = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.2, 0.2, 8.0], 512
+    imgs = torch.empty(B, 1, N, 3, H, W, device=dev)
+    flips = torch.zeros(BN, dtype=torch.uint8, device=dev)
+    norm = torch.empty(B, 1, N, H, W, 3, device=dev)
+    logits = torch.empty(BN, fH, fW, D, device=dev)                     # channels_last memory of [BN, D, fH, fW]
+    oracle = torch.empty(BN, fH, fW, D, device=dev)
+    probs, used = torch.empty_like(logits), torch.empty_like(logits)
+    g_probs, g_used, g_logits = torch.empty_like(logits), torch.empty_like(logits), torch.empty_like(logits)
+    cam = torch.empty(B, 128, 128, Cc, device=dev)
+    bda = torch.eye(4).repeat(B, 1, 1).to(dev)
+    bda[:, :2, :2] = torch.tensor([[0.96, -0.28], [0.28, 0.96]])
+    stacked = torch.empty(B, 128, 128, Cc + Cl, device=dev)
+    g_stacked = torch.empty_like(stacked)
+    g_cam = torch.empty_like(cam)
+    feats = torch.empty(B * V, Cl, device=dev)
+    g_feats = torch.empty_like(feats)
+    clouds = [synthetic.lidar_frame(9000, 5, RANGE, seed=70 + b).to(dev) for b in range(B)]
+    _, _, coors, _, _, table = hard_voxelize_mean_batch(clouds, VSIZE, RANGE, 15, V, 5, materialize_voxels=False, return_table=True)
+    mean3, std3 = L.float3((0.485, 0.456, 0.406)), L.float3((0.229, 0.224, 0.225))
+    import ctypes
+
+    def launch():
+        st = torch.cuda.current_stream().cuda_stream
+        L.call("mmt_normalize_flip_images", BN, 3, H, W, imgs.data_ptr(), ctypes.c_float(float(np.float32(1.0) / np.float32(255.0))), mean3, std3,
+               flips.data_ptr(), norm.data_ptr(), 1, st)
+        L.call("mmt_depth_softmax_forward", BN * fH * fW, D, logits.data_ptr(), D, L.DTYPE_F32, probs.data_ptr(), oracle.data_ptr(), D,
+               used.data_ptr(), L.DTYPE_F32, st)
+        L.call("mmt_depth_softmax_backward", BN * fH * fW, D, probs.data_ptr(), g_probs.data_ptr(), g_used.data_ptr(), L.DTYPE_F32,
+               oracle.data_ptr(), D, g_logits.data_ptr(), L.DTYPE_F32, st)
+        L.call("mmt_bev_warp_affine", B, 128, 128, Cc, bda.data_ptr(), cam.data_ptr(), Cc, stacked.data_ptr(), Cc + Cl, st)
+        L.call("mmt_pillar_scatter_nhwc_table_strided", Cl, B, ny, ny, V, 4, 4, feats.data_ptr(), table.data_ptr(),
+               stacked.data_ptr() + 4 * Cc, Cc + Cl, st)
+        g_cam.zero_()
+        L.call("mmt_bev_warp_affine_backward", B, 128, 128, Cc, bda.data_ptr(), g_stacked.data_ptr(), Cc + Cl, g_cam.data_ptr(), Cc, st)
+        L.call("mmt_pillar_scatter_nhwc_strided_backward", B * V, Cl, B, ny, ny, 4, 4, g_stacked.data_ptr() + 4 * Cc, Cc + Cl,
+               coors.data_ptr(), 0, g_feats.data_ptr(), st)
+
+    def fill(seed):
+        g = torch.Generator().manual_seed(seed)
+        imgs.copy_(torch.randint(0, 256, imgs.shape, generator=g).float())
+        flips.copy_((torch.rand(BN, generator=g) > 0.5).to(torch.uint8))
+        logits.copy_(torch.randn(logits.shape, generator=g) * 3)
+        hot = torch.randint(0, D, (BN, fH, fW), generator=g)
+        oracle.copy_(F.one_hot(hot, D).float() * (torch.rand(BN, fH, fW, 1, generator=g) < 0.5))
+        for t in (g_probs, g_used, cam, g_stacked, feats):
+            t.copy_(torch.rand(t.shape, generator=g) - 0.5)
+
+    def check():
+        torch.cuda.synchronize()
+        mean = torch.tensor((0.485, 0.456, 0.406), device=dev).view(1, 1, 1, 3, 1, 1)
+        std = torch.tensor((0.229, 0.224, 0.225), device=dev).view(1, 1, 1, 3, 1, 1)
+        want = (imgs / 255.0 - mean) / std
+        want = torch.where(flips.bool().view(B, 1, N, 1, 1, 1), want.flip(-1), want)
+        assert torch.equal(norm.permute(0, 1, 2, 5, 3, 4), want)
+        x = logits.detach().clone().requires_grad_(True)
+        p = x.softmax(-1)
+        fg = oracle.max(-1, keepdim=True).values > 0
+        u = torch.where(fg, oracle, p)
+        ((p * g_probs).sum() + (u * g_used).sum()).backward()
+        assert float((probs - p.detach()).abs().max()) <= 1e-6 and float((used - u.detach()).abs().max()) <= 1e-6
+        assert float((g_logits - x.grad).abs().max()) <= 1e-6
+        # the sampled scatter: rows of live voxels on cells (4i, 4j)
+        live = coors[:, 0] >= 0
+        sel = live & (coors[:, 2] % 4 == 0) & (coors[:, 3] % 4 == 0)
+        ref = torch.zeros(B, 128, 128, Cl, device=dev)
+        ref[coors[sel, 0].long(), (coors[sel, 2] // 4).long(), (coors[sel, 3] // 4).long()] = feats[sel]
+        assert torch.equal(stacked[..., Cc:], ref) and bool(sel.any())
+        gf = torch.zeros_like(feats)
+        gf[sel] = g_stacked[coors[sel, 0].long(), (coors[sel, 2] // 4).long(), (coors[sel, 3] // 4).long()][:, Cc:]
+        assert torch.equal(g_feats, gf)
+        from mm_training_amd.ops.bev_warp import bev_warp_affine
+        xc = cam.permute(0, 3, 1, 2).detach().clone().requires_grad_(True)
+        y = bev_warp_affine(xc, bda)
+        y.backward(g_stacked[..., :Cc].permute(0, 3, 1, 2))
+        assert torch.equal(stacked[..., :Cc], y.detach().permute(0, 2, 3, 1))
+        assert torch.equal(g_cam, xc.grad.permute(0, 2, 3, 1))
+
+    fill(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()                                     # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    check()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch()
+    for seed in (1, 2, 3):
+        fill(seed)
+        graph.replay()
+        check()
