@@ -57,6 +57,12 @@ def test_normalize_flip_images(mmt_lib, golden, channels_last):
     t = (raw[:, :, :, :3] / 255.0 - mean) / std
     t = torch.where(torch.from_numpy(g["flips"]).cuda().view(B, S, N, 1, 1, 1), t.flip(-1), t)
     assert torch.equal(out, t)
+    # another width (a four-pixels-per-thread variant of the kernel was measured slower -- 31.9 against 26.6 us at configs[3] -- and
+    # dropped: its 16-byte stores land 48 bytes apart; one pixel per thread writes whole 768-byte runs per wave)
+    narrow = raw[..., :46].contiguous()
+    tn = (narrow[:, :, :, :3] / 255.0 - mean) / std
+    tn = torch.where(torch.from_numpy(g["flips"]).cuda().view(B, S, N, 1, 1, 1), tn.flip(-1), tn)
+    assert torch.equal(normalize_flip_images(narrow, IMG_MEAN, IMG_STD, fl, channels_last=channels_last), tn)
     # no flags: plain normalize_images
     plain = normalize_flip_images(raw, IMG_MEAN, IMG_STD, None, channels_last=channels_last)
     assert torch.equal(plain, (raw[:, :, :, :3] / 255.0 - mean) / std)
