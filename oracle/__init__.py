@@ -320,3 +320,17 @@ def augment_images(images, depth_images, flips):
     labels = np.asarray(depth_images).copy()
     labels[flips] = labels[flips][:, :, ::-1, :]
     return flat.reshape(b, s, n, c, h, w), labels
+
+
+def depth_softmax(logits, depth_oracle=None):
+    """layers/backbones/lss_fpn.py:423 (`depth_feature[:, :D].softmax(1)`) and :427-438 (oracle-depth overwrite) in float64:
+    logits [B*N, D, fH, fW] -> (depth, depth_updated); a pixel whose oracle row has a positive entry
+    (`torch.max(depth_oracle, dim=1).values > 0.0`) takes the oracle row, every other pixel its softmax."""
+    x = np.asarray(logits, np.float64)
+    e = np.exp(x - x.max(1, keepdims=True))
+    depth = e / e.sum(1, keepdims=True)
+    if depth_oracle is None:
+        return depth, depth
+    o = np.asarray(depth_oracle, np.float64)
+    fg = o.max(1, keepdims=True) > 0.0
+    return depth, np.where(fg, o, depth)

@@ -37,7 +37,7 @@ SHAPES = [(24, 112, 16, 44), (12, 112, 32, 88), (2, 409, 11, 7), (3, 10, 5, 9), 
 
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("with_oracle", [False, True])
-def test_forward_and_backward_against_torch(mmt_lib, shape, with_oracle):
+def test_forward_and_backward_against_torch(mmt_lib, oracle_mod, shape, with_oracle):
     from mm_training_amd.ops.bev_geometry import depth_softmax
     BN, D, fH, fW = shape
     gen = torch.Generator().manual_seed(BN * 1000 + D)
@@ -64,6 +64,9 @@ def test_forward_and_backward_against_torch(mmt_lib, shape, with_oracle):
     if with_oracle:   # foreground rows ARE the label rows, bit for bit
         fg = (oracle.max(1, keepdim=True).values > 0).expand_as(oracle)
         assert torch.equal(used.detach().cpu()[fg], oracle[fg]) and bool(fg.any()) and not bool(fg.all())
+    # the oracle's float64 restatement (numpy)
+    od, ou = oracle_mod.depth_softmax(x.numpy(), oracle.numpy() if with_oracle else None)
+    assert np.abs(depth.detach().cpu().numpy() - od).max() <= TOL and np.abs(used.detach().cpu().numpy() - ou).max() <= TOL
     # fp64 on the CPU
     x64 = x.double().requires_grad_(True)
     d64, u64 = _ref_forward(x64, oracle.double() if with_oracle else None)
