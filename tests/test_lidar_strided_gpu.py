@@ -179,3 +179,7 @@ def test_model_forward_matches_the_full_canvas_path(mmt_lib):
     assert outs[0][3].keys() == outs[1][3].keys() and any("pillar_mlp" in k for k in outs[0][3])
     for k in outs[0][3]:
         assert torch.allclose(outs[0][3][k], outs[1][3][k], rtol=1e-3, atol=1e-6), k
+    # the encoder's own sampled form (no camera branch needed): forward_bev_strided == forward_bev sampled
+    enc = model.lidar_encoder
+    with torch.no_grad():
+        assert torch.equal(enc.forward_bev_strided(pcs, ny // H, nx // W), enc.forward_bev(pcs)[..., ::ny // H, ::nx // W])
