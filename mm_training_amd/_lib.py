@@ -203,7 +203,7 @@ def int3(values):
 # ---- small host-side integer arrays (per-sample row offsets) on the device ---------------------------------------------
 # The offsets depend on the point / box counts of the batch only.  `torch.tensor(list).to(device)` is a pageable host-to-device
 # copy: the host waits for it (and it shows up as a Memcpy HtoD in the middle of the launch queue).  Identical count patterns
-# reuse one read-only device tensor; a new pattern goes through pinned memory with an asynchronous copy.
+# reuse one read-only device tensor; a new pattern pays one blocking copy (it is then shared by calls on any stream).
 _INT_ARRAYS = {}
 
 
@@ -217,5 +217,7 @@ def device_ints(values, device):
             return torch.tensor(key[1], dtype=torch.int32).to(device, non_blocking=True)     # (a node of the graph, as before)
         if len(_INT_ARRAYS) >= 256:
             _INT_ARRAYS.pop(next(iter(_INT_ARRAYS)))
-        t = _INT_ARRAYS[key] = torch.tensor(key[1], dtype=torch.int32).pin_memory().to(device, non_blocking=True)
+        # a blocking copy, once per pattern: the tensor is shared by later calls on ANY stream, so it must be complete before it is
+        # handed out (an asynchronous copy would be ordered on the creating stream only)
+        t = _INT_ARRAYS[key] = torch.tensor(key[1], dtype=torch.int32, device=device)
     return t
