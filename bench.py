@@ -96,6 +96,8 @@ def parse(argv=None):
     ap.add_argument("--no-augment", action="store_true", help="skip augment_images (the reference's training_step always runs it)")
     ap.add_argument("--no-depth-oracle", action="store_true",
                     help="do not hand the depth labels to the model as its depth oracle (the reference does when use_depth_loss is set)")
+    ap.add_argument("--conv-overlap", default=None, choices=["off", "pair", "deferred"],
+                    help="weight gradients of the convolutions on a side HIP stream (ops/conv_overlap.py); default: MMT_CONV_OVERLAP or the TrainStep default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
     ap.add_argument("--hotpath-leg", action="store_true",
@@ -634,6 +636,8 @@ def train_main(args, rank, local_rank, world):
     np.random.seed(0)            # augment_images draws its per-camera flags from numpy's global generator (like the reference)
     if args.aten_softmax:
         os.environ["MMT_ATEN_SOFTMAX"] = "1"
+    if args.conv_overlap:
+        os.environ["MMT_CONV_OVERLAP"] = args.conv_overlap
     if args.no_augment:
         cfg["augment_images"] = False
     if args.no_depth_oracle:
@@ -693,6 +697,7 @@ def train_main(args, rank, local_rank, world):
                    "hot_path_storage_dtype": dtype,
                    # exps/mm_training_aim.py:258-259: both run inside every timed step
                    "augment_images": bool(ts.augment and cfg["use_cam"]), "depth_oracle": bool(ts.pass_depth_labels and cfg["use_cam"]),
+                   "conv_weight_gradients": ts.conv_overlap or "same stream",
                    "distributed": dinfo},
     }
     fb = 2 if dtype == "bf16" else 4

@@ -116,6 +116,17 @@ class TrainStep(nn.Module):
         if self.use_cam:
             self.model.backbone.hot_path_dtype = cfg.get("hot_path_dtype", "f32")
         self.net = self.model
+        # weight gradients of the convolutions on a side HIP stream, joined once at the end of the backward pass
+        # (ops/conv_overlap.py: 68.6 -> 67.2 ms at configs[3]).  Under DDP the bucket hooks read each gradient inside the backward
+        # pass, which would need a join per layer ("pair": measured slower than no overlap) -- so world size 1 only.
+        self.conv_overlap = None
+        overlap = os.environ.get("MMT_CONV_OVERLAP", "deferred")
+        if overlap == "deferred" and world_size > 1:
+            overlap = "off"
+        if device.type == "cuda" and overlap != "off":
+            from ..ops import conv_overlap
+            conv_overlap.enable(self.model, overlap)
+            self.conv_overlap = overlap
         if world_size > 1:
             # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183; the
             # reference survives on Lightning's find_unused_parameters=True, which walks the autograd

@@ -1,0 +1,128 @@
+"""Convolution whose two backward halves run on two HIP streams.
+
+``aten::convolution_backward`` launches the data-gradient kernel and then the weight-gradient kernel (plus MIOpen's zero-fill
+of a split-K weight gradient) one after the other on one stream.  Neither depends on the other -- both read ``grad_out`` --
+and at the activation sizes of this model (24 x 16 x 44 rows on the camera side, 4 x 128 x 128 on the BEV side) a single
+implicit-GEMM launch leaves a tail of idle CUs: the weight gradient goes to a side stream here and overlaps the data
+gradient.  Same kernels, same arithmetic, same results bit for bit (MIOpen picks its solvers per problem, not per stream).
+
+  mode "pair"     : the side stream joins the main stream before backward returns -- safe under every consumer of the
+                    gradient (autograd accumulation, DDP's bucket hooks);
+  mode "deferred" : no join per layer: the weight gradients queue up on the side stream and fill whatever the main stream
+                    leaves idle; ONE join at the end of the backward pass (an autograd-engine callback queued by the first
+                    layer that runs, so ``loss.backward()`` returns with the main stream already waiting for the side stream
+                    -- any caller of ``backward`` is covered, ``join()`` exists for code that drives the Function by hand).
+                    Only valid when nothing reads a weight gradient before that join: ``.grad`` is None at accumulation time
+                    (``zero_grad(set_to_none=True)``: AccumulateGrad then takes the tensor without launching anything).  A
+                    layer whose weight already holds a gradient (gradient accumulation) joins on the spot instead.  DDP's
+                    bucket hooks read the gradient inside the backward pass: TrainStep uses this mode at world size 1 only.
+
+Measured at BASELINE configs[3] (30 steps, alternating runs on one box): same stream 68.6 ms, pair 72.7 ms (two cross-stream
+event waits per layer cost more than the overlap returns), deferred 67.2 ms.
+"""
+import torch
+from torch.autograd import Function
+
+_side = {}
+_state = {"join_queued": False}
+
+
+def side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def join(device=None):
+    """Main stream waits for every weight gradient queued on the side stream (deferred mode: once per backward)."""
+    for (kind, index), s in _side.items():
+        if device is None or (kind, index) == (device.type, device.index):
+            torch.cuda.current_stream(torch.device(kind, index)).wait_stream(s)
+
+
+def _end_of_backward():
+    _state["join_queued"] = False
+    join()
+
+
+class _ConvOverlap(Function):
+    """conv2d(x, w, b) computed in `dtype` (None: as given; torch.bfloat16 under autocast -- the casts live INSIDE the Function so that
+    the weight gradient comes back in the parameter's own dtype from the side stream, with no main-stream cast node behind it)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation, groups, dtype, mode):
+        xc = x if dtype is None else x.to(dtype)
+        wc = w if dtype is None else w.to(dtype)
+        bc = b if (b is None or dtype is None) else b.to(dtype)
+        ctx.save_for_backward(xc, wc, w)
+        ctx.conf = (stride, padding, dilation, groups, b is not None, x.dtype, b.dtype if b is not None else None, mode)
+        return torch.ops.aten.convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, leaf = ctx.saved_tensors
+        stride, padding, dilation, groups, has_b, x_dtype, b_dtype, mode = ctx.conf
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        zeros = [0] * len(stride)
+        gx = gw = gb = None
+        deferred = False
+        main = torch.cuda.current_stream(gy.device)
+        side = side_stream(gy.device)
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        if need_w or has_b:
+            side.wait_stream(main)                       # grad_out (and, in the first layer of a backward, the saved tensors) are ready
+            with torch.cuda.stream(side):
+                _, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
+                                                                False, zeros, groups, [False, need_w, has_b])
+                if gw is not None and gw.dtype != leaf.dtype:
+                    gw = gw.to(leaf.dtype)
+                if gb is not None and gb.dtype != b_dtype:
+                    gb = gb.to(b_dtype)
+            deferred = mode == "deferred" and leaf.grad is None
+            if deferred:
+                # grad_out / x were allocated on the main stream: their blocks must not be handed to another main-stream kernel
+                # while the side stream still reads them (a join on the spot makes that unnecessary)
+                gy.record_stream(side)
+                x.record_stream(side)
+                if w is not leaf:
+                    w.record_stream(side)
+                if not _state["join_queued"]:
+                    _state["join_queued"] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        if need_x:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, stride, padding, dilation, False, zeros, groups,
+                                                     [True, False, False])[0]
+            if gx.dtype != x_dtype:
+                gx = gx.to(x_dtype)
+        if (need_w or has_b) and not deferred:
+            main.wait_stream(side)
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+class OverlapConv2d(torch.nn.Conv2d):
+    """nn.Conv2d with the two-stream backward (same parameters, same state_dict).  `enable` re-classes existing modules in
+    place -- no bound method stored on the instance, so copy.deepcopy of the model keeps working."""
+    _mmt_overlap_mode = "pair"
+
+    def forward(self, x):
+        if x.is_cuda and torch.is_grad_enabled() and self.padding_mode == "zeros" and not isinstance(self.padding, str):
+            dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+            with torch.autocast("cuda", enabled=False):
+                return _ConvOverlap.apply(x, self.weight, self.bias, list(self.stride), list(self.padding), list(self.dilation),
+                                          self.groups, dtype, self._mmt_overlap_mode)
+        return super().forward(x)
+
+
+def enable(model, mode="pair"):
+    """Route every nn.Conv2d of `model` through the two-stream backward.  Returns the number of modules switched."""
+    if mode not in ("pair", "deferred"):
+        raise ValueError("conv overlap mode must be 'pair' or 'deferred', got %r" % (mode,))
+    n = 0
+    for m in model.modules():
+        if type(m) in (torch.nn.Conv2d, OverlapConv2d):
+            m.__class__ = OverlapConv2d
+            m._mmt_overlap_mode = mode
+            n += 1
+    return n

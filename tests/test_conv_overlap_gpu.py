@@ -1,0 +1,101 @@
+"""GPU: ops/conv_overlap.py -- the weight-gradient half of a convolution's backward on a side stream.  Same ATen / MIOpen calls as
+nn.Conv2d's own backward, so the output is the same bits and the gradients agree to the last bits (MIOpen's split-K weight
+gradients use fp32 atomics), in both modes, for the layer kinds the model
+holds (1x1, 3x3 strided, dilated, grouped, with and without bias, channels_last), and a training step must produce the same
+losses with the overlap on."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # cin, cout, k, stride, padding, dilation, groups, bias
+    (16, 32, 1, 1, 0, 1, 1, False),
+    (16, 32, 3, 2, 1, 1, 1, False),
+    (32, 32, 3, 1, 6, 6, 1, True),
+    (32, 64, 3, 1, 1, 1, 4, True),
+    (3, 16, 7, 2, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("mode", ["pair", "deferred"])
+def test_gradients_are_autograds(mmt_lib, mode):
+    from mm_training_amd.ops import conv_overlap
+    torch.manual_seed(0)
+    for cin, cout, k, s, p, d, g, bias in CASES:
+        ref = torch.nn.Conv2d(cin, cout, k, s, p, d, g, bias).cuda().to(memory_format=torch.channels_last)
+        new = copy.deepcopy(ref)
+        assert conv_overlap.enable(new, mode) == 1
+        x = torch.randn(4, cin, 24, 40, device="cuda").contiguous(memory_format=torch.channels_last)
+        outs = []
+        for m in (ref, new):
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+            # (deferred mode: the end-of-backward callback has made the main stream wait for the side stream)
+            outs.append((y.detach(), xi.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone() if bias else None))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            assert (a is None) == (b is None)
+            if a is not None:               # MIOpen's split-K weight gradients add with fp32 atomics: run-to-run last-bit differences
+                assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), (mode, cin, cout, k)
+        # gradient accumulation: the weight already holds a gradient -> the layer joins on the spot, and the sum is right
+        xi = x.clone().requires_grad_(True)
+        new(xi).sum().backward()
+        ref(xi).sum().backward()
+        assert float((new.weight.grad - ref.weight.grad).abs().max()) <= 1e-5 * float(ref.weight.grad.abs().max())
+    # an input that needs no gradient (the first layer of a net): only the weight half runs
+    conv = torch.nn.Conv2d(3, 8, 3, 1, 1).cuda()
+    conv_overlap.enable(conv, mode)
+    conv(torch.randn(2, 3, 16, 16, device="cuda")).sum().backward()
+    assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
+    # under autocast the casts happen inside the Function: bf16 arithmetic, gradients back in the parameters' / input's own dtype
+    ref = torch.nn.Conv2d(16, 32, 3, 1, 1, bias=True).cuda().to(memory_format=torch.channels_last)
+    new = copy.deepcopy(ref)
+    conv_overlap.enable(new, mode)
+    x = torch.randn(4, 16, 24, 40, device="cuda").contiguous(memory_format=torch.channels_last)
+    got = []
+    for m in (ref, new):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        assert y.dtype == torch.bfloat16
+        y.float().square().sum().backward()
+        assert xi.grad.dtype == torch.float32 and m.weight.grad.dtype == torch.float32 and m.bias.grad.dtype == torch.float32
+        got.append((y.detach().float(), xi.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone()))
+    assert torch.equal(got[0][0], got[1][0])
+    for a, b in zip(got[0][1:], got[1][1:]):
+        assert float((a - b).abs().max()) <= 1e-2 * float(a.abs().max())
+    # no-grad / eval calls fall through to nn.Conv2d
+    with torch.no_grad():
+        assert conv(torch.randn(2, 3, 16, 16, device="cuda")).shape == (2, 8, 16, 16)
+    with pytest.raises(ValueError):
+        conv_overlap.enable(conv, "sideways")
+
+
+@pytest.mark.parametrize("mode", ["pair", "deferred"])
+def test_training_step_losses_do_not_change(mmt_lib, mode, monkeypatch):
+    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
+    cfg = make_config("tiny")
+    dev = torch.device("cuda", 0)
+    losses = {}
+    for key in ("off", mode):
+        monkeypatch.setenv("MMT_CONV_OVERLAP", key)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        ts = TrainStep(cfg, dev)
+        assert ts.conv_overlap == (None if key == "off" else mode)
+        ts.model.eval()                                   # no dropout; BatchNorm on running statistics: the steps compare exactly
+        ts.model.backbone.fused_lift_splat = False        # deterministic pooling (no fp32 atomics)
+        batch = synthetic_batch(cfg, dev, seed=3)
+        imgs, mats, pcs, boxes, labels = batch
+        batch = (imgs, dict(mats, calibration_id=("overlap", 0)), pcs, boxes, labels)
+        losses[key] = [float(ts(batch)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses[mode]))
+    # same kernels in another launch order on two streams: the DCN col2im atomics are the only source of a last-bit difference
+    for a, b in zip(losses["off"], losses[mode]):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), losses
+    assert losses[mode][-1] < losses[mode][0]

@@ -2,6 +2,8 @@
 lift-splat, and the forward / backward algorithmic-byte formulas of bench.py against their closed forms."""
 import math
 
+import pytest
+
 import torch
 
 
@@ -138,3 +140,27 @@ def test_loaded_frustum_reaches_the_camera_form():
     sd["frustum"][3, 1, 2, 0] += 1.0                    # one point off the grid of axes: no camera form for this frustum
     m.load_state_dict(sd)
     assert not m._has_frustum_axes and torch.equal(m.frustum, sd["frustum"])
+
+
+def test_conv_overlap_switch_is_transparent_on_the_host():
+    """ops/conv_overlap.py re-classes nn.Conv2d modules in place: same parameters and state_dict keys, deepcopy-safe, CPU /
+    no-grad calls fall through to nn.Conv2d, and TrainStep picks the mode by world size (deferred needs no DDP hooks)."""
+    import copy
+    import torch
+    from mm_training_amd.ops import conv_overlap
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.ConvTranspose2d(4, 2, 2, 2))
+    keys = list(net.state_dict())
+    x = torch.randn(2, 3, 8, 8)
+    want = net(x)
+    assert conv_overlap.enable(net, "deferred") == 1              # the transposed convolution is left alone
+    assert isinstance(net[0], torch.nn.Conv2d) and type(net[0]).__name__ == "OverlapConv2d"
+    assert list(net.state_dict()) == keys
+    assert torch.equal(net(x), want)                              # CPU input: nn.Conv2d's own forward
+    clone = copy.deepcopy(net)
+    clone[0].weight.data.zero_()
+    assert not torch.equal(clone(x), want) and torch.equal(net(x), want)      # the copy runs on ITS parameters
+    assert conv_overlap.enable(net, "pair") == 1 and net[0]._mmt_overlap_mode == "pair"
+    with pytest.raises(ValueError):
+        conv_overlap.enable(net, "both")
+    conv_overlap.join()                                           # no side stream yet: nothing to wait for
