@@ -698,6 +698,7 @@ def train_main(args, rank, local_rank, world):
                    # exps/mm_training_aim.py:258-259: both run inside every timed step
                    "augment_images": bool(ts.augment and cfg["use_cam"]), "depth_oracle": bool(ts.pass_depth_labels and cfg["use_cam"]),
                    "conv_weight_gradients": ts.conv_overlap or "same stream",
+                   "task_head_streams": int(ts.model.head.task_streams),
                    "distributed": dinfo},
     }
     fb = 2 if dtype == "bf16" else 4

@@ -33,7 +33,7 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 8
+#define MMT_ABI_VERSION 9   /* 9: mmt_bn_relu_forward_ex / _backward_ex (bf16 activations); additive */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -665,6 +665,15 @@ int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float *residual,
 int mmt_bn_relu_backward(int64_t R, int C, const float *x, const float *y, const float *grad_y,
                          const float *save, int relu, int has_residual, float *workspace, float *grad_x,
                          float *grad_residual, float *grad_weight, float *grad_bias, void *stream);
+/* ABI 9: the same with the ACTIVATIONS (x, residual, y and their gradients) stored as act_dtype = MMT_DTYPE_F32 or MMT_DTYPE_BF16
+ * (8-byte aligned rows then); statistics, weight / bias, running statistics, save and every sum stay fp32 -- the arithmetic of
+ * batch_norm inside a torch.autocast(bf16) region (BASELINE configs[4]), which otherwise runs through MIOpen's NHWC batch norm. */
+int mmt_bn_relu_forward_ex(int64_t R, int C, const void *x, const void *residual, const float *weight,
+                           const float *bias, float *running_mean, float *running_var, float momentum,
+                           float eps, int relu, float *workspace, float *save, void *y, int act_dtype, void *stream);
+int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const void *y, const void *grad_y,
+                            const float *save, int relu, int has_residual, float *workspace, void *grad_x,
+                            void *grad_residual, float *grad_weight, float *grad_bias, int act_dtype, void *stream);
 
 #ifdef __cplusplus
 }

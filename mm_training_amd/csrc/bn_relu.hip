@@ -16,6 +16,9 @@
 // in LDS once per workgroup and leave as one partial row per workgroup, summed (in double) by the
 // finalize kernel.  Loads in the row loops are
 // unconditional (clamped row index, zero weight) so several rows stay in flight per lane.
+// Activation type AT = float or bf16_t (the *_ex entry points; bf16 = the autocast region of BASELINE configs[4]): x, residual, y
+// and their gradients are stored in AT (4 channels per lane = 16 or 8 bytes), the statistics, the affine coefficients and all
+// arithmetic stay fp32 -- what autocast does for batch_norm -- so the bf16 nets no longer go through MIOpen's NHWC batch norm.
 #include "mmt_common.h"
 
 namespace {
@@ -36,22 +39,39 @@ struct BnArgs {
     BnGeom g;
     int relu, has_res;
     float momentum, eps;
-    const float *x, *res, *y_in, *dy;
+    const void *x, *res, *y_in, *dy;   // activations, AT
     const float *weight, *bias;
     float *running_mean, *running_var;
     float *acc;            // [blocks, 2*C] per-workgroup partial sums (scratch)
     float *save_mean, *save_rstd;
     float *scale, *shift;  // [C] each (workspace): y = x * scale + shift
-    float *y, *dx, *dres, *dweight, *dbias;
+    void *y, *dx, *dres;               // activations, AT
+    float *dweight, *dbias;
     float *coef;           // [2*C] backward: mean(dy'), mean(dy' * xhat)
 };
 
 constexpr int kMaxKC = 8;  // C <= 8192
 
+// the four channels of float4 column `i` of an activation tensor
+template <typename AT>
+__device__ __forceinline__ float4 ld4(const void *p, int64_t i) {
+    if constexpr (sizeof(AT) == 4) {
+        return reinterpret_cast<const float4 *>(p)[i];
+    } else {
+        const uint2 t = reinterpret_cast<const uint2 *>(p)[i];
+        return make_float4(bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y));
+    }
+}
+template <typename AT>
+__device__ __forceinline__ void st4(void *p, int64_t i, float4 v) {
+    if constexpr (sizeof(AT) == 4) reinterpret_cast<float4 *>(p)[i] = v;
+    else reinterpret_cast<uint2 *>(p)[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+
 // Sum of (a, b) per channel over this workgroup's rows -> partial[blockIdx][0:C], [C:2C] (plain stores:
 // 2*C same-address atomics per workgroup cost 150 us per launch, measured).
 // MODE 0: a = x, b = x*x.   MODE 1: a = dy', b = dy' * xhat  (dy' = relu-masked dy).
-template <int MODE>
+template <int MODE, typename AT>
 __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t rows_per_block) {
     __shared__ float4 red[2][kBlock];
     const BnGeom g = a.g;
@@ -78,11 +98,11 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
             for (int u = 0; u < kRowsInFlight; ++u) {
                 const int64_t r = r0 + (int64_t)u * g.rpi;
                 wgt[u] = r < r_end ? 1.f : 0.f;
-                const int64_t off = ((r < r_end ? r : last) * g.C4 + col) * 4;
-                vx[u] = *reinterpret_cast<const float4 *>(a.x + off);
+                const int64_t off = (r < r_end ? r : last) * g.C4 + col;
+                vx[u] = ld4<AT>(a.x, off);
                 if (MODE == 1) {
-                    vd[u] = *reinterpret_cast<const float4 *>(a.dy + off);
-                    if (a.has_res) vy[u] = *reinterpret_cast<const float4 *>(a.y_in + off);
+                    vd[u] = ld4<AT>(a.dy, off);
+                    if (a.has_res) vy[u] = ld4<AT>(a.y_in, off);
                 }
             }
 #pragma unroll
@@ -110,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
                     }
                     if (a.dres && wgt[u] != 0.f) {      // residual variant: the masked gradient IS grad_residual
                         const int64_t r = r0 + (int64_t)u * g.rpi;
-                        *reinterpret_cast<float4 *>(a.dres + (r * g.C4 + col) * 4) = d;
+                        st4<AT>(a.dres, r * g.C4 + col, d);
                     }
                     sa.x += d.x; sa.y += d.y; sa.z += d.z; sa.w += d.w;
                     sb.x += d.x * ((vx[u].x - mean.x) * rstd.x);
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(kFinBlock) void bn_bwd_finalize_kernel(BnArgs a, in
 }
 
 // MODE 0: y = relu(x * scale + shift [+ res]).   MODE 1: dx = scale * (dy' - c1 - xhat * c2) [, dres = dy'].
-template <int MODE>
+template <int MODE, typename AT>
 __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
     const int C4 = a.g.C4;
     const int64_t total = a.R * C4;
@@ -221,12 +241,12 @@ __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             idx[u] = i < total ? i : total - 1;              // clamped: unconditional loads
-            vx[u] = reinterpret_cast<const float4 *>(a.x)[idx[u]];
+            vx[u] = ld4<AT>(a.x, idx[u]);
             if (MODE == 0) {
-                if (a.has_res) vr[u] = reinterpret_cast<const float4 *>(a.res)[idx[u]];
+                if (a.has_res) vr[u] = ld4<AT>(a.res, idx[u]);
             } else {
-                vd[u] = reinterpret_cast<const float4 *>(a.dy)[idx[u]];
-                if (a.has_res) vr[u] = reinterpret_cast<const float4 *>(a.y_in)[idx[u]];
+                vd[u] = ld4<AT>(a.dy, idx[u]);
+                if (a.has_res) vr[u] = ld4<AT>(a.y_in, idx[u]);
             }
         }
 #pragma unroll
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
                 float4 y = make_float4(vx[u].x * sc.x + sh.x, vx[u].y * sc.y + sh.y, vx[u].z * sc.z + sh.z, vx[u].w * sc.w + sh.w);
                 if (a.has_res) { y.x += vr[u].x; y.y += vr[u].y; y.z += vr[u].z; y.w += vr[u].w; }
                 if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-                reinterpret_cast<float4 *>(a.y)[i] = y;
+                st4<AT>(a.y, i, y);
             } else {
                 const float4 mean = *reinterpret_cast<const float4 *>(a.save_mean + c);
                 const float4 rstd = *reinterpret_cast<const float4 *>(a.save_rstd + c);
@@ -260,13 +280,13 @@ __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
                         if (!(vx[u].w * sc.w + sh.w > 0.f)) d.w = 0.f;
                     }
                 }
-                if (a.dres) reinterpret_cast<float4 *>(a.dres)[i] = d;
+                if (a.dres) st4<AT>(a.dres, i, d);
                 float4 o;
                 o.x = sc.x * (d.x - c1.x - (vx[u].x - mean.x) * rstd.x * c2.x);
                 o.y = sc.y * (d.y - c1.y - (vx[u].y - mean.y) * rstd.y * c2.y);
                 o.z = sc.z * (d.z - c1.z - (vx[u].z - mean.z) * rstd.z * c2.z);
                 o.w = sc.w * (d.w - c1.w - (vx[u].w - mean.w) * rstd.w * c2.w);
-                reinterpret_cast<float4 *>(a.dx)[i] = o;
+                st4<AT>(a.dx, i, o);
             }
         }
     }
@@ -302,67 +322,107 @@ void reduce_grid(const BnGeom &g, int64_t R, int *blocks, int64_t *rows_per_bloc
 
 extern "C" int64_t mmt_bn_workspace_elems(int C) { return C > 0 ? (2ll * kMaxPartialBlocks + 2) * C : -1; }
 
-extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float *residual, const float *weight,
-                                   const float *bias, float *running_mean, float *running_var, float momentum,
-                                   float eps, int relu, float *workspace, float *save, float *y, void *stream) {
+namespace {
+
+template <typename AT>
+void launch_forward(const BnArgs &a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
+    hipLaunchKernelGGL((bn_reduce_kernel<0, AT>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
+    if ((*rc = mmt::check_launch("bn_relu_forward(stats)"))) return;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)mmt::ceil_div(a.C, 64)), dim3(kFinBlock), 0, st, a, blocks);
+    if ((*rc = mmt::check_launch("bn_relu_forward(finalize)"))) return;
+    hipLaunchKernelGGL((bn_map_kernel<0, AT>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
+    *rc = mmt::check_launch("bn_relu_forward(apply)");
+}
+
+template <typename AT>
+void launch_backward(BnArgs a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
+    hipLaunchKernelGGL((bn_reduce_kernel<1, AT>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
+    if ((*rc = mmt::check_launch("bn_relu_backward(reduce)"))) return;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)mmt::ceil_div(a.C, 64)), dim3(kFinBlock), 0, st, a, blocks);
+    if ((*rc = mmt::check_launch("bn_relu_backward(finalize)"))) return;
+    if (a.dres) {
+        // the reduce pass has written grad_residual = masked grad_y: the dx pass reads that instead of
+        // grad_y + y (7 passes instead of 8 for the residual variant)
+        a.dy = a.dres; a.dres = nullptr; a.relu = 0; a.has_res = 0;
+    }
+    hipLaunchKernelGGL((bn_map_kernel<1, AT>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
+    *rc = mmt::check_launch("bn_relu_backward(dx)");
+}
+
+}  // namespace
+
+extern "C" int mmt_bn_relu_forward_ex(int64_t R, int C, const void *x, const void *residual, const float *weight,
+                                      const float *bias, float *running_mean, float *running_var, float momentum,
+                                      float eps, int relu, float *workspace, float *save, void *y, int act_dtype, void *stream) {
     MMT_REQUIRE_PTR(x);
     MMT_REQUIRE_PTR(workspace);
     MMT_REQUIRE_PTR(save);
     MMT_REQUIRE_PTR(y);
+    if (act_dtype != MMT_DTYPE_F32 && act_dtype != MMT_DTYPE_BF16)
+        return mmt::fail(MMT_ERR_BAD_FLAG, "bn_relu_forward: unknown activation dtype %d", act_dtype);
     float *save_mean = save, *save_rstd = save + C;
     BnArgs a = {};
     if (int rc = geometry("bn_relu_forward", R, C, &a.g)) return rc;
-    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)workspace | (uintptr_t)save) & 15)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_forward: buffers must be 16-byte aligned");
+    const uintptr_t act_mask = act_dtype == MMT_DTYPE_F32 ? 15 : 7;      // one lane moves 4 channels: 16 or 8 bytes
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & act_mask) || (((uintptr_t)workspace | (uintptr_t)save) & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_forward: buffers must be 16-byte aligned (bf16 activations: 8)");
     a.R = R; a.C = C; a.relu = relu; a.has_res = residual != nullptr; a.momentum = momentum; a.eps = eps;
     a.x = x; a.res = residual; a.weight = weight; a.bias = bias; a.running_mean = running_mean; a.running_var = running_var;
     a.acc = workspace + 2 * C; a.coef = workspace; a.scale = save + 2 * C; a.shift = save + 3 * C;
     a.save_mean = save_mean; a.save_rstd = save_rstd; a.y = y;
-    hipStream_t st = (hipStream_t)stream;
     int blocks; int64_t rpb;
     reduce_grid(a.g, R, &blocks, &rpb);
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
-    if (int rc = mmt::check_launch("bn_relu_forward(stats)")) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)mmt::ceil_div(C, 64)), dim3(kFinBlock), 0, st, a, blocks);
-    if (int rc = mmt::check_launch("bn_relu_forward(finalize)")) return rc;
-    hipLaunchKernelGGL(bn_map_kernel<0>, dim3(mmt::stream_grid(mmt::ceil_div(R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
-    return mmt::check_launch("bn_relu_forward(apply)");
+    int rc = 0;
+    if (act_dtype == MMT_DTYPE_F32) launch_forward<float>(a, blocks, rpb, (hipStream_t)stream, &rc);
+    else launch_forward<bf16_t>(a, blocks, rpb, (hipStream_t)stream, &rc);
+    return rc;
 }
 
-extern "C" int mmt_bn_relu_backward(int64_t R, int C, const float *x, const float *y, const float *grad_y,
-                                    const float *save, int relu, int has_residual, float *workspace,
-                                    float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias,
-                                    void *stream) {
+extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float *residual, const float *weight,
+                                   const float *bias, float *running_mean, float *running_var, float momentum,
+                                   float eps, int relu, float *workspace, float *save, float *y, void *stream) {
+    return mmt_bn_relu_forward_ex(R, C, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, workspace, save, y,
+                                  MMT_DTYPE_F32, stream);
+}
+
+extern "C" int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const void *y, const void *grad_y,
+                                       const float *save, int relu, int has_residual, float *workspace,
+                                       void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
+                                       int act_dtype, void *stream) {
     MMT_REQUIRE_PTR(x);
     MMT_REQUIRE_PTR(grad_y);
     MMT_REQUIRE_PTR(save);
     MMT_REQUIRE_PTR(workspace);
+    if (act_dtype != MMT_DTYPE_F32 && act_dtype != MMT_DTYPE_BF16)
+        return mmt::fail(MMT_ERR_BAD_FLAG, "bn_relu_backward: unknown activation dtype %d", act_dtype);
     const float *save_mean = save, *save_rstd = save + C;
     MMT_REQUIRE_PTR(grad_x);
     if (relu && has_residual) MMT_REQUIRE_PTR(y);
+    if (has_residual) MMT_REQUIRE_PTR(grad_residual);
     BnArgs a = {};
     if (int rc = geometry("bn_relu_backward", R, C, &a.g)) return rc;
-    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_residual | (uintptr_t)workspace |
-         (uintptr_t)save) & 15)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_backward: buffers must be 16-byte aligned");
+    const uintptr_t act_mask = act_dtype == MMT_DTYPE_F32 ? 15 : 7;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_residual) & act_mask) ||
+        (((uintptr_t)workspace | (uintptr_t)save) & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_backward: buffers must be 16-byte aligned (bf16 activations: 8)");
     a.R = R; a.C = C; a.relu = relu; a.has_res = (relu && has_residual) ? 1 : 0;
     a.x = x; a.y_in = y; a.dy = grad_y;
     a.acc = workspace + 2 * C; a.coef = workspace;
     a.scale = const_cast<float *>(save) + 2 * C; a.shift = const_cast<float *>(save) + 3 * C;
     a.save_mean = const_cast<float *>(save_mean); a.save_rstd = const_cast<float *>(save_rstd);
     a.dx = grad_x; a.dres = has_residual ? grad_residual : nullptr; a.dweight = grad_weight; a.dbias = grad_bias;
-    hipStream_t st = (hipStream_t)stream;
     int blocks; int64_t rpb;
     reduce_grid(a.g, R, &blocks, &rpb);
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
-    if (int rc = mmt::check_launch("bn_relu_backward(reduce)")) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)mmt::ceil_div(C, 64)), dim3(kFinBlock), 0, st, a, blocks);
-    if (int rc = mmt::check_launch("bn_relu_backward(finalize)")) return rc;
-    if (a.dres) {
-        // the reduce pass has written grad_residual = masked grad_y: the dx pass reads that instead of
-        // grad_y + y (7 passes instead of 8 for the residual variant)
-        a.dy = a.dres; a.dres = nullptr; a.relu = 0; a.has_res = 0;
-    }
-    hipLaunchKernelGGL(bn_map_kernel<1>, dim3(mmt::stream_grid(mmt::ceil_div(R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
-    return mmt::check_launch("bn_relu_backward(dx)");
+    int rc = 0;
+    if (act_dtype == MMT_DTYPE_F32) launch_backward<float>(a, blocks, rpb, (hipStream_t)stream, &rc);
+    else launch_backward<bf16_t>(a, blocks, rpb, (hipStream_t)stream, &rc);
+    return rc;
+}
+
+extern "C" int mmt_bn_relu_backward(int64_t R, int C, const float *x, const float *y, const float *grad_y,
+                                    const float *save, int relu, int has_residual, float *workspace,
+                                    float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias,
+                                    void *stream) {
+    return mmt_bn_relu_backward_ex(R, C, x, y, grad_y, save, relu, has_residual, workspace, grad_x, grad_residual, grad_weight, grad_bias,
+                                   MMT_DTYPE_F32, stream);
 }

@@ -20,6 +20,8 @@ from torch import nn
 
 from .. import synthetic
 from ..models.bev_depth import BEVDepthLiDAR
+from ..ops.bn_relu import _supported as bn_supported
+from ..ops.bn_relu import bn_act
 from ..ops.train_targets import camera_flags_to_device, depth_labels, hflip, normalize_flip_images
 
 IMG_MEAN = (0.485, 0.456, 0.406)
@@ -69,6 +71,8 @@ def _batched_bn_counters(model):
 
     def bn_forward(self, x):
         if self.training and self.track_running_stats and self.momentum is not None:
+            if x.is_cuda and torch.is_autocast_enabled() and bn_supported(self, x):
+                return bn_act(self, x, relu=False)       # fused fp32 kernels, not MIOpen's NHWC batch norm (ops/bn_relu.py)
             return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
         return nn.BatchNorm2d.forward(self, x)
 

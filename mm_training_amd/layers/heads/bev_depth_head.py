@@ -9,6 +9,8 @@ semantics (bev_depth_head.py:85-111, :113-254, :256-312).  Host-side differences
   * the loss normalisers of all tasks are reduced across ranks with ONE all-reduce and
     stay on the device -- no ``.item()`` round trips (:273-276, :300-301).
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -48,6 +50,27 @@ def gaussian_radius(height, width, min_overlap=0.5):
 
 def _conv_module(cin, cout, k):
     return ConvBNAct(nn.Conv2d(cin, cout, k, 1, k // 2, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+_TASK_STREAMS = {}
+
+
+class _Fork(torch.autograd.Function):
+    """x -> n aliases of x, one per stream; backward: the sum of the n gradients, formed on the stream the fork ran on.  Every
+    alias is consumed on ONE stream, so each gradient slot of this node has a single producer stream and autograd's plain
+    cross-stream hand-over applies; the branches' gradients are never accumulated across streams into one buffer."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        total = None
+        for g in grads:
+            if g is not None:
+                total = g if total is None else total + g
+        return total, None
 
 
 class SeparateHead(nn.Module):
@@ -92,6 +115,8 @@ class BEVDepthHead(nn.Module):
         self.trunk = ResNet(**bb)
         self.neck = SECONDFPN(**{k: v for k, v in dict(bev_neck_conf).items() if k != 'type'})
         self.shared_conv = _conv_module(in_channels, share_conv_channel, 3)
+        # HIP streams the task heads are dealt to in training (see _forward_tasks_on_streams); 0 / 1 = the caller's stream only
+        self.task_streams = int(os.environ.get("MMT_HEAD_STREAMS", "2"))
         self.task_heads = nn.ModuleList()
         for n in self.num_classes:
             heads = dict(common_heads)
@@ -103,7 +128,36 @@ class BEVDepthHead(nn.Module):
     def forward(self, x):
         fpn_output = self.neck(self.trunk(x))
         x = self.shared_conv(fpn_output[0])
+        if self.task_streams > 1 and x.is_cuda and torch.is_grad_enabled():
+            return self._forward_tasks_on_streams(x, self.task_streams)
         return tuple([task(x)] for task in self.task_heads)
+
+    def _forward_tasks_on_streams(self, x, nstreams):
+        """The task heads (24 independent conv-bn-relu-conv branches on one 4 x 64 x 128 x 128 map, ~55 us per kernel) dealt to
+        `nstreams` HIP streams: their kernels fill each other's launch gaps and tails.  autograd runs every backward node on its
+        forward stream (and orders the streams itself, including the gradient accumulation of the parameters), so the backward
+        overlaps the same way.  Measured at BASELINE configs[3]: 2 streams 67.3 -> 66.1 ms per step; 3, 4, 8 streams no gain --
+        a process has four hardware queues, and the main stream, the weight-gradient stream (ops/conv_overlap.py) or RCCL's
+        stream, and these two fill them (GPU_MAX_HW_QUEUES=8 made every variant slower)."""
+        main = torch.cuda.current_stream(x.device)
+        key = (x.device.index, nstreams)
+        if key not in _TASK_STREAMS:                 # per process and device, not per module (a module stays deepcopy- / pickle-able)
+            _TASK_STREAMS[key] = [torch.cuda.Stream(device=x.device) for _ in range(nstreams)]
+        streams = _TASK_STREAMS[key]
+        outs = []
+        aliases = _Fork.apply(x, nstreams) if x.requires_grad else (x,) * nstreams
+        for i, task in enumerate(self.task_heads):
+            s = streams[i % nstreams]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                out = task(aliases[i % nstreams])
+            x.record_stream(s)
+            for v in out.values():
+                v.record_stream(main)
+            outs.append([out])
+        for s in streams:
+            main.wait_stream(s)
+        return tuple(outs)
 
     # ------------------------------------------------------------------ targets
     @torch.no_grad()

@@ -4,10 +4,11 @@ activation instead of 5 + 8 with MIOpen BatchNorm + ATen add / relu.
 
 ``bn_act(bn, x, residual=None, relu=True)`` takes a plain ``nn.BatchNorm2d`` (its parameters,
 running statistics, momentum and eps are used and updated exactly like ``bn(x)`` would) and
-returns ``relu(bn(x) + residual)``.  The fused path needs training mode, CUDA fp32
-channels-last activations and a supported channel count; everything else (eval mode, autocast
-to bf16, CPU tensors of the gloo unit tests, odd C) runs the ordinary torch modules -- these
-layers are PyTorch plumbing around the hot path, not part of it.
+returns ``relu(bn(x) + residual)``.  The fused path needs training mode, CUDA channels-last
+activations (fp32, or bf16 inside an autocast region: bf16 in and out, fp32 statistics and
+arithmetic) and a supported channel count; everything else (eval mode, CPU tensors of the gloo
+unit tests, odd C) runs the ordinary torch modules -- these layers are PyTorch plumbing around
+the hot path, not part of it.
 """
 import os
 
@@ -25,19 +26,23 @@ def _stream():
 
 
 def _supported(bn, x):
+    """fp32 activations anywhere; bf16 activations inside an autocast region (the arithmetic is fp32 either way)."""
     c = x.shape[1]
-    return (ENABLED and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    return (ENABLED and bn.training and x.is_cuda and x.dim() == 4
+            and (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and torch.is_autocast_enabled()))
             and bn.track_running_stats and bn.momentum is not None and bn.affine
             and c % 4 == 0 and (c <= 1024 or c == 2048)
-            and not torch.is_autocast_enabled()
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
 class _BnAct(Function):
+    """x, residual, y and their gradients share one dtype (fp32 or bf16); parameters, statistics and arithmetic are fp32."""
+
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, workspace, momentum, eps, relu):
         B, C, H, W = x.shape
         R = B * H * W
+        act = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
         y = torch.empty_like(x)                                   # preserves channels_last
         save = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         res_ptr = 0
@@ -46,19 +51,21 @@ class _BnAct(Function):
                 residual = residual.contiguous(memory_format=torch.channels_last)
             res_ptr = residual.data_ptr()
         with torch.cuda.device(x.device):
-            _lib.call("mmt_bn_relu_forward", R, C, x.data_ptr(), res_ptr, weight.data_ptr(), bias.data_ptr(),
+            _lib.call("mmt_bn_relu_forward_ex", R, C, x.data_ptr(), res_ptr, weight.data_ptr(), bias.data_ptr(),
                       running_mean.data_ptr(), running_var.data_ptr(), float(momentum), float(eps), int(relu),
-                      workspace.data_ptr(), save.data_ptr(), y.data_ptr(), _stream())
+                      workspace.data_ptr(), save.data_ptr(), y.data_ptr(), act, _stream())
         ctx.mark_non_differentiable(running_mean, running_var)
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, save, workspace)
-        ctx.cfg = (R, C, bool(relu), residual is not None)
+        ctx.cfg = (R, C, bool(relu), residual is not None, act)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
         x, y, save, workspace = ctx.saved_tensors
-        R, C, relu, has_res = ctx.cfg
+        R, C, relu, has_res, act = ctx.cfg
+        if grad_y.dtype != x.dtype:
+            grad_y = grad_y.to(x.dtype)
         if not grad_y.is_contiguous(memory_format=torch.channels_last):
             grad_y = grad_y.contiguous(memory_format=torch.channels_last)
         grad_x = torch.empty_like(x)
@@ -66,9 +73,9 @@ class _BnAct(Function):
         grad_w = torch.empty(C, dtype=torch.float32, device=x.device)
         grad_b = torch.empty(C, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.call("mmt_bn_relu_backward", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
+            _lib.call("mmt_bn_relu_backward_ex", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
                       save.data_ptr(), int(relu), int(has_res), workspace.data_ptr(), grad_x.data_ptr(),
-                      grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), _stream())
+                      grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), act, _stream())
         return grad_x, grad_res, grad_w, grad_b, None, None, None, None, None, None
 
 
@@ -76,21 +83,30 @@ _SCRATCH = {}
 
 
 def _workspace(bn, device):
-    """Per-device scratch for the per-workgroup partial sums: consumed inside each call on the calling
-    stream, so one buffer sized for the widest layer serves every BatchNorm of the model."""
+    """Scratch for the per-workgroup partial sums, one per (device, STREAM): consumed inside each call on the calling
+    stream, so one buffer sized for the widest layer serves every BatchNorm the stream runs -- and layers that run on
+    different streams at the same time (the task heads, layers/heads/bev_depth_head.py) never share one.  The backward
+    of a layer runs on its forward's stream (autograd) and receives the same buffer."""
     need = _lib.lib().mmt_bn_workspace_elems(max(2048, bn.num_features))
-    ws = _SCRATCH.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = _SCRATCH.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=device)
-        _SCRATCH[device] = ws
+        _SCRATCH[key] = ws
     return ws
 
 
 def bn_act(bn, x, residual=None, relu=True):
     """relu?(bn(x) [+ residual]) with ``bn`` an ``nn.BatchNorm2d`` (see module docstring)."""
     if _supported(bn, x):
-        return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            _workspace(bn, x.device), bn.momentum, bn.eps, relu)
+        if residual is not None and residual.dtype != x.dtype:
+            residual = residual.to(x.dtype)              # (autograd casts the gradient back)
+        # inside an autocast region: the statistics and the normalisation run in fp32 on the fused kernels -- what autocast does
+        # for batch_norm anyway -- with bf16 activations in and out, instead of MIOpen's NHWC batch norm (an out-of-bounds
+        # access inside it was met twice: DESIGN section 4, fuzz_dense; tools/scratch/soak_streams.py)
+        with torch.autocast("cuda", enabled=False):
+            return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                _workspace(bn, x.device), bn.momentum, bn.eps, relu)
     out = bn(x)
     if residual is not None:
         out = out + residual

@@ -24,7 +24,7 @@ import torch
 from torch.autograd import Function
 
 _side = {}
-_state = {"join_queued": False}
+_state = {"join_queued_for": None}      # id of the backward pass (autograd graph task) whose end-of-backward join is queued
 
 
 def side_stream(device):
@@ -42,7 +42,7 @@ def join(device=None):
 
 
 def _end_of_backward():
-    _state["join_queued"] = False
+    _state["join_queued_for"] = None
     join()
 
 
@@ -80,16 +80,27 @@ class _ConvOverlap(Function):
                     gw = gw.to(leaf.dtype)
                 if gb is not None and gb.dtype != b_dtype:
                     gb = gb.to(b_dtype)
+            # Memory across the two streams (the caching allocator hands a freed block back to the stream it was allocated on,
+            # whatever other stream may still be using it):
+            #  * grad_out / x / a cast weight were allocated elsewhere and are read on the side stream;
+            #  * without the deferral the gradients (allocated on the side stream) are consumed right away on this one: with
+            #    gradient accumulation that is an in-place add which may still be queued here when the NEXT layer's weight
+            #    gradient -- launched from another stream, e.g. a task head's -- takes the block again on the side stream.
+            #    (Deferred: the first consumer comes after the end-of-backward join, and the block is next taken on the side
+            #    stream in the following backward pass, behind everything this stream has queued by then.)
             deferred = mode == "deferred" and leaf.grad is None
+            for t in ((gy, x) if w is leaf else (gy, x, w)):
+                t.record_stream(side)
+            if not deferred:
+                for t in (gw, gb):
+                    if t is not None:
+                        t.record_stream(main)
             if deferred:
-                # grad_out / x were allocated on the main stream: their blocks must not be handed to another main-stream kernel
-                # while the side stream still reads them (a join on the spot makes that unnecessary)
-                gy.record_stream(side)
-                x.record_stream(side)
-                if w is not leaf:
-                    w.record_stream(side)
-                if not _state["join_queued"]:
-                    _state["join_queued"] = True
+                # one callback per backward pass; keyed by the pass, so a pass that died with an exception (its callbacks never
+                # ran) cannot leave the next one without its join
+                task = torch._C._current_graph_task_id()
+                if _state["join_queued_for"] != task:
+                    _state["join_queued_for"] = task
                     torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         if need_x:
             gx = torch.ops.aten.convolution_backward(gy, x, w, None, stride, padding, dilation, False, zeros, groups,

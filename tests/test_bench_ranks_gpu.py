@@ -81,4 +81,6 @@ def test_bench_two_ranks_at_a_baseline_camera_shape(mmt_lib):
     assert c["final_loss"] == c["final_loss"] and abs(c["final_loss"]) < 1e6
     k = c["lift_splat_kernels"]
     assert k["forward"] == "ray+camera+register+exclusive" and k["backward"].endswith("+camera") and k["exclusive_cell_cache"].startswith("on")
-    assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline"]["avg_ms"] < 5.0        # (two processes time-slice the card: no bound on speed here)
+    # (two processes time-slice the one card, each with its main stream and the task heads' two streams: a dispatch-attached
+    # event pair may span the other rank's time slice -- 212 ms was seen once -- so there is no bound on speed here)
+    assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline"]["avg_ms"] < 5000.0

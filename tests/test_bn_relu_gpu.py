@@ -67,3 +67,55 @@ def test_fallback_paths(mmt_lib):
     x8 = torch.randn(2, 8, 5, 5, device="cuda").contiguous(memory_format=torch.channels_last)
     assert not bn_relu._supported(bn8, x8)
     assert torch.equal(bn_act(bn8, x8, relu=False), bn8(x8))
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 32, 44), (2, 256, 16, 22), (2, 2048, 4, 6), (3, 160, 9, 7), (2, 12, 5, 7)])
+@pytest.mark.parametrize("use_res", [False, True])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bf16_activations_inside_autocast(mmt_lib, shape, use_res, relu):
+    """Inside torch.autocast(bf16) the activations arrive and leave as bf16 (mmt_bn_relu_*_ex, ABI 9); statistics, running
+    statistics and arithmetic are fp32.  Reference: the fp32 torch modules on the up-cast inputs, output rounded to bf16 --
+    forward within one bf16 ulp, running statistics to fp32 accuracy, gradients within bf16 rounding of grad_x."""
+    from mm_training_amd.ops import bn_relu
+    from mm_training_amd.ops.bn_relu import bn_act
+    B, C, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(C * 5 + W)
+    x0 = (torch.randn(shape, device="cuda", generator=g) * 1.7 + 0.4).bfloat16().contiguous(memory_format=torch.channels_last)
+    r0 = torch.randn(shape, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last) if use_res else None
+    go = torch.randn(shape, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    bn_a, bn_b = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(C, device="cuda", generator=g) + 0.5)
+        bn_a.bias.copy_(torch.randn(C, device="cuda", generator=g) * 0.3)
+        bn_b.load_state_dict(bn_a.state_dict())
+    assert not bn_relu._supported(bn_a, x0)                   # bf16 outside an autocast region: the torch modules
+    x = x0.clone().requires_grad_(True)
+    r = r0.clone().requires_grad_(True) if use_res else None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert bn_relu._supported(bn_a, x0)
+        y = bn_act(bn_a, x, r, relu)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    assert x.grad.dtype == torch.bfloat16 and bn_a.weight.grad.dtype == torch.float32
+    xf = x0.float().requires_grad_(True)
+    rf = r0.float().requires_grad_(True) if use_res else None
+    yf = _ref(bn_b, xf, rf, relu)
+    yf.backward(go.float())
+    yf = yf.detach()
+    ulp = 2.0 ** -7                                           # bf16: 8 bits of precision, round to nearest = half an ulp; one for the ReLU edge
+    assert float((y.float() - yf).abs().max()) <= ulp * max(1.0, float(yf.abs().max()))
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+    bad = ((x.grad.float() - xf.grad).abs() > ulp * max(1.0, float(xf.grad.abs().max()))).float().mean().item()
+    assert bad <= 1e-5, bad                                   # (a ReLU mask decided within rounding of zero may differ)
+    if use_res:
+        assert float((r.grad.float() - rf.grad).abs().max()) <= ulp * max(1.0, float(rf.grad.abs().max()))
+    for a, b in ((bn_a.weight.grad, bn_b.weight.grad), (bn_a.bias.grad, bn_b.bias.grad)):
+        assert float((a - b).abs().max()) <= 2e-3 * max(1.0, float(b.abs().max()))
+    # a residual of another dtype is cast on the way in and its gradient comes back in its own dtype
+    if use_res:
+        r32 = r0.float().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y2 = bn_act(bn_a, x0.clone().requires_grad_(True), r32, relu)
+        y2.backward(go)
+        assert r32.grad.dtype == torch.float32 and y2.dtype == torch.bfloat16

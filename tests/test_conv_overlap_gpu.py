@@ -99,3 +99,73 @@ def test_training_step_losses_do_not_change(mmt_lib, mode, monkeypatch):
     for a, b in zip(losses["off"], losses[mode]):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), losses
     assert losses[mode][-1] < losses[mode][0]
+
+
+@pytest.mark.parametrize("mode", ["pair", "deferred"])
+def test_gradient_accumulation_with_layers_on_other_streams(mmt_lib, mode):
+    """Layers whose forward ran on different streams (the task heads) run their backward there.  With gradient accumulation the
+    weight gradient is consumed by an in-place add queued on the LAYER's stream, while the next layer -- on another stream --
+    already launches its own weight gradient on the side stream: the block of the first must not be handed out again before
+    that add has run (it was: test_dp_gpu's micro-batch reference then lost one contribution of the last layer of a stream)."""
+    from mm_training_amd.ops import conv_overlap
+    torch.manual_seed(0)
+    ref = torch.nn.ModuleList([torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False) for _ in range(6)]).cuda().to(memory_format=torch.channels_last)
+    new = copy.deepcopy(ref)
+    assert conv_overlap.enable(new, mode) == 6
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    main = torch.cuda.current_stream()
+    for it in range(8):
+        x = torch.randn(2, 64, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+        for nets, use_streams in ((ref, False), (new, True)):
+            nets.zero_grad(set_to_none=True)
+            for micro in range(3):                               # .grad is None only in the first
+                xi = (x * (1 + micro)).requires_grad_(True)
+                outs = []
+                for i, conv in enumerate(nets):
+                    if use_streams:
+                        st = streams[i % 2]
+                        st.wait_stream(main)
+                        with torch.cuda.stream(st):
+                            y = conv(xi)
+                        y.record_stream(main)
+                    else:
+                        y = conv(xi)
+                    outs.append(y)
+                if use_streams:
+                    for st in streams:
+                        main.wait_stream(st)
+                sum((o * (1 + i)).square().mean() for i, o in enumerate(outs)).backward()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(ref, new)):
+            err = float((a.weight.grad - b.weight.grad).abs().max()) / float(a.weight.grad.abs().max())
+            assert err <= 1e-4, (mode, it, i, err)
+
+
+def test_a_failed_backward_pass_does_not_cost_the_next_one_its_join(mmt_lib):
+    """The end-of-backward join is queued once per backward pass.  A pass that dies with an exception never runs its callbacks;
+    the next pass must queue its own (the bookkeeping is keyed by the pass, not a flag that would stay set)."""
+    from mm_training_amd.ops import conv_overlap
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    torch.manual_seed(0)
+    ref = torch.nn.Conv2d(32, 32, 3, 1, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    new = copy.deepcopy(ref)
+    conv_overlap.enable(new, "deferred")
+    x = torch.randn(8, 32, 96, 96, device="cuda").contiguous(memory_format=torch.channels_last)
+    with pytest.raises(RuntimeError, match="boom"):
+        new(Boom.apply(x.clone().requires_grad_(True))).sum().backward()      # the convolution's backward ran, then the pass died
+    for _ in range(5):
+        new.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        new(x).square().mean().backward()
+        got = new.weight.grad.clone()                   # read on the caller's stream: only valid behind the join
+        ref(x).square().mean().backward()
+        assert float((got - ref.weight.grad).abs().max()) <= 1e-5 * float(ref.weight.grad.abs().max())
