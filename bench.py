@@ -152,6 +152,9 @@ def spawn_ranks(n, argv):
     # tensors' IPC handles on one device (tests/test_bench_ranks_gpu.py) -- DESIGN section 6.
     if n > _visible_gpus():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # ... and keeps every rank on ONE stream: processes that share a card are time-sliced per hardware queue, and the task
+        # heads' two extra queues per rank only add slices (88 s instead of ~40 for 13 cfg2 steps of two ranks)
+        env.setdefault("MMT_HEAD_STREAMS", "0")
     env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
     procs = []
     for r in range(n):
