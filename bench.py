@@ -98,6 +98,8 @@ def parse(argv=None):
                     help="do not hand the depth labels to the model as its depth oracle (the reference does when use_depth_loss is set)")
     ap.add_argument("--conv-overlap", default=None, choices=["off", "pair", "deferred"],
                     help="weight gradients of the convolutions on a side HIP stream (ops/conv_overlap.py); default: MMT_CONV_OVERLAP or the TrainStep default")
+    ap.add_argument("--head-streams", type=int, default=None,
+                    help="HIP streams the CenterPoint task heads are dealt to in training (default: MMT_HEAD_STREAMS or 2; 0 = the caller's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
     ap.add_argument("--hotpath-leg", action="store_true",
@@ -641,6 +643,8 @@ def train_main(args, rank, local_rank, world):
         os.environ["MMT_ATEN_SOFTMAX"] = "1"
     if args.conv_overlap:
         os.environ["MMT_CONV_OVERLAP"] = args.conv_overlap
+    if args.head_streams is not None:
+        os.environ["MMT_HEAD_STREAMS"] = str(args.head_streams)
     if args.no_augment:
         cfg["augment_images"] = False
     if args.no_depth_oracle:

@@ -10,6 +10,14 @@ run $out/bench_train_cfg4_unfused.jsonl python bench.py --unfused --no-cpu-basel
 run $out/bench_train_cfg4_geom_form.jsonl python bench.py --geom-form --no-cpu-baseline --no-hotpath-leg
 run $out/bench_train_cfg4_calibration_ids.jsonl python bench.py --calibration-ids --no-cpu-baseline --no-hotpath-leg
 for c in cfg2 cfg3 cfg5; do run $out/bench_train_$c.jsonl python bench.py --config $c --no-cpu-baseline; done
+# the step on ONE stream (no weight-gradient stream, task heads on the caller's stream): the A/B of ops/conv_overlap.py + the head streams
+run $out/bench_train_cfg4_single_stream.jsonl python bench.py --conv-overlap off --head-streams 0 --no-cpu-baseline --no-hotpath-leg
+run $out/bench_train_cfg5_single_stream.jsonl python bench.py --config cfg5 --conv-overlap off --head-streams 0 --no-cpu-baseline --no-hotpath-leg
+# which layers the dense part of the step belongs to, and MIOpen on the dominant shapes in both layouts (full find)
+run $out/conv_shapes_cfg4.txt python tools/conv_shapes.py cfg4 3
+run $out/kbench_conv_layout.jsonl python tools/kbench_conv_layout.py
+# multi-stream soak: every (weight-gradient stream, head streams, amp) variant of the tiny step, 400 steps each, fresh processes
+run $out/soak_streams.txt python tools/scratch/soak_streams.py 400
 run $out/kbench_fused.txt env KBF_EXTRA=1 python tools/kbench_fused.py
 run $out/kbench_camera_cfg4.json python tools/kbench_camera.py --shape cfg4
 run $out/kbench_camera_cfg5_bf16.json python tools/kbench_camera.py --shape cfg5 --dtype bf16

@@ -5,6 +5,9 @@ The convolutions are MIOpen's; this table says which LAYERS cost what, i.e. whic
 import os
 import sys
 
+# one stream: kernels that overlap would each be charged the time they share the card
+os.environ.setdefault("MMT_CONV_OVERLAP", "off")
+os.environ.setdefault("MMT_HEAD_STREAMS", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (MIOpen find DB / environment exactly as the benchmark sets them)
 
