@@ -96,7 +96,7 @@ def parse(argv=None):
     ap.add_argument("--no-augment", action="store_true", help="skip augment_images (the reference's training_step always runs it)")
     ap.add_argument("--no-depth-oracle", action="store_true",
                     help="do not hand the depth labels to the model as its depth oracle (the reference does when use_depth_loss is set)")
-    ap.add_argument("--conv-overlap", default=None, choices=["off", "pair", "deferred"],
+    ap.add_argument("--conv-overlap", default=None, choices=["off", "inline", "pair", "deferred"],
                     help="weight gradients of the convolutions on a side HIP stream (ops/conv_overlap.py); default: MMT_CONV_OVERLAP or the TrainStep default")
     ap.add_argument("--head-streams", type=int, default=None,
                     help="HIP streams the CenterPoint task heads are dealt to in training (default: MMT_HEAD_STREAMS or 2; 0 = the caller's stream)")
@@ -704,7 +704,7 @@ def train_main(args, rank, local_rank, world):
                    "hot_path_storage_dtype": dtype,
                    # exps/mm_training_aim.py:258-259: both run inside every timed step
                    "augment_images": bool(ts.augment and cfg["use_cam"]), "depth_oracle": bool(ts.pass_depth_labels and cfg["use_cam"]),
-                   "conv_weight_gradients": ts.conv_overlap or "same stream",
+                   "conv_weight_gradients": {None: "same stream (autograd)", "inline": "same stream"}.get(ts.conv_overlap, ts.conv_overlap),
                    "task_head_streams": int(ts.model.head.task_streams),
                    "distributed": dinfo},
     }

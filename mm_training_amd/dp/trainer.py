@@ -120,13 +120,14 @@ class TrainStep(nn.Module):
         if self.use_cam:
             self.model.backbone.hot_path_dtype = cfg.get("hot_path_dtype", "f32")
         self.net = self.model
-        # weight gradients of the convolutions on a side HIP stream, joined once at the end of the backward pass
-        # (ops/conv_overlap.py: 68.6 -> 67.2 ms at configs[3]).  Under DDP the bucket hooks read each gradient inside the backward
-        # pass, which would need a join per layer ("pair": measured slower than no overlap) -- so world size 1 only.
+        # The convolutions' backward (ops/conv_overlap.py).  "deferred": weight gradients on a side HIP stream, joined once at the end
+        # of the backward pass (68.6 -> 67.2 ms at configs[3]).  Under DDP the bucket hooks read each gradient inside the backward
+        # pass, which would need a join per layer ("pair": measured slower than no overlap), so world size > 1 runs "inline" --
+        # one stream, and the module's other duty only: narrow 16-bit convolutions in fp32 (a MIOpen bf16 kernel faults on them).
         self.conv_overlap = None
         overlap = os.environ.get("MMT_CONV_OVERLAP", "deferred")
         if overlap == "deferred" and world_size > 1:
-            overlap = "off"
+            overlap = "inline"
         if device.type == "cuda" and overlap != "off":
             from ..ops import conv_overlap
             conv_overlap.enable(self.model, overlap)

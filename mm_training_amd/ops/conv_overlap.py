@@ -6,6 +6,7 @@ and at the activation sizes of this model (24 x 16 x 44 rows on the camera side,
 implicit-GEMM launch leaves a tail of idle CUs: the weight gradient goes to a side stream here and overlaps the data
 gradient.  Same kernels, same arithmetic, same results bit for bit (MIOpen picks its solvers per problem, not per stream).
 
+  mode "inline"   : no second stream (the Function's other duty only, see NARROW below) -- what TrainStep uses under DDP;
   mode "pair"     : the side stream joins the main stream before backward returns -- safe under every consumer of the
                     gradient (autograd accumulation, DDP's bucket hooks);
   mode "deferred" : no join per layer: the weight gradients queue up on the side stream and fill whatever the main stream
@@ -17,12 +18,20 @@ gradient.  Same kernels, same arithmetic, same results bit for bit (MIOpen picks
                     layer whose weight already holds a gradient (gradient accumulation) joins on the spot instead.  DDP's
                     bucket hooks read the gradient inside the backward pass: TrainStep uses this mode at world size 1 only.
 
+NARROW 16-bit convolutions run in fp32.  MIOpen's bf16 NHWC implicit-GEMM data-gradient kernel reads past a buffer on a narrow
+problem of the tiny test model (`MIOpenDriver convbfp16 -n 4 -c 8 -H 16 -W 48 -k 8 -y 4 -x 4 -u 4 -v 4 --in_layout NHWC ... -F 2`,
+kernel igemm_bwd_gtcx35_nhwc_bf16_bx0_ex1_bt128x32x8_...: "Memory access fault by GPU" whenever the operand ends where mapped
+memory ends; found with tools/scratch/soak_streams.py, launches serialised + ROCclr kernel log + MIOPEN_ENABLE_LOGGING_CMD).  A
+convolution with fewer than 16 input AND fewer than 16 output channels therefore computes in fp32 inside an autocast region
+(bf16 in and out as autocast would give); no BASELINE configuration has such a layer.
+
 Measured at BASELINE configs[3] (30 steps, alternating runs on one box): same stream 68.6 ms, pair 72.7 ms (two cross-stream
 event waits per layer cost more than the overlap returns), deferred 67.2 ms.
 """
 import torch
 from torch.autograd import Function
 
+NARROW = 16
 _side = {}
 _state = {"join_queued_for": None}      # id of the backward pass (autograd graph task) whose end-of-backward join is queued
 
@@ -52,12 +61,16 @@ class _ConvOverlap(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, groups, dtype, mode):
+        out_dtype = None
+        if dtype in (torch.bfloat16, torch.float16) and x.shape[1] < NARROW and w.shape[0] < NARROW:
+            out_dtype, dtype = dtype, torch.float32          # NARROW (module docstring): fp32 arithmetic, 16-bit result
         xc = x if dtype is None else x.to(dtype)
         wc = w if dtype is None else w.to(dtype)
         bc = b if (b is None or dtype is None) else b.to(dtype)
         ctx.save_for_backward(xc, wc, w)
         ctx.conf = (stride, padding, dilation, groups, b is not None, x.dtype, b.dtype if b is not None else None, mode)
-        return torch.ops.aten.convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
+        y = torch.ops.aten.convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
+        return y if out_dtype is None else y.to(out_dtype)
 
     @staticmethod
     def backward(ctx, gy):
@@ -71,6 +84,16 @@ class _ConvOverlap(Function):
         side = side_stream(gy.device)
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
+        if mode == "inline":                                 # one stream, one call: autograd's own backward
+            gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
+                                                             False, zeros, groups, [need_x, need_w, has_b])
+            if gx is not None and gx.dtype != x_dtype:
+                gx = gx.to(x_dtype)
+            if gw is not None and gw.dtype != leaf.dtype:
+                gw = gw.to(leaf.dtype)
+            if gb is not None and gb.dtype != b_dtype:
+                gb = gb.to(b_dtype)
+            return gx, gw, gb, None, None, None, None, None, None
         if need_w or has_b:
             side.wait_stream(main)                       # grad_out (and, in the first layer of a backward, the saved tensors) are ready
             with torch.cuda.stream(side):
@@ -128,8 +151,8 @@ class OverlapConv2d(torch.nn.Conv2d):
 
 def enable(model, mode="pair"):
     """Route every nn.Conv2d of `model` through the two-stream backward.  Returns the number of modules switched."""
-    if mode not in ("pair", "deferred"):
-        raise ValueError("conv overlap mode must be 'pair' or 'deferred', got %r" % (mode,))
+    if mode not in ("inline", "pair", "deferred"):
+        raise ValueError("conv overlap mode must be 'inline', 'pair' or 'deferred', got %r" % (mode,))
     n = 0
     for m in model.modules():
         if type(m) in (torch.nn.Conv2d, OverlapConv2d):

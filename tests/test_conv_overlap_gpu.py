@@ -21,7 +21,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["pair", "deferred"])
+@pytest.mark.parametrize("mode", ["inline", "pair", "deferred"])
 def test_gradients_are_autograds(mmt_lib, mode):
     from mm_training_amd.ops import conv_overlap
     torch.manual_seed(0)
@@ -76,7 +76,7 @@ def test_gradients_are_autograds(mmt_lib, mode):
         conv_overlap.enable(conv, "sideways")
 
 
-@pytest.mark.parametrize("mode", ["pair", "deferred"])
+@pytest.mark.parametrize("mode", ["inline", "pair", "deferred"])
 def test_training_step_losses_do_not_change(mmt_lib, mode, monkeypatch):
     from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
     cfg = make_config("tiny")
@@ -169,3 +169,29 @@ def test_a_failed_backward_pass_does_not_cost_the_next_one_its_join(mmt_lib):
         got = new.weight.grad.clone()                   # read on the caller's stream: only valid behind the join
         ref(x).square().mean().backward()
         assert float((got - ref.weight.grad).abs().max()) <= 1e-5 * float(ref.weight.grad.abs().max())
+
+
+def test_narrow_16_bit_convolutions_compute_in_fp32(mmt_lib):
+    """MIOpen's bf16 NHWC data-gradient kernel faults on `convbfp16 -n 4 -c 8 -H 16 -W 48 -k 8 -y 4 -x 4 -u 4 -v 4` (the tiny model's
+    neck; ops/conv_overlap.py NARROW): inside an autocast region a convolution with fewer than 16 channels on both sides runs in
+    fp32 on its fp32 operands (the result is rounded to bf16 once, and handed on as bf16 like autocast would); wider layers stay
+    in bf16."""
+    from mm_training_amd.ops import conv_overlap
+    torch.manual_seed(0)
+    for mode in ("inline", "deferred"):
+        narrow = torch.nn.Conv2d(8, 8, 4, 4, 0, bias=False).cuda().to(memory_format=torch.channels_last)
+        wide = torch.nn.Conv2d(8, 32, 3, 1, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+        conv_overlap.enable(narrow, mode)
+        conv_overlap.enable(wide, mode)
+        x = torch.randn(4, 8, 16, 48, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = narrow(x)
+            z = wide(x)
+        assert y.dtype == torch.bfloat16 and z.dtype == torch.bfloat16
+        ref = torch.nn.functional.conv2d(x.detach(), narrow.weight.detach(), None, 4, 0)        # fp32 operands, not even rounded to bf16
+        assert float((y.float() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())       # one rounding of the result
+        (y.float().square().sum() + z.float().square().sum()).backward()
+        assert x.grad.dtype == torch.float32 and narrow.weight.grad.dtype == torch.float32 and torch.isfinite(x.grad).all()
+        gy = (2 * y.detach().float())
+        gw_ref = torch.nn.grad.conv2d_weight(x.detach(), narrow.weight.shape, gy, 4, 0)
+        assert float((narrow.weight.grad - gw_ref).abs().max()) <= 1e-4 * float(gw_ref.abs().max())

@@ -161,6 +161,7 @@ def test_conv_overlap_switch_is_transparent_on_the_host():
     clone[0].weight.data.zero_()
     assert not torch.equal(clone(x), want) and torch.equal(net(x), want)      # the copy runs on ITS parameters
     assert conv_overlap.enable(net, "pair") == 1 and net[0]._mmt_overlap_mode == "pair"
+    assert conv_overlap.enable(net, "inline") == 1 and net[0]._mmt_overlap_mode == "inline"
     with pytest.raises(ValueError):
         conv_overlap.enable(net, "both")
     conv_overlap.join()                                           # no side stream yet: nothing to wait for

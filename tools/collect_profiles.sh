@@ -6,7 +6,7 @@
 # runs.  The program itself follows `--` (python3 bench.py), never a wrapper.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-# Optional arguments pick groups (stats pmc4 pmc5 pmc2 pmc5bf16; default: all, into an emptied directory).
+# Optional arguments pick groups (stats stats1 pmc4 pmc5 pmc2 pmc5bf16; default: all, into an emptied directory).
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new; [ $# -eq 0 ] && rm -rf $out; mkdir -p $out
 want() { [ -z "$GROUPS_WANTED" ] && return 0; case " $GROUPS_WANTED " in *" $1 "*) return 0;; esac; return 1; }
 GROUPS_WANTED="$*"
@@ -33,6 +33,9 @@ stats train_cfg5 --config cfg5 --steps 12 --warmup 6 --no-cpu-baseline --no-hotp
 stats hotpath_cfg2 --mode hotpath --config cfg2 --steps 50 --warmup 10 --no-cpu-baseline
 stats hotpath_cfg5_bf16 --mode hotpath --config cfg5 --dtype bf16 --steps 50 --warmup 10 --no-cpu-baseline
 fi
+# the same step on ONE stream (no weight-gradient stream, task heads on the caller's stream): kernels that overlap are each charged the
+# time they share the card, so per-kernel durations are read from this one
+want stats1 && stats train_cfg4_single_stream --steps 20 --warmup 8 --no-cpu-baseline --conv-overlap off --head-streams 0
 # (cfg4: 16 launches, the later 8 in the steady state of the exclusive-cell cache; cfg5's forward has no cache: 5 launches)
 want pmc4 && pmc cfg4 --steps 8 --warmup 8 --no-cpu-baseline --no-hotpath-leg
 want pmc5 && pmc cfg5 --config cfg5 --steps 3 --warmup 2 --no-cpu-baseline --no-hotpath-leg
