@@ -28,6 +28,8 @@ convolution with fewer than 16 input AND fewer than 16 output channels therefore
 Measured at BASELINE configs[3] (30 steps, alternating runs on one box): same stream 68.6 ms, pair 72.7 ms (two cross-stream
 event waits per layer cost more than the overlap returns), deferred 67.2 ms.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -36,10 +38,30 @@ _side = {}
 _state = {"join_queued_for": None}      # id of the backward pass (autograd graph task) whose end-of-backward join is queued
 
 
+def _low_priority_stream(device):
+    """A HIP stream BELOW the default priority, wrapped for torch (torch.cuda.Stream only offers 0 = default and -1 = high): the
+    weight gradients are filler work -- whenever a kernel of the main stream and one of theirs are both ready, the main stream's
+    workgroups go first.  None when the runtime has no such level."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(device):
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0 or least.value <= 0:
+                return None                      # (numerically larger = lower priority; the default stream is 0)
+            handle = ctypes.c_void_p()
+            if hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0 or not handle.value:   # 1 = hipStreamNonBlocking
+                return None
+        return torch.cuda.ExternalStream(handle.value, device=device)
+    except (OSError, AttributeError):
+        return None
+
+
 def side_stream(device):
     key = (device.type, device.index)
     if key not in _side:
-        _side[key] = torch.cuda.Stream(device=device)
+        s = _low_priority_stream(device) if os.environ.get("MMT_SIDE_STREAM_PRIORITY", "low") == "low" else None
+        _side[key] = s if s is not None else torch.cuda.Stream(device=device)
     return _side[key]
 
 
