@@ -291,6 +291,7 @@ def distributed_info(world, local_rank, ts=None):
         info["gradient_bytes"] = int(sum(p.numel() * p.element_size() for p in params))
         ddp = ts.net if isinstance(ts.net, torch.nn.parallel.DistributedDataParallel) else None
         info["ddp"] = None
+        info["reducer"] = ts.reducer.describe() if getattr(ts, "reducer", None) is not None else None
         if ddp is not None:
             cap = int(ddp.bucket_bytes_cap)
             info["ddp"] = {"bucket_cap_mb": cap / (1024 * 1024), "static_graph": bool(getattr(ddp, "static_graph", False)),

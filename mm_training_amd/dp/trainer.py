@@ -126,13 +126,36 @@ class TrainStep(nn.Module):
         # one stream, and the module's other duty only: narrow 16-bit convolutions in fp32 (a MIOpen bf16 kernel faults on them).
         self.conv_overlap = None
         overlap = os.environ.get("MMT_CONV_OVERLAP", "deferred")
-        if overlap == "deferred" and world_size > 1:
+        # Gradient exchange at world size > 1: "native" = dp/reducer.py (bucketed all-reduce on a communication stream, a few launches
+        # per bucket, nothing read on the main stream inside the backward pass -- the deferred weight-gradient stream stays on);
+        # "ddp" = torch's DistributedDataParallel (one small kernel per parameter on the main stream; convolutions then run inline)
+        self.dp_reducer = os.environ.get("MMT_DP_REDUCER", "native") if world_size > 1 else None
+        if overlap == "deferred" and world_size > 1 and self.dp_reducer != "native":
             overlap = "inline"
         if device.type == "cuda" and overlap != "off":
             from ..ops import conv_overlap
             conv_overlap.enable(self.model, overlap)
             self.conv_overlap = overlap
-        if world_size > 1:
+        if world_size > 1 and "MMT_HEAD_STREAMS" not in os.environ:
+            # a process has four hardware queues: main + the weight-gradient / packing stream + RCCL's own leave one spare; the task
+            # heads' two streams (0.2 ms of the step) would oversubscribe them next to a collective that must make progress
+            self.model.head.task_streams = 0
+        self.reducer = None
+        if world_size > 1 and self.dp_reducer == "native":
+            # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183): not registered with the reducer
+            import torch.distributed as dist
+            from .reducer import GradReducer
+            if dist.is_initialized():                        # every rank starts from rank 0's parameters and buffers (what DDP does at construction)
+                with torch.no_grad():
+                    for t in list(self.model.parameters()) + list(self.model.buffers()):
+                        dist.broadcast(t, 0)
+            pack_on = None
+            if self.conv_overlap in ("deferred", "pair") and os.environ.get("MMT_REDUCER_STREAM", "side") == "side":
+                from ..ops import conv_overlap
+                pack_on = conv_overlap.side_stream(device)   # behind the weight gradients, on their stream
+            self.reducer = GradReducer(self.model.named_parameters(), world_size, bucket_mb=bucket_cap_mb, ignore=(".context_se.",),
+                                       extra_streams=self._gradient_streams, stream=pack_on)
+        elif world_size > 1:
             # DepthNet.context_se has parameters that never receive a gradient (lss_fpn.py:183; the
             # reference survives on Lightning's find_unused_parameters=True, which walks the autograd
             # graph on the host every step).  Tell the reducer to ignore exactly those instead: the
@@ -242,6 +265,22 @@ class TrainStep(nn.Module):
         depth_loss = self.get_depth_loss(depth_labels_flat, depth_preds) if self.use_cam else detection_loss.new_zeros(())
         return detection_loss + depth_loss, detection_loss, depth_loss
 
+    def _gradient_streams(self):
+        """The streams (besides the one a hook runs on) that may still be producing a gradient of this step."""
+        from ..ops import conv_overlap
+        from ..layers.heads import bev_depth_head
+        streams = [torch.cuda.current_stream(self.device), torch.cuda.default_stream(self.device)]
+        streams += list(conv_overlap._side.values())
+        for group in bev_depth_head._TASK_STREAMS.values():
+            streams += list(group)
+        return streams
+
+    def finish_backward(self):
+        """After `backward()` at world size > 1 with the native reducer: wait for the gradient all-reduces (the stream does, not the
+        host) and point every .grad at the reduced values.  A no-op otherwise (DDP has done it inside backward())."""
+        if self.reducer is not None:
+            self.reducer.finish()
+
     def forward(self, batch):
         """One optimisation step; returns the (detached) loss tensors, no host sync."""
         self.optimizer.zero_grad(set_to_none=True)
@@ -249,6 +288,7 @@ class TrainStep(nn.Module):
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)      # see _batched_bn_counters
         loss.backward()
+        self.finish_backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip, foreach=True)
         self.optimizer.step()
         return loss.detach(), det.detach(), dep.detach()

@@ -93,3 +93,73 @@ def test_loss_normaliser_is_one_collective_and_device_resident():
     x, boxes, labels = _data(cfg, 2)
     loss = _step(head, x, boxes, labels)
     assert loss.requires_grad and loss.dim() == 0
+
+
+def _reducer_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from mm_training_amd.dp.reducer import GradReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1), torch.nn.Flatten(),
+                              torch.nn.Linear(4 * 8 * 8, 5))
+    net[0].to(memory_format=torch.channels_last)
+    frozen = torch.nn.Linear(3, 3)                         # never used: must be kept out of the reducer
+    red = GradReducer(list(net.named_parameters()) + [("frozen." + n, p) for n, p in frozen.named_parameters()], world,
+                      bucket_mb=0.002, ignore=("frozen.",))          # 2 KB buckets: several of them
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(world * 4, 3, 8, 8, generator=g)
+    res = {}
+    for step in range(2):
+        net.zero_grad(set_to_none=True)
+        net(data[rank * 4:(rank + 1) * 4]).square().mean().backward()
+        red.finish()
+        res[step] = [p.grad.clone() for p in net.parameters()]
+    # a backward pass that dies half-way must not poison the next one
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError("boom")
+    net.zero_grad(set_to_none=True)
+    try:
+        net[4](net[3](Boom.apply(net[2](net[1](net[0](data[:4])))))).sum().backward()
+    except RuntimeError:
+        pass
+    net.zero_grad(set_to_none=True)
+    net(data[rank * 4:(rank + 1) * 4]).square().mean().backward()
+    red.finish()
+    res["after_failure"] = [p.grad.clone() for p in net.parameters()]
+    if rank == 0:
+        out["grads"] = res
+        out["describe"] = red.describe()
+        out["strides_match"] = all(p.grad.stride() == p.stride() for p in net.parameters())
+        out["data"] = data
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_reducer_two_ranks_equal_the_mean_gradient():
+    """dp/reducer.py on CPU tensors over gloo: two ranks with a shard each end up with the gradient of the mean of the two shard
+    losses = the single-process gradient of (loss(shard 0) + loss(shard 1)) / 2; several buckets, channels_last weights keep
+    their layout, an unused parameter is ignored, a failed backward pass does not poison the next."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_reducer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1), torch.nn.Flatten(),
+                              torch.nn.Linear(4 * 8 * 8, 5))
+    data = out["data"]
+    loss = (net(data[:4]).square().mean() + net(data[4:]).square().mean()) / 2
+    loss.backward()
+    ref = [p.grad for p in net.parameters()]
+    for key in (0, 1, "after_failure"):
+        for a, b in zip(out["grads"][key], ref):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), key
+    d = out["describe"]
+    assert d["buckets"] >= 3 and d["parameters"] == 6 and sum(d["bucket_bytes"]) == d["gradient_bytes"] and out["strides_match"]

@@ -74,6 +74,7 @@ def _worker(rank, world, port, out):
         ts.optimizer.zero_grad(set_to_none=True)
         loss, det, dep = ts.forward_loss(shard)
         (loss if with_depth else det).backward()
+        ts.finish_backward()                              # the native reducer's all-reduces (a no-op under DDP, which reduces inside backward)
         res[key] = _grads(ts)
     if rank == 0:
         out.update(res)
@@ -135,11 +136,12 @@ def test_two_ranks_equal_gradient_accumulation_and_double_batch(mmt_lib):
     assert sum(e > 2e-3 for e in errs) <= 3 and errs[-1] <= 5e-2, ("batch-4", worst)
 
 
-def _rccl_worker(_index, port, out):
+def _rccl_worker(_index, port, out, reducer="native"):
     """One rank over RCCL (backend "nccl"), the way bench.py initialises it (init_dist: device_id given), with the step
     wrapped in DistributedDataParallel exactly as for N > 1: bucketed all-reduce through RCCL, static graph, the fused
     HIP kernels (camera form + exclusive-cell cache) and the LiDAR branch inside."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1",
+                      MMT_DP_REDUCER=reducer)
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
@@ -154,7 +156,7 @@ def _rccl_worker(_index, port, out):
         batch = synthetic_batch(cfg, dev, seed=7, batch_size=2)
         losses = [float(ts(batch)[0]) for _ in range(5)]     # static_graph engages from the second iteration on
         res[key] = losses
-        res[key + "_wrapped"] = isinstance(ts.net, torch.nn.parallel.DistributedDataParallel)
+        res[key + "_wrapped"] = isinstance(ts.net, torch.nn.parallel.DistributedDataParallel) or ts.reducer is not None
     t = torch.ones(4, device=dev)
     dist.all_reduce(t)
     res["all_reduce"] = t.tolist()
@@ -168,12 +170,14 @@ def _rccl_worker(_index, port, out):
     dist.destroy_process_group()
 
 
-def test_rccl_backend_single_rank_ddp_step(mmt_lib):
+@pytest.mark.parametrize("reducer", ["native", "ddp"])
+def test_rccl_backend_single_rank_ddp_step(mmt_lib, reducer):
     """RCCL itself (one GPU per box here: the N > 1 tests above rendezvous over gloo): process group on the "nccl" backend,
-    DDP-wrapped training steps through it, same losses as the unwrapped step."""
+    training steps whose gradients go through it -- the native bucketed reducer (dp/reducer.py, the default) and torch's DDP wrap
+    (MMT_DP_REDUCER=ddp) -- same losses as the step without any exchange."""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(_free_port(), out, reducer), nprocs=1, join=True)
     assert out["backend"] == "nccl" and out["all_reduce"] == [1.0] * 4
     assert out["ddp_wrapped"] and not out["plain_wrapped"]
     for a, b in zip(out["ddp"], out["plain"]):
@@ -181,4 +185,4 @@ def test_rccl_backend_single_rank_ddp_step(mmt_lib):
     assert out["ddp"][-1] < out["ddp"][0]                  # and it trains
     info = out["info"]
     assert info["world"] == 1 and info["ranks"][0]["device"] == "cuda:0" and info["ranks"][0]["pci_bus_id"].count(":") == 2
-    assert info["rccl_version"] and info["gradient_bytes"] > 1e5 and info["ddp"] is None        # (the last TrainStep is the unwrapped one)
+    assert info["rccl_version"] and info["gradient_bytes"] > 1e5 and info["ddp"] is None and info["reducer"] is None     # (the last TrainStep is the unwrapped one)

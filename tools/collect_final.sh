@@ -16,6 +16,8 @@ run $out/bench_train_cfg5_single_stream.jsonl python bench.py --config cfg5 --co
 # which layers the dense part of the step belongs to, and MIOpen on the dominant shapes in both layouts (full find)
 run $out/conv_shapes_cfg4.txt python tools/conv_shapes.py cfg4 3
 run $out/kbench_conv_layout.jsonl python tools/kbench_conv_layout.py
+# what the gradient exchange costs ONE rank before any communication (one-rank RCCL group): native reducer, torch DDP, none
+for m in native ddp plain; do MASTER_PORT=$((29800 + RANDOM % 150)) run $out/exchange_tax_$m.txt python tools/scratch/ddp_tax.py $m 30; done
 # multi-stream soak: every (weight-gradient stream, head streams, amp) variant of the tiny step, 400 steps each, fresh processes
 run $out/soak_streams.txt python tools/scratch/soak_streams.py 400
 run $out/kbench_fused.txt env KBF_EXTRA=1 python tools/kbench_fused.py
