@@ -86,6 +86,40 @@ while time.time() < t_end:
         bad = ((a.double() - b).abs() > tol).float().mean().item()
         if bad > (2e-4 if name in ("y", "gx", "gres") else 0.0) and n >= 8:     # tiny batches: rstd amplifies rounding
             fail("bn", shape=shape, res=use_res, relu=relu, tensor=name, bad=bad, err=(a.double() - b).abs().max().item())
+    # ---- the same layer with bf16 activations inside autocast (mmt_bn_relu_*_ex): fp32 statistics and arithmetic on the bf16 values
+    if n >= 8:
+        xb, rb, gb16 = x0.bfloat16(), (r0.bfloat16() if use_res else None), go.bfloat16()
+        bn2 = nn.BatchNorm2d(C).cuda()
+        bn2.load_state_dict({k: (v if "running" not in k and "num" not in k else bn2.state_dict()[k]) for k, v in bn.state_dict().items()})
+        xq = xb.clone().requires_grad_(True)
+        rq = rb.clone().requires_grad_(True) if use_res else None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yq = bn_relu.bn_act(bn2, xq, rq, relu)
+        if yq.dtype != torch.bfloat16 or not isinstance(yq.grad_fn, torch.autograd.function.BackwardCFunction):
+            fail("bn bf16 fused path not taken", shape=shape)
+        yq.backward(gb16)
+        xd = xb.double().requires_grad_(True)
+        rd = rb.double().requires_grad_(True) if use_res else None
+        wd, bd = bn2.weight.detach().double().requires_grad_(True), bn2.bias.detach().double().requires_grad_(True)
+        mean = xd.mean((0, 2, 3), keepdim=True)
+        var = xd.var((0, 2, 3), unbiased=False, keepdim=True)
+        yd = (xd - mean) / torch.sqrt(var + bn2.eps) * wd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1)
+        if use_res:
+            yd = yd + rd
+        if relu:
+            yd = yd * (yq.detach() > 0).double()
+        yd.backward(gb16.double())
+        ulp = 2.0 ** -7
+        pairs = [("y", yq.detach(), yd.detach(), ulp), ("gx", xq.grad, xd.grad, 2 * ulp), ("gres", rq.grad if use_res else None, rd.grad if use_res else None, ulp),
+                 ("gw", bn2.weight.grad, wd.grad, 2e-4), ("gb", bn2.bias.grad, bd.grad, 2e-4),
+                 ("rm", bn2.running_mean, 0.1 * mean.flatten(), 5e-5), ("rv", bn2.running_var, 0.9 + 0.1 * var.flatten() * (n / max(n - 1, 1)), 5e-5)]
+        for name, a, b, rel in pairs:
+            if a is None:
+                continue
+            tol = rel * max(1.0, b.abs().max().item()) * (8.0 if n < 32 else 1.0)
+            bad = ((a.double() - b).abs() > tol).float().mean().item()
+            if bad > (2e-4 if name in ("y", "gx", "gres") else 0.0):
+                fail("bn bf16", shape=shape, res=use_res, relu=relu, tensor=name, bad=bad, err=(a.double() - b).abs().max().item())
     # ---- BEV warp
     B, H, W, C = int(rng.integers(1, 4)), int(rng.integers(2, 70)), int(rng.integers(2, 70)), int(rng.choice([4, 16, 80]))
     if VERB:
