@@ -664,7 +664,7 @@ def train_main(args, rank, local_rank, world):
     _lib.lib()
     # benchmark=True makes PyTorch ask MIOpen's find API, which is answered from the find DB
     # (only for the configurations the DB was produced on: an unknown shape would start a search)
-    db_cfg = SHIPPED_MIOPEN_DB and args.config in ("cfg2", "cfg4")
+    db_cfg = SHIPPED_MIOPEN_DB and args.config in ("cfg2", "cfg3", "cfg4", "cfg5")
     torch.backends.cudnn.benchmark = bool(args.miopen_tune) or db_cfg
     dev = torch.device("cuda", local_rank)
     cfg = make_config(args.config)

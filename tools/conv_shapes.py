@@ -20,7 +20,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
     import numpy as np
-    torch.backends.cudnn.benchmark = config in ("cfg2", "cfg4")
+    torch.backends.cudnn.benchmark = config in ("cfg2", "cfg3", "cfg4", "cfg5")
     dev = torch.device("cuda", 0)
     cfg = make_config(config)
     torch.manual_seed(0)
