@@ -242,6 +242,22 @@ def choose_backend(world, local_rank, ndev, requested="nccl"):
     return requested, local_rank
 
 
+class _StdoutToStderr:
+    """File descriptor 1 -> 2 for the duration: this image's RCCL prints a five-line version banner to STDOUT when its first
+    communicator is created, and rank 0's stdout is the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init_dist(n_gpus, device="cuda"):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,7 +273,9 @@ def init_dist(n_gpus, device="cuda"):
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            with _StdoutToStderr():                      # (device_id given: the communicator is created here, eagerly)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
         else:
             dist.init_process_group(backend=backend)
         if world <= ndev and "MMT_DIST_BACKEND" not in os.environ:

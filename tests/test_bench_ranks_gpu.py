@@ -84,3 +84,13 @@ def test_bench_two_ranks_at_a_baseline_camera_shape(mmt_lib):
     # (two processes time-slice the one card, each with its main stream and the task heads' two streams: a dispatch-attached
     # event pair may span the other rank's time slice -- 212 ms was seen once -- so there is no bound on speed here)
     assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline"]["avg_ms"] < 5000.0
+
+
+def test_rccl_banner_stays_out_of_stdout(mmt_lib):
+    """This image's RCCL prints a version banner to STDOUT when its first communicator is created; bench.init_dist creates it behind
+    a descriptor-level redirect to stderr, so rank 0's stdout stays the one JSON line (tools/scratch/rccl_banner.py: one rank on RCCL)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scratch", "rccl_banner.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "banner went to stderr: True" in out.stdout
