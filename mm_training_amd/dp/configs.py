@@ -6,7 +6,8 @@ lidar_conf :192-213, train_cfg :143-160).
   cfg3  LiDAR-only pillar path: 40k points, 0.2 m voxels
   cfg4  LiDAR + camera fusion (cfg2 camera half + pillar BEV concat)
   cfg5  LiDAR + radar + camera, 6 cams 512x1408, 80k points (8 columns)
-  tiny  a few-second smoke configuration for tests
+  tiny  a few-second smoke configuration for tests (no layer narrower than 16 channels on both sides: MIOpen's narrow NHWC
+        data-gradient kernel reads out of bounds, ops/conv_overlap.py NARROW)
 """
 import copy
 
@@ -38,12 +39,12 @@ def make_config(name="cfg2"):
         z_bound=[pc_range[2], pc_range[5], voxel_size[2]],
         d_bound=[2.0, 58.0, 4.0 if tiny else 0.5], final_dim=final_dim, output_channels=cam_channels,
         downsample_factor=16,
-        img_backbone_conf=dict(type='ResNet', depth=18 if tiny else 50, base_channels=8 if tiny else 64,
+        img_backbone_conf=dict(type='ResNet', depth=18 if tiny else 50, base_channels=16 if tiny else 64,
                                out_indices=[0, 1, 2, 3]),
         img_neck_conf=dict(type='SECONDFPN',
-                           in_channels=[8, 16, 32, 64] if tiny else [256, 512, 1024, 2048],
-                           upsample_strides=[0.25, 0.5, 1, 2], out_channels=[8] * 4 if tiny else [128] * 4),
-        depth_net_conf=dict(in_channels=32 if tiny else 512, mid_channels=32 if tiny else 512))
+                           in_channels=[16, 32, 64, 128] if tiny else [256, 512, 1024, 2048],
+                           upsample_strides=[0.25, 0.5, 1, 2], out_channels=[16] * 4 if tiny else [128] * 4),
+        depth_net_conf=dict(in_channels=64 if tiny else 512, mid_channels=32 if tiny else 512))
     base = 16 if tiny else 160
     head_conf = dict(
         bev_backbone_conf=dict(type='ResNet', in_channels=fuse_channels, depth=18, num_stages=3, strides=(1, 2, 2),

