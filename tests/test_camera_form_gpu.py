@@ -302,7 +302,7 @@ def test_lssfpn_camera_form_is_the_default_and_runs_no_geometry_kernel(mmt_lib, 
     assert "mmt_lss_splat_forward_cam" in calls_c and "mmt_lss_splat_backward_cam" in calls_c
     assert "mmt_frustum_geometry" not in calls_c and "mmt_frustum_geometry" in calls_g
     assert (bev_c - bev_g).abs().max().item() <= 1e-5 * max(1.0, bev_g.abs().max().item())
-    assert torch.allclose(g_c, g_g, rtol=1e-3, atol=1e-6)
+    assert (g_c - g_g).abs().max().item() <= 1e-3 * g_g.abs().max().item() + 1e-7     # (two passes through MIOpen's split-K nets: against the tensor's own size)
     # calibration id: the matrices are computed once
     cached = dict(mats, calibration_id="rig-a")
     run(True, cached)
