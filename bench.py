@@ -266,7 +266,9 @@ def init_dist(n_gpus, device="cuda"):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if device == "cpu":
         if world > 1:
-            dist.init_process_group(backend="gloo")
+            with _StdoutToStderr():
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
         return rank, local_rank, world
     ndev = torch.cuda.device_count()
     backend, local_rank = choose_backend(world, local_rank, ndev, os.environ.get("MMT_DIST_BACKEND", "nccl"))   # "nccl" is RCCL on ROCm
@@ -277,7 +279,9 @@ def init_dist(n_gpus, device="cuda"):
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
                 dist.barrier()
         else:
-            dist.init_process_group(backend=backend)
+            with _StdoutToStderr():                      # (gloo announces its connections on stdout, too)
+                dist.init_process_group(backend=backend)
+                dist.barrier()
         if world <= ndev and "MMT_DIST_BACKEND" not in os.environ:
             # one GPU per rank: the gradient all-reduce must ride RCCL (xGMI), never silently a host-staged backend
             assert dist.get_backend() == "nccl", f"world {world} on {ndev} GPUs initialised backend {dist.get_backend()!r}, expected RCCL"
