@@ -68,7 +68,8 @@ class GradReducer:
 
     # ---- one call per parameter and backward pass, on the autograd thread, right after its .grad was set
     def _on_grad(self, p):
-        task = torch._C._current_graph_task_id()
+        get = getattr(torch._C, "_current_graph_task_id", None)
+        task = get() if get is not None else 0               # (without the accessor: no protection against a pass that died half-way)
         if task != self._task:                               # first gradient of a new backward pass (the previous one may have died half-way)
             if any(n != len(m) for n, m in zip(self._pending, self.buckets)):
                 self._reset()

@@ -270,9 +270,7 @@ class TrainStep(nn.Module):
         from ..ops import conv_overlap
         from ..layers.heads import bev_depth_head
         streams = [torch.cuda.current_stream(self.device), torch.cuda.default_stream(self.device)]
-        streams += list(conv_overlap._side.values())
-        for group in bev_depth_head._TASK_STREAMS.values():
-            streams += list(group)
+        streams += conv_overlap.streams_in_use() + bev_depth_head.streams_in_use()
         return streams
 
     def finish_backward(self):

@@ -55,6 +55,11 @@ def _conv_module(cin, cout, k):
 _TASK_STREAMS = {}
 
 
+def streams_in_use():
+    """Every stream the task heads have been dealt to in this process."""
+    return [s for group in _TASK_STREAMS.values() for s in group]
+
+
 class _Fork(torch.autograd.Function):
     """x -> n aliases of x, one per stream; backward: the sum of the n gradients, formed on the stream the fork ran on.  Every
     alias is consumed on ONE stream, so each gradient slot of this node has a single producer stream and autograd's plain

@@ -68,11 +68,23 @@ def side_stream(device):
     return _side[key]
 
 
+def streams_in_use():
+    """The side streams created so far (one per device that ran a deferred / paired backward)."""
+    return list(_side.values())
+
+
 def join(device=None):
     """Main stream waits for every weight gradient queued on the side stream (deferred mode: once per backward)."""
     for (kind, index), s in _side.items():
         if device is None or (kind, index) == (device.type, device.index):
             torch.cuda.current_stream(torch.device(kind, index)).wait_stream(s)
+
+
+def _graph_task_id():
+    """Id of the running backward pass.  (A torch without the accessor: a fresh object per call, i.e. one join callback per layer
+    -- slower at the end of the pass, never wrong.)"""
+    get = getattr(torch._C, "_current_graph_task_id", None)
+    return get() if get is not None else object()
 
 
 def _end_of_backward():
@@ -151,7 +163,7 @@ class _ConvOverlap(Function):
             if deferred:
                 # one callback per backward pass; keyed by the pass, so a pass that died with an exception (its callbacks never
                 # ran) cannot leave the next one without its join
-                task = torch._C._current_graph_task_id()
+                task = _graph_task_id()
                 if _state["join_queued_for"] != task:
                     _state["join_queued_for"] = task
                     torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
