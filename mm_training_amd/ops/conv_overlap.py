@@ -122,7 +122,6 @@ class _ConvOverlap(Function):
         gx = gw = gb = None
         deferred = False
         main = torch.cuda.current_stream(gy.device)
-        side = side_stream(gy.device)
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
         if mode == "inline":                                 # one stream, one call: autograd's own backward
@@ -136,6 +135,7 @@ class _ConvOverlap(Function):
             if gb is not None and gb.dtype != b_dtype:
                 gb = gb.to(b_dtype)
             return gx, gw, gb, None, None, None, None, None, None
+        side = side_stream(gy.device)                    # (created on first use: an inline rank never owns one)
         if need_w or has_b:
             side.wait_stream(main)                       # grad_out (and, in the first layer of a backward, the saved tensors) are ready
             with torch.cuda.stream(side):
