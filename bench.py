@@ -200,27 +200,9 @@ def spawn_ranks(n, argv):
 
 
 def use_shipped_miopen_db():
-    """MIOpen's per-shape solver choice for the dense nets: the repo ships the user find/perf DB produced by an
-    exhaustive search of the cfg2 and cfg4 steps on an MI355X (mm_training_amd/miopen_db, ~100 KB of text).  Each
-    process works on a private copy (MIOpen rewrites the files), so a fresh box gets the tuned solvers without the
-    minutes of search.  Must run before the first convolution."""
-    src = os.path.join(ROOT, "mm_training_amd", "miopen_db")
-    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(src):
-        return False
-    import shutil
-    import tempfile
-    dst = tempfile.mkdtemp(prefix="mmt_miopen_db_")
-    for f in os.listdir(src):
-        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-    os.environ["MIOPEN_USER_DB_PATH"] = dst
-    # HYBRID find mode: a find-DB hit returns the tuned solver without running anything, a miss times the
-    # applicable solvers once (seconds) instead of trusting the immediate-mode heuristic.  The reference "naive"
-    # solvers (tens of ms per call, never chosen) are excluded from that timing: they alone cost ~15 s of warm-up
-    # per process (profiles/r01_miopen_find_modes.txt).
-    os.environ.setdefault("MIOPEN_FIND_MODE", "3")
-    for d in ("FWD", "BWD", "WRW"):
-        os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + d, "0")
-    return True
+    """MIOpen's per-shape solver choice for the dense nets: mm_training_amd/miopen_db (see its README and `enable`)."""
+    from mm_training_amd.miopen_db import enable
+    return enable()
 
 
 def _late_imports(device):
