@@ -33,7 +33,7 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 9   /* 9: mmt_bn_relu_forward_ex / _backward_ex (bf16 activations); additive */
+#define MMT_ABI_VERSION 10  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -416,6 +416,58 @@ int mmt_lss_camera_form_supported(int B, int N, int D, int fH, int fW, int C);
 /* 1 when mmt_lss_splat_forward_cam[_bf16] of this shape uses an exclusive_cache it is handed (ABI 8): a caller allocates the
  * cache (mmt_lss_exclusive_cache_bytes) only for such shapes; every other shape ignores the argument. */
 int mmt_lss_exclusive_cache_used(int B, int N, int D, int fH, int fW, int C);
+
+/* PLAN FORM of the fused lift-splat forward (ABI 10; SURVEY section 8 rows f1 + f3; replaces layers/backbones/lss_fpn.py:328-361,
+ * :461-462 and :441-464 like the camera form, same operands, same cells bit for bit): the OUTPUT-stationary forward.  Which
+ * frustum points feed a BEV cell depends on the calibration (a sample's N matrices, the frustum axes, the grid) only, so the
+ * library learns it once per calibration, on the device, into a PLAN kept in the caller's plan cache: runs (up to 4
+ * consecutive depth bins of a 16-row block of one image column that share a cell, with 16-bit row masks) grouped into jobs
+ * (a contiguous range of the cells of an 8 x 8 BEV tile, at most 96 runs).  The forward gives a job to a workgroup: lane
+ * groups sum depth * context per run in registers (the pair's 16 context rows loaded once), one partial row per run into
+ * LDS, then every cell's partial rows are summed in plan order and STORED.  Against the camera form's ray walks: no zero
+ * fill of the map, no global atomics, every output element written exactly once, results bit-identical from call to call
+ * (the sums are ordered by camera, column, row block, bin).
+ *   plan_cache  device memory, 256-byte aligned, plan_cache_bytes = mmt_lss_plan_cache_bytes(..., slots) bytes with
+ *               slots >= B; owned by the caller for good, contents owned by the library (no initialisation needed; calls that
+ *               share a cache must be ordered on one stream).  A slot holds one calibration (a few MB: cfg4 3.9 MB); the least
+ *               recently used one is replaced.  A change of the launch shape, the grid or the frustum axes' contents empties it.
+ *   mmt_lss_plan_prepare  looks every sample of the batch up (64-bit hash of its matrices, then bit for bit) and learns the
+ *               calibrations it does not know (two launches; ~3 us when everything is known).  It depends on `combine` only:
+ *               call it as early in the step as the matrices exist and pass MMT_LSS_PLAN_PREPARED to the forward -- or leave
+ *               the flag out and the forward does it itself in front of its kernel.
+ *   column_summary (forward, nullable): the batch's column summary [B*N, ceil(fH/16), fW, D, 2] as the camera form defines
+ *               it, WRITTEN (copied from the slots) for mmt_lss_splat_backward_cam.
+ * depth / context as in the camera form with MMT_LSS_PIXEL_MAJOR (required).  B <= 64, N <= 16, C in {64, 80, 128},
+ * 4 <= D <= 2047, fH <= 512, N * fW <= 65535, nx, ny <= 32767.  A calibration whose plan does not fit its slot (more than
+ * 2 * N * ceil(fH/16) * fW * D runs: cameras rolled so far that most 16-row blocks straddle cells) is served by the same kernel's brute-force path from the slot's summary: exact, deterministic, slow
+ * (~0.5 ms per sample) -- header word 10 of the cache counts such samples; use the camera form for such a rig. */
+#define MMT_LSS_PLAN_PREPARED 0x2000 /* mmt_lss_splat_forward_plan*: mmt_lss_plan_prepare ran for this batch on this stream since the last forward */
+#define MMT_LSS_PLAN_BRUTE 0x4000    /* mmt_lss_splat_forward_plan*: every sample through the brute-force path (tests) */
+#define MMT_LSS_FAMILY_PLAN 4        /* mmt_lss_last_kernel_family(0) & 0xF: the plan form */
+int mmt_lss_plan_supported(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z);
+int64_t mmt_lss_plan_cache_bytes(int N, int D, int fH, int fW, int num_voxel_x, int num_voxel_y, int slots);   /* 0: bad arguments */
+int mmt_lss_plan_prepare(int B, int N, int D, int fH, int fW, int num_voxel_x, int num_voxel_y, int num_voxel_z, const float *combine,
+                         const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
+                         const float *voxel_size_host, void *plan_cache, int64_t plan_cache_bytes, void *stream);
+int mmt_lss_splat_forward_plan(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                               const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,
+                               const float *voxel_coord_host, const float *voxel_size_host, const float *depth, const float *context,
+                               float *output_features, int32_t *column_summary, void *plan_cache, int64_t plan_cache_bytes, int flags,
+                               void *stream);
+int mmt_lss_splat_forward_plan_bf16(int B, int N, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                    const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,
+                                    const float *voxel_coord_host, const float *voxel_size_host, const uint16_t *depth,
+                                    const uint16_t *context, float *output_features, int32_t *column_summary, void *plan_cache,
+                                    int64_t plan_cache_bytes, int flags, void *stream);
+/* Counters of a plan cache (device -> host copy of 8 words: the call synchronises `stream`): [0] sample-calls that found their
+ * plan, [1] calibrations learnt, [2] sample-calls served by the brute-force path, [3] times the table was emptied, [4] calls,
+ * [5] slots. */
+int mmt_lss_plan_cache_counters(const void *plan_cache, int64_t plan_cache_bytes, int64_t *counters_host /* 8 */, void *stream);
+/* Where things are in a plan cache of plan_cache_bytes bytes for this shape (diagnostics and tests; 12 host words): [0] slots,
+ * [1] byte offset of slot 0, [2] bytes per slot, [3] / [4] offsets of a slot's column summary / job records, [5] offset of the
+ * per-sample verdicts (int32 x 4 each: slot, jobs, state 1 = planned / 2 = brute force, representative sample), [6] job capacity,
+ * [7] run capacity, [8] bytes per job record, [9] verdict entries, [10] strips (N * ceil(fH/16) * fW), [11] tiles. */
+int mmt_lss_plan_cache_layout(int N, int D, int fH, int fW, int num_voxel_x, int num_voxel_y, int64_t plan_cache_bytes, int64_t *layout_host);
 
 /* ------------------------------------------------- bf16 feature storage
  * BASELINE configs[4] names bf16.  The reference has no behaviour for it -- its extension takes data_ptr<float>()

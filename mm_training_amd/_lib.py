@@ -41,6 +41,13 @@ SIGNATURES = {
     "mmt_lss_exclusive_cache_bytes": (_c_i64, [_c_int] * 4),
     "mmt_lss_splat_backward_cam": (_c_int, [_c_int] * 9 + [_c_ptr] * 9 + [_c_i64] * 4 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
     "mmt_lss_splat_backward_cam_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 9 + [_c_i64] * 4 + [_c_ptr] * 4 + [_c_int, _c_ptr]),
+    "mmt_lss_plan_supported": (_c_int, [_c_int] * 9),
+    "mmt_lss_plan_cache_bytes": (_c_i64, [_c_int] * 7),
+    "mmt_lss_plan_prepare": (_c_int, [_c_int] * 8 + [_c_ptr] * 7 + [_c_i64, _c_ptr]),
+    "mmt_lss_splat_forward_plan": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_i64, _c_int, _c_ptr]),
+    "mmt_lss_splat_forward_plan_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_i64, _c_int, _c_ptr]),
+    "mmt_lss_plan_cache_counters": (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr]),
+    "mmt_lss_plan_cache_layout": (_c_int, [_c_int] * 6 + [_c_i64, _c_ptr]),
     "mmt_lss_last_kernel_family": (_c_int, [_c_int]),
     "mmt_lss_camera_form_supported": (_c_int, [_c_int] * 6),
     "mmt_lss_exclusive_cache_used": (_c_int, [_c_int] * 6),
@@ -103,7 +110,9 @@ LSS_COLUMN_BACKWARD = 0x400   # mmt_lss_splat_backward*: matrix-core column kern
 LSS_ZERO_OUTPUT = 0x800       # mmt_lss_splat_forward*: the call zero-fills the BEV map itself (write-through stores)
 LSS_SUMMARY_CACHED = 0x1000   # mmt_lss_splat_forward_cam*: read the column summary instead of computing the geometry
 LSS_STATS_SLOTS = 64          # column_stats of mmt_lss_splat_backward_cam*: int64 [2 * LSS_STATS_SLOTS], (mismatching, kept) pairs
-LSS_FAMILY = {0: "none", 1: "ray", 2: "tile", 3: "column"}     # mmt_lss_last_kernel_family() & 0xF; | 0x10 = camera form
+LSS_PLAN_PREPARED = 0x2000    # mmt_lss_splat_forward_plan*: mmt_lss_plan_prepare already ran for this batch
+LSS_PLAN_BRUTE = 0x4000       # mmt_lss_splat_forward_plan*: brute-force path for every sample (tests)
+LSS_FAMILY = {0: "none", 1: "ray", 2: "tile", 3: "column", 4: "plan"}     # mmt_lss_last_kernel_family() & 0xF; | 0x10 = camera form
 LSS_FAMILY_REGISTER, LSS_FAMILY_EXCLUSIVE, LSS_FAMILY_BLOCK = 0x20, 0x40, 0x80      # forward: register walk / an exclusive-cell cache was used / block walk
 
 _lib = None

@@ -1,0 +1,789 @@
+// Output-stationary fused lift-splat forward ("plan form", ABI 10; SURVEY section 8 rows f1 + f3): replaces
+// layers/backbones/lss_fpn.py:328-361 (get_geometry), :461-462 (quantise), :441-464 (lift, voxel_pooling) like the camera
+// form of lift_splat_tile.hip, but with the roles turned round: the OUTPUT is stationary.
+//
+// The camera-form ray walks are input-stationary: a workgroup owns an image column, and the BEV rows it produces meet in
+// memory through fp32 atomics on a zero-filled map (12 MB of atomics + a 21 MB fill per launch at BASELINE configs[3]; sums in
+// arrival order).  Which points feed a cell depends on the calibration only, so here it is worked out ONCE per calibration,
+// on the device, into a plan (lss_plan_core.h): runs (<= 4 consecutive depth bins of a 16-row block of one image column that
+// share a cell, with their row masks) grouped into jobs (a contiguous range of the cells of an 8 x 8 BEV tile, <= 96 runs).
+//   lss_plan_probe   one workgroup: hashes every sample's matrices, finds (or claims) its slot in the caller's plan cache,
+//                    leaves a verdict per sample and a to-do list of calibrations to learn
+//   lss_plan_build   one workgroup per calibration to learn: column summary (the geometry of mmt_camera.h), runs, jobs, records
+//   lss_plan_fwd     a workgroup per job: lane groups take the job's (column, row block) pairs -- the pair's 16 context rows
+//                    in registers, a run's depths summed per image row, one partial row per run into LDS -- then every cell's
+//                    partial rows are summed in plan order and STORED; cells nobody reaches are stored as zeros.
+// No zero fill, no atomics, every output element written exactly once, bit-identical from launch to launch.  A calibration
+// whose plan would not fit its slot (a rig rolled so far that most blocks of rows straddle cells) is served by the same
+// kernel's brute-force path from the slot's column summary: slow, still deterministic, still exact.
+#include <string.h>
+
+#include "lss_plan_core.h"
+#include "mmt_camera.h"
+
+namespace {
+
+using namespace mmt::plan;
+
+constexpr int kPlanMaxB = 64;            // samples per call
+constexpr int kPlanMaxN = 16;            // cameras per sample
+constexpr int kBuildPar = 8;             // calibrations learnt concurrently (scratch areas)
+constexpr int kBuildThreads = 1024;
+constexpr int kFwdThreads = 256;
+constexpr unsigned kPlanMagic = 0x4E4C504Du;      // "MPLN"
+constexpr int kStateEmpty = 0, kStateReady = 1, kStateBrute = 2;
+
+// ---- the caller's plan cache: header | verdicts | to-do list | slots | build scratch --------------------------------------
+constexpr int64_t kHdrBytes = 4096;
+constexpr int64_t kVerdictOff = 256;     // int4 [kPlanMaxB]: slot, units (jobs), state, representative sample
+constexpr int64_t kTodoOff = 256 + 16 * kPlanMaxB;       // int4 [kPlanMaxB]: sample, slot, hash lo, hash hi
+constexpr int64_t kDupOff = kTodoOff + 16 * kPlanMaxB;   // int [kPlanMaxB]: the earlier sample with the same matrices, or -1
+constexpr int64_t kSlotMetaBytes = 2048; // u64 hash | state, njobs, nruns, stamp | matrices [kPlanMaxN * 16] at +64
+
+struct CacheHeader {
+    unsigned magic, sig_lo, sig_hi, axes_lo, axes_hi, clock, nslots, todo_count;
+    unsigned hits, built, brute, resets, calls, reserved[3];
+};
+struct SlotMeta { unsigned hash_lo, hash_hi; int state, njobs, nruns; unsigned stamp; int pad[10]; float mats[kPlanMaxN * 16]; };
+
+struct Layout {
+    Dims d;
+    int64_t summary_off, records_off, slot_bytes, scratch_bytes, slots_off, scratch_off, total;
+    int nslots;
+};
+static inline int64_t up256(int64_t v) { return (v + 255) & ~255ll; }
+void make_layout(int N, int D, int fH, int fW, int nx, int ny, int slots, Layout *l) {
+    make_dims(N, D, fH, fW, nx, ny, &l->d);
+    l->summary_off = kSlotMetaBytes;
+    l->records_off = l->summary_off + up256(8ll * l->d.strips * D);
+    l->slot_bytes = l->records_off + up256((int64_t)l->d.jobs_cap * kJobBytes);
+    l->scratch_bytes = up256(scratch_bytes(l->d, kBuildThreads));
+    l->nslots = slots;
+    l->slots_off = kHdrBytes;
+    l->scratch_off = l->slots_off + (int64_t)slots * l->slot_bytes;
+    l->total = l->scratch_off + (int64_t)kBuildPar * l->scratch_bytes;
+}
+
+struct PlanArgs {                        // what the three kernels share
+    unsigned char *cache;
+    int64_t summary_off, records_off, slot_bytes, scratch_bytes, slots_off, scratch_off;
+    Dims d;
+    int B, nz, nslots;
+    unsigned sig_lo, sig_hi;
+    const float *combine, *fu, *fv, *fd;
+    mmt::CamGrid q;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---- probe ------------------------------------------------------------------------------------------------------------------
+// One workgroup.  Per sample: a 64-bit hash of its N matrices; a sample whose matrices equal an earlier sample's (bit for
+// bit) shares that sample's verdict; otherwise its slot is looked up among the cache's slots (hash, then the matrices bit for
+// bit); a miss claims an empty slot, else the least recently used one that this call does not use, and goes on the to-do
+// list.  The frustum axes' contents and the launch shape sign the table: a change empties it.
+__global__ __launch_bounds__(256) void lss_plan_probe(PlanArgs a) {
+    __shared__ unsigned long long s_hash[kPlanMaxB];
+    __shared__ unsigned long long s_axes;
+    __shared__ unsigned s_shash_lo[256], s_shash_hi[256], s_stamp[256];
+    __shared__ int s_state[256], s_used[256], s_slot[kPlanMaxB];
+    __shared__ int s_reset;
+    const int tid = threadIdx.x, lane = tid & 63;
+    CacheHeader *hdr = reinterpret_cast<CacheHeader *>(a.cache);
+    int4 *verdict = reinterpret_cast<int4 *>(a.cache + kVerdictOff);
+    int4 *todo = reinterpret_cast<int4 *>(a.cache + kTodoOff);
+    int *dup = reinterpret_cast<int *>(a.cache + kDupOff);
+    const int words = a.d.N * 16;
+    if (tid == 0) s_axes = 0ull;
+    __syncthreads();
+    {   // order-independent hash of the axes' contents (position-keyed terms, summed)
+        unsigned long long part = 0ull;
+        const int na = a.d.fW + a.d.fH + a.d.D;
+        for (int i = tid; i < na; i += 256) {
+            const float v = i < a.d.fW ? a.fu[i] : (i < a.d.fW + a.d.fH ? a.fv[i - a.d.fW] : a.fd[i - a.d.fW - a.d.fH]);
+            part += mix64(((unsigned long long)i << 32) | __float_as_uint(v));
+        }
+        atomicAdd(&s_axes, part);
+    }
+    if (tid < a.B) {
+        unsigned long long h = 0xCBF29CE484222325ull;
+        const unsigned *m = reinterpret_cast<const unsigned *>(a.combine) + (int64_t)tid * words;
+        for (int i = 0; i < words; ++i) { h ^= m[i]; h *= 0x100000001B3ull; h ^= h >> 29; }
+        s_hash[tid] = h;
+    }
+    __syncthreads();
+    const unsigned ax_lo = (unsigned)s_axes, ax_hi = (unsigned)(s_axes >> 32);
+    if (tid == 0)
+        s_reset = (hdr->magic != kPlanMagic || hdr->sig_lo != a.sig_lo || hdr->sig_hi != a.sig_hi || hdr->axes_lo != ax_lo || hdr->axes_hi != ax_hi ||
+                   hdr->nslots != (unsigned)a.nslots) ? 1 : 0;
+    __syncthreads();
+    const int reset = s_reset;
+    for (int s = tid; s < a.nslots; s += 256) {
+        SlotMeta *sm = reinterpret_cast<SlotMeta *>(a.cache + a.slots_off + (int64_t)s * a.slot_bytes);
+        if (reset) sm->state = kStateEmpty;
+        s_shash_lo[s] = sm->hash_lo; s_shash_hi[s] = sm->hash_hi; s_stamp[s] = sm->stamp;
+        s_state[s] = reset ? kStateEmpty : sm->state;
+        s_used[s] = 0;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // wave 0 decides, every lane with the same (uniform) values; only the bit-for-bit comparisons are spread over the lanes
+    auto same_words = [&](const unsigned *p, const unsigned *q) {
+        bool eq = true;
+        for (int i = lane; i < words; i += 64) eq = eq && p[i] == q[i];
+        return __all(eq) != 0;
+    };
+    const unsigned clock = reset ? 1u : hdr->clock + 1u;
+    const bool was_init = hdr->magic == kPlanMagic;
+    unsigned n_hit = 0, n_todo = 0;
+    // pass 1: duplicates inside the batch, and the samples whose calibration the table knows (their slots are in use: no victim)
+    for (int b = 0; b < a.B; ++b) {
+        const unsigned long long h = s_hash[b];
+        const unsigned *mb = reinterpret_cast<const unsigned *>(a.combine) + (int64_t)b * words;
+        int rep = -1;
+        for (int e = 0; e < b && rep < 0; ++e)
+            if (s_hash[e] == h && same_words(mb, reinterpret_cast<const unsigned *>(a.combine) + (int64_t)e * words)) rep = e;
+        if (lane == 0) dup[b] = rep;            // (a duplicate's verdict is written with its representative's: below for a hit, by the build otherwise)
+        int slot = -1;
+        if (rep < 0) {
+            for (int s = 0; s < a.nslots && slot < 0; ++s) {
+                if (s_state[s] != kStateEmpty && s_shash_lo[s] == (unsigned)h && s_shash_hi[s] == (unsigned)(h >> 32)) {
+                    const SlotMeta *sm = reinterpret_cast<const SlotMeta *>(a.cache + a.slots_off + (int64_t)s * a.slot_bytes);
+                    if (same_words(mb, reinterpret_cast<const unsigned *>(sm->mats))) slot = s;
+                }
+            }
+            if (slot >= 0) {
+                SlotMeta *sm = reinterpret_cast<SlotMeta *>(a.cache + a.slots_off + (int64_t)slot * a.slot_bytes);
+                if (lane == 0) { verdict[b] = make_int4(slot, sm->njobs, sm->state, b); sm->stamp = clock; }
+                s_used[slot] = 1;
+                ++n_hit;
+            }
+        }
+        s_slot[b] = rep >= 0 ? -2 : slot;
+    }
+    // pass 2: a slot for every calibration to learn -- an empty one, else the least recently used one this call does not use
+    // (the entry points demand nslots >= B, so there is one)
+    for (int b = 0; b < a.B; ++b) {
+        if (s_slot[b] != -1) continue;
+        const unsigned long long h = s_hash[b];
+        int victim = -1;
+        for (int s = 0; s < a.nslots && victim < 0; ++s) if (s_state[s] == kStateEmpty && !s_used[s]) victim = s;
+        if (victim < 0) {
+            unsigned best = 0xFFFFFFFFu;
+            for (int s = 0; s < a.nslots; ++s) if (!s_used[s] && (victim < 0 || s_stamp[s] < best)) { victim = s; best = s_stamp[s]; }
+        }
+        s_used[victim] = 1; s_state[victim] = kStateEmpty;
+        if (lane == 0) {
+            SlotMeta *sm = reinterpret_cast<SlotMeta *>(a.cache + a.slots_off + (int64_t)victim * a.slot_bytes);
+            sm->state = kStateEmpty;           // (nothing of it is served while it is being learnt)
+            todo[n_todo] = make_int4(b, victim, (int)(unsigned)h, (int)(unsigned)(h >> 32));
+            verdict[b] = make_int4(victim, 0, kStateEmpty, b);
+        }
+        ++n_todo;
+    }
+    // duplicates of a hit copy its verdict now (the build writes those of a sample it learns); lane 0 wrote them itself
+    if (lane == 0) {
+        for (int b = 0; b < a.B; ++b) {
+            const int rep = dup[b];
+            if (rep >= 0) { const int4 v = verdict[rep]; if (v.z != kStateEmpty) verdict[b] = make_int4(v.x, v.y, v.z, rep); }
+        }
+        hdr->magic = kPlanMagic; hdr->sig_lo = a.sig_lo; hdr->sig_hi = a.sig_hi; hdr->axes_lo = ax_lo; hdr->axes_hi = ax_hi;
+        hdr->clock = clock; hdr->nslots = (unsigned)a.nslots; hdr->todo_count = n_todo;
+        if (reset) { hdr->hits = 0; hdr->built = 0; hdr->brute = 0; hdr->resets = was_init ? hdr->resets + 1 : 0; hdr->calls = 0; }
+        hdr->hits += n_hit; hdr->built += n_todo; hdr->calls += 1;
+    }
+}
+
+// ---- build ------------------------------------------------------------------------------------------------------------------
+struct DevRowCells {                     // the cells of a mixed block's rows, from the matrices (mmt_camera.h: bit-identical to the kernels')
+    const PlanArgs &a;
+    int b;
+    int last_s, last_bin;
+    mmt_cam_column cc;
+    __device__ int operator()(int s, int bin, int row) {
+        const Dims &d = a.d;
+        const int w = s % d.fW, rb = (s / d.fW) % d.nb, n = s / (d.fW * d.nb);
+        if (s != last_s || bin != last_bin) {
+            float cm[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) cm[k] = a.combine[((int64_t)b * d.N + n) * 16 + k];
+            cc = mmt_cam_column_make(cm, a.fu[w], a.fd[bin]);
+            last_s = s; last_bin = bin;
+        }
+        const int r = rb * 16 + row;
+        int gx, gy;
+        const bool in = mmt_cam_row_xy(cc, a.fv[r < d.fH ? r : d.fH - 1], a.q, d.nx, d.ny, gx, gy);
+        return in ? ((gy << 16) | gx) : -1;
+    }
+};
+
+__global__ __launch_bounds__(kBuildThreads) void lss_plan_build(PlanArgs a) {
+    const CacheHeader *hdr = reinterpret_cast<const CacheHeader *>(a.cache);
+    const int4 *todo = reinterpret_cast<const int4 *>(a.cache + kTodoOff);
+    const int *dup = reinterpret_cast<const int *>(a.cache + kDupOff);
+    int4 *verdict = reinterpret_cast<int4 *>(a.cache + kVerdictOff);
+    const int ntodo = (int)hdr->todo_count;
+    const int tid = threadIdx.x, nt = kBuildThreads;
+    const Dims &d = a.d;
+    Scratch sc;
+    scratch_carve(d, kBuildThreads, a.cache + a.scratch_off + (int64_t)blockIdx.x * a.scratch_bytes, &sc);
+    for (int k = blockIdx.x; k < ntodo; k += gridDim.x) {
+        const int4 td = todo[k];
+        const int b = td.x, slot = td.y;
+        unsigned char *sbase = a.cache + a.slots_off + (int64_t)slot * a.slot_bytes;
+        int2 *summary = reinterpret_cast<int2 *>(sbase + a.summary_off);
+        // ---- the column summary: (cell of the first row | z mask | "one cell" bit) per (strip, bin)
+        const int total = d.strips * d.D;
+        for (int base = 0; base < total; base += nt) {
+            const int e = base + tid;
+            const bool valid = e < total;
+            const int ec = valid ? e : total - 1;
+            const int s = ec / d.D, bin = ec - s * d.D;
+            const int w = s % d.fW, rb = (s / d.fW) % d.nb, n = s / (d.fW * d.nb);
+            float cm[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) cm[q] = a.combine[((int64_t)b * d.N + n) * 16 + q];
+            const mmt_cam_column cc = mmt_cam_column_make(cm, a.fu[w], a.fd[bin]);
+            const int r0 = rb * 16;
+            const int nr = (d.fH - r0) < 16 ? (d.fH - r0) : 16;
+            unsigned zm16 = 0;
+            bool uni16 = true, in00 = false;
+            int x00 = 0, y00 = 0;
+#pragma unroll 1
+            for (int hb = 0; hb < 16; hb += 8) {
+                if (hb < nr) {
+                    const int nh = (nr - hb) < 8 ? (nr - hb) : 8;
+                    float cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cv[u] = a.fv[r0 + hb + (u < nh ? u : nh - 1)];
+                    bool uniform, in0;
+                    int x0, y0;
+                    const unsigned zmask = mmt_cam_column_cells<8>(cc, cv, nh, mmt_rows_sorted<8>(cv, nh), a.q, d.nx, d.ny, a.nz, uniform, in0, x0, y0);
+                    bool mine = uniform;       // `uniform` is a wave-wide verdict; when it fails, this block's own rows decide its bit
+                    if (!uniform) {
+                        mine = true;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            int gx, gy;
+                            mmt_cam_row_xy(cc, cv[u], a.q, d.nx, d.ny, gx, gy);
+                            mine = mine && gx == x0 && gy == y0;
+                        }
+                        mine = mine || zmask == 0u;
+                    }
+                    zm16 |= zmask << hb;
+                    if (hb == 0) { uni16 = mine; in00 = in0; x00 = x0; y00 = y0; }
+                    else uni16 = uni16 && mine && in0 == in00 && x0 == x00 && y0 == y00;      // (the rule of the forward kernels that write a summary)
+                }
+            }
+            if (valid) summary[e] = make_int2(in00 ? ((y00 << 16) | x00) : -1, (int)zm16 | (uni16 ? mmt::kSummaryUniform : 0));
+        }
+        __syncthreads();
+        const int32_t *sum32 = reinterpret_cast<const int32_t *>(summary);
+        DevRowCells rc{a, b, -1, -1, {}};
+        phase_clear(d, sc, tid, nt);
+        __syncthreads();
+        phase_count(d, sc, sum32, rc, tid, nt);
+        __syncthreads();
+        scan_a(sc.cell_off, d.ncells_tm, sc.partial, tid, nt); __syncthreads();
+        scan_b(sc.cell_off, d.ncells_tm, sc.partial, tid, nt); __syncthreads();
+        scan_c(sc.cell_off, d.ncells_tm, sc.partial, tid, nt); __syncthreads();
+        phase_check_runs(d, sc, tid);
+        __syncthreads();
+        int njobs = 0;
+        if (!sc.status[2]) {
+            phase_place(d, sc, sum32, rc, tid, nt);
+            __syncthreads();
+            phase_sort_cells(d, sc, tid, nt);
+            __syncthreads();
+            phase_count_jobs(d, sc, tid, nt);
+            __syncthreads();
+            scan_a(sc.tile_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
+            scan_b(sc.tile_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
+            scan_c(sc.tile_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
+            phase_check_jobs(d, sc, tid);
+            __syncthreads();
+            if (!sc.status[2]) {
+                phase_write_jobs(d, sc, tid, nt);
+                __syncthreads();
+                njobs = sc.status[1];
+                phase_records(d, sc, sbase + a.records_off, njobs, tid, nt);
+            }
+        }
+        __syncthreads();
+        const int state = sc.status[2] ? kStateBrute : kStateReady;
+        const int units = state == kStateReady ? njobs : d.ntiles;
+        SlotMeta *sm = reinterpret_cast<SlotMeta *>(sbase);
+        for (int i = tid; i < d.N * 16; i += nt) sm->mats[i] = a.combine[(int64_t)b * d.N * 16 + i];
+        if (tid == 0) {
+            sm->hash_lo = (unsigned)td.z; sm->hash_hi = (unsigned)td.w; sm->njobs = units; sm->nruns = sc.status[0]; sm->stamp = hdr->clock;
+            sm->state = state;
+        }
+        for (int e = tid; e < a.B; e += nt)
+            if (e == b || dup[e] == b) verdict[e] = make_int4(slot, units, state, b);
+        __syncthreads();
+    }
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    PlanArgs p;
+    const void *depth, *context;
+    float *out;
+    int2 *summary_out;                    // nullable: the batch's column summary [B*N, nb, fW, D] for the backward
+    int C, W, xps;                        // channels; workgroups per sample; XCDs per sample (0: plain mapping)
+    int force_brute;
+};
+
+template <int H>
+__device__ __forceinline__ float row_bcast(float v) {     // lane H of every row of 16 lanes, to all 16 (DPP row_newbcast)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + H, 0xF, 0xF, false));
+}
+
+typedef float plan_v2f __attribute__((ext_vector_type(2)));
+typedef float plan_f4u __attribute__((ext_vector_type(4), aligned(4)));      // four floats at a 4-byte aligned address
+
+// a lane group's share of a row of C = 16 * S channels: lane li holds channels [4 li, 4 li + 4) (+ [64 + 4 li, ..) for S = 8) and 64 + li (S = 5)
+
+template <int S> struct Acc {
+    static constexpr int NQ = S / 4, N1 = S % 4;          // float4 pieces, single floats (S in {4, 5, 8})
+    plan_v2f q[NQ * 2];
+    float s[N1 > 0 ? N1 : 1];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < NQ * 2; ++i) q[i] = plan_v2f{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < (N1 > 0 ? N1 : 1); ++i) s[i] = 0.f;
+    }
+    __device__ __forceinline__ void fma(float w, const Acc &c) {
+        const plan_v2f ww = {w, w};
+#pragma unroll
+        for (int i = 0; i < NQ * 2; ++i) q[i] = __builtin_elementwise_fma(c.q[i], ww, q[i]);
+#pragma unroll
+        for (int i = 0; i < N1; ++i) s[i] = __builtin_fmaf(w, c.s[i], s[i]);
+    }
+    __device__ __forceinline__ void add(const Acc &c) {
+#pragma unroll
+        for (int i = 0; i < NQ * 2; ++i) q[i] += c.q[i];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) s[i] += c.s[i];
+    }
+};
+
+// context row piece of lane li: elements at `row` (FT *), fp32 in registers
+template <typename FT, int S>
+__device__ __forceinline__ void load_ctx(const FT *row, int li, Acc<S> &c) {
+    constexpr int NQ = S / 4, N1 = S % 4;
+    if constexpr (sizeof(FT) == 4) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + 64 * i + 4 * li);
+            c.q[2 * i] = plan_v2f{v.x, v.y}; c.q[2 * i + 1] = plan_v2f{v.z, v.w};
+        }
+#pragma unroll
+        for (int i = 0; i < N1; ++i) c.s[i] = row[64 * NQ + 16 * i + li];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(row + 64 * i + 4 * li);
+            c.q[2 * i] = plan_v2f{bf16_lo(v.x), bf16_hi(v.x)}; c.q[2 * i + 1] = plan_v2f{bf16_lo(v.y), bf16_hi(v.y)};
+        }
+#pragma unroll
+        for (int i = 0; i < N1; ++i) c.s[i] = __uint_as_float((unsigned)row[64 * NQ + 16 * i + li] << 16);
+    }
+}
+template <int S>
+__device__ __forceinline__ void store_row(float *row, int li, const Acc<S> &c) {      // fp32 row in LDS or global, same channel layout
+    constexpr int NQ = S / 4, N1 = S % 4;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        *reinterpret_cast<float4 *>(row + 64 * i + 4 * li) = make_float4(c.q[2 * i].x, c.q[2 * i].y, c.q[2 * i + 1].x, c.q[2 * i + 1].y);
+#pragma unroll
+    for (int i = 0; i < N1; ++i) row[64 * NQ + 16 * i + li] = c.s[i];
+}
+template <int S>
+__device__ __forceinline__ void load_row(const float *row, int li, Acc<S> &c) {
+    load_ctx<float, S>(row, li, c);
+}
+
+// the depths of 4 consecutive bins of one pixel, starting at element e of the depth tensor.  The plan shifts a run at the end
+// of a ray back (lss_plan_core.h, phase_place), so the four bins always lie inside the pixel's D bins: plain loads.
+template <typename FT>
+__device__ __forceinline__ float4 load_depth4(const FT *depth, int64_t e) {
+    if constexpr (sizeof(FT) == 4) {
+        const plan_f4u v = *reinterpret_cast<const plan_f4u *>(depth + e);
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        // bf16: e may be odd (a 2-byte aligned address).  Even: the 8 bytes themselves.  Odd: the two dwords from e - 1 and the
+        // fourth element on its own (every access inside the pixel's four bins, or one element in front of them)
+        const bool odd = (e & 1) != 0;
+        const unsigned *q = reinterpret_cast<const unsigned *>(depth + (e & ~1ll));
+        const unsigned v0 = q[0], v1 = q[1], v2 = odd ? (unsigned)depth[e + 3] : 0u;
+        const unsigned a0 = odd ? (v0 >> 16) | (v1 << 16) : v0, a1 = odd ? (v1 >> 16) | (v2 << 16) : v1;
+        return make_float4(bf16_lo(a0), bf16_hi(a0), bf16_lo(a1), bf16_hi(a1));
+    }
+}
+
+#define PLAN_FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <typename FT, int S>
+__global__ __launch_bounds__(kFwdThreads) void lss_plan_fwd(FwdArgs a) {
+    extern __shared__ __align__(16) unsigned char plan_lds[];
+    constexpr int C = 16 * S;
+    const PlanArgs &p = a.p;
+    const Dims &d = p.d;
+    const int tid = threadIdx.x, g = tid >> 4, li = tid & 15;
+    // ---- which sample, which units (jobs of a learnt calibration / tiles of a brute-force one)
+    int b, first, stride, lo_k = 0, k_of = 0;
+    const int wg = blockIdx.x;
+    if (a.xps > 0) {                       // 8 % B == 0: the sample's workgroups sit on `xps` XCDs, each takes a contiguous share of the units
+        const int xcd = wg & 7, i = wg >> 3;
+        b = xcd / a.xps; k_of = xcd % a.xps;
+        first = i; stride = a.W / a.xps;
+    } else {
+        b = wg / a.W; first = wg - b * a.W; stride = a.W;
+    }
+    const int4 vd = reinterpret_cast<const int4 *>(p.cache + kVerdictOff)[b];
+    const int slot = vd.x;
+    if ((unsigned)slot >= (unsigned)p.nslots) return;       // (a cache nobody prepared: nothing to go by -- the entry point's contract, not a fault)
+    const bool brute = vd.z != kStateReady || a.force_brute;
+    const int units = brute ? d.ntiles : vd.y;
+    int hi_k = units;
+    if (a.xps > 0) { lo_k = (int)((int64_t)k_of * units / a.xps); hi_k = (int)((int64_t)(k_of + 1) * units / a.xps); }
+    const unsigned char *sbase = p.cache + p.slots_off + (int64_t)slot * p.slot_bytes;
+    const FT *depth = reinterpret_cast<const FT *>(a.depth);
+    const FT *context = reinterpret_cast<const FT *>(a.context);
+
+    // ---- the batch's column summary for the backward: every workgroup of the sample copies a slice of the slot's
+    if (a.summary_out != nullptr) {
+        const int64_t n8 = (int64_t)d.strips * d.D;
+        const int wl = a.xps > 0 ? k_of * stride + first : first;
+        const int2 *src = reinterpret_cast<const int2 *>(sbase + p.summary_off);
+        int2 *dst = a.summary_out + (int64_t)b * n8;
+        for (int64_t i = (int64_t)wl * kFwdThreads + tid; i < n8; i += (int64_t)a.W * kFwdThreads) dst[i] = src[i];
+    }
+
+    if (!brute) {
+        float *partial = reinterpret_cast<float *>(plan_lds + kJobBytes);
+        for (int job = lo_k + first; job < hi_k; job += stride) {
+          Acc<S> chain_acc;                    // a cell fed by more runs than a record holds: summed over its chain of records
+          chain_acc.zero();
+          bool more = false;
+          int rec = job;
+          do {
+            __syncthreads();
+            if (tid < kJobBytes / 16) reinterpret_cast<uint4 *>(plan_lds)[tid] = reinterpret_cast<const uint4 *>(sbase + p.records_off + (int64_t)rec * kJobBytes)[tid];
+            __syncthreads();
+            const JobHeader hdr = *reinterpret_cast<const JobHeader *>(plan_lds);
+            if (rec == job && (hdr.chain & kChainLink)) break;      // a link of a chain: the workgroup that met the head does it
+            more = (hdr.chain & kChainMore) != 0u;
+            ++rec;
+            const uint8_t *cb = plan_lds + kJobCellBeginOff;
+            const PairRec *pairs = reinterpret_cast<const PairRec *>(plan_lds + kJobPairsOff);
+            const RunRec *runs = reinterpret_cast<const RunRec *>(plan_lds + kJobRunsOff);
+            // ---- phase 1: a lane group per pair -- 16 context rows in registers, one partial row per run
+#pragma unroll 1
+            for (int pi = g; pi < hdr.npairs; pi += kFwdThreads / 16) {
+                const PairRec pr = pairs[pi];
+                const int n = pr.col / d.fW, w = pr.col - n * d.fW;
+                const int bn = b * d.N + n, r0 = pr.rb * 16;
+                Acc<S> ctx[16];
+#pragma unroll
+                for (int h = 0; h < 16; ++h) {
+                    const int row = (r0 + h) < d.fH ? (r0 + h) : d.fH - 1;
+                    load_ctx<FT, S>(context + (((int64_t)bn * d.fH + row) * d.fW + w) * C, li, ctx[h]);
+                }
+                const int myrow = (r0 + li) < d.fH ? (r0 + li) : d.fH - 1;
+                const int64_t pix = (((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D;
+                float4 dv[kMaxPairRuns];
+#pragma unroll
+                for (int r = 0; r < kMaxPairRuns; ++r) {
+                    dv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r < pr.nruns) dv[r] = load_depth4<FT>(depth, pix + runs[pr.run0 + r].d0);
+                }
+                if (r0 + 16 > d.fH) {          // rows past the image: their masks are zero, and so must their context be (0 * NaN)
+#pragma unroll
+                    for (int h = 0; h < 16; ++h) if (r0 + h >= d.fH) ctx[h].zero();
+                }
+#pragma unroll
+                for (int r = 0; r < kMaxPairRuns; ++r) {
+                    if (r < pr.nruns) {
+                        const RunRec rr = runs[pr.run0 + r];
+                        float wsum = ((rr.mask[0] >> li) & 1) ? dv[r].x : 0.f;
+                        wsum += ((rr.mask[1] >> li) & 1) ? dv[r].y : 0.f;
+                        wsum += ((rr.mask[2] >> li) & 1) ? dv[r].z : 0.f;
+                        wsum += ((rr.mask[3] >> li) & 1) ? dv[r].w : 0.f;
+                        Acc<S> acc;
+                        acc.zero();
+#define PLAN_STEP(h) acc.fma(row_bcast<h>(wsum), ctx[h]);
+                        PLAN_FOR16(PLAN_STEP)
+#undef PLAN_STEP
+                        store_row<S>(partial + (int)rr.pslot * C, li, acc);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- phase 2: a lane group per cell -- its partial rows in plan order, one store
+            const int tx0 = (hdr.tile % d.tiles_x) * kTile, ty0 = (hdr.tile / d.tiles_x) * kTile;
+            if (hdr.chain != kChainNone) {
+                if (g == 0) {
+                    for (int q = 0; q < hdr.nruns; ++q) { Acc<S> t; load_row<S>(partial + q * C, li, t); chain_acc.add(t); }
+                    const int x = tx0 + (hdr.c0 & 7), y = ty0 + (hdr.c0 >> 3);
+                    if (!more && x < d.nx && y < d.ny) store_row<S>(a.out + (((int64_t)b * d.ny + y) * d.nx + x) * C, li, chain_acc);
+                }
+            } else {
+#pragma unroll 1
+                for (int c = g; c < hdr.ncells; c += kFwdThreads / 16) {
+                    const int l = hdr.c0 + c;
+                    const int x = tx0 + (l & 7), y = ty0 + (l >> 3);
+                    Acc<S> acc;
+                    acc.zero();
+                    for (int q = cb[c]; q < cb[c + 1]; ++q) { Acc<S> t; load_row<S>(partial + q * C, li, t); acc.add(t); }
+                    if (x < d.nx && y < d.ny) store_row<S>(a.out + (((int64_t)b * d.ny + y) * d.nx + x) * C, li, acc);
+                }
+            }
+          } while (more);
+        }
+        return;
+    }
+
+    // ---- brute force: a calibration without a plan (its runs or jobs overflow the slot), straight from the slot's summary.
+    // A workgroup takes a tile; a lane group owns the cells whose index in the tile is g + 16 * pass, one pass at a time;
+    // the entries of the summary that can reach the tile are compacted in index order, so the sums are ordered as well.
+    if (tid == 0 && first == 0 && lo_k == 0) atomicAdd(&reinterpret_cast<CacheHeader *>(p.cache)->brute, 1u);
+    int *list = reinterpret_cast<int *>(plan_lds);
+    int *wcount = list + kFwdThreads;
+    const int2 *summary = reinterpret_cast<const int2 *>(sbase + p.summary_off);
+    const int total = d.strips * d.D;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int tile = lo_k + first; tile < hi_k; tile += stride) {
+        const int tx0 = (tile % d.tiles_x) * kTile, ty0 = (tile / d.tiles_x) * kTile;
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int mylocal = g + 16 * pass;
+            Acc<S> acc;
+            acc.zero();
+#pragma unroll 1
+            for (int base = 0; base < total; base += kFwdThreads) {
+                const int e = base + tid;
+                bool cand = false;
+                if (e < total) {
+                    const int2 sv = summary[e];
+                    const unsigned zm = (unsigned)sv.y & 0xFFFFu;
+                    if (sv.y & mmt::kSummaryUniform) {
+                        if (zm != 0u && sv.x >= 0) {
+                            const int lx = (sv.x & 0xFFFF) - tx0, ly = (sv.x >> 16) - ty0;
+                            cand = (unsigned)lx < (unsigned)kTile && (unsigned)ly < (unsigned)kTile && ((ly * kTile + lx) >> 4) == pass;
+                        }
+                    } else cand = zm != 0u;
+                }
+                const unsigned long long m = __ballot(cand);
+                __syncthreads();                 // (the list of the previous round has been consumed)
+                if (lane == 0) wcount[wave] = __popcll(m);
+                __syncthreads();
+                int off = 0, ncand = 0;
+#pragma unroll
+                for (int q = 0; q < kFwdThreads / 64; ++q) { const int cq = wcount[q]; off += q < wave ? cq : 0; ncand += cq; }
+                if (cand) list[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+                __syncthreads();
+#pragma unroll 1
+                for (int q = 0; q < ncand; ++q) {
+                    const int e2 = list[q];
+                    const int2 sv = summary[e2];
+                    const unsigned zm = (unsigned)sv.y & 0xFFFFu;
+                    const int s = e2 / d.D, bin = e2 - s * d.D;
+                    const int w = s % d.fW, rb = (s / d.fW) % d.nb, n = s / (d.fW * d.nb);
+                    const int bn = b * d.N + n, r0 = rb * 16;
+                    const int myrow = (r0 + li) < d.fH ? (r0 + li) : d.fH - 1;
+                    const int bin0 = bin + kRunBins > d.D ? d.D - kRunBins : bin;       // (the four bins stay inside the pixel's D)
+                    const float4 dq = load_depth4<FT>(depth, (((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D + bin0);
+                    const int dsel = bin - bin0;
+                    const float dbin = dsel == 0 ? dq.x : (dsel == 1 ? dq.y : (dsel == 2 ? dq.z : dq.w));
+                    const float dep = ((zm >> li) & 1u) ? dbin : 0.f;
+                    if (sv.y & mmt::kSummaryUniform) {
+                        const int local = ((sv.x >> 16) - ty0) * kTile + ((sv.x & 0xFFFF) - tx0);
+                        if (local == mylocal) {
+#define PLAN_STEP(h) { if (r0 + h < d.fH) { Acc<S> cr; load_ctx<FT, S>(context + (((int64_t)bn * d.fH + r0 + h) * d.fW + w) * C, li, cr); acc.fma(row_bcast<h>(dep), cr); } }
+                            PLAN_FOR16(PLAN_STEP)
+#undef PLAN_STEP
+                        }
+                    } else {
+                        float cm[12];
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) cm[k] = p.combine[(int64_t)bn * 16 + k];
+                        const mmt_cam_column cc = mmt_cam_column_make(cm, p.fu[w], p.fd[bin]);
+#define PLAN_STEP(h) { if (((zm >> h) & 1u) && r0 + h < d.fH) { int gx, gy; const bool in = mmt_cam_row_xy(cc, p.fv[r0 + h], p.q, d.nx, d.ny, gx, gy); \
+                            const float dh = row_bcast<h>(dep); \
+                            if (in && (gy - ty0) * kTile + (gx - tx0) == mylocal && (unsigned)(gx - tx0) < (unsigned)kTile && (unsigned)(gy - ty0) < (unsigned)kTile) { \
+                                Acc<S> cr; load_ctx<FT, S>(context + (((int64_t)bn * d.fH + r0 + h) * d.fW + w) * C, li, cr); acc.fma(dh, cr); } } }
+                        PLAN_FOR16(PLAN_STEP)
+#undef PLAN_STEP
+                    }
+                }
+            }
+            const int x = tx0 + (mylocal & 7), y = ty0 + (mylocal >> 3);
+            if (x < d.nx && y < d.ny) store_row<S>(a.out + (((int64_t)b * d.ny + y) * d.nx + x) * C, li, acc);
+        }
+    }
+}
+
+int plan_shape_ok(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, bool quiet) {
+    Dims d;
+    make_dims(N > 0 ? N : 1, D > 0 ? D : 1, fH > 0 ? fH : 1, fW > 0 ? fW : 1, nx > 0 ? nx : 1, ny > 0 ? ny : 1, &d);
+    const bool ok = B > 0 && B <= kPlanMaxB && N > 0 && N <= kPlanMaxN && D > 0 && fH > 0 && fW > 0 && nx > 0 && ny > 0 && nz > 0 && dims_ok(d) &&
+                    (C == 64 || C == 80 || C == 128) && (int64_t)B * N * fH * fW * D * 4 < (1ll << 31) && (int64_t)B * N * fH * fW * C < (1ll << 31) &&
+                    (int64_t)B * ny * nx * C < (1ll << 31);
+    if (!ok && !quiet)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the plan form takes B <= %d, N <= %d, C in {64, 80, 128}, D <= 2047, fH <= 512, N * fW <= 65535 and tensors "
+                         "below 2^31 elements (B=%d N=%d D=%d fH=%d fW=%d C=%d grid %d x %d x %d)", what, kPlanMaxB, kPlanMaxN, B, N, D, fH, fW, C, nx, ny, nz);
+    return ok ? MMT_OK : MMT_ERR_BAD_SHAPE;
+}
+
+int fill_plan_args(const char *what, int B, int N, int D, int fH, int fW, int nx, int ny, int nz, const float *combine, const float *fu, const float *fv,
+                   const float *fd, const float *vc, const float *vs, void *cache, int64_t cache_bytes, PlanArgs *p) {
+    if (!combine || !fu || !fv || !fd || !vc || !vs || !cache) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: a NULL pointer among the geometry operands / the plan cache", what);
+    if (((uintptr_t)cache & 255) != 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the plan cache must be 256-byte aligned", what);
+    Layout l;
+    make_layout(N, D, fH, fW, nx, ny, 1, &l);
+    const int64_t fixed = kHdrBytes + (int64_t)kBuildPar * l.scratch_bytes;
+    const int64_t fit = (cache_bytes - fixed) / l.slot_bytes;
+    if (cache_bytes < fixed || fit < B)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the plan cache (%lld bytes) holds %lld calibrations, the call has %d samples (mmt_lss_plan_cache_bytes)", what,
+                         (long long)cache_bytes, (long long)(cache_bytes < fixed ? 0 : fit), B);
+    const int slots = fit > 256 ? 256 : (int)fit;
+    make_layout(N, D, fH, fW, nx, ny, slots, &l);
+    p->cache = static_cast<unsigned char *>(cache);
+    p->summary_off = l.summary_off; p->records_off = l.records_off; p->slot_bytes = l.slot_bytes; p->scratch_bytes = l.scratch_bytes;
+    p->slots_off = l.slots_off; p->scratch_off = l.scratch_off;
+    p->d = l.d; p->B = B; p->nz = nz; p->nslots = slots;
+    p->combine = combine; p->fu = fu; p->fv = fv; p->fd = fd;
+    mmt::make_cam_grid(vc, vs, &p->q);
+    mmt::make_cam_range(&p->q, nx, ny, nz);
+    // what the learnt plans depend on besides the matrices and the axes' contents (hashed on the device)
+    int words[20] = {N, D, fH, fW, nx, ny, nz, kMaxRuns, kMaxPairRuns, kRunBins, kTile, kJobBytes, slots, 1 /* layout version */};
+    memcpy(words + 14, p->q.lo, 12);
+    memcpy(words + 17, p->q.vs, 12);
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (int w : words) { h ^= (uint32_t)w; h *= 0x100000001B3ull; h ^= h >> 29; }
+    p->sig_lo = (unsigned)h | 1u; p->sig_hi = (unsigned)(h >> 32);
+    return MMT_OK;
+}
+
+void launch_prepare(mmt::TimedSeq &seq, const PlanArgs &p, hipStream_t st, bool last) {
+    seq.launch(false, lss_plan_probe, dim3(1), dim3(256), 0, st, p);
+    const int g = p.B < kBuildPar ? p.B : kBuildPar;
+    seq.launch(last, lss_plan_build, dim3((unsigned)g), dim3(kBuildThreads), 0, st, p);
+}
+
+template <typename FT>
+int plan_forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine, const float *fu,
+                      const float *fv, const float *fd, const float *vc, const float *vs, const FT *depth, const FT *context, float *out,
+                      int32_t *column_summary, void *cache, int64_t cache_bytes, int flags, hipStream_t st) {
+    if (flags & ~(MMT_LSS_PIXEL_MAJOR | MMT_LSS_PLAN_PREPARED | MMT_LSS_PLAN_BRUTE))
+        return mmt::fail(MMT_ERR_BAD_FLAG, "%s: unknown flag bits 0x%x", what, flags);
+    if (!(flags & MMT_LSS_PIXEL_MAJOR)) return mmt::fail(MMT_ERR_BAD_FLAG, "%s: the plan form reads depth pixel-major (MMT_LSS_PIXEL_MAJOR)", what);
+    if (const int rc = plan_shape_ok(what, B, N, D, fH, fW, C, nx, ny, nz, false)) return rc;
+    if ((((uintptr_t)context | (uintptr_t)out) & 15) != 0 || ((uintptr_t)depth & 3) != 0 || (column_summary && ((uintptr_t)column_summary & 7) != 0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: context / out must be 16-byte aligned, the column summary 8-byte, depth 4-byte aligned", what);
+    FwdArgs a = {};
+    if (const int rc = fill_plan_args(what, B, N, D, fH, fW, nx, ny, nz, combine, fu, fv, fd, vc, vs, cache, cache_bytes, &a.p)) return rc;
+    a.depth = depth; a.context = context; a.out = out; a.summary_out = reinterpret_cast<int2 *>(column_summary);
+    a.C = C; a.force_brute = (flags & MMT_LSS_PLAN_BRUTE) ? 1 : 0;
+    const Dims &d = a.p.d;
+    int W = d.ntiles + (int)(((int64_t)d.strips * D) / (2 * kMaxRuns));
+    if (W > d.jobs_cap) W = d.jobs_cap;
+    W = (W + 7) & ~7;
+    a.W = W;
+    a.xps = (B <= 8 && 8 % B == 0) ? 8 / B : 0;
+    mmt::TimedSeq seq;
+    if (!(flags & MMT_LSS_PLAN_PREPARED)) launch_prepare(seq, a.p, st, false);
+    const size_t lds = (size_t)kJobBytes + (size_t)kMaxRuns * C * 4;
+    const dim3 grid((unsigned)((int64_t)B * W)), blk(kFwdThreads);
+    if (C == 80) seq.launch(true, lss_plan_fwd<FT, 5>, grid, blk, lds, st, a);
+    else if (C == 64) seq.launch(true, lss_plan_fwd<FT, 4>, grid, blk, lds, st, a);
+    else seq.launch(true, lss_plan_fwd<FT, 8>, grid, blk, lds, st, a);
+    mmt::lss_note_forward_family(MMT_LSS_FAMILY_PLAN | MMT_LSS_FAMILY_CAMERA);
+    return mmt::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int mmt_lss_plan_supported(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz) {
+    return plan_shape_ok("lss_plan_supported", B, N, D, fH, fW, C, nx, ny, nz, true) == MMT_OK ? 1 : 0;
+}
+
+extern "C" int64_t mmt_lss_plan_cache_bytes(int N, int D, int fH, int fW, int nx, int ny, int slots) {
+    if (N <= 0 || N > kPlanMaxN || D <= 0 || fH <= 0 || fW <= 0 || nx <= 0 || ny <= 0 || slots <= 0) return 0;
+    Layout l;
+    make_layout(N, D, fH, fW, nx, ny, slots > 256 ? 256 : slots, &l);
+    if (!dims_ok(l.d)) return 0;
+    return l.total;
+}
+
+extern "C" int mmt_lss_plan_prepare(int B, int N, int D, int fH, int fW, int nx, int ny, int nz, const float *combine, const float *frustum_u,
+                                    const float *frustum_v, const float *frustum_d, const float *voxel_coord_host, const float *voxel_size_host,
+                                    void *plan_cache, int64_t plan_cache_bytes, void *stream) {
+    if (const int rc = plan_shape_ok("lss_plan_prepare", B, N, D, fH, fW, 64, nx, ny, nz, false)) return rc;
+    PlanArgs p = {};
+    if (const int rc = fill_plan_args("lss_plan_prepare", B, N, D, fH, fW, nx, ny, nz, combine, frustum_u, frustum_v, frustum_d, voxel_coord_host,
+                                      voxel_size_host, plan_cache, plan_cache_bytes, &p)) return rc;
+    mmt::TimedSeq seq;
+    launch_prepare(seq, p, (hipStream_t)stream, true);
+    return mmt::check_launch("lss_plan_prepare");
+}
+
+extern "C" int mmt_lss_plan_cache_layout(int N, int D, int fH, int fW, int nx, int ny, int64_t plan_cache_bytes, int64_t *layout_host) {
+    MMT_REQUIRE_PTR(layout_host);
+    if (N <= 0 || N > kPlanMaxN || D <= 0 || fH <= 0 || fW <= 0 || nx <= 0 || ny <= 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "lss_plan_cache_layout: bad shape");
+    Layout l;
+    make_layout(N, D, fH, fW, nx, ny, 1, &l);
+    const int64_t fixed = kHdrBytes + (int64_t)kBuildPar * l.scratch_bytes;
+    int64_t fit = plan_cache_bytes < fixed ? 0 : (plan_cache_bytes - fixed) / l.slot_bytes;
+    if (fit > 256) fit = 256;
+    const int64_t v[12] = {fit, l.slots_off, l.slot_bytes, l.summary_off, l.records_off, kVerdictOff, l.d.jobs_cap, l.d.runs_cap, kJobBytes, kPlanMaxB, l.d.strips, l.d.ntiles};
+    memcpy(layout_host, v, sizeof(v));
+    return MMT_OK;
+}
+
+extern "C" int mmt_lss_plan_cache_counters(const void *plan_cache, int64_t plan_cache_bytes, int64_t *counters_host, void *stream) {
+    MMT_REQUIRE_PTR(plan_cache);
+    MMT_REQUIRE_PTR(counters_host);
+    if (plan_cache_bytes < kHdrBytes) return mmt::fail(MMT_ERR_BAD_SHAPE, "lss_plan_cache_counters: not a plan cache (%lld bytes)", (long long)plan_cache_bytes);
+    CacheHeader h;
+    if (const hipError_t e = hipMemcpyAsync(&h, plan_cache, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream); e != hipSuccess)
+        return mmt::fail((int)e, "lss_plan_cache_counters: %s", hipGetErrorString(e));
+    if (const hipError_t e = hipStreamSynchronize((hipStream_t)stream); e != hipSuccess)
+        return mmt::fail((int)e, "lss_plan_cache_counters: %s", hipGetErrorString(e));
+    const bool live = h.magic == kPlanMagic;
+    const int64_t v[8] = {live ? h.hits : 0, live ? h.built : 0, live ? h.brute : 0, live ? h.resets : 0, live ? h.calls : 0, live ? h.nslots : 0, 0, 0};
+    memcpy(counters_host, v, sizeof(v));
+    return MMT_OK;
+}
+
+extern "C" int mmt_lss_splat_forward_plan(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
+                                          const float *frustum_u, const float *frustum_v, const float *frustum_d, const float *voxel_coord_host,
+                                          const float *voxel_size_host, const float *depth, const float *context, float *out,
+                                          int32_t *column_summary, void *plan_cache, int64_t plan_cache_bytes, int flags, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    return plan_forward_impl<float>("lss_splat_forward_plan", B, N, D, fH, fW, C, nx, ny, nz, combine, frustum_u, frustum_v, frustum_d,
+                                    voxel_coord_host, voxel_size_host, depth, context, out, column_summary, plan_cache, plan_cache_bytes, flags,
+                                    (hipStream_t)stream);
+}
+
+extern "C" int mmt_lss_splat_forward_plan_bf16(int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine,
+                                               const float *frustum_u, const float *frustum_v, const float *frustum_d,
+                                               const float *voxel_coord_host, const float *voxel_size_host, const uint16_t *depth,
+                                               const uint16_t *context, float *out, int32_t *column_summary, void *plan_cache,
+                                               int64_t plan_cache_bytes, int flags, void *stream) {
+    MMT_REQUIRE_PTR(depth);
+    MMT_REQUIRE_PTR(context);
+    MMT_REQUIRE_PTR(out);
+    return plan_forward_impl<bf16_t>("lss_splat_forward_plan_bf16", B, N, D, fH, fW, C, nx, ny, nz, combine, frustum_u, frustum_v, frustum_d,
+                                     voxel_coord_host, voxel_size_host, depth, context, out, column_summary, plan_cache, plan_cache_bytes, flags,
+                                     (hipStream_t)stream);
+}

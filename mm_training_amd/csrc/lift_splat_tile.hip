@@ -2179,6 +2179,7 @@ extern "C" int mmt_lss_splat_backward_cam_bf16(int B, int N, int D, int fH, int 
 }
 
 extern "C" int mmt_lss_last_kernel_family(int backward) { return g_last_family[backward ? 1 : 0]; }
+void mmt::lss_note_forward_family(int family) { g_last_family[0] = family; }
 
 // 1 when mmt_lss_splat_forward_cam* of this shape uses an exclusive-cell cache it is handed (with MMT_LSS_ZERO_OUTPUT): the
 // kernel choice of forward_impl -- today the register walk.  A caller allocates the cache only then.

@@ -74,6 +74,7 @@ __device__ __forceinline__ float bf16_hi(unsigned pair) { return __uint_as_float
 // fused lift-splat backward on the matrix cores (lift_splat_col.hip), called from mmt_lss_splat_backward[_cam]
 namespace mmt {
 struct CamGeom;   // mmt_camera.h; NULL = geom form
+void lss_note_forward_family(int family);   // what mmt_lss_last_kernel_family(0) reports (lift_splat_tile.hip; set by lift_splat_plan.hip too)
 bool lss_col_backward_fits(int D, int fH, int fW, int C, int64_t span, int64_t grid_units);
 int lss_col_backward_f32(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const int32_t *geom,
                          const CamGeom *cam, const float *depth, const float *context, const float *grad_out, int64_t sb, int64_t sy,

@@ -440,6 +440,119 @@ class LiftSplatCamera(Function):
         return None, None, None, grad_depth.permute(0, 3, 1, 2), grad_ctx.permute(0, 3, 1, 2), None, None, None, None, None, None
 
 
+def plan_form_supported(B, N, D, fH, fW, C, voxel_num):
+    """True when the plan form of the fused lift-splat forward takes this shape (mmt_lss_plan_supported)."""
+    nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
+    return bool(_lib.lib().mmt_lss_plan_supported(int(B), int(N), int(D), int(fH), int(fW), int(C), nx, ny, nz))
+
+
+def new_plan_cache(num_cams, D, fH, fW, voxel_num, device, slots=16):
+    """Plan cache of the plan-form forward (include/mmt_hip.h `plan_cache`): `slots` calibrations (a sample's camera matrices)
+    with their learnt plans; needs slots >= the batch size of the calls that use it.  A uint8 CUDA tensor owned by the
+    caller for good; the library owns its contents.  ~3.9 MB per slot at BASELINE configs[3], ~13 MB at configs[4]."""
+    nx, ny = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)][:2]
+    nbytes = int(_lib.lib().mmt_lss_plan_cache_bytes(int(num_cams), int(D), int(fH), int(fW), nx, ny, int(slots)))
+    if nbytes <= 0:
+        raise RuntimeError(f"new_plan_cache: bad arguments (N={num_cams}, D={D}, fH={fH}, fW={fW}, nx={nx}, ny={ny}, slots={slots})")
+    # (uninitialised is fine: the probe recognises a table that is not its own -- but zeros make the counters readable at once)
+    return torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
+
+
+def _plan_ptr(cache):
+    """(256-byte aligned pointer into the cache tensor, bytes from there)"""
+    p = cache.data_ptr()
+    a = (p + 255) & ~255
+    return a, cache.numel() - (a - p)
+
+
+def plan_cache_counters(cache):
+    """dict(hit, learnt, brute, resets, calls, slots) of a plan cache (synchronises the current stream)."""
+    import ctypes
+    out = (ctypes.c_int64 * 8)()
+    ptr, nbytes = _plan_ptr(cache)
+    with torch.cuda.device(cache.device):
+        _lib.call("mmt_lss_plan_cache_counters", ptr, nbytes, out, _stream())
+    return dict(hit=int(out[0]), learnt=int(out[1]), brute=int(out[2]), resets=int(out[3]), calls=int(out[4]), slots=int(out[5]))
+
+
+def plan_prepare(combine, axes, voxel_num, voxel_coord, voxel_size, plan_cache):
+    """mmt_lss_plan_prepare: look the batch's calibrations up in `plan_cache` and learn the unknown ones.  Depends on the
+    matrices only -- call it as early in the step as they exist; the forward is then told MMT_LSS_PLAN_PREPARED."""
+    fu, fv, fd = axes
+    B, N = combine.shape[:2]
+    D, fH, fW = fd.numel(), fv.numel(), fu.numel()
+    _need_cuda(combine, "combine")
+    nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
+    vc = [float(v) for v in (voxel_coord.tolist() if isinstance(voxel_coord, torch.Tensor) else voxel_coord)]
+    vs = [float(v) for v in (voxel_size.tolist() if isinstance(voxel_size, torch.Tensor) else voxel_size)]
+    ptr, nbytes = _plan_ptr(plan_cache)
+    with torch.cuda.device(combine.device):
+        _lib.timed_call("lift_splat_plan_prepare", "mmt_lss_plan_prepare", B, N, D, fH, fW, nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(),
+                        fd.data_ptr(), _lib.float3(vc), _lib.float3(vs), ptr, nbytes, _stream())
+
+
+class LiftSplatPlan(Function):
+    """The plan form of the fused op (mmt_lss_splat_forward_plan; lss_fpn.py:328-361, :461-462, :441-464): the
+    output-stationary forward -- no zero fill, no atomics, bit-identical from call to call -- on the plan the library has
+    learnt for the batch's calibrations in `plan_cache`.  Backward: the camera form's kernels on the column summary this
+    forward hands them (mmt_lss_splat_backward_cam)."""
+
+    @staticmethod
+    def forward(ctx, combine, axes, grid, depth, context, voxel_num, column_backward, column_stats, plan_cache, prepared, brute):
+        fu, fv, fd = axes
+        vc, vs = grid
+        B, N = combine.shape[:2]
+        D, fH, fW = fd.numel(), fv.numel(), fu.numel()
+        BN, C = B * N, context.shape[1]
+        _need_cuda(combine, "combine")
+        for t, name in ((fu, "frustum_u"), (fv, "frustum_v"), (fd, "frustum_d")):
+            _need_cuda(t, name)
+        if tuple(combine.shape[2:]) != (4, 4):
+            raise RuntimeError("lift_splat_plan: combine must be [B, N, 4, 4]")
+        if tuple(depth.shape) != (BN, D, fH, fW) or tuple(context.shape) != (BN, C, fH, fW):
+            raise RuntimeError("lift_splat_plan: depth must be [B*N, D, fH, fW] and context [B*N, C, fH, fW]")
+        if not (depth.is_cuda and context.is_cuda):
+            raise RuntimeError("depth / context must be a CUDAtensor ")
+        if plan_cache is None or plan_cache.dtype != torch.uint8 or plan_cache.device != depth.device:
+            raise RuntimeError("lift_splat_plan: plan_cache must be the uint8 tensor of new_plan_cache on the inputs' device")
+        bf16 = depth.dtype == torch.bfloat16 and context.dtype == torch.bfloat16
+        sd = torch.bfloat16 if bf16 else torch.float32
+        depth_c = depth.to(sd).permute(0, 2, 3, 1).contiguous()            # free for channels_last nets
+        ctx_nhwc = context.to(sd).permute(0, 2, 3, 1).contiguous()
+        nx, ny, nz = [int(v) for v in (voxel_num.tolist() if isinstance(voxel_num, torch.Tensor) else voxel_num)]
+        out = torch.empty((B, ny, nx, C), dtype=torch.float32, device=depth.device)     # every element is written
+        need_bwd = any(ctx.needs_input_grad[3:5])
+        summary = new_column_summary(B, N, D, fH, fW, depth.device) if need_bwd else None
+        ptr, nbytes = _plan_ptr(plan_cache)
+        flags = _lib.LSS_PIXEL_MAJOR | (_lib.LSS_PLAN_PREPARED if prepared else 0) | (_lib.LSS_PLAN_BRUTE if brute else 0)
+        with torch.cuda.device(depth.device):
+            _lib.timed_call("lift_splat_forward", "mmt_lss_splat_forward_plan" + ("_bf16" if bf16 else ""), B, N, D, fH, fW, C, nx, ny, nz,
+                            combine.data_ptr(), fu.data_ptr(), fv.data_ptr(), fd.data_ptr(), _lib.float3(vc), _lib.float3(vs),
+                            depth_c.data_ptr(), ctx_nhwc.data_ptr(), out.data_ptr(), summary.data_ptr() if summary is not None else 0,
+                            ptr, nbytes, flags, _stream())
+        if need_bwd:
+            ctx.save_for_backward(combine, fu, fv, fd, depth_c, ctx_nhwc, summary)
+        ctx.dims = (B, N, D, fH, fW, C, nx, ny, nz)
+        ctx.grid = (tuple(float(v) for v in vc), tuple(float(v) for v in vs))
+        ctx.bf16, ctx.column_backward, ctx.column_stats = bf16, bool(column_backward), column_stats
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = LiftSplatCamera.backward(ctx, grad_out)          # same saved tensors, same attributes
+        return grads[0], grads[1], grads[2], grads[3], grads[4], None, None, None, None, None, None
+
+
+def lift_splat_plan(combine, axes, depth, context, voxel_num, voxel_coord, voxel_size, plan_cache, prepared=False, column_backward=False,
+                    column_stats=None, brute=False):
+    """lift_splat_camera's operands + the plan cache of new_plan_cache -> BEV fp32 [B,C,ny,nx] (channels_last memory), through the
+    output-stationary plan-form forward.  prepared=True: plan_prepare already ran for this batch on this stream."""
+    vc = [float(v) for v in (voxel_coord.tolist() if isinstance(voxel_coord, torch.Tensor) else voxel_coord)]
+    vs = [float(v) for v in (voxel_size.tolist() if isinstance(voxel_size, torch.Tensor) else voxel_size)]
+    return LiftSplatPlan.apply(combine.contiguous(), tuple(axes), (vc, vs), depth, context, voxel_num, bool(column_backward), column_stats,
+                               plan_cache, bool(prepared), bool(brute))
+
+
 def new_column_summary(B, N, D, fH, fW, device):
     """Uninitialised column summary of the camera form (include/mmt_hip.h `column_summary`): int32 [B*N, ceil(fH/16), fW, D, 2],
     8 bytes per (16-row block of a column, depth bin) -- written by a forward, read by its backward and by later forwards

@@ -17,7 +17,9 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 #   lss_ray_bwd, the per-pixel ray-walk backward (not the level rig's default): __launch_bounds__(256, 6) caps it at 80 VGPRs so
 #   that every workgroup of the launch is resident at once, and the camera form's geometry phase spills 12-76 bytes per
 #   thread for it -- a measured trade (round 3: 36.5 -> 26.7 us with the cap), outside the walk's loop.
-ALLOWED = ("rocprim", "lss_ray_bwd")
+# * lss_plan_build (lift_splat_plan.hip): learns a calibration's plan ONCE (one 1024-thread workgroup per calibration, phases of
+#   plain index arithmetic with per-thread row-cell arrays); not on the step's steady-state path.
+ALLOWED = ("rocprim", "lss_ray_bwd", "lss_plan_build")
 
 
 def _kernels(lib_path):

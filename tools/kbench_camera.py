@@ -247,6 +247,41 @@ def main():
         "ray_bwd_geom_cold": (lambda h: bwd(h, False, PM), dict(cold=True)),
         "ray_bwd_cam_cold": (lambda h: bwd(h, True, PM), dict(cold=True)),
     }
+    # ---- plan form (lift_splat_plan.hip): the output-stationary forward on the learnt plan
+    if hasattr(h0, "mmt_lss_splat_forward_plan"):
+        PREP = 0x2000
+        pbytes = h0.mmt_lss_plan_cache_bytes(N, D, fH, fW, nx, ny, max(B, 2))
+        pcache = {p: torch.zeros(pbytes + 256, dtype=torch.uint8, device="cuda") for p in libs}
+        pptr = {id(h): (pcache[p].data_ptr() + 255) & ~255 for p, h in zip(libs, hs)}
+
+        def fwd_plan(h, flags=PM, sm=None):
+            return getattr(h, "mmt_lss_splat_forward_plan" + sfx)(B, N, D, fH, fW, C, nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(),
+                                                                 fd.data_ptr(), vc_c, vs_c, depth.data_ptr(), ctx.data_ptr(), out.data_ptr(),
+                                                                 sm.data_ptr() if sm is not None else None, pptr[id(h)], pbytes, flags, st)
+
+        def prepare(h):
+            return h.mmt_lss_plan_prepare(B, N, D, fH, fW, nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(), fd.data_ptr(), vc_c, vs_c,
+                                          pptr[id(h)], pbytes, st)
+
+        out.fill_(float("nan")); assert fwd_plan(h0) == 0, h0.mmt_last_error()
+        out_p = out.clone()
+        out.fill_(float("nan")); assert fwd_plan(h0, PM | PREP) == 0, h0.mmt_last_error()
+        cnt = (ctypes.c_int64 * 8)()
+        h0.mmt_lss_plan_cache_counters(pptr[id(h0)], pbytes, cnt, st)
+        info["plan_form"] = dict(max_abs_diff_vs_camera=float((out_p - out_c).abs().max()), bit_identical_again=bool(torch.equal(out, out_p)),
+                                 every_element_written=not bool(torch.isnan(out_p).any()), counters=list(cnt)[:6], family=hex(h0.mmt_lss_last_kernel_family(0)))
+        assert info["plan_form"]["bit_identical_again"] and info["plan_form"]["every_element_written"]
+        assert info["plan_form"]["max_abs_diff_vs_camera"] <= 2e-5 * float(out_c.abs().max())
+        for p, h in zip(libs[1:], hs[1:]):
+            assert fwd_plan(h) == 0, h.mmt_last_error()
+        cases.update({
+            "plan_prepare(probe+build, all known)": (lambda h: prepare(h), {}),
+            "fwd_plan(prepare+kernel)": (lambda h: fwd_plan(h), {}),
+            "fwd_plan_prepared(kernel)": (lambda h: fwd_plan(h, PM | PREP), {}),
+            "fwd_plan_prepared_writes_summary(kernel)": (lambda h: fwd_plan(h, PM | PREP, summary), {}),
+            "fwd_plan_prepared_cold(kernel)": (lambda h: fwd_plan(h, PM | PREP), dict(cold=True)),
+            "fwd_plan_brute_force": (lambda h: fwd_plan(h, PM | PREP | 0x4000), dict(reps=3, warm=1)),
+        })
     res = {}
     for rnd in range(args.rounds):
         for name, (fn, kw) in cases.items():
