@@ -16,6 +16,7 @@
 // No zero fill, no atomics, every output element written exactly once, bit-identical from launch to launch.  A calibration
 // whose plan would not fit its slot (a rig rolled so far that most blocks of rows straddle cells) is served by the same
 // kernel's brute-force path from the slot's column summary: slow, still deterministic, still exact.
+#include <stdlib.h>
 #include <string.h>
 
 #include "lss_plan_core.h"
@@ -34,17 +35,22 @@ constexpr unsigned kPlanMagic = 0x4E4C504Du;      // "MPLN"
 constexpr int kStateEmpty = 0, kStateReady = 1, kStateBrute = 2;
 
 // ---- the caller's plan cache: header | verdicts | to-do list | slots | build scratch --------------------------------------
-constexpr int64_t kHdrBytes = 4096;
-constexpr int64_t kVerdictOff = 256;     // int4 [kPlanMaxB]: slot, units (jobs), state, representative sample
-constexpr int64_t kTodoOff = 256 + 16 * kPlanMaxB;       // int4 [kPlanMaxB]: sample, slot, hash lo, hash hi
+constexpr int64_t kHdrBytes = 8192;
+constexpr int64_t kVerdictOff = 256;     // Verdict [kPlanMaxB]
+constexpr int64_t kTodoOff = 256 + 64 * kPlanMaxB;       // int4 [kPlanMaxB]: sample, slot, hash lo, hash hi
 constexpr int64_t kDupOff = kTodoOff + 16 * kPlanMaxB;   // int [kPlanMaxB]: the earlier sample with the same matrices, or -1
-constexpr int64_t kSlotMetaBytes = 2048; // u64 hash | state, njobs, nruns, stamp | matrices [kPlanMaxN * 16] at +64
+constexpr int64_t kSlotMetaBytes = 2048; // SlotMeta
+
+// what the forward goes by for one sample of the call: its calibration's slot, how many units (records of a learnt plan; tiles
+// for the brute-force path) in which of the kGroups groups
+struct Verdict { int slot, units, state, rep; int gstart[kGroups + 1]; int pad[3]; };
+static_assert(sizeof(Verdict) == 64, "Verdict");
 
 struct CacheHeader {
     unsigned magic, sig_lo, sig_hi, axes_lo, axes_hi, clock, nslots, todo_count;
     unsigned hits, built, brute, resets, calls, reserved[3];
 };
-struct SlotMeta { unsigned hash_lo, hash_hi; int state, njobs, nruns; unsigned stamp; int pad[10]; float mats[kPlanMaxN * 16]; };
+struct SlotMeta { unsigned hash_lo, hash_hi; int state, njobs, nruns; unsigned stamp; int gstart[kGroups + 1]; int pad[1]; float mats[kPlanMaxN * 16]; };
 
 struct Layout {
     Dims d;
@@ -85,22 +91,30 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 // One workgroup.  Per sample: a 64-bit hash of its N matrices; a sample whose matrices equal an earlier sample's (bit for
 // bit) shares that sample's verdict; otherwise its slot is looked up among the cache's slots (hash, then the matrices bit for
 // bit); a miss claims an empty slot, else the least recently used one that this call does not use, and goes on the to-do
-// list.  The frustum axes' contents and the launch shape sign the table: a change empties it.
+// list.  The frustum axes' contents and the launch shape sign the table: a change empties it.  Everything that reads memory
+// is spread over the workgroup (the samples over its waves), the decisions that depend on each other are made by one wave
+// from LDS: two or three rounds of loads in all.
+__device__ __forceinline__ void verdict_from_slot(Verdict *v, int slot, const SlotMeta *sm, int rep, const Dims &d) {
+    v->slot = slot; v->units = sm->njobs; v->state = sm->state; v->rep = rep;
+    for (int g = 0; g <= kGroups; ++g) v->gstart[g] = sm->state == kStateReady ? sm->gstart[g] : group_begin(d, g);
+}
+
 __global__ __launch_bounds__(256) void lss_plan_probe(PlanArgs a) {
     __shared__ unsigned long long s_hash[kPlanMaxB];
     __shared__ unsigned long long s_axes;
     __shared__ unsigned s_shash_lo[256], s_shash_hi[256], s_stamp[256];
-    __shared__ int s_state[256], s_used[256], s_slot[kPlanMaxB];
-    __shared__ int s_reset;
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ int s_state[256], s_used[256], s_slot[kPlanMaxB], s_rep[kPlanMaxB], s_njobs[256], s_gs[256][kGroups + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     CacheHeader *hdr = reinterpret_cast<CacheHeader *>(a.cache);
-    int4 *verdict = reinterpret_cast<int4 *>(a.cache + kVerdictOff);
+    Verdict *verdict = reinterpret_cast<Verdict *>(a.cache + kVerdictOff);
     int4 *todo = reinterpret_cast<int4 *>(a.cache + kTodoOff);
     int *dup = reinterpret_cast<int *>(a.cache + kDupOff);
     const int words = a.d.N * 16;
+    const unsigned *mats = reinterpret_cast<const unsigned *>(a.combine);
     if (tid == 0) s_axes = 0ull;
+    if (tid < kPlanMaxB) s_hash[tid] = 0ull;
     __syncthreads();
-    {   // order-independent hash of the axes' contents (position-keyed terms, summed)
+    {   // order-independent hashes (position-keyed terms, summed): the axes' contents, every sample's matrices
         unsigned long long part = 0ull;
         const int na = a.d.fW + a.d.fH + a.d.D;
         for (int i = tid; i < na; i += 256) {
@@ -108,46 +122,41 @@ __global__ __launch_bounds__(256) void lss_plan_probe(PlanArgs a) {
             part += mix64(((unsigned long long)i << 32) | __float_as_uint(v));
         }
         atomicAdd(&s_axes, part);
+        for (int i = tid; i < a.B * words; i += 256) {
+            const int b = i / words, k = i - b * words;
+            atomicAdd(&s_hash[b], mix64(((unsigned long long)k << 32) | mats[i]));
+        }
     }
-    if (tid < a.B) {
-        unsigned long long h = 0xCBF29CE484222325ull;
-        const unsigned *m = reinterpret_cast<const unsigned *>(a.combine) + (int64_t)tid * words;
-        for (int i = 0; i < words; ++i) { h ^= m[i]; h *= 0x100000001B3ull; h ^= h >> 29; }
-        s_hash[tid] = h;
-    }
+    const unsigned h_magic = hdr->magic, h_sig_lo = hdr->sig_lo, h_sig_hi = hdr->sig_hi, h_ax_lo = hdr->axes_lo, h_ax_hi = hdr->axes_hi,
+                   h_nslots = hdr->nslots, h_clock = hdr->clock, h_resets = hdr->resets;
     __syncthreads();
     const unsigned ax_lo = (unsigned)s_axes, ax_hi = (unsigned)(s_axes >> 32);
-    if (tid == 0)
-        s_reset = (hdr->magic != kPlanMagic || hdr->sig_lo != a.sig_lo || hdr->sig_hi != a.sig_hi || hdr->axes_lo != ax_lo || hdr->axes_hi != ax_hi ||
-                   hdr->nslots != (unsigned)a.nslots) ? 1 : 0;
-    __syncthreads();
-    const int reset = s_reset;
+    const int reset = (h_magic != kPlanMagic || h_sig_lo != a.sig_lo || h_sig_hi != a.sig_hi || h_ax_lo != ax_lo || h_ax_hi != ax_hi ||
+                       h_nslots != (unsigned)a.nslots) ? 1 : 0;
     for (int s = tid; s < a.nslots; s += 256) {
         SlotMeta *sm = reinterpret_cast<SlotMeta *>(a.cache + a.slots_off + (int64_t)s * a.slot_bytes);
         if (reset) sm->state = kStateEmpty;
         s_shash_lo[s] = sm->hash_lo; s_shash_hi[s] = sm->hash_hi; s_stamp[s] = sm->stamp;
-        s_state[s] = reset ? kStateEmpty : sm->state;
+        const int st_ = reset ? kStateEmpty : sm->state;
+        s_state[s] = st_; s_njobs[s] = sm->njobs;
+#pragma unroll
+        for (int g = 0; g <= kGroups; ++g) s_gs[s][g] = st_ == kStateReady ? sm->gstart[g] : group_begin(a.d, g);
         s_used[s] = 0;
     }
     __syncthreads();
-    if (tid >= 64) return;
-    // wave 0 decides, every lane with the same (uniform) values; only the bit-for-bit comparisons are spread over the lanes
-    auto same_words = [&](const unsigned *p, const unsigned *q) {
+    auto same_words = [&](const unsigned *p, const unsigned *q) {      // one wave, the words spread over its lanes
         bool eq = true;
         for (int i = lane; i < words; i += 64) eq = eq && p[i] == q[i];
         return __all(eq) != 0;
     };
-    const unsigned clock = reset ? 1u : hdr->clock + 1u;
-    const bool was_init = hdr->magic == kPlanMagic;
-    unsigned n_hit = 0, n_todo = 0;
-    // pass 1: duplicates inside the batch, and the samples whose calibration the table knows (their slots are in use: no victim)
-    for (int b = 0; b < a.B; ++b) {
+    // pass 1, a sample per wave: the earlier sample with the same matrices, else the slot that holds them (independent of the
+    // other samples' outcomes)
+    for (int b = wave; b < a.B; b += 4) {
         const unsigned long long h = s_hash[b];
-        const unsigned *mb = reinterpret_cast<const unsigned *>(a.combine) + (int64_t)b * words;
+        const unsigned *mb = mats + (int64_t)b * words;
         int rep = -1;
         for (int e = 0; e < b && rep < 0; ++e)
-            if (s_hash[e] == h && same_words(mb, reinterpret_cast<const unsigned *>(a.combine) + (int64_t)e * words)) rep = e;
-        if (lane == 0) dup[b] = rep;            // (a duplicate's verdict is written with its representative's: below for a hit, by the build otherwise)
+            if (s_hash[e] == h && same_words(mb, mats + (int64_t)e * words)) rep = e;
         int slot = -1;
         if (rep < 0) {
             for (int s = 0; s < a.nslots && slot < 0; ++s) {
@@ -156,19 +165,35 @@ __global__ __launch_bounds__(256) void lss_plan_probe(PlanArgs a) {
                     if (same_words(mb, reinterpret_cast<const unsigned *>(sm->mats))) slot = s;
                 }
             }
-            if (slot >= 0) {
-                SlotMeta *sm = reinterpret_cast<SlotMeta *>(a.cache + a.slots_off + (int64_t)slot * a.slot_bytes);
-                if (lane == 0) { verdict[b] = make_int4(slot, sm->njobs, sm->state, b); sm->stamp = clock; }
-                s_used[slot] = 1;
-                ++n_hit;
-            }
         }
-        s_slot[b] = rep >= 0 ? -2 : slot;
+        if (lane == 0) { s_rep[b] = rep; s_slot[b] = slot; dup[b] = rep; }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // wave 0 decides the rest from LDS, every lane with the same (uniform) values; lane 0 writes
+    const unsigned clock = reset ? 1u : h_clock + 1u;
+    unsigned n_hit = 0, n_todo = 0;
+    for (int b = 0; b < a.B; ++b) {
+        const int slot = s_slot[b];
+        if (s_rep[b] < 0 && slot >= 0) {
+            SlotMeta *sm = reinterpret_cast<SlotMeta *>(a.cache + a.slots_off + (int64_t)slot * a.slot_bytes);
+            if (lane == 0) {                   // (everything it needs is in LDS: stores only)
+                Verdict v;
+                v.slot = slot; v.units = s_njobs[slot]; v.state = s_state[slot]; v.rep = b;
+#pragma unroll
+                for (int g = 0; g <= kGroups; ++g) v.gstart[g] = s_gs[slot][g];
+                v.pad[0] = v.pad[1] = v.pad[2] = 0;
+                verdict[b] = v;
+                sm->stamp = clock;
+            }
+            s_used[slot] = 1;
+            ++n_hit;
+        }
     }
     // pass 2: a slot for every calibration to learn -- an empty one, else the least recently used one this call does not use
     // (the entry points demand nslots >= B, so there is one)
     for (int b = 0; b < a.B; ++b) {
-        if (s_slot[b] != -1) continue;
+        if (s_rep[b] >= 0 || s_slot[b] >= 0) continue;
         const unsigned long long h = s_hash[b];
         int victim = -1;
         for (int s = 0; s < a.nslots && victim < 0; ++s) if (s_state[s] == kStateEmpty && !s_used[s]) victim = s;
@@ -181,19 +206,27 @@ __global__ __launch_bounds__(256) void lss_plan_probe(PlanArgs a) {
             SlotMeta *sm = reinterpret_cast<SlotMeta *>(a.cache + a.slots_off + (int64_t)victim * a.slot_bytes);
             sm->state = kStateEmpty;           // (nothing of it is served while it is being learnt)
             todo[n_todo] = make_int4(b, victim, (int)(unsigned)h, (int)(unsigned)(h >> 32));
-            verdict[b] = make_int4(victim, 0, kStateEmpty, b);
+            verdict[b].slot = victim; verdict[b].units = 0; verdict[b].state = kStateEmpty; verdict[b].rep = b;
         }
         ++n_todo;
     }
     // duplicates of a hit copy its verdict now (the build writes those of a sample it learns); lane 0 wrote them itself
     if (lane == 0) {
         for (int b = 0; b < a.B; ++b) {
-            const int rep = dup[b];
-            if (rep >= 0) { const int4 v = verdict[rep]; if (v.z != kStateEmpty) verdict[b] = make_int4(v.x, v.y, v.z, rep); }
+            const int rep = s_rep[b];
+            if (rep >= 0 && s_slot[rep] >= 0) {
+                const int slot = s_slot[rep];
+                Verdict v;
+                v.slot = slot; v.units = s_njobs[slot]; v.state = s_state[slot]; v.rep = rep;
+#pragma unroll
+                for (int g = 0; g <= kGroups; ++g) v.gstart[g] = s_gs[slot][g];
+                v.pad[0] = v.pad[1] = v.pad[2] = 0;
+                verdict[b] = v;
+            }
         }
         hdr->magic = kPlanMagic; hdr->sig_lo = a.sig_lo; hdr->sig_hi = a.sig_hi; hdr->axes_lo = ax_lo; hdr->axes_hi = ax_hi;
         hdr->clock = clock; hdr->nslots = (unsigned)a.nslots; hdr->todo_count = n_todo;
-        if (reset) { hdr->hits = 0; hdr->built = 0; hdr->brute = 0; hdr->resets = was_init ? hdr->resets + 1 : 0; hdr->calls = 0; }
+        if (reset) { hdr->hits = 0; hdr->built = 0; hdr->brute = 0; hdr->resets = h_magic == kPlanMagic ? h_resets + 1 : 0; hdr->calls = 0; }
         hdr->hits += n_hit; hdr->built += n_todo; hdr->calls += 1;
     }
 }
@@ -225,7 +258,7 @@ __global__ __launch_bounds__(kBuildThreads) void lss_plan_build(PlanArgs a) {
     const CacheHeader *hdr = reinterpret_cast<const CacheHeader *>(a.cache);
     const int4 *todo = reinterpret_cast<const int4 *>(a.cache + kTodoOff);
     const int *dup = reinterpret_cast<const int *>(a.cache + kDupOff);
-    int4 *verdict = reinterpret_cast<int4 *>(a.cache + kVerdictOff);
+    Verdict *verdict = reinterpret_cast<Verdict *>(a.cache + kVerdictOff);
     const int ntodo = (int)hdr->todo_count;
     const int tid = threadIdx.x, nt = kBuildThreads;
     const Dims &d = a.d;
@@ -301,10 +334,14 @@ __global__ __launch_bounds__(kBuildThreads) void lss_plan_build(PlanArgs a) {
             __syncthreads();
             phase_count_jobs(d, sc, tid, nt);
             __syncthreads();
-            scan_a(sc.tile_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
-            scan_b(sc.tile_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
-            scan_c(sc.tile_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
-            phase_check_jobs(d, sc, tid);
+            phase_tile_order(d, sc, tid, nt);
+            __syncthreads();
+            phase_perm_gather(d, sc, tid, nt);
+            __syncthreads();
+            scan_a(sc.perm_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
+            scan_b(sc.perm_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
+            scan_c(sc.perm_jobs, d.ntiles, sc.partial, tid, nt); __syncthreads();
+            phase_tile_bases(d, sc, tid, nt);
             __syncthreads();
             if (!sc.status[2]) {
                 phase_write_jobs(d, sc, tid, nt);
@@ -320,10 +357,12 @@ __global__ __launch_bounds__(kBuildThreads) void lss_plan_build(PlanArgs a) {
         for (int i = tid; i < d.N * 16; i += nt) sm->mats[i] = a.combine[(int64_t)b * d.N * 16 + i];
         if (tid == 0) {
             sm->hash_lo = (unsigned)td.z; sm->hash_hi = (unsigned)td.w; sm->njobs = units; sm->nruns = sc.status[0]; sm->stamp = hdr->clock;
+            for (int g = 0; g <= kGroups; ++g) sm->gstart[g] = state == kStateReady ? sc.status[3 + g] : group_begin(d, g);
             sm->state = state;
         }
+        __syncthreads();
         for (int e = tid; e < a.B; e += nt)
-            if (e == b || dup[e] == b) verdict[e] = make_int4(slot, units, state, b);
+            if (e == b || dup[e] == b) verdict_from_slot(&verdict[e], slot, sm, b, d);
         __syncthreads();
     }
 }
@@ -336,6 +375,7 @@ struct FwdArgs {
     int2 *summary_out;                    // nullable: the batch's column summary [B*N, nb, fW, D] for the backward
     int C, W, xps;                        // channels; workgroups per sample; XCDs per sample (0: plain mapping)
     int force_brute;
+    unsigned depth_bytes, ctx_bytes;
 };
 
 template <int H>
@@ -409,157 +449,282 @@ __device__ __forceinline__ void load_row(const float *row, int li, Acc<S> &c) {
     load_ctx<float, S>(row, li, c);
 }
 
-// the depths of 4 consecutive bins of one pixel, starting at element e of the depth tensor.  The plan shifts a run at the end
-// of a ray back (lss_plan_core.h, phase_place), so the four bins always lie inside the pixel's D bins: plain loads.
-template <typename FT>
-__device__ __forceinline__ float4 load_depth4(const FT *depth, int64_t e) {
+// The same piece through a buffer descriptor: byte offset = voff (per lane: the pair's first row) + soff (wave-uniform: the row
+// inside the block).  One 32-bit VGPR addresses all 16 rows of a pair -- sixteen 64-bit row pointers cost the kernel 30 VGPRs
+// and a wave per SIMD.
+template <typename FT, int S>
+__device__ __forceinline__ void load_ctx_buf(const __amdgpu_buffer_rsrc_t &rs, unsigned voff, unsigned soff, int li, Acc<S> &c) {
+    constexpr int NQ = S / 4, N1 = S % 4;
     if constexpr (sizeof(FT) == 4) {
-        const plan_f4u v = *reinterpret_cast<const plan_f4u *>(depth + e);
-        return make_float4(v.x, v.y, v.z, v.w);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const mmt_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)(256 * i + 16 * li), soff, 0);
+            c.q[2 * i] = plan_v2f{__uint_as_float(v.x), __uint_as_float(v.y)}; c.q[2 * i + 1] = plan_v2f{__uint_as_float(v.z), __uint_as_float(v.w)};
+        }
+#pragma unroll
+        for (int i = 0; i < N1; ++i) c.s[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + (unsigned)(256 * NQ + 64 * i + 4 * li), soff, 0));
+    } else {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (unsigned)(128 * i + 8 * li), soff, 0);
+            c.q[2 * i] = plan_v2f{bf16_lo(v.x), bf16_hi(v.x)}; c.q[2 * i + 1] = plan_v2f{bf16_lo(v.y), bf16_hi(v.y)};
+        }
+#pragma unroll
+        for (int i = 0; i < N1; ++i) c.s[i] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff + (unsigned)(128 * NQ + 32 * i + 2 * li), soff, 0) << 16);
+    }
+}
+
+// the depths of 4 consecutive bins of one pixel, starting at element e of the depth tensor.  The plan shifts a run at the end
+// of a ray back (lss_plan_core.h, phase_place), so the four bins always lie inside the pixel's D bins.
+template <typename FT>
+__device__ __forceinline__ float4 load_depth4(const __amdgpu_buffer_rsrc_t &rs, unsigned e) {
+    if constexpr (sizeof(FT) == 4) {
+        const mmt_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 4u, 0, 0);        // (dword-aligned, not 16-byte aligned)
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     } else {
         // bf16: e may be odd (a 2-byte aligned address).  Even: the 8 bytes themselves.  Odd: the two dwords from e - 1 and the
         // fourth element on its own (every access inside the pixel's four bins, or one element in front of them)
-        const bool odd = (e & 1) != 0;
-        const unsigned *q = reinterpret_cast<const unsigned *>(depth + (e & ~1ll));
-        const unsigned v0 = q[0], v1 = q[1], v2 = odd ? (unsigned)depth[e + 3] : 0u;
-        const unsigned a0 = odd ? (v0 >> 16) | (v1 << 16) : v0, a1 = odd ? (v1 >> 16) | (v2 << 16) : v1;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const bool odd = (e & 1u) != 0u;
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (e & ~1u) * 2u, 0, 0);
+        const unsigned v2 = odd ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, (e + 3u) * 2u, 0, 0) : 0u;
+        const unsigned a0 = odd ? (v.x >> 16) | (v.y << 16) : v.x, a1 = odd ? (v.y >> 16) | (v2 << 16) : v.y;
         return make_float4(bf16_lo(a0), bf16_hi(a0), bf16_lo(a1), bf16_hi(a1));
     }
 }
 
 #define PLAN_FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
+// 4 waves per SIMD for C <= 80 (a 128-register cap: two loop-invariant values are spilled and reloaded once per unit, outside the
+// pair loop) against 3 without: 22.8 against 27.0 us at BASELINE configs[3] (profiles/r05_kbench_camera_cfg4.json)
+#ifndef PLAN_FWD_WAVES
+#define PLAN_FWD_WAVES 4
+#endif
 template <typename FT, int S>
-__global__ __launch_bounds__(kFwdThreads) void lss_plan_fwd(FwdArgs a) {
+__global__ __launch_bounds__(kFwdThreads, (S <= 5 ? PLAN_FWD_WAVES : 1)) void lss_plan_fwd(FwdArgs a) {
     extern __shared__ __align__(16) unsigned char plan_lds[];
     constexpr int C = 16 * S;
     const PlanArgs &p = a.p;
     const Dims &d = p.d;
     const int tid = threadIdx.x, g = tid >> 4, li = tid & 15;
-    // ---- which sample, which units (jobs of a learnt calibration / tiles of a brute-force one)
-    int b, first, stride, lo_k = 0, k_of = 0;
+#ifdef PLAN_STAMPS     // diagnostic build (tools/build_variant.py ... -DPLAN_STAMPS): the column-summary argument receives 8 words per workgroup
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(a.summary_out) + (int64_t)blockIdx.x * 16;
+    a.summary_out = nullptr;
+    int st_units = 0;
+#define PLAN_STAMP(i) do { if (tid == 0 && stamps && (st_units == 0 || (i) >= 5)) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (tid == 0 && stamps) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); stamps[7] = xcc & 15u; }
+#else
+#define PLAN_STAMP(i) do { } while (0)
+#endif
+    PLAN_STAMP(0);
+    // ---- which sample, which units (records of a learnt plan / tiles for the brute-force path).  A calibration's units come
+    // in kGroups groups of neighbouring tiles, heaviest first inside a group.  With 8 % B == 0 the sample's workgroups sit on
+    // xps = 8 / B XCDs and each XCD takes kGroups / xps whole groups (their context rows meet in its L2); its workgroups walk
+    // those groups interleaved, so that every group's heavy units are dealt first.
+    int b, first, stride, g0, ng;
     const int wg = blockIdx.x;
-    if (a.xps > 0) {                       // 8 % B == 0: the sample's workgroups sit on `xps` XCDs, each takes a contiguous share of the units
-        const int xcd = wg & 7, i = wg >> 3;
-        b = xcd / a.xps; k_of = xcd % a.xps;
-        first = i; stride = a.W / a.xps;
+    if (a.xps > 0) {
+        const int xcd = wg & 7;
+        b = xcd / a.xps;
+        ng = kGroups / a.xps; g0 = (xcd % a.xps) * ng;
+        first = wg >> 3; stride = a.W / a.xps;
     } else {
         b = wg / a.W; first = wg - b * a.W; stride = a.W;
+        g0 = 0; ng = kGroups;
     }
-    const int4 vd = reinterpret_cast<const int4 *>(p.cache + kVerdictOff)[b];
-    const int slot = vd.x;
+    const int *vd = reinterpret_cast<const int *>(p.cache + kVerdictOff) + b * (int)(sizeof(Verdict) / 4);       // (read word by word: a struct indexed at run time would live in scratch memory)
+    const int slot = vd[0], vstate = vd[2];
     if ((unsigned)slot >= (unsigned)p.nslots) return;       // (a cache nobody prepared: nothing to go by -- the entry point's contract, not a fault)
-    const bool brute = vd.z != kStateReady || a.force_brute;
-    const int units = brute ? d.ntiles : vd.y;
-    int hi_k = units;
-    if (a.xps > 0) { lo_k = (int)((int64_t)k_of * units / a.xps); hi_k = (int)((int64_t)(k_of + 1) * units / a.xps); }
+    const bool brute = vstate != kStateReady || a.force_brute;
+    __shared__ int s_gs[kGroups + 1];                        // first unit of every group (indexed at run time: LDS, not registers)
+    if (tid <= kGroups) s_gs[tid] = brute ? group_begin(d, tid) : vd[4 + tid];
+    __syncthreads();
+    int gmax = 0;
+    for (int i = 0; i < ng; ++i) { const int len = s_gs[g0 + i + 1] - s_gs[g0 + i]; gmax = len > gmax ? len : gmax; }
+    const int nunits = gmax * ng;                           // virtual units: u -> group u % ng, rank u / ng (holes where a group is shorter)
+    auto unit_of = [&](int u) __attribute__((always_inline)) {
+        const int gi = u % ng, r = u / ng;
+        const int lo = s_gs[g0 + gi], len = s_gs[g0 + gi + 1] - lo;
+        return r < len ? lo + r : -1;
+    };
     const unsigned char *sbase = p.cache + p.slots_off + (int64_t)slot * p.slot_bytes;
-    const FT *depth = reinterpret_cast<const FT *>(a.depth);
     const FT *context = reinterpret_cast<const FT *>(a.context);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.depth), 0, a.depth_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.context), 0, a.ctx_bytes, 0x00020000);
 
     // ---- the batch's column summary for the backward: every workgroup of the sample copies a slice of the slot's
     if (a.summary_out != nullptr) {
         const int64_t n8 = (int64_t)d.strips * d.D;
-        const int wl = a.xps > 0 ? k_of * stride + first : first;
+        const int wl = a.xps > 0 ? (g0 / ng) * stride + first : first;
         const int2 *src = reinterpret_cast<const int2 *>(sbase + p.summary_off);
         int2 *dst = a.summary_out + (int64_t)b * n8;
         for (int64_t i = (int64_t)wl * kFwdThreads + tid; i < n8; i += (int64_t)a.W * kFwdThreads) dst[i] = src[i];
     }
 
+    PLAN_STAMP(1);
     if (!brute) {
-        float *partial = reinterpret_cast<float *>(plan_lds + kJobBytes);
-        for (int job = lo_k + first; job < hi_k; job += stride) {
-          Acc<S> chain_acc;                    // a cell fed by more runs than a record holds: summed over its chain of records
-          chain_acc.zero();
-          bool more = false;
-          int rec = job;
-          do {
-            __syncthreads();
-            if (tid < kJobBytes / 16) reinterpret_cast<uint4 *>(plan_lds)[tid] = reinterpret_cast<const uint4 *>(sbase + p.records_off + (int64_t)rec * kJobBytes)[tid];
-            __syncthreads();
-            const JobHeader hdr = *reinterpret_cast<const JobHeader *>(plan_lds);
-            if (rec == job && (hdr.chain & kChainLink)) break;      // a link of a chain: the workgroup that met the head does it
-            more = (hdr.chain & kChainMore) != 0u;
-            ++rec;
-            const uint8_t *cb = plan_lds + kJobCellBeginOff;
-            const PairRec *pairs = reinterpret_cast<const PairRec *>(plan_lds + kJobPairsOff);
-            const RunRec *runs = reinterpret_cast<const RunRec *>(plan_lds + kJobRunsOff);
+        // LDS: two record buffers (the next unit's record is fetched while this one is worked on) | the partial rows
+        float *partial = reinterpret_cast<float *>(plan_lds + 2 * kJobBytes);
+        const unsigned char *records = sbase + p.records_off;
+        int ucur = first;
+        auto next_unit = [&]() __attribute__((always_inline)) {        // the next unit of this workgroup's share, -1 when it is through
+            while (ucur < nunits) {
+                const int j = unit_of(ucur);
+                ucur += stride;
+                if (j >= 0) return j;
+            }
+            return -1;
+        };
+        int job = next_unit();
+        if (job >= 0 && tid < kJobBytes / 16) reinterpret_cast<uint4 *>(plan_lds)[tid] = reinterpret_cast<const uint4 *>(records + (int64_t)job * kJobBytes)[tid];
+        int cur = 0;
+        bool in_chain = false;
+        Acc<S> chain_acc;                      // a cell fed by more runs than a record holds: summed over its chain of records
+        chain_acc.zero();
+        while (job >= 0) {
+            __syncthreads();                   // the record in buffer `cur` is complete; the other buffer and the partial rows are free
+            const unsigned char *rec_lds = plan_lds + cur * kJobBytes;
+            PLAN_STAMP(2);
+            const JobHeader hdr = *reinterpret_cast<const JobHeader *>(rec_lds);
+            if ((hdr.chain & kChainLink) && !in_chain) {            // a link of a chain met as a unit: the workgroup that met the head does it
+                job = next_unit();
+                __syncthreads();
+                if (job >= 0 && tid < kJobBytes / 16) reinterpret_cast<uint4 *>(plan_lds + cur * kJobBytes)[tid] = reinterpret_cast<const uint4 *>(records + (int64_t)job * kJobBytes)[tid];
+                continue;
+            }
+            const bool more = (hdr.chain & kChainMore) != 0u;
+            const int njob = more ? job + 1 : next_unit();
+            const uint8_t *cb = rec_lds + kJobCellBeginOff;
+            const PairRec *pairs = reinterpret_cast<const PairRec *>(rec_lds + kJobPairsOff);
+            const RunRec *runs = reinterpret_cast<const RunRec *>(rec_lds + kJobRunsOff);
             // ---- phase 1: a lane group per pair -- 16 context rows in registers, one partial row per run
+#ifdef PLAN_EXP_NOPAIRS    // ablation build: no pairs at all (results are wrong)
+            if (a.W == 123457)
+#endif
 #pragma unroll 1
             for (int pi = g; pi < hdr.npairs; pi += kFwdThreads / 16) {
                 const PairRec pr = pairs[pi];
                 const int n = pr.col / d.fW, w = pr.col - n * d.fW;
                 const int bn = b * d.N + n, r0 = pr.rb * 16;
                 Acc<S> ctx[16];
+                const unsigned row_bytes = (unsigned)(d.fW * C) * (unsigned)sizeof(FT);
+                const unsigned cvoff = (unsigned)((((int64_t)bn * d.fH + r0) * d.fW + w) * C) * (unsigned)sizeof(FT);
 #pragma unroll
                 for (int h = 0; h < 16; ++h) {
-                    const int row = (r0 + h) < d.fH ? (r0 + h) : d.fH - 1;
-                    load_ctx<FT, S>(context + (((int64_t)bn * d.fH + row) * d.fW + w) * C, li, ctx[h]);
+#ifdef PLAN_EXP_NOCTX      // (ablation build: no context traffic, results are wrong)
+                    ctx[h].zero(); ctx[h].q[0].x = __uint_as_float(cvoff + h);
+#else
+                    load_ctx_buf<FT, S>(crs, cvoff, (unsigned)h * row_bytes, li, ctx[h]);       // (rows past the image: zeroed below)
+#endif
                 }
                 const int myrow = (r0 + li) < d.fH ? (r0 + li) : d.fH - 1;
-                const int64_t pix = (((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D;
+                const unsigned pix = (unsigned)((((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D);
                 float4 dv[kMaxPairRuns];
 #pragma unroll
                 for (int r = 0; r < kMaxPairRuns; ++r) {
                     dv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < pr.nruns) dv[r] = load_depth4<FT>(depth, pix + runs[pr.run0 + r].d0);
+                    if (r < pr.nruns) dv[r] = load_depth4<FT>(drs, pix + runs[pr.run0 + r].d0);
                 }
-                if (r0 + 16 > d.fH) {          // rows past the image: their masks are zero, and so must their context be (0 * NaN)
+#ifdef PLAN_STAMPS
+                if (pi == g) { PLAN_STAMP(8); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PLAN_STAMP(9); }
+#endif
+                // a run's weight per image row: its (up to four) bins' depths under the run's row masks -- lane li is row li
+                float wsum[kMaxPairRuns];
+#pragma unroll
+                for (int r = 0; r < kMaxPairRuns; ++r) {
+                    wsum[r] = 0.f;
+                    if (r < pr.nruns) {
+                        const uint2 mk = *reinterpret_cast<const uint2 *>(runs[pr.run0 + r].mask);
+                        float wv = ((mk.x >> li) & 1u) ? dv[r].x : 0.f;
+                        wv += ((mk.x >> (16 + li)) & 1u) ? dv[r].y : 0.f;
+                        wv += ((mk.y >> li) & 1u) ? dv[r].z : 0.f;
+                        wv += ((mk.y >> (16 + li)) & 1u) ? dv[r].w : 0.f;
+                        wsum[r] = wv;
+                    }
+                }
+                if (r0 + 16 > d.fH) {          // rows past the image: their weights are zero, and so must their context be (0 * NaN)
 #pragma unroll
                     for (int h = 0; h < 16; ++h) if (r0 + h >= d.fH) ctx[h].zero();
                 }
 #pragma unroll
                 for (int r = 0; r < kMaxPairRuns; ++r) {
                     if (r < pr.nruns) {
-                        const RunRec rr = runs[pr.run0 + r];
-                        float wsum = ((rr.mask[0] >> li) & 1) ? dv[r].x : 0.f;
-                        wsum += ((rr.mask[1] >> li) & 1) ? dv[r].y : 0.f;
-                        wsum += ((rr.mask[2] >> li) & 1) ? dv[r].z : 0.f;
-                        wsum += ((rr.mask[3] >> li) & 1) ? dv[r].w : 0.f;
+                        const float wr = wsum[r];
                         Acc<S> acc;
                         acc.zero();
-#define PLAN_STEP(h) acc.fma(row_bcast<h>(wsum), ctx[h]);
+#ifdef PLAN_EXP_NOFMA      // ablation build: one row's products instead of sixteen (results are wrong)
+#define PLAN_STEP(h) if (h == 0) acc.fma(row_bcast<h>(wr), ctx[h]); else acc.q[0].x += ctx[h].q[0].x + ctx[h].q[1].y + ctx[h].s[0];
+#else
+#define PLAN_STEP(h) acc.fma(row_bcast<h>(wr), ctx[h]);
+#endif
                         PLAN_FOR16(PLAN_STEP)
 #undef PLAN_STEP
-                        store_row<S>(partial + (int)rr.pslot * C, li, acc);
+                        store_row<S>(partial + (int)runs[pr.run0 + r].pslot * C, li, acc);
                     }
                 }
             }
+#ifdef PLAN_STAMPS
+            PLAN_STAMP(10);
+#endif
+            // the next record: requested now (behind the pairs, whose registers it would otherwise take four of), parked in LDS
+            // when this unit's cells are stored
+            uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+            const bool have = njob >= 0 && tid < kJobBytes / 16;
+            if (have) pre = reinterpret_cast<const uint4 *>(records + (int64_t)njob * kJobBytes)[tid];
             __syncthreads();
+            PLAN_STAMP(3);
+#ifdef PLAN_STAMPS
+            if (tid == 0 && stamps && st_units == 0) stamps[6] = ((unsigned long long)hdr.npairs << 32) | hdr.nruns;
+#endif
             // ---- phase 2: a lane group per cell -- its partial rows in plan order, one store
             const int tx0 = (hdr.tile % d.tiles_x) * kTile, ty0 = (hdr.tile / d.tiles_x) * kTile;
             if (hdr.chain != kChainNone) {
                 if (g == 0) {
                     for (int q = 0; q < hdr.nruns; ++q) { Acc<S> t; load_row<S>(partial + q * C, li, t); chain_acc.add(t); }
-                    const int x = tx0 + (hdr.c0 & 7), y = ty0 + (hdr.c0 >> 3);
+                    const int x = tx0 + z_x(hdr.c0), y = ty0 + z_y(hdr.c0);
                     if (!more && x < d.nx && y < d.ny) store_row<S>(a.out + (((int64_t)b * d.ny + y) * d.nx + x) * C, li, chain_acc);
                 }
             } else {
 #pragma unroll 1
                 for (int c = g; c < hdr.ncells; c += kFwdThreads / 16) {
                     const int l = hdr.c0 + c;
-                    const int x = tx0 + (l & 7), y = ty0 + (l >> 3);
+                    const int x = tx0 + z_x(l), y = ty0 + z_y(l);
                     Acc<S> acc;
                     acc.zero();
                     for (int q = cb[c]; q < cb[c + 1]; ++q) { Acc<S> t; load_row<S>(partial + q * C, li, t); acc.add(t); }
+#ifdef PLAN_EXP_NOSTORE    // ablation build: no output (results are wrong)
+                    if (acc.q[0].x == 1234.5f)
+#endif
                     if (x < d.nx && y < d.ny) store_row<S>(a.out + (((int64_t)b * d.ny + y) * d.nx + x) * C, li, acc);
                 }
             }
-          } while (more);
+            PLAN_STAMP(4);
+#ifdef PLAN_STAMPS
+            ++st_units;
+#endif
+            in_chain = more;
+            if (!more) chain_acc.zero();
+            if (have) reinterpret_cast<uint4 *>(plan_lds + (cur ^ 1) * kJobBytes)[tid] = pre;
+            job = njob;
+            cur ^= 1;
         }
+        PLAN_STAMP(5);
         return;
     }
 
     // ---- brute force: a calibration without a plan (its runs or jobs overflow the slot), straight from the slot's summary.
     // A workgroup takes a tile; a lane group owns the cells whose index in the tile is g + 16 * pass, one pass at a time;
     // the entries of the summary that can reach the tile are compacted in index order, so the sums are ordered as well.
-    if (tid == 0 && first == 0 && lo_k == 0) atomicAdd(&reinterpret_cast<CacheHeader *>(p.cache)->brute, 1u);
+    if (tid == 0 && first == 0 && g0 == 0) atomicAdd(&reinterpret_cast<CacheHeader *>(p.cache)->brute, 1u);
     int *list = reinterpret_cast<int *>(plan_lds);
     int *wcount = list + kFwdThreads;
     const int2 *summary = reinterpret_cast<const int2 *>(sbase + p.summary_off);
     const int total = d.strips * d.D;
     const int wave = tid >> 6, lane = tid & 63;
-    for (int tile = lo_k + first; tile < hi_k; tile += stride) {
+    for (int u = first; u < nunits; u += stride) {
+        const int tile = unit_of(u);
+        if (tile < 0) continue;
         const int tx0 = (tile % d.tiles_x) * kTile, ty0 = (tile / d.tiles_x) * kTile;
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) {
@@ -599,7 +764,7 @@ __global__ __launch_bounds__(kFwdThreads) void lss_plan_fwd(FwdArgs a) {
                     const int bn = b * d.N + n, r0 = rb * 16;
                     const int myrow = (r0 + li) < d.fH ? (r0 + li) : d.fH - 1;
                     const int bin0 = bin + kRunBins > d.D ? d.D - kRunBins : bin;       // (the four bins stay inside the pixel's D)
-                    const float4 dq = load_depth4<FT>(depth, (((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D + bin0);
+                    const float4 dq = load_depth4<FT>(drs, (unsigned)((((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D + bin0));
                     const int dsel = bin - bin0;
                     const float dbin = dsel == 0 ? dq.x : (dsel == 1 ? dq.y : (dsel == 2 ? dq.z : dq.w));
                     const float dep = ((zm >> li) & 1u) ? dbin : 0.f;
@@ -678,6 +843,11 @@ void launch_prepare(mmt::TimedSeq &seq, const PlanArgs &p, hipStream_t st, bool 
     seq.launch(last, lss_plan_build, dim3((unsigned)g), dim3(kBuildThreads), 0, st, p);
 }
 
+static int plan_fwd_wgs() {
+    static const char *env = getenv("MMT_PLAN_WGS");          // experiments only
+    return (env && atoi(env) > 0) ? atoi(env) : 1024;
+}
+
 template <typename FT>
 int plan_forward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, int nx, int ny, int nz, const float *combine, const float *fu,
                       const float *fv, const float *fd, const float *vc, const float *vs, const FT *depth, const FT *context, float *out,
@@ -692,15 +862,20 @@ int plan_forward_impl(const char *what, int B, int N, int D, int fH, int fW, int
     if (const int rc = fill_plan_args(what, B, N, D, fH, fW, nx, ny, nz, combine, fu, fv, fd, vc, vs, cache, cache_bytes, &a.p)) return rc;
     a.depth = depth; a.context = context; a.out = out; a.summary_out = reinterpret_cast<int2 *>(column_summary);
     a.C = C; a.force_brute = (flags & MMT_LSS_PLAN_BRUTE) ? 1 : 0;
+    a.depth_bytes = (unsigned)((int64_t)B * N * fH * fW * D * (int64_t)sizeof(FT));
+    a.ctx_bytes = (unsigned)((int64_t)B * N * fH * fW * C * (int64_t)sizeof(FT));
     const Dims &d = a.p.d;
-    int W = d.ntiles + (int)(((int64_t)d.strips * D) / (2 * kMaxRuns));
+    // persistent workgroups: as many as the chip holds at once (4 per CU: 35 KB of LDS, 128 VGPRs), every one walks its share of
+    // the sample's units with the next record in flight
+    int W = plan_fwd_wgs() / B;
     if (W > d.jobs_cap) W = d.jobs_cap;
     W = (W + 7) & ~7;
+    if (W < 8) W = 8;
     a.W = W;
     a.xps = (B <= 8 && 8 % B == 0) ? 8 / B : 0;
     mmt::TimedSeq seq;
     if (!(flags & MMT_LSS_PLAN_PREPARED)) launch_prepare(seq, a.p, st, false);
-    const size_t lds = (size_t)kJobBytes + (size_t)kMaxRuns * C * 4;
+    const size_t lds = 2 * (size_t)kJobBytes + (size_t)kMaxRuns * C * 4;
     const dim3 grid((unsigned)((int64_t)B * W)), blk(kFwdThreads);
     if (C == 80) seq.launch(true, lss_plan_fwd<FT, 5>, grid, blk, lds, st, a);
     else if (C == 64) seq.launch(true, lss_plan_fwd<FT, 4>, grid, blk, lds, st, a);
@@ -744,6 +919,7 @@ extern "C" int mmt_lss_plan_cache_layout(int N, int D, int fH, int fW, int nx, i
     int64_t fit = plan_cache_bytes < fixed ? 0 : (plan_cache_bytes - fixed) / l.slot_bytes;
     if (fit > 256) fit = 256;
     const int64_t v[12] = {fit, l.slots_off, l.slot_bytes, l.summary_off, l.records_off, kVerdictOff, l.d.jobs_cap, l.d.runs_cap, kJobBytes, kPlanMaxB, l.d.strips, l.d.ntiles};
+    static_assert(sizeof(Verdict) == 64, "tests read 16 words per verdict");
     memcpy(layout_host, v, sizeof(v));
     return MMT_OK;
 }

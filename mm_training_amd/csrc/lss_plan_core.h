@@ -28,9 +28,16 @@ namespace plan {
 
 constexpr int kTile = 8;                 // BEV tile edge in cells
 constexpr int kTileCells = kTile * kTile;
-constexpr int kMaxRuns = 96;             // runs (= partial rows in LDS) per job
-constexpr int kMaxPairRuns = 8;          // runs per pair record (a lane group keeps their depths in registers)
+#ifndef PLAN_MAX_RUNS
+#define PLAN_MAX_RUNS 96
+#endif
+#ifndef PLAN_MAX_PAIR_RUNS
+#define PLAN_MAX_PAIR_RUNS 4
+#endif
+constexpr int kMaxRuns = PLAN_MAX_RUNS;  // runs (= partial rows in LDS) per job (<= 255: a record's cell_begin is bytes)
+constexpr int kMaxPairRuns = PLAN_MAX_PAIR_RUNS;   // runs per pair record (a lane group keeps their depths in registers)
 constexpr int kRunBins = 4;              // depth bins per run (one 16-byte depth load per image row)
+constexpr int kGroups = 8;               // record groups of a plan: neighbouring tiles (one XCD's share at batch 1), heaviest tiles first inside
 constexpr int kSummaryUniformBit = 0x10000;   // = mmt::kSummaryUniform (mmt_camera.h)
 
 // job record: header | cell_begin[kTileCells + 1] u8 | pairs[kMaxRuns] | runs[kMaxRuns]
@@ -43,7 +50,7 @@ struct Dims {
     int N, D, fH, fW, nb;                // cameras, depth bins, image rows / columns of the feature map, 16-row blocks per column
     int nx, ny;                          // BEV grid
     int tiles_x, tiles_y, ntiles;        // 8 x 8 tiles (the last ones may overhang the grid)
-    int ncells_tm;                       // ntiles * 64: cells in TILE-MAJOR order (tile * 64 + (y % 8) * 8 + x % 8)
+    int ncells_tm;                       // ntiles * 64: cells in TILE-MAJOR order (tile * 64 + the cell's place on the tile's Z curve)
     int strips;                          // N * nb * fW: (camera, row block, column) = the summary's first three axes
     int runs_cap, jobs_cap;              // capacity of the slot / scratch arrays; beyond them a calibration is "unplannable"
 };
@@ -82,16 +89,25 @@ struct JobDesc { int32_t tile, c0, ncells, run_begin, nruns, chain, pad1, pad2; 
 // the head walks the whole chain and sums the records' partial rows in order; a workgroup that meets a link skips it
 constexpr uint32_t kChainNone = 0, kChainHead = 1, kChainLink = 2, kChainMore = 4;      // kChainMore: the next record continues this chain
 struct JobHeader { uint16_t ncells, npairs, nruns, c0; int32_t tile; uint32_t chain; };
-struct PairRec { uint16_t col; uint8_t rb; uint8_t nruns; uint16_t run0; uint16_t pad; };        // col = camera * fW + column
+struct PairRec { uint16_t col; uint8_t rb; uint8_t nruns; uint16_t run0; uint16_t live; };       // col = camera * fW + column; live: bit i = row i of the block is in some run of the pair
 struct RunRec { uint16_t d0; uint8_t len; uint8_t pslot; uint16_t mask[kRunBins]; uint32_t cell_local; };   // pslot: partial row; cell_local: index in the job
 
+// A tile's 64 cells are numbered along a Z curve (x bits at the even, y bits at the odd positions), so that a job -- a range of
+// consecutive cells -- is a compact block (2 x 2, 4 x 2, 4 x 4, ...) and not a strip: a column's ray then crosses several of
+// the job's cells and its 16 context rows, loaded once per job, serve them all (near the cameras, where a cell is fed by a
+// dozen columns and a job holds a handful of cells, a row-major strip is crossed in one or two cells only).
+PLAN_HD int z_of(int lx, int ly) {
+    return (lx & 1) | ((ly & 1) << 1) | ((lx & 2) << 1) | ((ly & 2) << 2) | ((lx & 4) << 2) | ((ly & 4) << 3);
+}
+PLAN_HD int z_x(int l) { return (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4); }
+PLAN_HD int z_y(int l) { return ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4); }
 PLAN_HD int cell_tm(const Dims &d, int x, int y) {
-    return ((y / kTile) * d.tiles_x + x / kTile) * kTileCells + (y % kTile) * kTile + (x % kTile);
+    return ((y / kTile) * d.tiles_x + x / kTile) * kTileCells + z_of(x % kTile, y % kTile);
 }
 PLAN_HD void cell_xy(const Dims &d, int ctm, int *x, int *y) {
     const int tile = ctm / kTileCells, l = ctm % kTileCells;
-    *x = (tile % d.tiles_x) * kTile + l % kTile;
-    *y = (tile / d.tiles_x) * kTile + l / kTile;
+    *x = (tile % d.tiles_x) * kTile + z_x(l);
+    *y = (tile / d.tiles_x) * kTile + z_y(l);
 }
 
 // Build scratch of ONE sample (device: a slice of the plan cache; host: plain arrays)
@@ -99,16 +115,19 @@ struct Scratch {
     int32_t *cell_off;                   // [ncells_tm + 1]  counts, then exclusive prefix
     int32_t *cursor;                     // [ncells_tm]
     RunTmp *runs;                        // [runs_cap], sorted by (cell, key) when phase_sort_cells is through
-    int32_t *tile_jobs;                  // [ntiles + 1] jobs per tile, then exclusive prefix
+    int32_t *tile_jobs;                  // [ntiles + 1] records per tile
+    int32_t *tile_perm;                  // [ntiles] the tiles in the order their records are laid out: eight groups of neighbouring tiles, heaviest first inside a group
+    int32_t *perm_jobs;                  // [ntiles + 1] records per tile in that order, then exclusive prefix
+    int32_t *tile_base;                  // [ntiles] first record of a tile
     JobDesc *jobs;                       // [jobs_cap]
     uint8_t *order;                      // [jobs_cap * kMaxRuns]
     int32_t *partial;                    // [nthreads_max] scan partials
-    int32_t *status;                     // [4]: nruns, njobs, unplannable (0 / 1), reserved
+    int32_t *status;                     // [16]: nruns, njobs, unplannable (0 / 1), first record of group g at [3 + g] (g = 0..kGroups)
 };
 
 PLAN_HD long long scratch_bytes(const Dims &d, int nthreads_max) {
     auto up = [](long long v) { return (v + 255) & ~255ll; };
-    return up(4ll * (d.ncells_tm + 1)) + up(4ll * d.ncells_tm) + up(16ll * d.runs_cap) + up(4ll * (d.ntiles + 1)) + up(32ll * d.jobs_cap) +
+    return up(4ll * (d.ncells_tm + 1)) + up(4ll * d.ncells_tm) + up(16ll * d.runs_cap) + 4 * up(4ll * (d.ntiles + 1)) + up(32ll * d.jobs_cap) +
            up((long long)d.jobs_cap * kMaxRuns) + up(4ll * nthreads_max) + 256;
 }
 PLAN_HD void scratch_carve(const Dims &d, int nthreads_max, void *base, Scratch *s) {
@@ -118,6 +137,9 @@ PLAN_HD void scratch_carve(const Dims &d, int nthreads_max, void *base, Scratch 
     s->cursor = reinterpret_cast<int32_t *>(p); p += up(4ll * d.ncells_tm);
     s->runs = reinterpret_cast<RunTmp *>(p); p += up(16ll * d.runs_cap);
     s->tile_jobs = reinterpret_cast<int32_t *>(p); p += up(4ll * (d.ntiles + 1));
+    s->tile_perm = reinterpret_cast<int32_t *>(p); p += up(4ll * (d.ntiles + 1));
+    s->perm_jobs = reinterpret_cast<int32_t *>(p); p += up(4ll * (d.ntiles + 1));
+    s->tile_base = reinterpret_cast<int32_t *>(p); p += up(4ll * (d.ntiles + 1));
     s->jobs = reinterpret_cast<JobDesc *>(p); p += up(32ll * d.jobs_cap);
     s->order = reinterpret_cast<uint8_t *>(p); p += up((long long)d.jobs_cap * kMaxRuns);
     s->partial = reinterpret_cast<int32_t *>(p); p += up(4ll * nthreads_max);
@@ -182,7 +204,7 @@ PLAN_HD void emit_strip(const Dims &d, const int32_t *summary, int s, RowCells &
 PLAN_HD void phase_clear(const Dims &d, Scratch &s, int tid, int nt) {
     for (int i = tid; i <= d.ncells_tm; i += nt) s.cell_off[i] = 0;
     for (int i = tid; i < d.ncells_tm; i += nt) s.cursor[i] = 0;
-    if (tid == 0) { s.status[0] = 0; s.status[1] = 0; s.status[2] = 0; s.status[3] = 0; }
+    if (tid == 0) for (int i = 0; i < 16; ++i) s.status[i] = 0;
 }
 // phase 1: runs per cell
 template <class RowCells>
@@ -275,25 +297,50 @@ PLAN_HD int cut_tile(const Scratch &s, int tile, Emit &emit) {
     if (c0 < kTileCells) { emit(jobs, c0, kTileCells - c0, off[c0], off[kTileCells] - off[c0], (int)kChainNone); ++jobs; }
     return jobs;
 }
-// phase 6: jobs per tile
+// phase 6: records per tile
 PLAN_HD void phase_count_jobs(const Dims &d, Scratch &s, int tid, int nt) {
     for (int t = tid; t < d.ntiles; t += nt) {
         auto none = [](int, int, int, int, int, int) {};
         s.tile_jobs[t] = cut_tile(s, t, none);
     }
-    if (tid == 0) s.tile_jobs[d.ntiles] = 0;
 }
-// phase 8 (after the scan of tile_jobs): too many jobs?
-PLAN_HD void phase_check_jobs(const Dims &d, Scratch &s, int tid) {
+// phase 7: the order the records are laid out in.  The forward deals a calibration's records to its workgroups in index
+// order, and workgroups start in index order: a tile that takes long (near the cameras a cell is fed by dozens of columns)
+// must not be met last.  kGroups groups of neighbouring tiles (a group's context rows meet in one XCD's L2); inside a group
+// the tiles by falling number of runs (ties: by tile index), so a group's heavy records come first.
+PLAN_HD int group_begin(const Dims &d, int g) { return (int)((long long)g * d.ntiles / kGroups); }
+PLAN_HD void phase_tile_order(const Dims &d, Scratch &s, int tid, int nt) {
+    for (int g = tid; g < kGroups; g += nt) {
+        const int lo = group_begin(d, g), hi = group_begin(d, g + 1);
+        for (int i = lo; i < hi; ++i) {
+            const int t = i, runs = s.cell_off[(t + 1) * kTileCells] - s.cell_off[t * kTileCells];
+            int j = i - 1;
+            while (j >= lo) {
+                const int tj = s.tile_perm[j], rj = s.cell_off[(tj + 1) * kTileCells] - s.cell_off[tj * kTileCells];
+                if (rj >= runs) break;
+                s.tile_perm[j + 1] = tj; --j;
+            }
+            s.tile_perm[j + 1] = t;
+        }
+    }
+}
+PLAN_HD void phase_perm_gather(const Dims &d, Scratch &s, int tid, int nt) {
+    for (int i = tid; i < d.ntiles; i += nt) s.perm_jobs[i] = s.tile_jobs[s.tile_perm[i]];
+    if (tid == 0) s.perm_jobs[d.ntiles] = 0;
+}
+// phase 8 (after the scan of perm_jobs): first record of every tile and group; too many records?
+PLAN_HD void phase_tile_bases(const Dims &d, Scratch &s, int tid, int nt) {
+    for (int i = tid; i < d.ntiles; i += nt) s.tile_base[s.tile_perm[i]] = s.perm_jobs[i];
     if (tid == 0) {
-        s.status[1] = s.tile_jobs[d.ntiles];
-        if (s.tile_jobs[d.ntiles] > d.jobs_cap) s.status[2] = 1;
+        s.status[1] = s.perm_jobs[d.ntiles];
+        if (s.perm_jobs[d.ntiles] > d.jobs_cap) s.status[2] = 1;
+        for (int g = 0; g <= kGroups; ++g) s.status[3 + g] = s.perm_jobs[group_begin(d, g)];
     }
 }
 // phase 9: job descriptors
 PLAN_HD void phase_write_jobs(const Dims &d, Scratch &s, int tid, int nt) {
     for (int t = tid; t < d.ntiles; t += nt) {
-        const int base = s.tile_jobs[t];
+        const int base = s.tile_base[t];
         auto put = [&](int j, int c0, int nc, int rb, int nr, int chain) {
             JobDesc jd; jd.tile = t; jd.c0 = c0; jd.ncells = nc; jd.run_begin = rb; jd.nruns = nr; jd.chain = chain; jd.pad1 = jd.pad2 = 0;
             s.jobs[base + j] = jd;
@@ -337,11 +384,12 @@ PLAN_HD void phase_records(const Dims &, Scratch &s, uint8_t *records, int njobs
             rr[p] = o;
             const uint32_t pk = r.key >> 11;          // (column, row block)
             if (pk != pkey || pairs[npairs - 1].nruns >= kMaxPairRuns) {
-                PairRec pr; pr.col = (uint16_t)(r.key >> 16); pr.rb = (uint8_t)((r.key >> 11) & 31u); pr.nruns = 0; pr.run0 = (uint16_t)p; pr.pad = 0;
+                PairRec pr; pr.col = (uint16_t)(r.key >> 16); pr.rb = (uint8_t)((r.key >> 11) & 31u); pr.nruns = 0; pr.run0 = (uint16_t)p; pr.live = 0;
                 pairs[npairs++] = pr;
                 pkey = pk;
             }
             ++pairs[npairs - 1].nruns;
+            pairs[npairs - 1].live |= (uint16_t)(o.mask[0] | o.mask[1] | o.mask[2] | o.mask[3]);
         }
         JobHeader h; h.ncells = (uint16_t)jd.ncells; h.npairs = (uint16_t)npairs; h.nruns = (uint16_t)jd.nruns; h.c0 = (uint16_t)jd.c0; h.tile = jd.tile; h.chain = (uint32_t)jd.chain;
         *reinterpret_cast<JobHeader *>(rec) = h;

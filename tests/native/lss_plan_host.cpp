@@ -23,7 +23,7 @@ extern "C" int plan_host_dims(int N, int D, int fH, int fW, int nx, int ny, int 
 
 extern "C" int plan_host_job_bytes(void) { return kJobBytes; }
 
-// Returns njobs (>= 0), or -1 unplannable; records: [jobs_cap * kJobBytes]; status: 4 ints (nruns, njobs, unplannable, 0)
+// Returns njobs (>= 0), or -1 unplannable; records: [jobs_cap * kJobBytes]; status: 16 ints (nruns, njobs, unplannable, group starts [9], ...)
 extern "C" int plan_host_build(int N, int D, int fH, int fW, int nx, int ny, int runs_cap_override, const int32_t *summary, const int32_t *rowcells,
                                uint8_t *records, int32_t *status) {
     Dims d;
@@ -41,15 +41,17 @@ extern "C" int plan_host_build(int N, int D, int fH, int fW, int nx, int ny, int
         phase_place(d, s, summary, rc, 0, 1);
         phase_sort_cells(d, s, 0, 1);
         phase_count_jobs(d, s, 0, 1);
-        scan_a(s.tile_jobs, d.ntiles, s.partial, 0, 1); scan_b(s.tile_jobs, d.ntiles, s.partial, 0, 1); scan_c(s.tile_jobs, d.ntiles, s.partial, 0, 1);
-        phase_check_jobs(d, s, 0);
+        phase_tile_order(d, s, 0, 1);
+        phase_perm_gather(d, s, 0, 1);
+        scan_a(s.perm_jobs, d.ntiles, s.partial, 0, 1); scan_b(s.perm_jobs, d.ntiles, s.partial, 0, 1); scan_c(s.perm_jobs, d.ntiles, s.partial, 0, 1);
+        phase_tile_bases(d, s, 0, 1);
         if (!s.status[2]) {
             phase_write_jobs(d, s, 0, 1);
             njobs = s.status[1];
             phase_records(d, s, records, njobs, 0, 1);
         }
     }
-    memcpy(status, s.status, 16);
+    memcpy(status, s.status, 64);
     free(mem);
     return njobs;
 }

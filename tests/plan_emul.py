@@ -13,10 +13,10 @@ _CORE = os.path.join(_HERE, "..", "mm_training_amd", "csrc", "lss_plan_core.h")
 _OUT = os.path.join(_HERE, "native", "_build", "libplanhost.so")
 
 UNIFORM = 0x10000
-MAX_RUNS, MAX_PAIR_RUNS, RUN_BINS, TILE = 96, 8, 4, 8
+MAX_RUNS, MAX_PAIR_RUNS, RUN_BINS, TILE = 96, 4, 4, 8
 HDR = np.dtype([("ncells", "<u2"), ("npairs", "<u2"), ("nruns", "<u2"), ("c0", "<u2"), ("tile", "<i4"), ("chain", "<u4")])
 CHAIN_HEAD, CHAIN_LINK, CHAIN_MORE = 1, 2, 4
-PAIR = np.dtype([("col", "<u2"), ("rb", "u1"), ("nruns", "u1"), ("run0", "<u2"), ("pad", "<u2")])
+PAIR = np.dtype([("col", "<u2"), ("rb", "u1"), ("nruns", "u1"), ("run0", "<u2"), ("live", "<u2")])
 RUN = np.dtype([("d0", "<u2"), ("len", "u1"), ("pslot", "u1"), ("mask", "<u2", (4,)), ("cell_local", "<u4")])
 CELL_BEGIN_OFF, PAIRS_OFF, RUNS_OFF, JOB_BYTES = 16, 96, 96 + 8 * MAX_RUNS, 96 + 8 * MAX_RUNS + 16 * MAX_RUNS
 
@@ -74,7 +74,7 @@ def build(N, D, fH, fW, nx, ny, summary, rowcells, runs_cap=0):
     """-> (njobs or -1, records uint8 [njobs, JOB_BYTES], status)"""
     d = dims(N, D, fH, fW, nx, ny, runs_cap)
     records = np.zeros((d["jobs_cap"], JOB_BYTES), np.uint8)
-    status = np.zeros(4, np.int32)
+    status = np.zeros(16, np.int32)
     summary = np.ascontiguousarray(summary, np.int32)
     rowcells = np.ascontiguousarray(rowcells, np.int32)
     n = host_lib().plan_host_build(N, D, fH, fW, nx, ny, int(runs_cap), summary.ctypes.data_as(ctypes.c_void_p),
@@ -95,8 +95,10 @@ def decode(record):
 def job_cells(d, job):
     """(x, y) of the job's cells, in order"""
     tile, c0, n = int(job["h"]["tile"]), int(job["h"]["c0"]), int(job["h"]["ncells"])
-    l = np.arange(c0, c0 + n)
-    return (tile % d["tiles_x"]) * TILE + l % TILE, (tile // d["tiles_x"]) * TILE + l // TILE
+    l = np.arange(c0, c0 + n)                 # places on the tile's Z curve: x bits at the even, y bits at the odd positions
+    lx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4)
+    ly = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4)
+    return (tile % d["tiles_x"]) * TILE + lx, (tile // d["tiles_x"]) * TILE + ly
 
 
 def emulate_forward(d, records, depth, context, dtype=np.float64):
@@ -118,14 +120,17 @@ def emulate_forward(d, records, depth, context, dtype=np.float64):
         for pr in job["pairs"]:
             n, w, rb = int(pr["col"]) // fW, int(pr["col"]) % fW, int(pr["rb"])
             assert 1 <= int(pr["nruns"]) <= MAX_PAIR_RUNS
+            live = 0
             for r in job["runs"][int(pr["run0"]):int(pr["run0"]) + int(pr["nruns"])]:
                 wgt = np.zeros(16, dtype)
+                live |= int(np.bitwise_or.reduce(r["mask"]))
                 for j in range(int(r["len"])):
                     bits = (int(r["mask"][j]) >> np.arange(16)) & 1
                     wgt += bits * dp[n, rb * 16:(rb + 1) * 16, w, int(r["d0"]) + j]
                 assert not written[int(r["pslot"])]
                 partial[int(r["pslot"])] = wgt @ cx[n, rb * 16:(rb + 1) * 16, w]
                 written[int(r["pslot"])] = True
+            assert live == int(pr["live"])          # the rows whose context the kernel loads
         assert written[:nruns].all()
         xs, ys = job_cells(d, job)
         cb = job["cell_begin"]

@@ -57,6 +57,19 @@ def _check_plan(geom, vn, C=16, seed=0, clear=None, runs_cap=0):
         total_runs += n
     assert (covered == 1).all()
     assert total_runs == status[0]
+    # layout: eight groups of neighbouring tiles; inside a group the tiles by falling number of runs, a tile's records together
+    gs = [int(v) for v in status[3:12]]
+    assert gs[0] == 0 and gs[8] == njobs and all(a <= b for a, b in zip(gs, gs[1:]))
+    tiles = [int(P.decode(r)["h"]["tile"]) for r in records]
+    runs_of = {}
+    for r in records:
+        j = P.decode(r)
+        runs_of[int(j["h"]["tile"])] = runs_of.get(int(j["h"]["tile"]), 0) + int(j["h"]["nruns"])
+    for g in range(8):
+        seq = tiles[gs[g]:gs[g + 1]]
+        order = [t for i, t in enumerate(seq) if i == 0 or seq[i - 1] != t]
+        assert len(order) == len(set(order)) and sorted(order) == list(range(g * d["ntiles"] // 8, (g + 1) * d["ntiles"] // 8))
+        assert all(runs_of[a] >= runs_of[b] for a, b in zip(order, order[1:]))
     # arithmetic: emulated forward == direct scatter
     rng = np.random.default_rng(seed)
     depth = rng.random((N, fH, fW, D))

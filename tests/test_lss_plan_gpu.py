@@ -34,7 +34,7 @@ def _layout(N, D, fH, fW, nx, ny, cache):
 
 def _verdicts(cache, lay, B):
     o = lay["base"] + lay["verdict_off"]
-    return cache[o:o + 16 * B].view(torch.int32).view(B, 4).cpu().numpy()
+    return cache[o:o + 64 * B].view(torch.int32).view(B, 16).cpu().numpy()      # slot, units, state, representative, group starts [9]
 
 
 def _slot_arrays(cache, lay, slot, njobs):

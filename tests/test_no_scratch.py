@@ -19,7 +19,9 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 #   thread for it -- a measured trade (round 3: 36.5 -> 26.7 us with the cap), outside the walk's loop.
 # * lss_plan_build (lift_splat_plan.hip): learns a calibration's plan ONCE (one 1024-thread workgroup per calibration, phases of
 #   plain index arithmetic with per-thread row-cell arrays); not on the step's steady-state path.
-ALLOWED = ("rocprim", "lss_ray_bwd", "lss_plan_build")
+# * lss_plan_fwd<.., 5> (lift_splat_plan.hip): capped at 128 VGPRs for four waves per SIMD; two loop-invariant values are spilled
+#   (8-12 bytes per thread, one reload per unit, outside the pair loop) -- 22.8 us with the cap against 27.0 us without.
+ALLOWED = ("rocprim", "lss_ray_bwd", "lss_plan_build", "lss_plan_fwd")
 
 
 def _kernels(lib_path):

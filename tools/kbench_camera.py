@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--stamps", choices=["fwd", "col"], default=None, help="the library is a -DLSS_STAMPS build of lift_splat_tile.hip (fwd) "
                     "or lift_splat_col.hip (col) (tools/build_variant.py): print that kernel's in-kernel s_memtime phase breakdown instead of "
                     "timing.  The choice must match the build: a stamp build writes stamps where a plain one writes its results")
+    ap.add_argument("--cases", default=None, help="regular expression: time only the cases whose name matches")
     ap.add_argument("libs", nargs="*")
     args = ap.parse_args()
     libs = args.libs or [_lib.LIB_PATH]
@@ -250,28 +251,28 @@ def main():
     # ---- plan form (lift_splat_plan.hip): the output-stationary forward on the learnt plan
     if hasattr(h0, "mmt_lss_splat_forward_plan"):
         PREP = 0x2000
-        pbytes = h0.mmt_lss_plan_cache_bytes(N, D, fH, fW, nx, ny, max(B, 2))
-        pcache = {p: torch.zeros(pbytes + 256, dtype=torch.uint8, device="cuda") for p in libs}
+        pbytes_of = {id(h): h.mmt_lss_plan_cache_bytes(N, D, fH, fW, nx, ny, max(B, 2)) for h in hs}      # (a variant build may size its slots differently)
+        pcache = {p: torch.zeros(pbytes_of[id(h)] + 256, dtype=torch.uint8, device="cuda") for p, h in zip(libs, hs)}
         pptr = {id(h): (pcache[p].data_ptr() + 255) & ~255 for p, h in zip(libs, hs)}
 
         def fwd_plan(h, flags=PM, sm=None):
             return getattr(h, "mmt_lss_splat_forward_plan" + sfx)(B, N, D, fH, fW, C, nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(),
                                                                  fd.data_ptr(), vc_c, vs_c, depth.data_ptr(), ctx.data_ptr(), out.data_ptr(),
-                                                                 sm.data_ptr() if sm is not None else None, pptr[id(h)], pbytes, flags, st)
+                                                                 sm.data_ptr() if sm is not None else None, pptr[id(h)], pbytes_of[id(h)], flags, st)
 
         def prepare(h):
             return h.mmt_lss_plan_prepare(B, N, D, fH, fW, nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(), fd.data_ptr(), vc_c, vs_c,
-                                          pptr[id(h)], pbytes, st)
+                                          pptr[id(h)], pbytes_of[id(h)], st)
 
         out.fill_(float("nan")); assert fwd_plan(h0) == 0, h0.mmt_last_error()
         out_p = out.clone()
         out.fill_(float("nan")); assert fwd_plan(h0, PM | PREP) == 0, h0.mmt_last_error()
         cnt = (ctypes.c_int64 * 8)()
-        h0.mmt_lss_plan_cache_counters(pptr[id(h0)], pbytes, cnt, st)
+        h0.mmt_lss_plan_cache_counters(pptr[id(h0)], pbytes_of[id(h0)], cnt, st)
         info["plan_form"] = dict(max_abs_diff_vs_camera=float((out_p - out_c).abs().max()), bit_identical_again=bool(torch.equal(out, out_p)),
                                  every_element_written=not bool(torch.isnan(out_p).any()), counters=list(cnt)[:6], family=hex(h0.mmt_lss_last_kernel_family(0)))
         assert info["plan_form"]["bit_identical_again"] and info["plan_form"]["every_element_written"]
-        assert info["plan_form"]["max_abs_diff_vs_camera"] <= 2e-5 * float(out_c.abs().max())
+        assert os.environ.get("KBC_ABLATION") or info["plan_form"]["max_abs_diff_vs_camera"] <= 2e-5 * float(out_c.abs().max())
         for p, h in zip(libs[1:], hs[1:]):
             assert fwd_plan(h) == 0, h.mmt_last_error()
         cases.update({
@@ -282,6 +283,9 @@ def main():
             "fwd_plan_prepared_cold(kernel)": (lambda h: fwd_plan(h, PM | PREP), dict(cold=True)),
             "fwd_plan_brute_force": (lambda h: fwd_plan(h, PM | PREP | 0x4000), dict(reps=3, warm=1)),
         })
+    if args.cases:
+        import re
+        cases = {k: v for k, v in cases.items() if re.search(args.cases, k)}
     res = {}
     for rnd in range(args.rounds):
         for name, (fn, kw) in cases.items():
