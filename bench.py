@@ -368,7 +368,7 @@ def pmc_traffic(config, kernels):
     """HBM bytes per launch from a committed rocprofv3 --pmc summary OF THIS CONFIGURATION (separate FETCH_SIZE /
     WRITE_SIZE passes with the gfx950 correction; tools/collect_profiles.sh writes profiles/r02_pmc_<config>.json).
     PMC collection cannot run inside this process; None when the shape has no summary."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{config}.json")
         if not os.path.exists(path):
             continue                  # an older round's summary stands in only while this round has none for the configuration
@@ -780,13 +780,24 @@ def train_main(args, rank, local_rank, world):
                     "aggregate L2 bandwidth; the drop-in op's HBM roofline is roofline_voxel_pooling[_backward]")
             sfx = "_bf16" if dtype == "bf16" else ""
             tiles = fam_f.startswith("tile")
+            plan = fam_f.startswith("plan")
             kfwd = {"ray": "lss_ray_fwd_reg" if "+register" in fam_f_detail else ("lss_ray_fwd_blk" if "+block" in fam_f_detail else "lss_ray_fwd"),
-                    "tile": "lss_splat_fwd_tile"}.get(fam_f.split("+")[0], fam_f)
+                    "tile": "lss_splat_fwd_tile", "plan": "lss_plan_fwd"}.get(fam_f.split("+")[0], fam_f)
+            if plan:
+                note = ("fused get_geometry + quantise + lift + voxel_pooling (SURVEY 8 rows f1 + f3) in its PLAN form: output-stationary on a "
+                        "per-calibration plan learnt on the device (cell -> runs of (column, row block, bins)); a workgroup takes a job (cells of an "
+                        "8 x 8 BEV tile, <= 96 runs), sums depth * context per run in registers, one partial row per run into LDS, then sums every "
+                        "cell's partial rows in plan order and STORES -- no zero fill, no atomics, bit-identical from step to step.  `avg_ms` is the "
+                        "forward kernel; the per-step lookup of the batch's calibrations (lss_plan_probe + an empty lss_plan_build) is issued in "
+                        "front of the image backbone and reported under `prepare`.  The kernel is bound by the context rows it re-reads through "
+                        "L1 (a column's 16 rows once per job it crosses: ~90 MB per launch at BASELINE configs[3]), not by HBM: l2_side")
             kbwd = {"ray": "lss_ray_bwd", "tile": "lss_splat_bwd_tile", "column": "lss_col_bwd"}.get(fam_b.split("+")[0], fam_b)
             column = fam_b.startswith("column")
             adaptive = lss._column_adaptive
             res["config"]["lift_splat_kernels"] = {
                 "forward": fam_f_detail, "backward": fam_b,
+                "plan_form": ("on: output-stationary forward on the learnt plan; calls / hits / calibrations learnt / samples served by the "
+                              "brute-force path: %s" % lss.plan_cache_counters()) if plan else "off",
                 "exclusive_cell_cache": ("on: runs into single-run cells are stored, not added (learnt on the device per calibration; "
                                          "the synthetic batch repeats, so every timed step uses it)") if "+exclusive" in fam_f_detail else "off",
                 "exclusive_cell_cache_calls": lss.exclusive_cache_counters() if "+exclusive" in fam_f_detail else None,
@@ -795,18 +806,25 @@ def train_main(args, rank, local_rank, world):
                     "auto: per calibration id, from the geometry" if args.calibration_ids else
                     "auto: from the column kernel's own counters, read back lazily (share of kept points outside their column's cell: %s)"
                     % (None if adaptive is None else adaptive["share"]))}
-            key_f = ("lift_splat_forward_tile" if tiles else ("lift_splat_forward_camera" if camera else "lift_splat_forward")) + sfx
+            key_f = ("lift_splat_forward_plan" if plan else "lift_splat_forward_tile" if tiles else ("lift_splat_forward_camera" if camera else "lift_splat_forward")) + sfx
             key_b = ("lift_splat_backward_tile" if tiles else (("lift_splat_backward_column" if column else "lift_splat_backward") + ("_camera" if camera else ""))) + sfx
             # the timed sequence of the forward is the zero fill + the kernel: so is its traffic
-            res["roofline"] = roofline_entry(f"lss_zero_fill + {kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
-                                             pmc_traffic(args.config, (key_f, "lss_zero_fill")), l2f, note)
+            if plan:
+                res["roofline"] = roofline_entry(f"{kfwd}{sfx} (fused lift-splat forward, plan form = the step's voxel_pooling forward)", fbytes, fwd_ms,
+                                                 pmc_traffic(args.config, (key_f,)), l2f, note)
+                if timing.get("lift_splat_plan_prepare"):
+                    res["roofline"]["prepare"] = {"kernels": "lss_plan_probe + lss_plan_build", "avg_ms": _lib.mean_ms(timing["lift_splat_plan_prepare"]),
+                                                  "note": "per step, issued in front of the image backbone (not in front of the forward kernel)"}
+            else:
+                res["roofline"] = roofline_entry(f"lss_zero_fill + {kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
+                                                 pmc_traffic(args.config, (key_f, "lss_zero_fill")), l2f, note)
             atomic_bytes = None
             try:
-                newest = [r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_{args.config}.json"))][0]
+                newest = [r for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_{args.config}.json"))][0]
                 atomic_bytes = float(json.load(open(os.path.join(ROOT, "profiles", f"{newest}_pmc_{args.config}.json")))["kernels"][key_f]["atomic_bytes"])
             except Exception:
                 pass
-            if atomic_bytes:
+            if atomic_bytes and not plan:
                 ab = atomic_bytes / (fwd_ms * 1e-3) / 1e9
                 res["roofline"]["atomic_side"] = {"bytes": atomic_bytes, "achieved": ab, "peak": ATOMIC_PEAK_GBS, "unit": "GB/s", "frac": ab / ATOMIC_PEAK_GBS,
                                                   "note": "TCC_EA0_ATOMIC x 64 B per launch (PMC pass) against the chip-wide memory-side fp32 atomic rate"}

@@ -18,6 +18,9 @@ COMMON_HEADS = dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2
 
 
 def make_config(name="cfg2"):
+    tiny64 = name == "tiny64"        # "tiny" with 64 camera channels: the narrowest width the camera-form / plan-form kernels take
+    if tiny64:
+        name = "tiny"
     tiny = name == "tiny"
     use_cam = name in ("cfg2", "cfg4", "cfg5", "tiny")
     use_lidar = name in ("cfg3", "cfg4", "cfg5", "tiny")
@@ -30,7 +33,7 @@ def make_config(name="cfg2"):
     cam_channels = 80 if use_cam else 0
     lidar_channels = 64 if use_lidar else 0
     if tiny:
-        cam_channels, lidar_channels = 16, 8
+        cam_channels, lidar_channels = (64 if tiny64 else 16), 8
     fuse_channels = cam_channels + lidar_channels
     grid = [int(round((pc_range[3] - pc_range[0]) / voxel_size[0])), int(round((pc_range[4] - pc_range[1]) / voxel_size[1]))]
 

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from ...ops.bev_geometry import (camera_form_supported, depth_softmax, exclusive_cache_used, frustum_axes, frustum_geometry, lift_features, lift_splat,
-                                 lift_splat_camera, new_column_summary, new_exclusive_cache)
+                                 lift_splat_camera, lift_splat_plan, new_column_summary, new_exclusive_cache, new_plan_cache, plan_form_supported, plan_prepare)
 from ...ops.bn_relu import ConvBNAct, bn_act
 from ...ops.voxel_pooling import VoxelPoolingPlan, voxel_pooling, voxel_pooling_bf16, voxel_pooling_planned
 from ..nets import BasicBlock, DeformConv2dPack, ResNet, SECONDFPN
@@ -153,6 +153,17 @@ class LSSFPN(nn.Module):
         # MMT_LSS_EXCL_SLOTS calibrations (default 1024: 64 MiB on a 128 x 128 map), 0 switches it off.
         self._excl_caches = {}
         self.exclusive_slots = int(os.environ.get("MMT_LSS_EXCL_SLOTS", "1024"))
+        # True (default): the camera-form FORWARD runs in its plan form (ops/bev_geometry.py::lift_splat_plan, csrc/lift_splat_plan.hip):
+        # output-stationary on a per-calibration plan the library learns on the device -- no zero fill, no atomics, every element
+        # of the map written once, bit-identical from step to step.  The lookup of the batch's calibrations (mmt_lss_plan_prepare)
+        # depends on the matrices only and is issued at the top of the sweep, in front of the image backbone.  Plan caches,
+        # (device, cameras, stream) -> uint8 tensor, MMT_LSS_PLAN_SLOTS calibrations each (default 16, at least the batch size);
+        # MMT_LSS_PLAN=0 keeps the ray walks.  A rig whose plans do not fit (served by the kernel's slow brute-force path) is
+        # noticed through the cache's counters, read back lazily, and sent back to the ray walks.
+        self.plan_form = os.environ.get("MMT_LSS_PLAN", "1") != "0"
+        self.plan_slots = int(os.environ.get("MMT_LSS_PLAN_SLOTS", "16"))
+        self._plan_caches = {}
+        self._plan_watch = None
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
         self.register_buffer('voxel_size', torch.Tensor([row[2] for row in rows]))
@@ -191,6 +202,10 @@ class LSSFPN(nn.Module):
         if axes is not None:
             self.frustum_u, self.frustum_v, self.frustum_d = (t.clone() for t in axes)
         self.depth_channels = fr.shape[0]
+        # what was derived from the old frustum per calibration must not be served for the new one (the plan caches need no
+        # clearing: the library signs them with the axes' contents and empties them itself)
+        self._summary_cache.clear(); self._plan_cache.clear(); self._column_backward_choice.clear(); self._excl_caches.clear()
+        self._column_adaptive = None
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
@@ -253,6 +268,62 @@ class LSSFPN(nn.Module):
             slots = max(16, min(self.exclusive_slots, (256 << 20) // max(4 * nx * ny, 1)))
             cache = self._excl_caches[key] = new_exclusive_cache(num_cams, self._voxel_num_host, device, slots)
         return cache
+
+    def _plan_cache_for(self, batch_size, num_cams, fH, fW, device):
+        """The plan cache of this (device, cameras, stream), or None: plan form off, a shape it does not take, or a capture is
+        running and the cache does not exist yet (it must outlive the graph's pool: warm up eagerly first)."""
+        if not self.plan_form or not plan_form_supported(batch_size, num_cams, self.depth_channels, fH, fW, self.output_channels, self._voxel_num_host):
+            return None
+        key = (str(device), int(num_cams), torch.cuda.current_stream(device).cuda_stream)      # calls sharing a cache are stream-ordered
+        cache = self._plan_caches.get(key)
+        if cache is not None and getattr(cache, "_mmt_slots", 0) < batch_size:
+            cache = None                                   # (a larger batch than the cache was sized for)
+        if cache is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            if len(self._plan_caches) >= 4:
+                self._plan_caches.pop(next(iter(self._plan_caches)))
+            slots = max(int(self.plan_slots), int(batch_size), 2)
+            cache = self._plan_caches[key] = new_plan_cache(num_cams, self.depth_channels, fH, fW, self._voxel_num_host, device, slots)
+            cache._mmt_slots = slots
+        return cache
+
+    def plan_cache_counters(self):
+        """dict(hit, learnt, brute, resets, calls, slots) summed over this module's plan caches (synchronises: outside timed regions)."""
+        from mm_training_amd.ops.bev_geometry import plan_cache_counters
+        tot = dict(hit=0, learnt=0, brute=0, resets=0, calls=0, slots=0)
+        for cache in self._plan_caches.values():
+            for k, v in plan_cache_counters(cache).items():
+                tot[k] += v
+        return tot
+
+    def _watch_plan_cache(self, cache):
+        """Lazy read-back of the plan cache's header (an asynchronous copy polled on later calls, no synchronisation): when samples
+        keep being served by the brute-force path -- a rig whose plans overflow their slots -- the module goes back to the ray
+        walks, which take any geometry at their own speed."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        w = self._plan_watch
+        if w is None or w["dev"] != cache.device:
+            w = self._plan_watch = dict(dev=cache.device, host=torch.zeros(64, dtype=torch.uint8).pin_memory(), event=torch.cuda.Event(),
+                                        pending=False, calls=0, last=None, strikes=0)
+        if w["pending"] and w["event"].query():
+            words = w["host"].view(torch.int32)
+            brute, calls = int(words[10]), int(words[12])           # CacheHeader: hits [8], built [9], brute [10], resets [11], calls [12]
+            if w["last"] is not None and calls > w["last"][1]:
+                w["strikes"] = w["strikes"] + 1 if brute > w["last"][0] else 0
+                if w["strikes"] >= 2:
+                    import warnings
+                    warnings.warn("LSSFPN: the plan form keeps serving calibrations through its brute-force path (their plans overflow the "
+                                  "cache's slots); falling back to the ray-walk forward")
+                    self.plan_form = False
+            w["last"], w["pending"] = (brute, calls), False
+        w["calls"] += 1
+        if not w["pending"] and w["calls"] % 16 == 0:
+            off = (-cache.data_ptr()) % 256
+            w["host"].copy_(cache[off:off + 64], non_blocking=True)
+            w["event"].record()
+            w["pending"] = True
 
     def exclusive_cache_counters(self):
         """(hits, learning calls, misses) summed over this module's exclusive-cell caches: per sample and forward call, whether
@@ -329,6 +400,21 @@ class LSSFPN(nn.Module):
 
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, depth_oracle, is_return_depth=False):
         batch_size, num_sweeps, num_cams = sweep_imgs.shape[:3]
+        # plan form of the fused forward: its lookup of the batch's calibrations depends on the matrices only -- issue it now, in
+        # front of the image backbone, so that the forward kernel finds the verdicts ready
+        plan_cache = plan_combine = None
+        if (self.fused_lift_splat and self.camera_form and self._has_frustum_axes and self.plan_form and isinstance(mats_dict, dict)
+                and os.environ.get("MMT_LIFT_SPLAT_TILES", "0") != "1" and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"):
+            fH_, fW_ = self.frustum_v.numel(), self.frustum_u.numel()
+            if camera_form_supported(batch_size, num_cams, self.depth_channels, fH_, fW_, self.output_channels):
+                plan_cache = self._plan_cache_for(batch_size, num_cams, fH_, fW_, sweep_imgs.device)
+            if plan_cache is not None:
+                calib0 = mats_dict.get('calibration_id', None)
+                ckey0 = None if calib0 is None else (calib0, sweep_index, batch_size, num_cams, str(sweep_imgs.device))
+                plan_combine = self.camera_matrices(mats_dict['sensor2ego_mats'][:, sweep_index, ...], mats_dict['intrin_mats'][:, sweep_index, ...], ckey0)
+                plan_prepare(plan_combine, (self.frustum_u, self.frustum_v, self.frustum_d), self._voxel_num_host, self._voxel_coord_host,
+                             self._voxel_size_host, plan_cache)
+                self._watch_plan_cache(plan_cache)
         img_feats = self.get_cam_feats(sweep_imgs)
         # the key frame (:389): every caller hands over ONE sweep here (forward slices sweep_imgs[:, k:k+1]); squeezing that axis is
         # a view in both directions, while `img_feats[:, 0]` costs the backward a zero-fill + a strided copy of the whole neck
@@ -382,8 +468,8 @@ class LSSFPN(nn.Module):
             fH, fW = context.shape[-2:]
             pixel_major_ok = fH <= 512 and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"
             ckey = None if calib_id is None else (calib_id, sweep_index, batch_size, num_cams, str(context.device))
-            combine = self.camera_matrices(mats_dict['sensor2ego_mats'][:, sweep_index, ...],
-                                           mats_dict['intrin_mats'][:, sweep_index, ...], ckey)
+            combine = plan_combine if plan_combine is not None else self.camera_matrices(
+                mats_dict['sensor2ego_mats'][:, sweep_index, ...], mats_dict['intrin_mats'][:, sweep_index, ...], ckey)
             if (self.camera_form and self._has_frustum_axes and pixel_major_ok and os.environ.get("MMT_LIFT_SPLAT_TILES", "0") != "1"
                     and camera_form_supported(batch_size, num_cams, self.depth_channels, fH, fW, self.output_channels)):
                 fused_kind = "camera"
@@ -399,6 +485,11 @@ class LSSFPN(nn.Module):
             if fused_kind == "camera":
                 col_bwd, stats = self._use_column_backward(
                     lambda: self.get_geometry_voxels(None, None, pixel_major=True, combine=combine), calib_id, context.device)
+                if plan_cache is not None and tuple(context.shape[-2:]) == (self.frustum_v.numel(), self.frustum_u.numel()):
+                    feature_map = lift_splat_plan(combine, (self.frustum_u, self.frustum_v, self.frustum_d), dep_in, ctx_in, self._voxel_num_host,
+                                                  self._voxel_coord_host, self._voxel_size_host, plan_cache, prepared=True,
+                                                  column_backward=col_bwd, column_stats=stats)
+                    return (feature_map, depth) if is_return_depth else feature_map
                 # with a calibration id the geometry's column summary is kept too: later forwards read 0.5 byte per point
                 # instead of computing the cells (without one every forward writes a fresh summary for its backward)
                 summary, cached, keep = None, False, False

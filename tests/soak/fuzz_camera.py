@@ -17,7 +17,8 @@ import torch
 
 from mm_training_amd import synthetic
 from mm_training_amd.ops.bev_geometry import (camera_form_supported, frustum_axes, frustum_geometry, last_kernel_family, lift_splat,
-                                              lift_splat_camera, new_exclusive_cache)
+                                              lift_splat_camera, lift_splat_plan, new_exclusive_cache, new_plan_cache, plan_cache_counters,
+                                              plan_form_supported)
 from tests.test_oracle_golden import _frustum_torch
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -40,7 +41,7 @@ def rot(axis, deg):
     return m
 
 
-it = calls = used = 0
+it = calls = used = plan_calls = plan_brute = 0
 while time.time() < t_end:
     it += 1
     N = int(rng.integers(1, 7))
@@ -69,6 +70,7 @@ while time.time() < t_end:
         pool.append(s2e.matmul(tilt).matmul(roll).matmul(torch.inverse(K)).contiguous())
     slots = int(rng.integers(1, 5))
     cache = new_exclusive_cache(N, vn, "cuda", slots)
+    pcache = new_plan_cache(N, D, fH, fW, vn, "cuda", slots=B + int(rng.integers(0, 2))) if plan_form_supported(B, N, D, fH, fW, C, vn) else None
     column = bool(rng.random() < 0.5)
     cfg = dict(it=it, seed=seed, B=B, N=N, D=D, fH=fH, fW=fW, C=C, grid=vn, vs=vs, pool=len(pool), slots=slots, column=column)
     for call in range(int(rng.integers(3, 9))):
@@ -99,7 +101,25 @@ while time.time() < t_end:
             fail("grad_depth (call %d)" % call, cfg)
         if not torch.allclose(c1.grad, c2.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(c2.grad.abs().max()))):
             fail("grad_context (call %d)" % call, cfg)
+        if pcache is not None:
+            brute = bool(rng.random() < 0.1)
+            d3, c3 = depth.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+            o3 = lift_splat_plan(cb, axes, d3, c3, vn, vc, vs, pcache, column_backward=column, brute=brute)
+            if last_kernel_family() != "plan+camera":
+                fail("plan form: family %s" % last_kernel_family(), cfg)
+            if float((o3 - o2).abs().max()) > 1e-4 * scale or not torch.equal((o3 != 0).any(1), (o2 != 0).any(1)):
+                fail("plan forward (call %d, picks %s, brute %s, counters %s): max diff %g of scale %g, %d cells differ in being zero"
+                     % (call, pick, brute, plan_cache_counters(pcache), float((o3 - o2).abs().max()), scale, int(((o3 != 0).any(1) != (o2 != 0).any(1)).sum())), cfg)
+            o3b = lift_splat_plan(cb, axes, depth, ctx, vn, vc, vs, pcache, brute=brute)
+            if not torch.equal(o3b, o3.detach()):
+                fail("plan forward not bit-identical on repeat (call %d, brute %s)" % (call, brute), cfg)
+            o3.backward(go)
+            if not (torch.equal(d3.grad, d1.grad) and torch.equal(c3.grad, c1.grad)):
+                fail("plan form: gradients differ from the camera form's (call %d)" % call, cfg)
+            plan_calls += 1
+            plan_brute += int(brute)
         calls += 1
         if "exclusive" in fam:
             used += int(3 in cache[24:24 + min(B, 8)].tolist())
-print("fuzz ok:", it, "shapes,", calls, "calls of the camera form against the geom form;", used, "of them stored single-run cells")
+print("fuzz ok:", it, "shapes,", calls, "calls of the camera form against the geom form;", used, "of them stored single-run cells;",
+      plan_calls, "calls of the plan form (", plan_brute, "through its brute-force path )")

@@ -69,8 +69,7 @@ def test_bench_reports_a_rank_that_dies_instead_of_hanging(mmt_lib):
 
 def test_bench_two_ranks_at_a_baseline_camera_shape(mmt_lib):
     """BASELINE configs[1] (camera BEVDepth R50, 6 x 256 x 704, C = 80) with two ranks on the one card: each rank runs the
-    step's own kernels -- camera form, register walk, exclusive-cell cache (one cache per process) -- side by side with the
-    other's, long enough for both caches to reach their steady state."""
+    step's own kernels -- camera form, plan-form forward (one plan cache per process) -- side by side with the other's."""
     out, _ = _run(None, "--gpus", "2", "--config", "cfg2", "--steps", "4", "--warmup", "9", "--no-cpu-baseline", timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -80,7 +79,7 @@ def test_bench_two_ranks_at_a_baseline_camera_shape(mmt_lib):
     assert d["n_gpus"] == 2 and c["parallelism"] == "dp2" and c["global_batch"] == 8
     assert c["final_loss"] == c["final_loss"] and abs(c["final_loss"]) < 1e6
     k = c["lift_splat_kernels"]
-    assert k["forward"] == "ray+camera+register+exclusive" and k["backward"].endswith("+camera") and k["exclusive_cell_cache"].startswith("on")
+    assert k["forward"] == "plan+camera" and k["backward"].endswith("+camera") and k["plan_form"].startswith("on") and "'brute': 0" in k["plan_form"]
     # (two processes time-slice the one card, each with its main stream and the task heads' two streams: a dispatch-attached
     # event pair may span the other rank's time slice -- 212 ms was seen once -- so there is no bound on speed here)
     assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline"]["avg_ms"] < 5000.0

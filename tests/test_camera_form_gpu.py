@@ -297,7 +297,14 @@ def test_lssfpn_camera_form_is_the_default_and_runs_no_geometry_kernel(mmt_lib, 
         bev.square().mean().backward()
         return bev.detach().clone(), m.depth_net.context_conv.weight.grad.detach().clone(), list(calls)
 
+    assert m.plan_form
+    bev_p, g_p, calls_p = run(True, mats)                                  # the default: camera form, its forward in the plan form
+    assert "mmt_lss_splat_forward_plan" in calls_p and "mmt_lss_plan_prepare" in calls_p and "mmt_lss_splat_backward_cam" in calls_p
+    assert calls_p.index("mmt_lss_plan_prepare") == 0 and "mmt_frustum_geometry" not in calls_p     # the lookup goes first, in front of the nets
+    m.plan_form = False
     bev_c, g_c, calls_c = run(True, mats)
+    assert (bev_p - bev_c).abs().max().item() <= 1e-5 * max(1.0, bev_c.abs().max().item())
+    assert (g_p - g_c).abs().max().item() <= 1e-3 * g_c.abs().max().item() + 1e-7
     bev_g, g_g, calls_g = run(False, mats)
     assert "mmt_lss_splat_forward_cam" in calls_c and "mmt_lss_splat_backward_cam" in calls_c
     assert "mmt_frustum_geometry" not in calls_c and "mmt_frustum_geometry" in calls_g

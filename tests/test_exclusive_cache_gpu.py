@@ -285,6 +285,7 @@ def test_training_lssfpn_with_and_without_the_cache(mmt_lib, monkeypatch):
         monkeypatch.setenv("MMT_LSS_EXCL_SLOTS", slots)
         torch.manual_seed(0)
         m = LSSFPN(**bc).cuda().train()
+        m.plan_form = False                    # (the ray-walk forward is what takes the exclusive-cell cache; the default is the plan form)
         assert m.exclusive_slots == int(slots)
         opt = torch.optim.SGD(m.parameters(), lr=1e-2)
         losses = []

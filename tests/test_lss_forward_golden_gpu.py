@@ -33,14 +33,16 @@ def _mirror(g):
     return m
 
 
-@pytest.mark.parametrize("path", ["camera", "geom", "unfused"])
+@pytest.mark.parametrize("path", ["plan", "camera", "geom", "unfused"])
 @pytest.mark.parametrize("case", ["flip", "oracle", "single"])
 def test_lssfpn_branches_match_the_reference_forward(mmt_lib, golden, case, path):
     from mm_training_amd import _lib
     g = golden["lss_forward"]
     m = _mirror(g)
-    assert m.fused_lift_splat and m.camera_form
-    if path == "geom":
+    assert m.fused_lift_splat and m.camera_form and m.plan_form         # the default: the camera form's forward in its plan form
+    if path == "camera":
+        m.plan_form = False
+    elif path == "geom":
         m.camera_form = False
     elif path == "unfused":
         m.fused_lift_splat = False
@@ -58,7 +60,7 @@ def test_lssfpn_branches_match_the_reference_forward(mmt_lib, golden, case, path
         bev, depth = m(imgs, mats, oracle_depth, None, is_return_depth=True)
     finally:
         _lib.call = real
-    want = {"camera": "mmt_lss_splat_forward_cam", "geom": "mmt_lss_splat_forward", "unfused": "mmt_voxel_pooling_forward_ex"}[path]
+    want = {"plan": "mmt_lss_splat_forward_plan", "camera": "mmt_lss_splat_forward_cam", "geom": "mmt_lss_splat_forward", "unfused": "mmt_voxel_pooling_forward_ex"}[path]
     assert want in calls, calls
     ref_bev, ref_depth = g[case + "_bev"], g[case + "_depth"]
     assert tuple(bev.shape) == ref_bev.shape and tuple(depth.shape) == ref_depth.shape
