@@ -156,7 +156,7 @@ PLAN_HD int plan_atomic_inc(int32_t *p) { return (*p)++; }
 // summary: int32 pairs [strips * D] of ONE sample (mmt_camera.h `column summary`): [0] = (y << 16 | x) of the block's first
 // row or -1, [1] = z mask | kSummaryUniformBit.  A block without the bit is MIXED: rc(strip, bin, row) gives the packed cell
 // of each of its rows (or -1 outside the grid) and the block yields one single-bin run per distinct cell.
-// sink(col, rb, d0, len, packed_cell, masks)
+// sink(col, rb, d0, len, packed_cell, masks) -- masks: the run's (up to) four 16-bit row masks packed into 64 bits, first bin lowest
 template <class RowCells, class Sink>
 PLAN_HD void emit_strip(const Dims &d, const int32_t *summary, int s, RowCells &rc, Sink &sink) {
     const int w = s % d.fW, rb = (s / d.fW) % d.nb, n = s / (d.fW * d.nb);
@@ -164,7 +164,7 @@ PLAN_HD void emit_strip(const Dims &d, const int32_t *summary, int s, RowCells &
     int cur = -1, cur_d0 = 0, cur_len = 0;
     uint16_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
     auto flush = [&]() {
-        if (cur >= 0 && cur_len > 0) { const uint16_t mm[kRunBins] = {m0, m1, m2, m3}; sink(col, rb, cur_d0, cur_len, cur, mm); }
+        if (cur >= 0 && cur_len > 0) sink(col, rb, cur_d0, cur_len, cur, (uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32) | ((uint64_t)m3 << 48));
         cur = -1; cur_len = 0; m0 = m1 = m2 = m3 = 0;
     };
     for (int bin = 0; bin < d.D; ++bin) {
@@ -191,8 +191,7 @@ PLAN_HD void emit_strip(const Dims &d, const int32_t *summary, int s, RowCells &
 #pragma unroll
                     for (int j = 0; j < 16; ++j) m |= (j >= i && ((left >> j) & 1u) && cells[j] == cells[i]) ? (1u << j) : 0u;
                     left &= ~m;
-                    const uint16_t mm[kRunBins] = {(uint16_t)m, 0, 0, 0};
-                    sink(col, rb, bin, 1, cells[i], mm);
+                    sink(col, rb, bin, 1, cells[i], (uint64_t)(m & 0xFFFFu));
                 }
             }
         }
@@ -210,7 +209,7 @@ PLAN_HD void phase_clear(const Dims &d, Scratch &s, int tid, int nt) {
 template <class RowCells>
 PLAN_HD void phase_count(const Dims &d, Scratch &s, const int32_t *summary, RowCells &rc, int tid, int nt) {
     for (int st = tid; st < d.strips; st += nt) {
-        auto sink = [&](int, int, int, int, int cell, const uint16_t *) { plan_atomic_inc(&s.cell_off[cell_tm(d, cell & 0xFFFF, cell >> 16)]); };
+        auto sink = [&](int, int, int, int, int cell, uint64_t) { plan_atomic_inc(&s.cell_off[cell_tm(d, cell & 0xFFFF, cell >> 16)]); };
         emit_strip(d, summary, st, rc, sink);
     }
 }
@@ -244,7 +243,7 @@ PLAN_HD void phase_check_runs(const Dims &d, Scratch &s, int tid) {
 template <class RowCells>
 PLAN_HD void phase_place(const Dims &d, Scratch &s, const int32_t *summary, RowCells &rc, int tid, int nt) {
     for (int st = tid; st < d.strips; st += nt) {
-        auto sink = [&](int col, int rb, int d0, int len, int cell, const uint16_t *mm) {
+        auto sink = [&](int col, int rb, int d0, int len, int cell, uint64_t mm) {
             const int c = cell_tm(d, cell & 0xFFFF, cell >> 16);
             const int pos = s.cell_off[c] + plan_atomic_inc(&s.cursor[c]);
             // the kernel loads the kRunBins depths [d0 - sh, d0 - sh + kRunBins) of every row: a run near the end of the ray is
@@ -253,8 +252,8 @@ PLAN_HD void phase_place(const Dims &d, Scratch &s, const int32_t *summary, RowC
             RunTmp r;
             r.cell_len = (uint32_t)c | ((uint32_t)(len + sh - 1) << 28) | ((uint32_t)sh << 30);
             r.key = ((uint32_t)col << 16) | ((uint32_t)rb << 11) | (uint32_t)d0;
-            r.mask[0] = r.mask[1] = r.mask[2] = r.mask[3] = 0;
-            for (int j = 0; j < kRunBins; ++j) if (j + sh < kRunBins) r.mask[j + sh] = mm[j];
+            const uint64_t ms = mm << (16 * sh);          // (sh <= 3; the bins shifted out are past the run's length: zero masks)
+            r.mask[0] = (uint16_t)ms; r.mask[1] = (uint16_t)(ms >> 16); r.mask[2] = (uint16_t)(ms >> 32); r.mask[3] = (uint16_t)(ms >> 48);
             s.runs[pos] = r;
         };
         emit_strip(d, summary, st, rc, sink);

@@ -268,9 +268,10 @@ extern "C" int mmt_normalize_flip_images(int64_t n_images, int channels_in, int 
 // (get_targets_single: a Python loop over tasks and boxes with per-box tensor construction and
 // mmdet3d's gaussian_radius / draw_heatmap_gaussian).  One workgroup per (box, sample): the box's
 // Gaussian window is max-combined into its class heat-map with an integer atomicMax on the float
-// bits (values are >= 0), lane 0 writes the regression target row.  Slot convention: box k of a
-// sample occupies slot k in the targets of the task that owns its class (the reference packs
-// each task's boxes densely; the loss sums over masked slots only, so the order is immaterial).
+// bits (values are >= 0), lane 0 writes the regression target row.  Slots as in the reference: a task's
+// boxes densely, class after class, each class in input order; the first max_objs of them (round 5: pinned by
+// tests/golden/centerpoint_targets.npz, produced by the reference's own lines -- rounds 1-4 kept box k at slot k and
+// cut the SAMPLE at max_objs, which differs once a sample holds more boxes than that).
 namespace {
 
 constexpr int kMaxTasks = 8;
@@ -314,8 +315,7 @@ __device__ __forceinline__ float cp_gaussian_radius(float h, float w, float o) {
 __global__ __launch_bounds__(64) void cp_draw_kernel(CpArgs a) {
     const int b = blockIdx.y, k = blockIdx.x;
     const int beg = a.offsets[b];
-    int nk = a.offsets[b + 1] - beg;
-    if (nk > a.max_objs) nk = a.max_objs;                       // bev_depth_head.py:171
+    const int nk = a.offsets[b + 1] - beg;
     if (k >= nk) return;
     const float *box = a.boxes + (int64_t)(beg + k) * 9;
     const int label = a.labels[beg + k];
@@ -324,6 +324,19 @@ __global__ __launch_bounds__(64) void cp_draw_kernel(CpArgs a) {
         if (label >= a.cls_begin[i] && label < a.cls_begin[i] + a.cls_count[i]) t = i;
     if (t < 0) return;
     const int cls = label - a.cls_begin[t];
+    // the box's slot: its place among the task's boxes in the reference's order -- class after class, inside a class in input order
+    // (:141-163: task_boxes = cat over the task's classes) -- and a task takes its first max_objs boxes only (:171)
+    int rank = 0;
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+        const int j = j0 + (int)threadIdx.x;
+        bool before = false;
+        if (j < nk) {
+            const int cj = a.labels[beg + j] - a.cls_begin[t];
+            before = cj >= 0 && cj < a.cls_count[t] && (cj < cls || (cj == cls && j < k));
+        }
+        rank += __popcll(__ballot(before));
+    }
+    if (rank >= a.max_objs) return;
     const float width = box[3] / a.vx / a.osf, length = box[4] / a.vy / a.osf;      // :176-181
     if (!(width > 0.f && length > 0.f)) return;                                     // :183
     float rf = cp_gaussian_radius(length, width, a.overlap);                        // :184-186
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(64) void cp_draw_kernel(CpArgs a) {
         atomicMax(reinterpret_cast<unsigned int *>(hm + (int64_t)(yi + dy) * a.fx + xi + dx), __float_as_uint(g));
     }
     if (threadIdx.x == 0) {
-        const int64_t slot = (int64_t)b * a.max_objs + k;
+        const int64_t slot = (int64_t)b * a.max_objs + rank;
         a.ind[t][slot] = (int64_t)yi * a.fx + xi;                                   // :218
         a.mask[t][slot] = 1;
         float *row = a.anno[t] + slot * 10;                                         // :220-234
@@ -404,7 +417,8 @@ extern "C" int mmt_centerpoint_targets(int B, int num_tasks, const int32_t *clas
     const int64_t biggest = (int64_t)B * max_cls * fy * fx;
     hipLaunchKernelGGL(cp_clear_kernel, dim3(mmt::stream_grid(biggest, kBlock, 1024), num_tasks), dim3(kBlock), 0, st, a);
     if (int rc = mmt::check_launch("centerpoint_targets(clear)")) return rc;
-    const int nb = max_boxes < max_objs ? max_boxes : max_objs;
+    const int nb = max_boxes;                 // (every box looks for its slot: a task keeps ITS first max_objs boxes, whatever their index in the sample)
+    if (nb > 65535 * 64) return mmt::fail(MMT_ERR_TOO_LARGE, "centerpoint_targets: %d boxes in one sample", nb);
     if (nb > 0) {
         hipLaunchKernelGGL(cp_draw_kernel, dim3(nb, B), dim3(64), 0, st, a);
         return mmt::check_launch("centerpoint_targets(draw)");

@@ -301,7 +301,7 @@ class LSSFPN(nn.Module):
         """Lazy read-back of the plan cache's header (an asynchronous copy polled on later calls, no synchronisation): when samples
         keep being served by the brute-force path -- a rig whose plans overflow their slots -- the module goes back to the ray
         walks, which take any geometry at their own speed."""
-        if torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("MMT_LSS_PLAN_WATCH", "1") == "0":
             return
         w = self._plan_watch
         if w is None or w["dev"] != cache.device:

@@ -190,10 +190,9 @@ class BEVDepthHead(nn.Module):
 
     @torch.no_grad()
     def get_targets_single(self, boxes, labels):
-        """Vectorised and free of host synchronisation: every task looks at ALL K boxes of the
-        sample and masks the ones of other tasks (the reference packs each task's boxes densely
-        at the front of its max_objs slots, bev_depth_head.py:142-163,186-248; the loss only sums
-        over masked slots, so the slot order is immaterial)."""
+        """Vectorised and free of host synchronisation: every task looks at ALL K boxes of the sample, ranks its own in the
+        reference's order (class after class, input order inside a class: bev_depth_head.py:142-163) and keeps the first
+        max_objs of them at their rank (:171,186-248) -- the reference's slots (tests/golden/centerpoint_targets.npz)."""
         cfg = self.train_cfg
         dev = boxes.device
         max_objs = cfg['max_objs'] * cfg['dense_reg']
@@ -202,8 +201,7 @@ class BEVDepthHead(nn.Module):
         fy = int(cfg['grid_size'][1]) // osf
         pc = cfg['point_cloud_range']
         vs = cfg['voxel_size']
-        boxes = boxes[:max_objs]
-        labels = labels[:max_objs].long()
+        labels = labels.long()
         K = boxes.shape[0]
         heatmaps, anno_boxes, inds, masks = [], [], [], []
         if K > 0:
@@ -235,12 +233,23 @@ class BEVDepthHead(nn.Module):
             ind = torch.zeros((max_objs,), dtype=torch.int64, device=dev)
             mask = torch.zeros((max_objs,), dtype=torch.uint8, device=dev)
             if K > 0:
-                valid = in_map & (labels >= flag) & (labels < flag + n_cls)
+                # the reference's slots (:141-163, :171): a task's boxes densely, class after class, each class in input order; its first
+                # max_objs boxes only.  A kept box that is not drawn (outside the map, zero size) leaves its slot empty.
+                in_task = (labels >= flag) & (labels < flag + n_cls)
                 cls = (labels - flag).clamp(0, n_cls - 1)
+                key = torch.where(in_task, cls * K + torch.arange(K, device=dev), torch.full_like(cls, n_cls * K))
+                rank = torch.empty_like(key)
+                rank[key.argsort()] = torch.arange(K, device=dev)
+                valid = in_map & in_task & (rank < max_objs)
+                slot = torch.where(valid, rank, torch.full_like(rank, max_objs))          # (invalid boxes write to a scratch row)
                 heatmap.index_reduce_(0, cls, gauss * valid.view(K, 1, 1), 'amax', include_self=True)
-                ind[:K] = torch.where(valid, ind_all, torch.zeros_like(ind_all))
-                mask[:K] = valid.to(torch.uint8)
-                anno[:K] = anno_all * valid.view(K, 1)
+                ind_x = torch.zeros((max_objs + 1,), dtype=torch.int64, device=dev)
+                mask_x = torch.zeros((max_objs + 1,), dtype=torch.uint8, device=dev)
+                anno_x = torch.zeros((max_objs + 1, 10), device=dev)
+                ind_x[slot] = ind_all
+                mask_x[slot] = 1
+                anno_x[slot] = anno_all
+                ind, mask, anno = ind_x[:max_objs], mask_x[:max_objs], anno_x[:max_objs]
             flag += n_cls
             heatmaps.append(heatmap)
             anno_boxes.append(anno)

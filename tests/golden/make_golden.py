@@ -23,6 +23,10 @@ What is executed from the reference:
     oracle depth, two sweeps -- with the conv nets replaced by the identity (lss_forward.npz).
   * exps/mm_training_aim.py augment_images (:88-112) and normalize_images (:510-512), exec'd as plain functions with a
     seeded numpy generator (augment_images.npz).
+  * layers/heads/bev_depth_head.py get_targets_single (:113-254) and loss (:256-312), exps/mm_training_aim.py get_depth_loss
+    (:165-178), exec'd from the files' text on CPU tensors with the un-vendored mmdet / mmdet3d callables they use supplied by
+    their published formulas; models/bev_depth.py BEVFuseLayer (:133-145) imported as it is (centerpoint_targets.npz,
+    head_loss.npz, depth_loss.npz, fuse_layer.npz).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -564,6 +568,189 @@ def make_augment_images():
     print("augment_images: flips", flips.astype(int).tolist(), "images", tuple(imgs_t.shape), "labels", tuple(labels_t.shape))
 
 
+
+# ---- stand-ins for the third-party callables of the CenterPoint head (mmdet3d 1.0.0rc4 / mmdet 2.25.1, un-vendored: README.md:19-27),
+# by their published definitions -- the reference's own lines call them, so the fixtures pin the reference's regrouping, packing,
+# masking and normaliser arithmetic around them (like `hflip` / `Normalize` in make_augment_images)
+def _gaussian_radius(det_size, min_overlap=0.5):
+    """mmdet3d.core.utils.gaussian.gaussian_radius (CornerNet's three quadratic bounds on tensors)."""
+    height, width = det_size
+    a1, b1, c1 = 1, (height + width), width * height * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 + torch.sqrt(b1 ** 2 - 4 * a1 * c1)) / 2
+    a2, b2, c2 = 4, 2 * (height + width), (1 - min_overlap) * width * height
+    r2 = (b2 + torch.sqrt(b2 ** 2 - 4 * a2 * c2)) / 2
+    a3, b3, c3 = 4 * min_overlap, -2 * min_overlap * (height + width), (min_overlap - 1) * width * height
+    r3 = (b3 + torch.sqrt(b3 ** 2 - 4 * a3 * c3)) / 2
+    return min(r1, r2, r3)
+
+
+def _gaussian_2d(shape, sigma=1):
+    m, n = [(ss - 1.) / 2. for ss in shape]
+    y, x = np.ogrid[-m:m + 1, -n:n + 1]
+    h = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    return h
+
+
+def _draw_heatmap_gaussian(heatmap, center, radius, k=1):
+    """mmdet3d.core.utils.gaussian.draw_heatmap_gaussian: a (2r+1)^2 float64 window, sigma = (2r+1)/6, max-combined in place."""
+    diameter = 2 * radius + 1
+    gaussian = _gaussian_2d((diameter, diameter), sigma=diameter / 6)
+    x, y = int(center[0]), int(center[1])
+    height, width = heatmap.shape[0:2]
+    left, right = min(x, radius), min(width - x, radius + 1)
+    top, bottom = min(y, radius), min(height - y, radius + 1)
+    masked_heatmap = heatmap[y - top:y + bottom, x - left:x + right]
+    masked_gaussian = torch.from_numpy(gaussian[radius - top:radius + bottom, radius - left:radius + right]).to(heatmap.device, torch.float32)
+    if min(masked_gaussian.shape) > 0 and min(masked_heatmap.shape) > 0:
+        torch.max(masked_heatmap, masked_gaussian * k, out=masked_heatmap)
+    return heatmap
+
+
+def _head_cases():
+    """(name, class_names per task, feature map, out_size_factor, max_objs, boxes per sample) of the CenterPoint fixtures"""
+    return [("aim", [['car'], ['truck/bus'], ['motorcycle'], ['pedestrian']], (128, 128), 4, 500, (40, 0, 7)),      # exps/conf_aim.py:125-130,143-160
+            ("multi", [['a', 'b'], ['c'], ['d', 'e', 'f']], (512, 64), 4, 6, (30, 9)),                                 # more boxes than max_objs
+            ("small", [['a', 'b', 'c', 'd']], (40, 56), 2, 16, (12,))]
+
+
+def _head_inputs(case, rng):
+    name, class_names, (fx, fy), osf, max_objs, counts = case
+    vs = (0.2, 0.2, 8.0)
+    pc = (-vs[0] * osf * fx / 2, -vs[1] * osf * fy / 2, -5.0, vs[0] * osf * fx / 2, vs[1] * osf * fy / 2, 3.0)
+    n_cls = sum(len(c) for c in class_names)
+    boxes, labels = [], []
+    for k in counts:
+        xy = rng.uniform([pc[0] - 3, pc[1] - 3], [pc[3] + 3, pc[4] + 3], (k, 2))          # some centres outside the map
+        dims = rng.uniform(0.3, 12.0, (k, 3))
+        if k > 3:
+            dims[0, 0] = 0.0                       # zero width: skipped (:183)
+            xy[1] = [pc[0] + 0.01, pc[1] + 0.01]   # window clipped at the map corner
+            xy[2] = [pc[3] - 0.01, pc[4] - 0.01]
+        bx = np.concatenate([xy, rng.uniform(-2, 1, (k, 1)), dims, rng.uniform(-3.2, 3.2, (k, 1)), rng.normal(size=(k, 2))], 1).astype(np.float32)
+        # keep the centre coordinates away from cell boundaries (the int() of a float32 quotient must not hinge on a rounding)
+        for a in (0, 1):
+            q = (bx[:, a] - pc[a]) / vs[a] / osf
+            bad = np.abs(q - np.round(q)) < 1e-3
+            bx[bad, a] += 0.05
+        boxes.append(bx)
+        labels.append(rng.integers(0, n_cls, k).astype(np.int64))
+    train_cfg = dict(point_cloud_range=list(pc), grid_size=[fx * osf, fy * osf, 1], voxel_size=list(vs), out_size_factor=osf, dense_reg=1,
+                     gaussian_overlap=0.1, max_objs=max_objs, min_radius=2, code_weights=[1.0] * 8 + [0.3, 0.3])
+    return boxes, labels, train_cfg
+
+
+def make_centerpoint_targets():
+    """CenterPoint training targets from the reference's own get_targets_single (layers/heads/bev_depth_head.py:113-254), read
+    from the file at run time and exec'd as a plain function on CPU tensors (its four `device='cuda'` become 'cpu' in the
+    text handed to exec), with mmdet3d's gaussian_radius / draw_heatmap_gaussian supplied by their published formulas.
+    Cases: the aiMotive head (four single-class tasks, 128 x 128, max_objs 500; one sample without boxes), multi-class tasks
+    with MORE boxes than max_objs, a small odd-sized map; boxes outside the map, of zero width, at the map corners."""
+    src = _ref_source_lines("layers/heads/bev_depth_head.py", 113, 254).replace("device='cuda'", "device='cpu'")
+    ns = {"torch": torch, "gaussian_radius": _gaussian_radius, "draw_heatmap_gaussian": _draw_heatmap_gaussian}
+    exec(src, ns)
+    rng = np.random.default_rng(77)
+    out = {}
+    for case in _head_cases():
+        name, class_names, (fx, fy), osf, max_objs, counts = case
+        boxes, labels, train_cfg = _head_inputs(case, rng)
+        self_ = types.SimpleNamespace(train_cfg=train_cfg, class_names=class_names, task_heads=[None] * len(class_names), norm_bbox=True)
+        out[name + "_n_samples"] = np.int32(len(counts))
+        out[name + "_class_counts"] = np.array([len(c) for c in class_names], np.int32)
+        out[name + "_cfg"] = np.array([fx, fy, osf, max_objs], np.int32)
+        out[name + "_pc_range"] = np.array(train_cfg["point_cloud_range"], np.float32)
+        for b, (bx, lb) in enumerate(zip(boxes, labels)):
+            hm, anno, ind, mask = ns["get_targets_single"](self_, torch.from_numpy(bx), torch.from_numpy(lb))
+            out[f"{name}_boxes_{b}"], out[f"{name}_labels_{b}"] = bx, lb
+            for t in range(len(class_names)):
+                out[f"{name}_hm_{b}_{t}"] = hm[t].numpy()
+                out[f"{name}_anno_{b}_{t}"] = anno[t].numpy()
+                out[f"{name}_ind_{b}_{t}"] = ind[t].numpy()
+                out[f"{name}_mask_{b}_{t}"] = mask[t].numpy()
+            print("centerpoint_targets:", name, "sample", b, "boxes", len(bx), "valid slots per task", [int(m.sum()) for m in mask])
+    np.savez_compressed(os.path.join(HERE, "centerpoint_targets.npz"), **out)
+
+
+def make_head_loss():
+    """BEVDepthHead.loss (layers/heads/bev_depth_head.py:256-312) exec'd from the reference's text on CPU tensors: the masking,
+    gather and normaliser arithmetic is the reference's; stand-ins by their published definitions for mmdet3d's clip_sigmoid
+    (sigmoid clamped to [1e-4, 1 - 1e-4]), mmdet's reduce_mean (the identity in one process), GaussianFocalLoss (alpha 2,
+    gamma 4, eps 1e-12, sum / avg_factor) and L1Loss (|pred - target| * weight, sum / avg_factor, loss_weight 0.25:
+    exps/conf_aim.py:186-187), and CenterHead._gather_feat (gather of the rows at `ind`).  Targets: the 'aim' case of
+    centerpoint_targets.npz stacked over its samples; predictions: seeded."""
+    src = _ref_source_lines("layers/heads/bev_depth_head.py", 256, 312)
+    clip_sigmoid = lambda x, eps=1e-4: torch.clamp(x.sigmoid_(), min=eps, max=1 - eps)
+
+    def focal(pred, target, avg_factor, alpha=2.0, gamma=4.0, eps=1e-12):
+        pos_w, neg_w = target.eq(1), (1 - target).pow(gamma)
+        loss = -(pred + eps).log() * (1 - pred).pow(alpha) * pos_w - (1 - pred + eps).log() * pred.pow(alpha) * neg_w
+        return loss.sum() / avg_factor
+
+    def l1(pred, target, weight, avg_factor, loss_weight=0.25):
+        return loss_weight * ((pred - target).abs() * weight).sum() / avg_factor
+
+    def gather_feat(feat, ind):
+        return feat.gather(1, ind.unsqueeze(2).expand(ind.size(0), ind.size(1), feat.size(2)))
+
+    ns = {"torch": torch, "clip_sigmoid": clip_sigmoid, "reduce_mean": lambda t: t}
+    exec(src, ns)
+    g = np.load(os.path.join(HERE, "centerpoint_targets.npz"))
+    B, T = int(g["aim_n_samples"]), len(g["aim_class_counts"])
+    fx, fy = int(g["aim_cfg"][0]), int(g["aim_cfg"][1])
+    stack = lambda f: [torch.from_numpy(np.stack([g[f"aim_{f}_{b}_{t}"] for b in range(B)])) for t in range(T)]
+    targets = (stack("hm"), stack("anno"), stack("ind"), stack("mask"))
+    heads = dict(reg=2, height=1, dim=3, rot=2, vel=2)
+    preds, salt = [], 100
+    for t in range(T):          # predictions by formula (tests/golden/formula.py): 4 x hashed_f32 in [-2, 2), heat-map logits shifted by -2
+        d = {}
+        for k, c in [("heatmap", int(g["aim_class_counts"][t]))] + list(heads.items()):
+            salt += 1
+            d[k] = torch.from_numpy(4.0 * hashed_f32((B, c, fy, fx), salt=salt)) - (2.0 if k == "heatmap" else 0.0)
+        preds.append([d])
+    code_weights = [1.0] * 8 + [0.3, 0.3]
+    self_ = types.SimpleNamespace(loss_cls=focal, loss_bbox=l1, train_cfg=dict(code_weights=code_weights), _gather_feat=gather_feat)
+    loss = ns["loss"](self_, targets, preds)
+    np.savez_compressed(os.path.join(HERE, "head_loss.npz"), loss=np.float64(float(loss)), code_weights=np.array(code_weights, np.float32), first_salt=np.int64(101))
+    print("head_loss:", float(loss))
+
+
+def make_depth_loss():
+    """get_depth_loss (exps/mm_training_aim.py:165-178) exec'd from the reference's text: BCE of the depth distribution on the
+    labelled pixels (fg_mask = max over bins > 0), summed, / max(1, their count), x 3.  Labels one-hot on 60 % of the pixels."""
+    src = _ref_source_lines("exps/mm_training_aim.py", 165, 178)
+    import contextlib
+    ns = {"torch": torch, "F": torch.nn.functional, "autocast": lambda enabled=False: contextlib.nullcontext()}
+    exec(src, ns)
+    rng = np.random.default_rng(8)
+    BN, D, fH, fW = 6, 20, 4, 11
+    hot = rng.integers(0, D, (BN * fH * fW,))
+    labels = (np.eye(D, dtype=np.float32)[hot] * (rng.random((BN * fH * fW, 1)) < 0.6)).astype(np.float32)
+    preds = torch.from_numpy(rng.standard_normal((BN, D, fH, fW)).astype(np.float32)).softmax(1)
+    self_ = types.SimpleNamespace(depth_channels=D)
+    loss = ns["get_depth_loss"](self_, torch.from_numpy(labels), preds)
+    empty = ns["get_depth_loss"](self_, torch.zeros_like(torch.from_numpy(labels)), preds)          # no labelled pixel: 0 / max(1, 0)
+    np.savez_compressed(os.path.join(HERE, "depth_loss.npz"), labels=labels, preds=preds.numpy(), loss=np.float64(float(loss)),
+                        loss_without_labels=np.float64(float(empty)))
+    print("depth_loss:", float(loss), float(empty))
+
+
+def make_fuse_layer():
+    """BEVFuseLayer (models/bev_depth.py:133-145): the reference's class itself, imported with the stubs in place, seeded
+    weights, CPU forward and the input gradient of a seeded output gradient."""
+    from models.bev_depth import BEVFuseLayer
+    torch.manual_seed(12)
+    C, B, H, W = 24, 2, 16, 12
+    m = BEVFuseLayer(C)
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    y = m(x)
+    go = torch.from_numpy(hashed_f32(tuple(y.shape), salt=5))
+    y.backward(go)
+    np.savez_compressed(os.path.join(HERE, "fuse_layer.npz"), x=x.detach().numpy(), y=y.detach().numpy(), grad_x=x.grad.numpy(), grad_out_salt=np.int64(5),
+                        **{"w_" + k: v.detach().numpy() for k, v in m.state_dict().items()},
+                        **{"g_" + k: p.grad.numpy() for k, p in m.named_parameters()})
+    print("fuse_layer:", tuple(y.shape), list(m.state_dict()))
+
+
 def main():
     _install_stubs()
     oracle.build()
@@ -573,12 +760,21 @@ def main():
         return make_lss_forward()
     if "--only-augment-images" in sys.argv:
         return make_augment_images()
+    if "--only-head" in sys.argv:
+        make_centerpoint_targets()
+        make_head_loss()
+        make_depth_loss()
+        return make_fuse_layer()
     make_vp_ref_test()
     make_vp_edge()
     make_quant_and_geom()
     make_lss_forward()
     make_depth_labels()
     make_augment_images()
+    make_centerpoint_targets()
+    make_head_loss()
+    make_depth_loss()
+    make_fuse_layer()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

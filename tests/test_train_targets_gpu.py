@@ -146,7 +146,7 @@ def test_centerpoint_targets_against_oracle(mmt_lib, oracle_mod, seed):
     for t, n in enumerate(class_counts):
         assert hm[t].shape == (B, n, fy, fx) and anno[t].shape == (B, max_objs, 10)
         for b in range(B):
-            r_hm, r_anno, r_ind, r_mask = oracle_mod.centerpoint_targets_task(boxes[b][:max_objs], labels[b][:max_objs], begin, n,
+            r_hm, r_anno, r_ind, r_mask = oracle_mod.centerpoint_targets_task(boxes[b], labels[b], begin, n,
                                                                               max_objs, fx, fy, pc, vs, osf, 0.1, 2)
             assert np.abs(hm[t][b].cpu().numpy() - r_hm).max() <= 1e-6
             assert np.array_equal(hm[t][b].cpu().numpy() == 1.0, r_hm == 1.0)            # the loss's positive set
