@@ -38,6 +38,8 @@ WORKLOADS = {
     "cfg2": "BASELINE configs[1]: camera-only BEVDepth (ResNet-50, 6 cams 256x704, D=112, C=80, BEV 128x128) "
             "full training step (fwd + det/depth loss + bwd + clip + AdamW)",
     "cfg3": "BASELINE configs[2]: LiDAR-only pillar path, 40k pts, 0.2 m voxels, full training step",
+    "cfg3n": "BASELINE configs[2] on the reference's native LiDAR range [-204.8,-25.6,-5,204.8,25.6,3] (2048x256 pillars at 0.2 m, "
+             "exps/conf_aim.py:16-18): LiDAR-only pillar path, 40k pts, full training step",
     "cfg4": "BASELINE configs[3]: LiDAR+camera fusion -- BEVDepth (ResNet-50, 6 cams 256x704, D=112, C=80, BEV 128x128) + "
             "40k-point LiDAR frames (0.2 m pillars, 512x512 canvas) concatenated in BEV; full training step "
             "(depth labels + fwd + det/depth loss + bwd + clip + AdamW)",
@@ -85,6 +87,9 @@ def parse(argv=None):
     ap.add_argument("--geom-form", action="store_true",
                     help="fused camera path: write a geom tensor with mmt_frustum_geometry every step and feed the geom form of the "
                          "kernels (the round-2 path) instead of the camera form, whose kernels compute the cells themselves")
+    ap.add_argument("--rig", default="analytic", help="camera rig of the synthetic batches: analytic (the level 6-camera fan SURVEY 8d prescribes; "
+                    "default) | pitched:<deg> (every camera pitched about its own x axis) | nuscenes (the reference fixture's real calibration, "
+                    "cameras that are not level: tests/golden/nusc_rig.npz)")
     ap.add_argument("--calibration-ids", action="store_true",
                     help="give every synthetic batch a mats_dict['calibration_id'] (a loader that knows its rig): camera matrices, "
                          "the geometry's column summary and the backward-kernel choice are then cached per calibration")
@@ -701,7 +706,12 @@ def train_main(args, rank, local_rank, world):
             ts.model.backbone.camera_form = False
     B = cfg["batch_size"]
     # a small pool of distinct pre-generated batches resident in HBM (input is never the bottleneck)
-    batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i) for i in range(2)]
+    rig = args.rig
+    if rig == "nuscenes":                    # the reference fixture's calibration (data: tests/golden/nusc_rig.npz, made by tests/golden/make_golden.py)
+        import numpy as np
+        g_ = np.load(os.path.join(ROOT, "tests", "golden", "nusc_rig.npz"))
+        rig = (g_["sensor2ego"], g_["intrin"], tuple(int(v) for v in g_["image_hw"]))
+    batches = [synthetic_batch(cfg, dev, seed=1000 * rank + i, rig=rig) for i in range(2)]
     if args.cached_plan or args.calibration_ids:
         # each synthetic batch has its own (jittered) rig; its id lets LSSFPN reuse what depends on the
         # calibration alone (unfused path: the sort of the points by BEV cell; fused path: the camera matrices, the
@@ -745,6 +755,7 @@ def train_main(args, rank, local_rank, world):
                    "dense_nets_dtype": "bf16 autocast" if ts.amp_dtype is not None else "f32",
                    "hot_path_storage_dtype": dtype,
                    # exps/mm_training_aim.py:258-259: both run inside every timed step
+                   "rig": args.rig,
                    "augment_images": bool(ts.augment and cfg["use_cam"]), "depth_oracle": bool(ts.pass_depth_labels and cfg["use_cam"]),
                    "conv_weight_gradients": {None: "same stream (autograd)", "inline": "same stream"}.get(ts.conv_overlap, ts.conv_overlap),
                    "task_head_streams": int(ts.model.head.task_streams),

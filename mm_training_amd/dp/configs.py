@@ -3,7 +3,8 @@ reference's config module (exps/conf_aim.py: backbone_conf :42-71, head_conf :17
 lidar_conf :192-213, train_cfg :143-160).
 
   cfg2  camera-only BEVDepth: ResNet-50, 6 cams 256x704, ds 16, D=112, C=80, BEV 128x128
-  cfg3  LiDAR-only pillar path: 40k points, 0.2 m voxels
+  cfg3  LiDAR-only pillar path: 40k points, 0.2 m voxels, the +-51.2 m square the camera configurations share (512 x 512 pillars)
+  cfg3n the same on the reference's native range [-204.8, -25.6, -5, 204.8, 25.6, 3] (exps/conf_aim.py:16-18: 2048 x 256 pillars), SURVEY 8d
   cfg4  LiDAR + camera fusion (cfg2 camera half + pillar BEV concat)
   cfg5  LiDAR + radar + camera, 6 cams 512x1408, 80k points (8 columns)
   tiny  a few-second smoke configuration for tests (no layer narrower than 16 channels on both sides: MIOpen's narrow NHWC
@@ -21,12 +22,15 @@ def make_config(name="cfg2"):
     tiny64 = name == "tiny64"        # "tiny" with 64 camera channels: the narrowest width the camera-form / plan-form kernels take
     if tiny64:
         name = "tiny"
+    native = name == "cfg3n"         # BASELINE configs[2] on the reference's own LiDAR range (exps/conf_aim.py:16-18: 2048 x 256 pillars at 0.2 m)
+    if native:
+        name = "cfg3"
     tiny = name == "tiny"
     use_cam = name in ("cfg2", "cfg4", "cfg5", "tiny")
     use_lidar = name in ("cfg3", "cfg4", "cfg5", "tiny")
     use_radar = name == "cfg5"
     final_dim = (512, 1408) if name == "cfg5" else ((64, 192) if tiny else (256, 704))
-    pc_range = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    pc_range = [-204.8, -25.6, -5.0, 204.8, 25.6, 3.0] if native else [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
     voxel_size = [0.2, 0.2, 8.0]
     out_size_factor = 4
     bev_cell = voxel_size[0] * out_size_factor            # 0.8 m camera BEV cells -> 128 x 128
@@ -77,7 +81,7 @@ def make_config(name="cfg2"):
     if tiny:
         lidar_conf['pts_voxel_layer']['max_voxels'] = (2000, 2000)
     cfg = dict(
-        name=name, use_cam=use_cam, use_lidar=use_lidar, use_radar=use_radar,
+        name="cfg3n" if native else name, use_cam=use_cam, use_lidar=use_lidar, use_radar=use_radar,
         batch_size={"cfg2": 4, "cfg3": 8, "cfg4": 4, "cfg5": 2, "tiny": 2}[name],
         num_cams=2 if tiny else 6, final_dim=final_dim,
         num_points=80000 if name == "cfg5" else (2000 if tiny else 40000),

@@ -17,6 +17,8 @@ Here:
     stream, and nothing the main stream waits for before the end of the backward pass;
   * `finish()` (after `backward()`): the calling stream waits for the collectives and every `.grad` is re-pointed at its view of
     the reduced buffer (what `gradient_as_bucket_view` gives under DDP).
+Buckets are not uniform (`cut_buckets`): a small first one (the first collective starts early), a small last one (the only
+all-reduce nothing overlaps is the last: DESIGN section 6 prices it), `bucket_mb` between.
 The autograd engine runs the nodes of a static graph in the same order on every rank, so the buckets complete -- and the
 collectives are issued -- in the same order everywhere (the property DDP relies on too).  Works on CPU tensors (gloo) without
 streams: tests/test_dp_gloo.py.  Gradient accumulation over several backward passes between two `finish()` calls is not supported
@@ -26,30 +28,63 @@ import torch
 import torch.distributed as dist
 
 
+def cut_buckets(sizes, bucket_bytes, first_bytes, last_bytes):
+    """Bucket boundaries over `sizes` (bytes per parameter, in the order the backward pass produces the gradients): a list of
+    (begin, end).  Not uniform: the FIRST bucket is small, so the first collective starts early in the backward pass; the LAST
+    one -- the first layers' gradients, complete only when the backward pass ends -- is small too, because its all-reduce is
+    the one nothing overlaps: what the step waits for after backward() is (last bucket) / (link bandwidth), not
+    (bucket_mb) / (link bandwidth).  Between them `bucket_bytes` (few, large collectives: xGMI is point-to-point, a ring
+    all-reduce is bound by one link per direction and every collective pays its latency once)."""
+    n = len(sizes)
+    tail, acc = n, 0                     # the parameters of the last bucket, from the end
+    while tail > 1 and acc + sizes[tail - 1] <= last_bytes:
+        tail -= 1
+        acc += sizes[tail]
+    if tail == n:
+        tail = n - 1 if n > 1 else n     # (one huge last parameter: its own bucket)
+    cuts, begin, acc, cap = [], 0, 0, first_bytes
+    for i in range(tail):
+        if i > begin and acc + sizes[i] > cap:
+            cuts.append((begin, i))
+            begin, acc, cap = i, 0, bucket_bytes
+        acc += sizes[i]
+    if tail > begin:
+        cuts.append((begin, tail))
+    if tail < n:
+        cuts.append((tail, n))
+    return cuts
+
+
 class GradReducer:
-    def __init__(self, named_parameters, world_size, bucket_mb=64, ignore=(), extra_streams=lambda: (), stream=None):
-        self.world = dist.get_world_size() if dist.is_initialized() else int(world_size)     # the mean is over the ranks that exchange
+    def __init__(self, named_parameters, world_size, bucket_mb=64, ignore=(), extra_streams=lambda: (), stream=None, first_mb=8, last_mb=8):
+        # the mean is over the ranks that exchange: without a process group nothing is exchanged and nothing is scaled
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.extra_streams = extra_streams                   # callable -> streams (besides the current one) gradients may come from
         params = [(n, p) for n, p in named_parameters if p.requires_grad and not any(tag in n for tag in ignore)]
         if not params:
             raise ValueError("GradReducer: no parameters")
+        if len({id(p) for _, p in params}) != len(params):
+            raise ValueError("GradReducer: a parameter is registered twice (tied weights: pass named_parameters(), which lists them once)")
         self.device = params[0][1].device
         self.cuda = self.device.type == "cuda"
-        # the stream the buckets are packed on (and the collective is issued from); a caller that already runs a side stream hands
-        # it in: a process has four hardware queues, and main + weight gradients + two head streams + RCCL's own are five already
+        # the stream the buckets are packed on (and the collective is issued from): its own, at normal priority, unless the caller
+        # hands one in
         self.comm = (stream if stream is not None else torch.cuda.Stream(device=self.device)) if self.cuda else None
-        cap = int(bucket_mb * 1024 * 1024)
-        self.buckets, cur, size = [], [], 0
-        for n, p in reversed(params):                        # backward produces the last layers' gradients first
-            nbytes = p.numel() * p.element_size()
-            if cur and (size + nbytes > cap or p.dtype != cur[0][1].dtype):
-                self.buckets.append(cur)
-                cur, size = [], 0
-            cur.append((n, p))
-            size += nbytes
-        if cur:
-            self.buckets.append(cur)
-        self._flat, self._views, self._bucket_of, self._pending, self._works, self._task = [], [], {}, [], [], None
+        mb = 1024 * 1024
+        order = list(reversed(params))                       # backward produces the last layers' gradients first
+        self.buckets = []
+        begin = 0                                            # (a change of dtype starts a new run of buckets)
+        for i in range(1, len(order) + 1):
+            if i == len(order) or order[i][1].dtype != order[begin][1].dtype:
+                run = order[begin:i]
+                sizes = [p.numel() * p.element_size() for _, p in run]
+                first = first_mb if begin == 0 else bucket_mb
+                last = last_mb if i == len(order) else bucket_mb
+                for lo, hi in cut_buckets(sizes, int(bucket_mb * mb), int(min(first, bucket_mb) * mb), int(min(last, bucket_mb) * mb)):
+                    self.buckets.append(run[lo:hi])
+                begin = i
+        self._flat, self._views, self._bucket_of, self._pending, self._works = [], [], {}, [], []
+        self._step, self._seen_step, self._arrived = 0, 0, set()
         for b, members in enumerate(self.buckets):
             flat = torch.zeros(sum(p.numel() for _, p in members), dtype=members[0][1].dtype, device=self.device)
             views, off = [], 0
@@ -66,14 +101,21 @@ class GradReducer:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for members in self.buckets for _, p in members]
         self.gradient_bytes = int(sum(f.numel() * f.element_size() for f in self._flat))
 
+    def begin_step(self):
+        """Called by the step before its backward pass (TrainStep does): a new pass starts from clean counters whatever became
+        of the previous one."""
+        self._step += 1
+
     # ---- one call per parameter and backward pass, on the autograd thread, right after its .grad was set
     def _on_grad(self, p):
-        get = getattr(torch._C, "_current_graph_task_id", None)
-        task = get() if get is not None else 0               # (without the accessor: no protection against a pass that died half-way)
-        if task != self._task:                               # first gradient of a new backward pass (the previous one may have died half-way)
+        # a new backward pass: the step said so (begin_step), or -- for a caller that does not -- a gradient arrives that this pass
+        # has seen already (AccumulateGrad runs once per parameter and pass, tied weights included: their uses are summed in front of it)
+        if self._seen_step != self._step or id(p) in self._arrived:
             if any(n != len(m) for n, m in zip(self._pending, self.buckets)):
-                self._reset()
-            self._task = task
+                self._reset()                                # the previous pass died half-way
+            self._seen_step = self._step
+            self._arrived.clear()
+        self._arrived.add(id(p))
         b = self._bucket_of[p]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -120,12 +162,20 @@ class GradReducer:
         self._reset()
 
     def _reset(self):
-        self._works, self._task = [], None
+        for w in self._works:                                # (collectives of a pass that died: every rank issued the same ones; let them end)
+            if w is not None:
+                try:
+                    w.wait()
+                except Exception:
+                    pass
+        self._works = []
+        self._arrived.clear()
         self._pending = [len(m) for m in self.buckets]
 
     def describe(self):
         return {"kind": "native bucketed all-reduce (dp/reducer.py)", "buckets": len(self.buckets),
                 "bucket_bytes": [int(f.numel() * f.element_size()) for f in self._flat], "gradient_bytes": self.gradient_bytes,
+                "bucket_layout": "small first bucket (the first collective starts early), small last bucket (the one all-reduce nothing overlaps), bucket_mb between",
                 "parameters": int(sum(len(m) for m in self.buckets)), "communication_stream": bool(self.cuda),
                 "launches_per_bucket": "one multi-tensor copy + one scale + the collective"}
 

@@ -28,7 +28,31 @@ IMG_MEAN = (0.485, 0.456, 0.406)
 IMG_STD = (0.229, 0.224, 0.225)
 
 
-def synthetic_batch(cfg, device, seed=0, batch_size=None):
+def camera_rig(rig, B, N, W, H, seed=0):
+    """(sensor2ego, intrin) [B, N, 4, 4] CPU tensors of the benchmark rigs:
+      "analytic"        the level 6-camera fan of SURVEY section 8d (mm_training_amd.synthetic.camera_rig), yaw jitter per sample
+      "pitched:<deg>"   the same with every camera pitched by <deg> about its own x axis (columns then straddle BEV cells)
+      (s2e, K, (h, w))  a given rig (e.g. the reference fixture's real calibration, tests/golden/nusc_rig.npz: cameras that are not
+                        level), its intrinsics rescaled from h x w to H x W, the same rig for every sample"""
+    if isinstance(rig, (tuple, list)):          # (sensor2ego [N, 4, 4], intrin [N, 4, 4], (image height, image width) the intrinsics are for)
+        s2e, K, (h0, w0) = rig
+        if N != s2e.shape[0]:
+            raise ValueError(f"the rig has {s2e.shape[0]} cameras, the configuration {N}")
+        K = torch.as_tensor(K).clone().float()
+        K[:, 0, :] *= W / float(w0)             # fx, skew, cx
+        K[:, 1, :] *= H / float(h0)             # fy, cy
+        return torch.as_tensor(s2e).float().unsqueeze(0).repeat(B, 1, 1, 1).contiguous(), K.unsqueeze(0).repeat(B, 1, 1, 1).contiguous()
+    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=seed)
+    if rig.startswith("pitched:"):
+        a = math.radians(float(rig.split(":", 1)[1]))
+        rx = torch.tensor([[1, 0, 0, 0], [0, math.cos(a), -math.sin(a), 0], [0, math.sin(a), math.cos(a), 0], [0, 0, 0, 1]], dtype=torch.float32)
+        s2e = s2e.matmul(rx)
+    elif rig != "analytic":
+        raise ValueError(f"unknown rig {rig!r} (analytic | pitched:<deg> | a (sensor2ego, intrin, (h, w)) tuple)")
+    return s2e, K
+
+
+def synthetic_batch(cfg, device, seed=0, batch_size=None, rig="analytic"):
     """One batch shaped like collate_aim's output (dataset/src/aimotive_dataset.py:182-231):
     (sweep_imgs [B,1,N,3,H,W] in 0..255, mats dict, pointclouds list[B] of [Ni,F], gt_boxes, gt_labels)."""
     B = batch_size or cfg["batch_size"]
@@ -36,7 +60,7 @@ def synthetic_batch(cfg, device, seed=0, batch_size=None):
     H, W = cfg["final_dim"]
     g = torch.Generator().manual_seed(seed)
     imgs = torch.randint(0, 256, (B, 1, N, 3, H, W), generator=g, dtype=torch.uint8).float()
-    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=seed)
+    s2e, K = camera_rig(rig, B, N, W, H, seed=seed)
     mats = {
         "sensor2ego_mats": s2e.unsqueeze(1).to(device), "intrin_mats": K.unsqueeze(1).to(device),
         "extrinsics": torch.inverse(s2e).unsqueeze(1).to(device),
@@ -149,6 +173,13 @@ class TrainStep(nn.Module):
                 with torch.no_grad():
                     for t in list(self.model.parameters()) + list(self.model.buffers()):
                         dist.broadcast(t, 0)
+            # Where the buckets are packed and the collectives issued: behind the weight gradients on THEIR stream (default), or on a
+            # stream of the reducer's own at normal priority (MMT_REDUCER_STREAM=own).  The review of round 4 asked for the latter
+            # (a collective queued behind a low-priority stream's backlog starts late); measured on ONE rank over RCCL
+            # (profiles/r05_exchange_tax.txt) the extra stream costs the rank 4.2 ms of a 66.7 ms step against 0.9 ms on the
+            # weight-gradient stream -- a process has four hardware queues, and main + weight gradients + a communication
+            # stream + RCCL's own are a fifth stream's worth of multiplexing.  What bounds the exposed tail instead is the size of
+            # the LAST bucket (dp/reducer.py: 6 MB, not 64).
             pack_on = None
             if self.conv_overlap in ("deferred", "pair") and os.environ.get("MMT_REDUCER_STREAM", "side") == "side":
                 from ..ops import conv_overlap
@@ -247,6 +278,8 @@ class TrainStep(nn.Module):
             #   get_depth_labels + the label half of augment_images   -> mmt_depth_labels_flipped (mirrored label write)
             #   normalize_images + the image half of augment_images   -> mmt_normalize_flip_images (one pass, channels_last out)
             B, S, N, _, H, W = sweep_imgs.shape
+            if S != 1:       # the labels, their flip flags and the oracle pass-through below are per key frame; the aiMotive loader feeds one sweep (aimotive_dataset.py:194)
+                raise RuntimeError(f"TrainStep: {S} sweeps per sample -- the training step takes the key frame only (one sweep), like the reference's loader")
             flips = np.random.uniform(size=(B * S * N)) > 0.5 if self.augment else np.zeros((B * S * N), dtype=bool)
             fl = camera_flags_to_device(flips, sweep_imgs.device)
             depth_labels_flat = depth_labels(pointclouds, mats["extrinsics"][:, 0], mats["intrin_mats"][:, 0], mats["bda_mat"],
@@ -282,6 +315,8 @@ class TrainStep(nn.Module):
     def forward(self, batch):
         """One optimisation step; returns the (detached) loss tensors, no host sync."""
         self.optimizer.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self.reducer.begin_step()                          # (a new backward pass, whatever became of the last one)
         loss, det, dep = self.forward_loss(batch)
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)      # see _batched_bn_counters

@@ -105,7 +105,7 @@ class BEVDepthLiDAR(BEVDepth):
     timestamps)` -> `(preds, depth_pred, lidar_bev, cam_bev)`; a disabled modality contributes None."""
 
     def __init__(self, backbone_conf, head_conf, lidar_conf, is_train_depth=False, use_cam=True,
-                 use_lidar=True, fuse_layer_in_channels=144):
+                 use_lidar=True, fuse_layer_in_channels=144, full_lidar_canvas=None):
         super().__init__(backbone_conf, head_conf, is_train_depth=False, use_cam=use_cam)
         self.use_cam, self.use_lidar = use_cam, use_lidar
         self.sync_free_lidar = os.environ.get("MMT_LIDAR_SYNC_FREE", "1") != "0"
@@ -114,8 +114,11 @@ class BEVDepthLiDAR(BEVDepth):
         # the reference reads (exps/mm_training_aim.py:268 binds it and drops it).  False (default): with both modalities
         # and an integer grid ratio only the canvas cells the resize samples are scattered, straight into the camera|LiDAR
         # buffer, and the third return value is that LiDAR half [B, Cl, H, W].  True: the reference's op sequence and its
-        # full-resolution third return value.
-        self.full_lidar_canvas = os.environ.get("MMT_LIDAR_FULL_CANVAS", "0") == "1"
+        # full-resolution third return value.  `full_lidar_canvas` (constructor argument beside the reference's; None: the
+        # MMT_LIDAR_FULL_CANVAS environment variable, default off).  A caller that READS `lidar_bev_ret` -- evaluation with
+        # reference parity, visualisation of the canvas -- constructs the module with full_lidar_canvas=True (INTEGRATION.md,
+        # mapping table: the one return value whose shape differs from the reference's by default).
+        self.full_lidar_canvas = (os.environ.get("MMT_LIDAR_FULL_CANVAS", "0") == "1") if full_lidar_canvas is None else bool(full_lidar_canvas)
         if use_lidar:
             self.lidar_encoder = LidarEncoder(**{k: v for k, v in dict(lidar_conf).items() if k != 'type'})
         if use_cam and use_lidar:

@@ -89,7 +89,31 @@ def _graph_task_id():
 
 def _end_of_backward():
     _state["join_queued_for"] = None
+    _uses.clear()                      # (a forward whose backward never ran must not count against the next pass for good)
     join()
+
+
+# Forward applications of a weight that still await their backward, by id(weight) -> [count, seen more than one].  A weight used
+# twice in one graph (a module applied twice, tied weights) has its two gradients SUMMED by the engine in AccumulateGrad's input
+# buffer -- a kernel on the consumer's stream, which in deferred mode has not waited for the side stream yet.
+_uses = {}
+
+
+def _deferral_is_safe(leaf, gw):
+    """Deferred mode hands AccumulateGrad a gradient that is still being written on the side stream.  That is only sound while
+    the engine does nothing with it but keep the reference: first gradient of the pass for this weight (no in-place add), no other
+    application of the weight in the graph (no input-buffer sum), the layout AccumulateGrad would keep (else it clones on the
+    consumer's stream: gradient layout contract) and no tensor hook on the weight (hooks run on the gradient, on that stream)."""
+    if leaf.grad is not None or gw is None:
+        return False
+    u = _uses.get(id(leaf))
+    if u is not None and u[1]:
+        return False
+    if getattr(leaf, "_backward_hooks", None):
+        return False
+    if tuple(gw.shape) != tuple(leaf.shape) or gw.dtype != leaf.dtype:
+        return False
+    return all(sg == sl for n, sg, sl in zip(leaf.shape, gw.stride(), leaf.stride()) if n != 1)
 
 
 class _ConvOverlap(Function):
@@ -106,6 +130,10 @@ class _ConvOverlap(Function):
         wc = w if dtype is None else w.to(dtype)
         bc = b if (b is None or dtype is None) else b.to(dtype)
         ctx.save_for_backward(xc, wc, w)
+        if mode == "deferred" and ctx.needs_input_grad[1]:
+            u = _uses.setdefault(id(w), [0, False])
+            u[0] += 1
+            u[1] = u[1] or u[0] > 1
         ctx.conf = (stride, padding, dilation, groups, b is not None, x.dtype, b.dtype if b is not None else None, mode, narrow)
         with torch.backends.cudnn.flags(enabled=not narrow):   # NARROW: ATen's own im2col + GEMM convolution, not MIOpen
             y = torch.ops.aten.convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
@@ -153,16 +181,16 @@ class _ConvOverlap(Function):
             #    gradient -- launched from another stream, e.g. a task head's -- takes the block again on the side stream.
             #    (Deferred: the first consumer comes after the end-of-backward join, and the block is next taken on the side
             #    stream in the following backward pass, behind everything this stream has queued by then.)
-            deferred = mode == "deferred" and leaf.grad is None
+            deferred = mode == "deferred" and _deferral_is_safe(leaf, gw)
             for t in ((gy, x) if w is leaf else (gy, x, w)):
                 t.record_stream(side)
             if not deferred:
                 for t in (gw, gb):
                     if t is not None:
                         t.record_stream(main)
-            if deferred:
-                # one callback per backward pass; keyed by the pass, so a pass that died with an exception (its callbacks never
-                # ran) cannot leave the next one without its join
+            if mode == "deferred":
+                # one callback per backward pass (also when THIS layer could not defer: the callback resets the use counts); keyed by
+                # the pass, so a pass that died with an exception (its callbacks never ran) cannot leave the next one without its join
                 task = _graph_task_id()
                 if _state["join_queued_for"] != task:
                     _state["join_queued_for"] = task

@@ -751,6 +751,31 @@ def make_fuse_layer():
     print("fuse_layer:", tuple(y.shape), list(m.state_dict()))
 
 
+def make_nusc_rig():
+    """The separate matrices of the reference fixture's real 6-camera calibration (test/data/nuscenes/infos.pkl; quant_geom.npz
+    holds only their product at 900 x 1600): sensor2ego and the 900 x 1600 intrinsics, for `bench.py --rig nuscenes`, which
+    rescales the intrinsics to the benchmark's image size.  Data only (96 + 96 floats)."""
+    import pickle
+    info = pickle.load(open(os.path.join(REF, "test/data/nuscenes/infos.pkl"), "rb"))[0]
+    cams = ["CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_LEFT", "CAM_BACK", "CAM_BACK_RIGHT"]
+    s2e = np.zeros((6, 4, 4), np.float32)
+    K = np.zeros((6, 4, 4), np.float32)
+    for i, cam in enumerate(cams):
+        cs = info["cam_infos"][cam]["calibrated_sensor"]
+        w, x, y, z = cs["rotation"]
+        s2e[i, :3, :3] = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        s2e[i, :3, 3] = cs["translation"]
+        s2e[i, 3, 3] = 1
+        K[i, :3, :3] = np.array(cs["camera_intrinsic"])
+        K[i, 3, 3] = 1
+    g = np.load(os.path.join(HERE, "quant_geom.npz"))
+    assert np.allclose(torch.from_numpy(s2e).matmul(torch.inverse(torch.from_numpy(K))).numpy(), g["nusc_fixture_combine"][0], rtol=0, atol=1e-6)
+    np.savez_compressed(os.path.join(HERE, "nusc_rig.npz"), sensor2ego=s2e, intrin=K, image_hw=np.array([900, 1600], np.int32))
+    print("nusc_rig: 6 cameras, image 900 x 1600")
+
+
 def main():
     _install_stubs()
     oracle.build()
@@ -760,6 +785,8 @@ def main():
         return make_lss_forward()
     if "--only-augment-images" in sys.argv:
         return make_augment_images()
+    if "--only-nusc-rig" in sys.argv:
+        return make_nusc_rig()
     if "--only-head" in sys.argv:
         make_centerpoint_targets()
         make_head_loss()
@@ -775,6 +802,7 @@ def main():
     make_head_loss()
     make_depth_loss()
     make_fuse_layer()
+    make_nusc_rig()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -217,3 +217,44 @@ def test_narrow_fp32_convolutions_bypass_miopen(mmt_lib, mode):
         yr.backward(g.cpu().double())
         for a, b in ((x.grad, xr.grad), (conv.weight.grad, ref.weight.grad)) + (((conv.bias.grad, ref.bias.grad),) if bias else ()):
             assert float((a.cpu().double() - b).abs().max()) <= 1e-5 * float(b.abs().max()), (cin, cout, k, s, d)
+
+
+@pytest.mark.parametrize("mode", ["pair", "deferred"])
+def test_deferred_mode_only_where_the_engine_does_nothing_with_the_gradient(mmt_lib, mode):
+    """A weight used twice in one graph (the engine sums its two gradients in AccumulateGrad's input buffer, on the consumer's
+    stream), a tensor hook on the weight, a gradient layout AccumulateGrad would not keep: each must make the layer join the side
+    stream on the spot instead of deferring -- gradients equal to plain autograd's, many times over with the streams busy."""
+    from mm_training_amd.ops import conv_overlap
+    conv_overlap._uses.clear()                                    # (a test whose backward pass died may have left its forwards counted)
+    torch.manual_seed(1)
+    ref = torch.nn.Conv2d(32, 32, 3, 1, 1, bias=True).cuda().to(memory_format=torch.channels_last)
+    new = copy.deepcopy(ref)
+    conv_overlap.enable(new, mode)
+    x = torch.randn(8, 32, 48, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    busy = torch.randn(4096, 4096, device="cuda")
+    for it in range(6):
+        grads = []
+        for m in (ref, new):
+            m.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            (busy @ busy).sum()                                   # keep the main stream's queue long
+            y = m(torch.relu(m(xi)))                              # the module applied twice: one weight, two gradients
+            (y * y).mean().backward()
+            grads.append((m.weight.grad.clone(), m.bias.grad.clone(), xi.grad.clone()))
+        for a, b in zip(*grads):
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()), (mode, it)        # (two split-K weight gradients summed: fp32 atomics)
+    assert not conv_overlap._uses                                 # the end-of-backward callback cleared the use counts
+    # a hook on the weight: it sees (and here scales) the complete gradient
+    new.zero_grad(set_to_none=True); ref.zero_grad(set_to_none=True)
+    hooks = [m.weight.register_hook(lambda g: g * 2.0) for m in (ref, new)]
+    for m in (ref, new):
+        m(x).square().mean().backward()
+    assert float((new.weight.grad - ref.weight.grad).abs().max()) <= 2e-5 * float(ref.weight.grad.abs().max())
+    for h in hooks:
+        h.remove()
+    # the layout test on its own: a gradient whose strides differ from the weight's (where the size is not 1) is not deferred
+    w = torch.nn.Parameter(torch.randn(8, 4, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last))
+    assert conv_overlap._deferral_is_safe(w, torch.empty_like(w))
+    assert not conv_overlap._deferral_is_safe(w, torch.empty(8, 4, 3, 3, device="cuda"))
+    w1 = torch.nn.Parameter(torch.randn(8, 4, 1, 1, device="cuda"))                       # 1 x 1: every layout has the same strides where it matters
+    assert conv_overlap._deferral_is_safe(w1, torch.empty(8, 4, 1, 1, device="cuda").contiguous(memory_format=torch.channels_last))

@@ -107,7 +107,7 @@ def _reducer_worker(rank, world, port, out):
     net[0].to(memory_format=torch.channels_last)
     frozen = torch.nn.Linear(3, 3)                         # never used: must be kept out of the reducer
     red = GradReducer(list(net.named_parameters()) + [("frozen." + n, p) for n, p in frozen.named_parameters()], world,
-                      bucket_mb=0.002, ignore=("frozen.",))          # 2 KB buckets: several of them
+                      bucket_mb=0.002, first_mb=0.0004, last_mb=0.0005, ignore=("frozen.",))   # 2 KB buckets, a smaller first and last one
     g = torch.Generator().manual_seed(100)
     data = torch.randn(world * 4, 3, 8, 8, generator=g)
     res = {}
@@ -134,6 +134,15 @@ def _reducer_worker(rank, world, port, out):
     net(data[rank * 4:(rank + 1) * 4]).square().mean().backward()
     red.finish()
     res["after_failure"] = [p.grad.clone() for p in net.parameters()]
+    # a layer applied twice in one graph (one weight, two uses): its hook fires once, with the sum
+    net.zero_grad(set_to_none=True)
+    red.begin_step()
+    shard = data[rank * 4:(rank + 1) * 4]
+    h = net[1](net[0](shard))
+    y = net[2](h) + net[2](h.flip(-1))
+    net[4](net[3](y)).square().mean().backward()
+    red.finish()
+    res["shared"] = [p.grad.clone() for p in net.parameters()]
     if rank == 0:
         out["grads"] = res
         out["describe"] = red.describe()
@@ -161,5 +170,16 @@ def test_native_reducer_two_ranks_equal_the_mean_gradient():
     for key in (0, 1, "after_failure"):
         for a, b in zip(out["grads"][key], ref):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), key
+    net.zero_grad(set_to_none=True)
+    def twice(x):
+        h = net[1](net[0](x))
+        return net[4](net[3](net[2](h) + net[2](h.flip(-1)))).square().mean()
+    ((twice(data[:4]) + twice(data[4:])) / 2).backward()
+    for a, b in zip(out["grads"]["shared"], [p.grad for p in net.parameters()]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), "shared"
     d = out["describe"]
+    # not uniform: the first and the last bucket are the small ones
+    bb = d["bucket_bytes"]
+    assert bb[0] <= 0.0004 * 2 ** 20 + 1 or len(bb) < 3
+    assert bb[-1] == 864                       # the first layer's weight alone (a parameter larger than the cap is a bucket of its own): 8 x 3 x 3 x 3 floats
     assert d["buckets"] >= 3 and d["parameters"] == 6 and sum(d["bucket_bytes"]) == d["gradient_bytes"] and out["strides_match"]
