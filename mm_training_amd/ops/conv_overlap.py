@@ -130,7 +130,7 @@ class _ConvOverlap(Function):
         wc = w if dtype is None else w.to(dtype)
         bc = b if (b is None or dtype is None) else b.to(dtype)
         ctx.save_for_backward(xc, wc, w)
-        if mode == "deferred" and ctx.needs_input_grad[1]:
+        if mode == "deferred" and ctx.needs_input_grad[1] and not narrow:    # (a narrow layer's backward is inline: nothing to count)
             u = _uses.setdefault(id(w), [0, False])
             u[0] += 1
             u[1] = u[1] or u[0] > 1

@@ -31,8 +31,10 @@ def test_reference_import_lines_resolve_to_the_hip_backed_modules():
     assert names == ["batch_size", "num_points", "num_channels", "num_voxel_x", "num_voxel_y", "num_voxel_z",
                      "geom_xyz_tensor", "input_features_tensor", "output_features_tensor", "pos_memo_tensor"]
     # and the model constructors keep the reference's argument names (models/bev_depth.py:22,148-150; lss_fpn.py:252-254)
-    assert list(inspect.signature(BEVDepthLiDAR.__init__).parameters)[1:] == [
+    assert list(inspect.signature(BEVDepthLiDAR.__init__).parameters)[1:8] == [
         "backbone_conf", "head_conf", "lidar_conf", "is_train_depth", "use_cam", "use_lidar", "fuse_layer_in_channels"]
+    extra = list(inspect.signature(BEVDepthLiDAR.__init__).parameters.values())[8:]      # additions come last and have defaults
+    assert [p.name for p in extra] == ["full_lidar_canvas"] and all(p.default is not inspect.Parameter.empty for p in extra)
     assert list(inspect.signature(LSSFPN.__init__).parameters)[1:] == [
         "x_bound", "y_bound", "z_bound", "d_bound", "final_dim", "downsample_factor", "output_channels",
         "img_backbone_conf", "img_neck_conf", "depth_net_conf"]

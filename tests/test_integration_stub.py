@@ -161,6 +161,54 @@ def test_fused_stub_equals_the_reference_op_sequence_through_the_extension_stub(
     assert torch.allclose(d1.grad, d2.grad, rtol=1e-4, atol=1e-5) and torch.allclose(c1.grad, c2.grad, rtol=1e-4, atol=1e-5)
 
 
+def _load_plan_stub():
+    """Sections D + F of INTEGRATION.md as one module (F is 'appended to' D's file)."""
+    from mm_training_amd import _lib
+    _lib.lib()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+    def block(begin, end):
+        sec = text[text.index(begin):text.index(end)]
+        code = sec[sec.index("```python\n") + len("```python\n"):]
+        return code[:code.index("\n```")]
+    code = block("## D. The fused camera path", "## E. The callers either side of the op") + "\n" + block("## F. The plan form of the fused forward", "## C. Other entry points")
+    assert "mmt_lss_splat_forward_plan" in code and "mmt_lss_plan_prepare" in code
+    mod = types.ModuleType("lss_fused_plan")
+    exec(compile(code.replace("/path/to/libmmt_hip.so", _lib.LIB_PATH), "INTEGRATION.md#D+F", "exec"), mod.__dict__)
+    return mod
+
+
+@pytest.mark.gpu
+def test_plan_form_stub_equals_the_camera_form_stub(mmt_lib):
+    """Section F (the plan form through ctypes, inside a torch.autograd.Function) against section D's op on the same inputs: the
+    map to fp32 summation order, the gradients bit for bit (same backward kernels on the summary the plan form hands back), the
+    same bits when the call is repeated."""
+    from mm_training_amd import synthetic
+    from tests.test_oracle_golden import _frustum_torch
+    m = _load_plan_stub()
+    B, N, C, H, W = 2, 3, 64, 64, 80
+    fr = _frustum_torch((H, W), 16, (2.0, 22.0, 2.0)).cuda()
+    D, fH, fW, _ = fr.shape
+    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=5)
+    lss = types.SimpleNamespace(frustum=fr, voxel_coord=torch.tensor([-50.8, -50.8, -1.0]), voxel_size=torch.tensor([0.8, 0.8, 8.0]),
+                                voxel_num=torch.tensor([128, 128, 1]))
+    g = torch.Generator().manual_seed(0)
+    depth = torch.rand(B * N, D, fH, fW, generator=g).softmax(1).cuda()
+    context = (torch.rand(B * N, C, fH, fW, generator=g) - 0.5).cuda()
+    go = torch.randn(B, C, 128, 128, generator=g).cuda()
+    d1, c1 = depth.clone().requires_grad_(True), context.clone().requires_grad_(True)
+    d2, c2 = depth.clone().requires_grad_(True), context.clone().requires_grad_(True)
+    prepared = m.plan_prepare(lss, s2e.cuda(), K.cuda())
+    bev = m.fused_lift_splat_plan(lss, d1, c1, prepared)
+    again = m.fused_lift_splat_plan(lss, depth, context, m.plan_prepare(lss, s2e.cuda(), K.cuda()))
+    assert torch.equal(bev.detach(), again)
+    ref = m.fused_lift_splat(lss, d2, c2, s2e.cuda(), K.cuda())
+    assert float((bev - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    bev.backward(go)
+    ref.backward(go)
+    assert torch.equal(d1.grad, d2.grad) and torch.equal(c1.grad, c2.grad)
+
+
 def _load_glue_stub():
     from mm_training_amd import _lib
     _lib.lib()
