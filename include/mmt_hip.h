@@ -33,7 +33,9 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 10  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive */
+#define MMT_ABI_VERSION 11  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
+                             * 11: region-owner voxelizer -- mmt_voxelize_table_elems / _scratch_elems / _workspace_elems take the point
+                             *     count / max_points as well; the table needs no zero fill and holds a cell directory */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -520,9 +522,9 @@ int mmt_lift_splat_backward_bf16(int B, int N, int D, int HW, int C, int num_vox
  *   voxel_count  int32 [B]   number of voxels of each sample (M_b <= max_voxels)
  * Voxels are numbered in order of their first point; <= max_points points per voxel,
  * first come first kept; voxels beyond max_voxels (in first-point order) are dropped.
- * workspace: int32, at least mmt_voxelize_workspace_elems(...) elements (device), any contents (this stateless
- * form clears its per-cell table itself; mmt_hard_voxelize_mean below avoids that pass). */
-int64_t mmt_voxelize_workspace_elems(int batch_size, int64_t total_points, const int32_t *grid_host);
+ * workspace: int32, at least mmt_voxelize_workspace_elems(...) elements (device), any contents (table + scratch of
+ * mmt_hard_voxelize_mean below in one buffer: every word the kernels read is written by them first). */
+int64_t mmt_voxelize_workspace_elems(int batch_size, int64_t total_points, const int32_t *grid_host, int max_points);
 int mmt_hard_voxelize(int batch_size, int64_t total_points, int num_features,
                       const float *points, const int32_t *point_offsets,
                       const float *voxel_size_host, const float *range_min_host,
@@ -531,20 +533,20 @@ int mmt_hard_voxelize(int batch_size, int64_t total_points, int num_features,
                       int32_t *workspace, void *stream);
 
 /* The same voxelization fused with the HardSimpleVFE mean (models/bev_depth.py:181-182 in one call; SURVEY
- * section 8 row a10: "fuse into a9's epilogue") and WITHOUT any clearing pass:
- *   table    int32 [mmt_voxelize_table_elems(B, grid)], 8-byte aligned, PERSISTENT: zero-filled ONCE by the
- *            caller after allocation, then handed to every call unchanged.  Its per-cell entries carry a
- *            generation stamp (a 40-bit counter kept in the table itself and advanced on the device by every
- *            call, so a captured hipGraph can be replayed), entries of earlier calls read as empty.  One table
- *            serves one stream at a time; after a failed call zero-fill it again.
- *   scratch  int32 [mmt_voxelize_scratch_elems(B, total_points)], any contents.
+ * section 8 row a10: "fuse into a9's epilogue"), no clearing pass, no memory atomics (ABI 11: the region-owner form --
+ * a workgroup per run of 1024..4096 consecutive cells settles them in LDS; lidar_voxelize.hip):
+ *   table    int32 [mmt_voxelize_table_elems(B, grid, total_points)], 8-byte aligned, any contents.  The call leaves the
+ *            cloud's CELL DIRECTORY in it (an occupancy bit per cell, block ordinals, the head point of every occupied
+ *            cell, the voxel id of every head) -- what mmt_pillar_scatter_nhwc_table[_strided] read instead of a
+ *            cell -> row map.  One table serves one stream at a time.
+ *   scratch  int32 [mmt_voxelize_scratch_elems(B, grid, total_points, max_points)], any contents.
  *   voxels   may be NULL: the padded [B*max_voxels, max_points, F] tensor is then not materialised
  *            (4*T*F bytes per voxel less traffic) -- what LidarEncoder.forward_bev does.
  *   mean     fp32 [B*max_voxels, num_features] or NULL: sum over the voxel's points (slot order) of the first
  *            num_features columns / num_points; rows past voxel_count[b] are written as zeros.
- * Other arguments and outputs as mmt_hard_voxelize.  total_points < 2^24. */
-int64_t mmt_voxelize_table_elems(int batch_size, const int32_t *grid_host);
-int64_t mmt_voxelize_scratch_elems(int batch_size, int64_t total_points);
+ * Other arguments and outputs as mmt_hard_voxelize.  total_points < 2^24, max_points <= 127. */
+int64_t mmt_voxelize_table_elems(int batch_size, const int32_t *grid_host, int64_t total_points);
+int64_t mmt_voxelize_scratch_elems(int batch_size, const int32_t *grid_host, int64_t total_points, int max_points);
 int mmt_hard_voxelize_mean(int batch_size, int64_t total_points, int num_features,
                            const float *points, const int32_t *point_offsets,
                            const float *voxel_size_host, const float *range_min_host,
@@ -592,9 +594,9 @@ int mmt_pillar_scatter_nhwc_backward(int64_t num_voxels, int C, int batch_size, 
                                      float *grad_feats, void *stream);
 
 /* Pillar scatter straight from the voxelizer's table (ABI 4; what LidarEncoder.forward_bev runs): for the fixed-capacity
- * rows of an mmt_hard_voxelize_mean call on `table` -- distinct cells by construction -- the canvas pass reads the table
- * entries (the emit kernel leaves generation | owned | voxel id in them) instead of building a cell -> row map: one kernel,
- * no fill, no atomics.  Must run on the same stream after that voxelization and before the next one on the table; needs a
+ * rows of an mmt_hard_voxelize_mean call on `table` -- distinct cells by construction -- the canvas pass walks the cell
+ * directory that call left (occupancy bit -> ordinal -> head point -> voxel id) instead of building a cell -> row map: one
+ * kernel, no fill, no atomics; a table no voxelization has written yields a canvas of NaN.  Must run on the same stream after that voxelization and before the next one on the table; needs a
  * single z layer and (ny, nx) = the voxel grid's (y, x); feats fp32 [B*max_voxels, C], canvas fp32 [B, ny, nx, C] fully written.
  * _unique_backward: grad_feats[m,:] = grad_canvas[cell(coors[m]),:] for rows whose coors are valid, 0 otherwise -- no map. */
 int mmt_pillar_scatter_nhwc_table(int C, int batch_size, int ny, int nx, int max_voxels, const float *voxel_features,

@@ -4,34 +4,35 @@
 // Replaces the third-party ops the reference reaches at models/bev_depth.py:181-183
 // (mmcv-full 1.7.0 ops.Voxelization, mmdet3d 1.0.0rc4 HardSimpleVFE and
 // PointPillarsScatter).  mmcv's deterministic GPU path compares every point with
-// every earlier point (O(N^2)) and numbers voxels in a single thread; here three
-// kernels, no memset, ONE scattered atomic per point (the scattered device-scope
-// atomic -- ~20 G/s chip-wide, MI355X_MICROARCH.md "Global float atomics" -- is what
-// bounds the first kernel, so there is exactly one):
-//   1. link  : per point, cell id; one 64-bit atomicExch on the cell's entry of a dense
-//              per-sample table threads the point onto its cell's chain.  Entries carry a
-//              GENERATION stamp in their upper 40 bits: an entry of an older call reads as
-//              "empty", so the table is never cleared (the round-1 version spent three
-//              memsets of dense per-cell tables, 34 MB, on 6 MB of points);
-//   2. heads : per 256-point tile, "is this point the first of its cell" by a chain walk
-//              that stops at the first earlier point; wave ballot + popcount -> rank of the
-//              head inside its tile and the tile's head count;
-//   3. emit  : per tile, offset = sum of the preceding tiles' head counts; voxel id of a
-//              head = offset + rank  ==> voxels numbered in order of their first point,
-//              exactly like the sequential algorithm; heads past max_voxels are dropped.
-//              Each head walks its cell's chain once, keeps the max_points smallest point
-//              indices sorted (LDS) and the tile then writes its voxels' rows -- a
-//              CONTIGUOUS block of the output, voxel ids of a tile are consecutive -- the
-//              zero padding, coors, num_points and the HardSimpleVFE mean (summed in slot
-//              order) as flat coalesced stores.  Rows past a sample's voxel count are
-//              marked empty (coors -1, num_points 0, mean 0) by the same kernel.
-// All samples of the batch go through each kernel together (flattened (sample, tile) space).
-// Round 3: a point whose cell holds nothing else (the table entry is the point itself and its link is empty -- the common
-// case: 93 % of the occupied 0.2 m cells of a 40 k-point cloud) is recognised in step 2 from ONE scattered read and flagged,
-// so step 3 emits it without touching the table or the chain links again (the two steps used to walk every chain twice).
-// A variant that merged steps 2 and 3 into one kernel (tile counts published in status words, decoupled look-back over
-// the earlier tiles) was built and measured: 38 us against 28 us at 4 x 40 k points -- every tile then pays several
-// round trips of uncached polls on its critical path -- and it hung once under rocprofv3; it was dropped.
+// every earlier point (O(N^2)) and numbers voxels in a single thread.
+//
+// Round 5: the REGION-OWNER form.  Rounds 1-4 threaded every point onto its cell's chain with one scattered 64-bit
+// atomicExch on a dense per-sample table in memory (160 k returning device-scope atomics at ~20 G/s = 8 us before anything
+// else happened), decided "first of its cell" by chain walks, and left the voxel ids in the table with one scattered write
+// per voxel: 28 us and 29 MB of traffic for 7 MB of points and outputs.  Here nothing is exchanged through memory atomics:
+//   1. cells : per point (coalesced): cell id -> the REGION it falls into (a run of R = 1024..4096 consecutive cells; one
+//              byte -- two when a grid has more than 254 regions) and the cell's position inside the region (16 bits);
+//   2. own   : one workgroup per (sample, region) streams the sample's region bytes (40 KB for 40 k points: every load is
+//              in flight at once), keeps the indices of ITS points in LDS, reads their cell positions (one gather) and
+//              settles every cell of the region in LDS: rounds of "smallest index not yet taken" (an LDS atomicMin per
+//              live point and round) give the cell's points in ascending order -- the first is the voxel's head, the
+//              next max_points - 1 go to the head's list in memory, the rest are dropped -- order-independent, so
+//              bit-reproducible.  It leaves: a count byte at the head's point (0 = not a head), and the region's slice
+//              of the sample's cell directory: an occupancy bit per cell, the ordinal of every 64-cell block's first
+//              occupied cell, and the head of every occupied cell in ordinal order -- all coalesced;
+//              It also leaves, per tile of 256 points, how many of ITS heads lie in front of that tile (a histogram over the
+//              heads' tiles + a prefix in LDS; row t, column r of a small table);
+//   3. emit  : per 256-point tile: row t of that table summed over the regions = the heads before the tile, the last row =
+//              the heads of the sample (clouds of more than 2 M points: every tile counts the sample's count bytes
+//              itself), a ballot + popcount over the tile's own count bytes the rank inside the tile:
+//              voxel id of a head = heads before it  ==> voxels numbered in order of their first point, exactly like
+//              the sequential algorithm; heads past max_voxels are dropped.  A head reads its list (contiguous), the
+//              tile then writes its voxels' rows -- a CONTIGUOUS block of the output -- the zero padding, coors,
+//              num_points and the HardSimpleVFE mean (summed in slot order) as flat coalesced stores, and the voxel id
+//              at the head's point index (the pillar scatter's last hop: cell -> bit -> ordinal -> head -> voxel id).
+//              Rows past a sample's voxel count are marked empty (coors -1, num_points 0, mean 0) by the same kernel.
+// The workgroups of a sample's regions sit on 8 / B XCDs (B | 8) or one (8 | B): what they all read is fetched into
+// that many L2s, not eight.
 #include "mmt_common.h"
 
 namespace {
@@ -39,11 +40,36 @@ namespace {
 constexpr int kTile = 256;            // points per tile / threads per workgroup (4 waves)
 constexpr int kTileWaves = kTile / 64;
 constexpr int kIdxBits = 24;          // point index inside its sample (host checks N < 2^24)
-constexpr unsigned long long kIdxMask = (1ull << kIdxBits) - 1ull;
-constexpr unsigned long long kOwnedBit = 1ull << (kIdxBits - 1);   // vox_emit: the entry now holds the cell's VOXEL ID (points < 2^23)
 constexpr int kMaxBatchLds = 255;     // sample offsets cached in LDS up to this batch size
-constexpr unsigned kMarkBit = 1u << 30;     // vox_link -> vox_heads, in a point's hrank word: a later point of this generation landed in its cell
-constexpr int kSingleBit = 1 << 20;   // hrank: the head's chain is the head alone (vox_emit then needs neither the table nor the links)
+constexpr int kInf = 0x7fffffff;
+constexpr int kEntries = 4096;        // vox_own: indices of the region's points waiting in LDS
+constexpr int kStreamDepth = 10;      // 16-byte loads of region ids in flight per thread (10 x 256 x 16 points: a 40 k cloud in one round trip)
+constexpr int kSlowChunk = kTile * 8; // points per step when a batch has to be done again step by step (vox_own)
+constexpr int kMinRegion = 1024, kMaxRegion = 4096;
+constexpr int kTableMagic = 0x32584f56;   // "VOX2": the table holds a cell directory of the region-owner form
+
+// the cell directory inside the caller's table (int32 units from its start; the table is 8-byte aligned)
+struct Directory {
+    int R, shift, NR;                 // cells per region (a power of two), log2 R, regions per sample
+    int64_t bits, pref, head_of, vidp, elems_without_vidp;
+};
+
+inline Directory directory_of(int B, int64_t cells) {
+    Directory d;
+    d.R = kMinRegion;
+    // regions large enough for a byte to name them and for two workgroups per CU (one per sample and region) to cover the batch
+    while (d.R < kMaxRegion && (mmt::ceil_div(cells, d.R) > 254 || (int64_t)B * mmt::ceil_div(cells, d.R) > 512)) d.R *= 2;
+    d.shift = 0;
+    while ((1 << d.shift) < d.R) ++d.shift;
+    d.NR = (int)mmt::ceil_div(cells, d.R);
+    const int64_t padded = (int64_t)B * d.NR * d.R;
+    d.bits = 4;                                   // uint64 [B * NR * R / 64]
+    d.pref = d.bits + padded / 32;                // uint16 [B * NR * R / 64]
+    d.head_of = d.pref + padded / 128;            // int32  [B * NR * R]   (a region's slice: its occupied cells' heads, in cell order)
+    d.vidp = d.head_of + padded;                  // int32  [total points] voxel id of a head point (-1: dropped by the voxel cap)
+    d.elems_without_vidp = d.vidp;
+    return d;
+}
 
 struct VoxArgs {
     int F, max_points, max_voxels, nf;
@@ -51,21 +77,34 @@ struct VoxArgs {
     float vs[3], rmin[3];
     const float *points;
     const int32_t *offsets;        // [B+1]
-    unsigned long long *table;     // [2 + B*cells]: [0] generation counter, [1] pad, then one entry per cell
-    int32_t *cell_of_point;        // [N]
-    int32_t *next;                 // [N] chain link (point index inside the sample, -1 = end)
-    int32_t *hrank;                // [N] rank of a head point among the heads of its tile, -1 = not a head
-    int32_t *tile_counts;          // [B*ntiles]
-    int32_t *gen_word;             // [1] the call's generation (low 30 bits) as vox_link used it, for vox_heads (table[0] changes under its feet)
+    int R, shift, NR, wide;        // directory_of; wide: region ids are 16 bits
+    int64_t cells;
+    // scratch, indexed by a point's FLAG POSITION fpos(b, i) = align16(offsets[b]) + 16 b + i (every sample's slice starts on a 16-byte boundary)
+    void *reg;                     // uint8 / uint16 region of the point (all ones: outside the grid)
+    unsigned short *cloc;          // the cell's position inside its region
+    unsigned char *flag;           // head: min(points of its cell, max_points); anything else: 0
+    unsigned short *tcum;          // [B][ntiles + 1][NR] heads of region r among the sample's points before tile t (NULL: emit counts the count bytes itself)
+    int32_t *lists;                // [N * (max_points - 1)] at a head's point: the cell's 2nd, 3rd, ... point (index inside the sample)
+    // table
+    int32_t *header;
+    unsigned long long *bits;
+    unsigned short *pref;
+    int32_t *head_of;
+    int32_t *vidp;
     int ntiles;
+    unsigned long long *stamps;    // -DVOX_STAMPS builds only (tools/scratch/vox_stamps.py): phase time stamps of the first 1024 workgroups
     float *voxels;                 // may be NULL (only the mean is wanted)
     int32_t *coors;
     int32_t *num_points;
     int32_t *voxel_count;
     float *mean;                   // may be NULL
-    int mark_owned;                // vox_emit leaves (generation | owned | voxel id) in the entries of the cells it emitted
 };
 
+#ifdef VOX_STAMPS
+#define VSTAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(blockIdx.x & 1023) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define VSTAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ int cell_coord(float p, float rmin, float vs) {
     // mmcv: int c = floor((p - range_min) / voxel_size)  (fp32; saturating convert, NaN -> 0)
     return (int)floorf(__fdiv_rn(__fsub_rn(p, rmin), vs));
@@ -77,6 +116,20 @@ __device__ __forceinline__ int sample_of_point(const int *offs, int B, int g) {
     while (b + 1 < B && g >= offs[b + 1]) ++b;
     return b;
 }
+
+// inclusive prefix sum across the 64 lanes of a wave on the DPP path (no LDS round trips): row_shr 1, 2, 4, 8 inside the rows of
+// 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+__device__ __forceinline__ int64_t flag_base(int beg, int b) { return (((int64_t)beg + 15) & ~(int64_t)15) + 16 * (int64_t)b; }
 
 // (sample, tile) of a workgroup in the flattened tile space: sample b owns max(ceil(n_b / kTile), 1) consecutive
 // workgroups (an empty sample keeps one: its rows still have to be marked empty).  Returns false past the last tile.
@@ -92,220 +145,522 @@ __device__ __forceinline__ bool locate_tile(const int32_t *offsets, int B, int w
     return false;
 }
 
-__global__ __launch_bounds__(kTile) void vox_link(VoxArgs a, int B, int total) {
+template <typename RT>
+__global__ __launch_bounds__(kTile) void vox_cells(VoxArgs a, int B, int total) {
     __shared__ int offs[kMaxBatchLds + 1];
     for (int i = threadIdx.x; i <= B && i <= kMaxBatchLds; i += kTile) offs[i] = a.offsets[i];
     __syncthreads();
-    const int64_t cells = (int64_t)a.gx * a.gy * a.gz;
-    // every workgroup reads the same value: the counter is advanced by the NEXT kernel of the call
-    const unsigned long long gen = a.table[0] + 1ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.gen_word[0] = (int)(kMarkBit | ((unsigned)gen & (kMarkBit - 1u)));
+    RT *reg = reinterpret_cast<RT *>(a.reg);
     for (int g = blockIdx.x * kTile + threadIdx.x; g < total; g += gridDim.x * kTile) {
         int b, beg;
         if (B <= kMaxBatchLds) { b = sample_of_point(offs, B, g); beg = offs[b]; }
         else { b = 0; while (b + 1 < B && g >= a.offsets[b + 1]) ++b; beg = a.offsets[b]; }
-        const int i = g - beg;
         const float *p = a.points + (int64_t)g * a.F;
         const int cx = cell_coord(p[0], a.rmin[0], a.vs[0]);
         const int cy = cell_coord(p[1], a.rmin[1], a.vs[1]);
         const int cz = cell_coord(p[2], a.rmin[2], a.vs[2]);
-        int cell = -1, nxt = -1;
+        unsigned r = ~0u, loc = 0;
         if (!(cx < 0 || cx >= a.gx || cy < 0 || cy >= a.gy || cz < 0 || cz >= a.gz)) {
-            cell = (cz * a.gy + cy) * a.gx + cx;
-            const unsigned long long old = atomicExch(&a.table[2 + (int64_t)b * cells + cell], (gen << kIdxBits) | (unsigned long long)i);
-            if ((old >> kIdxBits) == gen) {
-                nxt = (int)(old & kIdxMask);
-                // tell the point that was here before that it has company: vox_heads then recognises a cell's ONLY point from
-                // two coalesced words (its own link is empty and nobody marked it) without reading the table at all.  The mark
-                // carries the generation, so the word (the point's hrank slot, any contents before) is never cleared; a stale
-                // word that happens to equal the mark only sends a singleton down the general path.
-                a.hrank[beg + nxt] = (int)(kMarkBit | ((unsigned)gen & (kMarkBit - 1u)));
-            }
+            const int cell = (cz * a.gy + cy) * a.gx + cx;
+            r = (unsigned)cell >> a.shift;
+            loc = (unsigned)cell & (unsigned)(a.R - 1);
         }
-        a.cell_of_point[g] = cell;
-        a.next[g] = nxt;
+        const int64_t f = flag_base(beg, b) + (g - beg);
+        reg[f] = (RT)r;
+        a.cloc[f] = (unsigned short)loc;
+        a.flag[f] = 0;
+        if (g + 1 == (B <= kMaxBatchLds ? offs[b + 1] : a.offsets[b + 1]))      // the sample's last point also fills the slice up to its
+            for (int64_t q = f + 1; q & 15; ++q) { reg[q] = (RT)~0u; a.flag[q] = 0; }   // 16-element boundary: no region, not a head
     }
 }
 
-__global__ __launch_bounds__(kTile) void vox_heads(VoxArgs a, int B) {
-    __shared__ int wc[kTileWaves];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                        // vox_link of this call is done
-        a.table[0] += 1ull;
-        a.table[1] = a.mark_owned ? (1ull << 32) : 0ull;             // header word 1, bit 32: vox_emit leaves voxel ids in this generation's entries
+// which of the points of a streamed dword belong to the region (rrrr: its id in every byte / half): bit 8k+7 (bytes) / 16k+15
+// (halves) of the result for point k.  Exact (no borrow runs from a matching byte into the next), five operations
+__device__ __forceinline__ unsigned match_bytes(unsigned w, unsigned rrrr) {
+    const unsigned x = w ^ rrrr;
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ unsigned match_halves(unsigned w, unsigned rr) {
+    const unsigned x = w ^ rr;
+    return ~(((x & 0x7fff7fffu) + 0x7fff7fffu) | x) & 0x80008000u;
+}
+
+// LDS: head [R] | cur [R] | eidx [kEntries] | enext [kEntries] | filled (u8) [R]
+template <typename RT>
+__global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
+    extern __shared__ __align__(16) int lds[];
+    __shared__ int s_count, s_over;
+    __shared__ int wpop[kMaxRegion / 64], wpre[kMaxRegion / 64];
+    constexpr bool kWide = sizeof(RT) == 2;
+    const int R = a.R, T = a.max_points;
+    int *head = lds;
+    int *cur = head + R;
+    int *eidx = cur + R;
+    int *enext = eidx + kEntries;
+    unsigned char *filled = reinterpret_cast<unsigned char *>(enext + kEntries);
+    // (sample, region) of this workgroup.  Workgroup i runs on XCD i % 8: with B | 8 a sample's regions take 8 / B XCDs, with
+    // 8 | B one -- the region bytes and cell positions every workgroup of a sample reads then sit in that many L2s
+    VSTAMP(0);
+    int b, r;
+    {
+        const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        if (B <= 8 && 8 % B == 0) { const int xps = 8 / B; b = x / xps; r = q * xps + x % xps; }
+        else if (B % 8 == 0) { const int per = B / 8; b = x + 8 * (q % per); r = q / per; }
+        else { b = blockIdx.x / a.NR; r = blockIdx.x - b * a.NR; }
+        if (b >= B || r >= a.NR) return;
     }
-    int b, tile;
-    if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
     const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
-    if (tile * kTile >= n) {
-        if (threadIdx.x == 0) a.tile_counts[b * a.ntiles + tile] = 0;
-        return;
-    }
-    const int64_t cells = (int64_t)a.gx * a.gy * a.gz;
-    const unsigned long long *tab = a.table + 2 + (int64_t)b * cells;
-    const int i = tile * kTile + threadIdx.x;
+    const int64_t fb = flag_base(beg, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool h = false, single = false;
-    if (i < n) {
-        const int cell = a.cell_of_point[beg + i];
-        const int own_next = a.next[beg + i];                // coalesced; spares the scattered link read of a point's own entry
-        const int mark = a.hrank[beg + i];                   // coalesced: vox_link's "a later point joined your cell" (or anything else)
-        if (cell >= 0) {
-            const int joined = a.gen_word[0];             // (written by vox_link: the mark of this call)
-            if (own_next < 0 && mark != joined) {
-                // first into its cell and nobody after it: the cell's only point (87 % of the points of a 40 k cloud on a
-                // 0.2 m grid) -- a head, decided without touching the table or the links
-                h = true; single = true;
-            } else {
-                // head <=> no point of the chain comes earlier in the cloud (the chain holds every point of the cell)
-                h = true;
-                for (int j = (int)(tab[cell] & kIdxMask); j >= 0; j = (j == i) ? own_next : a.next[beg + j])
-                    if (j < i) { h = false; break; }
+    for (int c = threadIdx.x * 4; c < R; c += kTile * 4) {         // (16-byte LDS stores; R is a multiple of 1024)
+        *reinterpret_cast<int4 *>(head + c) = make_int4(kInf, kInf, kInf, kInf);
+        *reinterpret_cast<int4 *>(cur + c) = make_int4(kInf, kInf, kInf, kInf);
+        *reinterpret_cast<int *>(filled + c) = 0;
+    }
+    if (threadIdx.x == 0) { s_count = 0; s_over = 0; }
+    __syncthreads();
+
+    VSTAMP(1);
+    // settle what waits in eidx[0, count): every thread takes its share into registers and reads the cell positions (one gather);
+    // an LDS atomicExch per point threads it onto its cell's chain (arrival order: any); every point then walks its cell's chain
+    // once and knows its rank among the cell's points (those with a smaller index), the cell's smallest index and its count --
+    // order-independent, so bit-reproducible.  Rank 0 of a cell nobody had reached before is the voxel's head; ranks below
+    // max_points go to the head's list; the rest is dropped.  (A cell with very many points costs its points a long walk each;
+    // the walk of a dropped point ends as soon as it has seen max_points smaller indices.)
+    auto flush = [&](int count) {
+        constexpr int kPer = kEntries / kTile;
+        int idx[kPer], cl[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) idx[j] = j * kTile + threadIdx.x < count ? eidx[j * kTile + threadIdx.x] : -1;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) cl[j] = idx[j] >= 0 ? (int)a.cloc[fb + idx[j]] : 0;
+        VSTAMP(5);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (j * kTile >= count) break;
+            if (idx[j] >= 0) enext[j * kTile + threadIdx.x] = atomicExch(&cur[cl[j]], j * kTile + threadIdx.x);
+        }
+        __syncthreads();
+        int first[kPer];                                           // >= 0: this point is the smallest of its cell in this call -> the count to leave
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            first[j] = -1;
+            if (j * kTile >= count) break;
+            if (idx[j] < 0) continue;
+            const int c = cl[j], had = filled[c];
+            if (had >= T) continue;                                // (the cell already has its max_points: nothing of this call is kept)
+            int rank = 0, mn = idx[j], cnt = 0;
+            for (int e = cur[c]; e != kInf; e = enext[e]) {
+                const int v = eidx[e];
+                rank += v < idx[j] ? 1 : 0;
+                mn = v < mn ? v : mn;
+                ++cnt;
+                if (had + rank >= T) break;                        // dropped whatever follows
+            }
+            const int r = had + rank;
+            if (r < T) {
+                const int h = had > 0 ? head[c] : mn;
+                if (r > 0) a.lists[(int64_t)(beg + h) * (T - 1) + (r - 1)] = idx[j];
+                if (rank == 0) first[j] = had + cnt < T ? had + cnt : T;      // (rank 0 walked the whole chain: cnt is the cell's count)
             }
         }
-    }
-    const unsigned long long m = __ballot(h);
-    if (lane == 0) wc[wave] = __popcll(m);
-    __syncthreads();
-    int woff = 0, total = 0;
+        __syncthreads();                                           // every walk is over: the cells' states may change
 #pragma unroll
-    for (int w = 0; w < kTileWaves; ++w) {
-        const int c = wc[w];
-        if (w < wave) woff += c;
-        total += c;
+        for (int j = 0; j < kPer; ++j) {
+            if (j * kTile >= count) break;
+            if (idx[j] < 0) continue;
+            const int c = cl[j];
+            if (first[j] >= 0) {
+                if (filled[c] == 0) head[c] = idx[j];
+                filled[c] = (unsigned char)first[j];
+            }
+            cur[c] = kInf;                                         // (every point of the cell writes the same value)
+        }
+        __syncthreads();
+    };
+
+    // ---- stream the sample's region ids: 16 bytes per thread and step (16 points; 8 when the ids are 16 bits wide),
+    // kStreamDepth steps in flight.  A step's four dwords become ONE mask of the points that fall into region r; a thread counts
+    // its matches of the whole batch, reserves their places in the list with one LDS atomic and writes them (a region's share of
+    // 40 k points is a few hundred indices: the first match of a step without a loop, further ones in a loop few waves enter).
+    // Should the list overflow -- a cloud packed into few regions -- the batch is done again step by step, settling the list
+    // whenever the next step could overflow it (later steps only hold larger indices: the cells' lists stay ascending).
+    const RT *reg = reinterpret_cast<const RT *>(a.reg) + fb;
+    const int npad = (n + 15) & ~15;                               // (vox_cells filled the slice up to here: no region)
+    const unsigned rrrr = kWide ? (unsigned)r * 0x00010001u : (unsigned)r * 0x01010101u;
+    constexpr int kPts = kWide ? 8 : 16;                           // points per 16-byte load
+    constexpr int kChunk = kTile * kPts;
+    // point of mask bit j inside its step: bytes -- bit 8k + d is byte k of dword d; halves -- bit 16k + d is half k of dword d
+    auto point_of = [](int j) { return kWide ? (j & 15) * 2 + (j >> 4) : (j & 7) * 4 + (j >> 3); };
+    // every workgroup of the sample reads the same bytes: each starts at another step (registers in rotated order)
+    const int rot = (int)((unsigned)(r * 7 + b * 3) % kStreamDepth);
+    auto step_of = [&](int u) { const int x = u + rot; return x >= kStreamDepth ? x - kStreamDepth : x; };
+    for (int base = 0; base < n; base += kChunk * kStreamDepth) {
+        unsigned w[kStreamDepth];
+        {
+            uint4 v[kStreamDepth];
+#pragma unroll
+            for (int u = 0; u < kStreamDepth; ++u) {
+                const int p = base + step_of(u) * kChunk + threadIdx.x * kPts;
+                v[u] = p < npad ? *reinterpret_cast<const uint4 *>(reg + p) : make_uint4(~0u, ~0u, ~0u, ~0u);
+            }
+#pragma unroll
+            for (int u = 0; u < kStreamDepth; ++u) {
+                if (kWide) w[u] = (match_halves(v[u].x, rrrr) >> 15) | (match_halves(v[u].y, rrrr) >> 14) | (match_halves(v[u].z, rrrr) >> 13) | (match_halves(v[u].w, rrrr) >> 12);
+                else w[u] = (match_bytes(v[u].x, rrrr) >> 7) | (match_bytes(v[u].y, rrrr) >> 6) | (match_bytes(v[u].z, rrrr) >> 5) | (match_bytes(v[u].w, rrrr) >> 4);
+            }
+        }
+        VSTAMP(6);
+        int before = 0;
+        if (base > 0) { before = s_count; __syncthreads(); }      // (uniform: nobody appends between the last barrier and this one)
+        int mine = 0;
+#pragma unroll
+        for (int u = 0; u < kStreamDepth; ++u) mine += __popc(w[u]);
+        // places in the list: a prefix sum inside the wave, ONE LDS atomic per wave (256 returning atomics on one LDS word cost 3 us)
+        const int incl = wave_incl_scan(mine);
+        int wbase = 0;
+        if (lane == 63 && incl > 0) wbase = atomicAdd(&s_count, incl);
+        int pos = __builtin_amdgcn_readlane(wbase, 63) + incl - mine;
+        if (pos + mine <= kEntries) {
+            unsigned rest = 0;
+#pragma unroll
+            for (int u = 0; u < kStreamDepth; ++u) {               // a step's first match
+                if (w[u]) {
+                    eidx[pos++] = base + step_of(u) * kChunk + threadIdx.x * kPts + point_of(__ffs((int)w[u]) - 1);
+                    w[u] &= w[u] - 1;
+                }
+                rest |= w[u];
+            }
+            if (__any(rest != 0)) {
+#pragma unroll
+                for (int u = 0; u < kStreamDepth; ++u)
+                    while (w[u]) {
+                        eidx[pos++] = base + step_of(u) * kChunk + threadIdx.x * kPts + point_of(__ffs((int)w[u]) - 1);
+                        w[u] &= w[u] - 1;
+                    }
+            }
+        }
+        // did everything fit?  One barrier decides for everybody: the count only grows, and the thread whose reservation came
+        // last reads the full count afterwards, so the OR of "what I see is past the end" is the exact answer
+        VSTAMP(7);
+        if (s_count > kEntries) s_over = 1;
+        __syncthreads();
+        if (s_over) {
+            __syncthreads();
+            if (threadIdx.x == 0) { s_count = before; s_over = 0; }
+            __syncthreads();
+            const int end = base + kChunk * kStreamDepth < n ? base + kChunk * kStreamDepth : n;
+            for (int p0 = base; p0 < end; p0 += kSlowChunk) {     // ascending steps of 8 points per thread, read again
+                if (__syncthreads_or(s_count > kEntries - kSlowChunk ? 1 : 0)) {     // could this step overflow the list?  (same argument)
+                    flush(s_count);
+                    if (threadIdx.x == 0) s_count = 0;
+                    __syncthreads();
+                }
+                const int p = p0 + threadIdx.x * 8;
+                if (p >= npad) continue;                           // (no barrier below)
+                unsigned v[kWide ? 4 : 2];
+                if (kWide) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(reg + p);
+                    v[0] = q.x; v[1] = q.y; v[kWide ? 2 : 0] = q.z; v[kWide ? 3 : 1] = q.w;
+                } else {
+                    const uint2 q = *reinterpret_cast<const uint2 *>(reg + p);
+                    v[0] = q.x; v[1] = q.y;
+                }
+#pragma unroll
+                for (int d = 0; d < (kWide ? 4 : 2); ++d) {
+                    unsigned m = kWide ? match_halves(v[d], rrrr) : match_bytes(v[d], rrrr);
+                    while (m) {
+                        const int k = (__ffs((int)m) - 1) >> (kWide ? 4 : 3);
+                        m &= m - 1;
+                        eidx[atomicAdd(&s_count, 1)] = p + d * (kWide ? 2 : 4) + k;
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
-    // rank of a head inside its tile (< 256), bit kSingleBit: its cell holds no other point
-    if (i < n) a.hrank[beg + i] = h ? ((woff + __popcll(m & ((1ull << lane) - 1ull))) | (single ? kSingleBit : 0)) : -1;
-    if (threadIdx.x == 0) a.tile_counts[b * a.ntiles + tile] = total;
+    VSTAMP(2);
+    {
+        const int count = s_count;
+        if (count > 0) flush(count);
+    }
+    // heads per 256-point tile (for vox_emit: the heads in front of a tile): histogram in the list's LDS, which is free now
+    int *thist = eidx;
+    const int my_tiles = (n + kTile - 1) / kTile;
+    if (a.tcum)
+        for (int t = threadIdx.x; t <= my_tiles; t += kTile) thist[t] = 0;
+    __syncthreads();
+    VSTAMP(3);
+
+    // ---- the region's slice of the directory: occupancy bits, block ordinals, heads in cell order; the count byte at every head
+    const int nwords = R >> 6;
+    const int64_t region = (int64_t)b * a.NR + r;
+    // A thread takes 8 consecutive cells per pass (a wave 512: eight 64-cell blocks, a block = 8 lanes): one LDS round trip for
+    // the heads and counts, the block's occupancy word by three DPP ORs across its 8 lanes, a cell's ordinal from the block's
+    // ordinal (a scan over the region's <= 64 blocks by one wave) + the occupied cells before it inside the word.
+    const int passes = R > kTile * 8 ? R / (kTile * 8) : 1;        // 1 (half of the threads idle in a region of 1024 cells), 2 or 4
+    unsigned long long word[kMaxRegion / (kTile * 8)];
+    int hd[kMaxRegion / (kTile * 8)][8];
+    unsigned long long fl8[kMaxRegion / (kTile * 8)];
+#pragma unroll
+    for (int ps = 0; ps < kMaxRegion / (kTile * 8); ++ps) {
+        if (ps >= passes) break;
+        const int c0 = (ps * kTile + threadIdx.x) * 8;
+        const bool in = c0 < R;                                    // (whole blocks of 8 lanes are in or out)
+        const int4 none = make_int4(kInf, kInf, kInf, kInf);
+        const int4 h0 = in ? *reinterpret_cast<const int4 *>(head + c0) : none, h1 = in ? *reinterpret_cast<const int4 *>(head + c0 + 4) : none;
+        fl8[ps] = in ? *reinterpret_cast<const unsigned long long *>(filled + c0) : 0ull;
+        hd[ps][0] = h0.x; hd[ps][1] = h0.y; hd[ps][2] = h0.z; hd[ps][3] = h0.w;
+        hd[ps][4] = h1.x; hd[ps][5] = h1.y; hd[ps][6] = h1.z; hd[ps][7] = h1.w;
+        unsigned m8 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            m8 |= (hd[ps][k] != kInf ? 1u : 0u) << k;
+            if (a.tcum && hd[ps][k] != kInf) atomicAdd(&thist[hd[ps][k] >> 8], 1);
+        }
+        const int sub = lane & 7;
+        unsigned lo = sub < 4 ? m8 << (8 * sub) : 0u, hi = sub >= 4 ? m8 << (8 * (sub - 4)) : 0u;
+        // OR across the 8 lanes of the block: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+        lo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false); hi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+        lo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false); hi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
+        lo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x141, 0xF, 0xF, false); hi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x141, 0xF, 0xF, false);
+        word[ps] = ((unsigned long long)hi << 32) | lo;
+        if (sub == 0 && in) {
+            const int wi = (ps * kTile + threadIdx.x) >> 3;         // the block's index inside the region
+            wpop[wi] = __popcll(word[ps]);
+            a.bits[region * nwords + wi] = word[ps];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int v = lane < nwords ? wpop[lane] : 0;
+        const int incl = wave_incl_scan(v);
+        if (lane < nwords) { wpre[lane] = incl - v; a.pref[region * nwords + lane] = (unsigned short)(incl - v); }
+    } else if (wave == 1 && a.tcum) {
+        // exclusive prefix over the tiles (64 at a time, carried on), left as row t of the sample's table, column r
+        unsigned short *row = a.tcum + (int64_t)b * (a.ntiles + 1) * a.NR + r;
+        int carry = 0;
+        for (int t0 = 0; t0 <= my_tiles; t0 += 64) {
+            const int t = t0 + lane;
+            const int v = t <= my_tiles ? thist[t] : 0;
+            const int incl = wave_incl_scan(v);
+            if (t <= my_tiles) row[(int64_t)t * a.NR] = (unsigned short)(carry + incl - v);
+            carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < kMaxRegion / (kTile * 8); ++ps) {
+        if (ps >= passes) break;
+        const int wi = (ps * kTile + threadIdx.x) >> 3, sub = lane & 7;
+        int ord = (wi < nwords ? wpre[wi] : 0) + __popcll(word[ps] & ((1ull << (8 * sub)) - 1ull));
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (hd[ps][k] != kInf) {
+                a.head_of[region * R + ord++] = beg + hd[ps][k];
+                a.flag[fb + hd[ps][k]] = (unsigned char)(fl8[ps] >> (8 * k));
+            }
+    }
+    VSTAMP(4);
 }
+
+// nonzero bytes of a dword of count bytes (each < 128: max_points <= 127), added to acc
+__device__ __forceinline__ int nonzero_bytes(unsigned v, int acc) { return acc + __popc((v + 0x7f7f7f7fu) & 0x80808080u); }
 
 // LDS: lists [kTile][T] sorted point indices | cnt [kTile] | cellv [kTile].  FT = compile-time F (0 = any)
 template <int FT>
 __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     extern __shared__ __align__(16) int lds[];
-    __shared__ int s_off, s_total, s_mine;
+    __shared__ int s_before[kTileWaves], s_all[kTileWaves], s_heads[kTileWaves];
     const int T = a.max_points, F = FT > 0 ? FT : a.F, V = a.max_voxels;
     const int TF = T * F;
     int *lists = lds;
     int *cnt = lists + kTile * T;
     int *cellv = cnt + kTile;
+    VSTAMP(8);
     int b, tile;
     if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
     const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
+    VSTAMP(9);
     const int my_tiles = (n + kTile - 1) / kTile;
-    const int64_t cells = (int64_t)a.gx * a.gy * a.gz;
-    const unsigned long long *tab = a.table + 2 + (int64_t)b * cells;
+    const int64_t fb = flag_base(beg, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.header[0] = kTableMagic;
 
-    // this point's head rank and cell: requested BEFORE the prefix over the tile counts (they do not depend on it; behind the
-    // barrier they were one more round trip on the kernel's critical path)
+    // this point's count byte and cell: requested together with the stream of the sample's count bytes
     const int i = tile * kTile + threadIdx.x;
-    int hr = -1, my_cell = -1;
-    if (i < n) { hr = a.hrank[beg + i]; my_cell = a.cell_of_point[beg + i]; }
-    // heads before this tile / in the whole sample (a few hundred tile counts at most)
-    if (wave == 0) {
-        int before = 0, all = 0, mine = 0;
-        for (int t = lane; t < my_tiles; t += 64) {
-            const int c = a.tile_counts[b * a.ntiles + t];
-            all += c;
-            if (t < tile) before += c;
-            if (t == tile) mine = c;
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            before += __shfl_down(before, o);
-            all += __shfl_down(all, o);
-            mine += __shfl_down(mine, o);
-        }
-        if (lane == 0) { s_off = before; s_total = all; s_mine = mine; }
+    int fl = 0, my_cell = -1;
+    if (i < n) {
+        fl = a.flag[fb + i];
+        const unsigned rg = a.wide ? reinterpret_cast<const unsigned short *>(a.reg)[fb + i] : reinterpret_cast<const unsigned char *>(a.reg)[fb + i];
+        my_cell = (int)((rg << a.shift) | a.cloc[fb + i]);
     }
+    // heads before this tile / in the whole sample: the nonzero count bytes (16 per load, kFlagDepth loads in flight; the slice
+    // is 16-byte aligned)
+    int before = 0, all = 0;
+    if (a.tcum) {                                               // vox_own left the heads in front of every tile, per region: two rows to add up
+        const unsigned short *rows = a.tcum + (int64_t)b * (a.ntiles + 1) * a.NR;
+        for (int q = threadIdx.x; q < a.NR; q += kTile) {
+            before += rows[(int64_t)tile * a.NR + q];
+            all += rows[(int64_t)my_tiles * a.NR + q];
+        }
+    } else {
+        constexpr int kFlagDepth = 10;                          // 10 x 256 x 16 bytes: a 40 k cloud in one round trip
+        const uint4 *fw = reinterpret_cast<const uint4 *>(a.flag + fb);
+        const int nw = (n + 15) >> 4, bw = tile * (kTile / 16);
+        const int rot = (int)((unsigned)(tile * 3) % kFlagDepth);
+        auto frot = [&](int u) { const int x = u + rot; return x >= kFlagDepth ? x - kFlagDepth : x; };
+        for (int w0 = 0; w0 < nw; w0 += kTile * kFlagDepth) {
+            uint4 v[kFlagDepth];
+#pragma unroll
+            for (int u = 0; u < kFlagDepth; ++u) {                  // (every tile of the sample reads these bytes: each starts at another step)
+                const int w = w0 + frot(u) * kTile + threadIdx.x;
+                v[u] = w < nw ? fw[w] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < kFlagDepth; ++u) {                  // (vox_cells zeroed the bytes between the sample's end and the 16-byte boundary)
+                const int c = nonzero_bytes(v[u].x, nonzero_bytes(v[u].y, nonzero_bytes(v[u].z, nonzero_bytes(v[u].w, 0))));
+                all += c;
+                if (w0 + frot(u) * kTile + (int)threadIdx.x < bw) before += c;
+            }
+        }
+    }
+    VSTAMP(13);
+    const bool h = fl != 0;
+    const unsigned long long m = __ballot(h);
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_down(before, o);
+        all += __shfl_down(all, o);
+    }
+    if (lane == 0) { s_before[wave] = before; s_all[wave] = all; s_heads[wave] = __popcll(m); }
     __syncthreads();
-    const int off = s_off;
-    const int M = s_total < V ? s_total : V;            // voxels of this sample
+    int off = 0, total = 0, woff = 0, nheads = 0;
+#pragma unroll
+    for (int w = 0; w < kTileWaves; ++w) {
+        off += s_before[w];
+        total += s_all[w];
+        if (w < wave) woff += s_heads[w];
+        nheads += s_heads[w];
+    }
+    const int M = total < V ? total : V;                // voxels of this sample
     if (tile == 0 && threadIdx.x == 0) a.voxel_count[b] = M;
-    const int nheads = s_mine;
     const int nown = (off + nheads <= V) ? nheads : (V - off > 0 ? V - off : 0);   // heads of this tile below the cap
 
-    // ---- every owning head walks its chain once: the T smallest point indices, sorted, in LDS
-    if (i < n) {
-        const int r = hr < 0 ? -1 : (hr & (kSingleBit - 1));
-        if (r >= 0 && r < nown) {
-            const int cell = my_cell;
+    VSTAMP(10);
+    // ---- every head: its voxel id (heads before it), its list into LDS
+    if (h) {
+        const int r = woff + __popcll(m & ((1ull << lane) - 1ull));
+        a.vidp[beg + i] = r < nown ? off + r : -1;
+        if (r < nown) {
             int *L = lists + r * T;
-            int c = 0;
-            if (hr & kSingleBit) {                          // the whole chain, known since vox_heads
-                L[0] = i;
-                c = 1;
-            } else {
-                for (int j = (int)(tab[cell] & kIdxMask); j >= 0; j = a.next[beg + j]) {
-                    if (c == T && j > L[T - 1]) continue;
-                    int k = c < T ? c : T - 1;              // insertion position search from the top
-                    while (k > 0 && L[k - 1] > j) { L[k] = L[k - 1]; --k; }
-                    L[k] = j;
-                    if (c < T) ++c;
-                }
-            }
-            cnt[r] = c;
-            cellv[r] = cell;
-            // the chain has been read: the cell's entry now names its voxel, (generation | owned | voxel id), for the pillar
-            // scatter that follows (mmt_pillar_scatter_nhwc_table reads the table instead of building a cell -> row map)
-            if (a.mark_owned) a.table[2 + (int64_t)b * cells + cell] = (a.table[0] << kIdxBits) | kOwnedBit | (unsigned long long)(off + r);
+            L[0] = i;
+            const int32_t *src = a.lists + (int64_t)(beg + i) * (T - 1);
+            for (int k = 1; k < fl; ++k) L[k] = src[k - 1];
+            cnt[r] = fl;
+            cellv[r] = my_cell;
         }
     }
     __syncthreads();
 
+    VSTAMP(11);
     // ---- the tile's voxels are rows [off, off + nown) of the sample: flat, coalesced stores.  (row, element) of a
     // flat index advance incrementally (no integer division per element: (slot, column) of an element come from qmap)
     const int64_t row0 = (int64_t)b * V + off;
     if (a.voxels) {
-        // one (voxel, slot) per thread and trip: the point's F floats are requested together and stored as one
+        // one (voxel, slot) per thread and trip, four trips requested together: the point's F floats are stored as one
         // contiguous F*4-byte piece (the slots of a tile's voxels are one contiguous block of the output)
         float *dst = a.voxels + row0 * TF;
         const int total = nown * T;
-        int r = threadIdx.x / T, t = threadIdx.x - r * T;
-        const int dr = kTile / T, dt = kTile - dr * T;
-        for (int e = threadIdx.x; e < total; e += kTile) {
-            const bool live = t < cnt[r];
-            const float *src = a.points + (int64_t)(beg + (live ? lists[r * T + t] : 0)) * F;
-            float *d = dst + (int64_t)e * F;
+        constexpr int kU = 4, kFmax = FT > 0 ? FT : 1;
+        for (int e0 = threadIdx.x; e0 < total; e0 += kTile * kU) {
             if (FT > 0) {
-                float v[FT > 0 ? FT : 1];
+                float v[kU][kFmax];
 #pragma unroll
-                for (int f = 0; f < FT; ++f) v[f] = live ? src[f] : 0.f;
+                for (int u = 0; u < kU; ++u) {
+                    const int e = e0 + u * kTile;
+                    const int r = e < total ? e / T : 0, t = e < total ? e - r * T : 0;
+                    const bool live = e < total && t < cnt[r];
+                    const float *src = a.points + (int64_t)(beg + (live ? lists[r * T + t] : 0)) * F;
 #pragma unroll
-                for (int f = 0; f < FT; ++f) d[f] = v[f];
+                    for (int f = 0; f < kFmax; ++f) v[u][f] = live ? src[f] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int e = e0 + u * kTile;
+                    if (e < total) {
+#pragma unroll
+                        for (int f = 0; f < kFmax; ++f) dst[(int64_t)e * F + f] = v[u][f];
+                    }
+                }
             } else {
-                for (int f = 0; f < F; ++f) d[f] = live ? src[f] : 0.f;
+                for (int u = 0; u < kU; ++u) {
+                    const int e = e0 + u * kTile;
+                    if (e >= total) break;
+                    const int r = e / T, t = e - r * T;
+                    const bool live = t < cnt[r];
+                    const float *src = a.points + (int64_t)(beg + (live ? lists[r * T + t] : 0)) * F;
+                    for (int f = 0; f < F; ++f) dst[(int64_t)e * F + f] = live ? src[f] : 0.f;
+                }
             }
-            r += dr; t += dt;
-            if (t >= T) { t -= T; ++r; }
         }
     }
     if (a.mean) {
         const int nf = a.nf;
-        float *dst = a.mean + row0 * nf;
-        const int total = nown * nf;
-        int r = threadIdx.x / nf, k = threadIdx.x - r * nf;
-        const int dr = kTile / nf, dk = kTile - dr * nf;
-        for (int e = threadIdx.x; e < total; e += kTile) {
-            const int c = cnt[r];
-            const int *L = lists + r * T;
-            float sum = 0.f;
-            for (int t = 0; t < c; ++t) sum = __fadd_rn(sum, a.points[(int64_t)(beg + L[t]) * F + k]);
-            dst[e] = __fdiv_rn(sum, (float)c);          // zero-padded slots add nothing; c >= 1
-            r += dr; k += dk;
-            if (k >= nf) { k -= nf; ++r; }
+        if (FT > 0) {
+            // a voxel per thread: its points' rows four at a time (all requested before any is used), added in slot order
+            constexpr int kFmax = FT > 0 ? FT : 1;
+            for (int r = threadIdx.x; r < nown; r += kTile) {
+                const int c = cnt[r];
+                const int *L = lists + r * T;
+                float acc[kFmax];
+#pragma unroll
+                for (int f = 0; f < kFmax; ++f) acc[f] = 0.f;
+                for (int t0 = 0; t0 < c; t0 += 4) {
+                    float v[4][kFmax];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float *src = a.points + (int64_t)(beg + L[t0 + u < c ? t0 + u : 0]) * FT;
+#pragma unroll
+                        for (int f = 0; f < kFmax; ++f) v[u][f] = src[f];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (t0 + u < c) {
+#pragma unroll
+                            for (int f = 0; f < kFmax; ++f) acc[f] = __fadd_rn(acc[f], v[u][f]);
+                        }
+                }
+                float *dst = a.mean + (row0 + r) * nf;
+#pragma unroll
+                for (int f = 0; f < kFmax; ++f)
+                    if (f < nf) dst[f] = __fdiv_rn(acc[f], (float)c);     // zero-padded slots add nothing; c >= 1
+            }
+        } else {
+            float *dst = a.mean + row0 * nf;
+            const int total = nown * nf;
+            int r = threadIdx.x / nf, k = threadIdx.x - r * nf;
+            const int dr = kTile / nf, dk = kTile - dr * nf;
+            for (int e = threadIdx.x; e < total; e += kTile) {
+                const int c = cnt[r];
+                const int *L = lists + r * T;
+                float sum = 0.f;
+                for (int t = 0; t < c; ++t) sum = __fadd_rn(sum, a.points[(int64_t)(beg + L[t]) * F + k]);
+                dst[e] = __fdiv_rn(sum, (float)c);
+                r += dr; k += dk;
+                if (k >= nf) { k -= nf; ++r; }
+            }
         }
     }
-    for (int e = threadIdx.x; e < nown * 4; e += kTile) {
-        const int r = e >> 2, k = e & 3;
+    for (int r = threadIdx.x; r < nown; r += kTile) {
         const int cell = cellv[r];
-        int v = b;
-        if (k == 1) v = cell / (a.gx * a.gy);
-        else if (k == 2) v = (cell / a.gx) % a.gy;
-        else if (k == 3) v = cell % a.gx;
-        a.coors[row0 * 4 + e] = v;
+        const int plane = a.gx * a.gy;
+        const int z = cell / plane, rem = cell - z * plane;
+        const int y = rem / a.gx;
+        reinterpret_cast<int4 *>(a.coors)[row0 + r] = make_int4(b, z, y, rem - y * a.gx);
+        a.num_points[row0 + r] = cnt[r];
     }
-    for (int e = threadIdx.x; e < nown; e += kTile) a.num_points[row0 + e] = cnt[e];
 
+    VSTAMP(12);
     // ---- rows past the sample's voxel count: marked empty; each tile takes an equal share of them
     const int tiles = my_tiles > 0 ? my_tiles : 1;
     const int dead = V - M;
@@ -441,45 +796,88 @@ __global__ __launch_bounds__(256) void scatter_backward_kernel(int64_t M, int C,
 
 namespace {
 
+#ifdef VOX_STAMPS
+unsigned long long *g_vox_stamps = nullptr;
+#endif
 int64_t vox_tiles(int64_t N) { return mmt::ceil_div(N > 0 ? N : 1, kTile); }
 
 int vox_check(const char *what, int B, int64_t N, int F, const int32_t *grid_host, int max_points, int max_voxels, int nf) {
-    if (B <= 0 || B > 65535 || N < 0 || F < 3 || max_points <= 0 || max_voxels <= 0 || nf < 0 || nf > F)
+    if (B <= 0 || B > 65535 || N < 0 || F < 3 || max_points <= 0 || max_points > 127 || max_voxels <= 0 || nf < 0 || nf > F)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: bad sizes (B=%d N=%lld F=%d T=%d max_voxels=%d nf=%d)", what, B, (long long)N, F, max_points, max_voxels, nf);
     if (grid_host[0] <= 0 || grid_host[1] <= 0 || grid_host[2] <= 0)
         return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: non-positive grid", what);
     const int64_t cells = (int64_t)grid_host[0] * grid_host[1] * grid_host[2];
     if (cells * B >= (1ll << 31) || cells >= (1ll << 31) || N >= (1ll << kIdxBits))
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: B*cells exceeds int32 or N >= 2^24 points", what);
+    if (mmt::ceil_div(cells, kMaxRegion) > 65534)
+        return mmt::fail(MMT_ERR_TOO_LARGE, "%s: more than 65534 regions of %d cells", what, kMaxRegion);
     if ((size_t)(kTile * (int64_t)max_points + 2 * kTile) * 4 > 150 * 1024)
         return mmt::fail(MMT_ERR_TOO_LARGE, "%s: max_points=%d too large for the LDS index lists", what, max_points);
     return 0;
 }
 
-// the three kernels of one voxelization (table: 8-byte aligned, generation-stamped; scratch: any contents)
+int64_t align4(int64_t ints) { return (ints + 3) & ~(int64_t)3; }
+
+// scratch (int32 units; every part starts on a 16-byte boundary of the aligned base): lists | region ids | cell positions | count bytes
+constexpr int64_t kMaxTcumTiles = 2 * kEntries - 1;            // vox_own's tile histogram lives in the list's LDS (2 x kEntries ints)
+struct ScratchLayout { int64_t lists, reg, cloc, flag, tcum, elems; };
+ScratchLayout scratch_layout(int B, int64_t N, int max_points, bool wide, int NR) {
+    ScratchLayout l;
+    const int64_t slots = N + 32 * (int64_t)B + 32;          // flag positions (flag_base: every sample's slice 16-byte aligned)
+    l.lists = 0;
+    l.reg = l.lists + align4(N * (max_points > 1 ? max_points - 1 : 0));
+    l.cloc = l.reg + align4(mmt::ceil_div(slots * (wide ? 2 : 1), 4));
+    l.flag = l.cloc + align4(mmt::ceil_div(slots * 2, 4));
+    l.tcum = l.flag + align4(mmt::ceil_div(slots, 4));
+    l.elems = l.tcum + align4(mmt::ceil_div((int64_t)B * (vox_tiles(N) + 1) * NR, 2)) + 4;  // + 4: the base is aligned up to 16 bytes
+    return l;
+}
+
+// the three kernels of one voxelization (table: 8-byte aligned, any contents; scratch: any contents)
 int vox_run(const char *what, int B, int64_t N, int F, const float *points, const int32_t *point_offsets,
             const float *voxel_size_host, const float *range_min_host, const int32_t *grid_host, int max_points,
             int max_voxels, int nf, float *voxels, int32_t *coors, int32_t *num_points, int32_t *voxel_count,
-            float *mean, unsigned long long *table, int32_t *scratch, hipStream_t st) {
+            float *mean, int32_t *table, int32_t *scratch, hipStream_t st) {
     VoxArgs a;
     a.F = F; a.max_points = max_points; a.max_voxels = max_voxels; a.nf = nf;
     a.gx = grid_host[0]; a.gy = grid_host[1]; a.gz = grid_host[2];
     for (int k = 0; k < 3; ++k) { a.vs[k] = voxel_size_host[k]; a.rmin[k] = range_min_host[k]; }
     a.points = points; a.offsets = point_offsets;
     a.ntiles = (int)vox_tiles(N);
-    a.table = table;
-    a.cell_of_point = scratch;
-    a.next = a.cell_of_point + N;
-    a.hrank = a.next + N;
-    a.tile_counts = a.hrank + N;
-    a.gen_word = a.tile_counts + (int64_t)B * a.ntiles;          // (mmt_voxelize_scratch_elems leaves 16 spare words)
+    a.stamps = nullptr;
+#ifdef VOX_STAMPS
+    { static unsigned long long *buf = nullptr; if (!buf) (void)hipMalloc(&buf, 1024 * 16 * 8); a.stamps = buf; g_vox_stamps = buf; }
+#endif
+    a.cells = (int64_t)a.gx * a.gy * a.gz;
+    const Directory d = directory_of(B, a.cells);
+    a.R = d.R; a.shift = d.shift; a.NR = d.NR; a.wide = d.NR > 254 ? 1 : 0;
+    a.header = table;
+    a.bits = reinterpret_cast<unsigned long long *>(table + d.bits);
+    a.pref = reinterpret_cast<unsigned short *>(table + d.pref);
+    a.head_of = table + d.head_of;
+    a.vidp = table + d.vidp;
+    int32_t *base = reinterpret_cast<int32_t *>(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
+    const ScratchLayout l = scratch_layout(B, N, max_points, a.wide != 0, d.NR);
+    a.lists = base + l.lists;
+    a.reg = base + l.reg;
+    a.cloc = reinterpret_cast<unsigned short *>(base + l.cloc);
+    a.flag = reinterpret_cast<unsigned char *>(base + l.flag);
+    a.tcum = vox_tiles(N) <= kMaxTcumTiles ? reinterpret_cast<unsigned short *>(base + l.tcum) : nullptr;
     a.voxels = voxels; a.coors = coors; a.num_points = num_points; a.voxel_count = voxel_count; a.mean = mean;
-    a.mark_owned = (N < (1ll << (kIdxBits - 1))) ? 1 : 0;
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
     const unsigned gpts = (unsigned)mmt::stream_grid(N > 0 ? N : 1, kTile, 4096);
     const unsigned gtiles = (unsigned)(vox_tiles(N) + B);       // flattened (sample, tile) space, see locate_tile
-    seq.launch(false, vox_link, dim3(gpts), dim3(kTile), 0, st, a, B, (int)N);
-    seq.launch(false, vox_heads, dim3(gtiles), dim3(kTile), 0, st, a, B);
+    // (sample, region) workgroups; the XCD-aware numbering of vox_own covers B * NR rounded up to whole rows of 8
+    unsigned gown = (unsigned)((int64_t)B * d.NR);
+    if (B <= 8 && 8 % B == 0) gown = 8u * (unsigned)mmt::ceil_div(d.NR, 8 / B);
+    const size_t lds_own = (size_t)d.R * 9 + (size_t)kEntries * 8;
+    if (a.wide) {
+        seq.launch(false, vox_cells<unsigned short>, dim3(gpts), dim3(kTile), 0, st, a, B, (int)N);
+        seq.launch(false, vox_own<unsigned short>, dim3(gown), dim3(kTile), lds_own, st, a, B);
+    } else {
+        seq.launch(false, vox_cells<unsigned char>, dim3(gpts), dim3(kTile), 0, st, a, B, (int)N);
+        seq.launch(false, vox_own<unsigned char>, dim3(gown), dim3(kTile), lds_own, st, a, B);
+    }
     const size_t lds = (size_t)(kTile * (int64_t)max_points + 2 * kTile) * 4;
     if (F == 5) seq.launch(true, vox_emit<5>, dim3(gtiles), dim3(kTile), lds, st, a, B);
     else if (F == 8) seq.launch(true, vox_emit<8>, dim3(gtiles), dim3(kTile), lds, st, a, B);
@@ -490,19 +888,27 @@ int vox_run(const char *what, int B, int64_t N, int F, const float *points, cons
 
 }  // namespace
 
-extern "C" int64_t mmt_voxelize_table_elems(int B, const int32_t *grid) {
-    if (B <= 0 || grid == nullptr) return 0;
-    return 4 + 2 * (int64_t)B * grid[0] * grid[1] * grid[2];
+#ifdef VOX_STAMPS
+extern "C" int mmt_vox_debug_stamps(unsigned long long *host) { if (!g_vox_stamps) return 1; (void)hipDeviceSynchronize(); return (int)hipMemcpy(host, g_vox_stamps, 1024 * 16 * 8, hipMemcpyDeviceToHost); }
+#endif
+
+extern "C" int64_t mmt_voxelize_table_elems(int B, const int32_t *grid, int64_t total_points) {
+    if (B <= 0 || grid == nullptr || total_points < 0) return 0;
+    const int64_t cells = (int64_t)grid[0] * grid[1] * grid[2];
+    if (cells <= 0) return 0;
+    return directory_of(B, cells).elems_without_vidp + total_points + 4;
 }
 
-extern "C" int64_t mmt_voxelize_scratch_elems(int B, int64_t total_points) {
-    if (B <= 0 || total_points < 0) return 0;
-    return 3 * total_points + (int64_t)B * vox_tiles(total_points) + 16;
+extern "C" int64_t mmt_voxelize_scratch_elems(int B, const int32_t *grid, int64_t total_points, int max_points) {
+    if (B <= 0 || grid == nullptr || total_points < 0 || max_points <= 0) return 0;
+    const int64_t cells = (int64_t)grid[0] * grid[1] * grid[2];
+    if (cells <= 0) return 0;
+    return scratch_layout(B, total_points, max_points, true, directory_of(B, cells).NR).elems;
 }
 
-extern "C" int64_t mmt_voxelize_workspace_elems(int B, int64_t total_points, const int32_t *grid) {
-    if (B <= 0 || total_points < 0 || grid == nullptr) return 0;
-    return mmt_voxelize_table_elems(B, grid) + mmt_voxelize_scratch_elems(B, total_points) + 2;
+extern "C" int64_t mmt_voxelize_workspace_elems(int B, int64_t total_points, const int32_t *grid, int max_points) {
+    if (B <= 0 || total_points < 0 || grid == nullptr || max_points <= 0) return 0;
+    return mmt_voxelize_table_elems(B, grid, total_points) + mmt_voxelize_scratch_elems(B, grid, total_points, max_points) + 2;
 }
 
 extern "C" int mmt_hard_voxelize_mean(int B, int64_t N, int F, const float *points,
@@ -526,8 +932,7 @@ extern "C" int mmt_hard_voxelize_mean(int B, int64_t N, int F, const float *poin
     if (mean != nullptr && num_features <= 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "hard_voxelize_mean: mean requested with num_features=%d", num_features);
     if ((uintptr_t)table & 7) return mmt::fail(MMT_ERR_WORKSPACE, "hard_voxelize_mean: table must be 8-byte aligned");
     return vox_run("hard_voxelize_mean", B, N, F, points, point_offsets, voxel_size_host, range_min_host, grid_host,
-                   max_points, max_voxels, num_features, voxels, coors, num_points, voxel_count, mean,
-                   reinterpret_cast<unsigned long long *>(table), scratch, (hipStream_t)stream);
+                   max_points, max_voxels, num_features, voxels, coors, num_points, voxel_count, mean, table, scratch, (hipStream_t)stream);
 }
 
 extern "C" int mmt_hard_voxelize(int B, int64_t N, int F, const float *points,
@@ -548,16 +953,11 @@ extern "C" int mmt_hard_voxelize(int B, int64_t N, int F, const float *points,
     if (N > 0) MMT_REQUIRE_PTR(points);
     int rc = vox_check("hard_voxelize", B, N, F, grid_host, max_points, max_voxels, 0);
     if (rc) return rc;
-    // stateless form: the table lives in the caller's scratch workspace (any contents), so it is cleared here;
-    // mmt_hard_voxelize_mean with a persistent table skips this memset
+    // the cell directory and the scratch both live in the caller's workspace (any contents: every word read is written first)
     int32_t *tab = workspace + (((uintptr_t)workspace & 7) ? 1 : 0);
-    const int64_t tab_elems = mmt_voxelize_table_elems(B, grid_host);
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(tab, 0, sizeof(int32_t) * (size_t)tab_elems, st);
-    if (e != hipSuccess) return mmt::fail((int)e, "hard_voxelize: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const int64_t tab_elems = mmt_voxelize_table_elems(B, grid_host, N);
     return vox_run("hard_voxelize", B, N, F, points, point_offsets, voxel_size_host, range_min_host, grid_host,
-                   max_points, max_voxels, 0, voxels, coors, num_points, voxel_count, nullptr,
-                   reinterpret_cast<unsigned long long *>(tab), tab + tab_elems, st);
+                   max_points, max_voxels, 0, voxels, coors, num_points, voxel_count, nullptr, tab, tab + tab_elems, (hipStream_t)stream);
 }
 
 extern "C" int mmt_compact_voxels(int B, int max_voxels, int row_elems, const int32_t *voxel_count,
@@ -744,37 +1144,75 @@ extern "C" int mmt_pillar_scatter_nhwc(int64_t M, int C, int B, int ny, int nx, 
 }
 
 // Pillar scatter straight from the voxelizer's table (the model path: LidarEncoder.forward_bev).  The rows of the
-// fixed-capacity layout own DISTINCT cells, and vox_emit has left (generation | owned | voxel id) in the table entry of every
-// cell it emitted, so the canvas pass needs neither the cell -> row map, nor its fill, nor the scatter_map kernel: an entry
-// of another generation (or a chain head that lost to the voxel cap) reads as an empty cell.
+// fixed-capacity layout own DISTINCT cells, and the voxelization has left a cell directory in the table (vox_own: occupancy
+// bit, ordinal, head point; vox_emit: the head's voxel id), so the canvas pass needs neither the cell -> row map, nor its fill,
+// nor the scatter_map kernel: cell -> bit -> ordinal -> head -> voxel id; a head that lost to the voxel cap reads as an empty cell.
+struct DirView {
+    const int32_t *header;
+    const unsigned long long *bits;
+    const unsigned short *pref;
+    const int32_t *head_of;
+    const int32_t *vidp;
+    int R, shift, NR;
+};
+
+inline DirView dir_view(const int32_t *table, int B, int64_t cells) {
+    const Directory d = directory_of(B, cells);
+    DirView v;
+    v.header = table;
+    v.bits = reinterpret_cast<const unsigned long long *>(table + d.bits);
+    v.pref = reinterpret_cast<const unsigned short *>(table + d.pref);
+    v.head_of = table + d.head_of;
+    v.vidp = table + d.vidp;
+    v.R = d.R; v.shift = d.shift; v.NR = d.NR;
+    return v;
+}
+
+// first hop: the cell's 64-cell block of the directory; second: its head (-1: nobody there); third: the head's voxel id
+__device__ __forceinline__ int64_t dir_block(const DirView &d, int b, int cell) {
+    return ((int64_t)b * d.NR + (cell >> d.shift)) * (d.R >> 6) + ((cell & (d.R - 1)) >> 6);
+}
+__device__ __forceinline__ int dir_head(const DirView &d, int b, int cell, unsigned long long bits, int pref) {
+    const int k = cell & 63;
+    if (!((bits >> k) & 1ull)) return -1;
+    const int ord = pref + __popcll(bits & ((1ull << k) - 1ull));
+    return d.head_of[((int64_t)b * d.NR + (cell >> d.shift)) * d.R + ord];
+}
+
 __global__ __launch_bounds__(256) void scatter_write_nhwc_table_kernel(int C4, int B, int64_t cells_per_sample, int V,
-                                                                       const float *feats, const unsigned long long *table,
-                                                                       float *canvas) {
+                                                                       const float *feats, DirView dir, float *canvas) {
     constexpr int kCells = 4;
     const int lane_in = threadIdx.x % C4;
     const int groups_per_block = 256 / C4;
     const int grp = threadIdx.x / C4;
     if (grp >= groups_per_block) return;
-    const unsigned long long gen = table[0];            // the voxelization that ran last on this table
-    // header word 1, bit 32: that voxelization left voxel ids in its entries.  Without it (a cloud of 2^23 points or more: the
-    // id field is too narrow) the entries still hold chain heads; reading those as voxel ids would pair cells with the wrong
-    // rows SILENTLY, so the canvas is filled with NaN instead -- loud in the first loss that sees it.
-    const bool ids_valid = (table[1] >> 32) & 1ull;
+    // a table no voxelization of this form has written: pairing cells with rows from its contents would be SILENTLY wrong, so
+    // the canvas is filled with NaN instead -- loud in the first loss that sees it
+    const bool valid = dir.header[0] == kTableMagic;
     const int64_t cells = (int64_t)B * cells_per_sample;
     const int64_t ngroups = (int64_t)gridDim.x * groups_per_block;
     for (int64_t c0 = ((int64_t)blockIdx.x * groups_per_block + grp) * kCells; c0 < cells; c0 += ngroups * kCells) {
-        unsigned long long e[kCells];
+        unsigned long long bits[kCells];
+        int pref[kCells], bb[kCells], cc[kCells], hd[kCells], vid[kCells];
 #pragma unroll
-        for (int u = 0; u < kCells; ++u) e[u] = table[2 + ((c0 + u) < cells ? (c0 + u) : (cells - 1))];
+        for (int u = 0; u < kCells; ++u) {
+            const int64_t c = (c0 + u) < cells ? (c0 + u) : (cells - 1);
+            bb[u] = (int)(c / cells_per_sample);
+            cc[u] = (int)(c - (int64_t)bb[u] * cells_per_sample);
+            const int64_t w = dir_block(dir, bb[u], cc[u]);
+            bits[u] = dir.bits[w];
+            pref[u] = dir.pref[w];
+        }
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) hd[u] = dir_head(dir, bb[u], cc[u], bits[u], pref[u]);
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) vid[u] = hd[u] >= 0 ? dir.vidp[hd[u]] : -1;
 #pragma unroll
         for (int u = 0; u < kCells; ++u) {
             if (c0 + u >= cells) break;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((e[u] >> kIdxBits) == gen && (e[u] & kOwnedBit)) {
-                const int64_t row = (c0 + u) / cells_per_sample * V + (int64_t)(e[u] & (kOwnedBit - 1));
-                v = reinterpret_cast<const float4 *>(feats)[row * C4 + lane_in];
-            }
-            if (!ids_valid) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            if (vid[u] >= 0 && vid[u] < V) v = reinterpret_cast<const float4 *>(feats)[((int64_t)bb[u] * V + vid[u]) * C4 + lane_in];
+            if (!valid) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             mmt_nt_store4(v, reinterpret_cast<float4 *>(canvas) + (c0 + u) * C4 + lane_in);
         }
     }
@@ -815,15 +1253,14 @@ extern "C" int mmt_pillar_scatter_nhwc_table(int C, int B, int ny, int nx, int m
     MMT_REQUIRE_PTR(feats);
     MMT_REQUIRE_PTR(table);
     MMT_REQUIRE_PTR(canvas);
-    if (C <= 0 || C % 4 || C > 1024 || B <= 0 || ny <= 0 || nx <= 0 || max_voxels <= 0 || max_voxels > (1 << (kIdxBits - 1)) ||
+    if (C <= 0 || C % 4 || C > 1024 || B <= 0 || ny <= 0 || nx <= 0 || max_voxels <= 0 ||
         ((uintptr_t)canvas & 15) || ((uintptr_t)feats & 15) || ((uintptr_t)table & 7))
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_table: bad sizes (C %% 4 == 0, C <= 1024, aligned buffers, max_voxels <= 2^23)");
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_table: bad sizes (C %% 4 == 0, C <= 1024, aligned buffers)");
     const int64_t cells = (int64_t)B * ny * nx;
     if (cells >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "pillar_scatter_nhwc_table: B*ny*nx exceeds int32");
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
     seq.launch(true, scatter_write_nhwc_table_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / (C / 4))) * 256, 256, 256 * 32)),
-               dim3(256), 0, (hipStream_t)stream, C / 4, B, (int64_t)ny * nx, max_voxels, feats,
-               reinterpret_cast<const unsigned long long *>(table), canvas);
+               dim3(256), 0, (hipStream_t)stream, C / 4, B, (int64_t)ny * nx, max_voxels, feats, dir_view(table, B, (int64_t)ny * nx), canvas);
     return mmt::check_launch("pillar_scatter_nhwc_table");
 }
 
@@ -889,22 +1326,19 @@ struct StridedDims {
     int64_t row_stride4;           // float4 units between consecutive output cells' rows
 };
 
-// table form: one lane group of C4 lanes per OUTPUT cell, kCells cells per group and trip (entries first, then rows)
-__global__ __launch_bounds__(256) void scatter_write_strided_table_kernel(StridedDims d, int V, const float *feats,
-                                                                          const unsigned long long *table, float *out) {
+// table form: one lane group of C4 lanes per OUTPUT cell, kCells cells per group and trip (directory hops first, then rows)
+__global__ __launch_bounds__(256) void scatter_write_strided_table_kernel(StridedDims d, int V, const float *feats, DirView dir, float *out) {
     constexpr int kCells = 4;
     const int lane_in = threadIdx.x % d.C4;
     const int groups_per_block = 256 / d.C4;
     const int grp = threadIdx.x / d.C4;
     if (grp >= groups_per_block) return;
-    const unsigned long long gen = table[0];
-    const bool ids_valid = (table[1] >> 32) & 1ull;     // see scatter_write_nhwc_table_kernel
+    const bool valid = dir.header[0] == kTableMagic;     // see scatter_write_nhwc_table_kernel
     const int64_t per_b = (int64_t)d.oh * d.ow, cells = (int64_t)d.B * per_b;
-    const int64_t src_per_b = (int64_t)d.ny * d.nx;
     const int64_t ngroups = (int64_t)gridDim.x * groups_per_block;
     for (int64_t c0 = ((int64_t)blockIdx.x * groups_per_block + grp) * kCells; c0 < cells; c0 += ngroups * kCells) {
-        unsigned long long e[kCells];
-        int bb[kCells];
+        unsigned long long bits[kCells];
+        int pref[kCells], bb[kCells], cc[kCells], hd[kCells], vid[kCells];
 #pragma unroll
         for (int u = 0; u < kCells; ++u) {
             const int64_t oc = (c0 + u) < cells ? (c0 + u) : (cells - 1);
@@ -912,17 +1346,21 @@ __global__ __launch_bounds__(256) void scatter_write_strided_table_kernel(Stride
             const int r = (int)(oc - (int64_t)b * per_b);
             const int i = r / d.ow, j = r - i * d.ow;
             bb[u] = b;
-            e[u] = table[2 + (int64_t)b * src_per_b + (int64_t)(i * d.sy) * d.nx + j * d.sx];
+            cc[u] = (i * d.sy) * d.nx + j * d.sx;
+            const int64_t w = dir_block(dir, b, cc[u]);
+            bits[u] = dir.bits[w];
+            pref[u] = dir.pref[w];
         }
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) hd[u] = dir_head(dir, bb[u], cc[u], bits[u], pref[u]);
+#pragma unroll
+        for (int u = 0; u < kCells; ++u) vid[u] = hd[u] >= 0 ? dir.vidp[hd[u]] : -1;
 #pragma unroll
         for (int u = 0; u < kCells; ++u) {
             if (c0 + u >= cells) break;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((e[u] >> kIdxBits) == gen && (e[u] & kOwnedBit)) {
-                const int64_t row = (int64_t)bb[u] * V + (int64_t)(e[u] & (kOwnedBit - 1));
-                v = reinterpret_cast<const float4 *>(feats)[row * d.C4 + lane_in];
-            }
-            if (!ids_valid) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            if (vid[u] >= 0 && vid[u] < V) v = reinterpret_cast<const float4 *>(feats)[((int64_t)bb[u] * V + vid[u]) * d.C4 + lane_in];
+            if (!valid) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             reinterpret_cast<float4 *>(out)[(c0 + u) * d.row_stride4 + lane_in] = v;
         }
     }
@@ -1015,12 +1453,12 @@ extern "C" int mmt_pillar_scatter_nhwc_table_strided(int C, int B, int ny, int n
     MMT_REQUIRE_PTR(out);
     StridedDims d;
     if (int rc = strided_check("pillar_scatter_nhwc_table_strided", C, B, ny, nx, stride_y, stride_x, out_row_stride, out, &d)) return rc;
-    if (max_voxels <= 0 || max_voxels > (1 << (kIdxBits - 1)) || ((uintptr_t)feats & 15) || ((uintptr_t)table & 7))
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_table_strided: max_voxels <= 2^23, aligned feats / table");
+    if (max_voxels <= 0 || ((uintptr_t)feats & 15) || ((uintptr_t)table & 7))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "pillar_scatter_nhwc_table_strided: max_voxels > 0, aligned feats / table");
     const int64_t cells = (int64_t)B * d.oh * d.ow;
     mmt::TimedSeq seq;
     seq.launch(true, scatter_write_strided_table_kernel, dim3(mmt::stream_grid(mmt::ceil_div(cells, 4 * (256 / d.C4)) * 256, 256, 256 * 32)),
-               dim3(256), 0, (hipStream_t)stream, d, max_voxels, feats, reinterpret_cast<const unsigned long long *>(table), out);
+               dim3(256), 0, (hipStream_t)stream, d, max_voxels, feats, dir_view(table, B, (int64_t)ny * nx), out);
     return mmt::check_launch("pillar_scatter_nhwc_table_strided");
 }
 

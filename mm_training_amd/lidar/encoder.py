@@ -30,9 +30,15 @@ def grid_size(point_cloud_range, voxel_size):
     return [int(x) for x in torch.round((r[3:] - r[:3]) / v).long()]
 
 
-# Persistent per-cell tables of the voxelizer (mmt_hard_voxelize_mean): zero-filled once, then reused by every
-# call -- entries carry a generation stamp, nothing is cleared per step.  One table per (device, stream, size).
+# Per-cloud cell directories of the voxelizer (mmt_hard_voxelize_mean leaves one in its table; the table-form pillar
+# scatter reads it).  Allocated once per (device, stream, size) and reused: nothing is cleared per step (a table that no
+# voxelization has written reads as "no directory": the scatter answers with NaN).
 _TABLES = {}
+
+
+def _table_elems(B, grid_c, N):
+    """Table size for clouds of up to N points, N rounded up to 64 k so that a stream of ragged clouds keeps one table."""
+    return _lib.lib().mmt_voxelize_table_elems(B, grid_c, (int(N) + 65535) & ~65535)
 
 
 def _voxel_table(dev, elems, tables=None):
@@ -89,13 +95,13 @@ def hard_voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num
     voxel_count = torch.empty((B,), dtype=torch.int32, device=dev)
     mean = torch.empty((B * V, int(num_features)), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        table = _voxel_table(dev, _lib.lib().mmt_voxelize_table_elems(B, grid_c), tables)
-        scratch = torch.empty((_lib.lib().mmt_voxelize_scratch_elems(B, N),), dtype=torch.int32, device=dev)
+        table = _voxel_table(dev, _table_elems(B, grid_c, N), tables)
+        scratch = torch.empty((_lib.lib().mmt_voxelize_scratch_elems(B, grid_c, N, T),), dtype=torch.int32, device=dev)
         _lib.timed_call("voxelize", "mmt_hard_voxelize_mean", B, N, F, points.data_ptr(), offsets.data_ptr(),
                         _lib.float3(voxel_size), _lib.float3(point_cloud_range[:3]), grid_c, T, V, int(num_features),
                         voxels.data_ptr() if materialize_voxels else 0, coors.data_ptr(), num_points.data_ptr(),
                         voxel_count.data_ptr(), mean.data_ptr(), table.data_ptr(), scratch.data_ptr(), _stream())
-    if return_table:     # for pillar_scatter_from_table: the scatter reads the voxel ids vox_emit left in the table
+    if return_table:     # for pillar_scatter_from_table: the scatter walks the cell directory this call left in the table
         return voxels, num_points, coors, voxel_count, mean, table
     return voxels, num_points, coors, voxel_count, mean
 
@@ -119,7 +125,7 @@ def hard_voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_poin
     coors = torch.empty((B * V, 4), dtype=torch.int32, device=dev)
     num_points = torch.empty((B * V,), dtype=torch.int32, device=dev)
     voxel_count = torch.empty((B,), dtype=torch.int32, device=dev)
-    ws_elems = _lib.lib().mmt_voxelize_workspace_elems(B, N, grid_c)
+    ws_elems = _lib.lib().mmt_voxelize_workspace_elems(B, N, grid_c, T)
     workspace = torch.empty((ws_elems,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.timed_call("voxelize", "mmt_hard_voxelize", B, N, F, points.data_ptr(), offsets.data_ptr(),

@@ -166,7 +166,7 @@ def test_host_side_argument_checks_of_the_strided_pillar_scatter(mmt_lib):
     assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 100, 4, 4, p, p, p, 4, None) == -2      # row stride < C
     assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 100, 4, 4, p, p, p, 10, None) == -2     # not a multiple of 4
     assert lib.mmt_pillar_scatter_nhwc_table_strided(6, 1, 16, 16, 100, 4, 4, p, p, p, 8, None) == -2      # C % 4
-    assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 1 << 24, 4, 4, p, p, p, 8, None) == -2  # max_voxels > 2^23
+    assert lib.mmt_pillar_scatter_nhwc_table_strided(8, 1, 16, 16, 0, 4, 4, p, p, p, 8, None) == -2        # max_voxels <= 0 (ABI 11: no upper limit, the directory holds full 32-bit voxel ids)
     assert lib.mmt_pillar_scatter_nhwc_strided(4, 8, 1, 16, 16, 4, 4, p, p, p, 8, None, None) == -1
     assert lib.mmt_pillar_scatter_nhwc_strided(4, 8, 1, 16, 16, 0, 4, p, p, p, 8, p, None) == -2
     assert lib.mmt_pillar_scatter_nhwc_strided_backward(0, 8, 1, 16, 16, 4, 4, None, 8, None, None, None, None) == 0   # nothing to do

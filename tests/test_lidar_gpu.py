@@ -49,8 +49,8 @@ def _check(oracle_mod, frames, max_points, max_voxels, vsize=VSIZE, rng=RANGE):
         assert (c2[b * max_voxels + k:(b + 1) * max_voxels] == -1).all()
         assert (n2[b * max_voxels + k:(b + 1) * max_voxels] == 0).all()
         off += k
-    # fused voxelize + mean (mmt_hard_voxelize_mean): persistent generation-stamped table, no clearing pass;
-    # the second round runs on a table that still holds the first round's entries
+    # fused voxelize + mean (mmt_hard_voxelize_mean): no clearing pass; the second round runs on a table and a scratch
+    # that still hold the first round's contents
     from mm_training_amd.lidar import hard_voxelize_mean_batch
     for materialize in (True, False, True):
         v3, n3, c3, cnt3, m3 = hard_voxelize_mean_batch(dev, vsize, rng, max_points, max_voxels, nf, materialize_voxels=materialize)
@@ -94,9 +94,9 @@ def test_voxelize_overfull_voxels_and_voxel_cap(mmt_lib, oracle_mod):
 
 
 def test_voxelize_cells_spread_over_many_tiles(mmt_lib, oracle_mod):
-    """Every cell's points lie in DIFFERENT 256-point tiles, far apart: while the workgroup of a cell's first point is
-    already replacing the cell's table entry by (owned | voxel id), later tiles still start their walks from that entry
-    (the two used to be separate kernels; a walker reading the voxel id as a point index faulted).  Repeated on one table."""
+    """Every cell's points lie in DIFFERENT 256-point tiles, far apart (the chain form of rounds 1-4 walked a cell's chain from
+    several tiles at once; the region-owner form settles a cell inside one workgroup, whatever tiles its points come from).
+    Repeated on one table."""
     g = torch.Generator().manual_seed(17)
     clouds = []
     for n, ncell in ((60000, 900), (33000, 5000)):
@@ -113,6 +113,25 @@ def test_voxelize_cells_spread_over_many_tiles(mmt_lib, oracle_mod):
         _check(oracle_mod, clouds, 4, 700)                   # voxel cap hit: first points past it leave their entries unmarked
 
 
+def test_voxelize_region_owner_paths(mmt_lib, oracle_mod):
+    """The paths of the region-owner form (lidar_voxelize.hip, ABI 11) the BASELINE shapes do not reach:
+    a grid of more than 254 regions of 4096 cells (region ids 16 bits wide); a cloud longer than one streaming batch
+    (40 960 points: the list's count carries over); a cloud packed into ONE region, so that the region's list overflows and
+    the batch is worked through again step by step, with cells far beyond max_points (a walk ends at max_points smaller
+    indices) and the lists settled several times (later settlements find the cells' earlier counts)."""
+    wide = [-204.8, -64.0, -5.0, 204.8, 64.0, 3.0]                                     # 2048 x 640 x 1 = 1.3 M cells = 320 regions
+    _check(oracle_mod, _frames([30000, 12000], rng_range=wide, seed=41), 15, 25000, rng=wide)
+    _check(oracle_mod, _frames([100000, 50001], seed=42), 15, 25000)                   # three batches / two
+    g = torch.Generator().manual_seed(43)
+    pts = torch.rand(90000, 5, generator=g)
+    pts[:, 0] = 3.0 + pts[:, 0] * 6.0                                                  # 30 x 2 cells of the 2048 x 256 grid: one region
+    pts[:, 1] = 1.0 + pts[:, 1] * 0.4
+    pts[:, 2] = pts[:, 2] * 6 - 4
+    rv, rn, rc = _check(oracle_mod, [pts, _frames([7000], seed=44)[0]], 15, 25000)
+    assert (rn[:60] == 15).all()
+    _check(oracle_mod, [pts[:50000]], 100, 40)                                         # max_points above the usual, voxel cap inside the packed region
+
+
 def test_voxelize_boundaries_and_nonfinite(mmt_lib, oracle_mod):
     pts = torch.zeros(64, 5)
     edge = [RANGE[0], RANGE[0] - 1e-4, RANGE[3], RANGE[3] - 1e-4, 0.0, 0.2, 0.19999, -0.0]
@@ -127,8 +146,8 @@ def test_voxelize_boundaries_and_nonfinite(mmt_lib, oracle_mod):
 
 
 def test_voxelize_table_survives_other_clouds(mmt_lib, oracle_mod):
-    """The per-cell table is never cleared: alternating clouds (one of them much denser) on the same table must
-    each give their own result every time (entries of earlier calls read as empty)."""
+    """The table is never cleared: alternating clouds (one of them much denser) on the same table must each give their
+    own result every time (a call rewrites every word of the directory it leaves)."""
     from mm_training_amd.lidar import hard_voxelize_mean_batch
     a = [f.cuda() for f in _frames([20000, 18000], seed=31)]
     b = [f.cuda() for f in _frames([40000, 40000], seed=32, dense=True)]

@@ -44,7 +44,7 @@ KERNELS = [
     ("lift_splat_backward_pixel_bf16", ("lift_splat_backward_kernel<unsigned short",)),
     ("vp_planned_items", ("vp_planned_items",)), ("vp_planned_fold", ("vp_planned_fold",)),
     ("lift_kernel", ("lift_kernel<",)), ("lift_kernel_bf16", ("lift_kernel_bf16",)), ("lift_backward_vec4", ("lift_backward_vec4",)),
-    ("vox_link", ("vox_link",)), ("vox_heads", ("vox_heads",)), ("vox_emit", ("vox_emit",)),
+    ("vox_cells", ("vox_cells",)), ("vox_own", ("vox_own",)), ("vox_emit", ("vox_emit",)),
     ("fill_i32_kernel", ("fill_i32_kernel",)), ("scatter_map_kernel", ("scatter_map_kernel",)),
     ("scatter_write_nhwc_kernel", ("scatter_write_nhwc_kernel",)), ("scatter_backward_nhwc_kernel", ("scatter_backward_nhwc_kernel",)),
     ("scatter_write_strided_table_kernel", ("scatter_write_strided_table_kernel",)), ("scatter_write_strided_kernel", ("scatter_write_strided_kernel",)),

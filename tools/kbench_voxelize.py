@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Voxelize + mean (mmt_hard_voxelize_mean: vox_link / vox_heads / vox_emit) at BASELINE shapes, per library given on the
+"""Voxelize + mean (mmt_hard_voxelize_mean: vox_cells / vox_own / vox_emit; builds before ABI 11: vox_link / vox_heads / vox_emit) at BASELINE shapes, per library given on the
 command line (interleaved A/B of builds), dispatch-attached events = the three kernels' own time:
     python tools/kbench_voxelize.py [--points 40000 --batch 4 --cols 5] [lib.so ...]"""
 import argparse, json, os, sys
@@ -17,21 +17,31 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--cols", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--native-range", action="store_true", help="the reference's own range [-204.8, -25.6, ..] = a 2048 x 256 grid (exps/conf_aim.py:16-18)")
     ap.add_argument("libs", nargs="*")
     args = ap.parse_args()
     _lib.lib()
+    global RANGE
+    if args.native_range:
+        RANGE = [-204.8, -25.6, -5.0, 204.8, 25.6, 3.0]
     libs = args.libs or [_lib.LIB_PATH]
     hs = [load(p) for p in libs]
     B, F, V, T = args.batch, args.cols, 25000, 15
     pts = torch.cat([synthetic.lidar_frame(args.points, F, RANGE, num_radar=2000 if F == 8 else 0, seed=s) for s in range(B)], 0).cuda()
     offs = torch.tensor([i * args.points for i in range(B + 1)], dtype=torch.int32).cuda()
-    grid = _lib.int3([512, 512, 1])
+    grid = _lib.int3([int(round((RANGE[3 + k] - RANGE[k]) / VSIZE[k])) for k in range(3)])
     N = B * args.points
     out = {}
     res = {}
     for name, h in zip(libs, hs):
-        table = torch.zeros(int(h.mmt_voxelize_table_elems(B, grid)), dtype=torch.int32, device="cuda")
-        scratch = torch.empty(int(h.mmt_voxelize_scratch_elems(B, N)), dtype=torch.int32, device="cuda")
+        if h.mmt_abi_version() >= 11:
+            table = torch.zeros(int(h.mmt_voxelize_table_elems(B, grid, N)), dtype=torch.int32, device="cuda")
+            scratch = torch.empty(int(h.mmt_voxelize_scratch_elems(B, grid, N, T)), dtype=torch.int32, device="cuda")
+        else:                   # builds before the region-owner form: two-argument size functions
+            import ctypes
+            h.mmt_voxelize_table_elems.argtypes, h.mmt_voxelize_scratch_elems.argtypes = [ctypes.c_int, ctypes.c_void_p], [ctypes.c_int, ctypes.c_int64]
+            table = torch.zeros(int(h.mmt_voxelize_table_elems(B, grid)), dtype=torch.int32, device="cuda")
+            scratch = torch.empty(int(h.mmt_voxelize_scratch_elems(B, N)), dtype=torch.int32, device="cuda")
         coors = torch.empty((B * V, 4), dtype=torch.int32, device="cuda")
         nump = torch.empty((B * V,), dtype=torch.int32, device="cuda")
         cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
