@@ -741,6 +741,8 @@ def train_main(args, rank, local_rank, world):
     if rank != 0:
         barrier(world)          # rank 0 adds its roofline legs below; everybody leaves together
         return
+    from mm_training_amd import miopen_db
+    db_status = miopen_db.status()          # did MIOpen read the shipped find DB (same build string), or write files of its own?
     res = {
         "metric": "training samples/sec at bs=%d/GPU; voxel_pooling HBM GB/s" % B,
         "value": world * B * args.steps / elapsed, "unit": "samples/s",
@@ -751,7 +753,7 @@ def train_main(args, rank, local_rank, world):
                    "global_batch": world * B, "parallelism": f"dp{world}", "mode": "train",
                    "params_M": sum(p.numel() for p in ts.model.parameters()) / 1e6,
                    "final_loss": float(loss), "miopen_exhaustive_search": bool(args.miopen_tune),
-                   "miopen_shipped_find_db": bool(db_cfg), "fused_lift_splat": fused, "cached_plan": bool(args.cached_plan),
+                   "miopen_shipped_find_db": bool(db_cfg) and bool(db_status.get("matched")), "miopen_find_db": db_status, "fused_lift_splat": fused, "cached_plan": bool(args.cached_plan),
                    "dense_nets_dtype": "bf16 autocast" if ts.amp_dtype is not None else "f32",
                    "hot_path_storage_dtype": dtype,
                    # exps/mm_training_aim.py:258-259: both run inside every timed step

@@ -128,3 +128,18 @@ def test_bench_exit_code_reports_a_failed_rank():
     out = _run_bench("--gpus", "2", "--config", "no_such_config", "--device", "cpu", "--steps", "1", "--warmup", "0")
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_shipped_find_db_reports_whether_miopen_used_it():
+    """miopen_db.status(): matched only when MIOpen's version equals the shipped files' and MIOpen wrote no files of its own name
+    into the directory (another build ignores the shipped ones silently; bench.py then reports miopen_shipped_find_db false)."""
+    code = (
+        "import os, sys; os.environ.pop('MIOPEN_USER_DB_PATH', None)\n"
+        "from mm_training_amd import miopen_db as m\n"
+        "assert m.status(warn=False)['matched'] is None\n"
+        "assert m.enable(); s = m.status(warn=False); assert s['enabled'] and s['matched'] and s['shipped_build'].startswith('3.5.0-'), s\n"
+        "open(os.path.join(m._state['dir'], 'gfx950100.HIP.9_9_9_other.ufdb.txt'), 'w').write('x')\n"
+        "s = m.status(); assert s['matched'] is False and s['foreign_files'] == ['gfx950100.HIP.9_9_9_other.ufdb.txt'], s\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr
+    assert "NOT used by this MIOpen" in out.stderr
