@@ -43,7 +43,8 @@ constexpr int kIdxBits = 24;          // point index inside its sample (host che
 constexpr int kMaxBatchLds = 255;     // sample offsets cached in LDS up to this batch size
 constexpr int kInf = 0x7fffffff;
 constexpr int kEntries = 4096;        // vox_own: indices of the region's points waiting in LDS
-constexpr int kStreamDepth = 10;      // 16-byte loads of region ids in flight per thread (10 x 256 x 16 points: a 40 k cloud in one round trip)
+constexpr int kStreamDepth = 10;      // 16-byte loads of region ids in flight per thread (10 x 256 x 16 points: a 40 k cloud in one round trip;
+                                      // 20 measured the same at 2 x 80 k points)
 constexpr int kSlowChunk = kTile * 8; // points per step when a batch has to be done again step by step (vox_own)
 constexpr int kMinRegion = 1024, kMaxRegion = 4096;
 constexpr int kTableMagic = 0x32584f56;   // "VOX2": the table holds a cell directory of the region-owner form
@@ -145,6 +146,26 @@ __device__ __forceinline__ bool locate_tile(const int32_t *offsets, int B, int w
     return false;
 }
 
+// The same from ONE round trip (B <= 63; every wave for itself, same answer): lane l takes sample l's offsets, a prefix sum over the
+// samples' tile counts on the DPP path finds the sample whose range holds the workgroup.  Also hands back the sample's first point
+// and point count.
+__device__ __forceinline__ bool locate_tile_wave(const int32_t *offsets, int B, int wg, int *b_out, int *tile_out, int *beg_out, int *n_out) {
+    const int lane = threadIdx.x & 63;
+    const int o0 = offsets[lane < B ? lane : B], o1 = offsets[lane + 1 < B ? lane + 1 : B];
+    const int n = lane < B ? o1 - o0 : 0;
+    int t = (n + kTile - 1) / kTile;
+    t = lane < B ? (t > 0 ? t : 1) : 0;
+    const int incl = wave_incl_scan(t);
+    const unsigned long long m = __ballot(lane < B && wg >= incl - t && wg < incl);
+    if (m == 0ull) return false;
+    const int src = __ffsll((long long)m) - 1;
+    *b_out = src;
+    *tile_out = wg - __builtin_amdgcn_readlane(incl - t, src);
+    *beg_out = __builtin_amdgcn_readlane(o0, src);
+    *n_out = __builtin_amdgcn_readlane(n, src);
+    return true;
+}
+
 template <typename RT>
 __global__ __launch_bounds__(kTile) void vox_cells(VoxArgs a, int B, int total) {
     __shared__ int offs[kMaxBatchLds + 1];
@@ -233,7 +254,7 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
 #pragma unroll
         for (int j = 0; j < kPer; ++j) idx[j] = j * kTile + threadIdx.x < count ? eidx[j * kTile + threadIdx.x] : -1;
 #pragma unroll
-        for (int j = 0; j < kPer; ++j) cl[j] = idx[j] >= 0 ? (int)a.cloc[fb + idx[j]] : 0;
+        for (int j = 0; j < kPer; ++j) cl[j] = (int)a.cloc[fb + (idx[j] >= 0 ? idx[j] : 0)];        // (unconditional: one round trip for all)
         VSTAMP(5);
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
     };
 
     // ---- stream the sample's region ids: 16 bytes per thread and step (16 points; 8 when the ids are 16 bits wide),
-    // kStreamDepth steps in flight.  A step's four dwords become ONE mask of the points that fall into region r; a thread counts
+    // kDepth steps in flight.  A step's four dwords become ONE mask of the points that fall into region r; a thread counts
     // its matches of the whole batch, reserves their places in the list with one LDS atomic and writes them (a region's share of
     // 40 k points is a few hundred indices: the first match of a step without a loop, further ones in a loop few waves enter).
     // Should the list overflow -- a cloud packed into few regions -- the batch is done again step by step, settling the list
@@ -288,24 +309,23 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
     const RT *reg = reinterpret_cast<const RT *>(a.reg) + fb;
     const int npad = (n + 15) & ~15;                               // (vox_cells filled the slice up to here: no region)
     const unsigned rrrr = kWide ? (unsigned)r * 0x00010001u : (unsigned)r * 0x01010101u;
+    constexpr int kDepth = kStreamDepth;
     constexpr int kPts = kWide ? 8 : 16;                           // points per 16-byte load
     constexpr int kChunk = kTile * kPts;
     // point of mask bit j inside its step: bytes -- bit 8k + d is byte k of dword d; halves -- bit 16k + d is half k of dword d
     auto point_of = [](int j) { return kWide ? (j & 15) * 2 + (j >> 4) : (j & 7) * 4 + (j >> 3); };
-    // every workgroup of the sample reads the same bytes: each starts at another step (registers in rotated order)
-    const int rot = (int)((unsigned)(r * 7 + b * 3) % kStreamDepth);
-    auto step_of = [&](int u) { const int x = u + rot; return x >= kStreamDepth ? x - kStreamDepth : x; };
-    for (int base = 0; base < n; base += kChunk * kStreamDepth) {
-        unsigned w[kStreamDepth];
+    for (int base = 0; base < n; base += kChunk * kDepth) {
+        unsigned w[kDepth];
         {
-            uint4 v[kStreamDepth];
+            uint4 v[kDepth];
 #pragma unroll
-            for (int u = 0; u < kStreamDepth; ++u) {
-                const int p = base + step_of(u) * kChunk + threadIdx.x * kPts;
-                v[u] = p < npad ? *reinterpret_cast<const uint4 *>(reg + p) : make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (int u = 0; u < kDepth; ++u) {               // unconditional loads (clamped address): all in flight together
+                const int p = base + u * kChunk + threadIdx.x * kPts;
+                v[u] = *reinterpret_cast<const uint4 *>(reg + (p < npad ? p : npad - kPts));
             }
 #pragma unroll
-            for (int u = 0; u < kStreamDepth; ++u) {
+            for (int u = 0; u < kDepth; ++u) {
+                if (base + u * kChunk + (int)threadIdx.x * kPts >= npad) v[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
                 if (kWide) w[u] = (match_halves(v[u].x, rrrr) >> 15) | (match_halves(v[u].y, rrrr) >> 14) | (match_halves(v[u].z, rrrr) >> 13) | (match_halves(v[u].w, rrrr) >> 12);
                 else w[u] = (match_bytes(v[u].x, rrrr) >> 7) | (match_bytes(v[u].y, rrrr) >> 6) | (match_bytes(v[u].z, rrrr) >> 5) | (match_bytes(v[u].w, rrrr) >> 4);
             }
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
         if (base > 0) { before = s_count; __syncthreads(); }      // (uniform: nobody appends between the last barrier and this one)
         int mine = 0;
 #pragma unroll
-        for (int u = 0; u < kStreamDepth; ++u) mine += __popc(w[u]);
+        for (int u = 0; u < kDepth; ++u) mine += __popc(w[u]);
         // places in the list: a prefix sum inside the wave, ONE LDS atomic per wave (256 returning atomics on one LDS word cost 3 us)
         const int incl = wave_incl_scan(mine);
         int wbase = 0;
@@ -324,18 +344,18 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
         if (pos + mine <= kEntries) {
             unsigned rest = 0;
 #pragma unroll
-            for (int u = 0; u < kStreamDepth; ++u) {               // a step's first match
+            for (int u = 0; u < kDepth; ++u) {               // a step's first match
                 if (w[u]) {
-                    eidx[pos++] = base + step_of(u) * kChunk + threadIdx.x * kPts + point_of(__ffs((int)w[u]) - 1);
+                    eidx[pos++] = base + u * kChunk + threadIdx.x * kPts + point_of(__ffs((int)w[u]) - 1);
                     w[u] &= w[u] - 1;
                 }
                 rest |= w[u];
             }
             if (__any(rest != 0)) {
 #pragma unroll
-                for (int u = 0; u < kStreamDepth; ++u)
+                for (int u = 0; u < kDepth; ++u)
                     while (w[u]) {
-                        eidx[pos++] = base + step_of(u) * kChunk + threadIdx.x * kPts + point_of(__ffs((int)w[u]) - 1);
+                        eidx[pos++] = base + u * kChunk + threadIdx.x * kPts + point_of(__ffs((int)w[u]) - 1);
                         w[u] &= w[u] - 1;
                     }
             }
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
             __syncthreads();
             if (threadIdx.x == 0) { s_count = before; s_over = 0; }
             __syncthreads();
-            const int end = base + kChunk * kStreamDepth < n ? base + kChunk * kStreamDepth : n;
+            const int end = base + kChunk * kDepth < n ? base + kChunk * kDepth : n;
             for (int p0 = base; p0 < end; p0 += kSlowChunk) {     // ascending steps of 8 points per thread, read again
                 if (__syncthreads_or(s_count > kEntries - kSlowChunk ? 1 : 0)) {     // could this step overflow the list?  (same argument)
                     flush(s_count);
@@ -478,9 +498,13 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     int *cnt = lists + kTile * T;
     int *cellv = cnt + kTile;
     VSTAMP(8);
-    int b, tile;
-    if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
-    const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
+    int b, tile, beg, n;
+    if (B <= 63) {
+        if (!locate_tile_wave(a.offsets, B, blockIdx.x, &b, &tile, &beg, &n)) return;
+    } else {
+        if (!locate_tile(a.offsets, B, blockIdx.x, &b, &tile)) return;
+        beg = a.offsets[b]; n = a.offsets[b + 1] - beg;
+    }
     VSTAMP(9);
     const int my_tiles = (n + kTile - 1) / kTile;
     const int64_t fb = flag_base(beg, b);
@@ -515,8 +539,11 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
 #pragma unroll
             for (int u = 0; u < kFlagDepth; ++u) {                  // (every tile of the sample reads these bytes: each starts at another step)
                 const int w = w0 + frot(u) * kTile + threadIdx.x;
-                v[u] = w < nw ? fw[w] : make_uint4(0u, 0u, 0u, 0u);
+                v[u] = fw[w < nw ? w : nw - 1];
             }
+#pragma unroll
+            for (int u = 0; u < kFlagDepth; ++u)
+                if (w0 + frot(u) * kTile + (int)threadIdx.x >= nw) v[u] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
             for (int u = 0; u < kFlagDepth; ++u) {                  // (vox_cells zeroed the bytes between the sample's end and the 16-byte boundary)
                 const int c = nonzero_bytes(v[u].x, nonzero_bytes(v[u].y, nonzero_bytes(v[u].z, nonzero_bytes(v[u].w, 0))));

@@ -172,3 +172,21 @@ def test_host_side_argument_checks_of_the_strided_pillar_scatter(mmt_lib):
     assert lib.mmt_pillar_scatter_nhwc_strided_backward(0, 8, 1, 16, 16, 4, 4, None, 8, None, None, None, None) == 0   # nothing to do
     assert lib.mmt_pillar_scatter_nhwc_strided_backward(4, 8, 1, 16, 16, 4, 4, p, 8, None, None, p, None) == -1
     assert lib.mmt_pillar_scatter_nhwc_strided_backward(4, 8, 1, 16, 16, 5, 4, p, 8, p, None, p, None) == -2
+
+
+def test_voxelizer_size_functions(mmt_lib):
+    """mmt_voxelize_table_elems / _scratch_elems / _workspace_elems (ABI 11: they take the point count and max_points): zero for bad
+    arguments, growing with the cloud, the table below the dense 8-bytes-per-cell table of the chain form, the workspace their sum."""
+    lib = mmt_lib.lib()
+    g512, g_native = mmt_lib.int3([512, 512, 1]), mmt_lib.int3([2048, 256, 1])
+    assert lib.mmt_voxelize_table_elems(0, g512, 1000) == 0 and lib.mmt_voxelize_table_elems(4, None, 1000) == 0
+    assert lib.mmt_voxelize_scratch_elems(4, g512, -1, 15) == 0 and lib.mmt_voxelize_scratch_elems(4, g512, 1000, 0) == 0
+    t1, t2 = lib.mmt_voxelize_table_elems(4, g512, 160000), lib.mmt_voxelize_table_elems(4, g512, 320000)
+    assert t2 - t1 == 160000                                             # one voxel id per point on top of the directory
+    cells = 4 * 512 * 512
+    assert cells < t1 - 160000 < cells * 1.05 < 2 * cells                # bits + ordinals + one head per cell
+    s1 = lib.mmt_voxelize_scratch_elems(4, g512, 160000, 15)
+    assert 14 * 160000 < s1 < 16 * 160000 + 4 * 700 * 128                # the heads' lists dominate
+    assert lib.mmt_voxelize_scratch_elems(4, g512, 160000, 1) < 160000 + 4 * 700 * 128
+    assert lib.mmt_voxelize_workspace_elems(8, 320000, g_native, 15) == lib.mmt_voxelize_table_elems(8, g_native, 320000) + \
+        lib.mmt_voxelize_scratch_elems(8, g_native, 320000, 15) + 2
