@@ -844,8 +844,10 @@ void launch_prepare(mmt::TimedSeq &seq, const PlanArgs &p, hipStream_t st, bool 
 }
 
 static int plan_fwd_wgs() {
+    // 2 048 over the batch: at BASELINE configs[3] (1 280 records) the same as 1 024 (22.1 / 22.2 us), at configs[4] (1 844 records: a
+    // record per workgroup) 46.2 against 50.2 us, at the reference's native frustum 52.4 against 60.2 (tools/scratch/plan_wgs.sh)
     static const char *env = getenv("MMT_PLAN_WGS");          // experiments only
-    return (env && atoi(env) > 0) ? atoi(env) : 1024;
+    return (env && atoi(env) > 0) ? atoi(env) : 2048;
 }
 
 template <typename FT>
@@ -865,8 +867,8 @@ int plan_forward_impl(const char *what, int B, int N, int D, int fH, int fW, int
     a.depth_bytes = (unsigned)((int64_t)B * N * fH * fW * D * (int64_t)sizeof(FT));
     a.ctx_bytes = (unsigned)((int64_t)B * N * fH * fW * C * (int64_t)sizeof(FT));
     const Dims &d = a.p.d;
-    // persistent workgroups: as many as the chip holds at once (4 per CU: 35 KB of LDS, 128 VGPRs), every one walks its share of
-    // the sample's units with the next record in flight
+    // persistent workgroups: two rounds of what the chip holds at once (4 per CU: 35 KB of LDS, 128 VGPRs), every one walks its
+    // share of the sample's units with the next record in flight
     int W = plan_fwd_wgs() / B;
     if (W > d.jobs_cap) W = d.jobs_cap;
     W = (W + 7) & ~7;
