@@ -40,6 +40,7 @@ struct BnArgs {
     int relu, has_res;
     float momentum, eps;
     const void *x, *res, *y_in, *dy;   // activations, AT
+    const void *dy2;                   // backward, nullable: a second gradient of y (the output was handed out twice: conv path + identity of the next block), added on load
     const float *weight, *bias;
     float *running_mean, *running_var;
     float *acc;            // [blocks, 2*C] per-workgroup partial sums (scratch)
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
     if (live && r_begin < r_end) {
         const int64_t last = r_end - 1;
         for (int64_t r0 = r_begin + rsub; r0 < r_end; r0 += (int64_t)kRowsInFlight * g.rpi) {
-            float4 vx[kRowsInFlight], vd[kRowsInFlight], vy[kRowsInFlight];
+            float4 vx[kRowsInFlight], vd[kRowsInFlight], vd2[kRowsInFlight], vy[kRowsInFlight];
             float wgt[kRowsInFlight];
 #pragma unroll
             for (int u = 0; u < kRowsInFlight; ++u) {
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
                 vx[u] = ld4<AT>(a.x, off);
                 if (MODE == 1) {
                     vd[u] = ld4<AT>(a.dy, off);
+                    if (a.dy2) vd2[u] = ld4<AT>(a.dy2, off);
                     if (a.has_res) vy[u] = ld4<AT>(a.y_in, off);
                 }
             }
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
                     sb.z += w * vx[u].z * vx[u].z; sb.w += w * vx[u].w * vx[u].w;
                 } else {
                     float4 d = vd[u];
+                    if (a.dy2) { d.x += vd2[u].x; d.y += vd2[u].y; d.z += vd2[u].z; d.w += vd2[u].w; }
                     d.x *= wgt[u]; d.y *= wgt[u]; d.z *= wgt[u]; d.w *= wgt[u];
                     if (a.relu) {
                         if (a.has_res) {
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
                 if (a.has_res) vr[u] = ld4<AT>(a.res, idx[u]);
             } else {
                 vd[u] = ld4<AT>(a.dy, idx[u]);
+                if (a.dy2) { const float4 t = ld4<AT>(a.dy2, idx[u]); vd[u].x += t.x; vd[u].y += t.y; vd[u].z += t.z; vd[u].w += t.w; }
                 if (a.has_res) vr[u] = ld4<AT>(a.y_in, idx[u]);
             }
         }
@@ -343,7 +347,7 @@ void launch_backward(BnArgs a, int blocks, int64_t rpb, hipStream_t st, int *rc)
     if (a.dres) {
         // the reduce pass has written grad_residual = masked grad_y: the dx pass reads that instead of
         // grad_y + y (7 passes instead of 8 for the residual variant)
-        a.dy = a.dres; a.dres = nullptr; a.relu = 0; a.has_res = 0;
+        a.dy = a.dres; a.dy2 = nullptr; a.dres = nullptr; a.relu = 0; a.has_res = 0;
     }
     hipLaunchKernelGGL((bn_map_kernel<1, AT>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
     *rc = mmt::check_launch("bn_relu_backward(dx)");
@@ -385,10 +389,10 @@ extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float
                                   MMT_DTYPE_F32, stream);
 }
 
-extern "C" int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const void *y, const void *grad_y,
-                                       const float *save, int relu, int has_residual, float *workspace,
-                                       void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
-                                       int act_dtype, void *stream) {
+extern "C" int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const void *y, const void *grad_y, const void *grad_y2,
+                                        const float *save, int relu, int has_residual, float *workspace,
+                                        void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
+                                        int act_dtype, void *stream) {
     MMT_REQUIRE_PTR(x);
     MMT_REQUIRE_PTR(grad_y);
     MMT_REQUIRE_PTR(save);
@@ -402,11 +406,11 @@ extern "C" int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const vo
     BnArgs a = {};
     if (int rc = geometry("bn_relu_backward", R, C, &a.g)) return rc;
     const uintptr_t act_mask = act_dtype == MMT_DTYPE_F32 ? 15 : 7;
-    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_residual) & act_mask) ||
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_y2 | (uintptr_t)grad_x | (uintptr_t)grad_residual) & act_mask) ||
         (((uintptr_t)workspace | (uintptr_t)save) & 15))
         return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_backward: buffers must be 16-byte aligned (bf16 activations: 8)");
     a.R = R; a.C = C; a.relu = relu; a.has_res = (relu && has_residual) ? 1 : 0;
-    a.x = x; a.y_in = y; a.dy = grad_y;
+    a.x = x; a.y_in = y; a.dy = grad_y; a.dy2 = grad_y2;
     a.acc = workspace + 2 * C; a.coef = workspace;
     a.scale = const_cast<float *>(save) + 2 * C; a.shift = const_cast<float *>(save) + 3 * C;
     a.save_mean = const_cast<float *>(save_mean); a.save_rstd = const_cast<float *>(save_rstd);
@@ -417,6 +421,14 @@ extern "C" int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const vo
     if (act_dtype == MMT_DTYPE_F32) launch_backward<float>(a, blocks, rpb, (hipStream_t)stream, &rc);
     else launch_backward<bf16_t>(a, blocks, rpb, (hipStream_t)stream, &rc);
     return rc;
+}
+
+extern "C" int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const void *y, const void *grad_y,
+                                       const float *save, int relu, int has_residual, float *workspace,
+                                       void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
+                                       int act_dtype, void *stream) {
+    return mmt_bn_relu_backward_ex2(R, C, x, y, grad_y, nullptr, save, relu, has_residual, workspace, grad_x, grad_residual, grad_weight,
+                                    grad_bias, act_dtype, stream);
 }
 
 extern "C" int mmt_bn_relu_backward(int64_t R, int C, const float *x, const float *y, const float *grad_y,

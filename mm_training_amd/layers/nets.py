@@ -17,6 +17,7 @@ from ..ops.bn_relu import ConvBNAct, bn_act
 
 class BasicBlock(nn.Module):
     expansion = 1
+    fork_output = False        # True (set by ResNet for a block that another block of its stage follows): the output as a pair of aliases
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
@@ -28,13 +29,15 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
+        x, x_res = x if isinstance(x, tuple) else (x, x)          # (a forked block output: see _block_output)
+        identity = x_res if self.downsample is None else self.downsample(x)
         out = bn_act(self.bn1, self.conv1(x))
-        return bn_act(self.bn2, self.conv2(out), residual=identity)
+        return bn_act(self.bn2, self.conv2(out), residual=identity, fork=self.fork_output)
 
 
 class Bottleneck(nn.Module):
     expansion = 4
+    fork_output = False        # (see BasicBlock)
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
@@ -49,10 +52,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
+        x, x_res = x if isinstance(x, tuple) else (x, x)          # (a forked block output: see _block_output)
+        identity = x_res if self.downsample is None else self.downsample(x)
         out = bn_act(self.bn1, self.conv1(x))
         out = bn_act(self.bn2, self.conv2(out))
-        return bn_act(self.bn3, self.conv3(out), residual=identity)
+        return bn_act(self.bn3, self.conv3(out), residual=identity, fork=self.fork_output)
 
 
 class ResNet(nn.Module):
@@ -80,6 +84,7 @@ class ResNet(nn.Module):
                     down = ConvBNAct(nn.Conv2d(inplanes, planes * block.expansion, 1, s, bias=False),
                                          nn.BatchNorm2d(planes * block.expansion))
                 layers.append(block(inplanes, planes, s, down))
+                layers[-1].fork_output = j + 1 < blocks[i]           # its successor has no downsample: it reads the output twice
                 inplanes = planes * block.expansion
             self.stages.append(nn.Sequential(*layers))
         self.init_weights()
@@ -95,6 +100,9 @@ class ResNet(nn.Module):
     def forward(self, x):
         x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         outs = []
+        # Inside a stage a block hands its output on as a PAIR of aliases (bn_act(..., fork=True)): the next block reads the first
+        # with its convolutions and the second as its identity, and the two gradients meet inside the fused BatchNorm backward
+        # instead of in an accumulation pass of autograd's.  A stage's last block returns a plain tensor.
         for i, stage in enumerate(self.stages):
             x = stage(x)
             if i in self.out_indices:

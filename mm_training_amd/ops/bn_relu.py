@@ -39,7 +39,7 @@ class _BnAct(Function):
     """x, residual, y and their gradients share one dtype (fp32 or bf16); parameters, statistics and arithmetic are fp32."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, workspace, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, workspace, momentum, eps, relu, fork=False):
         B, C, H, W = x.shape
         R = B * H * W
         act = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
@@ -58,25 +58,38 @@ class _BnAct(Function):
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, save, workspace)
         ctx.cfg = (R, C, bool(relu), residual is not None, act)
+        if fork:
+            # the output twice, as two aliases of one buffer: the backward then receives the gradient of either use on its own and
+            # adds them while loading (no accumulation pass by autograd in between)
+            ctx.set_materialize_grads(False)
+            return y, y.view_as(y)
         return y
 
     @staticmethod
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, grad_y2=None):
         x, y, save, workspace = ctx.saved_tensors
         R, C, relu, has_res, act = ctx.cfg
-        if grad_y.dtype != x.dtype:
-            grad_y = grad_y.to(x.dtype)
-        if not grad_y.is_contiguous(memory_format=torch.channels_last):
-            grad_y = grad_y.contiguous(memory_format=torch.channels_last)
+        if grad_y is None:
+            grad_y, grad_y2 = grad_y2, None
+        if grad_y is None:                       # (neither alias was used in what was differentiated)
+            grad_y = torch.zeros_like(x)
+
+        def _prep(g):
+            if g.dtype != x.dtype:
+                g = g.to(x.dtype)
+            return g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
+        grad_y = _prep(grad_y)
+        grad_y2 = _prep(grad_y2) if grad_y2 is not None else None
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if has_res else None
         grad_w = torch.empty(C, dtype=torch.float32, device=x.device)
         grad_b = torch.empty(C, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.call("mmt_bn_relu_backward_ex", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
+            _lib.call("mmt_bn_relu_backward_ex2", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
+                      grad_y2.data_ptr() if grad_y2 is not None else 0,
                       save.data_ptr(), int(relu), int(has_res), workspace.data_ptr(), grad_x.data_ptr(),
                       grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), act, _stream())
-        return grad_x, grad_res, grad_w, grad_b, None, None, None, None, None, None
+        return grad_x, grad_res, grad_w, grad_b, None, None, None, None, None, None, None
 
 
 _SCRATCH = {}
@@ -96,8 +109,15 @@ def _workspace(bn, device):
     return ws
 
 
-def bn_act(bn, x, residual=None, relu=True):
-    """relu?(bn(x) [+ residual]) with ``bn`` an ``nn.BatchNorm2d`` (see module docstring)."""
+FORK = os.environ.get("MMT_BN_FORK", "1") != "0"
+
+
+def bn_act(bn, x, residual=None, relu=True, fork=False):
+    """relu?(bn(x) [+ residual]) with ``bn`` an ``nn.BatchNorm2d`` (see module docstring).  ``fork=True`` returns the result as a
+    pair of aliases ``(y, y')`` of one buffer for a caller that uses it twice (a residual block's output: the next block's first
+    convolution and its identity): the two gradients then meet inside the fused backward (added while loading,
+    ``mmt_bn_relu_backward_ex2``) instead of in an accumulation pass of autograd's -- three streams over the activation less per
+    residual join.  On the unfused path the pair is the same tensor twice."""
     if _supported(bn, x):
         if residual is not None and residual.dtype != x.dtype:
             residual = residual.to(x.dtype)              # (autograd casts the gradient back)
@@ -106,11 +126,12 @@ def bn_act(bn, x, residual=None, relu=True):
         # access inside it was met twice: DESIGN section 4, fuzz_dense; tools/scratch/soak_streams.py)
         with torch.autocast("cuda", enabled=False):
             return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                _workspace(bn, x.device), bn.momentum, bn.eps, relu)
+                                _workspace(bn, x.device), bn.momentum, bn.eps, relu, bool(fork and FORK))
     out = bn(x)
     if residual is not None:
         out = out + residual
-    return F.relu(out, inplace=True) if relu else out
+    out = F.relu(out, inplace=True) if relu else out
+    return (out, out) if fork else out
 
 
 class ConvBNAct(torch.nn.Sequential):

@@ -119,3 +119,64 @@ def test_bf16_activations_inside_autocast(mmt_lib, shape, use_res, relu):
             y2 = bn_act(bn_a, x0.clone().requires_grad_(True), r32, relu)
         y2.backward(go)
         assert r32.grad.dtype == torch.float32 and y2.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 32, 44), (2, 256, 16, 22), (24, 64, 64, 176)])
+@pytest.mark.parametrize("use_res", [True, False])
+def test_forked_output_adds_its_two_gradients_inside_the_backward(mmt_lib, shape, use_res):
+    """bn_act(..., fork=True): the output as a pair of aliases; the backward receives the gradient of either use and adds them while
+    loading (mmt_bn_relu_backward_ex2).  Against plain autograd on the same graph (one output used twice), with either alias unused,
+    and with both."""
+    from mm_training_amd.ops.bn_relu import bn_act
+    B, C, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    x0 = (torch.randn(shape, device="cuda", generator=g) * 1.3).contiguous(memory_format=torch.channels_last)
+    r0 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last) if use_res else None
+    w1 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w2 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    bn_a, bn_b = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
+    bn_b.load_state_dict(bn_a.state_dict())
+    for use in ((True, True), (True, False), (False, True)):
+        res = []
+        for bn, fork in ((bn_a, True), (bn_b, False)):
+            bn.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            r = r0.clone().requires_grad_(True) if use_res else None
+            if fork:
+                ya, yb = bn_act(bn, x, r, True, fork=True)
+                assert ya.data_ptr() == yb.data_ptr()
+            else:
+                ya = yb = bn_act(bn, x, r, True)
+            loss = (ya * w1).sum() * float(use[0]) + (yb * w2).sum() * float(use[1]) if all(use) else ((ya * w1).sum() if use[0] else (yb * w2).sum())
+            loss.backward()
+            res.append((x.grad, r.grad if use_res else None, bn.weight.grad, bn.bias.grad))
+        for name, a, b in zip(("grad_x", "grad_res", "grad_weight", "grad_bias"), res[0], res[1]):
+            if a is None:
+                continue
+            tol = (2e-3 if name in ("grad_weight", "grad_bias") else 2e-5) * max(1.0, b.abs().max().item())
+            assert ((a - b).abs() > tol).float().mean().item() <= 1e-5, (use, name, (a - b).abs().max().item())
+
+
+def test_resnet_stage_with_forked_blocks_equals_plain_blocks(mmt_lib):
+    """layers/nets.py::ResNet hands block outputs on as pairs inside a stage: same outputs and gradients as with MMT_BN_FORK off."""
+    from mm_training_amd.layers.nets import ResNet
+    from mm_training_amd.ops import bn_relu
+    torch.manual_seed(3)
+    m = ResNet(depth=50, in_channels=3, base_channels=16, num_stages=3, strides=(1, 2, 2), out_indices=(0, 1, 2)).cuda().to(memory_format=torch.channels_last)
+    x0 = torch.randn(2, 3, 64, 96, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = []
+    try:
+        for fork in (True, False):
+            bn_relu.FORK = fork
+            m.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            outs = m(x)
+            sum((o * o).mean() for o in outs).backward()
+            res.append(([o.detach() for o in outs], x.grad, [p.grad.clone() for p in m.parameters()]))
+    finally:
+        bn_relu.FORK = True
+    for a, b in zip(res[0][0], res[1][0]):                     # (MIOpen's convolutions are not bit-stable from call to call)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4 * float(res[1][1].abs().max())
+    for a, b in zip(res[0][2], res[1][2]):
+        assert float((a - b).abs().max()) <= 2e-3 * max(1e-6, float(b.abs().max()))
