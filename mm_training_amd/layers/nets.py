@@ -30,7 +30,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         x, x_res = x if isinstance(x, tuple) else (x, x)          # (a forked block output: see _block_output)
-        identity = x_res if self.downsample is None else self.downsample(x)
+        identity = x_res if self.downsample is None else self.downsample(x_res)
         out = bn_act(self.bn1, self.conv1(x))
         return bn_act(self.bn2, self.conv2(out), residual=identity, fork=self.fork_output)
 
@@ -53,7 +53,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         x, x_res = x if isinstance(x, tuple) else (x, x)          # (a forked block output: see _block_output)
-        identity = x_res if self.downsample is None else self.downsample(x)
+        identity = x_res if self.downsample is None else self.downsample(x_res)
         out = bn_act(self.bn1, self.conv1(x))
         out = bn_act(self.bn2, self.conv2(out))
         return bn_act(self.bn3, self.conv3(out), residual=identity, fork=self.fork_output)
@@ -84,7 +84,7 @@ class ResNet(nn.Module):
                     down = ConvBNAct(nn.Conv2d(inplanes, planes * block.expansion, 1, s, bias=False),
                                          nn.BatchNorm2d(planes * block.expansion))
                 layers.append(block(inplanes, planes, s, down))
-                layers[-1].fork_output = j + 1 < blocks[i]           # its successor has no downsample: it reads the output twice
+                layers[-1].fork_output = j + 1 < blocks[i] or i + 1 < num_stages      # another block reads the output twice (convolutions / identity or downsample)
                 inplanes = planes * block.expansion
             self.stages.append(nn.Sequential(*layers))
         self.init_weights()
@@ -100,13 +100,14 @@ class ResNet(nn.Module):
     def forward(self, x):
         x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         outs = []
-        # Inside a stage a block hands its output on as a PAIR of aliases (bn_act(..., fork=True)): the next block reads the first
-        # with its convolutions and the second as its identity, and the two gradients meet inside the fused BatchNorm backward
-        # instead of in an accumulation pass of autograd's.  A stage's last block returns a plain tensor.
+        # A block hands its output on as a PAIR of aliases (bn_act(..., fork=True)): the next block reads the first with its first
+        # convolution and the second as its identity (or through its downsample convolution), and the two gradients meet inside
+        # the fused BatchNorm backward instead of in an accumulation pass of autograd's.  The necks read the first alias; the last
+        # block of the last stage returns a plain tensor.
         for i, stage in enumerate(self.stages):
             x = stage(x)
             if i in self.out_indices:
-                outs.append(x)
+                outs.append(x[0] if isinstance(x, tuple) else x)
         return tuple(outs)
 
 
