@@ -728,12 +728,13 @@ int mmt_bn_relu_forward_ex(int64_t R, int C, const void *x, const void *residual
 int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const void *y, const void *grad_y,
                             const float *save, int relu, int has_residual, float *workspace, void *grad_x,
                             void *grad_residual, float *grad_weight, float *grad_bias, int act_dtype, void *stream);
-/* ABI 11: the same with a SECOND gradient of y (nullable), added to grad_y on load.  The output of a residual block is read twice --
- * by the next block's first convolution and as its identity -- and autograd would add the two gradients in a pass of its own
- * (three streams over the activation) before this backward reads the sum; `ops/bn_relu.py::bn_act(..., fork=True)` hands the
- * output out as two aliases instead and receives the two gradients here. */
+/* ABI 11: the same with a SECOND and a THIRD gradient of y (nullable; the third only with the second), added to grad_y on load.
+ * The output of a residual block is read twice -- by the next block's first convolution and as its identity (or through its
+ * downsample convolution), a stage's output a third time by the neck -- and autograd would add the gradients in passes of its own
+ * (three streams over the activation each) before this backward reads the sum; `ops/bn_relu.py::bn_act(..., fork=2|3)` hands the
+ * output out as aliases instead and receives their gradients here. */
 int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const void *y, const void *grad_y, const void *grad_y2,
-                             const float *save, int relu, int has_residual, float *workspace, void *grad_x,
+                             const void *grad_y3, const float *save, int relu, int has_residual, float *workspace, void *grad_x,
                              void *grad_residual, float *grad_weight, float *grad_bias, int act_dtype, void *stream);
 
 #ifdef __cplusplus

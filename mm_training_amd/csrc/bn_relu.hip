@@ -40,6 +40,7 @@ struct BnArgs {
     int relu, has_res;
     float momentum, eps;
     const void *x, *res, *y_in, *dy;   // activations, AT
+    const void *dy3;                   // backward, nullable (only with dy2): a third one
     const void *dy2;                   // backward, nullable: a second gradient of y (the output was handed out twice: conv path + identity of the next block), added on load
     const float *weight, *bias;
     float *running_mean, *running_var;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
     if (live && r_begin < r_end) {
         const int64_t last = r_end - 1;
         for (int64_t r0 = r_begin + rsub; r0 < r_end; r0 += (int64_t)kRowsInFlight * g.rpi) {
-            float4 vx[kRowsInFlight], vd[kRowsInFlight], vd2[kRowsInFlight], vy[kRowsInFlight];
+            float4 vx[kRowsInFlight], vd[kRowsInFlight], vd2[kRowsInFlight], vd3[kRowsInFlight], vy[kRowsInFlight];
             float wgt[kRowsInFlight];
 #pragma unroll
             for (int u = 0; u < kRowsInFlight; ++u) {
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
                 if (MODE == 1) {
                     vd[u] = ld4<AT>(a.dy, off);
                     if (a.dy2) vd2[u] = ld4<AT>(a.dy2, off);
+                    if (a.dy3) vd3[u] = ld4<AT>(a.dy3, off);
                     if (a.has_res) vy[u] = ld4<AT>(a.y_in, off);
                 }
             }
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
                 } else {
                     float4 d = vd[u];
                     if (a.dy2) { d.x += vd2[u].x; d.y += vd2[u].y; d.z += vd2[u].z; d.w += vd2[u].w; }
+                    if (a.dy3) { d.x += vd3[u].x; d.y += vd3[u].y; d.z += vd3[u].z; d.w += vd3[u].w; }
                     d.x *= wgt[u]; d.y *= wgt[u]; d.z *= wgt[u]; d.w *= wgt[u];
                     if (a.relu) {
                         if (a.has_res) {
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
             } else {
                 vd[u] = ld4<AT>(a.dy, idx[u]);
                 if (a.dy2) { const float4 t = ld4<AT>(a.dy2, idx[u]); vd[u].x += t.x; vd[u].y += t.y; vd[u].z += t.z; vd[u].w += t.w; }
+                if (a.dy3) { const float4 t = ld4<AT>(a.dy3, idx[u]); vd[u].x += t.x; vd[u].y += t.y; vd[u].z += t.z; vd[u].w += t.w; }
                 if (a.has_res) vr[u] = ld4<AT>(a.y_in, idx[u]);
             }
         }
@@ -347,7 +351,7 @@ void launch_backward(BnArgs a, int blocks, int64_t rpb, hipStream_t st, int *rc)
     if (a.dres) {
         // the reduce pass has written grad_residual = masked grad_y: the dx pass reads that instead of
         // grad_y + y (7 passes instead of 8 for the residual variant)
-        a.dy = a.dres; a.dy2 = nullptr; a.dres = nullptr; a.relu = 0; a.has_res = 0;
+        a.dy = a.dres; a.dy2 = nullptr; a.dy3 = nullptr; a.dres = nullptr; a.relu = 0; a.has_res = 0;
     }
     hipLaunchKernelGGL((bn_map_kernel<1, AT>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
     *rc = mmt::check_launch("bn_relu_backward(dx)");
@@ -390,7 +394,7 @@ extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float
 }
 
 extern "C" int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const void *y, const void *grad_y, const void *grad_y2,
-                                        const float *save, int relu, int has_residual, float *workspace,
+                                        const void *grad_y3, const float *save, int relu, int has_residual, float *workspace,
                                         void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
                                         int act_dtype, void *stream) {
     MMT_REQUIRE_PTR(x);
@@ -406,11 +410,11 @@ extern "C" int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const v
     BnArgs a = {};
     if (int rc = geometry("bn_relu_backward", R, C, &a.g)) return rc;
     const uintptr_t act_mask = act_dtype == MMT_DTYPE_F32 ? 15 : 7;
-    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_y2 | (uintptr_t)grad_x | (uintptr_t)grad_residual) & act_mask) ||
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_y2 | (uintptr_t)grad_y3 | (uintptr_t)grad_x | (uintptr_t)grad_residual) & act_mask) ||
         (((uintptr_t)workspace | (uintptr_t)save) & 15))
         return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_backward: buffers must be 16-byte aligned (bf16 activations: 8)");
     a.R = R; a.C = C; a.relu = relu; a.has_res = (relu && has_residual) ? 1 : 0;
-    a.x = x; a.y_in = y; a.dy = grad_y; a.dy2 = grad_y2;
+    a.x = x; a.y_in = y; a.dy = grad_y; a.dy2 = grad_y2; a.dy3 = grad_y2 ? grad_y3 : nullptr;
     a.acc = workspace + 2 * C; a.coef = workspace;
     a.scale = const_cast<float *>(save) + 2 * C; a.shift = const_cast<float *>(save) + 3 * C;
     a.save_mean = const_cast<float *>(save_mean); a.save_rstd = const_cast<float *>(save_rstd);
@@ -427,7 +431,7 @@ extern "C" int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const vo
                                        const float *save, int relu, int has_residual, float *workspace,
                                        void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
                                        int act_dtype, void *stream) {
-    return mmt_bn_relu_backward_ex2(R, C, x, y, grad_y, nullptr, save, relu, has_residual, workspace, grad_x, grad_residual, grad_weight,
+    return mmt_bn_relu_backward_ex2(R, C, x, y, grad_y, nullptr, nullptr, save, relu, has_residual, workspace, grad_x, grad_residual, grad_weight,
                                     grad_bias, act_dtype, stream);
 }
 

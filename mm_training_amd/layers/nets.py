@@ -29,7 +29,7 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        x, x_res = x if isinstance(x, tuple) else (x, x)          # (a forked block output: see _block_output)
+        x, x_res = x[:2] if isinstance(x, tuple) else (x, x)      # (a forked block output: see ResNet.forward)
         identity = x_res if self.downsample is None else self.downsample(x_res)
         out = bn_act(self.bn1, self.conv1(x))
         return bn_act(self.bn2, self.conv2(out), residual=identity, fork=self.fork_output)
@@ -52,7 +52,7 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        x, x_res = x if isinstance(x, tuple) else (x, x)          # (a forked block output: see _block_output)
+        x, x_res = x[:2] if isinstance(x, tuple) else (x, x)      # (a forked block output: see ResNet.forward)
         identity = x_res if self.downsample is None else self.downsample(x_res)
         out = bn_act(self.bn1, self.conv1(x))
         out = bn_act(self.bn2, self.conv2(out))
@@ -84,7 +84,8 @@ class ResNet(nn.Module):
                     down = ConvBNAct(nn.Conv2d(inplanes, planes * block.expansion, 1, s, bias=False),
                                          nn.BatchNorm2d(planes * block.expansion))
                 layers.append(block(inplanes, planes, s, down))
-                layers[-1].fork_output = j + 1 < blocks[i] or i + 1 < num_stages      # another block reads the output twice (convolutions / identity or downsample)
+                # another block reads the output twice (first convolution; identity or downsample), the neck a stage's output once more
+                layers[-1].fork_output = 2 if j + 1 < blocks[i] else ((3 if i in self.out_indices else 2) if i + 1 < num_stages else False)
                 inplanes = planes * block.expansion
             self.stages.append(nn.Sequential(*layers))
         self.init_weights()
@@ -100,14 +101,14 @@ class ResNet(nn.Module):
     def forward(self, x):
         x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         outs = []
-        # A block hands its output on as a PAIR of aliases (bn_act(..., fork=True)): the next block reads the first with its first
-        # convolution and the second as its identity (or through its downsample convolution), and the two gradients meet inside
-        # the fused BatchNorm backward instead of in an accumulation pass of autograd's.  The necks read the first alias; the last
-        # block of the last stage returns a plain tensor.
+        # A block hands its output on as a tuple of ALIASES of one buffer (bn_act(..., fork=2|3)): the next block reads the first with
+        # its first convolution and the second as its identity (or through its downsample convolution), the neck takes the third
+        # of a stage's output -- and the gradients of the uses meet inside the fused BatchNorm backward (added while loading)
+        # instead of in accumulation passes of autograd's.  The last block of the last stage returns a plain tensor.
         for i, stage in enumerate(self.stages):
             x = stage(x)
             if i in self.out_indices:
-                outs.append(x[0] if isinstance(x, tuple) else x)
+                outs.append(x[-1] if isinstance(x, tuple) else x)
         return tuple(outs)
 
 

@@ -59,20 +59,22 @@ class _BnAct(Function):
         ctx.save_for_backward(x, y if need_y else None, save, workspace)
         ctx.cfg = (R, C, bool(relu), residual is not None, act)
         if fork:
-            # the output twice, as two aliases of one buffer: the backward then receives the gradient of either use on its own and
-            # adds them while loading (no accumulation pass by autograd in between)
+            # the output two or three times, as aliases of one buffer: the backward then receives the gradient of every use on its
+            # own and adds them while loading (no accumulation pass by autograd in between)
             ctx.set_materialize_grads(False)
-            return y, y.view_as(y)
+            return (y,) + tuple(y.view_as(y) for _ in range(int(fork) - 1))
         return y
 
     @staticmethod
-    def backward(ctx, grad_y, grad_y2=None):
+    def backward(ctx, *grads):
         x, y, save, workspace = ctx.saved_tensors
         R, C, relu, has_res, act = ctx.cfg
-        if grad_y is None:
-            grad_y, grad_y2 = grad_y2, None
-        if grad_y is None:                       # (neither alias was used in what was differentiated)
-            grad_y = torch.zeros_like(x)
+        grads = [g for g in grads if g is not None]
+        if not grads:                            # (no alias was used in what was differentiated)
+            grads = [torch.zeros_like(x)]
+        grad_y = grads[0]
+        grad_y2 = grads[1] if len(grads) > 1 else None
+        grad_y3 = grads[2] if len(grads) > 2 else None
 
         def _prep(g):
             if g.dtype != x.dtype:
@@ -80,13 +82,14 @@ class _BnAct(Function):
             return g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
         grad_y = _prep(grad_y)
         grad_y2 = _prep(grad_y2) if grad_y2 is not None else None
+        grad_y3 = _prep(grad_y3) if grad_y3 is not None else None
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if has_res else None
         grad_w = torch.empty(C, dtype=torch.float32, device=x.device)
         grad_b = torch.empty(C, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.call("mmt_bn_relu_backward_ex2", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
-                      grad_y2.data_ptr() if grad_y2 is not None else 0,
+                      grad_y2.data_ptr() if grad_y2 is not None else 0, grad_y3.data_ptr() if grad_y3 is not None else 0,
                       save.data_ptr(), int(relu), int(has_res), workspace.data_ptr(), grad_x.data_ptr(),
                       grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), act, _stream())
         return grad_x, grad_res, grad_w, grad_b, None, None, None, None, None, None, None
@@ -113,8 +116,8 @@ FORK = os.environ.get("MMT_BN_FORK", "1") != "0"
 
 
 def bn_act(bn, x, residual=None, relu=True, fork=False):
-    """relu?(bn(x) [+ residual]) with ``bn`` an ``nn.BatchNorm2d`` (see module docstring).  ``fork=True`` returns the result as a
-    pair of aliases ``(y, y')`` of one buffer for a caller that uses it twice (a residual block's output: the next block's first
+    """relu?(bn(x) [+ residual]) with ``bn`` an ``nn.BatchNorm2d`` (see module docstring).  ``fork=True`` (or 2; 3 for three uses)
+    returns the result as a tuple of aliases ``(y, y', ..)`` of one buffer for a caller that uses it twice (a residual block's output: the next block's first
     convolution and its identity): the two gradients then meet inside the fused backward (added while loading,
     ``mmt_bn_relu_backward_ex2``) instead of in an accumulation pass of autograd's -- three streams over the activation less per
     residual join.  On the unfused path the pair is the same tensor twice."""
@@ -126,12 +129,12 @@ def bn_act(bn, x, residual=None, relu=True, fork=False):
         # access inside it was met twice: DESIGN section 4, fuzz_dense; tools/scratch/soak_streams.py)
         with torch.autocast("cuda", enabled=False):
             return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                _workspace(bn, x.device), bn.momentum, bn.eps, relu, bool(fork and FORK))
+                                _workspace(bn, x.device), bn.momentum, bn.eps, relu, (2 if fork is True else int(fork)) if (fork and FORK) else 0)
     out = bn(x)
     if residual is not None:
         out = out + residual
     out = F.relu(out, inplace=True) if relu else out
-    return (out, out) if fork else out
+    return (out,) * (2 if fork is True else int(fork)) if fork else out
 
 
 class ConvBNAct(torch.nn.Sequential):

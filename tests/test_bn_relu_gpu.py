@@ -136,6 +136,23 @@ def test_forked_output_adds_its_two_gradients_inside_the_backward(mmt_lib, shape
     w2 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
     bn_a, bn_b = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
     bn_b.load_state_dict(bn_a.state_dict())
+    # three aliases: every one used
+    bn_c = nn.BatchNorm2d(C).cuda()
+    bn_c.load_state_dict(bn_a.state_dict())
+    w3 = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    grads3 = []
+    for bn, fork in ((bn_a, 3), (bn_c, 0)):
+        bn.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if use_res else None
+        ys = bn_act(bn, x, r, True, fork=fork) if fork else (bn_act(bn, x, r, True),) * 3
+        assert len(ys) == 3 and ys[0].data_ptr() == ys[2].data_ptr()
+        ((ys[0] * w1).sum() + (ys[1] * w2).sum() + (ys[2] * w3).sum()).backward()
+        grads3.append((x.grad, r.grad if use_res else None, bn.weight.grad, bn.bias.grad))
+    for name, a, b in zip(("grad_x", "grad_res", "grad_weight", "grad_bias"), grads3[0], grads3[1]):
+        if a is not None:
+            tol = (2e-3 if name in ("grad_weight", "grad_bias") else 2e-5) * max(1.0, b.abs().max().item())
+            assert ((a - b).abs() > tol).float().mean().item() <= 1e-5, ("three aliases", name, (a - b).abs().max().item())
     for use in ((True, True), (True, False), (False, True)):
         res = []
         for bn, fork in ((bn_a, True), (bn_b, False)):
