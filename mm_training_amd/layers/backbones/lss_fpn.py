@@ -98,14 +98,19 @@ class DepthNet(nn.Module):
             BasicBlock(mid_channels, mid_channels), ASPP(mid_channels, mid_channels),
             DeformConv2dPack(mid_channels, mid_channels, kernel_size=3, padding=1, groups=4),
             nn.Conv2d(mid_channels, depth_channels, 1))
+        # the outputs that are read more than once leave as aliases, their gradients meet inside the fused BatchNorm backward
+        # (ops/bn_relu.py::bn_act, fork): reduce_conv -> context_conv / the first block's convolution / its identity
+        self.reduce_conv.fork = 3
+        self.depth_conv[0].fork_output = self.depth_conv[1].fork_output = 2
 
     def forward_parts(self, x, mats_dict=None):
         """(depth logits [BN, D, fH, fW], context [BN, C, fH, fW]): the two halves of forward()'s concatenation.  LSSFPN slices
         the concatenation apart again two lines later (lss_fpn.py:423, :441-443), so the mirror asks for the halves and the
         cat (two copies, and two slice-gradient copies in backward) never runs in the step."""
         x = self.reduce_conv(x)
-        context = self.context_conv(x)
-        depth = self.depth_conv(self.depth_se(x))
+        xc, xd = (x[0], x[1:]) if isinstance(x, tuple) else (x, x)
+        context = self.context_conv(xc)
+        depth = self.depth_conv(self.depth_se(xd))
         return depth, context
 
     def forward(self, x, mats_dict=None):

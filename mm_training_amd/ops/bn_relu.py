@@ -142,9 +142,11 @@ class ConvBNAct(torch.nn.Sequential):
     are those of the plain Sequential the reference's mmcv / mmdet modules produce) whose forward
     runs the normalisation (+ ReLU) through ``bn_act``."""
 
+    fork = False               # 2 | 3: the output as that many aliases (bn_act), for a caller that reads it that often
+
     def forward(self, x):
         relu = len(self) > 2 and isinstance(self[2], torch.nn.ReLU)
-        out = bn_act(self[1], self[0](x), relu=relu)
+        out = bn_act(self[1], self[0](x), relu=relu, fork=self.fork)
         for extra in list(self)[3 if relu else 2:]:
             out = extra(out)
         return out
