@@ -462,7 +462,12 @@ __device__ __forceinline__ void load_ctx_buf(const __amdgpu_buffer_rsrc_t &rs, u
             c.q[2 * i] = plan_v2f{__uint_as_float(v.x), __uint_as_float(v.y)}; c.q[2 * i + 1] = plan_v2f{__uint_as_float(v.z), __uint_as_float(v.w)};
         }
 #pragma unroll
-        for (int i = 0; i < N1; ++i) c.s[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + (unsigned)(256 * NQ + 64 * i + 4 * li), soff, 0));
+        for (int i = 0; i < N1; ++i)
+#ifdef PLAN_EXP_NOEXTRA      // ablation build: the channels past the float4 pieces are not loaded (results are wrong)
+            c.s[i] = __uint_as_float(voff + soff);
+#else
+            c.s[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + (unsigned)(256 * NQ + 64 * i + 4 * li), soff, 0));
+#endif
     } else {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -471,7 +476,12 @@ __device__ __forceinline__ void load_ctx_buf(const __amdgpu_buffer_rsrc_t &rs, u
             c.q[2 * i] = plan_v2f{bf16_lo(v.x), bf16_hi(v.x)}; c.q[2 * i + 1] = plan_v2f{bf16_lo(v.y), bf16_hi(v.y)};
         }
 #pragma unroll
-        for (int i = 0; i < N1; ++i) c.s[i] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff + (unsigned)(128 * NQ + 32 * i + 2 * li), soff, 0) << 16);
+        for (int i = 0; i < N1; ++i)
+#ifdef PLAN_EXP_NOEXTRA
+            c.s[i] = __uint_as_float(voff + soff);
+#else
+            c.s[i] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff + (unsigned)(128 * NQ + 32 * i + 2 * li), soff, 0) << 16);
+#endif
     }
 }
 
