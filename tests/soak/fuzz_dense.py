@@ -193,7 +193,7 @@ while time.time() < t_end:
     begin = 0
     for t, n in enumerate(class_counts):
         for b in range(B):
-            r_hm, r_anno, r_ind, r_mask = oracle.centerpoint_targets_task(bxs[b][:max_objs], lbs[b][:max_objs], begin, n, max_objs,
+            r_hm, r_anno, r_ind, r_mask = oracle.centerpoint_targets_task(bxs[b], lbs[b], begin, n, max_objs,      # (the cut at max_objs is per task, after the regrouping by class: bev_depth_head.py:186)
                                                                           fx, fy, pc, vs, osf, 0.1, 2)
             if np.abs(hm[t][b].cpu().numpy() - r_hm).max() > 1e-6 or int(mask[t][b].sum()) != int(r_mask.sum()):
                 fail("targets", B=B, task=t, b=b, fx=fx, fy=fy, max_objs=max_objs)
