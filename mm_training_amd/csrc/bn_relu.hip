@@ -319,6 +319,10 @@ void reduce_grid(const BnGeom &g, int64_t R, int *blocks, int64_t *rows_per_bloc
     // (2*C floats) stay below ~6 % of what it reads; at most kMaxPartialBlocks workgroups
     const int64_t trip = (int64_t)g.rpi * kRowsInFlight;
     int64_t nb = R / 64;
+    // ... unless that leaves most of the chip idle (ResNet-50's last stage at BASELINE configs[3]: R = 4 224 rows of 2 048 channels = 66 x 2
+    // workgroups, 18.6 us for 35-69 MB): then down to 16 rows per workgroup, up to 512 workgroups over the column blocks
+    const int64_t fill = 512 / g.kc, fine = R / 16;
+    if (nb < fill) nb = fine < fill ? (fine > nb ? fine : nb) : fill;
     if (nb < 1) nb = 1;
     if (nb > kMaxPartialBlocks) nb = kMaxPartialBlocks;
     const int64_t rpb = mmt::ceil_div(mmt::ceil_div(R, nb), trip) * trip;
