@@ -24,7 +24,6 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kRowsInFlight = 4;
 
 struct BnGeom {
     int C4;        // float4 columns per row
@@ -64,6 +63,20 @@ __device__ __forceinline__ float4 ld4(const void *p, int64_t i) {
         return make_float4(bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y));
     }
 }
+// the same in two steps: the raw 16 / 8 bytes stay in flight (a bf16 quadruple is two registers, not four), converted when consumed
+template <typename AT> struct Raw4 { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef uint2 type; };
+template <typename AT>
+__device__ __forceinline__ typename Raw4<AT>::type ldraw(const void *p, int64_t i) {
+    return reinterpret_cast<const typename Raw4<AT>::type *>(p)[i];
+}
+__device__ __forceinline__ float4 cvt4(const float4 &v) { return v; }
+__device__ __forceinline__ float4 cvt4(const uint2 &t) { return make_float4(bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y)); }
+// rows (reduce) / elements (map) a lane keeps in flight: the same BYTES for either activation type (four 16-byte or eight 8-byte
+// loads per tensor).  Measured flat against four for bf16 (tools/kbench_bn.py --bf16: 3.0-3.5 TB/s either way at the configs[4] shapes);
+// kept because the raw form costs the bf16 kernels no more registers than the fp32 ones use.
+template <typename AT> struct InFlight { static constexpr int value = sizeof(AT) == 2 ? 8 : 4; };
+
 template <typename AT>
 __device__ __forceinline__ void st4(void *p, int64_t i, float4 v) {
     if constexpr (sizeof(AT) == 4) reinterpret_cast<float4 *>(p)[i] = v;
@@ -73,7 +86,7 @@ __device__ __forceinline__ void st4(void *p, int64_t i, float4 v) {
 // Sum of (a, b) per channel over this workgroup's rows -> partial[blockIdx][0:C], [C:2C] (plain stores:
 // 2*C same-address atomics per workgroup cost 150 us per launch, measured).
 // MODE 0: a = x, b = x*x.   MODE 1: a = dy', b = dy' * xhat  (dy' = relu-masked dy).
-template <int MODE, typename AT>
+template <int MODE, typename AT, int NG>     // NG: gradients of y to add up (1; 2 or 3 for a forked output)
 __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t rows_per_block) {
     __shared__ float4 red[2][kBlock];
     const BnGeom g = a.g;
@@ -93,45 +106,49 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
     }
     if (live && r_begin < r_end) {
         const int64_t last = r_end - 1;
-        for (int64_t r0 = r_begin + rsub; r0 < r_end; r0 += (int64_t)kRowsInFlight * g.rpi) {
-            float4 vx[kRowsInFlight], vd[kRowsInFlight], vd2[kRowsInFlight], vd3[kRowsInFlight], vy[kRowsInFlight];
-            float wgt[kRowsInFlight];
+        constexpr int kRows = InFlight<AT>::value;
+        typedef typename Raw4<AT>::type RawT;
+        for (int64_t r0 = r_begin + rsub; r0 < r_end; r0 += (int64_t)kRows * g.rpi) {
+            RawT rx[kRows], rd[kRows], rd2[NG > 1 ? kRows : 1], rd3[NG > 2 ? kRows : 1], ry[kRows];
+            float wgt[kRows];
 #pragma unroll
-            for (int u = 0; u < kRowsInFlight; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const int64_t r = r0 + (int64_t)u * g.rpi;
                 wgt[u] = r < r_end ? 1.f : 0.f;
                 const int64_t off = (r < r_end ? r : last) * g.C4 + col;
-                vx[u] = ld4<AT>(a.x, off);
+                rx[u] = ldraw<AT>(a.x, off);
                 if (MODE == 1) {
-                    vd[u] = ld4<AT>(a.dy, off);
-                    if (a.dy2) vd2[u] = ld4<AT>(a.dy2, off);
-                    if (a.dy3) vd3[u] = ld4<AT>(a.dy3, off);
-                    if (a.has_res) vy[u] = ld4<AT>(a.y_in, off);
+                    rd[u] = ldraw<AT>(a.dy, off);
+                    if (NG > 1) rd2[NG > 1 ? u : 0] = ldraw<AT>(a.dy2, off);
+                    if (NG > 2) rd3[NG > 2 ? u : 0] = ldraw<AT>(a.dy3, off);
+                    if (a.has_res) ry[u] = ldraw<AT>(a.y_in, off);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kRowsInFlight; ++u) {
+            for (int u = 0; u < kRows; ++u) {
+                const float4 cx = cvt4(rx[u]);
                 if (MODE == 0) {
                     const float w = wgt[u];
-                    sa.x += w * vx[u].x; sa.y += w * vx[u].y; sa.z += w * vx[u].z; sa.w += w * vx[u].w;
-                    sb.x += w * vx[u].x * vx[u].x; sb.y += w * vx[u].y * vx[u].y;
-                    sb.z += w * vx[u].z * vx[u].z; sb.w += w * vx[u].w * vx[u].w;
+                    sa.x += w * cx.x; sa.y += w * cx.y; sa.z += w * cx.z; sa.w += w * cx.w;
+                    sb.x += w * cx.x * cx.x; sb.y += w * cx.y * cx.y;
+                    sb.z += w * cx.z * cx.z; sb.w += w * cx.w * cx.w;
                 } else {
-                    float4 d = vd[u];
-                    if (a.dy2) { d.x += vd2[u].x; d.y += vd2[u].y; d.z += vd2[u].z; d.w += vd2[u].w; }
-                    if (a.dy3) { d.x += vd3[u].x; d.y += vd3[u].y; d.z += vd3[u].z; d.w += vd3[u].w; }
+                    float4 d = cvt4(rd[u]);
+                    if (NG > 1) { const float4 t = cvt4(rd2[NG > 1 ? u : 0]); d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w; }
+                    if (NG > 2) { const float4 t = cvt4(rd3[NG > 2 ? u : 0]); d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w; }
                     d.x *= wgt[u]; d.y *= wgt[u]; d.z *= wgt[u]; d.w *= wgt[u];
                     if (a.relu) {
                         if (a.has_res) {
-                            if (!(vy[u].x > 0.f)) d.x = 0.f;
-                            if (!(vy[u].y > 0.f)) d.y = 0.f;
-                            if (!(vy[u].z > 0.f)) d.z = 0.f;
-                            if (!(vy[u].w > 0.f)) d.w = 0.f;
+                            const float4 cy = cvt4(ry[u]);
+                            if (!(cy.x > 0.f)) d.x = 0.f;
+                            if (!(cy.y > 0.f)) d.y = 0.f;
+                            if (!(cy.z > 0.f)) d.z = 0.f;
+                            if (!(cy.w > 0.f)) d.w = 0.f;
                         } else {
-                            if (!(vx[u].x * sc.x + sh.x > 0.f)) d.x = 0.f;
-                            if (!(vx[u].y * sc.y + sh.y > 0.f)) d.y = 0.f;
-                            if (!(vx[u].z * sc.z + sh.z > 0.f)) d.z = 0.f;
-                            if (!(vx[u].w * sc.w + sh.w > 0.f)) d.w = 0.f;
+                            if (!(cx.x * sc.x + sh.x > 0.f)) d.x = 0.f;
+                            if (!(cx.y * sc.y + sh.y > 0.f)) d.y = 0.f;
+                            if (!(cx.z * sc.z + sh.z > 0.f)) d.z = 0.f;
+                            if (!(cx.w * sc.w + sh.w > 0.f)) d.w = 0.f;
                         }
                     }
                     if (a.dres && wgt[u] != 0.f) {      // residual variant: the masked gradient IS grad_residual
@@ -139,10 +156,10 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
                         st4<AT>(a.dres, r * g.C4 + col, d);
                     }
                     sa.x += d.x; sa.y += d.y; sa.z += d.z; sa.w += d.w;
-                    sb.x += d.x * ((vx[u].x - mean.x) * rstd.x);
-                    sb.y += d.y * ((vx[u].y - mean.y) * rstd.y);
-                    sb.z += d.z * ((vx[u].z - mean.z) * rstd.z);
-                    sb.w += d.w * ((vx[u].w - mean.w) * rstd.w);
+                    sb.x += d.x * ((cx.x - mean.x) * rstd.x);
+                    sb.y += d.y * ((cx.y - mean.y) * rstd.y);
+                    sb.z += d.z * ((cx.z - mean.z) * rstd.z);
+                    sb.w += d.w * ((cx.w - mean.w) * rstd.w);
                 }
             }
         }
@@ -234,39 +251,41 @@ __global__ __launch_bounds__(kFinBlock) void bn_bwd_finalize_kernel(BnArgs a, in
 }
 
 // MODE 0: y = relu(x * scale + shift [+ res]).   MODE 1: dx = scale * (dy' - c1 - xhat * c2) [, dres = dy'].
-template <int MODE, typename AT>
+template <int MODE, typename AT, int NG>
 __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
     const int C4 = a.g.C4;
     const int64_t total = a.R * C4;
-    constexpr int U = 4;
+    constexpr int U = InFlight<AT>::value;
+    typedef typename Raw4<AT>::type RawT;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < total; i0 += U * stride) {
-        float4 vx[U], vr[U], vd[U];
+        RawT rx[U], rr[U], rd[U], rd2[NG > 1 ? U : 1], rd3[NG > 2 ? U : 1];
         int64_t idx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             idx[u] = i < total ? i : total - 1;              // clamped: unconditional loads
-            vx[u] = ld4<AT>(a.x, idx[u]);
+            rx[u] = ldraw<AT>(a.x, idx[u]);
             if (MODE == 0) {
-                if (a.has_res) vr[u] = ld4<AT>(a.res, idx[u]);
+                if (a.has_res) rr[u] = ldraw<AT>(a.res, idx[u]);
             } else {
-                vd[u] = ld4<AT>(a.dy, idx[u]);
-                if (a.dy2) { const float4 t = ld4<AT>(a.dy2, idx[u]); vd[u].x += t.x; vd[u].y += t.y; vd[u].z += t.z; vd[u].w += t.w; }
-                if (a.dy3) { const float4 t = ld4<AT>(a.dy3, idx[u]); vd[u].x += t.x; vd[u].y += t.y; vd[u].z += t.z; vd[u].w += t.w; }
-                if (a.has_res) vr[u] = ld4<AT>(a.y_in, idx[u]);
+                rd[u] = ldraw<AT>(a.dy, idx[u]);
+                if (NG > 1) rd2[NG > 1 ? u : 0] = ldraw<AT>(a.dy2, idx[u]);
+                if (NG > 2) rd3[NG > 2 ? u : 0] = ldraw<AT>(a.dy3, idx[u]);
+                if (a.has_res) rr[u] = ldraw<AT>(a.y_in, idx[u]);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             if (i >= total) break;
+            const float4 cx = cvt4(rx[u]);
             const int c = (total < (1ll << 31) ? (int)((unsigned)i % (unsigned)C4) : (int)(i % C4)) * 4;
             const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c);
             const float4 sh = *reinterpret_cast<const float4 *>(a.shift + c);
             if (MODE == 0) {
-                float4 y = make_float4(vx[u].x * sc.x + sh.x, vx[u].y * sc.y + sh.y, vx[u].z * sc.z + sh.z, vx[u].w * sc.w + sh.w);
-                if (a.has_res) { y.x += vr[u].x; y.y += vr[u].y; y.z += vr[u].z; y.w += vr[u].w; }
+                float4 y = make_float4(cx.x * sc.x + sh.x, cx.y * sc.y + sh.y, cx.z * sc.z + sh.z, cx.w * sc.w + sh.w);
+                if (a.has_res) { const float4 cr = cvt4(rr[u]); y.x += cr.x; y.y += cr.y; y.z += cr.z; y.w += cr.w; }
                 if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
                 st4<AT>(a.y, i, y);
             } else {
@@ -274,26 +293,29 @@ __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
                 const float4 rstd = *reinterpret_cast<const float4 *>(a.save_rstd + c);
                 const float4 c1 = *reinterpret_cast<const float4 *>(a.coef + c);
                 const float4 c2 = *reinterpret_cast<const float4 *>(a.coef + a.C + c);
-                float4 d = vd[u];
+                float4 d = cvt4(rd[u]);
+                if (NG > 1) { const float4 t = cvt4(rd2[NG > 1 ? u : 0]); d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w; }
+                if (NG > 2) { const float4 t = cvt4(rd3[NG > 2 ? u : 0]); d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w; }
                 if (a.relu) {
                     if (a.has_res) {
-                        if (!(vr[u].x > 0.f)) d.x = 0.f;
-                        if (!(vr[u].y > 0.f)) d.y = 0.f;
-                        if (!(vr[u].z > 0.f)) d.z = 0.f;
-                        if (!(vr[u].w > 0.f)) d.w = 0.f;
+                        const float4 cr = cvt4(rr[u]);
+                        if (!(cr.x > 0.f)) d.x = 0.f;
+                        if (!(cr.y > 0.f)) d.y = 0.f;
+                        if (!(cr.z > 0.f)) d.z = 0.f;
+                        if (!(cr.w > 0.f)) d.w = 0.f;
                     } else {
-                        if (!(vx[u].x * sc.x + sh.x > 0.f)) d.x = 0.f;
-                        if (!(vx[u].y * sc.y + sh.y > 0.f)) d.y = 0.f;
-                        if (!(vx[u].z * sc.z + sh.z > 0.f)) d.z = 0.f;
-                        if (!(vx[u].w * sc.w + sh.w > 0.f)) d.w = 0.f;
+                        if (!(cx.x * sc.x + sh.x > 0.f)) d.x = 0.f;
+                        if (!(cx.y * sc.y + sh.y > 0.f)) d.y = 0.f;
+                        if (!(cx.z * sc.z + sh.z > 0.f)) d.z = 0.f;
+                        if (!(cx.w * sc.w + sh.w > 0.f)) d.w = 0.f;
                     }
                 }
                 if (a.dres) st4<AT>(a.dres, i, d);
                 float4 o;
-                o.x = sc.x * (d.x - c1.x - (vx[u].x - mean.x) * rstd.x * c2.x);
-                o.y = sc.y * (d.y - c1.y - (vx[u].y - mean.y) * rstd.y * c2.y);
-                o.z = sc.z * (d.z - c1.z - (vx[u].z - mean.z) * rstd.z * c2.z);
-                o.w = sc.w * (d.w - c1.w - (vx[u].w - mean.w) * rstd.w * c2.w);
+                o.x = sc.x * (d.x - c1.x - (cx.x - mean.x) * rstd.x * c2.x);
+                o.y = sc.y * (d.y - c1.y - (cx.y - mean.y) * rstd.y * c2.y);
+                o.z = sc.z * (d.z - c1.z - (cx.z - mean.z) * rstd.z * c2.z);
+                o.w = sc.w * (d.w - c1.w - (cx.w - mean.w) * rstd.w * c2.w);
                 st4<AT>(a.dx, i, o);
             }
         }
@@ -314,10 +336,10 @@ int geometry(const char *who, int64_t R, int C, BnGeom *g) {
 
 constexpr int kMaxPartialBlocks = 512;
 
-void reduce_grid(const BnGeom &g, int64_t R, int *blocks, int64_t *rows_per_block) {
+void reduce_grid(const BnGeom &g, int64_t R, int rows_in_flight, int *blocks, int64_t *rows_per_block) {
     // every workgroup owns whole trips of rows and at least 64 rows, so the partial rows it writes
     // (2*C floats) stay below ~6 % of what it reads; at most kMaxPartialBlocks workgroups
-    const int64_t trip = (int64_t)g.rpi * kRowsInFlight;
+    const int64_t trip = (int64_t)g.rpi * rows_in_flight;
     int64_t nb = R / 64;
     // ... unless that leaves most of the chip idle (ResNet-50's last stage at BASELINE configs[3]: R = 4 224 rows of 2 048 channels = 66 x 2
     // workgroups, 18.6 us for 35-69 MB): then down to 16 rows per workgroup, up to 512 workgroups over the column blocks
@@ -338,27 +360,37 @@ namespace {
 
 template <typename AT>
 void launch_forward(const BnArgs &a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
-    hipLaunchKernelGGL((bn_reduce_kernel<0, AT>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
+    hipLaunchKernelGGL((bn_reduce_kernel<0, AT, 1>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
     if ((*rc = mmt::check_launch("bn_relu_forward(stats)"))) return;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)mmt::ceil_div(a.C, 64)), dim3(kFinBlock), 0, st, a, blocks);
     if ((*rc = mmt::check_launch("bn_relu_forward(finalize)"))) return;
-    hipLaunchKernelGGL((bn_map_kernel<0, AT>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((bn_map_kernel<0, AT, 1>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, InFlight<AT>::value), kBlock)), dim3(kBlock), 0, st, a);
     *rc = mmt::check_launch("bn_relu_forward(apply)");
 }
 
-template <typename AT>
-void launch_backward(BnArgs a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
-    hipLaunchKernelGGL((bn_reduce_kernel<1, AT>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
+template <typename AT, int NG>
+void launch_backward_ng(BnArgs a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
+    hipLaunchKernelGGL((bn_reduce_kernel<1, AT, NG>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
     if ((*rc = mmt::check_launch("bn_relu_backward(reduce)"))) return;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)mmt::ceil_div(a.C, 64)), dim3(kFinBlock), 0, st, a, blocks);
     if ((*rc = mmt::check_launch("bn_relu_backward(finalize)"))) return;
+    const dim3 grid(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, InFlight<AT>::value), kBlock));
     if (a.dres) {
-        // the reduce pass has written grad_residual = masked grad_y: the dx pass reads that instead of
+        // the reduce pass has written grad_residual = masked grad_y (the sum of its gradients): the dx pass reads that instead of
         // grad_y + y (7 passes instead of 8 for the residual variant)
         a.dy = a.dres; a.dy2 = nullptr; a.dy3 = nullptr; a.dres = nullptr; a.relu = 0; a.has_res = 0;
+        hipLaunchKernelGGL((bn_map_kernel<1, AT, 1>), grid, dim3(kBlock), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((bn_map_kernel<1, AT, NG>), grid, dim3(kBlock), 0, st, a);
     }
-    hipLaunchKernelGGL((bn_map_kernel<1, AT>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, 4), kBlock)), dim3(kBlock), 0, st, a);
     *rc = mmt::check_launch("bn_relu_backward(dx)");
+}
+
+template <typename AT>
+void launch_backward(const BnArgs &a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
+    if (a.dy3) launch_backward_ng<AT, 3>(a, blocks, rpb, st, rc);
+    else if (a.dy2) launch_backward_ng<AT, 2>(a, blocks, rpb, st, rc);
+    else launch_backward_ng<AT, 1>(a, blocks, rpb, st, rc);
 }
 
 }  // namespace
@@ -383,7 +415,7 @@ extern "C" int mmt_bn_relu_forward_ex(int64_t R, int C, const void *x, const voi
     a.acc = workspace + 2 * C; a.coef = workspace; a.scale = save + 2 * C; a.shift = save + 3 * C;
     a.save_mean = save_mean; a.save_rstd = save_rstd; a.y = y;
     int blocks; int64_t rpb;
-    reduce_grid(a.g, R, &blocks, &rpb);
+    reduce_grid(a.g, R, act_dtype == MMT_DTYPE_F32 ? InFlight<float>::value : InFlight<bf16_t>::value, &blocks, &rpb);
     int rc = 0;
     if (act_dtype == MMT_DTYPE_F32) launch_forward<float>(a, blocks, rpb, (hipStream_t)stream, &rc);
     else launch_forward<bf16_t>(a, blocks, rpb, (hipStream_t)stream, &rc);
@@ -424,7 +456,7 @@ extern "C" int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const v
     a.save_mean = const_cast<float *>(save_mean); a.save_rstd = const_cast<float *>(save_rstd);
     a.dx = grad_x; a.dres = has_residual ? grad_residual : nullptr; a.dweight = grad_weight; a.dbias = grad_bias;
     int blocks; int64_t rpb;
-    reduce_grid(a.g, R, &blocks, &rpb);
+    reduce_grid(a.g, R, act_dtype == MMT_DTYPE_F32 ? InFlight<float>::value : InFlight<bf16_t>::value, &blocks, &rpb);
     int rc = 0;
     if (act_dtype == MMT_DTYPE_F32) launch_backward<float>(a, blocks, rpb, (hipStream_t)stream, &rc);
     else launch_backward<bf16_t>(a, blocks, rpb, (hipStream_t)stream, &rc);
