@@ -737,6 +737,24 @@ int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const void *y, con
                              const void *grad_y3, const float *save, int relu, int has_residual, float *workspace, void *grad_x,
                              void *grad_residual, float *grad_weight, float *grad_bias, int act_dtype, void *stream);
 
+/* ------------------------------------------------------------------- optimizer step (row a13) */
+
+/* Gradient clipping + AdamW over every parameter in two launches (ABI 11).  Replaces, per step of the reference's harness
+ * (exps/mm_training_aim.py:575-608: Lightning's gradient_clip_val = 2 = torch.nn.utils.clip_grad_norm_, then torch.optim.AdamW):
+ * the multi-tensor norm, the multiply of all gradients by the clip coefficient and the fused AdamW kernels -- the multiply's read +
+ * write of every gradient disappears into the update (the gradient is scaled on load; the gradients themselves are left unscaled).
+ *   chunk_tensor int32 [num_chunks], chunk_offset int64 [num_chunks]: tensor index and first element of every chunk of
+ *     chunk_elems elements (a multiple of 4; a tensor's last chunk may be shorter); all DEVICE arrays
+ *   param_ptrs / grad_ptrs / exp_avg_ptrs / exp_avg_sq_ptrs int64 [T] DEVICE arrays of device addresses (fp32 tensors, dense), numel int64 [T]
+ *   step >= 1: the update's number (bias corrections 1 - beta^step); max_norm <= 0: no clipping (and no norm launch)
+ *   partials fp32 [num_chunks] scratch (max_norm > 0); norm_out fp32 [2] or NULL: total gradient norm, clip coefficient applied
+ * Arithmetic as torch's fused kernel (ADAMW, amsgrad off, maximize off): double products with lr / betas / weight decay / eps,
+ * fp32 state; clip coefficient = min(1, max_norm / (norm + 1e-6)). */
+int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_t *chunk_tensor, const int64_t *chunk_offset,
+                        const int64_t *param_ptrs, const int64_t *grad_ptrs, const int64_t *exp_avg_ptrs,
+                        const int64_t *exp_avg_sq_ptrs, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int64_t step, float max_norm, float *partials, float *norm_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

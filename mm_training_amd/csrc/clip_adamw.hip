@@ -1,0 +1,167 @@
+// Gradient clipping + AdamW as two launches over every parameter of the model (SURVEY section 8 row a13:
+// exps/mm_training_aim.py:575-608 -- `gradient_clip_val=2` and `torch.optim.AdamW(lr=1e-3/64*bs, weight_decay=1e-7)`).
+//
+// torch runs this as clip_grad_norm_ (a multi-tensor norm, a handful of scalar kernels, a multi-tensor multiply over all gradients)
+// followed by the fused AdamW: at BASELINE configs[3] (83.9 M parameters) 0.14 + 0.19 + 0.75 ms per step, of which the multiply is a
+// whole read + write of the gradients that only scales them for the kernel that follows.  Here:
+//   1. opt_sumsq : a workgroup per 64 K-element chunk of a gradient: sum of squares -> one partial per chunk;
+//   2. opt_adamw : a workgroup per chunk: adds the partials up in a fixed order (1 300 floats from L2: every workgroup for itself,
+//                  same value everywhere), total norm -> clip coefficient = min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.
+//                  clip_grad_norm_), then the AdamW update of its chunk with the gradient scaled on load -- torch's fused kernel's
+//                  arithmetic (fused_adam_utils.cuh, ADAMW, amsgrad off): decay, first and second moment, bias corrections
+//                  from the step count, one division.
+// The tensors are named by device arrays of pointers (parameters and moments: built once; gradients: uploaded per step, autograd
+// allocates them afresh) and a chunk table; 16-byte accesses where a chunk's four pointers allow it.
+#include "mmt_common.h"
+
+namespace {
+
+constexpr int kOptBlock = 256;
+
+struct OptArgs {
+    const int64_t *p, *g, *m, *v;     // [T] device pointers as integers
+    const int64_t *numel;             // [T]
+    const int32_t *chunk_tensor;      // [NC]
+    const int64_t *chunk_off;         // [NC] first element of the chunk inside its tensor
+    int chunk_elems, NC;
+    float *partials;                  // [NC]
+    float *norm_out;                  // [2] total norm, clip coefficient (written by workgroup 0 of opt_adamw); may be NULL
+    double lr_d, beta1_d, beta2_d, eps_d, wd_d;
+    float bc1, bc2_sqrt, max_norm;
+};
+
+__device__ __forceinline__ float block_sum(float v, float *lds) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kOptBlock / 64; ++w) t += lds[w];      // (fixed order: the same bits in every workgroup)
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(kOptBlock) void opt_sumsq(OptArgs a) {
+    __shared__ float lds[kOptBlock / 64];
+    const int t = a.chunk_tensor[blockIdx.x];
+    const int64_t off = a.chunk_off[blockIdx.x];
+    const int64_t left = a.numel[t] - off;
+    const int n = (int)(left < a.chunk_elems ? left : a.chunk_elems);
+    const float *g = reinterpret_cast<const float *>(a.g[t]) + off;
+    float s = 0.f;
+    if (((uintptr_t)g & 15) == 0) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);
+        for (int i = threadIdx.x; i < (n >> 2); i += kOptBlock) { const float4 x = g4[i]; s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; }
+        for (int i = (n & ~3) + threadIdx.x; i < n; i += kOptBlock) s += g[i] * g[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += kOptBlock) s += g[i] * g[i];
+    }
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
+}
+
+// torch's fused kernel (fused_adam_utils.cuh::adam_math, ADAMW, amsgrad off) keeps lr, betas, weight decay and eps as doubles: the
+// products with them are formed in double and rounded when assigned to the fp32 value -- mirrored here so that the two agree to the bit
+// wherever the gradients do
+__device__ __forceinline__ void adamw1(float &p, float g, float &m, float &v, const OptArgs &a, float step_size) {
+    const double lr = (double)a.lr_d, wd = (double)a.wd_d, b1 = (double)a.beta1_d, b2 = (double)a.beta2_d;
+    p = (float)((double)p - lr * wd * (double)p);
+    m = (float)(b1 * (double)m + (1.0 - b1) * (double)g);
+    v = (float)(b2 * (double)v + (1.0 - b2) * (double)g * (double)g);
+    const float denom = (float)((double)(sqrtf(v) / a.bc2_sqrt) + a.eps_d);
+    p -= step_size * m / denom;
+}
+
+__global__ __launch_bounds__(kOptBlock) void opt_adamw(OptArgs a) {
+    __shared__ float lds[kOptBlock / 64];
+    float coef = 1.f;
+    if (a.max_norm > 0.f) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < a.NC; i += kOptBlock) s += a.partials[i];
+        s = block_sum(s, lds);
+        const float norm = sqrtf(s);
+        const float c = a.max_norm / (norm + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+        if (!(norm == norm)) coef = norm;                       // a NaN norm poisons the update, like torch's multiply by a NaN coefficient
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) { a.norm_out[0] = norm; a.norm_out[1] = coef; }
+    }
+    const int t = a.chunk_tensor[blockIdx.x];
+    const int64_t off = a.chunk_off[blockIdx.x];
+    const int64_t left = a.numel[t] - off;
+    const int n = (int)(left < a.chunk_elems ? left : a.chunk_elems);
+    float *p = reinterpret_cast<float *>(a.p[t]) + off;
+    const float *g = reinterpret_cast<const float *>(a.g[t]) + off;
+    float *m = reinterpret_cast<float *>(a.m[t]) + off;
+    float *v = reinterpret_cast<float *>(a.v[t]) + off;
+    const float step_size = (float)(a.lr_d / (double)a.bc1);
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+        float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);
+        constexpr int U = 2;
+        for (int i0 = threadIdx.x; i0 < (n >> 2); i0 += U * kOptBlock) {
+            float4 pp[U], gg[U], mm[U], vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * kOptBlock < (n >> 2) ? i0 + u * kOptBlock : i0;
+                pp[u] = p4[i]; gg[u] = g4[i]; mm[u] = m4[i]; vv[u] = v4[i];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * kOptBlock;
+                if (i >= (n >> 2)) break;
+                adamw1(pp[u].x, gg[u].x * coef, mm[u].x, vv[u].x, a, step_size);
+                adamw1(pp[u].y, gg[u].y * coef, mm[u].y, vv[u].y, a, step_size);
+                adamw1(pp[u].z, gg[u].z * coef, mm[u].z, vv[u].z, a, step_size);
+                adamw1(pp[u].w, gg[u].w * coef, mm[u].w, vv[u].w, a, step_size);
+                p4[i] = pp[u]; m4[i] = mm[u]; v4[i] = vv[u];
+            }
+        }
+        for (int i = (n & ~3) + threadIdx.x; i < n; i += kOptBlock) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            adamw1(pp, g[i] * coef, mm, vv, a, step_size);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += kOptBlock) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            adamw1(pp, g[i] * coef, mm, vv, a, step_size);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_t *chunk_tensor, const int64_t *chunk_offset,
+                                   const int64_t *param_ptrs, const int64_t *grad_ptrs, const int64_t *exp_avg_ptrs,
+                                   const int64_t *exp_avg_sq_ptrs, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                                   double weight_decay, int64_t step, float max_norm, float *partials, float *norm_out, void *stream) {
+    if (num_chunks == 0) return MMT_OK;
+    MMT_REQUIRE_PTR(chunk_tensor);
+    MMT_REQUIRE_PTR(chunk_offset);
+    MMT_REQUIRE_PTR(param_ptrs);
+    MMT_REQUIRE_PTR(grad_ptrs);
+    MMT_REQUIRE_PTR(exp_avg_ptrs);
+    MMT_REQUIRE_PTR(exp_avg_sq_ptrs);
+    MMT_REQUIRE_PTR(numel);
+    if (num_chunks < 0 || chunk_elems <= 0 || (chunk_elems & 3) || step <= 0 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "clip_adamw_step: bad arguments (chunks=%d chunk_elems=%d step=%lld betas %g %g)", num_chunks, chunk_elems,
+                         (long long)step, beta1, beta2);
+    if (max_norm > 0.f) MMT_REQUIRE_PTR(partials);
+    OptArgs a;
+    a.p = param_ptrs; a.g = grad_ptrs; a.m = exp_avg_ptrs; a.v = exp_avg_sq_ptrs; a.numel = numel;
+    a.chunk_tensor = chunk_tensor; a.chunk_off = chunk_offset; a.chunk_elems = chunk_elems; a.NC = num_chunks;
+    a.partials = partials; a.norm_out = norm_out;
+    a.lr_d = lr; a.beta1_d = beta1; a.beta2_d = beta2; a.eps_d = eps; a.wd_d = weight_decay; a.max_norm = max_norm;
+    // torch (fused_adam_utils.cuh): bias_correction1 = 1 - pow(beta1, step), bias_correction2_sqrt = sqrt(1 - pow(beta2, step)), in double then float
+    a.bc1 = (float)(1.0 - pow(beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    hipStream_t st = (hipStream_t)stream;
+    if (max_norm > 0.f) {
+        hipLaunchKernelGGL(opt_sumsq, dim3(num_chunks), dim3(kOptBlock), 0, st, a);
+        if (int rc = mmt::check_launch("clip_adamw_step(norm)")) return rc;
+    }
+    hipLaunchKernelGGL(opt_adamw, dim3(num_chunks), dim3(kOptBlock), 0, st, a);
+    return mmt::check_launch("clip_adamw_step(update)");
+}

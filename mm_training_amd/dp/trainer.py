@@ -202,10 +202,17 @@ class TrainStep(nn.Module):
                 # rank 0's ~390 buffers before every forward would be one more collective per step
                 broadcast_buffers=False)
         bs = cfg["batch_size"]
-        self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr or 1e-3 / 64 * bs, weight_decay=1e-7,
-                                           fused=(device.type == "cuda"))
-        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, [19, 23])
         self.grad_clip = 2.0
+        # exps/mm_training_aim.py:575-608: gradient_clip_val 2 + AdamW.  On the GPU: clip + update as two launches over all
+        # parameters (dp/optim.py; MMT_FUSED_OPT=0: torch's clip_grad_norm_ + fused AdamW, which is also what the CPU tests run)
+        self.fused_optimizer = device.type == "cuda" and os.environ.get("MMT_FUSED_OPT", "1") != "0"
+        if self.fused_optimizer:
+            from .optim import ClipAdamW
+            self.optimizer = ClipAdamW(self.model.parameters(), lr=lr or 1e-3 / 64 * bs, weight_decay=1e-7, max_norm=self.grad_clip)
+        else:
+            self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr or 1e-3 / 64 * bs, weight_decay=1e-7,
+                                               fused=(device.type == "cuda"))
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, [19, 23])
         db = cfg["backbone_conf"]["d_bound"]
         self.dbound = db
         self.downsample = cfg["backbone_conf"]["downsample_factor"]
@@ -322,6 +329,7 @@ class TrainStep(nn.Module):
             torch._foreach_add_(self._bn_counters, 1)      # see _batched_bn_counters
         loss.backward()
         self.finish_backward()
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip, foreach=True)
+        if not self.fused_optimizer:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip, foreach=True)
         self.optimizer.step()
         return loss.detach(), det.detach(), dep.detach()

@@ -1,0 +1,121 @@
+"""ClipAdamW (dp/optim.py, mmt_clip_adamw_step) against torch: clip_grad_norm_ + torch.optim.AdamW on the same parameters and
+gradients, several steps, assorted sizes and layouts (channels_last weights, tiny tensors, a tensor longer than a chunk that does
+not end on one, a parameter without a gradient), the state dictionaries interchangeable."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 32, 3, 3), (256, 64, 1, 1), (7,), (1,), (100003,), (70000, 3), (16, 8, 3, 3), (5, 5)]
+    ps = []
+    for i, sh in enumerate(shapes):
+        t = torch.randn(sh, generator=g).cuda()
+        if len(sh) == 4 and i != 6:
+            t = t.contiguous(memory_format=torch.channels_last)
+        ps.append(torch.nn.Parameter(t))
+    return ps
+
+
+def _grads(ps, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for p in ps:
+        t = (torch.randn(p.shape, generator=g) * scale).cuda()
+        out.append(t.contiguous(memory_format=torch.channels_last) if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous() else t)
+    return out
+
+
+@pytest.mark.parametrize("max_norm", [2.0, 0.0, 1e6])
+def test_clip_adamw_matches_torch(mmt_lib, max_norm):
+    from mm_training_amd.dp.optim import ClipAdamW
+    a, b = _params(0), [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in _params(0)]
+    kw = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ours, ref = ClipAdamW(a, max_norm=max_norm, **kw), torch.optim.AdamW(b, fused=True, **kw)
+    for step in range(6):
+        gs = _grads(a, 10 + step, 0.05 if step % 2 else 3.0)          # (small: below the clip norm; large: clipped)
+        for k, (p, q, g) in enumerate(zip(a, b, gs)):
+            p.grad = None if k == 7 else g.clone(memory_format=torch.preserve_format)
+            q.grad = None if k == 7 else g.clone(memory_format=torch.preserve_format)
+        if max_norm > 0:
+            total = torch.nn.utils.clip_grad_norm_([q for q in b if q.grad is not None], max_norm, foreach=True)
+        ours.step()
+        ref.step()
+        if max_norm > 0:
+            assert abs(float(ours.last_norm[0]) - float(total)) <= 1e-5 * float(total)
+            assert abs(float(ours.last_norm[1]) - min(1.0, max_norm / (float(total) + 1e-6))) <= 1e-5
+        for k, (p, q) in enumerate(zip(a, b)):
+            assert p.stride() == q.stride()
+            err = float((p - q).abs().max())
+            assert err <= 2e-6 * max(1.0, float(q.abs().max())), (step, k, err)
+            if k != 7:
+                assert torch.equal(p.grad, gs[k]), "the gradients themselves are left unscaled"
+                for name in ("exp_avg", "exp_avg_sq"):
+                    e = float((ours.state[p][name] - ref.state[q][name]).abs().max())
+                    assert e <= 2e-6 * max(1e-3, float(ref.state[q][name].abs().max())), (step, k, name, e)
+    assert torch.equal(a[7], _params(0)[7]) and 7 not in [i for i, p in enumerate(a) if p in ours.state and "exp_avg" in ours.state[p]]
+    # the state dictionaries are interchangeable
+    sd = ours.state_dict()
+    ref2 = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a], fused=True, **kw)
+    sd2 = copy.deepcopy(sd)
+    # (the parameter without a gradient has no state on either side)
+    ref2.load_state_dict(sd2)
+    ours2 = ClipAdamW([torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a], max_norm=max_norm, **kw)
+    ours2.load_state_dict(ref.state_dict())
+    assert int(ours2.state[ours2.param_groups[0]["params"][0]]["step"]) == 6
+
+
+def test_training_step_with_either_optimizer(mmt_lib, monkeypatch):
+    """TrainStep with the two-launch optimizer against torch's clip + fused AdamW (MMT_FUSED_OPT=0): same losses over a few steps of
+    the tiny configuration to the tolerance of the convolutions' own run-to-run differences."""
+    import numpy as np
+    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
+    losses = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MMT_FUSED_OPT", fused)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = make_config("tiny")
+        ts = TrainStep(cfg, torch.device("cuda", 0))
+        assert ts.fused_optimizer == (fused == "1")
+        batches = [synthetic_batch(cfg, torch.device("cuda", 0), seed=i) for i in range(2)]
+        ls = []
+        for i in range(6):
+            np.random.seed(100 + i)
+            ls.append(float(ts(batches[i % 2])[0]))
+        losses.append(ls)
+    assert all(np.isfinite(losses[0])) and losses[0][-1] < losses[0][0]
+    assert np.allclose(losses[0], losses[1], rtol=2e-2), losses
+
+
+def test_steps_queued_without_a_host_sync(mmt_lib):
+    """The host runs ahead of the device: many steps are queued behind a long kernel before the first executes, every one with
+    freshly allocated gradients.  Each step's kernels must see ITS gradients' addresses (they are staged through a ring of pinned
+    buffers guarded by events, not through one buffer that the next step overwrites)."""
+    from mm_training_amd.dp.optim import ClipAdamW
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    a = [torch.nn.Parameter(torch.zeros(50000, device="cuda")), torch.nn.Parameter(torch.zeros(64, 16, 3, 3, device="cuda"))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ours, ref = ClipAdamW(a, max_norm=0.0, **kw), torch.optim.AdamW(b, fused=True, **kw)
+    busy = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(6):
+        busy = busy @ busy * 1e-4                     # (the device is busy for a while: everything below is queued behind it)
+    keep = []
+    for step in range(12):
+        for p, q in zip(a, b):
+            g = torch.full_like(p, float(step + 1))   # a fresh allocation per step, distinct contents per step
+            p.grad, q.grad = g, g.clone()
+            keep.append(g)
+        ours.step()
+        ref.step()
+        for p in a:
+            p.grad = None                             # (the allocator may hand the block to the next step's gradient)
+        keep.clear()
+    torch.cuda.synchronize()
+    for p, q in zip(a, b):
+        assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(q.abs().max()))
