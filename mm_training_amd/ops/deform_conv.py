@@ -46,10 +46,20 @@ class _DeformConv3x3(Function):
         go2d = grad_out.float().permute(0, 2, 3, 1).reshape(N, O)    # free for a channels_last gradient
         grad_wmat = torch.empty((groups, 9 * Cg, Og), dtype=torch.float32, device=go2d.device)
         grad_col = torch.empty((groups, N, 9 * Cg), dtype=torch.float32, device=go2d.device)
+        # The weight gradient col[g]^T @ go_g is a reduction over all N pixels into a 9*Cg x Og matrix (1152 x 128 at BASELINE
+        # configs[3]: nine output tiles, 36 TFLOP/s as one GEMM).  Split into S batched pieces over the pixels + one sum it fills
+        # the chip: 547 -> 210 us for the four groups (tools/scratch/dcn_wgrad_gemm.py: S = 4 / 8 / 16 / 32 -> 277 / 210 / 262 / 395).
+        S = 8 if N % 8 == 0 and N >= 4096 else 1
+        parts = torch.empty((groups, S, 9 * Cg, Og), dtype=torch.float32, device=go2d.device) if S > 1 else None
         for g in range(groups):                                     # the group's Og gradient columns are read in place (leading dimension O)
             go_g = go2d[:, g * Og:(g + 1) * Og]
-            torch.mm(col[g].t(), go_g, out=grad_wmat[g])
+            if S > 1:
+                torch.bmm(col[g].view(S, N // S, 9 * Cg).transpose(1, 2), go2d.view(S, N // S, O)[:, :, g * Og:(g + 1) * Og], out=parts[g])
+            else:
+                torch.mm(col[g].t(), go_g, out=grad_wmat[g])
             torch.mm(go_g, wmat[g].t(), out=grad_col[g])
+        if S > 1:
+            torch.sum(parts, 1, out=grad_wmat)
         grad_weight = grad_wmat.reshape(groups, 9, Cg, Og).permute(0, 3, 2, 1).reshape(O, Cg, 3, 3)
         grad_off = torch.empty_like(off_nhwc)
         lpg = Cg // 4
