@@ -254,3 +254,28 @@ def test_lidar_encoder_three_calls(mmt_lib, oracle_mod):
     # no-sync path gives the same BEV
     bev2 = enc.forward_bev(lidar)
     assert torch.equal(bev2, bev)
+
+
+def test_row_linear_equals_nn_linear(mmt_lib):
+    """lidar/encoder.py::RowLinear (the pillar MLP's layer: the weight gradient's reduction over the rows cut into batched pieces)
+    against nn.Linear: outputs, weight / bias / input gradients, plain and under bf16 autocast (where it computes in fp32)."""
+    from mm_training_amd.lidar.encoder import RowLinear
+    torch.manual_seed(0)
+    for N, requires in ((100000, False), (4000, True), (777, False)):
+        ref = torch.nn.Linear(5, 64).cuda()
+        new = RowLinear(5, 64).cuda()
+        new.load_state_dict(ref.state_dict())
+        x = torch.randn(N, 5, device="cuda")
+        g = torch.randn(N, 64, device="cuda")
+        outs = []
+        for m in (ref, new):
+            xi = x.clone().requires_grad_(requires)
+            y = torch.relu(m(xi))
+            y.backward(g)
+            outs.append((y.detach(), m.weight.grad, m.bias.grad, xi.grad))
+        for name, a, b in zip(("y", "grad_weight", "grad_bias", "grad_x"), outs[1], outs[0]):
+            if b is not None:
+                assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (N, name)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = RowLinear(5, 64).cuda()(torch.randn(1000, 5, device="cuda"))
+    assert y.dtype == torch.float32
