@@ -732,9 +732,11 @@ int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const void *y, cons
  * The output of a residual block is read twice -- by the next block's first convolution and as its identity (or through its
  * downsample convolution), a stage's output a third time by the neck -- and autograd would add the gradients in passes of its own
  * (three streams over the activation each) before this backward reads the sum; `ops/bn_relu.py::bn_act(..., fork=2|3)` hands the
- * output out as aliases instead and receives their gradients here. */
+ * output out as aliases instead and receives their gradients here.  grad_y_row_stride: 0 (dense rows of C) or the distance in
+ * elements between the rows of grad_y when it is a channel slice of a wider channels-last tensor (the gradient of one input of a
+ * torch.cat: read in place instead of through a .contiguous() copy); >= C, a multiple of 4. */
 int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const void *y, const void *grad_y, const void *grad_y2,
-                             const void *grad_y3, const float *save, int relu, int has_residual, float *workspace, void *grad_x,
+                             const void *grad_y3, int64_t grad_y_row_stride, const float *save, int relu, int has_residual, float *workspace, void *grad_x,
                              void *grad_residual, float *grad_weight, float *grad_bias, int act_dtype, void *stream);
 
 /* ------------------------------------------------------------------- optimizer step (row a13) */
@@ -754,6 +756,11 @@ int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_t *chunk_te
                         const int64_t *param_ptrs, const int64_t *grad_ptrs, const int64_t *exp_avg_ptrs,
                         const int64_t *exp_avg_sq_ptrs, const int64_t *numel, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int64_t step, float max_norm, float *partials, float *norm_out, void *stream);
+
+/* out = inputs[0] + ... + inputs[n-1] (n <= 32 dense fp32 tensors of numel elements; inputs_host: a HOST array of device pointers,
+ * passed to the kernel by value), summed in argument order, one pass: the gradient of a tensor that n branches read
+ * (layers/heads/bev_depth_head.py: the 24 branches of the CenterPoint head) without autograd's n - 1 accumulation passes. */
+int mmt_add_n(int n, const void *const *inputs_host, int64_t numel, float *out, void *stream);
 
 #ifdef __cplusplus
 }

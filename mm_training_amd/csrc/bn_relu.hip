@@ -39,6 +39,8 @@ struct BnArgs {
     int relu, has_res;
     float momentum, eps;
     const void *x, *res, *y_in, *dy;   // activations, AT
+    int64_t dy_pitch4;                 // rows of dy are this many quadruples apart (C4: dense; more: dy is a channel slice of a wider channels-last tensor,
+                                       // e.g. the gradient of one input of a torch.cat -- read in place instead of through a copy)
     const void *dy3;                   // backward, nullable (only with dy2): a third one
     const void *dy2;                   // backward, nullable: a second gradient of y (the output was handed out twice: conv path + identity of the next block), added on load
     const float *weight, *bias;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
                 const int64_t off = (r < r_end ? r : last) * g.C4 + col;
                 rx[u] = ldraw<AT>(a.x, off);
                 if (MODE == 1) {
-                    rd[u] = ldraw<AT>(a.dy, off);
+                    rd[u] = ldraw<AT>(a.dy, (r < r_end ? r : last) * a.dy_pitch4 + col);
                     if (NG > 1) rd2[NG > 1 ? u : 0] = ldraw<AT>(a.dy2, off);
                     if (NG > 2) rd3[NG > 2 ? u : 0] = ldraw<AT>(a.dy3, off);
                     if (a.has_res) ry[u] = ldraw<AT>(a.y_in, off);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void bn_map_kernel(BnArgs a) {
             if (MODE == 0) {
                 if (a.has_res) rr[u] = ldraw<AT>(a.res, idx[u]);
             } else {
-                rd[u] = ldraw<AT>(a.dy, idx[u]);
+                rd[u] = ldraw<AT>(a.dy, a.dy_pitch4 == C4 ? idx[u] : (idx[u] / C4) * a.dy_pitch4 + idx[u] % C4);
                 if (NG > 1) rd2[NG > 1 ? u : 0] = ldraw<AT>(a.dy2, idx[u]);
                 if (NG > 2) rd3[NG > 2 ? u : 0] = ldraw<AT>(a.dy3, idx[u]);
                 if (a.has_res) rr[u] = ldraw<AT>(a.y_in, idx[u]);
@@ -378,7 +380,7 @@ void launch_backward_ng(BnArgs a, int blocks, int64_t rpb, hipStream_t st, int *
     if (a.dres) {
         // the reduce pass has written grad_residual = masked grad_y (the sum of its gradients): the dx pass reads that instead of
         // grad_y + y (7 passes instead of 8 for the residual variant)
-        a.dy = a.dres; a.dy2 = nullptr; a.dy3 = nullptr; a.dres = nullptr; a.relu = 0; a.has_res = 0;
+        a.dy = a.dres; a.dy_pitch4 = a.g.C4; a.dy2 = nullptr; a.dy3 = nullptr; a.dres = nullptr; a.relu = 0; a.has_res = 0;
         hipLaunchKernelGGL((bn_map_kernel<1, AT, 1>), grid, dim3(kBlock), 0, st, a);
     } else {
         hipLaunchKernelGGL((bn_map_kernel<1, AT, NG>), grid, dim3(kBlock), 0, st, a);
@@ -430,7 +432,7 @@ extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float
 }
 
 extern "C" int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const void *y, const void *grad_y, const void *grad_y2,
-                                        const void *grad_y3, const float *save, int relu, int has_residual, float *workspace,
+                                        const void *grad_y3, int64_t grad_y_row_stride, const float *save, int relu, int has_residual, float *workspace,
                                         void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
                                         int act_dtype, void *stream) {
     MMT_REQUIRE_PTR(x);
@@ -451,6 +453,9 @@ extern "C" int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const v
         return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_backward: buffers must be 16-byte aligned (bf16 activations: 8)");
     a.R = R; a.C = C; a.relu = relu; a.has_res = (relu && has_residual) ? 1 : 0;
     a.x = x; a.y_in = y; a.dy = grad_y; a.dy2 = grad_y2; a.dy3 = grad_y2 ? grad_y3 : nullptr;
+    if (grad_y_row_stride != 0 && (grad_y_row_stride < C || (grad_y_row_stride & 3)))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_backward: grad_y_row_stride must be 0 (dense), or >= C and a multiple of 4");
+    a.dy_pitch4 = grad_y_row_stride ? grad_y_row_stride / 4 : a.g.C4;
     a.acc = workspace + 2 * C; a.coef = workspace;
     a.scale = const_cast<float *>(save) + 2 * C; a.shift = const_cast<float *>(save) + 3 * C;
     a.save_mean = const_cast<float *>(save_mean); a.save_rstd = const_cast<float *>(save_rstd);
@@ -467,7 +472,7 @@ extern "C" int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const vo
                                        const float *save, int relu, int has_residual, float *workspace,
                                        void *grad_x, void *grad_residual, float *grad_weight, float *grad_bias,
                                        int act_dtype, void *stream) {
-    return mmt_bn_relu_backward_ex2(R, C, x, y, grad_y, nullptr, nullptr, save, relu, has_residual, workspace, grad_x, grad_residual, grad_weight,
+    return mmt_bn_relu_backward_ex2(R, C, x, y, grad_y, nullptr, nullptr, 0, save, relu, has_residual, workspace, grad_x, grad_residual, grad_weight,
                                     grad_bias, act_dtype, stream);
 }
 

@@ -165,3 +165,55 @@ extern "C" int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_
     hipLaunchKernelGGL(opt_adamw, dim3(num_chunks), dim3(kOptBlock), 0, st, a);
     return mmt::check_launch("clip_adamw_step(update)");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out = in_0 + in_1 + ... + in_{n-1} (n <= 32 dense fp32 tensors of one size) in ONE pass: n reads + 1 write, where autograd's
+// accumulation of n gradients is n - 1 read-read-write passes (the 24 branches of the CenterPoint head hand their input's gradient
+// back separately: 22 adds of 16.8 MB per step at BASELINE configs[3]).  Summed in argument order.
+namespace {
+
+struct AddNArgs {
+    const float *in[32];
+    float *out;
+    int64_t n4, tail0, numel;
+    int n;
+};
+
+__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += stride) {
+        float4 s = reinterpret_cast<const float4 *>(a.in[0])[i];
+        for (int k = 1; k < a.n; ++k) {
+            const float4 v = reinterpret_cast<const float4 *>(a.in[k])[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4 *>(a.out)[i] = s;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = a.tail0 + threadIdx.x; i < a.numel; i += 256) {
+            float s = a.in[0][i];
+            for (int k = 1; k < a.n; ++k) s += a.in[k][i];
+            a.out[i] = s;
+        }
+}
+
+}  // namespace
+
+extern "C" int mmt_add_n(int n, const void *const *inputs_host, int64_t numel, float *out, void *stream) {
+    MMT_REQUIRE_PTR(inputs_host);
+    MMT_REQUIRE_PTR(out);
+    if (n < 1 || n > 32 || numel < 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "add_n: 1 <= n <= 32 tensors (n=%d numel=%lld)", n, (long long)numel);
+    if (numel == 0) return MMT_OK;
+    AddNArgs a;
+    bool aligned = ((uintptr_t)out & 15) == 0;
+    for (int k = 0; k < n; ++k) {
+        if (inputs_host[k] == nullptr) return mmt::fail(MMT_ERR_NULL_POINTER, "add_n: input %d is NULL", k);
+        a.in[k] = static_cast<const float *>(inputs_host[k]);
+        aligned = aligned && ((uintptr_t)inputs_host[k] & 15) == 0;
+    }
+    a.out = out; a.n = n; a.numel = numel;
+    a.n4 = aligned ? numel / 4 : 0;
+    a.tail0 = a.n4 * 4;
+    hipLaunchKernelGGL(add_n_kernel, dim3(mmt::stream_grid(a.n4 > 0 ? a.n4 : 1, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, a);
+    return mmt::check_launch("add_n");
+}

@@ -80,7 +80,16 @@ class _BnAct(Function):
             if g.dtype != x.dtype:
                 g = g.to(x.dtype)
             return g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
-        grad_y = _prep(grad_y)
+        # a channel slice of a wider channels-last tensor (the gradient of one input of a torch.cat: ASPP's five branches) is read
+        # in place through its row stride -- .contiguous() was a 35 MB copy per branch and step at BASELINE configs[3]
+        pitch = 0
+        Bn, Cn, Hn, Wn = grad_y.shape
+        sb, sc, sh, sw = grad_y.stride()
+        if (grad_y.dtype == x.dtype and not grad_y.is_contiguous(memory_format=torch.channels_last) and sc == 1 and sw > Cn and sw % 4 == 0
+                and sh == Wn * sw and sb == Hn * Wn * sw and grad_y.data_ptr() % (16 if grad_y.element_size() == 4 else 8) == 0):
+            pitch = sw
+        else:
+            grad_y = _prep(grad_y)
         grad_y2 = _prep(grad_y2) if grad_y2 is not None else None
         grad_y3 = _prep(grad_y3) if grad_y3 is not None else None
         grad_x = torch.empty_like(x)
@@ -89,7 +98,7 @@ class _BnAct(Function):
         grad_b = torch.empty(C, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.call("mmt_bn_relu_backward_ex2", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
-                      grad_y2.data_ptr() if grad_y2 is not None else 0, grad_y3.data_ptr() if grad_y3 is not None else 0,
+                      grad_y2.data_ptr() if grad_y2 is not None else 0, grad_y3.data_ptr() if grad_y3 is not None else 0, pitch,
                       save.data_ptr(), int(relu), int(has_res), workspace.data_ptr(), grad_x.data_ptr(),
                       grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), act, _stream())
         return grad_x, grad_res, grad_w, grad_b, None, None, None, None, None, None, None

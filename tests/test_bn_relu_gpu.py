@@ -197,3 +197,31 @@ def test_resnet_stage_with_forked_blocks_equals_plain_blocks(mmt_lib):
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4 * float(res[1][1].abs().max())
     for a, b in zip(res[0][2], res[1][2]):
         assert float((a - b).abs().max()) <= 2e-3 * max(1e-6, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("use_res", [False, True])
+def test_gradient_that_is_a_channel_slice_is_read_in_place(mmt_lib, use_res):
+    """The gradient of one input of a torch.cat arrives as a channel slice of the concatenation's gradient (rows a wider pitch
+    apart): the backward reads it through its row stride (no .contiguous() copy) and gives the gradients of the dense case."""
+    from mm_training_amd.ops.bn_relu import bn_act
+    torch.manual_seed(5)
+    B, C, H, W = 6, 64, 16, 44
+    xs = [(torch.randn(B, C, H, W, device="cuda") * 1.5).contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    rs = [torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    wsum = torch.randn(B, 3 * C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    bns = [nn.BatchNorm2d(C).cuda() for _ in range(3)]
+    res = []
+    for dense in (False, True):
+        for bn in bns:
+            bn.zero_grad(set_to_none=True)
+        xi = [x.clone().requires_grad_(True) for x in xs]
+        ri = [r.clone().requires_grad_(True) for r in rs]
+        ys = [bn_act(bn, x, r if use_res else None, True) for bn, x, r in zip(bns, xi, ri)]
+        if dense:
+            loss = sum((y * wsum[:, k * C:(k + 1) * C].contiguous(memory_format=torch.channels_last)).sum() for k, y in enumerate(ys))
+        else:
+            loss = (torch.cat(ys, 1) * wsum).sum()              # cat backward hands each branch a slice of wsum-shaped memory
+        loss.backward()
+        res.append([x.grad for x in xi] + ([r.grad for r in ri] if use_res else []) + [bn.weight.grad for bn in bns] + [bn.bias.grad for bn in bns])
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b), float((a - b).abs().max())
