@@ -57,7 +57,9 @@ class _DeformConv3x3(Function):
                 torch.bmm(col[g].view(S, N // S, 9 * Cg).transpose(1, 2), go2d.view(S, N // S, O)[:, :, g * Og:(g + 1) * Og], out=parts[g])
             else:
                 torch.mm(col[g].t(), go_g, out=grad_wmat[g])
-            torch.mm(go_g, wmat[g].t(), out=grad_col[g])
+        # the column gradient of all groups as ONE strided-batch GEMM (the groups' gradient columns read in place: batch stride Og,
+        # row stride O): 276 -> 230 us against four GEMMs, bit-identical (tools/scratch/dcn_gradcol_gemm.py)
+        torch.bmm(go2d.view(N, groups, Og).permute(1, 0, 2), wmat.transpose(1, 2), out=grad_col)
         if S > 1:
             torch.sum(parts, 1, out=grad_wmat)
         grad_weight = grad_wmat.reshape(groups, 9, Cg, Og).permute(0, 3, 2, 1).reshape(O, Cg, 3, 3)
