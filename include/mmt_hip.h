@@ -748,13 +748,15 @@ int mmt_bn_relu_backward_ex2(int64_t R, int C, const void *x, const void *y, con
  *   chunk_tensor int32 [num_chunks], chunk_offset int64 [num_chunks]: tensor index and first element of every chunk of
  *     chunk_elems elements (a multiple of 4; a tensor's last chunk may be shorter); all DEVICE arrays
  *   param_ptrs / grad_ptrs / exp_avg_ptrs / exp_avg_sq_ptrs int64 [T] DEVICE arrays of device addresses (fp32 tensors, dense), numel int64 [T]
+ *   bf16_shadow_ptrs int64 [T] or NULL: per tensor the address of a bf16 copy of the parameter (same memory order; 0 = none), rewritten
+ *     with the updated values (round to nearest even) -- the autocast convolutions' weights without a cast kernel per layer and step
  *   step >= 1: the update's number (bias corrections 1 - beta^step); max_norm <= 0: no clipping (and no norm launch)
  *   partials fp32 [num_chunks] scratch (max_norm > 0); norm_out fp32 [2] or NULL: total gradient norm, clip coefficient applied
  * Arithmetic as torch's fused kernel (ADAMW, amsgrad off, maximize off): double products with lr / betas / weight decay / eps,
  * fp32 state; clip coefficient = min(1, max_norm / (norm + 1e-6)). */
 int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_t *chunk_tensor, const int64_t *chunk_offset,
                         const int64_t *param_ptrs, const int64_t *grad_ptrs, const int64_t *exp_avg_ptrs,
-                        const int64_t *exp_avg_sq_ptrs, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                        const int64_t *exp_avg_sq_ptrs, const int64_t *bf16_shadow_ptrs, const int64_t *numel, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int64_t step, float max_norm, float *partials, float *norm_out, void *stream);
 
 /* out = inputs[0] + ... + inputs[n-1] (n <= 32 dense fp32 tensors of numel elements; inputs_host: a HOST array of device pointers,

@@ -20,6 +20,7 @@ constexpr int kOptBlock = 256;
 
 struct OptArgs {
     const int64_t *p, *g, *m, *v;     // [T] device pointers as integers
+    const int64_t *shadow;            // [T] or NULL: bf16 copies of the parameters (0: none for this tensor), rewritten with the update
     const int64_t *numel;             // [T]
     const int32_t *chunk_tensor;      // [NC]
     const int64_t *chunk_off;         // [NC] first element of the chunk inside its tensor
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(kOptBlock) void opt_adamw(OptArgs a) {
     float *m = reinterpret_cast<float *>(a.m[t]) + off;
     float *v = reinterpret_cast<float *>(a.v[t]) + off;
     const float step_size = (float)(a.lr_d / (double)a.bc1);
-    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+    bf16_t *sh = (a.shadow && a.shadow[t]) ? reinterpret_cast<bf16_t *>(a.shadow[t]) + off : nullptr;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)sh & 7) == 0) {
         float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
         const float4 *g4 = reinterpret_cast<const float4 *>(g);
         constexpr int U = 2;
@@ -115,18 +117,21 @@ __global__ __launch_bounds__(kOptBlock) void opt_adamw(OptArgs a) {
                 adamw1(pp[u].z, gg[u].z * coef, mm[u].z, vv[u].z, a, step_size);
                 adamw1(pp[u].w, gg[u].w * coef, mm[u].w, vv[u].w, a, step_size);
                 p4[i] = pp[u]; m4[i] = mm[u]; v4[i] = vv[u];
+                if (sh) reinterpret_cast<uint2 *>(sh)[i] = make_uint2(pack_bf16x2(pp[u].x, pp[u].y), pack_bf16x2(pp[u].z, pp[u].w));
             }
         }
         for (int i = (n & ~3) + threadIdx.x; i < n; i += kOptBlock) {
             float pp = p[i], mm = m[i], vv = v[i];
             adamw1(pp, g[i] * coef, mm, vv, a, step_size);
             p[i] = pp; m[i] = mm; v[i] = vv;
+            if (sh) sh[i] = (bf16_t)(pack_bf16x2(pp, 0.f) & 0xFFFFu);
         }
     } else {
         for (int i = threadIdx.x; i < n; i += kOptBlock) {
             float pp = p[i], mm = m[i], vv = v[i];
             adamw1(pp, g[i] * coef, mm, vv, a, step_size);
             p[i] = pp; m[i] = mm; v[i] = vv;
+            if (sh) sh[i] = (bf16_t)(pack_bf16x2(pp, 0.f) & 0xFFFFu);
         }
     }
 }
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(kOptBlock) void opt_adamw(OptArgs a) {
 
 extern "C" int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_t *chunk_tensor, const int64_t *chunk_offset,
                                    const int64_t *param_ptrs, const int64_t *grad_ptrs, const int64_t *exp_avg_ptrs,
-                                   const int64_t *exp_avg_sq_ptrs, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                                   const int64_t *exp_avg_sq_ptrs, const int64_t *bf16_shadow_ptrs, const int64_t *numel, double lr, double beta1, double beta2, double eps,
                                    double weight_decay, int64_t step, float max_norm, float *partials, float *norm_out, void *stream) {
     if (num_chunks == 0) return MMT_OK;
     MMT_REQUIRE_PTR(chunk_tensor);
@@ -150,7 +155,7 @@ extern "C" int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_
                          (long long)step, beta1, beta2);
     if (max_norm > 0.f) MMT_REQUIRE_PTR(partials);
     OptArgs a;
-    a.p = param_ptrs; a.g = grad_ptrs; a.m = exp_avg_ptrs; a.v = exp_avg_sq_ptrs; a.numel = numel;
+    a.p = param_ptrs; a.g = grad_ptrs; a.m = exp_avg_ptrs; a.v = exp_avg_sq_ptrs; a.shadow = bf16_shadow_ptrs; a.numel = numel;
     a.chunk_tensor = chunk_tensor; a.chunk_off = chunk_offset; a.chunk_elems = chunk_elems; a.NC = num_chunks;
     a.partials = partials; a.norm_out = norm_out;
     a.lr_d = lr; a.beta1_d = beta1; a.beta2_d = beta2; a.eps_d = eps; a.wd_d = weight_decay; a.max_norm = max_norm;

@@ -33,6 +33,7 @@ class ClipAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_norm = float(max_norm)
         self.last_norm = None
+        self.shadows = {}       # parameter -> bf16 copy kept current by step() (see make_bf16_shadows)
         self._plans = {}        # group index -> (key of the participating parameters, device tables)
         for group in self.param_groups:
             for p in group["params"]:
@@ -66,6 +67,7 @@ class ClipAdamW(torch.optim.Optimizer):
                     chunk_t=torch.tensor(chunk_t, dtype=torch.int32, device=dev), chunk_o=i64(chunk_o),
                     p=i64([p.data_ptr() for p in ps]), m=i64([self.state[p]["exp_avg"].data_ptr() for p in ps]),
                     v=i64([self.state[p]["exp_avg_sq"].data_ptr() for p in ps]), numel=i64([p.numel() for p in ps]),
+                    shadow=i64([self.shadows[p].data_ptr() if p in self.shadows else 0 for p in ps]) if self.shadows else None,
                     # the gradients' addresses change from step to step (autograd allocates them afresh): staged through a RING of pinned
                     # buffers, each guarded by an event -- the host runs ahead of the device by more than a step, and a single buffer
                     # would be overwritten with the next step's addresses before this step's copy has executed
@@ -75,6 +77,21 @@ class ClipAdamW(torch.optim.Optimizer):
                     norm=torch.zeros(2, dtype=torch.float32, device=dev))
         self._plans[gi] = plan
         return plan
+
+    @torch.no_grad()
+    def make_bf16_shadows(self, params):
+        """A bf16 copy of every given parameter (same shape and memory order), rewritten by every step() with the updated values:
+        what an autocast convolution would otherwise produce with a cast kernel per layer and step (ops/conv_overlap.py looks the
+        copy up and remembers the parameter's version counter: step() updates the parameter through raw pointers and leaves the counter
+        alone, so any OTHER in-place change of the parameter (load_state_dict, an initialiser) shows as a mismatch and the consumer
+        refreshes the copy)."""
+        from ..ops import conv_overlap
+        for p in params:
+            sh = torch.empty_like(p, dtype=torch.bfloat16, memory_format=torch.preserve_format)
+            sh.copy_(p)
+            self.shadows[p] = sh
+            conv_overlap.register_bf16_shadow(p, sh)
+        self._plans.clear()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -110,7 +127,8 @@ class ClipAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             with torch.cuda.device(ps[0].device):
                 _lib.call("mmt_clip_adamw_step", plan["n_chunks"], CHUNK, plan["chunk_t"].data_ptr(), plan["chunk_o"].data_ptr(),
-                          plan["p"].data_ptr(), plan["g"].data_ptr(), plan["m"].data_ptr(), plan["v"].data_ptr(), plan["numel"].data_ptr(),
+                          plan["p"].data_ptr(), plan["g"].data_ptr(), plan["m"].data_ptr(), plan["v"].data_ptr(),
+                          plan["shadow"].data_ptr() if plan["shadow"] is not None else 0, plan["numel"].data_ptr(),
                           float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
                           float(self.max_norm), plan["partials"].data_ptr(), plan["norm"].data_ptr(),
                           torch.cuda.current_stream().cuda_stream)

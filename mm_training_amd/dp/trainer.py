@@ -218,6 +218,13 @@ class TrainStep(nn.Module):
         self.downsample = cfg["backbone_conf"]["downsample_factor"]
         self.depth_channels = len(torch.arange(*db)) if self.use_cam else 0
         self.amp_dtype = torch.bfloat16 if (amp or cfg.get("dtype")) == "bf16" else None
+        if self.fused_optimizer and self.amp_dtype is torch.bfloat16 and self.conv_overlap is not None \
+                and os.environ.get("MMT_BF16_SHADOWS", "1") != "0":
+            # the autocast convolutions' bf16 weights are written by the optimizer step itself (ClipAdamW.make_bf16_shadows): no cast
+            # kernel per layer and step (253 launches, 1.05 ms per step at BASELINE configs[4])
+            from ..ops.conv_overlap import OverlapConv2d
+            convs = [m.weight for m in self.model.modules() if isinstance(m, OverlapConv2d) and m.weight.requires_grad]
+            self.optimizer.make_bf16_shadows(convs)
         # exps/mm_training_aim.py:258: training_step always runs augment_images(..., 'train'); :78 + :259: the depth labels are
         # handed to the model as the depth oracle when use_depth_loss is set (True in exps/conf_aim.py:23 and in the reference's
         # camera + LiDAR config exps/configs/lidar_cam.py:23)

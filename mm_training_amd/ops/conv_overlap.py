@@ -116,6 +116,31 @@ def _deferral_is_safe(leaf, gw):
     return all(sg == sl for n, sg, sl in zip(leaf.shape, gw.stride(), leaf.stride()) if n != 1)
 
 
+# bf16 copies of convolution weights kept current by the optimizer (dp/optim.py::ClipAdamW.make_bf16_shadows): id(weight) ->
+# (weak reference to the weight, the copy, the weight's version counter when the copy was last known to be current)
+_shadows = {}
+
+
+def register_bf16_shadow(weight, shadow):
+    import weakref
+    _shadows[id(weight)] = (weakref.ref(weight), shadow, weight._version)
+
+
+def _cast_weight(w, dtype):
+    """The weight in the autocast dtype: the optimizer's copy when there is one, else a cast.  The optimizer updates weight and copy
+    through raw pointers, so the weight's version counter only moves for OTHER writers (load_state_dict, an initialiser, another
+    optimizer): a moved counter means the copy is stale, and it is refreshed here (one copy kernel -- what the cast would have cost)."""
+    if dtype is torch.bfloat16:
+        ent = _shadows.get(id(w))
+        if ent is not None and ent[0]() is w:
+            if w._version != ent[2]:
+                with torch.no_grad():
+                    ent[1].copy_(w)
+                _shadows[id(w)] = (ent[0], ent[1], w._version)
+            return ent[1]
+    return w.to(dtype)
+
+
 class _ConvOverlap(Function):
     """conv2d(x, w, b) computed in `dtype` (None: as given; torch.bfloat16 under autocast -- the casts live INSIDE the Function so that
     the weight gradient comes back in the parameter's own dtype from the side stream, with no main-stream cast node behind it)."""
@@ -127,7 +152,7 @@ class _ConvOverlap(Function):
         if narrow and dtype in (torch.bfloat16, torch.float16):
             out_dtype, dtype = dtype, torch.float32          # NARROW (module docstring): fp32 arithmetic, 16-bit result
         xc = x if dtype is None else x.to(dtype)
-        wc = w if dtype is None else w.to(dtype)
+        wc = w if dtype is None else _cast_weight(w, dtype)
         bc = b if (b is None or dtype is None) else b.to(dtype)
         ctx.save_for_backward(xc, wc, w)
         if mode == "deferred" and ctx.needs_input_grad[1] and not narrow:    # (a narrow layer's backward is inline: nothing to count)

@@ -119,3 +119,60 @@ def test_steps_queued_without_a_host_sync(mmt_lib):
     torch.cuda.synchronize()
     for p, q in zip(a, b):
         assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(q.abs().max()))
+
+
+def test_bf16_shadows_follow_the_parameters(mmt_lib):
+    """make_bf16_shadows: after every step the bf16 copy of a parameter equals `p.to(bfloat16)` bit for bit (channels_last weights,
+    odd lengths, a tensor without a copy next to them), and the autocast convolution uses the copy -- until somebody else writes the
+    weight, which refreshes it."""
+    from mm_training_amd.dp.optim import ClipAdamW
+    from mm_training_amd.ops import conv_overlap
+    ps = _params(3)
+    opt = ClipAdamW(ps, lr=3e-3, max_norm=2.0)
+    with_copy = [ps[0], ps[1], ps[4], ps[6], ps[7]]
+    opt.make_bf16_shadows(with_copy)
+    for step in range(4):
+        for p, g in zip(ps, _grads(ps, 20 + step, 1.0)):
+            p.grad = g
+        opt.step()
+        for p in with_copy:
+            sh = opt.shadows[p]
+            assert sh.stride() == p.stride() and sh.dtype == torch.bfloat16
+            assert torch.equal(sh, p.detach().to(torch.bfloat16)), step
+    w = ps[0]
+    version = w._version
+    assert conv_overlap._cast_weight(w, torch.bfloat16) is opt.shadows[w] and w._version == version
+    assert conv_overlap._cast_weight(ps[2], torch.bfloat16).dtype == torch.bfloat16          # (no copy registered: a cast)
+    assert conv_overlap._cast_weight(w, torch.float16).dtype == torch.float16
+    with torch.no_grad():
+        w.mul_(2.0)                                                                       # another writer: the copy is stale
+    got = conv_overlap._cast_weight(w, torch.bfloat16)
+    assert got is opt.shadows[w] and torch.equal(got, w.detach().to(torch.bfloat16))
+    for p, g in zip(ps, _grads(ps, 99, 1.0)):
+        p.grad = g
+    opt.step()
+    assert torch.equal(conv_overlap._cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))
+
+
+def test_bf16_training_step_with_and_without_shadows(mmt_lib, monkeypatch):
+    """The bf16-autocast training step with the optimizer-maintained weight copies against the same step casting per layer
+    (MMT_BF16_SHADOWS=0): the convolutions see the same bf16 weights either way."""
+    import numpy as np
+    from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
+    losses = []
+    for shadows in ("1", "0"):
+        monkeypatch.setenv("MMT_BF16_SHADOWS", shadows)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = make_config("tiny")
+        ts = TrainStep(cfg, torch.device("cuda", 0), amp="bf16")
+        assert ts.amp_dtype is torch.bfloat16
+        assert bool(ts.optimizer.shadows) == (shadows == "1")
+        batches = [synthetic_batch(cfg, torch.device("cuda", 0), seed=i) for i in range(2)]
+        ls = []
+        for i in range(6):
+            np.random.seed(100 + i)
+            ls.append(float(ts(batches[i % 2])[0]))
+        losses.append(ls)
+    assert all(np.isfinite(losses[0])) and losses[0][-1] < losses[0][0]
+    assert np.allclose(losses[0], losses[1], rtol=3e-2), losses
