@@ -147,6 +147,50 @@ def lib():
     return _lib
 
 
+# ---- cheap host-side plumbing for the per-layer wrappers (ops/bn_relu.py, ops/conv_overlap.py: ~250 calls each per training step;
+# BASELINE configs[4] is bound by the host's issue rate, tools/scratch/host_vs_gpu.py) -------------------------------------------
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def raw_stream(device=None):
+    """Handle of the current HIP stream of `device` (None: the current device) -- `torch.cuda.current_stream(device).cuda_stream`
+    without building the Stream object (8 us -> under 1 us)."""
+    import torch
+    index = device.index if device is not None and device.index is not None else torch._C._cuda_getDevice()
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
+def on_device(device):
+    """`with on_device(t.device):` = `with torch.cuda.device(t.device):` that costs nothing when `device` is the current one already
+    (the usual case: one process per GPU; the autograd engine sets the device for its backward thread)."""
+    import torch
+    if device.index is None or torch._C._cuda_getDevice() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
+_bound_apply = {}
+
+
+def apply_function(fn_class, *args):
+    """`fn_class.apply(*args)` for a plain torch.autograd.Function (no setup_context; not for use under a functorch transform):
+    the C++ `apply` bound to the class once, past Function.apply's per-call signature inspection and wrapper scan (2-3 us of host
+    time per layer)."""
+    f = _bound_apply.get(fn_class)
+    if f is None:
+        import torch
+        f = _bound_apply[fn_class] = torch._C._FunctionBase.__dict__["apply"].__get__(None, fn_class)
+    return f(*args)
+
+
 def call(name, *args):
     """Call an int-returning entry point; raise MmtError with the library's message."""
     rc = getattr(lib(), name)(*args)

@@ -21,8 +21,7 @@ from .. import _lib
 ENABLED = os.environ.get("MMT_FUSED_BN", "1") != "0"
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = _lib.raw_stream
 
 
 def _supported(bn, x):
@@ -50,10 +49,10 @@ class _BnAct(Function):
             if not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
             res_ptr = residual.data_ptr()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.call("mmt_bn_relu_forward_ex", R, C, x.data_ptr(), res_ptr, weight.data_ptr(), bias.data_ptr(),
                       running_mean.data_ptr(), running_var.data_ptr(), float(momentum), float(eps), int(relu),
-                      workspace.data_ptr(), save.data_ptr(), y.data_ptr(), act, _stream())
+                      workspace.data_ptr(), save.data_ptr(), y.data_ptr(), act, _stream(x.device))
         ctx.mark_non_differentiable(running_mean, running_var)
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, save, workspace)
@@ -96,15 +95,16 @@ class _BnAct(Function):
         grad_res = torch.empty_like(x) if has_res else None
         grad_w = torch.empty(C, dtype=torch.float32, device=x.device)
         grad_b = torch.empty(C, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.call("mmt_bn_relu_backward_ex2", R, C, x.data_ptr(), y.data_ptr() if y is not None else 0, grad_y.data_ptr(),
                       grad_y2.data_ptr() if grad_y2 is not None else 0, grad_y3.data_ptr() if grad_y3 is not None else 0, pitch,
                       save.data_ptr(), int(relu), int(has_res), workspace.data_ptr(), grad_x.data_ptr(),
-                      grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), act, _stream())
+                      grad_res.data_ptr() if has_res else 0, grad_w.data_ptr(), grad_b.data_ptr(), act, _stream(x.device))
         return grad_x, grad_res, grad_w, grad_b, None, None, None, None, None, None, None
 
 
 _SCRATCH = {}
+_NEED = {}
 
 
 def _workspace(bn, device):
@@ -112,8 +112,11 @@ def _workspace(bn, device):
     stream, so one buffer sized for the widest layer serves every BatchNorm the stream runs -- and layers that run on
     different streams at the same time (the task heads, layers/heads/bev_depth_head.py) never share one.  The backward
     of a layer runs on its forward's stream (autograd) and receives the same buffer."""
-    need = _lib.lib().mmt_bn_workspace_elems(max(2048, bn.num_features))
-    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    width = max(2048, bn.num_features)
+    need = _NEED.get(width)
+    if need is None:
+        need = _NEED[width] = _lib.lib().mmt_bn_workspace_elems(width)
+    key = (device, _lib.raw_stream(device) if device.type == "cuda" else 0)
     ws = _SCRATCH.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=device)
@@ -136,9 +139,9 @@ def bn_act(bn, x, residual=None, relu=True, fork=False):
         # inside an autocast region: the statistics and the normalisation run in fp32 on the fused kernels -- what autocast does
         # for batch_norm anyway -- with bf16 activations in and out, instead of MIOpen's NHWC batch norm (an out-of-bounds
         # access inside it was met twice: DESIGN section 4, fuzz_dense; tools/scratch/soak_streams.py)
-        with torch.autocast("cuda", enabled=False):
-            return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                _workspace(bn, x.device), bn.momentum, bn.eps, relu, (2 if fork is True else int(fork)) if (fork and FORK) else 0)
+        # (nothing inside the Function is an autocast-wrapped operator: no `autocast(enabled=False)` region around it)
+        return _lib.apply_function(_BnAct, x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   _workspace(bn, x.device), bn.momentum, bn.eps, relu, (2 if fork is True else int(fork)) if (fork and FORK) else 0)
     out = bn(x)
     if residual is not None:
         out = out + residual

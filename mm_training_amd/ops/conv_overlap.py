@@ -36,7 +36,33 @@ import os
 import torch
 from torch.autograd import Function
 
+from .. import _lib
+
+_aten_convolution = torch.ops.aten.convolution.default                      # (the overload itself: no resolution per call)
+_aten_convolution_backward = torch.ops.aten.convolution_backward.default
+
 NARROW = 16
+_events = {}
+
+
+_stream_objects = {}
+
+
+def _current_stream(device):
+    """torch.cuda.current_stream(device), the Stream object looked up by the raw handle (8 us -> 1 us per layer)."""
+    key = (device.index, _lib.raw_stream(device))
+    st = _stream_objects.get(key)
+    if st is None:
+        st = _stream_objects[key] = torch.cuda.current_stream(device)
+    return st
+
+
+def _fork_event(device):
+    ev = _events.get(device.index)
+    if ev is None:
+        ev = _events[device.index] = torch.cuda.Event()
+    return ev
+
 _side = {}
 _state = {"join_queued_for": None}      # id of the backward pass (autograd graph task) whose end-of-backward join is queued
 
@@ -160,8 +186,11 @@ class _ConvOverlap(Function):
             u[0] += 1
             u[1] = u[1] or u[0] > 1
         ctx.conf = (stride, padding, dilation, groups, b is not None, x.dtype, b.dtype if b is not None else None, mode, narrow)
-        with torch.backends.cudnn.flags(enabled=not narrow):   # NARROW: ATen's own im2col + GEMM convolution, not MIOpen
-            y = torch.ops.aten.convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
+        if narrow:
+            with torch.backends.cudnn.flags(enabled=False):    # NARROW: ATen's own im2col + GEMM convolution, not MIOpen
+                y = _aten_convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
+        else:
+            y = _aten_convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
         return y if out_dtype is None else y.to(out_dtype)
 
     @staticmethod
@@ -174,13 +203,12 @@ class _ConvOverlap(Function):
         zeros = [0] * len(stride)
         gx = gw = gb = None
         deferred = False
-        main = torch.cuda.current_stream(gy.device)
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
         if mode == "inline":                                 # one stream, one call: autograd's own backward
-            with torch.backends.cudnn.flags(enabled=not narrow):
-                gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
-                                                                 False, zeros, groups, [need_x, need_w, has_b])
+            with (torch.backends.cudnn.flags(enabled=False) if narrow else _lib._NO_GUARD):
+                gx, gw, gb = _aten_convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
+                                                        False, zeros, groups, [need_x, need_w, has_b])
             if gx is not None and gx.dtype != x_dtype:
                 gx = gx.to(x_dtype)
             if gw is not None and gw.dtype != leaf.dtype:
@@ -188,16 +216,25 @@ class _ConvOverlap(Function):
             if gb is not None and gb.dtype != b_dtype:
                 gb = gb.to(b_dtype)
             return gx, gw, gb, None, None, None, None, None, None
+        main = _current_stream(gy.device)
         side = side_stream(gy.device)                    # (created on first use: an inline rank never owns one)
         if need_w or has_b:
-            side.wait_stream(main)                       # grad_out (and, in the first layer of a backward, the saved tensors) are ready
-            with torch.cuda.stream(side):
-                _, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
-                                                                False, zeros, groups, [False, need_w, has_b])
+            # grad_out (and, in the first layer of a backward, the saved tensors) are ready: side.wait_stream(main), with ONE event
+            # per device recorded again and again (a wait takes the record that is current when it is issued) instead of an event
+            # created and destroyed per layer; the stream switch likewise without the context-manager object
+            ev = _fork_event(gy.device)
+            ev.record(main)
+            side.wait_event(ev)
+            torch.cuda.set_stream(side)
+            try:
+                _, gw, gb = _aten_convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
+                                                       False, zeros, groups, [False, need_w, has_b])
                 if gw is not None and gw.dtype != leaf.dtype:
                     gw = gw.to(leaf.dtype)
                 if gb is not None and gb.dtype != b_dtype:
                     gb = gb.to(b_dtype)
+            finally:
+                torch.cuda.set_stream(main)
             # Memory across the two streams (the caching allocator hands a freed block back to the stream it was allocated on,
             # whatever other stream may still be using it):
             #  * grad_out / x / a cast weight were allocated elsewhere and are read on the side stream;
@@ -221,8 +258,7 @@ class _ConvOverlap(Function):
                     _state["join_queued_for"] = task
                     torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         if need_x:
-            gx = torch.ops.aten.convolution_backward(gy, x, w, None, stride, padding, dilation, False, zeros, groups,
-                                                     [True, False, False])[0]
+            gx = _aten_convolution_backward(gy, x, w, None, stride, padding, dilation, False, zeros, groups, [True, False, False])[0]
             if gx.dtype != x_dtype:
                 gx = gx.to(x_dtype)
         if (need_w or has_b) and not deferred:
@@ -237,10 +273,16 @@ class OverlapConv2d(torch.nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and torch.is_grad_enabled() and self.padding_mode == "zeros" and not isinstance(self.padding, str):
-            dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
-            with torch.autocast("cuda", enabled=False):
-                return _ConvOverlap.apply(x, self.weight, self.bias, list(self.stride), list(self.padding), list(self.dilation),
-                                          self.groups, dtype, self._mmt_overlap_mode)
+            amp = torch.is_autocast_enabled()
+            dtype = torch.get_autocast_dtype("cuda") if amp else None
+            args = (x, self.weight, self.bias, list(self.stride), list(self.padding), list(self.dilation), self.groups, dtype,
+                    self._mmt_overlap_mode)
+            if amp and x.shape[1] < NARROW and self.out_channels < NARROW:
+                with torch.autocast("cuda", enabled=False):      # NARROW: fp32 arithmetic inside an autocast region
+                    return _lib.apply_function(_ConvOverlap, *args)
+            # (otherwise the operands reach aten::convolution in the autocast dtype already: autocast finds nothing to cast, and
+            # the region switch per layer is host time)
+            return _lib.apply_function(_ConvOverlap, *args)
         return super().forward(x)
 
 
