@@ -183,15 +183,18 @@ __global__ __launch_bounds__(kBlock) void bn_reduce_kernel(BnArgs a, int64_t row
     }
 }
 
-// Sum of the workgroups' partial rows for 64 channels per workgroup: 16 waves take every 16th partial
-// row each (coalesced across channels, 8 independent loads in flight), double accumulation, LDS
-// combine.  Returns the totals to the threads of wave 0 (tid < 64).
-constexpr int kFinBlock = 1024;
+// Sum of the workgroups' partial rows, 16 channels per workgroup: 16 groups of 16 lanes take every 16th partial row each (64-byte
+// pieces of rows that sit in L2, 8 independent loads in flight), double accumulation, LDS combine.  Returns the totals to the first
+// 16 threads.  256 threads, not 1024 (as up to round 4): the kernel sits between two streaming passes of the main stream while
+// the weight-gradient stream keeps the CUs full of long-running workgroups, and a workgroup that needs 16 free wave slots on ONE
+// CU waited for them -- 75 us per launch behind DepthNet's 512-channel weight gradients against 5 us alone (tools/glue_audit.py).
+constexpr int kFinBlock = 256;
+constexpr int kFinCh = 16;
 __device__ __forceinline__ bool bn_block_sums(const BnArgs &a, int nblocks, int *c_out, double *s0, double *s1) {
     __shared__ double red[2][kFinBlock];
-    constexpr int NSEG = kFinBlock / 64;
-    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    constexpr int NSEG = kFinBlock / kFinCh;
+    const int lane = threadIdx.x & (kFinCh - 1), seg = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + lane;
     double t0 = 0.0, t1 = 0.0;
     if (c < a.C) {
         const int last = nblocks - 1;
@@ -214,7 +217,7 @@ __device__ __forceinline__ bool bn_block_sums(const BnArgs &a, int nblocks, int 
     __syncthreads();
     *c_out = c;
     if (seg != 0 || c >= a.C) return false;
-    for (int j = 1; j < NSEG; ++j) { t0 += red[0][lane + 64 * j]; t1 += red[1][lane + 64 * j]; }
+    for (int j = 1; j < NSEG; ++j) { t0 += red[0][lane + kFinCh * j]; t1 += red[1][lane + kFinCh * j]; }
     *s0 = t0; *s1 = t1;
     return true;
 }
@@ -364,7 +367,7 @@ template <typename AT>
 void launch_forward(const BnArgs &a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
     hipLaunchKernelGGL((bn_reduce_kernel<0, AT, 1>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
     if ((*rc = mmt::check_launch("bn_relu_forward(stats)"))) return;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)mmt::ceil_div(a.C, 64)), dim3(kFinBlock), 0, st, a, blocks);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)mmt::ceil_div(a.C, kFinCh)), dim3(kFinBlock), 0, st, a, blocks);
     if ((*rc = mmt::check_launch("bn_relu_forward(finalize)"))) return;
     hipLaunchKernelGGL((bn_map_kernel<0, AT, 1>), dim3(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, InFlight<AT>::value), kBlock)), dim3(kBlock), 0, st, a);
     *rc = mmt::check_launch("bn_relu_forward(apply)");
@@ -374,7 +377,7 @@ template <typename AT, int NG>
 void launch_backward_ng(BnArgs a, int blocks, int64_t rpb, hipStream_t st, int *rc) {
     hipLaunchKernelGGL((bn_reduce_kernel<1, AT, NG>), dim3(blocks, a.g.kc), dim3(kBlock), 0, st, a, rpb);
     if ((*rc = mmt::check_launch("bn_relu_backward(reduce)"))) return;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)mmt::ceil_div(a.C, 64)), dim3(kFinBlock), 0, st, a, blocks);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)mmt::ceil_div(a.C, kFinCh)), dim3(kFinBlock), 0, st, a, blocks);
     if ((*rc = mmt::check_launch("bn_relu_backward(finalize)"))) return;
     const dim3 grid(mmt::stream_grid(mmt::ceil_div(a.R * a.g.C4, InFlight<AT>::value), kBlock));
     if (a.dres) {
