@@ -219,11 +219,11 @@ class TrainStep(nn.Module):
         self.depth_channels = len(torch.arange(*db)) if self.use_cam else 0
         self.amp_dtype = torch.bfloat16 if (amp or cfg.get("dtype")) == "bf16" else None
         if self.fused_optimizer and self.amp_dtype is torch.bfloat16 and self.conv_overlap is not None \
-                and os.environ.get("MMT_BF16_SHADOWS", "0") == "1":
-            # opt-in: the autocast convolutions' bf16 weights are written by the optimizer step itself (ClipAdamW.make_bf16_shadows), no
-            # cast kernel per layer and step (253 launches, 1.05 ms of kernels per step at BASELINE configs[4]).  Measured at
-            # configs[4], three alternating 80-step runs: 42.3-45.4 ms with, 42.4-42.9 ms without -- the casts are not on the critical
-            # path, so the default stays the plain cast
+                and os.environ.get("MMT_BF16_SHADOWS", "1") != "0":
+            # the autocast convolutions' bf16 weights are written by the optimizer step itself (ClipAdamW.make_bf16_shadows), no cast
+            # kernel per layer and step (253 launches: 1.05 ms of kernels and ~2 ms of host time per step at BASELINE configs[4],
+            # which sits at the host/device crossover).  Three alternating 80-step runs on one box: 41.1-41.3 ms with,
+            # 41.5-42.6 ms without
             from ..ops.conv_overlap import OverlapConv2d
             convs = [m.weight for m in self.model.modules() if isinstance(m, OverlapConv2d) and m.weight.requires_grad]
             self.optimizer.make_bf16_shadows(convs)
