@@ -33,9 +33,11 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 11  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
+#define MMT_ABI_VERSION 12  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
                              * 11: region-owner voxelizer -- mmt_voxelize_table_elems / _scratch_elems / _workspace_elems take the point
-                             *     count / max_points as well; the table needs no zero fill and holds a cell directory */
+                             *     count / max_points as well; the table needs no zero fill and holds a cell directory
+                             * 12: mmt_clip_adamw_step takes bf16_shadow_ptrs (may be NULL); mmt_channel_blocks_split / _gather;
+                             *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048) */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -763,6 +765,14 @@ int mmt_clip_adamw_step(int num_chunks, int chunk_elems, const int32_t *chunk_te
  * passed to the kernel by value), summed in argument order, one pass: the gradient of a tensor that n branches read
  * (layers/heads/bev_depth_head.py: the 24 branches of the CenterPoint head) without autograd's n - 1 accumulation passes. */
 int mmt_add_n(int n, const void *const *inputs_host, int64_t numel, float *out, void *stream);
+
+/* A channels-last activation [rows, n * W] (n blocks of W channels per pixel; block_bytes = W * element size, a multiple of 16)
+ * <-> n dense [rows, W] tensors (parts_host: a HOST array of n <= 32 device pointers, 16-byte aligned), one pass either way.  The
+ * task heads' 24 first convolutions (the reference's 24 ConvModules on one shared map, bev_depth_head.py SeparateHead) run as ONE
+ * 64 -> 24 x 64 convolution and ONE BatchNorm; `split` hands every final convolution its 64 channels as a dense tensor, `gather`
+ * puts the 24 gradients that come back side by side again. */
+int mmt_channel_blocks_split(int64_t rows, int n, int block_bytes, const void *wide, void *const *parts_host, void *stream);
+int mmt_channel_blocks_gather(int64_t rows, int n, int block_bytes, const void *const *parts_host, void *wide, void *stream);
 
 #ifdef __cplusplus
 }

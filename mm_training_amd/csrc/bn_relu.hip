@@ -331,9 +331,13 @@ int geometry(const char *who, int64_t R, int C, BnGeom *g) {
     if (R <= 0 || C <= 0 || C % 4) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: need R > 0 and C %% 4 == 0 (R=%lld C=%d)", who, (long long)R, C);
     const int C4 = C / 4;
     g->C4 = C4;
+    // wider rows: column blocks of 256, 128 or 64 lanes (C = 1536 = 3 x 128 lanes: the task heads' 24 x 64 channels normalised in one go)
+    g->tpr = 0;
     if (C4 <= kBlock) { g->tpr = C4; g->kc = 1; }
-    else if (C4 % kBlock == 0 && C4 / kBlock <= kMaxKC) { g->tpr = kBlock; g->kc = C4 / kBlock; }
-    else return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: C=%d is not supported (C <= 1024, or a multiple of 1024 up to %d)", who, C, 1024 * kMaxKC);
+    else
+        for (int t = kBlock; t >= 64 && !g->tpr; t /= 2)
+            if (C4 % t == 0 && C4 / t <= kMaxKC) { g->tpr = t; g->kc = C4 / t; }
+    if (!g->tpr) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: C=%d is not supported (C <= 1024, or a multiple of 256 with at most %d column blocks of 1024 / 512 / 256 channels)", who, C, kMaxKC);
     g->rpi = kBlock / g->tpr;
     if (R * C4 >= (1ll << 40)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: activation too large", who);
     return 0;

@@ -222,3 +222,60 @@ extern "C" int mmt_add_n(int n, const void *const *inputs_host, int64_t numel, f
     hipLaunchKernelGGL(add_n_kernel, dim3(mmt::stream_grid(a.n4 > 0 ? a.n4 : 1, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, a);
     return mmt::check_launch("add_n");
 }
+
+// A channels-last activation [rows, n * W] (n blocks of W channels per pixel) <-> n dense [rows, W] tensors, one pass either way.
+// The task heads' 24 first convolutions run as ONE 64 -> 24 x 64 convolution and ONE BatchNorm (layers/heads/bev_depth_head.py); the
+// 24 final convolutions each want their 64 channels as a dense tensor (split), and hand 24 separate gradients back (gather).
+namespace {
+
+struct ChanBlocksArgs {
+    void *part[32];
+    void *wide;
+    int64_t units;      // rows * n * wb16 16-byte units in the wide tensor
+    int n, wb16;        // blocks per row, 16-byte units per block row
+};
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void channel_blocks_kernel(ChanBlocksArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int per_row = a.n * a.wb16;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < a.units; u += stride) {
+        const int64_t r = u / per_row;
+        const int rem = (int)(u - r * per_row);
+        const int k = rem / a.wb16, j = rem - k * a.wb16;
+        uint4 *p = reinterpret_cast<uint4 *>(a.part[k]) + r * a.wb16 + j;
+        uint4 *w = reinterpret_cast<uint4 *>(a.wide) + u;
+        if (SPLIT) *p = *w;
+        else *w = *p;
+    }
+}
+
+int channel_blocks(const char *who, bool split, int64_t rows, int n, int block_bytes, void *wide, void *const *parts_host, void *stream) {
+    if (!wide || !parts_host) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: NULL argument", who);
+    if (rows < 0 || n < 1 || n > 32 || block_bytes < 16 || block_bytes % 16)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: rows >= 0, 1 <= n <= 32 blocks of a multiple of 16 bytes (rows=%lld n=%d block_bytes=%d)", who,
+                         (long long)rows, n, block_bytes);
+    if (rows == 0) return MMT_OK;
+    ChanBlocksArgs a;
+    if ((uintptr_t)wide & 15) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the wide tensor is not 16-byte aligned", who);
+    for (int k = 0; k < n; ++k) {
+        if (!parts_host[k]) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: part %d is NULL", who, k);
+        if ((uintptr_t)parts_host[k] & 15) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: part %d is not 16-byte aligned", who, k);
+        a.part[k] = parts_host[k];
+    }
+    a.wide = wide; a.n = n; a.wb16 = block_bytes / 16; a.units = rows * n * a.wb16;
+    const dim3 grid(mmt::stream_grid(a.units, 256, 256 * 16));
+    if (split) hipLaunchKernelGGL(channel_blocks_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(channel_blocks_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return mmt::check_launch(who);
+}
+
+}  // namespace
+
+extern "C" int mmt_channel_blocks_split(int64_t rows, int n, int block_bytes, const void *wide, void *const *parts_host, void *stream) {
+    return channel_blocks("channel_blocks_split", true, rows, n, block_bytes, const_cast<void *>(wide), parts_host, stream);
+}
+
+extern "C" int mmt_channel_blocks_gather(int64_t rows, int n, int block_bytes, const void *const *parts_host, void *wide, void *stream) {
+    return channel_blocks("channel_blocks_gather", false, rows, n, block_bytes, wide, const_cast<void *const *>(parts_host), stream);
+}

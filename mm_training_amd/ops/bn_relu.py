@@ -30,7 +30,7 @@ def _supported(bn, x):
     return (ENABLED and bn.training and x.is_cuda and x.dim() == 4
             and (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and torch.is_autocast_enabled()))
             and bn.track_running_stats and bn.momentum is not None and bn.affine
-            and c % 4 == 0 and (c <= 1024 or c == 2048)
+            and c % 4 == 0 and (c <= 1024 or (c % 256 == 0 and c <= 2048))
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -107,12 +107,12 @@ _SCRATCH = {}
 _NEED = {}
 
 
-def _workspace(bn, device):
+def _workspace(bn, device, width=None):
     """Scratch for the per-workgroup partial sums, one per (device, STREAM): consumed inside each call on the calling
     stream, so one buffer sized for the widest layer serves every BatchNorm the stream runs -- and layers that run on
     different streams at the same time (the task heads, layers/heads/bev_depth_head.py) never share one.  The backward
     of a layer runs on its forward's stream (autograd) and receives the same buffer."""
-    width = max(2048, bn.num_features)
+    width = max(2048, width or bn.num_features)
     need = _NEED.get(width)
     if need is None:
         need = _NEED[width] = _lib.lib().mmt_bn_workspace_elems(width)

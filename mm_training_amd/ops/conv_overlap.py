@@ -125,12 +125,28 @@ def _end_of_backward():
 _uses = {}
 
 
-def _deferral_is_safe(leaf, gw):
+def _deferral_is_safe(leaf, gw, leaves=None):
     """Deferred mode hands AccumulateGrad a gradient that is still being written on the side stream.  That is only sound while
     the engine does nothing with it but keep the reference: first gradient of the pass for this weight (no in-place add), no other
     application of the weight in the graph (no input-buffer sum), the layout AccumulateGrad would keep (else it clones on the
     consumer's stream: gradient layout contract) and no tensor hook on the weight (hooks run on the gradient, on that stream)."""
-    if leaf.grad is not None or gw is None:
+    if gw is None:
+        return False
+    if leaves is not None:
+        # `leaf` is torch.cat(leaves, 0): CatBackward hands every leaf a narrow() view of gw -- no kernel -- and AccumulateGrad keeps
+        # that view under the same conditions as below, per leaf (a dim-0 slice of gw has gw's strides)
+        if tuple(gw.shape) != tuple(leaf.shape) or gw.dtype != leaf.dtype or gw.stride() != leaf.stride():
+            return False
+        u = _uses.get(id(leaf))
+        if u is not None and u[1]:
+            return False
+        for p in leaves:
+            if not p.is_leaf or p.grad is not None or getattr(p, "_backward_hooks", None) or p.dtype != gw.dtype:
+                return False
+            if not all(sg == sl for n, sg, sl in zip(p.shape, gw.stride(), p.stride()) if n != 1):
+                return False
+        return True
+    if not leaf.is_leaf or leaf.grad is not None:
         return False
     u = _uses.get(id(leaf))
     if u is not None and u[1]:
@@ -172,7 +188,7 @@ class _ConvOverlap(Function):
     the weight gradient comes back in the parameter's own dtype from the side stream, with no main-stream cast node behind it)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, groups, dtype, mode):
+    def forward(ctx, x, w, b, stride, padding, dilation, groups, dtype, mode, leaves=None):
         out_dtype = None
         narrow = x.shape[1] < NARROW and w.shape[0] < NARROW
         if narrow and dtype in (torch.bfloat16, torch.float16):
@@ -186,6 +202,7 @@ class _ConvOverlap(Function):
             u[0] += 1
             u[1] = u[1] or u[0] > 1
         ctx.conf = (stride, padding, dilation, groups, b is not None, x.dtype, b.dtype if b is not None else None, mode, narrow)
+        ctx.leaves = leaves          # `w` is torch.cat(leaves, 0) of parameters (conv2d below), None for a parameter itself
         if narrow:
             with torch.backends.cudnn.flags(enabled=False):    # NARROW: ATen's own im2col + GEMM convolution, not MIOpen
                 y = _aten_convolution(xc, wc, bc, stride, padding, dilation, False, [0] * len(stride), groups)
@@ -215,7 +232,7 @@ class _ConvOverlap(Function):
                 gw = gw.to(leaf.dtype)
             if gb is not None and gb.dtype != b_dtype:
                 gb = gb.to(b_dtype)
-            return gx, gw, gb, None, None, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None, None, None
         main = _current_stream(gy.device)
         side = side_stream(gy.device)                    # (created on first use: an inline rank never owns one)
         if need_w or has_b:
@@ -243,7 +260,7 @@ class _ConvOverlap(Function):
             #    gradient -- launched from another stream, e.g. a task head's -- takes the block again on the side stream.
             #    (Deferred: the first consumer comes after the end-of-backward join, and the block is next taken on the side
             #    stream in the following backward pass, behind everything this stream has queued by then.)
-            deferred = mode == "deferred" and _deferral_is_safe(leaf, gw)
+            deferred = mode == "deferred" and _deferral_is_safe(leaf, gw, ctx.leaves)
             for t in ((gy, x) if w is leaf else (gy, x, w)):
                 t.record_stream(side)
             if not deferred:
@@ -263,7 +280,20 @@ class _ConvOverlap(Function):
                 gx = gx.to(x_dtype)
         if (need_w or has_b) and not deferred:
             main.wait_stream(side)
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, mode="deferred", leaves=None):
+    """F.conv2d through the two-stream backward for a weight that is not a module's parameter.  `leaves`: the parameters `weight` is
+    the torch.cat(.., 0) of (the task heads' 24 first convolutions run as one, layers/heads/bev_depth_head.py) -- their gradients are
+    views of the one weight gradient and the deferral rules apply to each of them."""
+    amp = torch.is_autocast_enabled()
+    dtype = torch.get_autocast_dtype("cuda") if amp else None
+    args = (x, weight, bias, list(stride), list(padding), list(dilation), groups, dtype, mode, leaves)
+    if amp and x.shape[1] < NARROW and weight.shape[0] < NARROW:
+        with torch.autocast("cuda", enabled=False):
+            return _lib.apply_function(_ConvOverlap, *args)
+    return _lib.apply_function(_ConvOverlap, *args)
 
 
 class OverlapConv2d(torch.nn.Conv2d):
