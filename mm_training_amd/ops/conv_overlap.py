@@ -43,6 +43,7 @@ _aten_convolution_backward = torch.ops.aten.convolution_backward.default
 
 NARROW = 16
 _events = {}
+_REUSE_FORK_EVENT = os.environ.get("MMT_REUSE_FORK_EVENT", "1") != "0"
 
 
 _stream_objects = {}
@@ -239,9 +240,12 @@ class _ConvOverlap(Function):
             # grad_out (and, in the first layer of a backward, the saved tensors) are ready: side.wait_stream(main), with ONE event
             # per device recorded again and again (a wait takes the record that is current when it is issued) instead of an event
             # created and destroyed per layer; the stream switch likewise without the context-manager object
-            ev = _fork_event(gy.device)
-            ev.record(main)
-            side.wait_event(ev)
+            if _REUSE_FORK_EVENT:
+                ev = _fork_event(gy.device)
+                ev.record(main)
+                side.wait_event(ev)
+            else:
+                side.wait_stream(main)
             torch.cuda.set_stream(side)
             try:
                 _, gw, gb = _aten_convolution_backward(gy, x, w, [w.shape[0]] if has_b else None, stride, padding, dilation,
