@@ -188,7 +188,11 @@ class BEVDepthHead(nn.Module):
         # HIP streams the task heads are dealt to in training (see _forward_tasks_on_streams); 0 / 1 = the caller's stream only
         self.task_streams = int(os.environ.get("MMT_HEAD_STREAMS", "2"))
         # the branches' first ConvModules as one wide convolution + one BatchNorm in training (_forward_tasks_fused); 0: per branch
-        self.fuse_branch_stems = os.environ.get("MMT_HEAD_FUSED", "1") != "0"
+        # "auto" (default): when the branches would otherwise share ONE stream (task_streams <= 1: every rank at N > 1), or on maps of
+        # at most 64 K pixels -- at bs 8 on two streams the per-branch kernels overlap well enough that the two copies around the final
+        # convolutions cost more than the wide layer saves (BASELINE configs[2]: 47.5-47.7 ms per branch, 48.0-48.1 fused);
+        # True / False (MMT_HEAD_FUSED=1 / 0): always / never
+        self.fuse_branch_stems = {"0": False, "1": True}.get(os.environ.get("MMT_HEAD_FUSED", "auto"), "auto")
         self.task_heads = nn.ModuleList()
         for n in self.num_classes:
             heads = dict(common_heads)
@@ -200,7 +204,10 @@ class BEVDepthHead(nn.Module):
     def forward(self, x):
         fpn_output = self.neck(self.trunk(x))
         x = self.shared_conv(fpn_output[0])
-        if self.fuse_branch_stems and x.is_cuda and torch.is_grad_enabled() and self.training:
+        fuse = self.fuse_branch_stems
+        if fuse == "auto":
+            fuse = self.task_streams <= 1 or x.shape[0] * x.shape[2] * x.shape[3] <= 65536
+        if fuse and x.is_cuda and torch.is_grad_enabled() and self.training:
             stems = self._branch_stems(x)
             if stems is not None:
                 return self._forward_tasks_fused(x, stems)
