@@ -37,7 +37,7 @@ extern "C" {
                              * 11: region-owner voxelizer -- mmt_voxelize_table_elems / _scratch_elems / _workspace_elems take the point
                              *     count / max_points as well; the table needs no zero fill and holds a cell directory
                              * 12: mmt_clip_adamw_step takes bf16_shadow_ptrs (may be NULL); mmt_channel_blocks_split / _gather;
-                             *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048) */
+                             *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048); mmt_bn_relu_inference */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -730,6 +730,13 @@ int mmt_bn_relu_forward_ex(int64_t R, int C, const void *x, const void *residual
 int mmt_bn_relu_backward_ex(int64_t R, int C, const void *x, const void *y, const void *grad_y,
                             const float *save, int relu, int has_residual, float *workspace, void *grad_x,
                             void *grad_residual, float *grad_weight, float *grad_bias, int act_dtype, void *stream);
+/* ABI 12: eval-mode BatchNorm (+ residual) (+ ReLU) in one pass: y = relu?(x * w / sqrt(running_var + eps) + (b - running_mean * ..)
+ * [+ residual]); nothing is reduced, nothing updated.  The reference's image backbone is built with frozen_stages=0
+ * (exps/conf_aim.py:57: mmdet ResNet keeps conv1 + norm1 without gradients and norm1 in eval mode while training).
+ * workspace: fp32 [2 * C] scratch. */
+int mmt_bn_relu_inference(int64_t R, int C, const void *x, const void *residual, const float *weight, const float *bias,
+                          const float *running_mean, const float *running_var, float eps, int relu, float *workspace,
+                          void *y, int act_dtype, void *stream);
 /* ABI 11: the same with a SECOND and a THIRD gradient of y (nullable; the third only with the second), added to grad_y on load.
  * The output of a residual block is read twice -- by the next block's first convolution and as its identity (or through its
  * downsample convolution), a stage's output a third time by the neck -- and autograd would add the gradients in passes of its own

@@ -431,6 +431,47 @@ extern "C" int mmt_bn_relu_forward_ex(int64_t R, int C, const void *x, const voi
     return rc;
 }
 
+namespace {
+// eval mode: y = x * scale + shift from the RUNNING statistics (nothing to reduce, nothing updated)
+__global__ __launch_bounds__(256) void bn_eval_coefficients(BnArgs a) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    const float rstd = 1.f / sqrtf(a.running_var[c] + a.eps);
+    const float w = a.weight ? a.weight[c] : 1.f, b = a.bias ? a.bias[c] : 0.f;
+    a.scale[c] = w * rstd;
+    a.shift[c] = b - a.running_mean[c] * (w * rstd);
+}
+}  // namespace
+
+extern "C" int mmt_bn_relu_inference(int64_t R, int C, const void *x, const void *residual, const float *weight, const float *bias,
+                                     const float *running_mean, const float *running_var, float eps, int relu, float *workspace,
+                                     void *y, int act_dtype, void *stream) {
+    MMT_REQUIRE_PTR(x);
+    MMT_REQUIRE_PTR(running_mean);
+    MMT_REQUIRE_PTR(running_var);
+    MMT_REQUIRE_PTR(workspace);
+    MMT_REQUIRE_PTR(y);
+    if (act_dtype != MMT_DTYPE_F32 && act_dtype != MMT_DTYPE_BF16)
+        return mmt::fail(MMT_ERR_BAD_FLAG, "bn_relu_inference: unknown activation dtype %d", act_dtype);
+    BnArgs a = {};
+    if (int rc = geometry("bn_relu_inference", R, C, &a.g)) return rc;
+    const uintptr_t act_mask = act_dtype == MMT_DTYPE_F32 ? 15 : 7;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & act_mask) || ((uintptr_t)workspace & 15))
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "bn_relu_inference: buffers must be 16-byte aligned (bf16 activations: 8)");
+    a.R = R; a.C = C; a.relu = relu; a.has_res = residual != nullptr; a.eps = eps;
+    a.x = x; a.res = residual; a.weight = weight; a.bias = bias;
+    a.running_mean = const_cast<float *>(running_mean); a.running_var = const_cast<float *>(running_var);
+    a.scale = workspace; a.shift = workspace + C; a.y = y;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_eval_coefficients, dim3((int)mmt::ceil_div(C, 256)), dim3(256), 0, st, a);
+    if (int rc = mmt::check_launch("bn_relu_inference(coefficients)")) return rc;
+    if (act_dtype == MMT_DTYPE_F32)
+        hipLaunchKernelGGL((bn_map_kernel<0, float, 1>), dim3(mmt::stream_grid(mmt::ceil_div(R * a.g.C4, InFlight<float>::value), kBlock)), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL((bn_map_kernel<0, bf16_t, 1>), dim3(mmt::stream_grid(mmt::ceil_div(R * a.g.C4, InFlight<bf16_t>::value), kBlock)), dim3(kBlock), 0, st, a);
+    return mmt::check_launch("bn_relu_inference(apply)");
+}
+
 extern "C" int mmt_bn_relu_forward(int64_t R, int C, const float *x, const float *residual, const float *weight,
                                    const float *bias, float *running_mean, float *running_var, float momentum,
                                    float eps, int relu, float *workspace, float *save, float *y, void *stream) {

@@ -46,8 +46,9 @@ def make_config(name="cfg2"):
         z_bound=[pc_range[2], pc_range[5], voxel_size[2]],
         d_bound=[2.0, 58.0, 4.0 if tiny else 0.5], final_dim=final_dim, output_channels=cam_channels,
         downsample_factor=16,
+        # exps/conf_aim.py:54-61: frozen_stages=0 -- the stem (conv1 + norm1) has no gradients and its BatchNorm runs in eval mode
         img_backbone_conf=dict(type='ResNet', depth=18 if tiny else 50, base_channels=16 if tiny else 64,
-                               out_indices=[0, 1, 2, 3]),
+                               frozen_stages=0, out_indices=[0, 1, 2, 3], norm_eval=False),
         img_neck_conf=dict(type='SECONDFPN',
                            in_channels=[16, 32, 64, 128] if tiny else [256, 512, 1024, 2048],
                            upsample_strides=[0.25, 0.5, 1, 2], out_channels=[16] * 4 if tiny else [128] * 4),

@@ -104,7 +104,8 @@ def _batched_bn_counters(model):
     for m in model.modules():
         if type(m) is nn.BatchNorm2d and m.track_running_stats and m.momentum is not None:
             m.forward = types.MethodType(bn_forward, m)
-            counters.append(m.num_batches_tracked)
+            if m.training:                                   # (a frozen layer -- the image backbone's norm1 -- counts nothing)
+                counters.append(m.num_batches_tracked)
     return counters
 
 

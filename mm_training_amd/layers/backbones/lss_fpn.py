@@ -190,7 +190,7 @@ class LSSFPN(nn.Module):
         self._voxel_size_host = [float(v) for v in self.voxel_size]
         self._voxel_coord_host = [float(v) for v in self.voxel_coord]
 
-        bb = {k: v for k, v in dict(img_backbone_conf).items() if k not in ('type', 'init_cfg', 'frozen_stages', 'norm_eval')}
+        bb = {k: v for k, v in dict(img_backbone_conf).items() if k not in ('type', 'init_cfg')}      # (no checkpoints here: random init)
         self.img_backbone = ResNet(**bb)
         nk = {k: v for k, v in dict(img_neck_conf).items() if k != 'type'}
         self.img_neck = SECONDFPN(**nk)

@@ -63,10 +63,15 @@ class ResNet(nn.Module):
     ARCH = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3))}
 
     def __init__(self, depth=50, in_channels=3, base_channels=64, num_stages=4, strides=(1, 2, 2, 2),
-                 dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), **unused):
+                 dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False, **unused):
         super().__init__()
         block, blocks = self.ARCH[depth]
         self.out_indices = tuple(out_indices)
+        # mmdet ResNet (the reference's image backbone is built with frozen_stages=0, norm_eval=False: exps/conf_aim.py:57-59):
+        # frozen_stages >= 0 freezes the stem (conv1 + norm1: no gradients, norm1 in eval mode), >= i also stage i; norm_eval keeps
+        # every BatchNorm in eval mode while training.  `train()` re-applies both, as mmdet's does.
+        self.frozen_stages = int(frozen_stages)
+        self.norm_eval = bool(norm_eval)
         self.conv1 = nn.Conv2d(in_channels, base_channels, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(base_channels)
         self.relu = nn.ReLU(inplace=True)
@@ -89,6 +94,7 @@ class ResNet(nn.Module):
                 inplanes = planes * block.expansion
             self.stages.append(nn.Sequential(*layers))
         self.init_weights()
+        self._freeze_stages()
 
     def init_weights(self):
         for m in self.modules():
@@ -97,6 +103,27 @@ class ResNet(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            if i <= len(self.stages):
+                self.stages[i - 1].eval()
+                for p in self.stages[i - 1].parameters():
+                    p.requires_grad = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
 
     def forward(self, x):
         x = self.maxpool(bn_act(self.bn1, self.conv1(x)))

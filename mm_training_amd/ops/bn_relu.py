@@ -34,6 +34,17 @@ def _supported(bn, x):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
+def _frozen_inference(bn, x, residual):
+    c = x.shape[1] if x.dim() == 4 else 0
+    return (ENABLED and not bn.training and x.is_cuda and x.dim() == 4 and bn.affine and bn.track_running_stats
+            and not x.requires_grad and not bn.weight.requires_grad and not bn.bias.requires_grad
+            and (residual is None or (not residual.requires_grad and residual.dtype == x.dtype
+                                      and residual.is_contiguous(memory_format=torch.channels_last)))
+            and (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and torch.is_autocast_enabled()))
+            and c % 4 == 0 and (c <= 1024 or (c % 256 == 0 and c <= 2048))
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
 class _BnAct(Function):
     """x, residual, y and their gradients share one dtype (fp32 or bf16); parameters, statistics and arithmetic are fp32."""
 
@@ -142,6 +153,18 @@ def bn_act(bn, x, residual=None, relu=True, fork=False):
         # (nothing inside the Function is an autocast-wrapped operator: no `autocast(enabled=False)` region around it)
         return _lib.apply_function(_BnAct, x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                    _workspace(bn, x.device), bn.momentum, bn.eps, relu, (2 if fork is True else int(fork)) if (fork and FORK) else 0)
+    if _frozen_inference(bn, x, residual):
+        # eval-mode BatchNorm of a FROZEN layer on an input that carries no gradient (the image backbone's stem under the
+        # reference's frozen_stages=0): one pass, no autograd node
+        act = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        y = torch.empty_like(x)
+        C = x.shape[1]
+        with _lib.on_device(x.device):
+            _lib.call("mmt_bn_relu_inference", x.shape[0] * x.shape[2] * x.shape[3], C, x.data_ptr(),
+                      residual.data_ptr() if residual is not None else 0, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps), int(relu),
+                      _workspace(bn, x.device).data_ptr(), y.data_ptr(), act, _lib.raw_stream(x.device))
+        return (y,) * (2 if fork is True else int(fork)) if fork else y
     out = bn(x)
     if residual is not None:
         out = out + residual
