@@ -303,12 +303,14 @@ def test_lssfpn_camera_form_is_the_default_and_runs_no_geometry_kernel(mmt_lib, 
     assert calls_p.index("mmt_lss_plan_prepare") == 0 and "mmt_frustum_geometry" not in calls_p     # the lookup goes first, in front of the nets
     m.plan_form = False
     bev_c, g_c, calls_c = run(True, mats)
-    assert (bev_p - bev_c).abs().max().item() <= 1e-5 * max(1.0, bev_c.abs().max().item())
+    # (two passes through the MIOpen backbone in front of the pooling: its split-K forward kernels leave the last bits open, and with the
+    # stem frozen -- eval-mode norm1 on a randomly initialised conv1 -- the activations behind it are larger than batch-normalised ones)
+    assert (bev_p - bev_c).abs().max().item() <= 5e-5 * max(1.0, bev_c.abs().max().item())
     assert (g_p - g_c).abs().max().item() <= 1e-3 * g_c.abs().max().item() + 1e-7
     bev_g, g_g, calls_g = run(False, mats)
     assert "mmt_lss_splat_forward_cam" in calls_c and "mmt_lss_splat_backward_cam" in calls_c
     assert "mmt_frustum_geometry" not in calls_c and "mmt_frustum_geometry" in calls_g
-    assert (bev_c - bev_g).abs().max().item() <= 1e-5 * max(1.0, bev_g.abs().max().item())
+    assert (bev_c - bev_g).abs().max().item() <= 5e-5 * max(1.0, bev_g.abs().max().item())
     assert (g_c - g_g).abs().max().item() <= 1e-3 * g_g.abs().max().item() + 1e-7     # (two passes through MIOpen's split-K nets: against the tensor's own size)
     # calibration id: the matrices are computed once
     cached = dict(mats, calibration_id="rig-a")
@@ -318,7 +320,7 @@ def test_lssfpn_camera_form_is_the_default_and_runs_no_geometry_kernel(mmt_lib, 
     bev2, _, calls2 = run(True, cached)
     assert next(iter(m._combine_cache.values())) is first and "mmt_frustum_geometry" not in calls2
     assert len(m._summary_cache) == 1                                      # and so is the geometry's column summary
-    assert torch.allclose(bev2, bev_c, rtol=0, atol=1e-5 * max(1.0, bev_c.abs().max().item()))
+    assert torch.allclose(bev2, bev_c, rtol=0, atol=5e-5 * max(1.0, bev_c.abs().max().item()))
 
 
 def test_lssfpn_follows_the_column_kernel_counters_without_a_calibration_id(mmt_lib):
