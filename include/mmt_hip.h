@@ -37,7 +37,8 @@ extern "C" {
                              * 11: region-owner voxelizer -- mmt_voxelize_table_elems / _scratch_elems / _workspace_elems take the point
                              *     count / max_points as well; the table needs no zero fill and holds a cell directory
                              * 12: mmt_clip_adamw_step takes bf16_shadow_ptrs (may be NULL); mmt_channel_blocks_split / _gather;
-                             *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048); mmt_bn_relu_inference */
+                             *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048); mmt_bn_relu_inference;
+                             *     mmt_heads_final_forward / _backward */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -780,6 +781,21 @@ int mmt_add_n(int n, const void *const *inputs_host, int64_t numel, float *out, 
  * puts the 24 gradients that come back side by side again. */
 int mmt_channel_blocks_split(int64_t rows, int n, int block_bytes, const void *wide, void *const *parts_host, void *stream);
 int mmt_channel_blocks_gather(int64_t rows, int n, int block_bytes, const void *const *parts_host, void *wide, void *stream);
+
+/* The task heads' FINAL convolutions in one launch per direction (ABI 12; csrc/thin_conv.hip).  The reference's SeparateHead ends every
+ * branch with Conv2d(64, classes, 3, padding=1, bias=True), classes = 1..3 (layers/heads/bev_depth_head.py; mmdet3d CenterHead): NB
+ * branches (<= 32), branch j reading channels [64 j, 64 j + 64) of ONE channels-last map z [B, H, W, NB * 64] and writing k_host[j]
+ * (1..4) channels of ONE channels-last map out [B, H, W, KT], KT = sum of k_host, its channels at the running sum of k_host.
+ *   weight fp32 [KT][9][64] (= the memory of a channels-last [KT, 64, 3, 3] tensor: the branches' weights one after the other), bias
+ *   fp32 [KT] or NULL; z / out / grad_out / grad_z: act_dtype (fp32 or bf16; fp32 arithmetic)
+ *   backward: grad_z (nullable) [B, H, W, NB * 64]; grad_weight [KT][9][64] + grad_bias [KT] + workspace (nullable together;
+ *   workspace: mmt_heads_final_workspace_elems(B, H, NB) floats) -- per-workgroup partial sums added in a fixed order, no atomics */
+int64_t mmt_heads_final_workspace_elems(int B, int H, int NB);
+int mmt_heads_final_forward(int B, int H, int W, int NB, const unsigned char *k_host, const void *z, const float *weight,
+                            const float *bias, void *out, int act_dtype, void *stream);
+int mmt_heads_final_backward(int B, int H, int W, int NB, const unsigned char *k_host, const void *z, const float *weight,
+                             const void *grad_out, void *grad_z, float *grad_weight, float *grad_bias, float *workspace,
+                             int act_dtype, void *stream);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,63 @@ class _SplitBlocks(torch.autograd.Function):
         return out, None
 
 
+class _FinalConvs(torch.autograd.Function):
+    """The branches' final 3x3 convolutions (64 -> 1..4 channels each, bias) on the wide map [B, n * 64, H, W], one launch per
+    direction (`mmt_heads_final_forward / _backward`, csrc/thin_conv.hip).  weight [KT, 64, 3, 3] channels-last = the branches' weights
+    one after the other, bias [KT]; returns the n outputs as channel slices of ONE narrow map [B, KT, H, W]."""
+
+    @staticmethod
+    def forward(ctx, wide, weight, bias, ks):
+        import ctypes
+        from ... import _lib
+        B, C, H, W = wide.shape
+        n, kt = len(ks), sum(ks)
+        out = torch.empty((B, kt, H, W), dtype=wide.dtype, device=wide.device, memory_format=torch.channels_last)
+        karr = (ctypes.c_ubyte * n)(*ks)
+        act = _lib.DTYPE_BF16 if wide.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        with _lib.on_device(wide.device):
+            _lib.call("mmt_heads_final_forward", B, H, W, n, karr, wide.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                      act, _lib.raw_stream(wide.device))
+        ctx.save_for_backward(wide, weight)
+        ctx.ks = tuple(ks)
+        ctx.set_materialize_grads(False)
+        offs = [sum(ks[:j]) for j in range(n)]
+        return tuple(out[:, o:o + k] for o, k in zip(offs, ks))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        from ... import _lib
+        wide, weight = ctx.saved_tensors
+        ks = ctx.ks
+        B, C, H, W = wide.shape
+        n, kt = len(ks), sum(ks)
+        if all(g is None for g in grads):
+            return None, None, None, None
+        gout = torch.empty((B, kt, H, W), dtype=wide.dtype, device=wide.device, memory_format=torch.channels_last)
+        if any(g is None for g in grads):
+            gout.zero_()
+        o = 0
+        for g, k in zip(grads, ks):
+            if g is not None:
+                gout[:, o:o + k].copy_(g)
+            o += k
+        need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gz = torch.empty_like(wide) if need_z else None
+        gw = gb = ws = None
+        if need_w:
+            gw = torch.empty_like(weight)                                  # channels-last [KT, 64, 3, 3] = [KT][9][64]
+            gb = torch.empty(kt, dtype=torch.float32, device=wide.device)
+            ws = torch.empty(_lib.lib().mmt_heads_final_workspace_elems(B, H, n), dtype=torch.float32, device=wide.device)
+        karr = (ctypes.c_ubyte * n)(*ks)
+        act = _lib.DTYPE_BF16 if wide.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        with _lib.on_device(wide.device):
+            _lib.call("mmt_heads_final_backward", B, H, W, n, karr, wide.data_ptr(), weight.data_ptr(), gout.data_ptr(),
+                      gz.data_ptr() if need_z else 0, gw.data_ptr() if need_w else 0, gb.data_ptr() if need_w else 0,
+                      ws.data_ptr() if need_w else 0, act, _lib.raw_stream(wide.device))
+        return gz, gw, gb, None
+
+
 class SeparateHead(nn.Module):
     def __init__(self, in_channels, heads, head_conv=64, final_kernel=3, init_bias=-2.19):
         super().__init__()
@@ -193,6 +250,8 @@ class BEVDepthHead(nn.Module):
         # convolutions cost more than the wide layer saves (BASELINE configs[2]: 47.5-47.7 ms per branch, 48.0-48.1 fused);
         # True / False (MMT_HEAD_FUSED=1 / 0): always / never
         self.fuse_branch_stems = {"0": False, "1": True}.get(os.environ.get("MMT_HEAD_FUSED", "auto"), "auto")
+        # with the fused first layer: the branches' final convolutions as one hand-written kernel per direction (csrc/thin_conv.hip)
+        self.fuse_final_convs = os.environ.get("MMT_HEAD_FINALS", "1") != "0"
         self.task_heads = nn.ModuleList()
         for n in self.num_classes:
             heads = dict(common_heads)
@@ -289,6 +348,19 @@ class BEVDepthHead(nn.Module):
             y = y.contiguous(memory_format=torch.channels_last)
         z = _lib.apply_function(bn_relu._BnAct, y, None, gamma, beta, mean, var, bn_relu._workspace(bns[0], y.device, width=y.shape[1]),
                                 bns[0].momentum, bns[0].eps, True, 0)
+        if self.fuse_final_convs and self._finals_fit(finals, z):
+            # the 24 final convolutions (64 -> 1..3 channels) in one launch per direction, straight on the wide map: no split, no
+            # 24 gradients to put side by side again (_FinalConvs)
+            weight = torch.cat([f.weight for f in finals], 0)
+            if not weight.is_contiguous(memory_format=torch.channels_last):
+                weight = weight.contiguous(memory_format=torch.channels_last)
+            bias = torch.cat([f.bias for f in finals])
+            parts = _FinalConvs.apply(z, weight.float(), bias.float(), tuple(f.out_channels for f in finals))
+            outs, k = [], 0
+            for task in self.task_heads:
+                outs.append([{name: parts[k + i] for i, name in enumerate(task.heads)}])
+                k += len(task.heads)
+            return tuple(outs)
         parts = _SplitBlocks.apply(z, n)
         outs, k = [], 0
         for task in self.task_heads:
@@ -298,6 +370,14 @@ class BEVDepthHead(nn.Module):
                 k += 1
             outs.append([out])
         return tuple(outs)
+
+    @staticmethod
+    def _finals_fit(finals, z):
+        c = z.shape[1] // len(finals)
+        return (c == 64 and len(finals) <= 32 and z.is_contiguous(memory_format=torch.channels_last)
+                and all(f.kernel_size == (3, 3) and f.stride == (1, 1) and f.padding == (1, 1) and f.dilation == (1, 1) and f.groups == 1
+                        and f.in_channels == 64 and 1 <= f.out_channels <= 4 and f.bias is not None and f.padding_mode == "zeros"
+                        and f.weight.dtype == torch.float32 for f in finals))
 
     def _forward_tasks_on_streams(self, x, nstreams):
         """The task heads (24 independent conv-bn-relu-conv branches on one 4 x 64 x 128 x 128 map, ~55 us per kernel) dealt to

@@ -109,3 +109,45 @@ def test_fused_branch_stems_equal_the_per_branch_modules(mmt_lib):
     fused.eval()
     with torch.no_grad():
         assert len(fused(full)) == 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_final_convolutions_in_one_launch(mmt_lib, dtype):
+    """_FinalConvs (mmt_heads_final_forward / _backward) against F.conv2d per branch: outputs, the gradient of the wide map, every
+    branch's weight and bias gradient; widths that are not a multiple of the 32-pixel segment, one to four output channels."""
+    import torch.nn.functional as F
+    from mm_training_amd.layers.heads.bev_depth_head import _FinalConvs
+    torch.manual_seed(0)
+    for (B, H, W, ks) in ((2, 9, 37, (2, 1, 3, 2, 2, 1)), (1, 4, 5, (4,)), (2, 16, 64, (1, 2, 3, 4) * 6), (1, 3, 130, (3, 1) * 16)):
+        n, kt = len(ks), sum(ks)
+        wide = (torch.randn(B, n * 64, H, W, device="cuda") * 0.5).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ws = [torch.randn(k, 64, 3, 3, device="cuda").mul_(0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True) for k in ks]
+        bs = [torch.randn(k, device="cuda").requires_grad_(True) for k in ks]
+        gos = [torch.randn(B, k, H, W, device="cuda").to(dtype).float() for k in ks]          # (representable in the activation type)
+        # reference: fp32 convolutions per branch on the (rounded) inputs
+        ref_in = wide.detach().float().requires_grad_(True)
+        refs = [F.conv2d(ref_in[:, j * 64:(j + 1) * 64], w, b, padding=1) for j, (w, b) in enumerate(zip(ws, bs))]
+        torch.autograd.backward(refs, gos)
+        ref_gw, ref_gb = [w.grad.clone() for w in ws], [b.grad.clone() for b in bs]
+        for t in ws + bs:
+            t.grad = None
+        weight = torch.cat(ws, 0).contiguous(memory_format=torch.channels_last)
+        assert weight.stride() == (576, 1, 192, 64)
+        outs = _FinalConvs.apply(wide, weight, torch.cat(bs), tuple(ks))
+        assert len(outs) == n and all(o.shape == r.shape and o.dtype == dtype for o, r in zip(outs, refs))
+        fwd_tol = 2e-5 if dtype is torch.float32 else 2e-2
+        for j, (o, r) in enumerate(zip(outs, refs)):
+            assert float((o.detach().float() - r.detach()).abs().max()) <= fwd_tol * max(1.0, float(r.detach().abs().max())), (ks, j)
+        torch.autograd.backward(outs, [g.to(dtype) for g in gos])
+        bwd_tol = 1e-4 if dtype is torch.float32 else 3e-2
+        assert float((wide.grad.float() - ref_in.grad).abs().max()) <= bwd_tol * max(1.0, float(ref_in.grad.abs().max()))
+        for j in range(n):
+            assert ws[j].grad.shape == ws[j].shape and ws[j].grad.stride() == ws[j].stride()
+            assert float((ws[j].grad - ref_gw[j]).abs().max()) <= bwd_tol * max(1.0, float(ref_gw[j].abs().max())), (ks, j)
+            assert float((bs[j].grad - ref_gb[j]).abs().max()) <= bwd_tol * max(1.0, float(ref_gb[j].abs().max())), (ks, j)
+        # a branch that was not used hands back no gradient: zeros for it, the others unchanged
+        wide.grad = None
+        outs = _FinalConvs.apply(wide, weight.detach(), torch.cat(bs).detach(), tuple(ks))
+        outs[0].float().mul(gos[0]).sum().backward()
+        only0 = torch.autograd.grad(F.conv2d(ref_in[:, :64], ws[0].detach(), bs[0].detach(), padding=1).mul(gos[0]).sum(), ref_in)[0]
+        assert float((wide.grad.float() - only0).abs().max()) <= bwd_tol * max(1.0, float(only0.abs().max()))
