@@ -60,24 +60,90 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// the lane's channel at pixel (yy, xx) of image b, zero outside the image (clamped address, unconditional load)
+// The three input rows of an output row: base pointers and validity are the same for the whole wave (SGPRs); a lane's load is then
+// `row + (xc * C + chan)` with a 32-bit offset -- the 64-bit address arithmetic per load was what bound the first version (VALU).
 template <typename AT>
-__device__ __forceinline__ float tap(const ThinArgs &a, int b, int yy, int xx, int chan) {
-    const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-    const int yc = yy < 0 ? 0 : (yy >= a.H ? a.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= a.W ? a.W - 1 : xx);
-    const float v = ldact<AT>(a.z, ((int64_t)(b * a.H + yc) * a.W + xc) * ((int64_t)a.NB * 64) + chan);
-    return in ? v : 0.f;
-}
-
-__device__ __forceinline__ void load_weights(const ThinArgs &a, int j, int lane, float (&wr)[kThinMaxK][9]) {
-    const int kj = a.k[j], off = a.off[j];
+struct Rows {
+    const AT *p[3];
+    bool ok[3];
+    int C, W;
+    __device__ __forceinline__ Rows(const ThinArgs &a, int b, int y) {
+        C = a.NB * 64; W = a.W;
 #pragma unroll
-    for (int k = 0; k < kThinMaxK; ++k)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wr[k][t] = k < kj ? a.w[((off + k) * 9 + t) * 64 + lane] : 0.f;
-}
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            ok[r] = yy >= 0 && yy < a.H;
+            const int yc = yy < 0 ? 0 : (yy >= a.H ? a.H - 1 : yy);
+            p[r] = static_cast<const AT *>(a.z) + (int64_t)(b * a.H + yc) * a.W * C;
+        }
+    }
+    // the lane's channel at column xx of row r, zero outside the image (clamped address, unconditional load)
+    __device__ __forceinline__ float at(int r, int xx, int chan) const {
+        const bool in = ok[r] && xx >= 0 && xx < W;
+        const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        float v;
+        if constexpr (sizeof(AT) == 4) v = p[r][xc * C + chan];
+        else v = __uint_as_float((unsigned)p[r][xc * C + chan] << 16);
+        return in ? v : 0.f;
+    }
+};
 
 constexpr int kThinTrip = 4;        // pixels per trip of a wave: their 3 x 4 new window entries are requested together
+
+// The bodies are compiled per number of output channels K of the branch (1..4; the kernel switches once per wave): the inner sums
+// then hold exactly 9 K fused multiply-adds per pixel.  (With a run-time K the compiler computed all four channels and masked:
+// 144 multiplies + 144 adds + 144 selects per trip of 4 pixels where 9 K x 4 fused operations do.)
+template <int K>
+__device__ __forceinline__ void load_weights(const ThinArgs &a, int off, int lane, float (&wr)[K][9]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[k][t] = a.w[((off + k) * 9 + t) * 64 + lane];
+}
+
+template <typename AT, int K>
+__device__ __forceinline__ void fwd_body(const ThinArgs &a, int b, int y, int x0, int x1, int off, int chan, int lane) {
+    float wr[K][9], bk[K];
+    load_weights<K>(a, off, lane, wr);
+#pragma unroll
+    for (int k = 0; k < K; ++k) bk[k] = a.bias ? a.bias[off + k] : 0.f;      // (in registers: a load per output in the loop was a round trip each)
+    const Rows<AT> rows(a, b, y);
+    float win[3][kThinTrip + 2], nxt[3][kThinTrip];                            // nxt: the next trip's new columns, requested one trip ahead
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        win[r][kThinTrip] = rows.at(r, x0 - 1, chan);
+        win[r][kThinTrip + 1] = rows.at(r, x0, chan);
+#pragma unroll
+        for (int p = 0; p < kThinTrip; ++p) nxt[r][p] = rows.at(r, x0 + 1 + p, chan);
+    }
+    for (int x = x0; x < x1; x += kThinTrip) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            win[r][0] = win[r][kThinTrip];
+            win[r][1] = win[r][kThinTrip + 1];
+#pragma unroll
+            for (int p = 0; p < kThinTrip; ++p) {
+                win[r][2 + p] = nxt[r][p];
+                nxt[r][p] = rows.at(r, x + kThinTrip + 1 + p, chan);          // (clamped inside: a trip past the segment reads valid memory)
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < kThinTrip; ++p) {
+            if (x + p >= x1) break;                                            // (uniform)
+            const int64_t o = ((int64_t)(b * a.H + y) * a.W + x + p) * a.KT + off;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) s = fmaf(win[r][p + c], wr[k][r * 3 + c], s);
+                s = wave_sum(s);
+                if (lane == 0) stact<AT>(a.out, o + k, s + bk[k]);
+            }
+        }
+    }
+}
 
 // grid: (B * H * segments, ceil(NB / 4)); wave = one branch
 template <typename AT>
@@ -89,45 +155,66 @@ __global__ __launch_bounds__(256) void thin_conv_fwd(ThinArgs a) {
     const int xs = t % segs; t /= segs;
     const int y = t % a.H, b = t / a.H;
     const int kj = a.k[j], off = a.off[j], chan = j * 64 + lane;
-    float wr[kThinMaxK][9];
-    load_weights(a, j, lane, wr);
     const int x0 = xs * kThinSeg, x1 = min(x0 + kThinSeg, a.W);
-    float win[3][kThinTrip + 2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        win[r][kThinTrip] = tap<AT>(a, b, y + r - 1, x0 - 1, chan);
-        win[r][kThinTrip + 1] = tap<AT>(a, b, y + r - 1, x0, chan);
+    switch (kj) {
+        case 1: fwd_body<AT, 1>(a, b, y, x0, x1, off, chan, lane); break;
+        case 2: fwd_body<AT, 2>(a, b, y, x0, x1, off, chan, lane); break;
+        case 3: fwd_body<AT, 3>(a, b, y, x0, x1, off, chan, lane); break;
+        default: fwd_body<AT, 4>(a, b, y, x0, x1, off, chan, lane); break;
     }
-    for (int x = x0; x < x1; x += kThinTrip) {
+}
+
+// gz[p, chan] = sum over the 9 output pixels that read p, and the branch's K output channels.  The gradients of a trip's 4 pixels
+// (3 rows x 6 columns x K values, the same for every lane) come in by TWO lane-parallel loads -- lane l fetches position l / 4 (and
+// 16 + l / 4), channel l % 4 -- and reach the arithmetic through SGPRs (v_readlane); requested one trip ahead.
+template <typename AT, int K>
+__device__ __forceinline__ void bwd_data_body(const ThinArgs &a, int b, int y, int x0, int x1, int off, int chan, int lane) {
+    float wr[K][9];
+    load_weights<K>(a, off, lane, wr);
+    auto fetch = [&](int x, float &va, float &vb) {
+        const int k = lane & 3;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            win[r][0] = win[r][kThinTrip];
-            win[r][1] = win[r][kThinTrip + 1];
-#pragma unroll
-            for (int p = 0; p < kThinTrip; ++p) win[r][2 + p] = tap<AT>(a, b, y + r - 1, x + 1 + p, chan);
+        for (int half = 0; half < 2; ++half) {
+            const int pos = half * 16 + (lane >> 2);
+            const int r = pos / (kThinTrip + 2), ci = pos - r * (kThinTrip + 2);
+            const int yy = y - 1 + r, xx = x - 1 + ci;
+            const bool in = pos < 3 * (kThinTrip + 2) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && k < K;
+            const int yc = min(max(yy, 0), a.H - 1), xc = min(max(xx, 0), a.W - 1);
+            const float v = ldact<AT>(a.gout, ((int64_t)(b * a.H + yc) * a.W + xc) * a.KT + off + (k < K ? k : 0));
+            (half ? vb : va) = in ? v : 0.f;
         }
+    };
+    float na, nb;
+    fetch(x0, na, nb);
+    for (int x = x0; x < x1; x += kThinTrip) {
+        const float va = na, vb = nb;
+        fetch(x + kThinTrip, na, nb);                          // (clamped: always valid memory)
+        float gw[3][kThinTrip + 2][K];                          // gout[y - 1 + r][x - 1 + ci][off + k]
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int ci = 0; ci < kThinTrip + 2; ++ci)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int pos = r * (kThinTrip + 2) + ci;
+                    gw[r][ci][k] = __int_as_float(pos < 16 ? __builtin_amdgcn_readlane(__float_as_int(va), pos * 4 + k)
+                                                           : __builtin_amdgcn_readlane(__float_as_int(vb), (pos - 16) * 4 + k));
+                }
 #pragma unroll
         for (int p = 0; p < kThinTrip; ++p) {
-            if (x + p >= x1) break;                          // (uniform)
-            const int64_t o = ((int64_t)(b * a.H + y) * a.W + x + p) * a.KT + off;
+            if (x + p >= x1) break;
+            float g = 0.f;
 #pragma unroll
-            for (int k = 0; k < kThinMaxK; ++k) {
-                if (k < kj) {                                 // (uniform over the wave)
-                    float s = 0.f;
+            for (int ty = 0; ty < 3; ++ty)                      // out[yy, xx] read in[yy + ty - 1, xx + tx - 1]
 #pragma unroll
-                    for (int r = 0; r < 3; ++r)
+                for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) s += win[r][p + c] * wr[k][r * 3 + c];
-                    s = wave_sum(s);
-                    if (lane == 0) stact<AT>(a.out, o + k, s + (a.bias ? a.bias[off + k] : 0.f));
-                }
-            }
+                    for (int k = 0; k < K; ++k) g = fmaf(gw[2 - ty][p + 2 - tx][k], wr[k][ty * 3 + tx], g);
+            stact<AT>(a.gz, ((int64_t)(b * a.H + y) * a.W + x + p) * ((int64_t)a.NB * 64) + chan, g);
         }
     }
 }
 
-// same grid; gz[p, chan] = sum over the 9 output pixels that read p, and the branch's k output channels.  The gradients of a trip's
-// 4 pixels (3 rows x 6 columns x k values, the same for every lane: uniform addresses) are requested together.
 template <typename AT>
 __global__ __launch_bounds__(256) void thin_conv_bwd_data(ThinArgs a) {
     const int lane = threadIdx.x & 63, j = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -137,37 +224,58 @@ __global__ __launch_bounds__(256) void thin_conv_bwd_data(ThinArgs a) {
     const int xs = t % segs; t /= segs;
     const int y = t % a.H, b = t / a.H;
     const int kj = a.k[j], off = a.off[j], chan = j * 64 + lane;
-    float wr[kThinMaxK][9];
-    load_weights(a, j, lane, wr);
     const int x0 = xs * kThinSeg, x1 = min(x0 + kThinSeg, a.W);
-    for (int x = x0; x < x1; x += kThinTrip) {
-        float gw[3][kThinTrip + 2][kThinMaxK];               // gout[y - 1 + r][x - 1 + ci][off + k]
+    switch (kj) {
+        case 1: bwd_data_body<AT, 1>(a, b, y, x0, x1, off, chan, lane); break;
+        case 2: bwd_data_body<AT, 2>(a, b, y, x0, x1, off, chan, lane); break;
+        case 3: bwd_data_body<AT, 3>(a, b, y, x0, x1, off, chan, lane); break;
+        default: bwd_data_body<AT, 4>(a, b, y, x0, x1, off, chan, lane); break;
+    }
+}
+
+// one image row of one branch: acc[k][tap] += gout[p, off + k] * z[p + tap, chan] over the row's pixels (+ the bias sums)
+template <typename AT, int K>
+__device__ __forceinline__ void wgrad_row(const ThinArgs &a, int q, int off, int chan, int lane, float (&acc)[kThinMaxK][9], float (&bacc)[kThinMaxK]) {
+    const int b = q / a.H, y = q % a.H;
+    const Rows<AT> rows(a, b, y);
+    auto fetch_g = [&](int x) {
+        const int p = (lane >> 2) & (kThinTrip - 1), k = lane & 3;            // (lanes 0..15 matter)
+        const bool in = x + p < a.W && k < K;
+        const float v = ldact<AT>(a.gout, ((int64_t)q * a.W + (x + p < a.W ? x + p : a.W - 1)) * a.KT + off + (k < K ? k : 0));
+        return in ? v : 0.f;
+    };
+    float win[3][kThinTrip + 2], nxt[3][kThinTrip], ng = fetch_g(0);            // one trip ahead
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r) {
+        win[r][kThinTrip] = rows.at(r, -1, chan);
+        win[r][kThinTrip + 1] = rows.at(r, 0, chan);
 #pragma unroll
-            for (int ci = 0; ci < kThinTrip + 2; ++ci) {
-                const int yy = y - 1 + r, xx = x - 1 + ci;
-                const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                const int yc = min(max(yy, 0), a.H - 1), xc = min(max(xx, 0), a.W - 1);
-                const int64_t o = ((int64_t)(b * a.H + yc) * a.W + xc) * a.KT + off;
+        for (int p = 0; p < kThinTrip; ++p) nxt[r][p] = rows.at(r, 1 + p, chan);
+    }
+    for (int x = 0; x < a.W; x += kThinTrip) {
 #pragma unroll
-                for (int k = 0; k < kThinMaxK; ++k) {            // (unconditional loads from a clamped address, then the select)
-                    const float v = ldact<AT>(a.gout, o + (k < kj ? k : 0));
-                    gw[r][ci][k] = (in && k < kj) ? v : 0.f;
-                }
+        for (int r = 0; r < 3; ++r) {
+            win[r][0] = win[r][kThinTrip];
+            win[r][1] = win[r][kThinTrip + 1];
+#pragma unroll
+            for (int p = 0; p < kThinTrip; ++p) {
+                win[r][2 + p] = nxt[r][p];
+                nxt[r][p] = rows.at(r, x + kThinTrip + 1 + p, chan);
             }
-#pragma unroll
-        for (int p = 0; p < kThinTrip; ++p) {
-            if (x + p >= x1) break;
-            float g = 0.f;
-#pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                    for (int k = 0; k < kThinMaxK; ++k) g += gw[2 - ty][p + 2 - tx][k] * wr[k][ty * 3 + tx];
-            stact<AT>(a.gz, ((int64_t)(b * a.H + y) * a.W + x + p) * ((int64_t)a.NB * 64) + chan, g);
         }
+        const float vv = ng;
+        ng = fetch_g(x + kThinTrip);
+#pragma unroll
+        for (int p = 0; p < kThinTrip; ++p)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), p * 4 + k));
+                bacc[k] += g;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[k][r * 3 + c] = fmaf(g, win[r][p + c], acc[k][r * 3 + c]);
+            }
     }
 }
 
@@ -186,42 +294,11 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad(ThinArgs a) {
     }
     const int rows = a.B * a.H;
     for (int q = blockIdx.x * kThinRowsPerBlock + wave; q < min((int)(blockIdx.x + 1) * kThinRowsPerBlock, rows); q += 4) {
-        const int b = q / a.H, y = q % a.H;
-        float win[3][kThinTrip + 2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            win[r][kThinTrip] = tap<AT>(a, b, y + r - 1, -1, chan);
-            win[r][kThinTrip + 1] = tap<AT>(a, b, y + r - 1, 0, chan);
-        }
-        for (int x = 0; x < a.W; x += kThinTrip) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                win[r][0] = win[r][kThinTrip];
-                win[r][1] = win[r][kThinTrip + 1];
-#pragma unroll
-                for (int p = 0; p < kThinTrip; ++p) win[r][2 + p] = tap<AT>(a, b, y + r - 1, x + 1 + p, chan);
-            }
-            float g[kThinTrip][kThinMaxK];
-#pragma unroll
-            for (int p = 0; p < kThinTrip; ++p) {
-                const bool in = x + p < a.W;
-                const int64_t o = ((int64_t)q * a.W + (in ? x + p : a.W - 1)) * a.KT + off;
-#pragma unroll
-                for (int k = 0; k < kThinMaxK; ++k) {
-                    const float v = ldact<AT>(a.gout, o + (k < kj ? k : 0));
-                    g[p][k] = (in && k < kj) ? v : 0.f;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < kThinTrip; ++p)
-#pragma unroll
-                for (int k = 0; k < kThinMaxK; ++k) {
-                    bacc[k] += g[p][k];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) acc[k][r * 3 + c] += g[p][k] * win[r][p + c];
-                }
+        switch (kj) {
+            case 1: wgrad_row<AT, 1>(a, q, off, chan, lane, acc, bacc); break;
+            case 2: wgrad_row<AT, 2>(a, q, off, chan, lane, acc, bacc); break;
+            case 3: wgrad_row<AT, 3>(a, q, off, chan, lane, acc, bacc); break;
+            default: wgrad_row<AT, 4>(a, q, off, chan, lane, acc, bacc); break;
         }
     }
 #pragma unroll

@@ -245,10 +245,7 @@ class BEVDepthHead(nn.Module):
         # HIP streams the task heads are dealt to in training (see _forward_tasks_on_streams); 0 / 1 = the caller's stream only
         self.task_streams = int(os.environ.get("MMT_HEAD_STREAMS", "2"))
         # the branches' first ConvModules as one wide convolution + one BatchNorm in training (_forward_tasks_fused); 0: per branch
-        # "auto" (default): when the branches would otherwise share ONE stream (task_streams <= 1: every rank at N > 1), or on maps of
-        # at most 64 K pixels -- at bs 8 on two streams the per-branch kernels overlap well enough that the two copies around the final
-        # convolutions cost more than the wide layer saves (BASELINE configs[2]: 47.5-47.7 ms per branch, 48.0-48.1 fused);
-        # True / False (MMT_HEAD_FUSED=1 / 0): always / never
+        # "auto" (default): see forward(); True / False (MMT_HEAD_FUSED=1 / 0): always / never
         self.fuse_branch_stems = {"0": False, "1": True}.get(os.environ.get("MMT_HEAD_FUSED", "auto"), "auto")
         # with the fused first layer: the branches' final convolutions as one hand-written kernel per direction (csrc/thin_conv.hip)
         self.fuse_final_convs = os.environ.get("MMT_HEAD_FINALS", "1") != "0"
@@ -265,7 +262,9 @@ class BEVDepthHead(nn.Module):
         x = self.shared_conv(fpn_output[0])
         fuse = self.fuse_branch_stems
         if fuse == "auto":
-            fuse = self.task_streams <= 1 or x.shape[0] * x.shape[2] * x.shape[3] <= 65536
+            # with the final convolutions in the hand-written kernels (no copies around them): always (configs[2], bs 8: 47.3 ms per
+            # branch, 44.5 fused); without them: when the branches would share one stream, or on maps of at most 64 K pixels
+            fuse = self.fuse_final_convs or self.task_streams <= 1 or x.shape[0] * x.shape[2] * x.shape[3] <= 65536
         if fuse and x.is_cuda and torch.is_grad_enabled() and self.training:
             stems = self._branch_stems(x)
             if stems is not None:
