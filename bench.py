@@ -761,6 +761,11 @@ def train_main(args, rank, local_rank, world):
                    "augment_images": bool(ts.augment and cfg["use_cam"]), "depth_oracle": bool(ts.pass_depth_labels and cfg["use_cam"]),
                    "conv_weight_gradients": {None: "same stream (autograd)", "inline": "same stream"}.get(ts.conv_overlap, ts.conv_overlap),
                    "task_head_streams": int(ts.model.head.task_streams),
+                   # the 24 CenterPoint branches: first ConvModules as one wide layer, final convolutions in csrc/thin_conv.hip
+                   # ("auto": when applicable -- training on the GPU; MMT_HEAD_FUSED / MMT_HEAD_FINALS switch them off)
+                   "task_heads_fused": {"first_layer": ts.model.head.fuse_branch_stems, "final_convolutions": bool(ts.model.head.fuse_final_convs)},
+                   # exps/conf_aim.py:57: the image backbone's stem has no gradients, its BatchNorm runs in eval mode
+                   "image_backbone_frozen_stages": (int(ts.model.backbone.img_backbone.frozen_stages) if cfg["use_cam"] else None),
                    "distributed": dinfo},
     }
     fb = 2 if dtype == "bf16" else 4
