@@ -258,3 +258,40 @@ def test_deferred_mode_only_where_the_engine_does_nothing_with_the_gradient(mmt_
     assert not conv_overlap._deferral_is_safe(w, torch.empty(8, 4, 3, 3, device="cuda"))
     w1 = torch.nn.Parameter(torch.randn(8, 4, 1, 1, device="cuda"))                       # 1 x 1: every layout has the same strides where it matters
     assert conv_overlap._deferral_is_safe(w1, torch.empty(8, 4, 1, 1, device="cuda").contiguous(memory_format=torch.channels_last))
+
+
+def test_convolution_with_a_weight_that_is_the_cat_of_parameters(mmt_lib):
+    """conv_overlap.conv2d(x, torch.cat(ws), leaves=ws) -- the task heads' first layer (layers/heads/bev_depth_head.py): every parameter
+    receives a dim-0 view of the ONE weight gradient (its own layout), equal to the per-layer convolutions' gradients; the deferral
+    applies per parameter (none while one of them holds a gradient already, i.e. gradient accumulation), whatever the mode."""
+    import torch.nn.functional as F
+    from mm_training_amd.ops import conv_overlap
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(16, 32, 3, 3, device="cuda").mul_(0.1).contiguous(memory_format=torch.channels_last)) for _ in range(5)]
+    x = torch.randn(2, 32, 24, 40, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 80, 24, 40, device="cuda").contiguous(memory_format=torch.channels_last)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, torch.cat([w.detach() for w in ws], 0).requires_grad_(False), padding=1)          # (warm MIOpen)
+    ref = [F.conv2d(xr, w, padding=1) for w in ws]
+    torch.autograd.backward(ref, [gy[:, 16 * j:16 * j + 16] for j in range(5)])
+    ref_gw, ref_gx = [w.grad.clone() for w in ws], xr.grad.clone()
+    for mode in ("deferred", "pair", "inline"):
+        for accumulate in (False, True):
+            for w in ws:
+                w.grad = None
+            if accumulate:
+                ws[2].grad = torch.ones_like(ws[2])                                             # one leaf holds a gradient already
+            xi = x.clone().requires_grad_(True)
+            weight = torch.cat(list(ws), 0)
+            # the rule itself: safe only while every leaf would keep the view it is handed
+            assert conv_overlap._deferral_is_safe(weight, torch.empty_like(weight), list(ws)) == (not accumulate)
+            assert not conv_overlap._deferral_is_safe(weight, torch.empty(80, 32, 3, 3, device="cuda"), list(ws))   # (another layout)
+            y = conv_overlap.conv2d(xi, weight, None, (1, 1), (1, 1), (1, 1), 1, mode, leaves=list(ws))
+            y.backward(gy)
+            torch.cuda.synchronize()
+            assert float((xi.grad - ref_gx).abs().max()) <= 1e-4 * float(ref_gx.abs().max()), (mode, accumulate)
+            for j, w in enumerate(ws):
+                want = ref_gw[j] + (1.0 if (accumulate and j == 2) else 0.0)
+                assert w.grad.shape == w.shape and w.grad.stride() == w.stride(), (mode, j)
+                assert float((w.grad - want).abs().max()) <= 1e-4 * float(want.abs().max()), (mode, accumulate, j)
+    assert not conv_overlap._uses
