@@ -38,7 +38,7 @@ extern "C" {
                              *     count / max_points as well; the table needs no zero fill and holds a cell directory
                              * 12: mmt_clip_adamw_step takes bf16_shadow_ptrs (may be NULL); mmt_channel_blocks_split / _gather;
                              *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048); mmt_bn_relu_inference;
-                             *     mmt_heads_final_forward / _backward */
+                             *     mmt_heads_final_forward / _backward; mmt_head_loss_forward_backward */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -790,6 +790,20 @@ int mmt_channel_blocks_gather(int64_t rows, int n, int block_bytes, const void *
  *   fp32 [KT] or NULL; z / out / grad_out / grad_z: act_dtype (fp32 or bf16; fp32 arithmetic)
  *   backward: grad_z (nullable) [B, H, W, NB * 64]; grad_weight [KT][9][64] + grad_bias [KT] + workspace (nullable together;
  *   workspace: mmt_heads_final_workspace_elems(B, H, NB) floats) -- per-workgroup partial sums added in a fixed order, no atomics */
+/* The CenterPoint head's loss and its gradient on the fused heads' one output map, two launches (ABI 12; csrc/head_loss.hip; the
+ * reference: layers/heads/bev_depth_head.py:256-312 = mmdet GaussianFocalLoss(alpha 2, gamma 4) on clip_sigmoid(heatmap, 1e-4) +
+ * L1 on the boxes gathered at `inds`, weighted by mask * !isnan(target) * code_weights * loss_bbox.loss_weight, each divided by the
+ * task's normaliser).  map [B, H, W, 11 T] (act_dtype): per task reg 0-1, height 2, dim 3-5, rot 6-7, vel 8-9, heatmap 10.
+ *   heatmaps_host / anno_host / inds_host / masks_host: HOST arrays of T device pointers (fp32 [B, H, W] / fp32 [B, M, 10] /
+ *   int64 [B, M] / uint8 [B, M]); normalisers fp32 [2 T] on the device (positives per task, masked slots per task, before the clamps
+ *   to >= 1 and >= 1e-4); code_weights fp32 [10]
+ *   grad_map fp32 [B, H, W, 11 T]: d loss / d map, written whole; partials fp32 [mmt_head_loss_partials(..)]: the loss = their sum */
+int mmt_head_loss_partials(int B, int H, int W, int T, int M);
+int mmt_head_loss_forward_backward(int B, int H, int W, int T, int M, const void *map, const void *const *heatmaps_host,
+                                   const void *const *anno_host, const void *const *inds_host, const void *const *masks_host,
+                                   const float *normalisers, const float *code_weights, float box_weight, float *grad_map,
+                                   float *partials, int act_dtype, void *stream);
+
 int64_t mmt_heads_final_workspace_elems(int B, int H, int NB);
 int mmt_heads_final_forward(int B, int H, int W, int NB, const unsigned char *k_host, const void *z, const float *weight,
                             const float *bias, void *out, int act_dtype, void *stream);

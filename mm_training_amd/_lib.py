@@ -78,6 +78,8 @@ SIGNATURES = {
     "mmt_bn_relu_forward_ex": (_c_int, [_c_i64, _c_int] + [_c_ptr] * 6 + [ctypes.c_float, ctypes.c_float, _c_int] + [_c_ptr] * 3 + [_c_int, _c_ptr]),
     "mmt_bn_relu_backward_ex": (_c_int, [_c_i64, _c_int] + [_c_ptr] * 4 + [_c_int, _c_int] + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_add_n": (_c_int, [_c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr]),
+    "mmt_head_loss_partials": (_c_int, [_c_int] * 5),
+    "mmt_head_loss_forward_backward": (_c_int, [_c_int] * 5 + [_c_ptr] * 7 + [ctypes.c_float, _c_ptr, _c_ptr, _c_int, _c_ptr]),
     "mmt_heads_final_workspace_elems": (_c_i64, [_c_int, _c_int, _c_int]),
     "mmt_heads_final_forward": (_c_int, [_c_int] * 4 + [_c_ptr] * 5 + [_c_int, _c_ptr]),
     "mmt_heads_final_backward": (_c_int, [_c_int] * 4 + [_c_ptr] * 8 + [_c_int, _c_ptr]),

@@ -160,7 +160,8 @@ class _FinalConvs(torch.autograd.Function):
         ctx.ks = tuple(ks)
         ctx.set_materialize_grads(False)
         offs = [sum(ks[:j]) for j in range(n)]
-        return tuple(out[:, o:o + k] for o, k in zip(offs, ks))
+        # the branches' outputs, and the whole narrow map once more (what the fused loss reads, _HeadLoss)
+        return tuple(out[:, o:o + k] for o, k in zip(offs, ks)) + (out,)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -172,14 +173,26 @@ class _FinalConvs(torch.autograd.Function):
         n, kt = len(ks), sum(ks)
         if all(g is None for g in grads):
             return None, None, None, None
-        gout = torch.empty((B, kt, H, W), dtype=wide.dtype, device=wide.device, memory_format=torch.channels_last)
-        if any(g is None for g in grads):
-            gout.zero_()
-        o = 0
-        for g, k in zip(grads, ks):
-            if g is not None:
-                gout[:, o:o + k].copy_(g)
-            o += k
+        whole, grads = grads[-1], grads[:-1]
+        if whole is not None and all(g is None for g in grads):
+            # the gradient of the whole map (the fused loss): used as it comes
+            gout = whole if whole.dtype == wide.dtype else whole.to(wide.dtype)
+            if not gout.is_contiguous(memory_format=torch.channels_last):
+                gout = gout.contiguous(memory_format=torch.channels_last)
+        else:
+            gout = torch.empty((B, kt, H, W), dtype=wide.dtype, device=wide.device, memory_format=torch.channels_last)
+            if whole is not None:
+                gout.copy_(whole)
+            elif any(g is None for g in grads):
+                gout.zero_()
+            o = 0
+            for g, k in zip(grads, ks):
+                if g is not None:
+                    if whole is not None:
+                        gout[:, o:o + k].add_(g)
+                    else:
+                        gout[:, o:o + k].copy_(g)
+                o += k
         need_z, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         gz = torch.empty_like(wide) if need_z else None
         gw = gb = ws = None
@@ -194,6 +207,42 @@ class _FinalConvs(torch.autograd.Function):
                       gz.data_ptr() if need_z else 0, gw.data_ptr() if need_w else 0, gb.data_ptr() if need_w else 0,
                       ws.data_ptr() if need_w else 0, act, _lib.raw_stream(wide.device))
         return gz, gw, gb, None
+
+
+class _Preds(dict):
+    """A task's prediction dict (reg, height, dim, rot, vel, heatmap -- the reference's keys) that also remembers the ONE map the
+    six tensors are channel slices of, and the task's first channel in it (for the fused loss; invisible to dict consumers)."""
+    __slots__ = ("fused_map", "first_channel")
+
+
+class _HeadLoss(torch.autograd.Function):
+    """The head's loss on the fused heads' one output map and its gradient in two launches (`mmt_head_loss_forward_backward`)."""
+
+    @staticmethod
+    def forward(ctx, fmap, heatmaps, annos, inds, masks, norm, code_weights, box_weight):
+        import ctypes
+        from ... import _lib
+        B, KT, H, W = fmap.shape
+        T, M = len(heatmaps), annos[0].shape[1]
+        grad = torch.empty((B, H, W, KT), dtype=torch.float32, device=fmap.device)
+        partials = torch.empty(_lib.lib().mmt_head_loss_partials(B, H, W, T, M), dtype=torch.float32, device=fmap.device)
+        arr = lambda ts: (ctypes.c_void_p * T)(*[t.data_ptr() for t in ts])
+        act = _lib.DTYPE_BF16 if fmap.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        keep = (heatmaps, annos, inds, masks)                   # (contiguous copies, if any, live until the launch is queued)
+        with _lib.on_device(fmap.device):
+            _lib.call("mmt_head_loss_forward_backward", B, H, W, T, M, fmap.data_ptr(), arr(heatmaps), arr(annos), arr(inds), arr(masks),
+                      norm.data_ptr(), code_weights.data_ptr(), float(box_weight), grad.data_ptr(), partials.data_ptr(), act,
+                      _lib.raw_stream(fmap.device))
+        del keep
+        ctx.save_for_backward(grad)
+        ctx.dims = (B, KT, H, W)
+        return partials.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        B, KT, H, W = ctx.dims
+        return (grad * g).view(B, H, W, KT).permute(0, 3, 1, 2), None, None, None, None, None, None, None
 
 
 class SeparateHead(nn.Module):
@@ -249,6 +298,8 @@ class BEVDepthHead(nn.Module):
         self.fuse_branch_stems = {"0": False, "1": True}.get(os.environ.get("MMT_HEAD_FUSED", "auto"), "auto")
         # with the fused first layer: the branches' final convolutions as one hand-written kernel per direction (csrc/thin_conv.hip)
         self.fuse_final_convs = os.environ.get("MMT_HEAD_FINALS", "1") != "0"
+        # with both: the loss and its gradient on the heads' one output map in two launches (csrc/head_loss.hip)
+        self.fuse_loss = os.environ.get("MMT_HEAD_LOSS", "1") != "0"
         self.task_heads = nn.ModuleList()
         for n in self.num_classes:
             heads = dict(common_heads)
@@ -354,10 +405,13 @@ class BEVDepthHead(nn.Module):
             if not weight.is_contiguous(memory_format=torch.channels_last):
                 weight = weight.contiguous(memory_format=torch.channels_last)
             bias = torch.cat([f.bias for f in finals])
-            parts = _FinalConvs.apply(z, weight.float(), bias.float(), tuple(f.out_channels for f in finals))
+            ks = tuple(f.out_channels for f in finals)
+            parts = _FinalConvs.apply(z, weight.float(), bias.float(), ks)
             outs, k = [], 0
             for task in self.task_heads:
-                outs.append([{name: parts[k + i] for i, name in enumerate(task.heads)}])
+                preds = _Preds((name, parts[k + i]) for i, name in enumerate(task.heads))
+                preds.fused_map, preds.first_channel = parts[-1], sum(ks[:k])
+                outs.append([preds])
                 k += len(task.heads)
             return tuple(outs)
         parts = _SplitBlocks.apply(z, n)
@@ -509,6 +563,32 @@ class BEVDepthHead(nn.Module):
         heatmaps, _, _, masks = targets
         return torch.stack([h.eq(1).float().sum() for h in heatmaps] + [m.float().sum() for m in masks])
 
+    def _fused_loss_map(self, preds_dicts, heatmaps, anno_boxes, inds, masks):
+        """The one map all predictions are slices of, when the fused loss applies: the fused heads' outputs (_Preds) in the standard
+        layout (per task reg 2, height 1, dim 3, rot 2, vel 2, heatmap 1 = 11 channels, tasks one after the other), single-class
+        tasks, at most 8 of them, targets of the matching shapes on the map's device."""
+        if not self.fuse_loss:
+            return None
+        fmap = None
+        for t, preds in enumerate(preds_dicts):
+            p = preds[0]
+            m = getattr(p, "fused_map", None)
+            if m is None or (fmap is not None and m is not fmap) or p.first_channel != 11 * t:
+                return None
+            if [(k, v.shape[1]) for k, v in p.items()] != [("reg", 2), ("height", 1), ("dim", 3), ("rot", 2), ("vel", 2), ("heatmap", 1)]:
+                return None
+            fmap = m
+        T = len(preds_dicts)
+        if fmap is None or not fmap.is_cuda or T > 8 or fmap.shape[1] != 11 * T or not fmap.is_contiguous(memory_format=torch.channels_last):
+            return None
+        B, _, H, W = fmap.shape
+        for t in range(T):
+            if (tuple(heatmaps[t].shape) != (B, 1, H, W) or anno_boxes[t].dim() != 3 or anno_boxes[t].shape[0] != B or anno_boxes[t].shape[2] != 10
+                    or tuple(inds[t].shape) != tuple(anno_boxes[t].shape[:2]) or tuple(masks[t].shape) != tuple(inds[t].shape)
+                    or anno_boxes[t].shape[1] != anno_boxes[0].shape[1] or heatmaps[t].device != fmap.device):
+                return None
+        return fmap
+
     def loss(self, targets, preds_dicts, normalisers=None, **kwargs):
         """`normalisers` (optional): use these instead of the (cross-rank mean of the) batch's own -- a single process
         that accumulates the gradients of N micro-batches reproduces N data-parallel ranks by passing the mean of the
@@ -523,6 +603,14 @@ class BEVDepthHead(nn.Module):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 dist.all_reduce(norm)
                 norm = norm / dist.get_world_size()
+        fmap = self._fused_loss_map(preds_dicts, heatmaps, anno_boxes, inds, masks)
+        if fmap is not None:
+            # every prediction is a channel slice of ONE map (the fused heads): loss + gradient in two launches (csrc/head_loss.hip)
+            # instead of ~150 small ATen kernels on 64 K-element tensors, forward and backward
+            cont = lambda ts: [t if t.is_contiguous() else t.contiguous() for t in ts]
+            return _HeadLoss.apply(fmap, cont([h.float() for h in heatmaps]), cont([a.float() for a in anno_boxes]),
+                                   cont([i.long() for i in inds]), cont([m.to(torch.uint8) for m in masks]), norm.float().contiguous(),
+                                   self.code_weights, self.loss_bbox_weight)
         cls_norm = norm[:n_task].clamp(min=1)
         box_norm = norm[n_task:].clamp(min=1e-4)
         code_weights = self.code_weights

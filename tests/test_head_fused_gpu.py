@@ -134,6 +134,8 @@ def test_final_convolutions_in_one_launch(mmt_lib, dtype):
         weight = torch.cat(ws, 0).contiguous(memory_format=torch.channels_last)
         assert weight.stride() == (576, 1, 192, 64)
         outs = _FinalConvs.apply(wide, weight, torch.cat(bs), tuple(ks))
+        whole, outs = outs[-1], outs[:-1]                      # (the branches' outputs, and the whole narrow map they are slices of)
+        assert whole.shape == (B, kt, H, W) and all(o.data_ptr() == whole[:, sum(ks[:j]):].data_ptr() for j, o in enumerate(outs))
         assert len(outs) == n and all(o.shape == r.shape and o.dtype == dtype for o, r in zip(outs, refs))
         fwd_tol = 2e-5 if dtype is torch.float32 else 2e-2
         for j, (o, r) in enumerate(zip(outs, refs)):
@@ -147,7 +149,52 @@ def test_final_convolutions_in_one_launch(mmt_lib, dtype):
             assert float((bs[j].grad - ref_gb[j]).abs().max()) <= bwd_tol * max(1.0, float(ref_gb[j].abs().max())), (ks, j)
         # a branch that was not used hands back no gradient: zeros for it, the others unchanged
         wide.grad = None
-        outs = _FinalConvs.apply(wide, weight.detach(), torch.cat(bs).detach(), tuple(ks))
+        outs = _FinalConvs.apply(wide, weight.detach(), torch.cat(bs).detach(), tuple(ks))[:-1]
         outs[0].float().mul(gos[0]).sum().backward()
         only0 = torch.autograd.grad(F.conv2d(ref_in[:, :64], ws[0].detach(), bs[0].detach(), padding=1).mul(gos[0]).sum(), ref_in)[0]
         assert float((wide.grad.float() - only0).abs().max()) <= bwd_tol * max(1.0, float(only0.abs().max()))
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_fused_head_loss_equals_the_torch_loss(mmt_lib, amp):
+    """BEVDepthHead.loss on the fused heads' one output map (mmt_head_loss_forward_backward) against the same method's torch ops on
+    the same predictions: the value, and the gradients of the shared map and of every parameter; with NaN targets, two boxes on one
+    pixel, an empty task, and under autocast (bf16 map)."""
+    import copy
+    from mm_training_amd.dp import make_config
+    cfg = make_config("tiny")
+    head = _head(cfg)
+    head.fuse_branch_stems = True
+    torch.manual_seed(1)
+    B = 2
+    boxes, labels = [], []
+    for b in range(B):
+        k = 12
+        xy = torch.rand(k, 2) * 80 - 40
+        bx = torch.cat([xy, torch.rand(k, 1) * 2 - 2, torch.rand(k, 3) * 3 + 0.5, torch.rand(k, 1) * 6 - 3, torch.randn(k, 2)], 1)
+        bx[1, :2] = bx[0, :2]                                            # two boxes of one class on one pixel
+        lab = torch.randint(0, 3, (k,))                                   # (class 3 = the fourth task stays empty)
+        lab[1] = lab[0]
+        boxes.append(bx.cuda()); labels.append(lab.cuda())
+    targets = head.get_targets(boxes, labels)
+    targets[1][0][0, 0, 7:9] = float("nan")                               # NaN velocity targets carry no weight (bev_depth_head.py:296)
+    x = torch.randn(B, 64, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+    results = []
+    for fused in (True, False):
+        h = copy.deepcopy(head)
+        h.fuse_loss = fused
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            preds = h._forward_tasks_fused(xi, h._branch_stems(xi))
+            assert (h._fused_loss_map(preds, *targets) is not None) == fused
+        loss = h.loss(targets, preds)
+        loss.backward()
+        results.append((float(loss), xi.grad.clone(), {n: p.grad.clone() for n, p in h.named_parameters() if p.grad is not None}))
+    (la, ga, pa), (lb, gb, pb) = results
+    tol = 2e-2 if amp else 1e-4
+    assert abs(la - lb) <= (2e-3 if amp else 1e-5) * abs(lb), (la, lb)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-12))
+    assert rel(ga, gb) <= tol, rel(ga, gb)
+    assert set(pa) == set(pb) and len(pa) == 24 * 5
+    worst = max(rel(pa[n], pb[n]) for n in pa)
+    assert worst <= (5e-2 if amp else 2e-3), worst
