@@ -33,12 +33,14 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 12  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
+#define MMT_ABI_VERSION 13  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
                              * 11: region-owner voxelizer -- mmt_voxelize_table_elems / _scratch_elems / _workspace_elems take the point
                              *     count / max_points as well; the table needs no zero fill and holds a cell directory
                              * 12: mmt_clip_adamw_step takes bf16_shadow_ptrs (may be NULL); mmt_channel_blocks_split / _gather;
                              *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048); mmt_bn_relu_inference;
-                             *     mmt_heads_final_forward / _backward; mmt_head_loss_forward_backward */
+                             *     mmt_heads_final_forward / _backward; mmt_head_loss_forward_backward
+                             * 13: mmt_dcn_forward / mmt_dcn_backward (+ _supported / _workspace_bytes): the deformable convolution as implicit
+                             *     GEMMs on the fp32 matrix cores, no column buffer; additive */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -273,6 +275,27 @@ int64_t mmt_dcn_col2im_workspace_elems(int B, int H, int W);
 int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x, const float *offset,
                           const float *grad_col, float *grad_x, float *grad_offset, int32_t *workspace,
                           int64_t workspace_elems, void *stream);
+
+/* The whole deformable convolution as IMPLICIT GEMMs on the fp32 matrix cores (ABI 13; csrc/deform_conv_mfma.hip): no
+ * [groups][B*H*W][9*C/groups] column buffer exists -- the bilinear taps are sampled into LDS tiles and multiplied there
+ * (v_mfma_f32_32x32x2_f32 / _16x16x4_f32: exact fp32, a k-ordered fmaf chain).  Same operator as mmt_dcn_im2col + GEMM and
+ * the GEMMs + mmt_dcn_col2im_sorted (lss_fpn.py:189-197: 3x3, stride 1, pad 1, dilation 1, deform_groups 1).  Channels-last fp32:
+ *   x [B,H,W,C]; offset [B,H,W,18]; weight [O, C/groups, 3, 3] (the torch parameter as it lies); out / grad_out [B,H,W,O];
+ *   grad_x [B,H,W,C] and grad_offset [B,H,W,18] are OVERWRITTEN (no zero-fill by the caller); grad_weight like weight.
+ * Shapes: C/groups a multiple of 64, O/groups 64 or 128 (mmt_dcn_mfma_supported() == 1); anything else is MMT_ERR_BAD_SHAPE
+ * and the im2col / col2im entry points above are the general form.  workspace: device memory, any contents, 16-byte aligned,
+ * mmt_dcn_mfma_workspace_bytes(...) bytes (packed weights, the weight gradient's partial sums over pixel slices, the offset
+ * gradient's partial sums over 16-channel chunks); nothing is retained between calls.
+ * The forward and grad_weight / grad_offset are bit-reproducible; grad_x is summed with LDS float atomics (and, for images whose
+ * rows do not fit one LDS window, global ones): its fp32 sum order may differ between runs, as with mmt_dcn_col2im[_sorted].
+ * fwd_waves: 0 = let the library choose the forward's workgroup height (2, 3 or 4 waves of 32 pixels; a tuning knob). */
+int mmt_dcn_mfma_supported(int B, int H, int W, int C, int O, int groups);
+int64_t mmt_dcn_mfma_workspace_bytes(int B, int H, int W, int C, int O, int groups);
+int mmt_dcn_forward(int B, int H, int W, int C, int O, int groups, const float *x, const float *offset, const float *weight,
+                    float *out, void *workspace, int64_t workspace_bytes, int fwd_waves, void *stream);
+int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, const float *x, const float *offset, const float *weight,
+                     const float *grad_out, float *grad_x, float *grad_offset, float *grad_weight, void *workspace,
+                     int64_t workspace_bytes, void *stream);
 
 /* Fused lift-splat on a camera frustum (ABI 4): the same result as mmt_lift_splat_forward for a
  * point set laid out as a frustum [B*N, D, fH, fW].  Default kernels (ABI 5): RAY WALKS -- a workgroup owns one image

@@ -92,6 +92,10 @@ SIGNATURES = {
     "mmt_dcn_col2im": (_c_int, [_c_int] * 5 + [_c_ptr] * 5 + [_c_ptr]),
     "mmt_dcn_col2im_workspace_elems": (_c_i64, [_c_int] * 3),
     "mmt_dcn_col2im_sorted": (_c_int, [_c_int] * 5 + [_c_ptr] * 6 + [_c_i64, _c_ptr]),
+    "mmt_dcn_mfma_supported": (_c_int, [_c_int] * 6),
+    "mmt_dcn_mfma_workspace_bytes": (_c_i64, [_c_int] * 6),
+    "mmt_dcn_forward": (_c_int, [_c_int] * 6 + [_c_ptr] * 5 + [_c_i64, _c_int, _c_ptr]),
+    "mmt_dcn_backward": (_c_int, [_c_int] * 6 + [_c_ptr] * 8 + [_c_i64, _c_ptr]),
     "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr, _c_int]),
     "mmt_voxelize_table_elems": (_c_i64, [_c_int, _c_ptr, _c_i64]),
     "mmt_voxelize_scratch_elems": (_c_i64, [_c_int, _c_ptr, _c_i64, _c_int]),

@@ -1,5 +1,10 @@
-"""Deformable 3x3 convolution (mmcv 'DCN' / DeformConv2dPack, lss_fpn.py:189-197) on the
-HIP im2col / col2im kernels of libmmt_hip.so + torch.bmm for the grouped GEMMs."""
+"""Deformable 3x3 convolution (mmcv 'DCN' / DeformConv2dPack, lss_fpn.py:189-197).
+
+Default: the implicit-GEMM kernels of csrc/deform_conv_mfma.hip (mmt_dcn_forward / mmt_dcn_backward: bilinear taps sampled
+into LDS tiles, exact-fp32 MFMA, no column buffer).  Shapes they do not take (C/groups not a multiple of 64, O/groups not
+64 or 128) go through the HIP im2col / col2im kernels + torch.mm for the grouped GEMMs (`_DeformConv3x3Columns`)."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -10,7 +15,56 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-class _DeformConv3x3(Function):
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """One workspace per device, grown on demand (nothing is retained in it between calls; calls on one stream are ordered)."""
+    key = (device.type, device.index)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
+class _DeformConv3x3Mfma(Function):
+    """x [B,C,H,W], offset [B,18,H,W], weight [O, C/groups, 3, 3] -> [B,O,H,W] (channels_last view)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, weight, groups):
+        x_nhwc = x.float().permute(0, 2, 3, 1).contiguous()        # free for channels_last inputs
+        off_nhwc = offset.float().permute(0, 2, 3, 1).contiguous()
+        w = weight.float().contiguous()
+        B, H, W, C = x_nhwc.shape
+        O = w.shape[0]
+        if off_nhwc.shape != (B, H, W, 18) or tuple(w.shape) != (O, C // groups, 3, 3):
+            raise RuntimeError("deform_conv3x3: expected offset [B,18,H,W] and weight [O, C/groups, 3, 3]")
+        out = torch.empty((B, H, W, O), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = _workspace(_lib.lib().mmt_dcn_mfma_workspace_bytes(B, H, W, C, O, groups), x.device)
+            _lib.call("mmt_dcn_forward", B, H, W, C, O, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(), w.data_ptr(), out.data_ptr(),
+                      ws.data_ptr(), ws.numel(), int(os.environ.get("MMT_DCN_FWD_WAVES", "0")), _stream())
+        ctx.save_for_backward(x_nhwc, off_nhwc, w)
+        ctx.dims = (B, H, W, C, O, groups)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_nhwc, off_nhwc, w = ctx.saved_tensors
+        B, H, W, C, O, groups = ctx.dims
+        go = grad_out.float().permute(0, 2, 3, 1).contiguous()      # free for a channels_last gradient
+        grad_x = torch.empty_like(x_nhwc)
+        grad_off = torch.empty_like(off_nhwc)
+        grad_w = torch.empty_like(w)
+        with torch.cuda.device(x_nhwc.device):
+            ws = _workspace(_lib.lib().mmt_dcn_mfma_workspace_bytes(B, H, W, C, O, groups), x_nhwc.device)
+            _lib.call("mmt_dcn_backward", B, H, W, C, O, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(), w.data_ptr(), go.data_ptr(),
+                      grad_x.data_ptr(), grad_off.data_ptr(), grad_w.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        return grad_x.permute(0, 3, 1, 2), grad_off.permute(0, 3, 1, 2), grad_w, None
+
+
+class _DeformConv3x3Columns(Function):
     @staticmethod
     def forward(ctx, x, offset, weight, groups):
         if not x.is_cuda:
@@ -80,6 +134,13 @@ class _DeformConv3x3(Function):
         return grad_x.permute(0, 3, 1, 2), grad_off.permute(0, 3, 1, 2), grad_weight, None
 
 
-def deform_conv3x3(x, offset, weight, groups=1):
-    """x [B,C,H,W], offset [B,18,H,W], weight [O, C/groups, 3, 3] -> [B,O,H,W] (channels_last)."""
-    return _DeformConv3x3.apply(x, offset, weight, int(groups))
+def deform_conv3x3(x, offset, weight, groups=1, columns=False):
+    """x [B,C,H,W], offset [B,18,H,W], weight [O, C/groups, 3, 3] -> [B,O,H,W] (channels_last).
+    columns=True forces the im2col / col2im + GEMM form (the fallback; A/B tools and tests)."""
+    if not x.is_cuda:
+        raise RuntimeError("x must be a CUDAtensor ")
+    groups = int(groups)
+    B, C, H, W = x.shape
+    if not columns and _lib.lib().mmt_dcn_mfma_supported(B, H, W, C, weight.shape[0], groups):
+        return _DeformConv3x3Mfma.apply(x, offset, weight, groups)
+    return _DeformConv3x3Columns.apply(x, offset, weight, groups)

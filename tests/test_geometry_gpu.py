@@ -121,6 +121,78 @@ def test_deform_conv_matches_torch_reference(mmt_lib, shape):
         assert (a - b).abs().max().item() <= tol, name
 
 
+# (B, C, H, W, O, groups, offset scale, expected bands of the data gradient's LDS window)
+MFMA_SHAPES = [(2, 128, 5, 7, 128, 2, 0.4, 1), (3, 256, 16, 44, 256, 2, 1.5, 1), (2, 128, 9, 13, 256, 2, 0.0, 1), (24, 512, 16, 44, 512, 4, 0.7, 1),
+               (2, 64, 150, 40, 64, 1, 2.5, 3), (1, 512, 32, 88, 512, 4, 1.0, 2)]
+
+
+@pytest.mark.parametrize("shape", MFMA_SHAPES)
+def test_deform_conv_implicit_gemm(mmt_lib, shape):
+    """Row f2: mmt_dcn_forward / mmt_dcn_backward (implicit GEMMs on the fp32 matrix cores, no column buffer) against
+    (a) an fp64 evaluation of the torch restatement of mmcv's operator (DeformConv2dPack.forward_reference; PARITY UNPINNED upstream,
+    see the test above), 1e-4 of the result's scale, and (b) the im2col / col2im + GEMM form of this library on the same inputs.
+    Shapes: 64- and 128-wide weight groups, zero offsets (integer sampling points), offsets of several pixels with one pixel's
+    taps far outside / on half pixels / at the border, pixel counts that are no multiple of any tile, and two images whose
+    rows do not fit one LDS window (banded data gradient, global-atomic flush + strays)."""
+    from mm_training_amd.layers.nets import DeformConv2dPack
+    from mm_training_amd.ops.deform_conv import deform_conv3x3
+    B, C, H, W, O, groups, off_scale, bands = shape
+    assert mmt_lib.lib().mmt_dcn_mfma_supported(B, H, W, C, O, groups) == 1
+    torch.manual_seed(1)
+    m = DeformConv2dPack(C, O, groups=groups).cuda()
+    x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    offset = torch.randn(B, 18, H, W, device="cuda") * off_scale
+    if off_scale > 0:
+        # (no sampling coordinate exactly on -1 / H / W or on an integer of the border: there the fp64 reference's normalise /
+        # un-normalise round trip decides which side it falls on)
+        offset[0, :, 2, 2] = torch.tensor([-30.0, -30.0, 50.0, 50.0, -0.5, -0.5, 0.25, -1.25, 0.1, 0.1, 1.5, 1.5, -1.75, 2.25, 0.5, 0.5, 0.99, -0.99])
+        offset[-1, :, H - 1, W - 1] = torch.tensor([3.0, 0.0, -float(H), 2.0, 0.5, -float(W) + 1.5, 0.2, -0.3, 7.0, -7.0, 1.25, 1.0, -2.5, -2.5, 0.25, 0.75, -0.75, 0.3])
+    go = torch.randn(B, O, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def run(fn, dtype):
+        xa, oa, wa = x.to(dtype).requires_grad_(True), offset.to(dtype).requires_grad_(True), m.weight.detach().to(dtype).requires_grad_(True)
+        out = fn(xa, oa, wa)
+        gx, goff, gw = torch.autograd.grad(out, (xa, oa, wa), go.to(dtype))
+        return [t.detach().double() for t in (out, gx, goff, gw)]
+
+    def reference(xa, oa, wa):
+        import types
+        return DeformConv2dPack.forward_reference(types.SimpleNamespace(groups=groups, weight=wa), xa, oa)
+
+    got = run(lambda a, b, c: deform_conv3x3(a, b, c, groups), torch.float32)
+    ref = run(reference, torch.float64)
+    col = run(lambda a, b, c: deform_conv3x3(a, b, c, groups, columns=True), torch.float32)
+    names = ("out", "grad_x", "grad_offset", "grad_weight")
+    for a, r, c, name in zip(got, ref, col, names):
+        if name == "grad_offset" and off_scale == 0.0:
+            # every sampling point sits on an integer: the sample is piecewise linear with a kink there, mmcv (and this library)
+            # take the derivative of the piece above, and the reference's fp64 normalise / un-normalise round trip lands on
+            # either side.  Only the two HIP forms are comparable (the column form is pinned to torch's fp32 grid_sample in
+            # test_deform_conv_matches_torch_reference, interior pixels)
+            assert (a - c).abs().max().item() <= 1e-4 * max(c.abs().max().item(), 1.0), name
+            continue
+        tol = 1e-4 * max(r.abs().max().item(), 1.0)
+        assert (a - r).abs().max().item() <= tol, (name, "vs fp64", (a - r).abs().max().item(), tol)
+        assert (a - c).abs().max().item() <= 2 * tol, (name, "vs the column form", (a - c).abs().max().item(), tol)
+    # bit-reproducible: the forward, grad_weight, grad_offset (grad_x: LDS / global float atomics)
+    again = run(lambda a, b, c: deform_conv3x3(a, b, c, groups), torch.float32)
+    for i in (0, 2, 3):
+        assert torch.equal(got[i], again[i]), names[i]
+
+
+def test_dcn_implicit_gemm_refusals(mmt_lib):
+    lib = mmt_lib.lib()
+    assert lib.mmt_dcn_mfma_supported(2, 5, 7, 16, 16, 4) == 0            # 4-wide groups: the column form's business
+    assert lib.mmt_dcn_mfma_supported(2, 5, 7, 128, 512, 2) == 0          # 256 output channels per group
+    assert lib.mmt_dcn_mfma_workspace_bytes(2, 5, 7, 16, 16, 4) == 0
+    x = torch.zeros(1 << 12, device="cuda")
+    p = x.data_ptr()
+    assert lib.mmt_dcn_forward(2, 5, 7, 16, 16, 4, p, p, p, p, p, 1 << 14, 0, None) == -2
+    assert lib.mmt_dcn_forward(1, 2, 2, 64, 64, 1, p, p, p, p, p, 16, 0, None) == -5           # workspace too small
+    assert lib.mmt_dcn_backward(1, 2, 2, 64, 64, 1, p, p, p, p, p, None, p, p, 1 << 14, None) == -1
+    assert lib.mmt_dcn_forward(1, 2, 2, 64, 64, 1, p + 4, p, p, p, p, 1 << 14, 0, None) == -2   # alignment
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 7, 16, 4, 3.0), (24, 16, 44, 512, 4, 0.7), (3, 32, 88, 64, 2, 6.0)])
 def test_dcn_col2im_sorted_equals_the_atomic_form(mmt_lib, shape):
     """mmt_dcn_col2im_sorted (contributions binned by destination pixel in LDS, then a gather: no global atomics,

@@ -21,8 +21,41 @@ def timeit(fn, reps=20, warm=3):
     return ts[len(ts) // 2]
 
 
+def whole_op(res):
+    """The whole operator, both forms, forward and backward (A/B in one process): the implicit-GEMM kernels
+    (mmt_dcn_forward / mmt_dcn_backward) against im2col / col2im + the vendor GEMMs (ops/deform_conv.py, columns=True)."""
+    from mm_training_amd.ops.deform_conv import deform_conv3x3
+    for B, C, H, W, O, groups in ((24, 512, 16, 44, 512, 4), (12, 512, 32, 88, 512, 4)):
+        torch.manual_seed(0)
+        x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        off = (torch.randn(B, 18, H, W, device="cuda") * 0.5).requires_grad_(True)
+        w = (torch.randn(O, C // groups, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+        go = torch.randn(B, O, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        flop = 2.0 * B * H * W * 9 * (C // groups) * O
+        hbm_fwd = 4.0 * (x.numel() + off.numel() + w.numel() + B * H * W * O)
+        hbm_bwd = 4.0 * (2 * x.numel() + 2 * off.numel() + 2 * w.numel() + B * H * W * O)
+        entry = {"gflop_per_gemm": flop / 1e9, "algorithmic_MB_fwd": hbm_fwd / 1e6, "algorithmic_MB_bwd": hbm_bwd / 1e6}
+        for name, columns in (("implicit_gemm", False), ("columns", True)):
+            for waves in ((0, 2, 3, 4) if not columns else (0,)):
+                os.environ["MMT_DCN_FWD_WAVES"] = str(waves)
+                tf = timeit(lambda: deform_conv3x3(x, off, w, groups, columns=columns))
+                key = name if waves == 0 else f"{name}_fwd_waves{waves}"
+                entry[key + "_fwd_ms"] = tf
+                entry[key + "_fwd_TFLOPs"] = flop / tf / 1e9
+            os.environ["MMT_DCN_FWD_WAVES"] = "0"
+            out = deform_conv3x3(x, off, w, groups, columns=columns)
+            tb = timeit(lambda: torch.autograd.grad(out, (x, off, w), go, retain_graph=True))
+            entry[name + "_bwd_ms"] = tb
+            entry[name + "_bwd_TFLOPs"] = 2 * flop / tb / 1e9
+        res[f"whole_op_B{B}_C{C}_{H}x{W}_g{groups}"] = entry
+
+
 def main():
     res = {}
+    whole_op(res)
+    if "--whole-op-only" in sys.argv:
+        print(json.dumps(res, indent=1))
+        return
     for B, H, W, C, groups, scale in ((24, 16, 44, 512, 4, 0.0), (24, 16, 44, 512, 4, 1.0), (12, 32, 88, 512, 4, 1.0)):
         g = torch.Generator().manual_seed(0)
         x = torch.randn(B, H, W, C, generator=g).cuda()
