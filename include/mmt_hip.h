@@ -288,11 +288,12 @@ int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x
  * gradient's partial sums over 16-channel chunks); nothing is retained between calls.
  * The forward and grad_weight / grad_offset are bit-reproducible; grad_x is summed with LDS float atomics (and, for images whose
  * rows do not fit one LDS window, global ones): its fp32 sum order may differ between runs, as with mmt_dcn_col2im[_sorted].
- * fwd_waves: 0 = let the library choose the forward's workgroup height (2, 3 or 4 waves of 32 pixels; a tuning knob). */
+ * fwd_config: 0 = let the library choose the forward's workgroup shape; 1-4 = (3x2, 2x2, 4x1, 4x2) waves along (pixels x
+ * output channels), 32 pixels per wave row (a tuning knob for the A/B tools). */
 int mmt_dcn_mfma_supported(int B, int H, int W, int C, int O, int groups);
 int64_t mmt_dcn_mfma_workspace_bytes(int B, int H, int W, int C, int O, int groups);
 int mmt_dcn_forward(int B, int H, int W, int C, int O, int groups, const float *x, const float *offset, const float *weight,
-                    float *out, void *workspace, int64_t workspace_bytes, int fwd_waves, void *stream);
+                    float *out, void *workspace, int64_t workspace_bytes, int fwd_config, void *stream);
 int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, const float *x, const float *offset, const float *weight,
                      const float *grad_out, float *grad_x, float *grad_offset, float *grad_weight, void *workspace,
                      int64_t workspace_bytes, void *stream);

@@ -18,6 +18,8 @@
 // HBM: x + offsets + weights + out are ~77 MB.
 #include "mmt_common.h"
 #include "dcn_tap.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -85,24 +87,28 @@ __global__ __launch_bounds__(256) void dcn_pack_weights(int O, int Cg, int group
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// forward: a workgroup owns BM = 32*NW output pixels x BN output channels of one weight group; K-steps of (tap, 32 channels).
+// forward: a workgroup owns BM = 32*WM output pixels x BN output channels of one weight group; K-steps of (tap, 32 channels).
 // Per K-step the bilinear taps of x are sampled straight into the LDS A tile (what dcn_im2col_kernel wrote to memory), the weight
-// tile streams into the B tile, each wave multiplies its 32 rows by all BN columns with v_mfma_f32_32x32x2_f32.  Both tiles are
-// [row][k] with k contiguous: lane (i, h) reads k = 8j + 4h .. + 3 with one ds_read_b128 and feeds MFMA t with element t -- the
-// k order inside a K-step is permuted identically for A and B.  Double-buffered: the global loads of step s+1 are in flight
-// under the MFMAs of step s, one barrier per step.
-template <int NW, int BN>
-__global__ __launch_bounds__(NW * 64) void dcn_fwd_mfma(int H, int W, int C, int O, int groups, int npos, const float *__restrict__ x,
-                                                        const float *__restrict__ offset, const float *__restrict__ wf,
-                                                        float *__restrict__ out) {
-    constexpr int BM = NW * 32, NT = NW * 64, NB = BN / 32;
-    constexpr int PPP = NT / 8;                  // pixels per fill pass (8 lanes x float4 per pixel); BM / PPP = 4 passes
+// tile streams into the B tile; WM x WN waves, wave (wm, wn) multiplies rows 32*wm.. by columns wn*BN/WN.. with
+// v_mfma_f32_32x32x2_f32.  Both tiles are [row][k] with k contiguous: lane (i, h) reads k = 8j + 4h .. + 3 with one ds_read_b128
+// and feeds MFMA t with element t -- the k order inside a K-step is permuted identically for A and B.  Double-buffered: the
+// global loads of step s+1 are in flight under the MFMAs of step s, one barrier per step.  The sampling points of a tap are
+// computed once per (pixel, tap) by the first BM threads (offsets prefetched a tap ahead) and shared through LDS.
+template <int WM, int WN, int BN>
+__global__ __launch_bounds__(WM * WN * 64) void dcn_fwd_mfma(int H, int W, int C, int O, int groups, int npos, const float *__restrict__ x,
+                                                             const float *__restrict__ offset, const float *__restrict__ wf,
+                                                             float *__restrict__ out) {
+    constexpr int BM = WM * 32, NT = WM * WN * 64, NB = BN / WN / 32;
+    constexpr int PPP = NT / 8;                  // pixels per fill pass (8 lanes x float4 per pixel)
+    constexpr int AP = BM / PPP;                 // fill passes
     constexpr int NBL = (BN * 8 + NT - 1) / NT;  // B-tile float4 per thread
+    static_assert(BM % PPP == 0 && BM <= NT, "fill mapping");
     extern __shared__ __align__(16) float smem[];
     float *As = smem;                                   // [2][BM][kLd]
     float *Bs = As + 2 * BM * kLd;                      // [2][BN][kLd]
     TapRec *taps = reinterpret_cast<TapRec *>(Bs + 2 * BN * kLd);   // [2][BM]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int Cg = C / groups, Og = O / groups, ntn = Og / BN, HW = H * W;
     int bid = blockIdx.x;
     const int nt = bid % ntn; bid /= ntn;
@@ -118,49 +124,75 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd_mfma(int H, int W, int C, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-    float4 va[4][4];
-    f32x4 vb[NBL];          // (an ext vector: a float4 struct copied global -> array -> LDS stays a memcpy through scratch)
-    float wa[4][4];
-
-    auto write_taps = [&](int tap) {
-        if (tid < BM) taps[(tap & 1) * BM + tid] = tap_record(pos0 + tid, npos, HW, H, W, tap, offset);
+    // two register stages: the loads of step s+2 are issued at the top of step s (a whole step ahead of their use)
+    struct Stage {
+        float4 va[AP][4];
+        f32x4 vb[NBL];          // (an ext vector: a float4 struct copied global -> array -> LDS stays a memcpy through scratch)
+        float wa[AP][4];
     };
-    auto issue_loads = [&](int s) {
+    Stage sa, sb;
+
+    // the pixel whose sampling points this thread computes (threads < BM), and its offsets for the NEXT tap to be written
+    const int tpos = pos0 + tid;
+    const bool towner = tid < BM && tpos < npos;
+    const int tb = towner ? tpos / HW : 0, thw = towner ? tpos - tb * HW : 0, th = thw / W, tw = thw - th * W;
+    const float *toff = offset + (size_t)(towner ? tpos : 0) * 18;
+    float2 onext = *reinterpret_cast<const float2 *>(toff);
+    auto write_taps = [&](int tap) {      // consumes onext (= the offsets of `tap`), prefetches tap + 1
+        if (tid < BM) {
+            TapRec r;
+            if (towner) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const Tap t = mmt_dcn::make_tap((float)(th + ky - 1) + onext.x, (float)(tw + kx - 1) + onext.y, H, W);
+                const int base = tb * HW;
+                r.w[0] = t.w1; r.w[1] = t.w2; r.w[2] = t.w3; r.w[3] = t.w4;
+                // byte offsets of the corner rows in x (B*H*W*C*4 < 2^32: dcn_shape)
+                r.o[0] = (base + t.o1) * C * 4; r.o[1] = (base + t.o2) * C * 4; r.o[2] = (base + t.o3) * C * 4; r.o[3] = (base + t.o4) * C * 4;
+            } else {
+                r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
+                r.o[0] = r.o[1] = r.o[2] = r.o[3] = 0;
+            }
+            taps[(tap & 1) * BM + tid] = r;
+            onext = *reinterpret_cast<const float2 *>(toff + 2 * (tap < 8 ? tap + 1 : 8));
+        }
+    };
+    const unsigned lane_bytes = (tid & 7) * 16;
+    auto issue_loads = [&](int s, Stage &st) {
         const int tap = s / nchunk, ch = s - tap * nchunk;
         const TapRec *tp = taps + (tap & 1) * BM + (tid >> 3);
-        const float *xc = xg + ch * kKC;
+        const char *xc = reinterpret_cast<const char *>(x + g * Cg + ch * kKC);      // wave-uniform base + 32-bit per-lane offset
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < AP; ++p) {
             const TapRec r = tp[p * PPP];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                wa[p][i] = r.w[i];
-                va[p][i] = *reinterpret_cast<const float4 *>(xc + (size_t)r.o[i] * C);
+                st.wa[p][i] = r.w[i];
+                st.va[p][i] = *reinterpret_cast<const float4 *>(xc + ((unsigned)r.o[i] + lane_bytes));
             }
         }
         const float *ws = wfg + (size_t)tap * Og * Cg + ch * kKC;
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
             const int e = min(tid + i * NT, BN * 8 - 1);      // (a thread past the tile re-reads its last float4)
-            vb[i] = *reinterpret_cast<const f32x4 *>(ws + (size_t)(e >> 3) * Cg + (e & 7) * 4);
+            st.vb[i] = *reinterpret_cast<const f32x4 *>(ws + (unsigned)((e >> 3) * Cg + (e & 7) * 4));
         }
     };
-    auto write_lds = [&](int buf) {
+    auto write_lds = [&](int buf, Stage &st) {
         float *ad = As + ((size_t)buf * BM + (tid >> 3)) * kLd + (tid & 7) * 4;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<float4 *>(ad + p * PPP * kLd) = corner_mix(wa[p], va[p]);
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<float4 *>(ad + p * PPP * kLd) = corner_mix(st.wa[p], st.va[p]);
         float *bd = Bs + (size_t)buf * BN * kLd;
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
             const int e = min(tid + i * NT, BN * 8 - 1);      // (threads past the tile store the same float4 again)
-            *reinterpret_cast<f32x4 *>(bd + (e >> 3) * kLd + (e & 7) * 4) = vb[i];
+            *reinterpret_cast<f32x4 *>(bd + (e >> 3) * kLd + (e & 7) * 4) = st.vb[i];
         }
     };
-    auto compute = [&](int buf) {
-        const float *ar = As + ((size_t)buf * BM + wave * 32 + l31) * kLd + 4 * hh;
-        const float *br = Bs + ((size_t)buf * BN + l31) * kLd + 4 * hh;
+    auto compute = [&](int buf, int j0, int j1) {
+        const float *ar = As + ((size_t)buf * BM + wm * 32 + l31) * kLd + 4 * hh;
+        const float *br = Bs + ((size_t)buf * BN + wn * (BN / WN) + l31) * kLd + 4 * hh;
 #pragma unroll
-        for (int j = 0; j < kKC / 8; ++j) {
+        for (int j = j0; j < j1; ++j) {
             const f32x4 a = *reinterpret_cast<const f32x4 *>(ar + 8 * j);
             f32x4 b[NB];
 #pragma unroll
@@ -171,26 +203,39 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd_mfma(int H, int W, int C, int
                 for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[n][t], acc[n], 0, 0, 0);
         }
     };
+    // step s: `done` held step s (already in LDS; free for step s+2), `next` holds step s+1 (its loads issued a step ago).
+    // FULL = neither of the two is past the end (no branches in the body).
+    auto step = [&](int s, Stage &done, Stage &next, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        if (FULL || s + 2 < nsteps) issue_loads(s + 2, done);
+        compute(s & 1, 0, kKC / 16);
+        if (FULL || s + 1 < nsteps) write_lds((s + 1) & 1, next);
+        compute(s & 1, kKC / 16, kKC / 8);
+        // the tap records step s+3 needs (read at the top of step s+1) go into the buffer the loads of steps s+1 / s+2 do not read
+        if (s + 3 < nsteps && (s + 3) / nchunk != (s + 2) / nchunk) write_taps((s + 3) / nchunk);
+        __syncthreads();
+    };
 
     write_taps(0);
-    if (nchunk == 1) write_taps(1);
+    if (nchunk == 2) write_taps(1);        // (nchunk >= 2: C/groups is a multiple of 64)
     __syncthreads();
-    issue_loads(0);
-    write_lds(0);
+    issue_loads(0, sa);
+    issue_loads(1, sb);
+    write_lds(0, sa);
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
-        if (more) issue_loads(s + 1);
-        compute(s & 1);
-        if (more) write_lds((s + 1) & 1);
-        // the tap records step s+2 needs (read at the top of step s+1) go into the buffer step s+1's loads do not read
-        if (s + 2 < nsteps && (s + 2) / nchunk != (s + 1) / nchunk) write_taps((s + 2) / nchunk);
-        __syncthreads();
+    int s = 0;
+    for (; s + 3 < nsteps; s += 2) {
+        step(s, sa, sb, std::true_type{});
+        step(s + 1, sb, sa, std::true_type{});
     }
-    float *ob = out + g * Og + nt * BN + l31;
+    for (; s < nsteps; s += 2) {
+        step(s, sa, sb, std::false_type{});
+        if (s + 1 < nsteps) step(s + 1, sb, sa, std::false_type{});
+    }
+    float *ob = out + g * Og + nt * BN + wn * (BN / WN) + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int pos = pos0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int pos = pos0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (pos < npos) {
 #pragma unroll
             for (int n = 0; n < NB; ++n) ob[(size_t)pos * O + n * 32] = acc[n][r];
@@ -347,7 +392,7 @@ template <int OG>
 __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O, int groups, int npos, int bands, int band_rows, int halo,
                                                       const float *__restrict__ x, const float *__restrict__ offset,
                                                       const float *__restrict__ wd, const float *__restrict__ go,
-                                                      float *__restrict__ grad_x, float *__restrict__ part) {
+                                                      float *__restrict__ grad_x, float *__restrict__ part, int dbg) {
     constexpr int KQ = OG / 4;        // output channels (k values) per lane quarter
     constexpr int WLD = OG + 2;       // weight-tile row stride: ds_read_b64 of lane (c, kq) at c*WLD + kq*KQ is conflict-free
     extern __shared__ __align__(16) float smem[];
@@ -421,7 +466,7 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             const float *ar = wl + buf * 16 * WLD + l15 * WLD + kq * KQ;
 #pragma unroll
-            for (int s = 0; s < KQ / 2; ++s) {
+            for (int s = 0; s < ((dbg & 4) ? 1 : KQ / 2); ++s) {
                 const f32x2 a = *reinterpret_cast<const f32x2 *>(ar + 2 * s);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[0][2 * s], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[1][2 * s], acc[1], 0, 0, 0);
@@ -438,7 +483,7 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
                 const f32x4 a4 = acc[sub];
                 float4 xv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xb + (size_t)to[i] * C);
+                for (int i = 0; i < 4; ++i) xv[i] = (dbg & 2) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4 *>(xb + (size_t)to[i] * C);
                 float gy = 0.f, gx = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -448,7 +493,7 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
                     d = live ? d : 0.f;
                     gy = __builtin_fmaf(tdy[i], d, gy);
                     gx = __builtin_fmaf(tdx[i], d, gx);
-                    if (valid[sub] && tw[i] != 0.f) {
+                    if (valid[sub] && tw[i] != 0.f && !(dbg & 1)) {
                         const int wp = to[i] - wpix0;
                         if ((unsigned)wp < (unsigned)wnpix) {
                             float *dst = win + wp * kWinLd + 4 * kq;
@@ -494,6 +539,264 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The data gradient WITHOUT float atomics.  ds_add_f32 runs at one LANE per 3 cycles on gfx950 (192 cycles per wave
+// instruction whatever the addresses: tools/ubench/lds_atomic.hip) -- the LDS-window scatter of dcn_dgrad_mfma spends 1.3 ms
+// of its 1.7 ms in them at the DepthNet shape.  Here the scatter is turned into a gather through per-destination lists:
+//   dcn_plan_taps      one workgroup per (tap, image): every source pixel's sampling point has up to 4 corners with a non-zero
+//                      weight; they are binned by (round of the source, destination pixel) in LDS (count -> scan -> counting
+//                      sort, integer LDS atomics) and leave as lists of (source pixel, weight).  A "round" = the nw*32 source
+//                      pixels the gather kernel's waves hold at a time.
+//   dcn_dgrad_gather   as dcn_dgrad_mfma up to gc[c][p] in registers and the offset-gradient dots; then each wave stages its
+//                      gc tile in LDS ([pixel of the round][16 channels], double-buffered), and after the barrier every thread
+//                      walks the lists of the destinations it owns -- (pixel, 4 channels) items, fixed for the whole kernel,
+//                      sums in registers -- reading the staged rows.  grad_x is written once at the end with plain stores.
+// The gather of (round, tap) is issued after the MFMAs + staging of the NEXT tap, so that waves drift apart and one wave's list
+// walk runs under another's matrix work.  Needs H*W*4 items <= 4 per thread (H*W <= 64 * waves <= 768) and rounds*H*W bins in
+// LDS; larger images take dcn_dgrad_mfma (the general, banded form).
+struct PlanEntry { int src; float w; };     // source pixel inside the image, bilinear weight of the corner that lands here
+
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanMaxBins = 8192;
+
+__global__ __launch_bounds__(kPlanThreads) void dcn_plan_taps(int H, int W, int ppr, int rounds, const float *offset, int32_t *bin_off,
+                                                              PlanEntry *entries) {
+    __shared__ int cnt[kPlanMaxBins];
+    __shared__ int off[kPlanMaxBins + 1];
+    __shared__ int wsum[kPlanThreads / 64];
+    const int HW = H * W, nbins = rounds * HW;
+    const int tap = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *ob = offset + (int64_t)b * HW * 18;
+    for (int i = tid; i < nbins; i += kPlanThreads) cnt[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < HW; p += kPlanThreads) {
+        const int h = p / W, w = p - h * W;
+        const Tap t = tap_at(h, w, tap, ob + (int64_t)p * 18, H, W);
+        const int rb = (p / ppr) * HW;
+        if (t.w1 != 0.f) atomicAdd(&cnt[rb + t.o1], 1);
+        if (t.w2 != 0.f) atomicAdd(&cnt[rb + t.o2], 1);
+        if (t.w3 != 0.f) atomicAdd(&cnt[rb + t.o3], 1);
+        if (t.w4 != 0.f) atomicAdd(&cnt[rb + t.o4], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts: kPer consecutive bins per thread, wave scan, then the wave totals
+    constexpr int kPer = kPlanMaxBins / kPlanThreads;
+    int loc[kPer], sum = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int idx = tid * kPer + i;
+        loc[i] = idx < nbins ? cnt[idx] : 0;
+        sum += loc[i];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int run = base + incl - sum;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int idx = tid * kPer + i;
+        if (idx < nbins) { off[idx] = run; cnt[idx] = 0; }
+        run += loc[i];
+    }
+    if (tid == kPlanThreads - 1) off[nbins] = run;
+    __syncthreads();
+    int32_t *bo = bin_off + ((int64_t)b * 9 + tap) * (nbins + 1);
+    for (int i = tid; i <= nbins; i += kPlanThreads) bo[i] = off[i];
+    PlanEntry *eb = entries + ((int64_t)b * 9 + tap) * HW * 4;
+    for (int p = tid; p < HW; p += kPlanThreads) {
+        const int h = p / W, w = p - h * W;
+        const Tap t = tap_at(h, w, tap, ob + (int64_t)p * 18, H, W);
+        const int rb = (p / ppr) * HW;
+        if (t.w1 != 0.f) eb[off[rb + t.o1] + atomicAdd(&cnt[rb + t.o1], 1)] = PlanEntry{p, t.w1};
+        if (t.w2 != 0.f) eb[off[rb + t.o2] + atomicAdd(&cnt[rb + t.o2], 1)] = PlanEntry{p, t.w2};
+        if (t.w3 != 0.f) eb[off[rb + t.o3] + atomicAdd(&cnt[rb + t.o3], 1)] = PlanEntry{p, t.w3};
+        if (t.w4 != 0.f) eb[off[rb + t.o4] + atomicAdd(&cnt[rb + t.o4], 1)] = PlanEntry{p, t.w4};
+    }
+}
+
+constexpr int kGcLd = 20;        // floats per staged pixel row (16 channels, 80-byte rows: 16-byte aligned float4 slots)
+constexpr int kItems = 4;        // (pixel, 4-channel) destinations per thread
+
+template <int OG>
+__global__ __launch_bounds__(768) void dcn_dgrad_gather(int H, int W, int C, int O, int groups, int npos, int rounds,
+                                                        const float *__restrict__ x, const float *__restrict__ offset,
+                                                        const float *__restrict__ wd, const float *__restrict__ go,
+                                                        const int32_t *__restrict__ bin_off, const PlanEntry *__restrict__ entries,
+                                                        float *__restrict__ grad_x, float *__restrict__ part) {
+    constexpr int KQ = OG / 4;
+    constexpr int WLD = OG + 2;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int nth = blockDim.x, nw = nth >> 6, ppr = nw * 32;
+    const int Cg = C / groups, HW = H * W, nch = Cg / 16;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = bid % nch; bid /= nch;
+    const int g = bid % groups, b = bid / groups;
+    const int ntiles = (HW + 31) / 32;
+    const int cb = g * Cg + chunk * 16;
+    const int cglob = g * nch + chunk;
+    float *gcs = smem;                                   // [2][ppr][kGcLd]
+    float *wl = smem + 2 * ppr * kGcLd;                  // [2][16][WLD]
+    const float *wdg = wd + ((size_t)g * 9 * Cg + chunk * 16) * OG;
+    const float *gob = go + (size_t)b * HW * O + g * OG + kq * KQ;
+    const float *xb = x + (size_t)b * HW * C + cb + 4 * kq;
+    const float *ofb = offset + (size_t)b * HW * 18;
+    const int nbins = rounds * HW;
+
+    // the destinations this thread owns: item k = (pixel (tid + k*nth) >> 2, channels 4 * ((tid + k*nth) & 3) ..)
+    float4 sums[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) sums[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    bool wfill[2];
+    int wsrc[2], wdst[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = tid + k * nth;
+        wfill[k] = e < 4 * OG;
+        const int wc = e / (OG / 4), wo = (e % (OG / 4)) * 4;
+        wsrc[k] = wc * OG + wo;
+        wdst[k] = wc * WLD + wo;
+        if (wfill[k]) {
+            const float4 v = *reinterpret_cast<const float4 *>(wdg + wsrc[k]);
+            float *d = wl + wdst[k];
+            *reinterpret_cast<f32x2 *>(d) = f32x2{v.x, v.y};
+            *reinterpret_cast<f32x2 *>(d + 2) = f32x2{v.z, v.w};
+        }
+    }
+    __syncthreads();
+
+    // gather of unit u = rd * 9 + tap from staging buffer `sbuf`; lo / hi = the list bounds of this thread's items (prefetched)
+    auto gather = [&](int rd, int tap, int sbuf, const int (&lo)[kItems], const int (&hi)[kItems]) {
+        const PlanEntry *eb = entries + ((size_t)b * 9 + tap) * HW * 4;
+        const float *gb = gcs + sbuf * ppr * kGcLd - rd * ppr * kGcLd;
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int quad = (tid + k * nth) & 3;
+            for (int e = lo[k]; e < hi[k]; ++e) {
+                const PlanEntry en = eb[e];
+                const float4 v = *reinterpret_cast<const float4 *>(gb + en.src * kGcLd + 4 * quad);
+                sums[k].x = __builtin_fmaf(en.w, v.x, sums[k].x);
+                sums[k].y = __builtin_fmaf(en.w, v.y, sums[k].y);
+                sums[k].z = __builtin_fmaf(en.w, v.z, sums[k].z);
+                sums[k].w = __builtin_fmaf(en.w, v.w, sums[k].w);
+            }
+        }
+    };
+    auto bounds = [&](int rd, int tap, int (&lo)[kItems], int (&hi)[kItems]) {
+        const int32_t *bo = bin_off + ((size_t)b * 9 + tap) * (nbins + 1) + rd * HW;
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int q = (tid + k * nth) >> 2;
+            const bool on = q < HW;
+            lo[k] = on ? bo[q] : 0;
+            hi[k] = on ? bo[q + 1] : 0;
+        }
+    };
+
+    int buf = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int tile = rd * nw + wave;
+        const bool active = tile < ntiles;
+        float gq[2][KQ];
+        int pp[2];
+        bool valid[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            pp[sub] = tile * 32 + sub * 16 + l15;
+            valid[sub] = active && pp[sub] < HW;
+            if (!valid[sub]) pp[sub] = 0;
+            const float *src = gob + (size_t)pp[sub] * O;
+#pragma unroll
+            for (int j = 0; j < KQ / 4; ++j) {
+                const float4 v = valid[sub] ? *reinterpret_cast<const float4 *>(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gq[sub][4 * j] = v.x; gq[sub][4 * j + 1] = v.y; gq[sub][4 * j + 2] = v.z; gq[sub][4 * j + 3] = v.w;
+            }
+        }
+        for (int tap = 0; tap < 9; ++tap) {
+            const int u = rd * 9 + tap;
+            const bool pre = tap < 8 || rd + 1 < rounds;      // the next tap's weight tile (tap 0 again for the next round)
+            float4 vw[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (pre && wfill[k]) vw[k] = *reinterpret_cast<const float4 *>(wdg + (size_t)(tap == 8 ? 0 : tap + 1) * Cg * OG + wsrc[k]);
+            // list bounds of the PREVIOUS unit (its staged tile is complete: the barrier that ended it)
+            int lo[kItems], hi[kItems];
+            const int prd = tap == 0 ? rd - 1 : rd, ptap = tap == 0 ? 8 : tap - 1;
+            if (u > 0) bounds(prd, ptap, lo, hi);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const float *ar = wl + (buf & 1) * 16 * WLD + l15 * WLD + kq * KQ;
+#pragma unroll
+            for (int s = 0; s < KQ / 2; ++s) {
+                const f32x2 a = *reinterpret_cast<const f32x2 *>(ar + 2 * s);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[0][2 * s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[1][2 * s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[0][2 * s + 1], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[1][2 * s + 1], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int p = pp[sub];
+                const int h = p / W, w = p - h * W;
+                const Tap t = tap_at(h, w, tap, ofb + (size_t)p * 18, H, W);
+                const float tw[4] = {t.w1, t.w2, t.w3, t.w4}, tdy[4] = {t.dy1, t.dy2, t.dy3, t.dy4}, tdx[4] = {t.dx1, t.dx2, t.dx3, t.dx4};
+                const int to[4] = {t.o1, t.o2, t.o3, t.o4};
+                const f32x4 a4 = acc[sub];
+                float4 xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xb + (size_t)to[i] * C);
+                float gy = 0.f, gx = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // the corner takes part when it is inside the image: a non-zero weight or a non-zero coordinate derivative
+                    const bool live = valid[sub] && (tw[i] != 0.f || tdy[i] != 0.f || tdx[i] != 0.f);
+                    float d = __builtin_fmaf(a4[0], xv[i].x, __builtin_fmaf(a4[1], xv[i].y, __builtin_fmaf(a4[2], xv[i].z, a4[3] * xv[i].w)));
+                    d = live ? d : 0.f;
+                    gy = __builtin_fmaf(tdy[i], d, gy);
+                    gx = __builtin_fmaf(tdx[i], d, gx);
+                }
+                gy += __shfl_xor(gy, 16); gx += __shfl_xor(gx, 16);
+                gy += __shfl_xor(gy, 32); gx += __shfl_xor(gx, 32);
+                if (kq == 0 && valid[sub]) {
+                    float *pd = part + ((size_t)(cglob * 9 + tap) * 2) * npos + (size_t)b * HW + p;
+                    pd[0] = gy;
+                    pd[npos] = gx;
+                }
+                // stage gc[pixel of the round][4 channels of this lane] (pixels past the image stage zeros: never listed)
+                *reinterpret_cast<f32x4 *>(gcs + ((buf & 1) * ppr + wave * 32 + sub * 16 + l15) * kGcLd + 4 * kq) = a4;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (pre && wfill[k]) {
+                    float *d = wl + ((buf & 1) ^ 1) * 16 * WLD + wdst[k];
+                    *reinterpret_cast<f32x2 *>(d) = f32x2{vw[k].x, vw[k].y};
+                    *reinterpret_cast<f32x2 *>(d + 2) = f32x2{vw[k].z, vw[k].w};
+                }
+            if (u > 0) gather(prd, ptap, (buf & 1) ^ 1, lo, hi);
+            buf ^= 1;
+            __syncthreads();
+        }
+    }
+    {
+        int lo[kItems], hi[kItems];
+        bounds(rounds - 1, 8, lo, hi);
+        gather(rounds - 1, 8, (buf & 1) ^ 1, lo, hi);
+    }
+    float *gxb = grad_x + (size_t)b * HW * C + cb;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int idx = tid + k * nth, q = idx >> 2, quad = idx & 3;
+        if (q < HW) *reinterpret_cast<float4 *>(gxb + (size_t)q * C + 4 * quad) = sums[k];
+    }
+}
+
 // grad_offset[pos][2*tap + yx] = sum over the 16-channel chunks of part[chunk][tap][yx][pos], in chunk order
 __global__ __launch_bounds__(256) void dcn_offset_reduce_parts(int npos, int nparts, const float *part, float *grad_offset) {
     const int64_t n = (int64_t)npos * 18;
@@ -518,7 +821,7 @@ int dcn_shape(int B, int H, int W, int C, int O, int groups, DcnShape *s, const 
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || groups <= 0 || C % groups != 0 || O % groups != 0) return bad(MMT_ERR_BAD_SHAPE, "bad sizes");
     const int Cg = C / groups, Og = O / groups;
     if (Cg % 64 != 0 || (Og != 64 && Og != 128)) return bad(MMT_ERR_BAD_SHAPE, "the matrix-core form needs C/groups % 64 == 0 and O/groups in {64, 128}");
-    if ((int64_t)B * H * W * (int64_t)(C > O ? C : O) >= (1ll << 31)) return bad(MMT_ERR_TOO_LARGE, "B*H*W*max(C,O) exceeds int32");
+    if ((int64_t)B * H * W * (int64_t)(C > O ? C : O) >= (1ll << 30)) return bad(MMT_ERR_TOO_LARGE, "B*H*W*max(C,O)*4 bytes exceeds 32 bits");
     // the window of the data gradient: at least 1 row + 2 halo rows of W pixels next to the weight tiles
     if ((int64_t)3 * W * kWinLd * 4 + 2 * 16 * (Og + 2) * 4 + 64 > kLdsBudget) return bad(MMT_ERR_BAD_SHAPE, "W too large for the LDS window");
     *s = DcnShape{B, H, W, C, O, groups, Cg, Og, B * H * W};
@@ -552,6 +855,26 @@ DgradPlan dgrad_plan(const DcnShape &s) {
     return p;
 }
 
+// the gather form of the data gradient: waves per workgroup (fewest wasted wave slots over the image's 32-pixel tiles, every
+// (pixel, 4 channels) destination owned by a thread), rounds, LDS; ok = the image fits it
+struct GatherPlan { bool ok; int nw, rounds; size_t lds; };
+
+GatherPlan gather_plan(const DcnShape &s) {
+    GatherPlan p{false, 0, 0, 0};
+    const int HW = s.H * s.W, ntiles = (HW + 31) / 32;
+    double beff = 0.0;
+    for (int nw = 4; nw <= kMaxWaves; ++nw) {
+        if (HW * 4 > kItems * nw * 64) continue;
+        const int rounds = (ntiles + nw - 1) / nw;
+        const double eff = (double)ntiles / ((double)rounds * nw);
+        if (eff > beff + 1e-9) { beff = eff; p.nw = nw; p.rounds = rounds; }
+    }
+    if (p.nw == 0 || (int64_t)p.rounds * HW > kPlanMaxBins) return p;
+    p.lds = (size_t)2 * p.nw * 32 * kGcLd * 4 + (size_t)2 * 16 * (s.Og + 2) * 4;
+    p.ok = p.lds <= (size_t)kLdsBudget;
+    return p;
+}
+
 int wgrad_splits(const DcnShape &s) {
     // workgroups = splits * groups * 9 * (Cg/TC) * (Og/TO); two fit a CU: aim at one full round of 512
     const int tc = s.Cg % 128 == 0 ? 128 : 64, to = s.Og % 128 == 0 ? 128 : 64;
@@ -563,7 +886,7 @@ int wgrad_splits(const DcnShape &s) {
     return splits;
 }
 
-struct DcnWorkspace { size_t wf, wd, slab, part, total; int splits; };
+struct DcnWorkspace { size_t wf, wd, slab, part, bins, entries, total; int splits; };
 
 DcnWorkspace dcn_workspace(const DcnShape &s) {
     DcnWorkspace w;
@@ -573,7 +896,11 @@ DcnWorkspace dcn_workspace(const DcnShape &s) {
     w.wd = wbytes;
     w.slab = 2 * wbytes;
     w.part = w.slab + (size_t)w.splits * wbytes;
-    w.total = w.part + (size_t)(s.C / 16) * 18 * s.npos * 4;
+    w.bins = w.part + (size_t)(s.C / 16) * 18 * s.npos * 4;
+    const GatherPlan gp = gather_plan(s);
+    const size_t HW = (size_t)s.H * s.W;
+    w.entries = w.bins + (gp.ok ? (((size_t)s.B * 9 * (gp.rounds * HW + 1) * 4 + 15) & ~(size_t)15) : 0);
+    w.total = w.entries + (gp.ok ? (size_t)s.B * 9 * HW * 4 * sizeof(PlanEntry) : 0);
     return w;
 }
 
@@ -586,22 +913,16 @@ int set_lds(K kernel, size_t bytes, const char *what) {
     return 0;
 }
 
-// the forward's workgroup height: the number of waves (32 pixels each) whose last round of workgroups wastes the least
-int fwd_waves(const DcnShape &s, int bn) {
-    int best = 4; double bcost = 1e30;
-    for (int nw = 4; nw >= 2; --nw) {
-        const int bm = 32 * nw;
-        const int64_t wgs = (int64_t)((s.npos + bm - 1) / bm) * s.groups * (s.Og / bn);
-        const size_t lds = (size_t)2 * (bm + bn) * kLd * 4 + (size_t)2 * bm * sizeof(TapRec);
-        const int per_cu = (int)(kLdsBudget / lds) < 1 ? 1 : (int)(kLdsBudget / lds);
-        const int64_t slots = 256 * (int64_t)(per_cu > 2 ? 2 : per_cu);
-        const int64_t rounds = (wgs + slots - 1) / slots;
-        // time ~ rounds * (work of a workgroup) ; smaller workgroups re-read the weight tile more often: 3 % per step down
-        const double cost = (double)rounds * bm * (per_cu >= 2 ? 1.0 : 1.15) * (1.0 + 0.03 * (4 - nw));
-        if (cost < bcost) { bcost = cost; best = nw; }
-    }
-    return best;
-}
+// forward configurations: (waves along the pixels, waves along the output channels)
+struct FwdCfg { int wm, wn; };
+constexpr FwdCfg kFwdCfgs[] = {{3, 2}, {2, 2}, {4, 1}, {4, 2}};
+
+size_t fwd_lds(int wm, int bn) { return (size_t)2 * (32 * wm + bn) * kLd * 4 + (size_t)2 * 32 * wm * sizeof(TapRec); }
+
+// default: 2 x 2 waves on a 64-pixel x 128-channel tile, two workgroups per CU (measured at [24,512,16,44] and [12,512,32,88],
+// tools/kbench_dcn.py: 267 / 452 us against 300-350 / 490-580 for the taller tiles -- the step's barrier, tap records and LDS
+// fill are paid per workgroup-step, and smaller workgroups interleave them better)
+int fwd_config(const DcnShape &, int) { return 1; }
 
 }  // namespace
 
@@ -617,7 +938,7 @@ extern "C" int64_t mmt_dcn_mfma_workspace_bytes(int B, int H, int W, int C, int 
 }
 
 extern "C" int mmt_dcn_forward(int B, int H, int W, int C, int O, int groups, const float *x, const float *offset, const float *weight,
-                               float *out, void *workspace, int64_t workspace_bytes, int fwd_waves_override, void *stream) {
+                               float *out, void *workspace, int64_t workspace_bytes, int fwd_config_override, void *stream) {
     MMT_REQUIRE_PTR(x);
     MMT_REQUIRE_PTR(offset);
     MMT_REQUIRE_PTR(weight);
@@ -636,20 +957,20 @@ extern "C" int mmt_dcn_forward(int B, int H, int W, int C, int O, int groups, co
     seq.launch(false, dcn_pack_weights, dim3(mmt::stream_grid((int64_t)s.O * s.Cg * 9, 256, 1024)), dim3(256), 0, st, s.O, s.Cg, s.groups, weight, wf,
                (float *)nullptr);
     const int bn = s.Og % 128 == 0 ? 128 : 64;
-    int nw = fwd_waves_override >= 2 && fwd_waves_override <= 4 ? fwd_waves_override : fwd_waves(s, bn);
-    const int bm = 32 * nw;
-    const size_t lds = (size_t)2 * (bm + bn) * kLd * 4 + (size_t)2 * bm * sizeof(TapRec);
+    const int cfg = fwd_config_override >= 1 && fwd_config_override <= 4 ? fwd_config_override - 1 : fwd_config(s, bn);
+    const int wm = kFwdCfgs[cfg].wm, wn = kFwdCfgs[cfg].wn, bm = 32 * wm;
+    const size_t lds = fwd_lds(wm, bn);
     const unsigned grid = (unsigned)(((s.npos + bm - 1) / bm) * s.groups * (s.Og / bn));
-#define MMT_DCN_FWD(NW, BN)                                                                                                   \
+#define MMT_DCN_FWD(WM, WN, BN)                                                                                               \
     {                                                                                                                         \
-        if (int rc = set_lds(dcn_fwd_mfma<NW, BN>, lds, "dcn_forward")) return rc;                                            \
-        seq.launch(true, dcn_fwd_mfma<NW, BN>, dim3(grid), dim3(NW * 64), lds, st, H, W, C, O, groups, s.npos, x, offset,      \
-                   (const float *)wf, out);                                                                                   \
+        if (int rc = set_lds(dcn_fwd_mfma<WM, WN, BN>, lds, "dcn_forward")) return rc;                                        \
+        seq.launch(true, dcn_fwd_mfma<WM, WN, BN>, dim3(grid), dim3(WM * WN * 64), lds, st, H, W, C, O, groups, s.npos, x,    \
+                   offset, (const float *)wf, out);                                                                           \
     }
     if (bn == 128) {
-        if (nw == 4) MMT_DCN_FWD(4, 128) else if (nw == 3) MMT_DCN_FWD(3, 128) else MMT_DCN_FWD(2, 128)
+        if (cfg == 0) MMT_DCN_FWD(3, 2, 128) else if (cfg == 1) MMT_DCN_FWD(2, 2, 128) else if (cfg == 2) MMT_DCN_FWD(4, 1, 128) else MMT_DCN_FWD(4, 2, 128)
     } else {
-        if (nw == 4) MMT_DCN_FWD(4, 64) else if (nw == 3) MMT_DCN_FWD(3, 64) else MMT_DCN_FWD(2, 64)
+        if (cfg == 0) MMT_DCN_FWD(3, 2, 64) else if (cfg == 1) MMT_DCN_FWD(2, 2, 64) else if (cfg == 2) MMT_DCN_FWD(4, 1, 64) else MMT_DCN_FWD(4, 2, 64)
     }
 #undef MMT_DCN_FWD
     return mmt::check_launch("dcn_forward");
@@ -677,11 +998,17 @@ extern "C" int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, c
     float *wd = reinterpret_cast<float *>((char *)workspace + ws.wd);
     float *slab = reinterpret_cast<float *>((char *)workspace + ws.slab);
     float *part = reinterpret_cast<float *>((char *)workspace + ws.part);
+    const GatherPlan gp = gather_plan(s);
+    const bool general = !gp.ok || (getenv("MMT_DCN_DGRAD_GENERAL") && atoi(getenv("MMT_DCN_DGRAD_GENERAL")));
     const DgradPlan dp = dgrad_plan(s);
     mmt::TimedSeq seq;
     seq.launch(false, dcn_pack_weights, dim3(mmt::stream_grid((int64_t)s.O * s.Cg * 9, 256, 1024)), dim3(256), 0, st, s.O, s.Cg, s.groups, weight,
                (float *)nullptr, wd);
-    if (dp.bands > 1) {
+    int32_t *bins = reinterpret_cast<int32_t *>((char *)workspace + ws.bins);
+    PlanEntry *entries = reinterpret_cast<PlanEntry *>((char *)workspace + ws.entries);
+    if (!general) {
+        seq.launch(false, dcn_plan_taps, dim3(9, s.B), dim3(kPlanThreads), 0, st, H, W, gp.nw * 32, gp.rounds, offset, bins, entries);
+    } else if (dp.bands > 1) {
         const hipError_t e = hipMemsetAsync(grad_x, 0, (size_t)s.npos * s.C * 4, st);
         if (e != hipSuccess) return mmt::fail((int)e, "dcn_backward: hipMemsetAsync: %s", hipGetErrorString(e));
     }
@@ -703,15 +1030,29 @@ extern "C" int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, c
     }
     // data + offset gradient
     {
-        const unsigned grid = (unsigned)(s.B * dp.bands * s.groups * (s.Cg / 16));
-        if (s.Og == 128) {
-            if (int rc = set_lds(dcn_dgrad_mfma<128>, dp.lds, "dcn_backward")) return rc;
-            seq.launch(false, dcn_dgrad_mfma<128>, dim3(grid), dim3(dp.nw * 64), dp.lds, st, H, W, C, O, groups, s.npos, dp.bands, dp.band_rows, dp.halo,
-                       x, offset, (const float *)wd, grad_out, grad_x, part);
+        const int dbg = getenv("MMT_DCN_DGRAD_DEBUG") ? atoi(getenv("MMT_DCN_DGRAD_DEBUG")) : 0;
+        if (!general) {
+            const unsigned grid = (unsigned)(s.B * s.groups * (s.Cg / 16));
+            if (s.Og == 128) {
+                if (int rc = set_lds(dcn_dgrad_gather<128>, gp.lds, "dcn_backward")) return rc;
+                seq.launch(false, dcn_dgrad_gather<128>, dim3(grid), dim3(gp.nw * 64), gp.lds, st, H, W, C, O, groups, s.npos, gp.rounds, x, offset,
+                           (const float *)wd, grad_out, (const int32_t *)bins, (const PlanEntry *)entries, grad_x, part);
+            } else {
+                if (int rc = set_lds(dcn_dgrad_gather<64>, gp.lds, "dcn_backward")) return rc;
+                seq.launch(false, dcn_dgrad_gather<64>, dim3(grid), dim3(gp.nw * 64), gp.lds, st, H, W, C, O, groups, s.npos, gp.rounds, x, offset,
+                           (const float *)wd, grad_out, (const int32_t *)bins, (const PlanEntry *)entries, grad_x, part);
+            }
         } else {
-            if (int rc = set_lds(dcn_dgrad_mfma<64>, dp.lds, "dcn_backward")) return rc;
-            seq.launch(false, dcn_dgrad_mfma<64>, dim3(grid), dim3(dp.nw * 64), dp.lds, st, H, W, C, O, groups, s.npos, dp.bands, dp.band_rows, dp.halo,
-                       x, offset, (const float *)wd, grad_out, grad_x, part);
+            const unsigned grid = (unsigned)(s.B * dp.bands * s.groups * (s.Cg / 16));
+            if (s.Og == 128) {
+                if (int rc = set_lds(dcn_dgrad_mfma<128>, dp.lds, "dcn_backward")) return rc;
+                seq.launch(false, dcn_dgrad_mfma<128>, dim3(grid), dim3(dp.nw * 64), dp.lds, st, H, W, C, O, groups, s.npos, dp.bands, dp.band_rows, dp.halo,
+                           x, offset, (const float *)wd, grad_out, grad_x, part, dbg);
+            } else {
+                if (int rc = set_lds(dcn_dgrad_mfma<64>, dp.lds, "dcn_backward")) return rc;
+                seq.launch(false, dcn_dgrad_mfma<64>, dim3(grid), dim3(dp.nw * 64), dp.lds, st, H, W, C, O, groups, s.npos, dp.bands, dp.band_rows, dp.halo,
+                           x, offset, (const float *)wd, grad_out, grad_x, part, dbg);
+            }
         }
         seq.launch(true, dcn_offset_reduce_parts, dim3(mmt::stream_grid((int64_t)s.npos * 18, 256, 2048)), dim3(256), 0, st, s.npos, s.C / 16,
                    (const float *)part, grad_offset);

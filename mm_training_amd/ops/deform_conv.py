@@ -44,7 +44,7 @@ class _DeformConv3x3Mfma(Function):
         with torch.cuda.device(x.device):
             ws = _workspace(_lib.lib().mmt_dcn_mfma_workspace_bytes(B, H, W, C, O, groups), x.device)
             _lib.call("mmt_dcn_forward", B, H, W, C, O, groups, x_nhwc.data_ptr(), off_nhwc.data_ptr(), w.data_ptr(), out.data_ptr(),
-                      ws.data_ptr(), ws.numel(), int(os.environ.get("MMT_DCN_FWD_WAVES", "0")), _stream())
+                      ws.data_ptr(), ws.numel(), int(os.environ.get("MMT_DCN_FWD_CONFIG", "0")), _stream())
         ctx.save_for_backward(x_nhwc, off_nhwc, w)
         ctx.dims = (B, H, W, C, O, groups)
         return out.permute(0, 3, 1, 2)

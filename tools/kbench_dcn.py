@@ -36,13 +36,13 @@ def whole_op(res):
         hbm_bwd = 4.0 * (2 * x.numel() + 2 * off.numel() + 2 * w.numel() + B * H * W * O)
         entry = {"gflop_per_gemm": flop / 1e9, "algorithmic_MB_fwd": hbm_fwd / 1e6, "algorithmic_MB_bwd": hbm_bwd / 1e6}
         for name, columns in (("implicit_gemm", False), ("columns", True)):
-            for waves in ((0, 2, 3, 4) if not columns else (0,)):
-                os.environ["MMT_DCN_FWD_WAVES"] = str(waves)
+            for waves in ((0, 1, 2, 3, 4) if not columns else (0,)):
+                os.environ["MMT_DCN_FWD_CONFIG"] = str(waves)
                 tf = timeit(lambda: deform_conv3x3(x, off, w, groups, columns=columns))
-                key = name if waves == 0 else f"{name}_fwd_waves{waves}"
+                key = name if waves == 0 else f"{name}_fwd_config{waves}"
                 entry[key + "_fwd_ms"] = tf
                 entry[key + "_fwd_TFLOPs"] = flop / tf / 1e9
-            os.environ["MMT_DCN_FWD_WAVES"] = "0"
+            os.environ["MMT_DCN_FWD_CONFIG"] = "0"
             out = deform_conv3x3(x, off, w, groups, columns=columns)
             tb = timeit(lambda: torch.autograd.grad(out, (x, off, w), go, retain_graph=True))
             entry[name + "_bwd_ms"] = tb
