@@ -554,6 +554,40 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
 // The gather of (round, tap) is issued after the MFMAs + staging of the NEXT tap, so that waves drift apart and one wave's list
 // walk runs under another's matrix work.  Needs H*W*4 items <= 4 per thread (H*W <= 64 * waves <= 768) and rounds*H*W bins in
 // LDS; larger images take dcn_dgrad_mfma (the general, banded form).
+// what the offset gradient needs of a sampling point: the corner pixels, d(weight)/d(py, px), and which corners take part
+// (inside the image: a non-zero weight or a non-zero coordinate derivative)
+struct CornerInfo { int o[4]; float dy[4], dx[4]; unsigned live; };
+
+__device__ __forceinline__ CornerInfo corner_info(const Tap &t, bool valid) {
+    CornerInfo c;
+    c.o[0] = t.o1; c.o[1] = t.o2; c.o[2] = t.o3; c.o[3] = t.o4;
+    c.dy[0] = t.dy1; c.dy[1] = t.dy2; c.dy[2] = t.dy3; c.dy[3] = t.dy4;
+    c.dx[0] = t.dx1; c.dx[1] = t.dx2; c.dx[2] = t.dx3; c.dx[3] = t.dx4;
+    const float w[4] = {t.w1, t.w2, t.w3, t.w4};
+    c.live = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.live |= (valid && (w[i] != 0.f || c.dy[i] != 0.f || c.dx[i] != 0.f)) ? (1u << i) : 0u;
+    return c;
+}
+
+// (d/dy, d/dx) of one (pixel, tap) over this lane quarter's 4 channels, summed over the 4 quarters; lane quarter 0 stores
+__device__ __forceinline__ void offset_dots(const CornerInfo &c, f32x4 a4, const float4 (&xv)[4], bool store, float *pd, int npos) {
+    float gy = 0.f, gx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float d = __builtin_fmaf(a4[0], xv[i].x, __builtin_fmaf(a4[1], xv[i].y, __builtin_fmaf(a4[2], xv[i].z, a4[3] * xv[i].w)));
+        d = (c.live >> i) & 1 ? d : 0.f;
+        gy = __builtin_fmaf(c.dy[i], d, gy);
+        gx = __builtin_fmaf(c.dx[i], d, gx);
+    }
+    gy += __shfl_xor(gy, 16); gx += __shfl_xor(gx, 16);
+    gy += __shfl_xor(gy, 32); gx += __shfl_xor(gx, 32);
+    if (store) {
+        pd[0] = gy;
+        pd[npos] = gx;
+    }
+}
+
 struct PlanEntry { int src; float w; };     // source pixel inside the image, bilinear weight of the corner that lands here
 
 constexpr int kPlanThreads = 1024;
@@ -622,7 +656,7 @@ __global__ __launch_bounds__(kPlanThreads) void dcn_plan_taps(int H, int W, int 
 }
 
 constexpr int kGcLd = 20;        // floats per staged pixel row (16 channels, 80-byte rows: 16-byte aligned float4 slots)
-constexpr int kItems = 4;        // (pixel, 4-channel) destinations per thread
+constexpr int kItems = 1;        // destination pixels per thread (all 16 channels of the chunk each)
 
 template <int OG>
 __global__ __launch_bounds__(768) void dcn_dgrad_gather(int H, int W, int C, int O, int groups, int npos, int rounds,
@@ -632,6 +666,7 @@ __global__ __launch_bounds__(768) void dcn_dgrad_gather(int H, int W, int C, int
                                                         float *__restrict__ grad_x, float *__restrict__ part) {
     constexpr int KQ = OG / 4;
     constexpr int WLD = OG + 2;
+    constexpr int kPieces = 16 * OG / 64;       // 256-byte pieces of a weight tile (one LDS-DMA wave instruction each)
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int nth = blockDim.x, nw = nth >> 6, ppr = nw * 32;
@@ -646,93 +681,120 @@ __global__ __launch_bounds__(768) void dcn_dgrad_gather(int H, int W, int C, int
     float *wl = smem + 2 * ppr * kGcLd;                  // [2][16][WLD]
     const float *wdg = wd + ((size_t)g * 9 * Cg + chunk * 16) * OG;
     const float *gob = go + (size_t)b * HW * O + g * OG + kq * KQ;
-    const float *xb = x + (size_t)b * HW * C + cb + 4 * kq;
+    // corner rows of x: wave-uniform base + 32-bit byte offsets (B*H*W*C*4 < 2^32: dcn_shape)
+    const char *xbase = reinterpret_cast<const char *>(x + (size_t)b * HW * C + cb);
+    const unsigned xstride = (unsigned)C * 4, xlane = 16u * kq;
     const float *ofb = offset + (size_t)b * HW * 18;
     const int nbins = rounds * HW;
 
-    // the destinations this thread owns: item k = (pixel (tid + k*nth) >> 2, channels 4 * ((tid + k*nth) & 3) ..)
-    float4 sums[kItems];
+    // the destinations this thread owns: item k = pixel tid + k*nth, all 16 channels of the chunk.  Consecutive lanes own
+    // consecutive pixels, so the lists of a wave's 64 pixels of item k are ONE contiguous run of the entry array.
+    float4 sums[kItems][4];
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) sums[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < kItems; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sums[k][c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    bool wfill[2];
-    int wsrc[2], wdst[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int e = tid + k * nth;
-        wfill[k] = e < 4 * OG;
-        const int wc = e / (OG / 4), wo = (e % (OG / 4)) * 4;
-        wsrc[k] = wc * OG + wo;
-        wdst[k] = wc * WLD + wo;
-        if (wfill[k]) {
-            const float4 v = *reinterpret_cast<const float4 *>(wdg + wsrc[k]);
-            float *d = wl + wdst[k];
-            *reinterpret_cast<f32x2 *>(d) = f32x2{v.x, v.y};
-            *reinterpret_cast<f32x2 *>(d + 2) = f32x2{v.z, v.w};
-        }
-    }
-    __syncthreads();
-
-    // gather of unit u = rd * 9 + tap from staging buffer `sbuf`; lo / hi = the list bounds of this thread's items (prefetched)
-    auto gather = [&](int rd, int tap, int sbuf, const int (&lo)[kItems], const int (&hi)[kItems]) {
-        const PlanEntry *eb = entries + ((size_t)b * 9 + tap) * HW * 4;
-        const float *gb = gcs + sbuf * ppr * kGcLd - rd * ppr * kGcLd;
-#pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int quad = (tid + k * nth) & 3;
-            for (int e = lo[k]; e < hi[k]; ++e) {
-                const PlanEntry en = eb[e];
-                const float4 v = *reinterpret_cast<const float4 *>(gb + en.src * kGcLd + 4 * quad);
-                sums[k].x = __builtin_fmaf(en.w, v.x, sums[k].x);
-                sums[k].y = __builtin_fmaf(en.w, v.y, sums[k].y);
-                sums[k].z = __builtin_fmaf(en.w, v.z, sums[k].z);
-                sums[k].w = __builtin_fmaf(en.w, v.w, sums[k].w);
-            }
+    // weight tile of tap t -> wl[buf]: LDS-DMA, 64 lanes x 4 bytes per instruction (a 256-byte piece of a row; the rows are padded
+    // by 8 bytes, so wider pieces would cross the pad), the pieces dealt to the waves
+    auto fill_weights = [&](int tap, int buf) {
+        for (int pc = wave; pc < kPieces; pc += nw) {
+            const int row = pc / (OG / 64), hf = pc - row * (OG / 64);
+            const float *src = wdg + ((size_t)tap * Cg + row) * OG + hf * 64 + lane;
+            float *dst = wl + (buf * 16 + row) * WLD + hf * 64;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
         }
     };
-    auto bounds = [&](int rd, int tap, int (&lo)[kItems], int (&hi)[kItems]) {
+    fill_weights(0, 0);
+
+    // list bounds of unit (rd, tap) for this thread's items; pixels past the image get the (empty) end of the round's run
+    int lo[kItems], hi[kItems];
+    auto bounds = [&](int rd, int tap) {
         const int32_t *bo = bin_off + ((size_t)b * 9 + tap) * (nbins + 1) + rd * HW;
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
-            const int q = (tid + k * nth) >> 2;
-            const bool on = q < HW;
-            lo[k] = on ? bo[q] : 0;
-            hi[k] = on ? bo[q + 1] : 0;
+            const int q = min(tid + k * nth, HW);
+            lo[k] = bo[q];
+            hi[k] = bo[min(q + 1, HW)];
+        }
+    };
+    // the wave's run of entries per item: lane l holds entry run_lo + l (runs longer than 64 entries: the rest is read in place)
+    int esrc[kItems];
+    float ew[kItems];
+    auto prefetch_entries = [&](int tap) {
+        const PlanEntry *eb = entries + ((size_t)b * 9 + tap) * HW * 4;
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int rlo = __builtin_amdgcn_readfirstlane(lo[k]), rhi = __builtin_amdgcn_readlane(hi[k], 63);
+            const int e = min(rlo + lane, max(rhi - 1, rlo));
+            const PlanEntry en = rhi > rlo ? eb[e] : PlanEntry{0, 0.f};
+            esrc[k] = en.src;
+            ew[k] = en.w;
+        }
+    };
+    auto gather_item = [&](int k, int rd, int tap, int sbuf) {
+        const PlanEntry *eb = entries + ((size_t)b * 9 + tap) * HW * 4;
+        const float *gb = gcs + (sbuf * ppr - rd * ppr) * kGcLd;
+        const int rlo = __builtin_amdgcn_readfirstlane(lo[k]);
+        const int n = hi[k] - lo[k];
+        for (int j = 0; __any(j < n); ++j) {
+            const int idx = lo[k] + j - rlo;
+            int src = __shfl(esrc[k], idx & 63);
+            float w = __shfl(ew[k], idx & 63);
+            if (j < n) {
+                if (idx >= 64) { const PlanEntry en = eb[lo[k] + j]; src = en.src; w = en.w; }
+                const float *row = gb + src * kGcLd;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 v = *reinterpret_cast<const float4 *>(row + 4 * c);
+                    sums[k][c].x = __builtin_fmaf(w, v.x, sums[k][c].x);
+                    sums[k][c].y = __builtin_fmaf(w, v.y, sums[k][c].y);
+                    sums[k][c].z = __builtin_fmaf(w, v.z, sums[k][c].z);
+                    sums[k][c].w = __builtin_fmaf(w, v.w, sums[k][c].w);
+                }
+            }
         }
     };
 
+    __syncthreads();
     int buf = 0;
     for (int rd = 0; rd < rounds; ++rd) {
         const int tile = rd * nw + wave;
         const bool active = tile < ntiles;
         float gq[2][KQ];
-        int pp[2];
+        int phw[2];               // the sub-tile's pixel of this lane as (row << 16) | column (registers are what this kernel is short of)
         bool valid[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            pp[sub] = tile * 32 + sub * 16 + l15;
-            valid[sub] = active && pp[sub] < HW;
-            if (!valid[sub]) pp[sub] = 0;
-            const float *src = gob + (size_t)pp[sub] * O;
+            int p = tile * 32 + sub * 16 + l15;
+            valid[sub] = active && p < HW;
+            if (!valid[sub]) p = 0;
+            const int h = p / W;
+            phw[sub] = (h << 16) | (p - h * W);
+            const float *src = gob + (size_t)p * O;
 #pragma unroll
             for (int j = 0; j < KQ / 4; ++j) {
                 const float4 v = valid[sub] ? *reinterpret_cast<const float4 *>(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
                 gq[sub][4 * j] = v.x; gq[sub][4 * j + 1] = v.y; gq[sub][4 * j + 2] = v.z; gq[sub][4 * j + 3] = v.w;
             }
         }
+        float2 onext[2];        // the two pixels' offsets of the tap about to be processed (loaded a unit ahead)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) onext[sub] = *reinterpret_cast<const float2 *>(ofb + (size_t)((phw[sub] >> 16) * W + (phw[sub] & 0xFFFF)) * 18);
         for (int tap = 0; tap < 9; ++tap) {
             const int u = rd * 9 + tap;
-            const bool pre = tap < 8 || rd + 1 < rounds;      // the next tap's weight tile (tap 0 again for the next round)
-            float4 vw[2];
+            const int prd = tap == 0 ? rd - 1 : rd, ptap = tap == 0 ? 8 : tap - 1;     // the unit whose staged tile is gathered now
+            // the next tap's weight tile (tap 0 again for the next round) into the other buffer: last read before the barrier
+            if (tap < 8 || rd + 1 < rounds) fill_weights(tap == 8 ? 0 : tap + 1, buf ^ 1);
+            if (u > 0) prefetch_entries(ptap);          // (the bounds of the previous unit were loaded at its end)
+            const int ky = tap / 3, kx = tap - ky * 3;
+            // sub-tile 0: sampling point and corner rows before the matrix work (the rows arrive under it)
+            CornerInfo c0 = corner_info(mmt_dcn::make_tap((float)((phw[0] >> 16) + ky - 1) + onext[0].x, (float)((phw[0] & 0xFFFF) + kx - 1) + onext[0].y, H, W), valid[0]);
+            float4 xv[4];
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-                if (pre && wfill[k]) vw[k] = *reinterpret_cast<const float4 *>(wdg + (size_t)(tap == 8 ? 0 : tap + 1) * Cg * OG + wsrc[k]);
-            // list bounds of the PREVIOUS unit (its staged tile is complete: the barrier that ended it)
-            int lo[kItems], hi[kItems];
-            const int prd = tap == 0 ? rd - 1 : rd, ptap = tap == 0 ? 8 : tap - 1;
-            if (u > 0) bounds(prd, ptap, lo, hi);
+            for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xbase + ((unsigned)c0.o[i] * xstride + xlane));
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            const float *ar = wl + (buf & 1) * 16 * WLD + l15 * WLD + kq * KQ;
+            const float *ar = wl + buf * 16 * WLD + l15 * WLD + kq * KQ;
 #pragma unroll
             for (int s = 0; s < KQ / 2; ++s) {
                 const f32x2 a = *reinterpret_cast<const f32x2 *>(ar + 2 * s);
@@ -741,59 +803,42 @@ __global__ __launch_bounds__(768) void dcn_dgrad_gather(int H, int W, int C, int
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[0][2 * s + 1], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[1][2 * s + 1], acc[1], 0, 0, 0);
             }
+            float *pd = part + ((size_t)(cglob * 9 + tap) * 2) * npos + (size_t)b * HW;
+            // stage gc[pixel of the round][4 channels of this lane] (pixels past the image stage zeros: never listed)
+            float *sg = gcs + (buf * ppr + wave * 32 + l15) * kGcLd + 4 * kq;
+            *reinterpret_cast<f32x4 *>(sg) = acc[0];
+            *reinterpret_cast<f32x4 *>(sg + 16 * kGcLd) = acc[1];
+            offset_dots(c0, acc[0], xv, kq == 0 && valid[0], pd + ((phw[0] >> 16) * W + (phw[0] & 0xFFFF)), npos);
+            // sub-tile 1: its corner rows arrive under the previous unit's gather
+            CornerInfo c1 = corner_info(mmt_dcn::make_tap((float)((phw[1] >> 16) + ky - 1) + onext[1].x, (float)((phw[1] & 0xFFFF) + kx - 1) + onext[1].y, H, W), valid[1]);
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int p = pp[sub];
-                const int h = p / W, w = p - h * W;
-                const Tap t = tap_at(h, w, tap, ofb + (size_t)p * 18, H, W);
-                const float tw[4] = {t.w1, t.w2, t.w3, t.w4}, tdy[4] = {t.dy1, t.dy2, t.dy3, t.dy4}, tdx[4] = {t.dx1, t.dx2, t.dx3, t.dx4};
-                const int to[4] = {t.o1, t.o2, t.o3, t.o4};
-                const f32x4 a4 = acc[sub];
-                float4 xv[4];
+            for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xbase + ((unsigned)c1.o[i] * xstride + xlane));
+            if (u > 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xb + (size_t)to[i] * C);
-                float gy = 0.f, gx = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // the corner takes part when it is inside the image: a non-zero weight or a non-zero coordinate derivative
-                    const bool live = valid[sub] && (tw[i] != 0.f || tdy[i] != 0.f || tdx[i] != 0.f);
-                    float d = __builtin_fmaf(a4[0], xv[i].x, __builtin_fmaf(a4[1], xv[i].y, __builtin_fmaf(a4[2], xv[i].z, a4[3] * xv[i].w)));
-                    d = live ? d : 0.f;
-                    gy = __builtin_fmaf(tdy[i], d, gy);
-                    gx = __builtin_fmaf(tdx[i], d, gx);
-                }
-                gy += __shfl_xor(gy, 16); gx += __shfl_xor(gx, 16);
-                gy += __shfl_xor(gy, 32); gx += __shfl_xor(gx, 32);
-                if (kq == 0 && valid[sub]) {
-                    float *pd = part + ((size_t)(cglob * 9 + tap) * 2) * npos + (size_t)b * HW + p;
-                    pd[0] = gy;
-                    pd[npos] = gx;
-                }
-                // stage gc[pixel of the round][4 channels of this lane] (pixels past the image stage zeros: never listed)
-                *reinterpret_cast<f32x4 *>(gcs + ((buf & 1) * ppr + wave * 32 + sub * 16 + l15) * kGcLd + 4 * kq) = a4;
+                for (int k = 0; k < kItems; ++k) gather_item(k, prd, ptap, buf ^ 1);
             }
+            offset_dots(c1, acc[1], xv, kq == 0 && valid[1], pd + ((phw[1] >> 16) * W + (phw[1] & 0xFFFF)), npos);
+            if (tap < 8) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-                if (pre && wfill[k]) {
-                    float *d = wl + ((buf & 1) ^ 1) * 16 * WLD + wdst[k];
-                    *reinterpret_cast<f32x2 *>(d) = f32x2{vw[k].x, vw[k].y};
-                    *reinterpret_cast<f32x2 *>(d + 2) = f32x2{vw[k].z, vw[k].w};
-                }
-            if (u > 0) gather(prd, ptap, (buf & 1) ^ 1, lo, hi);
+                for (int sub = 0; sub < 2; ++sub)
+                    onext[sub] = *reinterpret_cast<const float2 *>(ofb + (size_t)((phw[sub] >> 16) * W + (phw[sub] & 0xFFFF)) * 18 + 2 * (tap + 1));
+            }
+            bounds(rd, tap);                 // for the gather of THIS unit, one unit from now
             buf ^= 1;
             __syncthreads();
         }
     }
-    {
-        int lo[kItems], hi[kItems];
-        bounds(rounds - 1, 8, lo, hi);
-        gather(rounds - 1, 8, (buf & 1) ^ 1, lo, hi);
-    }
+    prefetch_entries(8);
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) gather_item(k, rounds - 1, 8, buf ^ 1);
     float *gxb = grad_x + (size_t)b * HW * C + cb;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
-        const int idx = tid + k * nth, q = idx >> 2, quad = idx & 3;
-        if (q < HW) *reinterpret_cast<float4 *>(gxb + (size_t)q * C + 4 * quad) = sums[k];
+        const int q = tid + k * nth;
+        if (q < HW) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<float4 *>(gxb + (size_t)q * C + 4 * c) = sums[k][c];
+        }
     }
 }
 
@@ -864,7 +909,7 @@ GatherPlan gather_plan(const DcnShape &s) {
     const int HW = s.H * s.W, ntiles = (HW + 31) / 32;
     double beff = 0.0;
     for (int nw = 4; nw <= kMaxWaves; ++nw) {
-        if (HW * 4 > kItems * nw * 64) continue;
+        if (HW > kItems * nw * 64) continue;
         const int rounds = (ntiles + nw - 1) / nw;
         const double eff = (double)ntiles / ((double)rounds * nw);
         if (eff > beff + 1e-9) { beff = eff; p.nw = nw; p.rounds = rounds; }
@@ -876,10 +921,10 @@ GatherPlan gather_plan(const DcnShape &s) {
 }
 
 int wgrad_splits(const DcnShape &s) {
-    // workgroups = splits * groups * 9 * (Cg/TC) * (Og/TO); two fit a CU: aim at one full round of 512
-    const int tc = s.Cg % 128 == 0 ? 128 : 64, to = s.Og % 128 == 0 ? 128 : 64;
+    // workgroups = splits * groups * 9 * (Cg/TC) * (Og/TO); three fit a CU: aim at one full round of 768
+    const int tc = 64, to = s.Og % 128 == 0 ? 128 : 64;
     const int tiles = s.groups * 9 * (s.Cg / tc) * (s.Og / to);
-    int splits = 512 / tiles;
+    int splits = 768 / tiles;
     const int nblk = (s.npos + 31) / 32;
     if (splits > nblk / 4) splits = nblk / 4;       // at least 4 K-steps per slice
     if (splits < 1) splits = 1;
@@ -1014,7 +1059,9 @@ extern "C" int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, c
     }
     // weight gradient
     {
-        const int tc = s.Cg % 128 == 0 ? 128 : 64, to = s.Og % 128 == 0 ? 128 : 64;
+        // 64 input x 128 output channels per workgroup (48 KB of LDS: three per CU) and 768 / tiles pixel slices measured best at
+        // [24,512,16,44] g=4 (tools/scratch/dcn_wgrad_tiles.py: 128 x 128 / 512 slots +60 us)
+        const int tc = 64, to = s.Og % 128 == 0 ? 128 : 64;
         const size_t lds = (size_t)2 * 32 * (tc + to) * 4 + 2 * 32 * sizeof(TapRec);
         const unsigned grid = (unsigned)(ws.splits * s.groups * 9 * (s.Cg / tc) * (s.Og / to));
 #define MMT_DCN_WG(TC, TO)                                                                                                    \
@@ -1023,7 +1070,7 @@ extern "C" int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, c
         seq.launch(false, dcn_wgrad_mfma<TC, TO>, dim3(grid), dim3(256), lds, st, H, W, C, O, groups, s.npos, ws.splits, x, offset, \
                    grad_out, slab);                                                                                           \
     }
-        if (tc == 128 && to == 128) MMT_DCN_WG(128, 128) else if (tc == 128) MMT_DCN_WG(128, 64) else if (to == 128) MMT_DCN_WG(64, 128) else MMT_DCN_WG(64, 64)
+        if (to == 128) MMT_DCN_WG(64, 128) else MMT_DCN_WG(64, 64)
 #undef MMT_DCN_WG
         seq.launch(false, dcn_wgrad_reduce, dim3(mmt::stream_grid((int64_t)s.O * s.Cg * 9, 256, 2048)), dim3(256), 0, st, ws.splits, s.groups, s.Cg,
                    s.Og, (const float *)slab, grad_weight);
