@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide ("L2 (per XCD)")
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): same guide, "Matrix cores" (= the fp32 vector peak)
 ATOMIC_PEAK_GBS = 1300.0  # chip-wide memory-side fp32 atomic-add rate, same guide ("Global float atomics": 1.26-1.36 TB/s of added bytes)
 
 WORKLOADS = {
@@ -369,12 +370,18 @@ def lidar_bytes(F, total_points, M, nf, C, B, ny, nx, voxels_T=0, sampled=None):
     return vox, scat, scat_bwd
 
 
-def pmc_traffic(config, kernels):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary OF THIS CONFIGURATION (separate FETCH_SIZE /
-    WRITE_SIZE passes with the gfx950 correction; tools/collect_profiles.sh writes profiles/r02_pmc_<config>.json).
-    PMC collection cannot run inside this process; None when the shape has no summary."""
-    for rnd in ("r05", "r04", "r03", "r02"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{config}.json")
+PMC_RIG = "analytic"      # set by train_main: the camera rig of the run (the summaries are per configuration AND rig)
+
+
+def pmc_traffic(config, kernels, rig=None):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary OF THIS CONFIGURATION AND CAMERA RIG (separate FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 correction; tools/collect_profiles.sh writes profiles/rNN_pmc_<config>[_<rig>].json, no
+    suffix = the analytic level rig).  PMC collection cannot run inside this process; None when no summary of that
+    configuration and rig exists, or the newest one lacks a kernel (it was not measured -- never "as on another rig")."""
+    rig = PMC_RIG if rig is None else rig
+    tag = config if rig == "analytic" else f"{config}_{rig.replace(':', '_')}"
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{tag}.json")
         if not os.path.exists(path):
             continue                  # an older round's summary stands in only while this round has none for the configuration
         try:
@@ -671,6 +678,8 @@ def train_main(args, rank, local_rank, world):
     from mm_training_amd import _lib
     from mm_training_amd.dp import TrainStep, make_config, synthetic_batch
     _lib.lib()
+    global PMC_RIG
+    PMC_RIG = args.rig
     # benchmark=True makes PyTorch ask MIOpen's find API, which is answered from the find DB
     # (only for the configurations the DB was produced on: an unknown shape would start a search)
     db_cfg = SHIPPED_MIOPEN_DB and args.config in ("cfg2", "cfg3", "cfg4", "cfg5")
@@ -876,6 +885,44 @@ def train_main(args, rank, local_rank, world):
         res["roofline_softmax"] = roofline_entry("depth_softmax_fwd (depth distribution + oracle overwrite, pixel-major; lss_fpn.py:423-438)", sm_f, t_f,
                                                  pmc_traffic(args.config, ("depth_softmax_fwd",)))
         res["roofline_softmax"]["backward"] = roofline_entry("depth_softmax_bwd", sm_b, t_b, pmc_traffic(args.config, ("depth_softmax_bwd",)))
+    if cfg["use_cam"] and timing.get("dcn_forward") and timing.get("dcn_backward"):
+        # DepthNet's deformable convolution (lss_fpn.py:189-197) as implicit GEMMs: bound by the fp32 matrix rate
+        # (exact-fp32 MFMA), the HBM side beside it.  One GEMM forward, two backward (weight + data gradient).
+        dcn = [m for m in ts.model.modules() if type(m).__name__ == "DeformConv2dPack"][0]
+        dB, dC, dH, dW, dO, dG = dcn.last_shape
+        flop = 2.0 * dB * dH * dW * 9 * (dC // dG) * dO
+        io_f = 4.0 * (dB * dH * dW * (dC + 18 + dO) + dcn.weight.numel())
+        io_b = 4.0 * (dB * dH * dW * (2 * dC + 2 * 18 + dO) + 2 * dcn.weight.numel())
+        t_f, t_b = _lib.mean_ms(timing["dcn_forward"]), _lib.mean_ms(timing["dcn_backward"])
+
+        def dcn_entry(kernels, nflop, nbytes, ms):
+            tf = nflop / (ms * 1e-3) / 1e12
+            e = {"bound": "mfma", "kernel": kernels, "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                 "flop": nflop, "avg_ms": ms, "algorithmic_bytes": nbytes,
+                 "hbm_side": {"achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            return e
+        fwd_k = ("dcn_pack_weights", "dcn_fwd_mfma")
+        bwd_k = ("dcn_pack_weights", "dcn_plan_taps", "dcn_wgrad_mfma", "dcn_wgrad_reduce", "dcn_dgrad_gather", "dcn_offset_reduce_parts")
+        r = dcn_entry(" + ".join(fwd_k) + " (deformable 3x3 convolution forward as one implicit GEMM: taps sampled into LDS, no column buffer)",
+                      flop, io_f, t_f)
+        r["traffic"] = pmc_traffic(args.config, fwd_k)
+        r["shape"] = {"x": [dB, dC, dH, dW], "out_channels": dO, "groups": dG, "operands": "f32", "accumulate": "f32 (v_mfma_f32_32x32x2_f32)"}
+        r["backward"] = dcn_entry(" + ".join(bwd_k) + " (weight gradient + data / offset gradient: two implicit GEMMs, the scatter of the data "
+                                  "gradient as a gather through per-destination lists)", 2 * flop, io_b, t_b)
+        r["backward"]["traffic"] = pmc_traffic(args.config, bwd_k)
+        r["note"] = ("x + offsets + weights + out (and their gradients) are the algorithmic bytes: the [B*H*W, 9*C] fp32 columns of the im2col form "
+                     "(311 MB at this shape, written once and read by three GEMM passes) no longer exist")
+        res["roofline_dcn"] = r
+    if cfg["use_cam"] and timing.get("bev_warp"):
+        # BEV augmentation warp of the pooled camera map into the camera|LiDAR buffer (models/bev_depth.py:69-84):
+        # forward = every output cell reads 4 input rows (a row is read by ~4 cells: L2 hits) and writes one; backward = the same gather transposed
+        nxw, nyw = vn[0], vn[1]
+        wb = 4.0 * B * nyw * nxw * ts.model.backbone.output_channels
+        res["roofline_bev_warp"] = roofline_entry("bev_warp_kernel (bilinear affine warp, channels-last, into the concat buffer)", 2 * wb,
+                                                  _lib.mean_ms(timing["bev_warp"]), pmc_traffic(args.config, ("bev_warp_kernel",)))
+        if timing.get("bev_warp_backward"):
+            res["roofline_bev_warp"]["backward"] = roofline_entry("bev_warp_backward_gather (the warp's adjoint as a gather: bit-reproducible)", 2 * wb,
+                                                                  _lib.mean_ms(timing["bev_warp_backward"]), pmc_traffic(args.config, ("bev_warp_backward_gather",)))
     if cfg["use_lidar"] and timing.get("voxelize") and timing.get("scatter"):
         enc = ts.model.lidar_encoder
         from mm_training_amd.lidar import hard_voxelize_mean_batch

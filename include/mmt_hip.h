@@ -291,6 +291,11 @@ int mmt_dcn_col2im_sorted(int B, int H, int W, int C, int groups, const float *x
  * fwd_config: 0 = let the library choose the forward's workgroup shape; 1-4 = (3x2, 2x2, 4x1, 4x2) waves along (pixels x
  * output channels), 32 pixels per wave row (a tuning knob for the A/B tools). */
 int mmt_dcn_mfma_supported(int B, int H, int W, int C, int O, int groups);
+/* which data-gradient kernel mmt_dcn_backward runs for this shape: 0 = shape not supported, 2 = the gather form (H*W <= 768:
+ * per-destination lists, no float atomics, grad_x written once), 1 = the general banded form (LDS windows summed with
+ * ds_add_f32 -- 192 cycles per wave instruction on gfx950, tools/ubench/lds_atomic.hip: correct for any image, 3-4x slower
+ * than the column form; callers with large images should rebuild the columns for the backward instead, as ops/deform_conv.py does) */
+int mmt_dcn_backward_form(int B, int H, int W, int C, int O, int groups);
 int64_t mmt_dcn_mfma_workspace_bytes(int B, int H, int W, int C, int O, int groups);
 int mmt_dcn_forward(int B, int H, int W, int C, int O, int groups, const float *x, const float *offset, const float *weight,
                     float *out, void *workspace, int64_t workspace_bytes, int fwd_config, void *stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mmt_dcn_col2im_workspace_elems": (_c_i64, [_c_int] * 3),
     "mmt_dcn_col2im_sorted": (_c_int, [_c_int] * 5 + [_c_ptr] * 6 + [_c_i64, _c_ptr]),
     "mmt_dcn_mfma_supported": (_c_int, [_c_int] * 6),
+    "mmt_dcn_backward_form": (_c_int, [_c_int] * 6),
     "mmt_dcn_mfma_workspace_bytes": (_c_i64, [_c_int] * 6),
     "mmt_dcn_forward": (_c_int, [_c_int] * 6 + [_c_ptr] * 5 + [_c_i64, _c_int, _c_ptr]),
     "mmt_dcn_backward": (_c_int, [_c_int] * 6 + [_c_ptr] * 8 + [_c_i64, _c_ptr]),

@@ -168,7 +168,8 @@ extern "C" int mmt_bev_warp_affine(int B, int H, int W, int C, const float *bda_
     if (int rc = check("bev_warp_affine", B, H, W, C, bda_mat, input, output, in_row_stride, out_row_stride)) return rc;
     WarpArgs a{B, H, W, C, in_row_stride, out_row_stride, bda_mat, input, output};
     const int64_t work = (int64_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(bev_warp_kernel, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    mmt::TimedSeq seq;      // (kernel timing for the bench: mmt_arm_kernel_timing)
+    seq.launch(true, bev_warp_kernel, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
     return mmt::check_launch("bev_warp_affine");
 }
 
@@ -182,6 +183,7 @@ extern "C" int mmt_bev_warp_affine_backward(int B, int H, int W, int C, const fl
         return mmt::fail(MMT_ERR_TOO_LARGE, "bev_warp_affine_backward: grad_output spans 2 GiB or more");
     WarpArgs a{B, H, W, C, grad_out_row_stride, grad_in_row_stride, bda_mat, grad_output, grad_input};
     const int64_t work = (int64_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(bev_warp_backward_gather, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    mmt::TimedSeq seq;
+    seq.launch(true, bev_warp_backward_gather, dim3(mmt::stream_grid(work, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
     return mmt::check_launch("bev_warp_affine_backward");
 }

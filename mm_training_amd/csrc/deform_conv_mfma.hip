@@ -392,7 +392,7 @@ template <int OG>
 __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O, int groups, int npos, int bands, int band_rows, int halo,
                                                       const float *__restrict__ x, const float *__restrict__ offset,
                                                       const float *__restrict__ wd, const float *__restrict__ go,
-                                                      float *__restrict__ grad_x, float *__restrict__ part, int dbg) {
+                                                      float *__restrict__ grad_x, float *__restrict__ part) {
     constexpr int KQ = OG / 4;        // output channels (k values) per lane quarter
     constexpr int WLD = OG + 2;       // weight-tile row stride: ds_read_b64 of lane (c, kq) at c*WLD + kq*KQ is conflict-free
     extern __shared__ __align__(16) float smem[];
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             const float *ar = wl + buf * 16 * WLD + l15 * WLD + kq * KQ;
 #pragma unroll
-            for (int s = 0; s < ((dbg & 4) ? 1 : KQ / 2); ++s) {
+            for (int s = 0; s < KQ / 2; ++s) {
                 const f32x2 a = *reinterpret_cast<const f32x2 *>(ar + 2 * s);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[0][2 * s], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[1][2 * s], acc[1], 0, 0, 0);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
                 const f32x4 a4 = acc[sub];
                 float4 xv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xv[i] = (dbg & 2) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4 *>(xb + (size_t)to[i] * C);
+                for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xb + (size_t)to[i] * C);
                 float gy = 0.f, gx = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(768) void dcn_dgrad_mfma(int H, int W, int C, int O
                     d = live ? d : 0.f;
                     gy = __builtin_fmaf(tdy[i], d, gy);
                     gx = __builtin_fmaf(tdx[i], d, gx);
-                    if (valid[sub] && tw[i] != 0.f && !(dbg & 1)) {
+                    if (valid[sub] && tw[i] != 0.f) {
                         const int wp = to[i] - wpix0;
                         if ((unsigned)wp < (unsigned)wnpix) {
                             float *dst = win + wp * kWinLd + 4 * kq;
@@ -976,6 +976,12 @@ extern "C" int mmt_dcn_mfma_supported(int B, int H, int W, int C, int O, int gro
     return dcn_shape(B, H, W, C, O, groups, &s, "dcn_mfma_supported", true) == 0 ? 1 : 0;
 }
 
+extern "C" int mmt_dcn_backward_form(int B, int H, int W, int C, int O, int groups) {
+    DcnShape s;
+    if (dcn_shape(B, H, W, C, O, groups, &s, "dcn_backward_form", true) != 0) return 0;
+    return gather_plan(s).ok ? 2 : 1;
+}
+
 extern "C" int64_t mmt_dcn_mfma_workspace_bytes(int B, int H, int W, int C, int O, int groups) {
     DcnShape s;
     if (dcn_shape(B, H, W, C, O, groups, &s, "dcn_mfma_workspace_bytes", true) != 0) return 0;
@@ -1077,7 +1083,6 @@ extern "C" int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, c
     }
     // data + offset gradient
     {
-        const int dbg = getenv("MMT_DCN_DGRAD_DEBUG") ? atoi(getenv("MMT_DCN_DGRAD_DEBUG")) : 0;
         if (!general) {
             const unsigned grid = (unsigned)(s.B * s.groups * (s.Cg / 16));
             if (s.Og == 128) {
@@ -1094,11 +1099,11 @@ extern "C" int mmt_dcn_backward(int B, int H, int W, int C, int O, int groups, c
             if (s.Og == 128) {
                 if (int rc = set_lds(dcn_dgrad_mfma<128>, dp.lds, "dcn_backward")) return rc;
                 seq.launch(false, dcn_dgrad_mfma<128>, dim3(grid), dim3(dp.nw * 64), dp.lds, st, H, W, C, O, groups, s.npos, dp.bands, dp.band_rows, dp.halo,
-                           x, offset, (const float *)wd, grad_out, grad_x, part, dbg);
+                           x, offset, (const float *)wd, grad_out, grad_x, part);
             } else {
                 if (int rc = set_lds(dcn_dgrad_mfma<64>, dp.lds, "dcn_backward")) return rc;
                 seq.launch(false, dcn_dgrad_mfma<64>, dim3(grid), dim3(dp.nw * 64), dp.lds, st, H, W, C, O, groups, s.npos, dp.bands, dp.band_rows, dp.halo,
-                           x, offset, (const float *)wd, grad_out, grad_x, part, dbg);
+                           x, offset, (const float *)wd, grad_out, grad_x, part);
             }
         }
         seq.launch(true, dcn_offset_reduce_parts, dim3(mmt::stream_grid((int64_t)s.npos * 18, 256, 2048)), dim3(256), 0, st, s.npos, s.C / 16,

@@ -182,7 +182,8 @@ class DeformConv2dPack(nn.Module):
 
     def forward(self, x):
         offset = self.conv_offset(x)
-        from ..ops.deform_conv import deform_conv3x3              # HIP im2col/col2im + rocBLAS GEMMs
+        from ..ops.deform_conv import deform_conv3x3              # implicit GEMMs on the matrix cores (csrc/deform_conv_mfma.hip)
+        self.last_shape = (x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.weight.shape[0], self.groups)   # (bench.py's roofline_dcn)
         with torch.autocast("cuda", enabled=False):
             return deform_conv3x3(x, offset, self.weight, self.groups)   # raises for CPU tensors: no fallback
 

@@ -37,7 +37,7 @@ class BevWarpConcat(Function):
         out = torch.empty((B, C + c_other, H, W), dtype=torch.float32, device=x.device,
                           memory_format=torch.channels_last)
         with torch.cuda.device(x.device):
-            _lib.call("mmt_bev_warp_affine", B, H, W, C, bda.data_ptr(), x.data_ptr(), C, out.data_ptr(), C + c_other, _stream())
+            _lib.timed_call("bev_warp", "mmt_bev_warp_affine", B, H, W, C, bda.data_ptr(), x.data_ptr(), C, out.data_ptr(), C + c_other, _stream())
         if other is not None:
             out[:, C:] = other
         ctx.save_for_backward(bda)
@@ -51,7 +51,7 @@ class BevWarpConcat(Function):
         grad_out = _channels_last(grad_out, "grad_out")
         grad_x = torch.zeros((B, H, W, C), dtype=torch.float32, device=grad_out.device).permute(0, 3, 1, 2)
         with torch.cuda.device(grad_out.device):
-            _lib.call("mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + c_other,
+            _lib.timed_call("bev_warp_backward", "mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + c_other,
                       grad_x.data_ptr(), C, _stream())
         grad_other = grad_out[:, C:] if c_other else None
         return grad_x, None, grad_other
@@ -83,7 +83,7 @@ class BevWarpConcatPillars(Function):
         lidar_ptr = out.data_ptr() + 4 * C
         cell_map = None
         with torch.cuda.device(x.device):
-            _lib.call("mmt_bev_warp_affine", B, H, W, C, bda.data_ptr(), x.data_ptr(), C, out.data_ptr(), C + Cl, _stream())
+            _lib.timed_call("bev_warp", "mmt_bev_warp_affine", B, H, W, C, bda.data_ptr(), x.data_ptr(), C, out.data_ptr(), C + Cl, _stream())
             if table is not None:
                 _lib.timed_call("scatter", "mmt_pillar_scatter_nhwc_table_strided", Cl, B, ny, nx, max_voxels, sy, sx,
                                 feats.data_ptr(), table.data_ptr(), lidar_ptr, C + Cl, _stream())
@@ -105,7 +105,7 @@ class BevWarpConcatPillars(Function):
         with torch.cuda.device(grad_out.device):
             if ctx.needs_input_grad[0]:
                 grad_x = torch.zeros((B, H, W, C), dtype=torch.float32, device=grad_out.device).permute(0, 3, 1, 2)
-                _lib.call("mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + Cl,
+                _lib.timed_call("bev_warp_backward", "mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + Cl,
                           grad_x.data_ptr(), C, _stream())
             if ctx.needs_input_grad[2]:
                 grad_feats = torch.empty((M, Cl), dtype=torch.float32, device=grad_out.device)

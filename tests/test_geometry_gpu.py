@@ -121,23 +121,25 @@ def test_deform_conv_matches_torch_reference(mmt_lib, shape):
         assert (a - b).abs().max().item() <= tol, name
 
 
-# (B, C, H, W, O, groups, offset scale, expected bands of the data gradient's LDS window)
-MFMA_SHAPES = [(2, 128, 5, 7, 128, 2, 0.4, 1), (3, 256, 16, 44, 256, 2, 1.5, 1), (2, 128, 9, 13, 256, 2, 0.0, 1), (24, 512, 16, 44, 512, 4, 0.7, 1),
-               (2, 64, 150, 40, 64, 1, 2.5, 3), (1, 512, 32, 88, 512, 4, 1.0, 2)]
+# (B, C, H, W, O, groups, offset scale, the data gradient's form: 2 = gather (H*W <= 768), 1 = general banded LDS windows)
+MFMA_SHAPES = [(2, 128, 5, 7, 128, 2, 0.4, 2), (3, 256, 16, 44, 256, 2, 1.5, 2), (2, 128, 9, 13, 256, 2, 0.0, 2), (24, 512, 16, 44, 512, 4, 0.7, 2),
+               (2, 64, 150, 40, 64, 1, 2.5, 1), (1, 512, 32, 88, 512, 4, 1.0, 1)]
 
 
 @pytest.mark.parametrize("shape", MFMA_SHAPES)
-def test_deform_conv_implicit_gemm(mmt_lib, shape):
+def test_deform_conv_implicit_gemm(mmt_lib, shape, monkeypatch):
     """Row f2: mmt_dcn_forward / mmt_dcn_backward (implicit GEMMs on the fp32 matrix cores, no column buffer) against
     (a) an fp64 evaluation of the torch restatement of mmcv's operator (DeformConv2dPack.forward_reference; PARITY UNPINNED upstream,
     see the test above), 1e-4 of the result's scale, and (b) the im2col / col2im + GEMM form of this library on the same inputs.
     Shapes: 64- and 128-wide weight groups, zero offsets (integer sampling points), offsets of several pixels with one pixel's
     taps far outside / on half pixels / at the border, pixel counts that are no multiple of any tile, and two images whose
-    rows do not fit one LDS window (banded data gradient, global-atomic flush + strays)."""
+    pixels exceed the gather form of the data gradient: there ops/deform_conv.py rebuilds the columns for the backward (the
+    default) and the library's general kernel (banded LDS windows, global-atomic flush + strays) is run as well."""
     from mm_training_amd.layers.nets import DeformConv2dPack
     from mm_training_amd.ops.deform_conv import deform_conv3x3
-    B, C, H, W, O, groups, off_scale, bands = shape
+    B, C, H, W, O, groups, off_scale, form = shape
     assert mmt_lib.lib().mmt_dcn_mfma_supported(B, H, W, C, O, groups) == 1
+    assert mmt_lib.lib().mmt_dcn_backward_form(B, H, W, C, O, groups) == form
     torch.manual_seed(1)
     m = DeformConv2dPack(C, O, groups=groups).cuda()
     x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -174,7 +176,14 @@ def test_deform_conv_implicit_gemm(mmt_lib, shape):
         tol = 1e-4 * max(r.abs().max().item(), 1.0)
         assert (a - r).abs().max().item() <= tol, (name, "vs fp64", (a - r).abs().max().item(), tol)
         assert (a - c).abs().max().item() <= 2 * tol, (name, "vs the column form", (a - c).abs().max().item(), tol)
-    # bit-reproducible: the forward, grad_weight, grad_offset (grad_x: LDS / global float atomics)
+    if form == 1:      # the library's own general backward as well
+        monkeypatch.setenv("MMT_DCN_BACKWARD_GENERAL", "1")
+        gen = run(lambda a, b, c: deform_conv3x3(a, b, c, groups), torch.float32)
+        for a, r, name in zip(gen, ref, names):
+            tol = 1e-4 * max(r.abs().max().item(), 1.0)
+            assert (a - r).abs().max().item() <= tol, (name, "general form vs fp64", (a - r).abs().max().item(), tol)
+        got = gen
+    # bit-reproducible: the forward, grad_weight, grad_offset (grad_x: list order / float atomics)
     again = run(lambda a, b, c: deform_conv3x3(a, b, c, groups), torch.float32)
     for i in (0, 2, 3):
         assert torch.equal(got[i], again[i]), names[i]

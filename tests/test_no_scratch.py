@@ -21,7 +21,10 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 #   plain index arithmetic with per-thread row-cell arrays); not on the step's steady-state path.
 # * lss_plan_fwd<.., 5> (lift_splat_plan.hip): capped at 128 VGPRs for four waves per SIMD; two loop-invariant values are spilled
 #   (8-12 bytes per thread, one reload per unit, outside the pair loop) -- 22.8 us with the cap against 27.0 us without.
-ALLOWED = ("rocprim", "lss_ray_bwd", "lss_plan_build", "lss_plan_fwd")
+# * dcn_dgrad_gather<128> (deform_conv_mfma.hip): eleven waves per workgroup = three per SIMD = 168 VGPRs, of which 64 hold the wave's
+#   grad_out fragments for all nine taps; two loop-carried dwordx2 values (20 bytes per thread) are stored once and reloaded once
+#   per tap, outside the MFMA block (rounds of 8 waves at 256 VGPRs would waste a quarter of the wave slots at 16 x 44 pixels).
+ALLOWED = ("rocprim", "lss_ray_bwd", "lss_plan_build", "lss_plan_fwd", "dcn_dgrad_gather")
 
 
 def _kernels(lib_path):
