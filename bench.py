@@ -837,11 +837,18 @@ def train_main(args, rank, local_rank, world):
             key_b = ("lift_splat_backward_tile" if tiles else (("lift_splat_backward_column" if column else "lift_splat_backward") + ("_camera" if camera else ""))) + sfx
             # the timed sequence of the forward is the zero fill + the kernel: so is its traffic
             if plan:
-                res["roofline"] = roofline_entry(f"{kfwd}{sfx} (fused lift-splat forward, plan form = the step's voxel_pooling forward)", fbytes, fwd_ms,
-                                                 pmc_traffic(args.config, (key_f,)), l2f, note)
-                if timing.get("lift_splat_plan_prepare"):
-                    res["roofline"]["prepare"] = {"kernels": "lss_plan_probe + lss_plan_build", "avg_ms": _lib.mean_ms(timing["lift_splat_plan_prepare"]),
-                                                  "note": "per step, issued in front of the image backbone (not in front of the forward kernel)"}
+                # "sum of all kernels launched by one op call" -- the plan form's per-step lookup of the batch's
+                # calibrations (lss_plan_probe + lss_plan_build, issued in front of the image backbone) belongs to the forward's
+                # chain: avg_ms / achieved / frac are the CHAIN's; `parts` keeps the split.  With mats_dict['calibration_id'] the
+                # module skips the lookup while the ids repeat (0 launches per step in steady state).
+                prep = timing.get("lift_splat_plan_prepare") or []
+                prep_ms = sum(s_.elapsed_time(e_) for s_, e_ in prep) / max(len(timing["lift_splat_forward"]), 1)
+                res["roofline"] = roofline_entry(f"{kfwd}{sfx} + the per-step calibration lookup (fused lift-splat forward, plan form = the step's "
+                                                 "voxel_pooling forward)", fbytes, fwd_ms + prep_ms, pmc_traffic(args.config, (key_f,)), l2f, note)
+                res["roofline"]["parts"] = {"forward_kernel_ms": fwd_ms, "lookup_ms_per_step": prep_ms,
+                                            "lookup_launches_per_step": 2.0 * len(prep) / max(len(timing["lift_splat_forward"]), 1),
+                                            "lookup_kernels": "lss_plan_probe + lss_plan_build (issued in front of the image backbone)",
+                                            "forward_kernel_frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             else:
                 res["roofline"] = roofline_entry(f"lss_zero_fill + {kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,
                                                  pmc_traffic(args.config, (key_f, "lss_zero_fill")), l2f, note)

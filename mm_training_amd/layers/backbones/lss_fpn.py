@@ -167,8 +167,10 @@ class LSSFPN(nn.Module):
         # noticed through the cache's counters, read back lazily, and sent back to the ray walks.
         self.plan_form = os.environ.get("MMT_LSS_PLAN", "1") != "0"
         self.plan_slots = int(os.environ.get("MMT_LSS_PLAN_SLOTS", "16"))
+        self.plan_named_caches = int(os.environ.get("MMT_LSS_PLAN_NAMED", "8"))    # caches kept for batches that name their calibrations
         self._plan_caches = {}
         self._plan_watch = None
+        self._frustum_version = 0      # bumped by _refresh_frustum_axes: verdicts left in a plan cache belong to the axes they were looked up with
         rows = [x_bound, y_bound, z_bound]
         # lss_fpn.py:278-289, same expressions (Python doubles -> fp32 / truncating int64)
         self.register_buffer('voxel_size', torch.Tensor([row[2] for row in rows]))
@@ -211,6 +213,7 @@ class LSSFPN(nn.Module):
         # clearing: the library signs them with the axes' contents and empties them itself)
         self._summary_cache.clear(); self._plan_cache.clear(); self._column_backward_choice.clear(); self._excl_caches.clear()
         self._column_adaptive = None
+        self._frustum_version = getattr(self, "_frustum_version", 0) + 1      # (verdicts left in a plan cache are those of the old axes)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
@@ -274,23 +277,32 @@ class LSSFPN(nn.Module):
             cache = self._excl_caches[key] = new_exclusive_cache(num_cams, self._voxel_num_host, device, slots)
         return cache
 
-    def _plan_cache_for(self, batch_size, num_cams, fH, fW, device):
-        """The plan cache of this (device, cameras, stream), or None: plan form off, a shape it does not take, or a capture is
-        running and the cache does not exist yet (it must outlive the graph's pool: warm up eagerly first)."""
+    def _plan_cache_for(self, batch_size, num_cams, fH, fW, device, calib_key=None):
+        """The plan cache of this (device, cameras, stream[, calibration id]), or None: plan form off, a shape it does not take, or
+        a capture is running and the cache does not exist yet (it must outlive the graph's pool: warm up eagerly first).
+        A batch that NAMES its calibrations (calib_key) gets a cache of its own, sized for just that batch: nothing else ever
+        replaces its slots or its verdicts, so after the first lookup the forward can go by what is in the cache for as long
+        as the module keeps it (the `plan_named_caches` most recently used ids; anonymous batches share one cache of
+        `plan_slots` calibrations per (device, cameras, stream) and are looked up every call)."""
         if not self.plan_form or not plan_form_supported(batch_size, num_cams, self.depth_channels, fH, fW, self.output_channels, self._voxel_num_host):
             return None
-        key = (str(device), int(num_cams), torch.cuda.current_stream(device).cuda_stream)      # calls sharing a cache are stream-ordered
+        key = (str(device), int(num_cams), torch.cuda.current_stream(device).cuda_stream, calib_key)    # calls sharing a cache are stream-ordered
         cache = self._plan_caches.get(key)
         if cache is not None and getattr(cache, "_mmt_slots", 0) < batch_size:
             cache = None                                   # (a larger batch than the cache was sized for)
         if cache is None:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            if len(self._plan_caches) >= 4:
-                self._plan_caches.pop(next(iter(self._plan_caches)))
-            slots = max(int(self.plan_slots), int(batch_size), 2)
+            named = [k for k in self._plan_caches if k[3] is not None]
+            if calib_key is not None and len(named) >= self.plan_named_caches:
+                self._plan_caches.pop(named[0])
+            elif calib_key is None and len(self._plan_caches) - len(named) >= 4:
+                self._plan_caches.pop(next(k for k in self._plan_caches if k[3] is None))
+            slots = max(int(batch_size), 2) if calib_key is not None else max(int(self.plan_slots), int(batch_size), 2)
             cache = self._plan_caches[key] = new_plan_cache(num_cams, self.depth_channels, fH, fW, self._voxel_num_host, device, slots)
             cache._mmt_slots = slots
+        elif calib_key is not None:
+            self._plan_caches[key] = self._plan_caches.pop(key)       # most recently used last
         return cache
 
     def plan_cache_counters(self):
@@ -411,14 +423,25 @@ class LSSFPN(nn.Module):
         if (self.fused_lift_splat and self.camera_form and self._has_frustum_axes and self.plan_form and isinstance(mats_dict, dict)
                 and os.environ.get("MMT_LIFT_SPLAT_TILES", "0") != "1" and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"):
             fH_, fW_ = self.frustum_v.numel(), self.frustum_u.numel()
+            calib0 = mats_dict.get('calibration_id', None)
+            ckey0 = None if calib0 is None else (calib0, sweep_index, batch_size, num_cams, str(sweep_imgs.device))
             if camera_form_supported(batch_size, num_cams, self.depth_channels, fH_, fW_, self.output_channels):
-                plan_cache = self._plan_cache_for(batch_size, num_cams, fH_, fW_, sweep_imgs.device)
+                plan_cache = self._plan_cache_for(batch_size, num_cams, fH_, fW_, sweep_imgs.device, ckey0)
             if plan_cache is not None:
-                calib0 = mats_dict.get('calibration_id', None)
-                ckey0 = None if calib0 is None else (calib0, sweep_index, batch_size, num_cams, str(sweep_imgs.device))
                 plan_combine = self.camera_matrices(mats_dict['sensor2ego_mats'][:, sweep_index, ...], mats_dict['intrin_mats'][:, sweep_index, ...], ckey0)
-                plan_prepare(plan_combine, (self.frustum_u, self.frustum_v, self.frustum_d), self._voxel_num_host, self._voxel_coord_host,
-                             self._voxel_size_host, plan_cache)
+                # The verdicts of the last prepared batch stay in the cache, and a batch that names its calibrations
+                # (mats_dict['calibration_id']) has a cache of its own: when the same ids come again -- the steady state of a
+                # loader with a fixed set of rigs -- no lookup is needed at all: neither lss_plan_probe nor lss_plan_build is
+                # launched, the forward goes by the verdicts that are there (lss_fpn.py:328-361 has no per-step term for an
+                # unchanged calibration either).  Anonymous batches are looked up every call.
+                fresh = (ckey0 is not None and getattr(plan_cache, "_mmt_prepared_for", None) == ckey0
+                         and getattr(plan_cache, "_mmt_frustum_version", None) == self._frustum_version
+                         and not torch.cuda.is_current_stream_capturing())
+                if not fresh:
+                    plan_prepare(plan_combine, (self.frustum_u, self.frustum_v, self.frustum_d), self._voxel_num_host, self._voxel_coord_host,
+                                 self._voxel_size_host, plan_cache)
+                    plan_cache._mmt_prepared_for = ckey0
+                    plan_cache._mmt_frustum_version = self._frustum_version
                 self._watch_plan_cache(plan_cache)
         img_feats = self.get_cam_feats(sweep_imgs)
         # the key frame (:389): every caller hands over ONE sweep here (forward slices sweep_imgs[:, k:k+1]); squeezing that axis is

@@ -76,3 +76,71 @@ def test_lssfpn_branches_match_the_reference_forward(mmt_lib, golden, case, path
     assert np.abs(imgs.grad.cpu().numpy() - ref_g).max() <= 5e-5 * gscale
     if sweeps > 1:
         assert float(imgs.grad[:, 1:].abs().max()) == 0.0                             # older sweeps ran under no_grad (:516-524)
+
+
+def test_plan_lookup_is_skipped_while_the_calibration_ids_repeat(mmt_lib, golden):
+    """SURVEY 8 row f3 (lss_fpn.py:328-361: no per-step term for an unchanged calibration): with mats_dict['calibration_id'] the
+    module runs mmt_lss_plan_prepare (lss_plan_probe + lss_plan_build) once; while the ids repeat, NO lookup kernel is launched and
+    the forward goes by the verdicts left in the id's own cache -- bit-identical output, also when two rigs alternate.  A new id,
+    a batch without ids, an id whose cache was dropped (more than `plan_named_caches` ids) or a frustum change runs the lookup
+    (and the result still matches the reference's forward)."""
+    from mm_training_amd import _lib
+    g = golden["lss_forward"]
+    m = _mirror(g)
+    case = "single"
+    imgs = torch.from_numpy(g[case + "_imgs"]).cuda()
+    sweeps, B = imgs.shape[1], imgs.shape[0]
+    oracle_depth = torch.from_numpy(g[case + "_depth_oracle"]).cuda() if (case + "_depth_oracle") in g.files else None
+
+    def mats(cid=None, shift=0.0):
+        d = dict(sensor2ego_mats=torch.from_numpy(g["sensor2ego"][:, :sweeps]).cuda().clone(), intrin_mats=torch.from_numpy(g["intrin"][:, :sweeps]).cuda(),
+                 bda_mat=torch.eye(4).repeat(B, 1, 1).cuda(), flipped=torch.from_numpy(g[case + "_flipped"]))
+        d["sensor2ego_mats"][..., 0, 3] += shift
+        if cid is not None:
+            d["calibration_id"] = cid
+        return d
+
+    def run(md):
+        calls = []
+        real = _lib.call
+        _lib.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            with torch.no_grad():
+                out = m(imgs, md, oracle_depth, None)
+        finally:
+            _lib.call = real
+        assert "mmt_lss_splat_forward_plan" in calls, calls
+        return out, calls.count("mmt_lss_plan_prepare")
+
+    ref = g[case + "_bev"]
+    scale = max(1.0, float(np.abs(ref).max()))
+    a, n = run(mats("rig-A"))
+    assert n == 1 and np.abs(a.cpu().numpy() - ref).max() <= 2e-5 * scale
+    for _ in range(3):
+        b_, n = run(mats("rig-A"))
+        assert n == 0 and torch.equal(a, b_)                     # steady state: zero lookup launches
+    c, n = run(mats("rig-B", shift=0.37))                       # another rig: looked up (and learnt)
+    assert n == 1 and not torch.equal(a, c)
+    d, n = run(mats("rig-B", shift=0.37))
+    assert n == 0 and torch.equal(c, d)
+    for _ in range(2):                                          # two rigs alternating: each id has its own cache
+        e, n = run(mats("rig-A"))
+        assert n == 0 and torch.equal(a, e)
+        e, n = run(mats("rig-B", shift=0.37))
+        assert n == 0 and torch.equal(c, e)
+    f, n = run(mats(None))                                      # no ids: always looked up (a cache of its own)
+    assert n == 1 and torch.equal(a, f)
+    f, n = run(mats(None))
+    assert n == 1 and torch.equal(a, f)
+    h, n = run(mats("rig-A"))                                   # (the anonymous batches did not touch the named caches)
+    assert n == 0 and torch.equal(a, h)
+    m.plan_named_caches = 2
+    k, n = run(mats("rig-C", shift=-0.21))                      # a third id: the least recently used named cache (rig-B's) goes
+    assert n == 1
+    h, n = run(mats("rig-A"))
+    assert n == 0 and torch.equal(a, h)
+    e, n = run(mats("rig-B", shift=0.37))                       # rig-B again: a fresh cache, looked up and learnt again
+    assert n == 1 and torch.equal(c, e)
+    m._refresh_frustum_axes()                                    # a (re-)loaded frustum: what is in the cache belongs to the old axes
+    i, n = run(mats("rig-A"))
+    assert n == 1 and torch.equal(a, i)
