@@ -108,6 +108,10 @@ def parse(argv=None):
                     help="HIP streams the CenterPoint task heads are dealt to in training (default: MMT_HEAD_STREAMS or 2; 0 = the caller's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", action="store_true", help="train mode: skip the drop-in voxel_pooling timing after the steps")
+    ap.add_argument("--shared-gpu-rehearsal", action="store_true",
+                    help="functional rehearsal of the N > 1 path on a box with FEWER GPUs than ranks: the ranks share devices and exchange "
+                         "over gloo (RCCL refuses two ranks per device).  Without this flag such a launch fails in the preflight -- a scaling "
+                         "run must never degrade silently to a host-staged backend on shared cards")
     ap.add_argument("--hotpath-leg", action="store_true",
                     help="train mode with --gpus > 1: run rank 0's drop-in voxel_pooling timing after the steps anyway (by default only a "
                          "1-GPU run does: the other ranks would sit in the final barrier for its seconds)")
@@ -246,7 +250,7 @@ class _StdoutToStderr:
         return False
 
 
-def init_dist(n_gpus, device="cuda"):
+def init_dist(n_gpus, device="cuda", shared_gpu_rehearsal=False):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,6 +263,12 @@ def init_dist(n_gpus, device="cuda"):
                 dist.barrier()
         return rank, local_rank, world
     ndev = torch.cuda.device_count()
+    if world > max(ndev, 1) and not shared_gpu_rehearsal:
+        # fail fast, before any communicator exists (nothing to hang on, nothing re-exec'd): every rank sees the same (world, ndev)
+        if rank == 0:
+            print(f"[bench] preflight FAILED: --gpus {world} but {ndev} GPU(s) visible: RCCL needs a GPU per rank "
+                  "(--shared-gpu-rehearsal runs the ranks on shared cards over gloo, for functional tests only)", file=sys.stderr, flush=True)
+        sys.exit(4)
     backend, local_rank = choose_backend(world, local_rank, ndev, os.environ.get("MMT_DIST_BACKEND", "nccl"))   # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -273,7 +283,48 @@ def init_dist(n_gpus, device="cuda"):
         if world <= ndev and "MMT_DIST_BACKEND" not in os.environ:
             # one GPU per rank: the gradient all-reduce must ride RCCL (xGMI), never silently a host-staged backend
             assert dist.get_backend() == "nccl", f"world {world} on {ndev} GPUs initialised backend {dist.get_backend()!r}, expected RCCL"
+        preflight(rank, local_rank, world, ndev)
     return rank, local_rank, world
+
+
+RCCL_RANKS = None      # ranks that answered the preflight all-reduce on the RCCL communicator (None: not an RCCL run)
+
+
+def preflight(rank, local_rank, world, ndev):
+    """Before any warm-up step of an N > 1 run: one all-reduce of ones over the communicator the gradients will use (its size must
+    be the world), every rank's device gathered, and rank 0 says on stderr what the run is on.  An RCCL run whose ranks do not
+    each have a GPU of their own -- fewer visible devices than ranks, or two ranks on one PCI function -- ends HERE with a
+    non-zero exit on every rank (nothing is re-exec'd): RCCL would hang or crawl, and the scaling figure would mean nothing."""
+    global RCCL_RANKS
+    backend = dist.get_backend()
+    ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(ones)
+    answered = int(ones.item())
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": rank, "device": f"cuda:{local_rank}",
+            "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if backend == "nccl":
+        RCCL_RANKS = answered
+    shared = len({g["pci_bus_id"] for g in gathered}) < world
+    if rank == 0:
+        print(f"[bench] preflight: backend {backend} ({'RCCL' if backend == 'nccl' else 'host-staged'}), communicator of {answered} ranks "
+              f"(world {world}), {ndev} visible GPUs, HSA_ENABLE_IPC_MODE_LEGACY={mine['HSA_ENABLE_IPC_MODE_LEGACY']}", file=sys.stderr)
+        for g in gathered:
+            print(f"[bench] preflight:   rank {g['rank']} -> {g['device']} ({g['pci_bus_id']})", file=sys.stderr)
+        sys.stderr.flush()
+    bad = None
+    if answered != world:
+        bad = f"the communicator answered with {answered} ranks, the world is {world}"
+    elif backend == "nccl" and (world > ndev or shared):
+        bad = f"RCCL needs a GPU per rank: world {world}, {ndev} visible GPUs" + (", two ranks on one device" if shared else "")
+    if bad:
+        if rank == 0:
+            print(f"[bench] preflight FAILED: {bad}", file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        sys.exit(4)
 
 
 def distributed_info(world, local_rank, ts=None):
@@ -296,6 +347,7 @@ def distributed_info(world, local_rank, ts=None):
     except Exception:
         info["rccl_version"] = None
     info["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    info["rccl_ranks"] = RCCL_RANKS          # ranks on the RCCL communicator (preflight all-reduce); None = no RCCL in this run
     if ts is not None:
         params = [p for n, p in ts.model.named_parameters() if p.requires_grad and ".context_se." not in n]
         info["gradient_bytes"] = int(sum(p.numel() * p.element_size() for p in params))
@@ -1009,7 +1061,7 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, argv))
     _late_imports(args.device)
-    rank, local_rank, world = init_dist(args.gpus, args.device)
+    rank, local_rank, world = init_dist(args.gpus, args.device, args.shared_gpu_rehearsal)
     try:
         if args.device == "cpu":
             rehearsal_main(args, rank, world)

@@ -24,8 +24,11 @@ def _run(extra_env=None, *argv, timeout=420):
 
 
 def test_bench_two_ranks_on_the_gpu_box(mmt_lib):
-    out, _ = _run(None, "--gpus", "2", "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    out, _ = _run(None, "--gpus", "2", "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--shared-gpu-rehearsal")
     assert out.returncode == 0, out.stderr[-3000:]
+    # the preflight said on stderr what the run is on, before the warm-up
+    assert "[bench] preflight: backend gloo" in out.stderr and "communicator of 2 ranks (world 2)" in out.stderr
+    assert "rank 0 -> cuda:0" in out.stderr and "rank 1 -> cuda:0" in out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
@@ -47,7 +50,7 @@ def test_bench_two_ranks_on_the_gpu_box(mmt_lib):
     assert dd["world"] == 2 and dd["backend"] == "gloo" and dd["ranks_share_a_device"] is True
     assert [r["rank"] for r in dd["ranks"]] == [0, 1] and all(r["device"] == "cuda:0" for r in dd["ranks"])
     assert len({r["pci_bus_id"] for r in dd["ranks"]}) == 1 and dd["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    assert dd["rccl_version"] and dd["gradient_bytes"] > 1e5
+    assert dd["rccl_version"] and dd["gradient_bytes"] > 1e5 and dd["rccl_ranks"] is None          # (no RCCL communicator in a shared-card rehearsal)
     # the gradient exchange: the native bucketed reducer (dp/reducer.py) by default, torch's DDP with MMT_DP_REDUCER=ddp
     red = dd["reducer"]
     assert dd["ddp"] is None and red["buckets"] >= 1 and red["gradient_bytes"] == dd["gradient_bytes"] and red["communication_stream"] is True
@@ -60,7 +63,8 @@ def test_bench_two_ranks_on_the_gpu_box(mmt_lib):
 def test_bench_reports_a_rank_that_dies_instead_of_hanging(mmt_lib):
     """rank 1 exits after its warm-up (test hook MMT_BENCH_FAIL_RANK): rank 0 is then blocked in the barrier in front of the
     timed steps; the launcher must notice, terminate it and exit non-zero -- within seconds, not at a timeout."""
-    out, took = _run({"MMT_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", timeout=300)
+    out, took = _run({"MMT_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                     "--shared-gpu-rehearsal", timeout=300)
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "rank 1 exited with code 3" in out.stderr
@@ -70,7 +74,7 @@ def test_bench_reports_a_rank_that_dies_instead_of_hanging(mmt_lib):
 def test_bench_two_ranks_at_a_baseline_camera_shape(mmt_lib):
     """BASELINE configs[1] (camera BEVDepth R50, 6 x 256 x 704, C = 80) with two ranks on the one card: each rank runs the
     step's own kernels -- camera form, plan-form forward (one plan cache per process) -- side by side with the other's."""
-    out, _ = _run(None, "--gpus", "2", "--config", "cfg2", "--steps", "4", "--warmup", "9", "--no-cpu-baseline", timeout=600)
+    out, _ = _run(None, "--gpus", "2", "--config", "cfg2", "--steps", "4", "--warmup", "9", "--no-cpu-baseline", "--shared-gpu-rehearsal", timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -83,6 +87,19 @@ def test_bench_two_ranks_at_a_baseline_camera_shape(mmt_lib):
     # (two processes time-slice the one card, each with its main stream and the task heads' two streams: a dispatch-attached
     # event pair may span the other rank's time slice -- 212 ms was seen once -- so there is no bound on speed here)
     assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline"]["avg_ms"] < 5000.0
+
+
+def test_more_ranks_than_gpus_fails_in_the_preflight(mmt_lib):
+    """`bench.py --gpus 2` on a one-GPU box WITHOUT --shared-gpu-rehearsal: RCCL needs a GPU per rank -- every rank exits non-zero
+    before a communicator exists, quickly, with the reason on stderr and no JSON line (a scaling run never degrades silently to
+    gloo on shared cards)."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a one-GPU box")
+    out, took = _run(None, "--gpus", "2", "--config", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=300)
+    assert out.returncode != 0 and took < 120
+    assert "preflight FAILED" in out.stderr and "1 GPU(s) visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
 def test_rccl_banner_stays_out_of_stdout(mmt_lib):

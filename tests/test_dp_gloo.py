@@ -32,16 +32,19 @@ def _make(seed=0):
     return cfg, head
 
 
-def _data(cfg, n, seed=1):
+def _data(cfg, n, seed=1, every_class=False):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cfg["fuse_layer_in_channels"], 128, 128, generator=g)
     boxes, labels = [], []
     for i in range(n):
-        k = 3 + i
+        k = 8 if every_class else 3 + i
         xy = torch.rand(k, 2, generator=g) * 80 - 40
         rest = torch.tensor([[-1.0, 1.9, 4.6, 1.7, 0.3, 0.5, -0.2]]).repeat(k, 1)
         boxes.append(torch.cat([xy, rest], 1))
-        labels.append(torch.randint(0, 4, (k,), generator=g))
+        # every_class: two boxes of each of the 4 classes in EVERY sample, so that no rank's per-task positive count is 0 -- the
+        # reference clamps the cross-rank MEAN of the counts at 1 (bev_depth_head.py:273-276), which equals the single-process
+        # normaliser max(sum, 1) / world only while that mean is >= 1
+        labels.append(torch.arange(k) % 4 if every_class else torch.randint(0, 4, (k,), generator=g))
     return x, boxes, labels
 
 
@@ -183,3 +186,76 @@ def test_native_reducer_two_ranks_equal_the_mean_gradient():
     assert bb[0] <= 0.0004 * 2 ** 20 + 1 or len(bb) < 3
     assert bb[-1] == 864                       # the first layer's weight alone (a parameter larger than the cap is a bucket of its own): 8 x 3 x 3 x 3 floats
     assert d["buckets"] >= 3 and d["parameters"] == 6 and sum(d["bucket_bytes"]) == d["gradient_bytes"] and out["strides_match"]
+
+
+class _HeadWithUnused(torch.nn.Module):
+    """The tiny config's detection head plus a `context_se` block whose parameters never receive a gradient -- what DepthNet
+    carries (lss_fpn.py:183) and what dp/trainer.py tells the reducer to ignore by that name."""
+
+    def __init__(self, head):
+        super().__init__()
+        self.depth_net = torch.nn.Module()
+        self.depth_net.context_se = torch.nn.Linear(4, 4)
+        self.head = head
+
+    def forward(self, x):
+        return self.head(x)
+
+
+def _world4_worker(rank, world, port, out):
+    from mm_training_amd.dp.reducer import GradReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg, head = _make()
+    model = _HeadWithUnused(head)
+    red = GradReducer(model.named_parameters(), world, bucket_mb=0.5, first_mb=0.02, last_mb=0.05, ignore=(".context_se.",))
+    opt = torch.optim.SGD([p for p in model.parameters()], lr=1e-5, momentum=0.9)
+    for step in range(3):
+        x, boxes, labels = _data(cfg, world, seed=10 + step, every_class=True)
+        opt.zero_grad(set_to_none=True)
+        sl = slice(rank, rank + 1)
+        loss = head.loss(head.get_targets_torch(boxes[sl], labels[sl]), model(x[sl]))
+        loss.backward()
+        red.finish()
+        opt.step()
+    if rank == 0:
+        out["params"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+        out["describe"] = red.describe()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_native_reducer_three_steps_equal_one_process_with_the_whole_batch():
+    """World 4 over gloo, the tiny config's head through dp/reducer.py (not torch's DDP): after three optimiser steps every
+    parameter equals the single-process run on the 4-sample batch -- the gradient is the MEAN over the ranks and the head's loss
+    normalisers are global sums turned into means by one collective (bev_depth_head.py:273-276, :300-301) -- with `.context_se.`
+    parameters kept out of the reducer (they never get a gradient: an incomplete bucket would raise) and at least three buckets
+    of different sizes (small first and last one)."""
+    world = 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world4_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    cfg, head = _make()
+    model = _HeadWithUnused(head)
+    opt = torch.optim.SGD([p for p in model.parameters()], lr=1e-5, momentum=0.9)
+    for step in range(3):
+        x, boxes, labels = _data(cfg, world, seed=10 + step, every_class=True)
+        opt.zero_grad(set_to_none=True)
+        _step(head, x, boxes, labels).backward()
+        opt.step()
+    got, d = out["params"], out["describe"]
+    init = dict(_HeadWithUnused(_make()[1]).named_parameters())
+    moved = 0
+    for n, p in model.named_parameters():
+        # the UPDATES agree (the weights are O(1), three small steps move them by far less: compare what moved)
+        du, dr = got[n] - init[n].detach(), p.detach() - init[n].detach()
+        ulp = 1.2e-7 * float(init[n].detach().abs().max())            # the weights themselves round to fp32: a few ulps of slack
+        assert torch.isfinite(dr).all() and torch.allclose(du, dr, rtol=1e-3, atol=1e-3 * float(dr.abs().max()) + 4 * ulp + 1e-12), n
+        moved += int(float(dr.abs().max()) > 0)
+        if ".context_se." in n:
+            assert float(du.abs().max()) == 0.0
+    assert moved > 10                                       # (the steps did change the weights)
+    bb = d["bucket_bytes"]
+    assert d["buckets"] >= 3 and len(set(bb)) >= 2 and bb[0] < max(bb) and bb[-1] < max(bb), d
+    assert d["parameters"] == sum(1 for n, p in model.named_parameters() if ".context_se." not in n and p.requires_grad)

@@ -249,6 +249,22 @@ def test_plan_form_equals_camera_form_with_gradients(mmt_lib, cfg, bf16):
         assert torch.equal(c1.grad, c2.grad)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_plan_form_against_the_oracle_at_configs4_full_shape(mmt_lib, oracle_mod, bf16):
+    """BASELINE configs[4]'s camera half in full -- (B, N, D, fH, fW, C) = (2, 6, 112, 32, 88, 80), fp32 and bf16 storage -- DIRECTLY
+    against oracle.voxel_pooling_forward_f64(oracle.lift(...)) on the cells of mmt_frustum_geometry (not only against the camera
+    form, as test_plan_form_equals_camera_form_with_gradients does): <= 1e-4 of the map's scale, every element written,
+    bit-identical from call to call, the brute-force path as well."""
+    from mm_training_amd import synthetic
+    B, N, D, fH, fW, C = 2, 6, 112, 32, 88, 80
+    H, W = fH * 16, fW * 16
+    s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=0)
+    combine = s2e.matmul(torch.inverse(K)).contiguous()
+    fr = _frustum((H, W), 16, (2.0, 2.0 + 0.5 * D, 0.5))
+    vc, vs, vn = [-51.2 + 0.4, -51.2 + 0.4, -5.0 + 4.0], [0.8, 0.8, 8.0], [128, 128, 1]
+    _case(combine, fr, vc, vs, vn, oracle_mod, C=C, bf16=bf16, seed=11, check_host_plan=False)
+
+
 def test_plan_cache_duplicates_reordering_eviction_and_shape_change(mmt_lib, oracle_mod):
     """a batch whose samples share a calibration learns it once; reordered / mixed batches hit; more calibrations than slots
     evict the least recently used; a change of the frustum axes empties the table; every call's map is right"""
