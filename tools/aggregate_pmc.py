@@ -53,6 +53,10 @@ KERNELS = [
     ("normalize_flip_kernel", ("normalize_flip_kernel",)), ("hflip_kernel", ("hflip_kernel",)),
     ("depth_project_kernel", ("depth_project_kernel",)), ("depth_bins_kernel", ("depth_bins_kernel",)),
     ("scatter_write_nhwc_table_kernel", ("scatter_write_nhwc_table_kernel",)), ("scatter_backward_nhwc_unique_kernel", ("scatter_backward_nhwc_unique_kernel",)),
+    # implicit-GEMM form of the deformable convolution (csrc/deform_conv_mfma.hip); dcn_plan_taps before the column form's dcn_plan
+    ("dcn_pack_weights", ("dcn_pack_weights",)), ("dcn_fwd_mfma", ("dcn_fwd_mfma",)), ("dcn_plan_taps", ("dcn_plan_taps",)),
+    ("dcn_wgrad_mfma", ("dcn_wgrad_mfma",)), ("dcn_wgrad_reduce", ("dcn_wgrad_reduce",)), ("dcn_dgrad_gather", ("dcn_dgrad_gather",)),
+    ("dcn_dgrad_mfma", ("dcn_dgrad_mfma",)), ("dcn_offset_reduce_parts", ("dcn_offset_reduce_parts",)),
     ("dcn_col2im_gather", ("dcn_col2im_gather",)), ("dcn_offset_grad", ("dcn_offset_grad",)), ("dcn_plan", ("dcn_plan",)),
     ("dcn_col2im", ("dcn_col2im",)), ("dcn_im2col", ("dcn_im2col",)),
     ("bev_warp_kernel", ("bev_warp_kernel",)), ("bev_warp_backward_gather", ("bev_warp_backward_gather",)),
