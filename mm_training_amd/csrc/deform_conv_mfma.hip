@@ -106,14 +106,31 @@ __global__ __launch_bounds__(WM * WN * 64) void dcn_fwd_mfma(int H, int W, int C
     extern __shared__ __align__(16) float smem[];
     float *As = smem;                                   // [2][BM][kLd]
     float *Bs = As + 2 * BM * kLd;                      // [2][BN][kLd]
-    TapRec *taps = reinterpret_cast<TapRec *>(Bs + 2 * BN * kLd);   // [2][BM]
+    TapRec *taps = reinterpret_cast<TapRec *>(Bs + 2 * BN * kLd);   // [9][BM]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int Cg = C / groups, Og = O / groups, ntn = Og / BN, HW = H * W;
-    int bid = blockIdx.x;
-    const int nt = bid % ntn; bid /= ntn;
-    const int g = bid % groups, mt = bid / groups;
+    // Which tile.  Workgroup i runs on XCD i % 8 (a label for "shares an L2"): with groups | 8 a weight group's tiles take 8 / groups
+    // XCDs, so an L2 holds ONE group's weights (0.6 MB at the DepthNet shape) next to its tiles' pixels instead of all four groups'
+    // (2.4 MB of its 4 MB).
+    int nt, g, mt;
+    {
+        const int mtiles = (npos + BM - 1) / BM;
+        if (8 % groups == 0) {
+            const int xps = 8 / groups, x = blockIdx.x & 7, q = blockIdx.x >> 3;          // grid = 8 * ceil(mtiles * ntn / xps)
+            g = x / xps;
+            const int u = q * xps + x % xps;
+            nt = u % ntn; mt = u / ntn;
+            if (mt >= mtiles) return;
+        } else {
+            int bid = blockIdx.x;
+            nt = bid % ntn; bid /= ntn;
+            g = bid % groups; mt = bid / groups;
+        }
+    }
     const int pos0 = mt * BM;
+    // K-steps: channel chunk OUTER, tap INNER -- the nine taps of a pixel read the same 128-byte pieces of its 3 x 3 neighbours'
+    // rows, so a piece is re-used within 9 consecutive steps (out of L2, and often L1) instead of once every Cg/32 steps
     const int nchunk = Cg / kKC, nsteps = 9 * nchunk;
     const float *wfg = wf + ((size_t)g * 9 * Og + (size_t)nt * BN) * Cg;
     const float *xg = x + g * Cg + (tid & 7) * 4;
@@ -132,34 +149,27 @@ __global__ __launch_bounds__(WM * WN * 64) void dcn_fwd_mfma(int H, int W, int C
     };
     Stage sa, sb;
 
-    // the pixel whose sampling points this thread computes (threads < BM), and its offsets for the NEXT tap to be written
-    const int tpos = pos0 + tid;
-    const bool towner = tid < BM && tpos < npos;
-    const int tb = towner ? tpos / HW : 0, thw = towner ? tpos - tb * HW : 0, th = thw / W, tw = thw - th * W;
-    const float *toff = offset + (size_t)(towner ? tpos : 0) * 18;
-    float2 onext = *reinterpret_cast<const float2 *>(toff);
-    auto write_taps = [&](int tap) {      // consumes onext (= the offsets of `tap`), prefetches tap + 1
-        if (tid < BM) {
-            TapRec r;
-            if (towner) {
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const Tap t = mmt_dcn::make_tap((float)(th + ky - 1) + onext.x, (float)(tw + kx - 1) + onext.y, H, W);
-                const int base = tb * HW;
-                r.w[0] = t.w1; r.w[1] = t.w2; r.w[2] = t.w3; r.w[3] = t.w4;
-                // byte offsets of the corner rows in x (B*H*W*C*4 < 2^32: dcn_shape)
-                r.o[0] = (base + t.o1) * C * 4; r.o[1] = (base + t.o2) * C * 4; r.o[2] = (base + t.o3) * C * 4; r.o[3] = (base + t.o4) * C * 4;
-            } else {
-                r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
-                r.o[0] = r.o[1] = r.o[2] = r.o[3] = 0;
-            }
-            taps[(tap & 1) * BM + tid] = r;
-            onext = *reinterpret_cast<const float2 *>(toff + 2 * (tap < 8 ? tap + 1 : 8));
+    // the sampling points of all 9 taps of the tile's pixels, once: record (tap, pixel) by thread e = tid, tid + NT, ...
+    for (int e = tid; e < 9 * BM; e += NT) {
+        const int tap = e / BM, pl = e - tap * BM, pos = pos0 + pl;
+        TapRec r;
+        if (pos < npos) {
+            const int b = pos / HW, hw = pos - b * HW, h = hw / W, w = hw - h * W;
+            const Tap t = tap_at(h, w, tap, offset + (size_t)pos * 18, H, W);
+            const int base = b * HW;
+            r.w[0] = t.w1; r.w[1] = t.w2; r.w[2] = t.w3; r.w[3] = t.w4;
+            // byte offsets of the corner rows in x (B*H*W*C*4 < 2^32: dcn_shape)
+            r.o[0] = (base + t.o1) * C * 4; r.o[1] = (base + t.o2) * C * 4; r.o[2] = (base + t.o3) * C * 4; r.o[3] = (base + t.o4) * C * 4;
+        } else {
+            r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
+            r.o[0] = r.o[1] = r.o[2] = r.o[3] = 0;
         }
-    };
+        taps[e] = r;
+    }
     const unsigned lane_bytes = (tid & 7) * 16;
     auto issue_loads = [&](int s, Stage &st) {
-        const int tap = s / nchunk, ch = s - tap * nchunk;
-        const TapRec *tp = taps + (tap & 1) * BM + (tid >> 3);
+        const int ch = s / 9, tap = s - ch * 9;
+        const TapRec *tp = taps + tap * BM + (tid >> 3);
         const char *xc = reinterpret_cast<const char *>(x + g * Cg + ch * kKC);      // wave-uniform base + 32-bit per-lane offset
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
@@ -211,13 +221,9 @@ __global__ __launch_bounds__(WM * WN * 64) void dcn_fwd_mfma(int H, int W, int C
         compute(s & 1, 0, kKC / 16);
         if (FULL || s + 1 < nsteps) write_lds((s + 1) & 1, next);
         compute(s & 1, kKC / 16, kKC / 8);
-        // the tap records step s+3 needs (read at the top of step s+1) go into the buffer the loads of steps s+1 / s+2 do not read
-        if (s + 3 < nsteps && (s + 3) / nchunk != (s + 2) / nchunk) write_taps((s + 3) / nchunk);
         __syncthreads();
     };
 
-    write_taps(0);
-    if (nchunk == 2) write_taps(1);        // (nchunk >= 2: C/groups is a multiple of 64)
     __syncthreads();
     issue_loads(0, sa);
     issue_loads(1, sb);
@@ -262,7 +268,8 @@ __global__ __launch_bounds__(256) void dcn_wgrad_mfma(int H, int W, int C, int O
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int Cg = C / groups, Og = O / groups, nct = Cg / TC, nto = Og / TO, HW = H * W;
-    int bid = blockIdx.x;
+    // the 9 * nct * nto workgroups of one (pixel slice, weight group) read the same x and grad_out rows: consecutive ids, one XCD
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int ot = bid % nto; bid /= nto;
     const int ct = bid % nct; bid /= nct;
     const int tap = bid % 9; bid /= 9;
@@ -962,7 +969,7 @@ int set_lds(K kernel, size_t bytes, const char *what) {
 struct FwdCfg { int wm, wn; };
 constexpr FwdCfg kFwdCfgs[] = {{3, 2}, {2, 2}, {4, 1}, {4, 2}};
 
-size_t fwd_lds(int wm, int bn) { return (size_t)2 * (32 * wm + bn) * kLd * 4 + (size_t)2 * 32 * wm * sizeof(TapRec); }
+size_t fwd_lds(int wm, int bn) { return (size_t)2 * (32 * wm + bn) * kLd * 4 + (size_t)9 * 32 * wm * sizeof(TapRec); }
 
 // default: 2 x 2 waves on a 64-pixel x 128-channel tile, two workgroups per CU (measured at [24,512,16,44] and [12,512,32,88],
 // tools/kbench_dcn.py: 267 / 452 us against 300-350 / 490-580 for the taller tiles -- the step's barrier, tap records and LDS
@@ -1011,7 +1018,8 @@ extern "C" int mmt_dcn_forward(int B, int H, int W, int C, int O, int groups, co
     const int cfg = fwd_config_override >= 1 && fwd_config_override <= 4 ? fwd_config_override - 1 : fwd_config(s, bn);
     const int wm = kFwdCfgs[cfg].wm, wn = kFwdCfgs[cfg].wn, bm = 32 * wm;
     const size_t lds = fwd_lds(wm, bn);
-    const unsigned grid = (unsigned)(((s.npos + bm - 1) / bm) * s.groups * (s.Og / bn));
+    const int tiles_per_group = ((s.npos + bm - 1) / bm) * (s.Og / bn);
+    const unsigned grid = 8 % s.groups == 0 ? (unsigned)(8 * ((tiles_per_group + 8 / s.groups - 1) / (8 / s.groups))) : (unsigned)(tiles_per_group * s.groups);
 #define MMT_DCN_FWD(WM, WN, BN)                                                                                               \
     {                                                                                                                         \
         if (int rc = set_lds(dcn_fwd_mfma<WM, WN, BN>, lds, "dcn_forward")) return rc;                                        \

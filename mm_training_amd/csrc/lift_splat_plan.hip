@@ -48,7 +48,7 @@ static_assert(sizeof(Verdict) == 64, "Verdict");
 
 struct CacheHeader {
     unsigned magic, sig_lo, sig_hi, axes_lo, axes_hi, clock, nslots, todo_count;
-    unsigned hits, built, brute, resets, calls, reserved[3];
+    unsigned hits, built, brute, resets, calls, stale, reserved[2];     // stale: forwards that found a verdict nobody prepared (see lss_plan_fwd)
 };
 struct SlotMeta { unsigned hash_lo, hash_hi; int state, njobs, nruns; unsigned stamp; int gstart[kGroups + 1]; int pad[1]; float mats[kPlanMaxN * 16]; };
 
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void lss_plan_probe(PlanArgs a) {
         }
         hdr->magic = kPlanMagic; hdr->sig_lo = a.sig_lo; hdr->sig_hi = a.sig_hi; hdr->axes_lo = ax_lo; hdr->axes_hi = ax_hi;
         hdr->clock = clock; hdr->nslots = (unsigned)a.nslots; hdr->todo_count = n_todo;
-        if (reset) { hdr->hits = 0; hdr->built = 0; hdr->brute = 0; hdr->resets = h_magic == kPlanMagic ? h_resets + 1 : 0; hdr->calls = 0; }
+        if (reset) { hdr->hits = 0; hdr->built = 0; hdr->brute = 0; hdr->resets = h_magic == kPlanMagic ? h_resets + 1 : 0; hdr->calls = 0; hdr->stale = 0; }
         hdr->hits += n_hit; hdr->built += n_todo; hdr->calls += 1;
     }
 }
@@ -546,6 +546,14 @@ __global__ __launch_bounds__(kFwdThreads, (S <= 5 ? PLAN_FWD_WAVES : 1)) void ls
     const int *vd = reinterpret_cast<const int *>(p.cache + kVerdictOff) + b * (int)(sizeof(Verdict) / 4);       // (read word by word: a struct indexed at run time would live in scratch memory)
     const int slot = vd[0], vstate = vd[2];
     if ((unsigned)slot >= (unsigned)p.nslots) return;       // (a cache nobody prepared: nothing to go by -- the entry point's contract, not a fault)
+    if (vstate == kStateEmpty) {
+        // MMT_LSS_PLAN_PREPARED with a verdict that no lookup of THIS batch left: the slot's summary was never built for these
+        // matrices, and serving the sample from it would write a wrong map without any sign.  The sample's part of the map is
+        // left as the caller allocated it and the header counts the event (mmt_lss_plan_cache_counters, counters[6]; LSSFPN's
+        // lazy read-back raises on it): loud instead of silently wrong.
+        if (tid == 0 && first == 0 && g0 == 0) atomicAdd(&reinterpret_cast<CacheHeader *>(p.cache)->stale, 1u);
+        return;
+    }
     const bool brute = vstate != kStateReady || a.force_brute;
     __shared__ int s_gs[kGroups + 1];                        // first unit of every group (indexed at run time: LDS, not registers)
     if (tid <= kGroups) s_gs[tid] = brute ? group_begin(d, tid) : vd[4 + tid];
@@ -809,11 +817,11 @@ int plan_shape_ok(const char *what, int B, int N, int D, int fH, int fW, int C, 
     Dims d;
     make_dims(N > 0 ? N : 1, D > 0 ? D : 1, fH > 0 ? fH : 1, fW > 0 ? fW : 1, nx > 0 ? nx : 1, ny > 0 ? ny : 1, &d);
     const bool ok = B > 0 && B <= kPlanMaxB && N > 0 && N <= kPlanMaxN && D > 0 && fH > 0 && fW > 0 && nx > 0 && ny > 0 && nz > 0 && dims_ok(d) &&
-                    (C == 64 || C == 80 || C == 128) && (int64_t)B * N * fH * fW * D * 4 < (1ll << 31) && (int64_t)B * N * fH * fW * C < (1ll << 31) &&
+                    (C == 64 || C == 80 || C == 128) && (int64_t)B * N * fH * fW * D * 4 < (1ll << 31) && (int64_t)B * N * fH * fW * C * 4 < (1ll << 32) &&      /* context rows: 32-bit BYTE offsets (fp32 worst case) */
                     (int64_t)B * ny * nx * C < (1ll << 31);
     if (!ok && !quiet)
-        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the plan form takes B <= %d, N <= %d, C in {64, 80, 128}, D <= 2047, fH <= 512, N * fW <= 65535 and tensors "
-                         "below 2^31 elements (B=%d N=%d D=%d fH=%d fW=%d C=%d grid %d x %d x %d)", what, kPlanMaxB, kPlanMaxN, B, N, D, fH, fW, C, nx, ny, nz);
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: the plan form takes B <= %d, N <= %d, C in {64, 80, 128}, D <= 2047, fH <= 512, N * fW <= 65535, tensors "
+                         "below 2^31 elements and a context tensor below 2^30 (B=%d N=%d D=%d fH=%d fW=%d C=%d grid %d x %d x %d)", what, kPlanMaxB, kPlanMaxN, B, N, D, fH, fW, C, nx, ny, nz);
     return ok ? MMT_OK : MMT_ERR_BAD_SHAPE;
 }
 
@@ -946,7 +954,8 @@ extern "C" int mmt_lss_plan_cache_counters(const void *plan_cache, int64_t plan_
     if (const hipError_t e = hipStreamSynchronize((hipStream_t)stream); e != hipSuccess)
         return mmt::fail((int)e, "lss_plan_cache_counters: %s", hipGetErrorString(e));
     const bool live = h.magic == kPlanMagic;
-    const int64_t v[8] = {live ? h.hits : 0, live ? h.built : 0, live ? h.brute : 0, live ? h.resets : 0, live ? h.calls : 0, live ? h.nslots : 0, 0, 0};
+    const int64_t v[8] = {live ? h.hits : 0, live ? h.built : 0, live ? h.brute : 0, live ? h.resets : 0, live ? h.calls : 0, live ? h.nslots : 0,
+                          live ? h.stale : 0, 0};
     memcpy(counters_host, v, sizeof(v));
     return MMT_OK;
 }

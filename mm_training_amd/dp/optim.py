@@ -43,7 +43,10 @@ class ClipAdamW(torch.optim.Optimizer):
     # ---- tables of one group: which parameters take part (those with a gradient), their chunks, the static pointer arrays
     def _plan(self, gi, group):
         ps = [p for p in group["params"] if p.grad is not None]
-        key = tuple(id(p) for p in ps)
+        # the tables hold raw device addresses: a parameter whose storage was replaced after the tables were built (module.to(),
+        # `p.data = ..`, a memory-format conversion) must not be written through the old one -- its address is part of the key
+        # (the moments only change through load_state_dict, which drops the tables)
+        key = tuple((id(p), p.data_ptr()) for p in ps)
         plan = self._plans.get(gi)
         if plan is not None and plan["key"] == key:
             return plan
@@ -57,6 +60,14 @@ class ClipAdamW(torch.optim.Optimizer):
             # (moments follow the parameter's own memory order: a channels_last weight and its moments line up element by element)
             if not (_same_layout(st["exp_avg"], p) and _same_layout(st["exp_avg_sq"], p)):
                 raise RuntimeError("ClipAdamW: a moment's layout differs from its parameter's")
+        # One launch de-biases every tensor of the group with the SAME step count (torch.optim.AdamW keeps one per parameter).  The
+        # counts only diverge when the participating set changes -- a parameter that starts receiving gradients later, a loaded
+        # state with differing counts -- and every such change rebuilds these tables: refuse it here, loudly, instead of
+        # de-biasing the newcomer with the wrong power of beta.
+        counts = {int(self.state[p]["step"]) for p in ps}
+        if len(counts) > 1:
+            raise RuntimeError(f"ClipAdamW: the parameters of group {gi} that have gradients carry different step counts {sorted(counts)[:4]}: "
+                               "per-parameter bias correction is not supported (a parameter that joins later belongs in a parameter group of its own)")
         chunk_t, chunk_o = [], []
         for t, p in enumerate(ps):
             for off in range(0, p.numel(), CHUNK):

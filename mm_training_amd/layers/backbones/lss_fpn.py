@@ -326,7 +326,10 @@ class LSSFPN(nn.Module):
                                         pending=False, calls=0, last=None, strikes=0)
         if w["pending"] and w["event"].query():
             words = w["host"].view(torch.int32)
-            brute, calls = int(words[10]), int(words[12])           # CacheHeader: hits [8], built [9], brute [10], resets [11], calls [12]
+            brute, calls = int(words[10]), int(words[12])           # CacheHeader: hits [8], built [9], brute [10], resets [11], calls [12], stale [13]
+            if int(words[13]) > 0:
+                raise RuntimeError("LSSFPN: a plan-form forward found a verdict that no lookup of its batch had left in the plan cache "
+                                   f"({int(words[13])} sample-forwards wrote no output); the pooled maps of those steps are invalid")
             if w["last"] is not None and calls > w["last"][1]:
                 w["strikes"] = w["strikes"] + 1 if brute > w["last"][0] else 0
                 if w["strikes"] >= 2:

@@ -63,8 +63,13 @@ class ResNet(nn.Module):
     ARCH = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3))}
 
     def __init__(self, depth=50, in_channels=3, base_channels=64, num_stages=4, strides=(1, 2, 2, 2),
-                 dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False, **unused):
+                 dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False, init_cfg=None, pretrained=None, **unused):
         super().__init__()
+        # whether weights from a checkpoint have reached this module (load_state_dict / init_cfg / pretrained): a FROZEN stem
+        # (frozen_stages >= 0, the reference's configuration) that still holds its random initialisation is a model-quality trap --
+        # conv1 / bn1 never train and bn1 normalises with identity statistics -- so the first training forward warns about it
+        self._weights_loaded = False
+        self._warned_frozen_random = False
         block, blocks = self.ARCH[depth]
         self.out_indices = tuple(out_indices)
         # mmdet ResNet (the reference's image backbone is built with frozen_stages=0, norm_eval=False: exps/conf_aim.py:57-59):
@@ -95,6 +100,11 @@ class ResNet(nn.Module):
             self.stages.append(nn.Sequential(*layers))
         self.init_weights()
         self._freeze_stages()
+        ckpt = pretrained
+        if ckpt is None and isinstance(init_cfg, dict) and init_cfg.get("type") == "Pretrained":
+            ckpt = init_cfg.get("checkpoint")            # exps/conf_aim.py:60: dict(type='Pretrained', checkpoint='torchvision://resnet50')
+        if ckpt:
+            self.load_pretrained(ckpt)
 
     def init_weights(self):
         for m in self.modules():
@@ -103,6 +113,49 @@ class ResNet(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
+
+    # torchvision / mmdet name the stages layer1..layer4; this module keeps them in `stages` (0-based).  Everything below a stage has
+    # the same names (N.conv1, N.bn1, N.downsample.0 / .1), so a checkpoint of either family loads after this one substitution.
+    @staticmethod
+    def _checkpoint_key(key):
+        import re
+        m = re.match(r"layer([1-9])\.(.*)", key)
+        return f"stages.{int(m.group(1)) - 1}.{m.group(2)}" if m else key
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for key in [k for k in state_dict if k.startswith(prefix)]:
+            local = key[len(prefix):]
+            if local.startswith("fc."):                  # the classifier of an ImageNet checkpoint: not part of a backbone
+                state_dict.pop(key)
+                continue
+            mapped = self._checkpoint_key(local)
+            if mapped != local:
+                state_dict[prefix + mapped] = state_dict.pop(key)
+        if any(k.startswith(prefix) for k in state_dict):
+            self._weights_loaded = True
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def load_pretrained(self, checkpoint):
+        """Weights of a torchvision / mmdet ResNet checkpoint file.  `torchvision://resnet50`-style names (what the reference's
+        configuration carries) cannot be fetched here: they are looked up as $MMT_PRETRAINED_DIR/<name>.pth; a name that resolves
+        to no file leaves the random initialisation and says so."""
+        import os
+        import warnings
+        path = checkpoint
+        if "://" in checkpoint:
+            root = os.environ.get("MMT_PRETRAINED_DIR")
+            path = os.path.join(root, checkpoint.split("://", 1)[1] + ".pth") if root else None
+        if not path or not os.path.exists(path):
+            warnings.warn(f"ResNet: pretrained checkpoint {checkpoint!r} not found"
+                          + ("" if path else " (set MMT_PRETRAINED_DIR to a directory holding <name>.pth)") + "; keeping the random initialisation")
+            return False
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+        sd = {(k[len("backbone."):] if k.startswith("backbone.") else k): v for k, v in sd.items()}
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        if missing:
+            warnings.warn(f"ResNet: {len(missing)} parameters not in {checkpoint!r} (e.g. {missing[:3]})")
+        return True
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:
@@ -126,6 +179,14 @@ class ResNet(nn.Module):
         return self
 
     def forward(self, x):
+        if self.training and self.frozen_stages >= 0 and not self._weights_loaded and not self._warned_frozen_random:
+            import warnings
+            self._warned_frozen_random = True
+            warnings.warn(f"ResNet: frozen_stages={self.frozen_stages} freezes the stem"
+                          + (f" and stages 1..{self.frozen_stages}" if self.frozen_stages > 0 else "")
+                          + ", but no checkpoint has been loaded: the frozen layers keep their RANDOM initialisation and identity BatchNorm "
+                          "statistics for the whole training (the reference freezes a pretrained stem: exps/conf_aim.py:57-60).  Load weights "
+                          "(load_state_dict / init_cfg / pretrained=) or build with frozen_stages=-1; throughput benchmarks are unaffected.")
         x = self.maxpool(bn_act(self.bn1, self.conv1(x)))
         outs = []
         # A block hands its output on as a tuple of ALIASES of one buffer (bn_act(..., fork=2|3)): the next block reads the first with

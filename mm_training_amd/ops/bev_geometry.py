@@ -466,13 +466,14 @@ def _plan_ptr(cache):
 
 
 def plan_cache_counters(cache):
-    """dict(hit, learnt, brute, resets, calls, slots) of a plan cache (synchronises the current stream)."""
+    """dict(hit, learnt, brute, resets, calls, slots, stale) of a plan cache (synchronises the current stream).  stale: forwards told
+    MMT_LSS_PLAN_PREPARED that found a verdict no lookup had left (they wrote nothing for that sample)."""
     import ctypes
     out = (ctypes.c_int64 * 8)()
     ptr, nbytes = _plan_ptr(cache)
     with torch.cuda.device(cache.device):
         _lib.call("mmt_lss_plan_cache_counters", ptr, nbytes, out, _stream())
-    return dict(hit=int(out[0]), learnt=int(out[1]), brute=int(out[2]), resets=int(out[3]), calls=int(out[4]), slots=int(out[5]))
+    return dict(hit=int(out[0]), learnt=int(out[1]), brute=int(out[2]), resets=int(out[3]), calls=int(out[4]), slots=int(out[5]), stale=int(out[6]))
 
 
 def plan_prepare(combine, axes, voxel_num, voxel_coord, voxel_size, plan_cache):

@@ -160,26 +160,42 @@ def _deferral_is_safe(leaf, gw, leaves=None):
 
 
 # bf16 copies of convolution weights kept current by the optimizer (dp/optim.py::ClipAdamW.make_bf16_shadows): id(weight) ->
-# (weak reference to the weight, the copy, the weight's version counter when the copy was last known to be current)
+# (weak reference to the weight, the copy, the weight's version counter and storage address when the copy was last known to be current)
 _shadows = {}
 
 
 def register_bf16_shadow(weight, shadow):
     import weakref
-    _shadows[id(weight)] = (weakref.ref(weight), shadow, weight._version)
+    _shadows[id(weight)] = (weakref.ref(weight), shadow, weight._version, weight.data_ptr())
+
+
+def refresh_bf16_shadows():
+    """Re-copy every registered bf16 weight copy from its parameter.  For writers the version counter does not see: `p.data.copy_(..)`
+    and `p.data = ..` leave `p._version` alone (a replaced storage is caught by its address; an in-place write through `.data` into
+    the SAME storage is not) -- code that writes weights that way calls this afterwards."""
+    for key, ent in list(_shadows.items()):
+        w = ent[0]()
+        if w is None:
+            _shadows.pop(key)
+            continue
+        with torch.no_grad():
+            ent[1].copy_(w)
+        _shadows[key] = (ent[0], ent[1], w._version, w.data_ptr())
 
 
 def _cast_weight(w, dtype):
     """The weight in the autocast dtype: the optimizer's copy when there is one, else a cast.  The optimizer updates weight and copy
     through raw pointers, so the weight's version counter only moves for OTHER writers (load_state_dict, an initialiser, another
-    optimizer): a moved counter means the copy is stale, and it is refreshed here (one copy kernel -- what the cast would have cost)."""
+    optimizer): a moved counter -- or a storage that is no longer the one the copy was made from (`p.data = ..`, `module.to(..)`) --
+    means the copy is stale, and it is refreshed here (one copy kernel -- what the cast would have cost).  In-place writes through
+    `.data` into the same storage move neither: refresh_bf16_shadows() is for those."""
     if dtype is torch.bfloat16:
         ent = _shadows.get(id(w))
         if ent is not None and ent[0]() is w:
-            if w._version != ent[2]:
+            if w._version != ent[2] or w.data_ptr() != ent[3]:
                 with torch.no_grad():
                     ent[1].copy_(w)
-                _shadows[id(w)] = (ent[0], ent[1], w._version)
+                _shadows[id(w)] = (ent[0], ent[1], w._version, w.data_ptr())
             return ent[1]
     return w.to(dtype)
 

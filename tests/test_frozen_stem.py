@@ -32,6 +32,43 @@ def test_frozen_stages_semantics_cpu():
     assert net2.bn1.training and all(p.requires_grad for p in net2.parameters())
 
 
+def test_torchvision_style_checkpoint_loads_and_a_random_frozen_stem_warns(tmp_path, monkeypatch):
+    """ADVICE (round 5): the reference freezes a PRETRAINED stem (exps/conf_aim.py:57-60, torchvision://resnet50).  A checkpoint with
+    torchvision / mmdet keys (layerN.*, fc.*) loads into this ResNet (stages.N-1.*), directly and through init_cfg with
+    $MMT_PRETRAINED_DIR; a frozen stem that never received weights warns at its first training forward, a loaded or unfrozen one
+    does not."""
+    import warnings
+    from mm_training_amd.layers.nets import ResNet
+    torch.manual_seed(1)
+    src = ResNet(depth=18, base_channels=8)
+    with torch.no_grad():
+        src.bn1.running_mean.normal_(); src.bn1.running_var.uniform_(0.5, 2.0)
+    tv = {}
+    for k, v in src.state_dict().items():
+        parts = k.split(".")
+        tv[".".join(["layer%d" % (int(parts[1]) + 1)] + parts[2:]) if parts[0] == "stages" else k] = v.clone()
+    tv["fc.weight"], tv["fc.bias"] = torch.zeros(10, 64), torch.zeros(10)          # an ImageNet classifier rides along
+    assert any(k.startswith("layer4.1.") for k in tv) and any(".downsample.0.weight" in k for k in tv)
+    dst = ResNet(depth=18, base_channels=8, frozen_stages=0)
+    missing, unexpected = dst.load_state_dict(dict(tv), strict=True)
+    assert not missing and not unexpected and dst._weights_loaded
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        dst.train()(torch.randn(2, 3, 64, 64))                                      # loaded: silent
+        ResNet(depth=18, base_channels=8).train()(torch.randn(2, 3, 64, 64))       # nothing frozen: silent
+    with pytest.warns(UserWarning, match="RANDOM initialisation"):
+        ResNet(depth=18, base_channels=8, frozen_stages=0).train()(torch.randn(2, 3, 64, 64))
+    # the reference's init_cfg: resolved through MMT_PRETRAINED_DIR; a name that resolves to nothing says so
+    torch.save({"state_dict": {"backbone." + k: v for k, v in tv.items()}}, tmp_path / "resnet18.pth")
+    monkeypatch.setenv("MMT_PRETRAINED_DIR", str(tmp_path))
+    via_cfg = ResNet(depth=18, base_channels=8, frozen_stages=0, init_cfg=dict(type="Pretrained", checkpoint="torchvision://resnet18"))
+    assert via_cfg._weights_loaded and torch.equal(via_cfg.stages[3][1].conv2.weight, src.stages[3][1].conv2.weight)
+    with pytest.warns(UserWarning, match="not found"):
+        ResNet(depth=18, base_channels=8, init_cfg=dict(type="Pretrained", checkpoint="torchvision://resnet999"))
+
+
 def test_bench_configurations_freeze_the_stem():
     from mm_training_amd.dp import make_config
     for name in ("cfg2", "cfg4", "cfg5", "tiny"):

@@ -342,3 +342,36 @@ def test_plan_form_argument_checks(mmt_lib):
     assert ok(*args(nbytes=4096)) == -2
     assert ok(*args(geo=[0] + geo[1:])) == -1
     torch.cuda.synchronize()
+
+
+def test_prepared_flag_on_an_unprepared_cache_writes_nothing_and_is_counted(mmt_lib, golden):
+    """ADVICE (round 5): mmt_lss_splat_forward_plan told MMT_LSS_PLAN_PREPARED goes by the verdicts in the cache.  On a cache no
+    lookup has filled (verdict state Empty) it used to serve the samples from slot summaries that were never built -- a wrong map,
+    no error.  Now such a sample's part of the map is left untouched and the header counts it (counters['stale']; LSSFPN's lazy
+    read-back raises on it); the same call without the flag, and with it after a lookup, is correct."""
+    from mm_training_amd.ops.bev_geometry import frustum_axes, new_plan_cache, plan_cache_counters, plan_prepare
+    g = golden["quant_geom"]
+    fr = torch.from_numpy(g["nusc_frustum"])
+    cb = torch.from_numpy(g["rig_combine"]).contiguous().cuda()
+    B, N = cb.shape[:2]
+    D, fH, fW, _ = fr.shape
+    vc, vs, vn = g["nusc_voxel_coord"], g["nusc_voxel_size"], [128, 128, 1]
+    axes = tuple(a.cuda() for a in frustum_axes(fr))
+    gen = torch.Generator().manual_seed(3)
+    depth = torch.rand(B * N, fH, fW, D, generator=gen).softmax(-1).cuda()
+    ctx = torch.randn(B * N, fH, fW, 64, generator=gen).cuda()
+    cache = new_plan_cache(N, D, fH, fW, vn, "cuda", slots=max(B, 2))
+    out = _forward(cb, axes, vc, vs, vn, depth, ctx, cache, prepared=True)
+    assert bool(torch.isnan(out).all())                                    # nothing written
+    # (the header is only signed by a lookup: before one, the counters read 0 -- the stale count shows after it)
+    good = _forward(cb, axes, vc, vs, vn, depth, ctx, cache)
+    assert not bool(torch.isnan(good).any())
+    assert torch.equal(good, _forward(cb, axes, vc, vs, vn, depth, ctx, cache, prepared=True))
+    assert plan_cache_counters(cache)["stale"] == 0
+    # verdicts wiped behind the library's back (what a stale snapshot would look like): counted, nothing written
+    lay = _layout(N, D, fH, fW, vn[0], vn[1], cache)
+    o = lay["base"] + lay["verdict_off"]
+    cache[o:o + 64 * B] = 0
+    out = _forward(cb, axes, vc, vs, vn, depth, ctx, cache, prepared=True)
+    assert bool(torch.isnan(out).all()) and plan_cache_counters(cache)["stale"] == B
+

