@@ -40,6 +40,12 @@ while time.time() < t_end:
     C = groups * 4 * int(rng.integers(1, 9))
     O = groups * int(rng.integers(1, 17))
     B, H, W = int(rng.integers(1, 4)), int(rng.integers(2, 20)), int(rng.integers(2, 30))   # H or W == 1: the grid_sample reference degenerates (align_corners)
+    if it % 3 == 0:
+        # every third configuration: a shape of the implicit-GEMM form (round 6, csrc/deform_conv_mfma.hip: C/groups a multiple of 64,
+        # O/groups 64 or 128): frames on both sides of the gather form's 768 pixels, pixel counts that are multiples of nothing
+        C = groups * int(rng.choice([64, 128]))
+        O = groups * int(rng.choice([64, 128]))
+        H, W = (int(rng.integers(2, 28)), int(rng.integers(2, 30))) if rng.random() < 0.8 else (int(rng.integers(20, 60)), int(rng.integers(30, 50)))
     cfg = dict(it=it, op="dcn", B=B, C=C, O=O, H=H, W=W, groups=groups)
     if verbose:
         print(cfg, flush=True)
