@@ -45,6 +45,8 @@ WORKLOADS = {
             "40k-point LiDAR frames (0.2 m pillars, 512x512 canvas) concatenated in BEV; full training step "
             "(depth labels + fwd + det/depth loss + bwd + clip + AdamW)",
     "cfg5": "BASELINE configs[4]: LiDAR+radar+camera, 6 cams 512x1408, 80k pts (8 columns); bf16 storage on the hot path",
+    "aim": "the reference's native configuration (exps/conf_aim.py + exps/configs/lidar_cam.py; not a BASELINE config, SURVEY 8 'for fidelity'): "
+           "2 cams 704x1280, D=409, C=80, camera BEV 512x64 (0.8 m), 40k-point LiDAR frames on 2048x256 pillars, bs 4; full training step",
     "tiny": "tiny smoke configuration",
 }
 # camera halves for --mode hotpath (SURVEY.md section 8 shape table)
@@ -734,7 +736,7 @@ def train_main(args, rank, local_rank, world):
     PMC_RIG = args.rig
     # benchmark=True makes PyTorch ask MIOpen's find API, which is answered from the find DB
     # (only for the configurations the DB was produced on: an unknown shape would start a search)
-    db_cfg = SHIPPED_MIOPEN_DB and args.config in ("cfg2", "cfg3", "cfg4", "cfg5")
+    db_cfg = SHIPPED_MIOPEN_DB and args.config in ("cfg2", "cfg3", "cfg4", "cfg5", "aim")
     torch.backends.cudnn.benchmark = bool(args.miopen_tune) or db_cfg
     dev = torch.device("cuda", local_rank)
     cfg = make_config(args.config)

@@ -7,6 +7,11 @@ lidar_conf :192-213, train_cfg :143-160).
   cfg3n the same on the reference's native range [-204.8, -25.6, -5, 204.8, 25.6, 3] (exps/conf_aim.py:16-18: 2048 x 256 pillars), SURVEY 8d
   cfg4  LiDAR + camera fusion (cfg2 camera half + pillar BEV concat)
   cfg5  LiDAR + radar + camera, 6 cams 512x1408, 80k points (8 columns)
+  aim   the reference's OWN configuration (exps/conf_aim.py:1-3,16-18,42-52 with the camera + LiDAR switches of exps/configs/lidar_cam.py):
+        2 cameras 704x1280 (camera_loader.py:111-116), d_bound [2, 206.4, 0.5] -> D = 409, C = 80, camera BEV 512 x 64 cells of 0.8 m on the
+        range [-204.8, -25.6, -5, 204.8, 25.6, 3], 2048 x 256 pillars, bs 4.  Not a BASELINE config; SURVEY 8 lists it "for fidelity": the shape
+        with P = 2.88 M points per sample (3.7 GB of lifted features the fused path never materialises).  The reference's SparseEncoder
+        (out of scope) is replaced by the pillar scatter as in every other configuration here.
   tiny  a few-second smoke configuration for tests (no layer narrower than 16 channels on both sides: MIOpen's narrow NHWC
         data-gradient kernel reads out of bounds, ops/conv_overlap.py NARROW)
 """
@@ -26,11 +31,12 @@ def make_config(name="cfg2"):
     if native:
         name = "cfg3"
     tiny = name == "tiny"
-    use_cam = name in ("cfg2", "cfg4", "cfg5", "tiny")
-    use_lidar = name in ("cfg3", "cfg4", "cfg5", "tiny")
+    aim = name == "aim"
+    use_cam = name in ("cfg2", "cfg4", "cfg5", "tiny", "aim")
+    use_lidar = name in ("cfg3", "cfg4", "cfg5", "tiny", "aim")
     use_radar = name == "cfg5"
-    final_dim = (512, 1408) if name == "cfg5" else ((64, 192) if tiny else (256, 704))
-    pc_range = [-204.8, -25.6, -5.0, 204.8, 25.6, 3.0] if native else [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    final_dim = (512, 1408) if name == "cfg5" else ((64, 192) if tiny else ((704, 1280) if aim else (256, 704)))
+    pc_range = [-204.8, -25.6, -5.0, 204.8, 25.6, 3.0] if (native or aim) else [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
     voxel_size = [0.2, 0.2, 8.0]
     out_size_factor = 4
     bev_cell = voxel_size[0] * out_size_factor            # 0.8 m camera BEV cells -> 128 x 128
@@ -44,7 +50,8 @@ def make_config(name="cfg2"):
     backbone_conf = dict(
         x_bound=[pc_range[0], pc_range[3], bev_cell], y_bound=[pc_range[1], pc_range[4], bev_cell],
         z_bound=[pc_range[2], pc_range[5], voxel_size[2]],
-        d_bound=[2.0, 58.0, 4.0 if tiny else 0.5], final_dim=final_dim, output_channels=cam_channels,
+        # exps/conf_aim.py:46: d_bound = [2.0, point_cloud_range[3] + 1.6, 0.5] -> 409 bins on the native range
+        d_bound=[2.0, pc_range[3] + 1.6, 0.5] if aim else [2.0, 58.0, 4.0 if tiny else 0.5], final_dim=final_dim, output_channels=cam_channels,
         downsample_factor=16,
         # exps/conf_aim.py:54-61: frozen_stages=0 -- the stem (conv1 + norm1) has no gradients and its BatchNorm runs in eval mode
         img_backbone_conf=dict(type='ResNet', depth=18 if tiny else 50, base_channels=16 if tiny else 64,
@@ -83,8 +90,8 @@ def make_config(name="cfg2"):
         lidar_conf['pts_voxel_layer']['max_voxels'] = (2000, 2000)
     cfg = dict(
         name="cfg3n" if native else name, use_cam=use_cam, use_lidar=use_lidar, use_radar=use_radar,
-        batch_size={"cfg2": 4, "cfg3": 8, "cfg4": 4, "cfg5": 2, "tiny": 2}[name],
-        num_cams=2 if tiny else 6, final_dim=final_dim,
+        batch_size={"cfg2": 4, "cfg3": 8, "cfg4": 4, "cfg5": 2, "tiny": 2, "aim": 4}[name],
+        num_cams=2 if (tiny or aim) else 6, final_dim=final_dim,
         num_points=80000 if name == "cfg5" else (2000 if tiny else 40000),
         point_features=8 if use_radar else 5,
         point_cloud_range=pc_range, backbone_conf=backbone_conf, head_conf=head_conf, lidar_conf=lidar_conf,

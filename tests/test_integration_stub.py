@@ -291,3 +291,30 @@ def test_glue_stub_equals_the_reference_lines(mmt_lib):
     want = (imgs[:, :, :, :3] / 255.0 - mean) / std                                          # :510-512
     want = torch.where(torch.from_numpy(flips).cuda().view(2, 1, 3, 1, 1, 1), want.flip(-1), want)   # :100-104
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_section_h_dcn_stub_runs_through_the_c_abi(mmt_lib):
+    """the code block that replaces mmcv's deform_conv2d inside DeformConv2dPack is extracted, executed as
+    written (plain ctypes on the C ABI) and its forward compared with this package's own op and with the fp32 torch restatement
+    (layers/nets.py::DeformConv2dPack.forward_reference) at DepthNet's group shape."""
+    from mm_training_amd import _lib
+    from mm_training_amd.layers.nets import DeformConv2dPack
+    from mm_training_amd.ops.deform_conv import deform_conv3x3
+    _lib.lib()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## H. The deformable convolution of DepthNet"):text.index("## C. Other entry points")]
+    code = sec[sec.index("```python\n") + len("```python\n"):]
+    code = code[:code.index("\n```")]
+    assert 'ctypes.CDLL("mm_training_amd/libmmt_hip.so")' in code
+    ns = {}
+    exec(compile(code.replace('"mm_training_amd/libmmt_hip.so"', repr(_lib.LIB_PATH)), "INTEGRATION.md#H", "exec"), ns)
+    torch.manual_seed(0)
+    B, C, H, W, O, groups = 2, 256, 9, 14, 256, 2
+    m = DeformConv2dPack(C, O, groups=groups).cuda()
+    x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    off = torch.randn(B, 18, H, W, device="cuda") * 0.7
+    got = ns["DeformConv3x3"].apply(x, off, m.weight.detach(), groups)
+    assert torch.equal(got, deform_conv3x3(x, off, m.weight.detach(), groups))
+    ref = m.forward_reference(x, off)
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) + 1e-5
