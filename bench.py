@@ -869,8 +869,8 @@ def train_main(args, rank, local_rank, world):
                         "per-calibration plan learnt on the device (cell -> runs of (column, row block, bins)); a workgroup takes a job (cells of an "
                         "8 x 8 BEV tile, <= 96 runs), sums depth * context per run in registers, one partial row per run into LDS, then sums every "
                         "cell's partial rows in plan order and STORES -- no zero fill, no atomics, bit-identical from step to step.  `avg_ms` is the "
-                        "forward kernel; the per-step lookup of the batch's calibrations (lss_plan_probe + an empty lss_plan_build) is issued in "
-                        "front of the image backbone and reported under `prepare`.  The kernel is bound by the context rows it re-reads through "
+                        "forward CHAIN: the kernel + the per-step lookup of the batch's calibrations (lss_plan_probe + an empty lss_plan_build, issued in "
+                        "front of the image backbone; none at all while named calibrations repeat) -- `parts` has the split.  The kernel is bound by the context rows it re-reads through "
                         "L1 (a column's 16 rows once per job it crosses: ~90 MB per launch at BASELINE configs[3]), not by HBM: l2_side")
             kbwd = {"ray": "lss_ray_bwd", "tile": "lss_splat_bwd_tile", "column": "lss_col_bwd"}.get(fam_b.split("+")[0], fam_b)
             column = fam_b.startswith("column")

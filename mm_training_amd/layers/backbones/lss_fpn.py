@@ -306,9 +306,9 @@ class LSSFPN(nn.Module):
         return cache
 
     def plan_cache_counters(self):
-        """dict(hit, learnt, brute, resets, calls, slots) summed over this module's plan caches (synchronises: outside timed regions)."""
+        """dict(hit, learnt, brute, resets, calls, slots, stale) summed over this module's plan caches (synchronises: outside timed regions)."""
         from mm_training_amd.ops.bev_geometry import plan_cache_counters
-        tot = dict(hit=0, learnt=0, brute=0, resets=0, calls=0, slots=0)
+        tot = dict(hit=0, learnt=0, brute=0, resets=0, calls=0, slots=0, stale=0)
         for cache in self._plan_caches.values():
             for k, v in plan_cache_counters(cache).items():
                 tot[k] += v
