@@ -946,7 +946,7 @@ def train_main(args, rank, local_rank, world):
         res["roofline_softmax"] = roofline_entry("depth_softmax_fwd (depth distribution + oracle overwrite, pixel-major; lss_fpn.py:423-438)", sm_f, t_f,
                                                  pmc_traffic(args.config, ("depth_softmax_fwd",)))
         res["roofline_softmax"]["backward"] = roofline_entry("depth_softmax_bwd", sm_b, t_b, pmc_traffic(args.config, ("depth_softmax_bwd",)))
-    if cfg["use_cam"] and timing.get("dcn_forward") and timing.get("dcn_backward"):
+    if cfg["use_cam"] and timing.get("dcn_forward"):
         # DepthNet's deformable convolution (lss_fpn.py:189-197) as implicit GEMMs: bound by the fp32 matrix rate
         # (exact-fp32 MFMA), the HBM side beside it.  One GEMM forward, two backward (weight + data gradient).
         dcn = [m for m in ts.model.modules() if type(m).__name__ == "DeformConv2dPack"][0]
@@ -954,7 +954,8 @@ def train_main(args, rank, local_rank, world):
         flop = 2.0 * dB * dH * dW * 9 * (dC // dG) * dO
         io_f = 4.0 * (dB * dH * dW * (dC + 18 + dO) + dcn.weight.numel())
         io_b = 4.0 * (dB * dH * dW * (2 * dC + 2 * 18 + dO) + 2 * dcn.weight.numel())
-        t_f, t_b = _lib.mean_ms(timing["dcn_forward"]), _lib.mean_ms(timing["dcn_backward"])
+        t_f = _lib.mean_ms(timing["dcn_forward"])
+        t_b = _lib.mean_ms(timing["dcn_backward"]) if timing.get("dcn_backward") else None
 
         def dcn_entry(kernels, nflop, nbytes, ms):
             tf = nflop / (ms * 1e-3) / 1e12
@@ -968,9 +969,14 @@ def train_main(args, rank, local_rank, world):
                       flop, io_f, t_f)
         r["traffic"] = pmc_traffic(args.config, fwd_k)
         r["shape"] = {"x": [dB, dC, dH, dW], "out_channels": dO, "groups": dG, "operands": "f32", "accumulate": "f32 (v_mfma_f32_32x32x2_f32)"}
-        r["backward"] = dcn_entry(" + ".join(bwd_k) + " (weight gradient + data / offset gradient: two implicit GEMMs, the scatter of the data "
-                                  "gradient as a gather through per-destination lists)", 2 * flop, io_b, t_b)
-        r["backward"]["traffic"] = pmc_traffic(args.config, bwd_k)
+        if t_b is not None:
+            r["backward"] = dcn_entry(" + ".join(bwd_k) + " (weight gradient + data / offset gradient: two implicit GEMMs, the scatter of the data "
+                                      "gradient as a gather through per-destination lists)", 2 * flop, io_b, t_b)
+            r["backward"]["traffic"] = pmc_traffic(args.config, bwd_k)
+        else:
+            r["backward"] = {"kernel": "column form: dcn_im2col (columns rebuilt in the backward, not stored by the forward) + vendor GEMMs + dcn_plan + "
+                                       "dcn_col2im_gather + dcn_offset_reduce", "note": f"frame of {dH * dW} pixels: above the 768 of the gather form of the "
+                                       "implicit data gradient (mmt_dcn_backward_form == 1); not timed as one sequence (the GEMMs are the vendor library's)"}
         r["note"] = ("x + offsets + weights + out (and their gradients) are the algorithmic bytes: the [B*H*W, 9*C] fp32 columns of the im2col form "
                      "(311 MB at this shape, written once and read by three GEMM passes) no longer exist")
         res["roofline_dcn"] = r
