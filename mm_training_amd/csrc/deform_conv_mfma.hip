@@ -764,23 +764,13 @@ __global__ __launch_bounds__(768) void dcn_dgrad_gather(int H, int W, int C, int
     };
 
     __syncthreads();
-    // ---- the units (round, tap), STAGGERED: the waves are two groups.  Group A (the first half) runs a unit as matrix work, then
-    // its epilogue (offset-gradient dots of this unit + the gather of the previous one); group B runs the epilogue of its PREVIOUS
-    // unit first and the matrix work after it.  Between two barriers one group is on the matrix pipe while the other is in
-    // VALU / memory work, instead of every wave doing the same phase at the same time (56 % of the wave cycles were waits).
-    // What the barrier orders is unchanged: a unit's gc tile is staged by every wave before the barrier that ends the unit
-    // (A stages mid-way, B at the end), and gathered during the next unit (A at its end, B at its start).
-    const bool late = wave >= (nw + 1) / 2;      // group B
-    const int units = rounds * 9;
-    float gq[2][KQ];
-    int phw[2] = {0, 0};          // the sub-tiles' pixels of this lane as (row << 16) | column (registers are what this kernel is short of)
-    bool valid[2] = {false, false};
-    float2 onext[2];              // offsets of the tap whose epilogue comes next (loaded a unit ahead)
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    auto pixel = [&](int sub) { return (phw[sub] >> 16) * W + (phw[sub] & 0xFFFF); };
-    auto load_round = [&](int rd) {
+    int buf = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
         const int tile = rd * nw + wave;
         const bool active = tile < ntiles;
+        float gq[2][KQ];
+        int phw[2];               // the sub-tile's pixel of this lane as (row << 16) | column (registers are what this kernel is short of)
+        bool valid[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             int p = tile * 32 + sub * 16 + l15;
@@ -795,100 +785,59 @@ __global__ __launch_bounds__(768) void dcn_dgrad_gather(int H, int W, int C, int
                 gq[sub][4 * j] = v.x; gq[sub][4 * j + 1] = v.y; gq[sub][4 * j + 2] = v.z; gq[sub][4 * j + 3] = v.w;
             }
         }
-    };
-    auto load_offsets = [&](int tap) {
+        float2 onext[2];        // the two pixels' offsets of the tap about to be processed (loaded a unit ahead)
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) onext[sub] = *reinterpret_cast<const float2 *>(ofb + (size_t)pixel(sub) * 18 + 2 * tap);
-    };
-    auto corners = [&](int sub, int tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        return corner_info(mmt_dcn::make_tap((float)((phw[sub] >> 16) + ky - 1) + onext[sub].x, (float)((phw[sub] & 0xFFFF) + kx - 1) + onext[sub].y, H, W), valid[sub]);
-    };
-    auto load_rows = [&](const CornerInfo &c, float4 (&xv)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xbase + ((unsigned)c.o[i] * xstride + xlane));
-    };
-    auto matrix = [&](int buf) {
-        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *ar = wl + buf * 16 * WLD + l15 * WLD + kq * KQ;
-#pragma unroll
-        for (int s = 0; s < KQ / 2; ++s) {
-            const f32x2 a = *reinterpret_cast<const f32x2 *>(ar + 2 * s);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[0][2 * s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[1][2 * s], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[0][2 * s + 1], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[1][2 * s + 1], acc[1], 0, 0, 0);
-        }
-        // stage gc[pixel of the round][4 channels of this lane] (pixels past the image stage zeros: never listed)
-        float *sg = gcs + (buf * ppr + wave * 32 + l15) * kGcLd + 4 * kq;
-        *reinterpret_cast<f32x4 *>(sg) = acc[0];
-        *reinterpret_cast<f32x4 *>(sg + 16 * kGcLd) = acc[1];
-    };
-    auto part_of = [&](int tap) { return part + ((size_t)(cglob * 9 + tap) * 2) * npos + (size_t)b * HW; };
-
-    if (!late) { load_round(0); load_offsets(0); }
-    for (int u = 0; u < units; ++u) {
-        const int rd = u / 9, tap = u - rd * 9, buf = u & 1;
-        const int prd = tap == 0 ? rd - 1 : rd, ptap = tap == 0 ? 8 : tap - 1;         // the previous unit: its staged tile is gathered now
-        // the next unit's weight tile into the other buffer (last read before the previous barrier)
-        if (u + 1 < units) fill_weights(tap == 8 ? 0 : tap + 1, buf ^ 1);
-        if (!late) {
-            if (u > 0) prefetch_entries(ptap);          // (its bounds were loaded at the previous unit's end)
-            if (tap == 0 && u > 0) { load_round(rd); load_offsets(0); }
+        for (int sub = 0; sub < 2; ++sub) onext[sub] = *reinterpret_cast<const float2 *>(ofb + (size_t)((phw[sub] >> 16) * W + (phw[sub] & 0xFFFF)) * 18);
+        for (int tap = 0; tap < 9; ++tap) {
+            const int u = rd * 9 + tap;
+            const int prd = tap == 0 ? rd - 1 : rd, ptap = tap == 0 ? 8 : tap - 1;     // the unit whose staged tile is gathered now
+            // the next tap's weight tile (tap 0 again for the next round) into the other buffer: last read before the barrier
+            if (tap < 8 || rd + 1 < rounds) fill_weights(tap == 8 ? 0 : tap + 1, buf ^ 1);
+            if (u > 0) prefetch_entries(ptap);          // (the bounds of the previous unit were loaded at its end)
+            const int ky = tap / 3, kx = tap - ky * 3;
             // sub-tile 0: sampling point and corner rows before the matrix work (the rows arrive under it)
-            const CornerInfo c0 = corners(0, tap);
+            CornerInfo c0 = corner_info(mmt_dcn::make_tap((float)((phw[0] >> 16) + ky - 1) + onext[0].x, (float)((phw[0] & 0xFFFF) + kx - 1) + onext[0].y, H, W), valid[0]);
             float4 xv[4];
-            load_rows(c0, xv);
-            matrix(buf);
-            float *pd = part_of(tap);
-            offset_dots(c0, acc[0], xv, kq == 0 && valid[0], pd + pixel(0), npos);
-            // sub-tile 1: its corner rows arrive under the previous unit's gather
-            const CornerInfo c1 = corners(1, tap);
-            load_rows(c1, xv);
-            if (u > 0) gather_item(0, prd, ptap, buf ^ 1);
-            offset_dots(c1, acc[1], xv, kq == 0 && valid[1], pd + pixel(1), npos);
-            if (tap < 8) load_offsets(tap + 1);
-            bounds(rd, tap);                 // for the gather of THIS unit, one unit from now
-        } else {
-            if (u > 0) {
-                // epilogue of the previous unit: its accumulators, pixels and offsets are still in the registers; its list run was
-                // prefetched behind its matrix work
-                const CornerInfo c0 = corners(0, ptap);
-                float4 xv[4];
-                load_rows(c0, xv);
-                gather_item(0, prd, ptap, buf ^ 1);
-                float *pd = part_of(ptap);
-                offset_dots(c0, acc[0], xv, kq == 0 && valid[0], pd + pixel(0), npos);
-                const CornerInfo c1 = corners(1, ptap);
-                load_rows(c1, xv);
-                offset_dots(c1, acc[1], xv, kq == 0 && valid[1], pd + pixel(1), npos);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xbase + ((unsigned)c0.o[i] * xstride + xlane));
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const float *ar = wl + buf * 16 * WLD + l15 * WLD + kq * KQ;
+#pragma unroll
+            for (int s = 0; s < KQ / 2; ++s) {
+                const f32x2 a = *reinterpret_cast<const f32x2 *>(ar + 2 * s);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[0][2 * s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gq[1][2 * s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[0][2 * s + 1], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gq[1][2 * s + 1], acc[1], 0, 0, 0);
             }
-            if (tap == 0) load_round(rd);
-            load_offsets(tap);                // consumed by this unit's epilogue, one barrier from now
-            bounds(rd, tap);
-            matrix(buf);
-            prefetch_entries(tap);            // this unit's list run, for its gather at the top of the next unit
+            float *pd = part + ((size_t)(cglob * 9 + tap) * 2) * npos + (size_t)b * HW;
+            // stage gc[pixel of the round][4 channels of this lane] (pixels past the image stage zeros: never listed)
+            float *sg = gcs + (buf * ppr + wave * 32 + l15) * kGcLd + 4 * kq;
+            *reinterpret_cast<f32x4 *>(sg) = acc[0];
+            *reinterpret_cast<f32x4 *>(sg + 16 * kGcLd) = acc[1];
+            offset_dots(c0, acc[0], xv, kq == 0 && valid[0], pd + ((phw[0] >> 16) * W + (phw[0] & 0xFFFF)), npos);
+            // sub-tile 1: its corner rows arrive under the previous unit's gather
+            CornerInfo c1 = corner_info(mmt_dcn::make_tap((float)((phw[1] >> 16) + ky - 1) + onext[1].x, (float)((phw[1] & 0xFFFF) + kx - 1) + onext[1].y, H, W), valid[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xbase + ((unsigned)c1.o[i] * xstride + xlane));
+            if (u > 0) {
+#pragma unroll
+                for (int k = 0; k < kItems; ++k) gather_item(k, prd, ptap, buf ^ 1);
+            }
+            offset_dots(c1, acc[1], xv, kq == 0 && valid[1], pd + ((phw[1] >> 16) * W + (phw[1] & 0xFFFF)), npos);
+            if (tap < 8) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+                    onext[sub] = *reinterpret_cast<const float2 *>(ofb + (size_t)((phw[sub] >> 16) * W + (phw[sub] & 0xFFFF)) * 18 + 2 * (tap + 1));
+            }
+            bounds(rd, tap);                 // for the gather of THIS unit, one unit from now
+            buf ^= 1;
+            __syncthreads();
         }
-        __syncthreads();
     }
-    {
-        const int lrd = rounds - 1, lbuf = (units - 1) & 1;
-        if (!late) {
-            prefetch_entries(8);
-            gather_item(0, lrd, 8, lbuf);
-        } else {
-            const CornerInfo c0 = corners(0, 8);
-            float4 xv[4];
-            load_rows(c0, xv);
-            gather_item(0, lrd, 8, lbuf);
-            float *pd = part_of(8);
-            offset_dots(c0, acc[0], xv, kq == 0 && valid[0], pd + pixel(0), npos);
-            const CornerInfo c1 = corners(1, 8);
-            load_rows(c1, xv);
-            offset_dots(c1, acc[1], xv, kq == 0 && valid[1], pd + pixel(1), npos);
-        }
-    }
+    prefetch_entries(8);
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) gather_item(k, rounds - 1, 8, buf ^ 1);
     float *gxb = grad_x + (size_t)b * HW * C + cb;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
