@@ -900,8 +900,8 @@ def train_main(args, rank, local_rank, world):
                 res["roofline"] = roofline_entry(f"{kfwd}{sfx} + the per-step calibration lookup (fused lift-splat forward, plan form = the step's "
                                                  "voxel_pooling forward)", fbytes, fwd_ms + prep_ms, pmc_traffic(args.config, (key_f,)), l2f, note)
                 res["roofline"]["parts"] = {"forward_kernel_ms": fwd_ms, "lookup_ms_per_step": prep_ms,
-                                            "lookup_launches_per_step": 2.0 * len(prep) / max(len(timing["lift_splat_forward"]), 1),
-                                            "lookup_kernels": "lss_plan_probe + lss_plan_build (issued in front of the image backbone)",
+                                            "lookup_launches_per_step": 1.0 * len(prep) / max(len(timing["lift_splat_forward"]), 1),
+                                            "lookup_kernels": "lss_plan_lookup (probe + build in one launch; a batch seen before is recognised from a snapshot; issued in front of the image backbone)",
                                             "forward_kernel_frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             else:
                 res["roofline"] = roofline_entry(f"lss_zero_fill + {kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,

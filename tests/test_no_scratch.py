@@ -17,14 +17,15 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 #   lss_ray_bwd, the per-pixel ray-walk backward (not the level rig's default): __launch_bounds__(256, 6) caps it at 80 VGPRs so
 #   that every workgroup of the launch is resident at once, and the camera form's geometry phase spills 12-76 bytes per
 #   thread for it -- a measured trade (round 3: 36.5 -> 26.7 us with the cap), outside the walk's loop.
-# * lss_plan_build (lift_splat_plan.hip): learns a calibration's plan ONCE (one 1024-thread workgroup per calibration, phases of
+# * lss_plan_lookup (round 6: the probe + lss_plan_build in one launch; the scratch is the build part's) /
+#   lss_plan_build (lift_splat_plan.hip): learns a calibration's plan ONCE (one 1024-thread workgroup per calibration, phases of
 #   plain index arithmetic with per-thread row-cell arrays); not on the step's steady-state path.
 # * lss_plan_fwd<.., 5> (lift_splat_plan.hip): capped at 128 VGPRs for four waves per SIMD; two loop-invariant values are spilled
 #   (8-12 bytes per thread, one reload per unit, outside the pair loop) -- 22.8 us with the cap against 27.0 us without.
 # * dcn_dgrad_gather<128> (deform_conv_mfma.hip): eleven waves per workgroup = three per SIMD = 168 VGPRs, of which 64 hold the wave's
 #   grad_out fragments for all nine taps; two loop-carried dwordx2 values (20 bytes per thread) are stored once and reloaded once
 #   per tap, outside the MFMA block (rounds of 8 waves at 256 VGPRs would waste a quarter of the wave slots at 16 x 44 pixels).
-ALLOWED = ("rocprim", "lss_ray_bwd", "lss_plan_build", "lss_plan_fwd", "dcn_dgrad_gather")
+ALLOWED = ("rocprim", "lss_ray_bwd", "lss_plan_build", "lss_plan_lookup", "lss_plan_fwd", "dcn_dgrad_gather")
 
 
 def _kernels(lib_path):
