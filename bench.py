@@ -480,6 +480,43 @@ def add_alone(entry, alone, kinds, _lib):
                       "note": "single-stream leg after the timed steps (no weight-gradient stream, task heads on the caller's stream)"}
 
 
+def lookup_rider_ab(lss, mats, logits_dtype, used_dtype, has_oracle, reps=60):
+    """What the calibration lookup costs as a rider of the depth softmax's launch (mmt_depth_softmax_forward_plan_prepare): the
+    softmax of the step's shape with and without it, `reps` launches each between two events on the current stream (the lookup's
+    own workgroups run beside the softmax's rows; the batch is one the cache knows, as in every timed step).  -> dict of ms."""
+    import torch
+    from mm_training_amd.ops.bev_geometry import depth_softmax
+    B, N = mats["sensor2ego_mats"].shape[0], mats["sensor2ego_mats"].shape[2]
+    D, fH, fW = lss.frustum_d.numel(), lss.frustum_v.numel(), lss.frustum_u.numel()
+    cache = lss._plan_cache_for(B, N, fH, fW, lss.frustum_d.device, None)
+    if cache is None:
+        return None
+    combine = lss.camera_matrices(mats["sensor2ego_mats"][:, 0], mats["intrin_mats"][:, 0], None)
+    lookup = (combine, (lss.frustum_u, lss.frustum_v, lss.frustum_d), lss._voxel_num_host, lss._voxel_coord_host, lss._voxel_size_host, cache)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    logits = torch.randn(B * N, D, fH, fW, device="cuda", generator=g).to(logits_dtype).contiguous(memory_format=torch.channels_last)
+    oracle = None
+    if has_oracle:
+        oracle = torch.zeros(B * N, D, fH, fW, device="cuda").contiguous(memory_format=torch.channels_last)
+        oracle[:, 3, ::2, ::2] = 1.0
+    from mm_training_amd import _lib
+    out = {}
+    with torch.no_grad():
+        for name, lk in (("plain", None), ("with_lookup", lookup), ("plain_again", None)):
+            for _ in range(5):
+                depth_softmax(logits, oracle, used_dtype, plan_lookup=lk)
+            saved, _lib.TIMING = _lib.TIMING, {}              # the library's dispatch-attached events around every launch
+            try:
+                for _ in range(reps):
+                    depth_softmax(logits, oracle, used_dtype, plan_lookup=lk)
+                torch.cuda.synchronize()
+                out[name] = _lib.mean_ms(_lib.TIMING["softmax"])
+            finally:
+                _lib.TIMING = saved
+    plain = min(out["plain"], out["plain_again"])
+    return {"softmax_ms": plain, "softmax_with_lookup_ms": out["with_lookup"], "lookup_cost_ms": max(0.0, out["with_lookup"] - plain), "launches_each": reps}
+
+
 def roofline_entry(kernel, nbytes, ms, traffic=None, l2_bytes=None, note=None):
     gbs = nbytes / (ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -869,8 +906,8 @@ def train_main(args, rank, local_rank, world):
                         "per-calibration plan learnt on the device (cell -> runs of (column, row block, bins)); a workgroup takes a job (cells of an "
                         "8 x 8 BEV tile, <= 96 runs), sums depth * context per run in registers, one partial row per run into LDS, then sums every "
                         "cell's partial rows in plan order and STORES -- no zero fill, no atomics, bit-identical from step to step.  `avg_ms` is the "
-                        "forward CHAIN: the kernel + the per-step lookup of the batch's calibrations (lss_plan_probe + an empty lss_plan_build, issued in "
-                        "front of the image backbone; none at all while named calibrations repeat) -- `parts` has the split.  The kernel is bound by the context rows it re-reads through "
+                        "forward CHAIN: the kernel + the per-step lookup of the batch's calibrations (no launch of its own: it rides in the depth softmax's "
+                        "launch, and there is none at all while named calibrations repeat) -- `parts` has the split.  The kernel is bound by the context rows it re-reads through "
                         "L1 (a column's 16 rows once per job it crosses: ~90 MB per launch at BASELINE configs[3]), not by HBM: l2_side")
             kbwd = {"ray": "lss_ray_bwd", "tile": "lss_splat_bwd_tile", "column": "lss_col_bwd"}.get(fam_b.split("+")[0], fam_b)
             column = fam_b.startswith("column")
@@ -892,16 +929,27 @@ def train_main(args, rank, local_rank, world):
             # the timed sequence of the forward is the zero fill + the kernel: so is its traffic
             if plan:
                 # "sum of all kernels launched by one op call" -- the plan form's per-step lookup of the batch's
-                # calibrations (lss_plan_probe + lss_plan_build, issued in front of the image backbone) belongs to the forward's
-                # chain: avg_ms / achieved / frac are the CHAIN's; `parts` keeps the split.  With mats_dict['calibration_id'] the
+                # calibrations (mmt_lss_plan_prepare) belongs to the forward's chain: avg_ms / achieved / frac are the CHAIN's;
+                # `parts` keeps the split.  With mats_dict['calibration_id'] the
                 # module skips the lookup while the ids repeat (0 launches per step in steady state).
                 prep = timing.get("lift_splat_plan_prepare") or []
                 prep_ms = sum(s_.elapsed_time(e_) for s_, e_ in prep) / max(len(timing["lift_splat_forward"]), 1)
+                # without ids the lookup RIDES in the depth softmax's launch (mmt_depth_softmax_forward_plan_prepare: its 1 + min(B, 8)
+                # workgroups in front of the softmax's grid): no launch of its own; what it adds to that launch is measured here, A/B
+                rider = None
+                if not prep and not args.calibration_ids and os.environ.get("MMT_PLAN_LOOKUP_RIDER", "1") != "0":
+                    rider = lookup_rider_ab(lss, batches[0][1], torch.bfloat16 if ts.amp_dtype is not None else torch.float32,
+                                            torch.bfloat16 if dtype == "bf16" else torch.float32, bool(ts.pass_depth_labels))
+                ride_ms = rider["lookup_cost_ms"] if rider else 0.0
                 res["roofline"] = roofline_entry(f"{kfwd}{sfx} + the per-step calibration lookup (fused lift-splat forward, plan form = the step's "
-                                                 "voxel_pooling forward)", fbytes, fwd_ms + prep_ms, pmc_traffic(args.config, (key_f,)), l2f, note)
-                res["roofline"]["parts"] = {"forward_kernel_ms": fwd_ms, "lookup_ms_per_step": prep_ms,
+                                                 "voxel_pooling forward)", fbytes, fwd_ms + prep_ms + ride_ms, pmc_traffic(args.config, (key_f,)), l2f, note)
+                res["roofline"]["parts"] = {"forward_kernel_ms": fwd_ms, "lookup_ms_per_step": prep_ms + ride_ms,
                                             "lookup_launches_per_step": 1.0 * len(prep) / max(len(timing["lift_splat_forward"]), 1),
-                                            "lookup_kernels": "lss_plan_lookup (probe + build in one launch; a batch seen before is recognised from a snapshot; issued in front of the image backbone)",
+                                            "lookup_kernels": ("none: the named calibrations repeat, the verdicts in their cache stand" if args.calibration_ids and not prep else
+                                                               "rides in the depth softmax's launch (lss_plan_lookup_softmax: the lookup's workgroups in front of the softmax's grid; "
+                                                               "a batch seen before is recognised from a snapshot); lookup_ms_per_step = that launch with the lookup minus without, `lookup_rider_ab`"
+                                                               if rider else "lss_plan_lookup (probe + build in one launch; a batch seen before is recognised from a snapshot)"),
+                                            "lookup_rider_ab": rider,
                                             "forward_kernel_frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             else:
                 res["roofline"] = roofline_entry(f"lss_zero_fill + {kfwd}{sfx} (fused lift-splat forward = the step's voxel_pooling forward)", fbytes, fwd_ms,

@@ -33,14 +33,16 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 13  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
+#define MMT_ABI_VERSION 14  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
                              * 11: region-owner voxelizer -- mmt_voxelize_table_elems / _scratch_elems / _workspace_elems take the point
                              *     count / max_points as well; the table needs no zero fill and holds a cell directory
                              * 12: mmt_clip_adamw_step takes bf16_shadow_ptrs (may be NULL); mmt_channel_blocks_split / _gather;
                              *     fused BatchNorm also for C = a multiple of 256 up to 2048 (was: <= 1024 or 2048); mmt_bn_relu_inference;
                              *     mmt_heads_final_forward / _backward; mmt_head_loss_forward_backward
                              * 13: mmt_dcn_forward / mmt_dcn_backward (+ _supported / _workspace_bytes): the deformable convolution as implicit
-                             *     GEMMs on the fp32 matrix cores, no column buffer; additive */
+                             *     GEMMs on the fp32 matrix cores, no column buffer; additive
+                             * 14: mmt_lss_plan_prepare is ONE launch with a fast path for batches seen before;
+                             *     mmt_depth_softmax_forward_plan_prepare (the lookup rides in the depth softmax's launch); additive */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -168,6 +170,18 @@ int mmt_frustum_geometry(int num_cams_total, int64_t frustum_points, const float
 int mmt_depth_softmax_forward(int64_t pixels, int D, const void *logits, int64_t logit_row_stride, int logits_dtype,
                               float *probs, const float *oracle, int64_t oracle_row_stride, void *depth_used, int used_dtype,
                               void *stream);
+/* The same forward with the plan form's calibration lookup (mmt_lss_plan_prepare, below) riding in its launch (ABI 14): the
+ * lookup's 1 + min(B, 8) workgroups go in front of the softmax's grid, so a step whose calibrations are known launches
+ * nothing for the lookup -- as a launch of its own it costs 4.8 us on an idle card and 6-10 us inside a training step, against
+ * a forward of 28 us.  The softmax rows are those of the batch the lookup is for: pixels == B * N * fH * fW, D = the frustum's
+ * depth bins.  Rows must take 16-byte pieces (D % 4 == 0, every row on a 16-byte (fp32) / 8-byte (bf16) boundary:
+ * MMT_ERR_BAD_SHAPE otherwise -- make the two calls instead).  Afterwards the forward is told MMT_LSS_PLAN_PREPARED. */
+int mmt_depth_softmax_forward_plan_prepare(int64_t pixels, int D, const void *logits, int64_t logit_row_stride, int logits_dtype,
+                                           float *probs, const float *oracle, int64_t oracle_row_stride, void *depth_used, int used_dtype,
+                                           int B, int N, int fH, int fW, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                           const float *combine, const float *frustum_u, const float *frustum_v, const float *frustum_d,
+                                           const float *voxel_coord_host, const float *voxel_size_host, void *plan_cache,
+                                           int64_t plan_cache_bytes, void *stream);
 int mmt_depth_softmax_backward(int64_t pixels, int D, const float *probs, const float *grad_probs, const void *grad_used,
                                int used_dtype, const float *oracle, int64_t oracle_row_stride, void *grad_logits,
                                int logits_dtype, void *stream);
@@ -466,7 +480,8 @@ int mmt_lss_exclusive_cache_used(int B, int N, int D, int fH, int fW, int C);
  *               share a cache must be ordered on one stream).  A slot holds one calibration (a few MB: cfg4 3.9 MB); the least
  *               recently used one is replaced.  A change of the launch shape, the grid or the frustum axes' contents empties it.
  *   mmt_lss_plan_prepare  looks every sample of the batch up (64-bit hash of its matrices, then bit for bit) and learns the
- *               calibrations it does not know (two launches; ~3 us when everything is known).  It depends on `combine` only:
+ *               calibrations it does not know (ONE launch: workgroup 0 looks up, the others wait for its word and build; a batch seen before --
+ *               one of the last four, bit for bit -- takes one round of loads: 4.8 us on an idle card).  It depends on `combine` only:
  *               call it as early in the step as the matrices exist and pass MMT_LSS_PLAN_PREPARED to the forward -- or leave
  *               the flag out and the forward does it itself in front of its kernel.
  *   column_summary (forward, nullable): the batch's column summary [B*N, ceil(fH/16), fW, D, 2] as the camera form defines

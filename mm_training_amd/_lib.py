@@ -44,6 +44,8 @@ SIGNATURES = {
     "mmt_lss_plan_supported": (_c_int, [_c_int] * 9),
     "mmt_lss_plan_cache_bytes": (_c_i64, [_c_int] * 7),
     "mmt_lss_plan_prepare": (_c_int, [_c_int] * 8 + [_c_ptr] * 7 + [_c_i64, _c_ptr]),
+    "mmt_depth_softmax_forward_plan_prepare": (_c_int, [_c_i64, _c_int, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int]
+                                               + [_c_int] * 7 + [_c_ptr] * 7 + [_c_i64, _c_ptr]),
     "mmt_lss_splat_forward_plan": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_i64, _c_int, _c_ptr]),
     "mmt_lss_splat_forward_plan_bf16": (_c_int, [_c_int] * 9 + [_c_ptr] * 11 + [_c_i64, _c_int, _c_ptr]),
     "mmt_lss_plan_cache_counters": (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr]),

@@ -18,125 +18,15 @@
 
 namespace {
 
-constexpr int kGroup = 16;                 // lanes per pixel = one DPP row
+#include "depth_softmax_body.h"
+
 constexpr int kBlock = 256;
 constexpr int kGroupsPerBlock = kBlock / kGroup;
-
-struct SoftmaxArgs {
-    int64_t pixels;
-    int D;
-    const void *logits;          // forward: [pixels] rows of D (fp32 or bf16), logit_stride elements apart
-    int64_t logit_stride;
-    float *probs;                // [pixels, D] fp32 (forward: written; backward: read)
-    const float *oracle;         // nullable; rows oracle_stride floats apart
-    int64_t oracle_stride;
-    void *used;                  // forward, nullable: [pixels, D] fp32 or bf16
-    const float *grad_probs;     // backward, nullable [pixels, D]
-    const void *grad_used;       // backward, nullable [pixels, D] fp32 or bf16
-    void *grad_logits;           // backward: [pixels, D] fp32 or bf16
-};
-
-template <bool MAX>
-__device__ __forceinline__ float row16_reduce(float v) {
-    // xor 1, xor 2 inside the quad, then the mirrored half row and the mirrored row: every lane of the 16 ends with the result
-#define MMT_DPP_STEP(ctrl)                                                                              \
-    {                                                                                                   \
-        const float o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xF, 0xF, true)); \
-        v = MAX ? fmaxf(v, o) : v + o;                                                                  \
-    }
-    MMT_DPP_STEP(0xB1)      // quad_perm [1,0,3,2]
-    MMT_DPP_STEP(0x4E)      // quad_perm [2,3,0,1]
-    MMT_DPP_STEP(0x141)     // row_half_mirror
-    MMT_DPP_STEP(0x140)     // row_mirror
-#undef MMT_DPP_STEP
-    return v;
-}
-
-// element e0 .. e0 + VEC - 1 of a row -> fp32 registers; dead pieces (e0 >= D) read as `fill`
-template <typename T, int VEC>
-__device__ __forceinline__ void load_piece(const T *row, int e0, int D, float fill, float *dst) {
-    if (e0 >= D) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) dst[j] = fill;
-        return;
-    }
-    if constexpr (sizeof(T) == 4) {
-        if constexpr (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(row + e0);
-            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
-        } else {
-            dst[0] = row[e0];
-        }
-    } else {
-        if constexpr (VEC == 4) {
-            const uint2 t = *reinterpret_cast<const uint2 *>(row + e0);
-            dst[0] = bf16_lo(t.x); dst[1] = bf16_hi(t.x); dst[2] = bf16_lo(t.y); dst[3] = bf16_hi(t.y);
-        } else {
-            dst[0] = __uint_as_float((unsigned)row[e0] << 16);
-        }
-    }
-}
-
-template <typename T, int VEC>
-__device__ __forceinline__ void store_piece(T *row, int e0, int D, const float *src) {
-    if (e0 >= D) return;
-    if constexpr (sizeof(T) == 4) {
-        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(row + e0) = make_float4(src[0], src[1], src[2], src[3]);
-        else row[e0] = src[0];
-    } else {
-        if constexpr (VEC == 4) *reinterpret_cast<uint2 *>(row + e0) = make_uint2(pack_bf16x2(src[0], src[1]), pack_bf16x2(src[2], src[3]));
-        else row[e0] = (bf16_t)(pack_bf16x2(src[0], 0.f) & 0xFFFFu);
-    }
-}
 
 // LT: logits type, UT: depth_used type (float / bf16_t); NV pieces of VEC elements per lane cover D <= 16 * NV * VEC
 template <typename LT, typename UT, int VEC, int NV>
 __global__ __launch_bounds__(kBlock) void depth_softmax_fwd(SoftmaxArgs a) {
-    const int grp = threadIdx.x / kGroup, lane = threadIdx.x % kGroup;
-    const int D = a.D;
-    for (int64_t pix = (int64_t)blockIdx.x * kGroupsPerBlock + grp; pix < a.pixels; pix += (int64_t)gridDim.x * kGroupsPerBlock) {
-        const LT *row = static_cast<const LT *>(a.logits) + pix * a.logit_stride;
-        float v[NV * VEC], o[NV * VEC];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) load_piece<LT, VEC>(row, (k * kGroup + lane) * VEC, D, -INFINITY, v + k * VEC);
-        const bool has_oracle = a.oracle != nullptr;
-        if (has_oracle) {
-            const float *orow = a.oracle + pix * a.oracle_stride;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) load_piece<float, VEC>(orow, (k * kGroup + lane) * VEC, D, 0.f, o + k * VEC);
-        }
-        float m = v[0];
-#pragma unroll
-        for (int i = 1; i < NV * VEC; ++i) m = fmaxf(m, v[i]);
-        m = row16_reduce<true>(m);
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV * VEC; ++i) {
-            v[i] = expf(v[i] - m);            // dead pieces: exp(-inf) = 0
-            s += v[i];
-        }
-        s = row16_reduce<false>(s);
-#pragma unroll
-        for (int i = 0; i < NV * VEC; ++i) v[i] = __fdiv_rn(v[i], s);
-        float *prow = a.probs + pix * D;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) store_piece<float, VEC>(prow, (k * kGroup + lane) * VEC, D, v + k * VEC);
-        if (a.used != nullptr) {
-            if (has_oracle) {
-                float om = o[0];
-#pragma unroll
-                for (int i = 1; i < NV * VEC; ++i) om = fmaxf(om, o[i]);
-                om = row16_reduce<true>(om);
-                if (om > 0.f) {                 // lss_fpn.py:429: fg_mask = torch.max(depth_oracle, dim=1).values > 0.0
-#pragma unroll
-                    for (int i = 0; i < NV * VEC; ++i) v[i] = o[i];
-                }
-            }
-            UT *urow = static_cast<UT *>(a.used) + pix * D;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) store_piece<UT, VEC>(urow, (k * kGroup + lane) * VEC, D, v + k * VEC);
-        }
-    }
+    softmax_fwd_rows<LT, UT, VEC, NV>(a, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, kBlock);
 }
 
 template <typename LT, typename UT, int VEC, int NV>
@@ -218,25 +108,12 @@ void launch_types(const SoftmaxArgs &a, bool logits_bf16, bool used_bf16, bool v
     }
 }
 
-int common_check(const char *who, int64_t pixels, int D, int logits_dtype, int used_dtype) {
-    if (pixels < 0 || D <= 0) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: bad sizes (pixels=%lld D=%d)", who, (long long)pixels, D);
-    if (D > 512) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: D=%d exceeds 512 depth bins", who, D);
-    if ((logits_dtype != MMT_DTYPE_F32 && logits_dtype != MMT_DTYPE_BF16) || (used_dtype != MMT_DTYPE_F32 && used_dtype != MMT_DTYPE_BF16))
-        return mmt::fail(MMT_ERR_BAD_FLAG, "%s: dtype must be MMT_DTYPE_F32 or MMT_DTYPE_BF16", who);
-    return 0;
-}
-
-// 16-byte pieces need rows that start on 16-byte (fp32) / 8-byte (bf16) boundaries and D % 4 == 0
-bool aligned(const void *p, int64_t stride_elems, int elem_bytes) {
-    return p == nullptr || ((((uintptr_t)p) % (4 * elem_bytes)) == 0 && (stride_elems % 4) == 0);
-}
-
 }  // namespace
 
 extern "C" int mmt_depth_softmax_forward(int64_t pixels, int D, const void *logits, int64_t logit_row_stride, int logits_dtype,
                                          float *probs, const float *oracle, int64_t oracle_row_stride, void *depth_used,
                                          int used_dtype, void *stream) {
-    if (int rc = common_check("depth_softmax_forward", pixels, D, logits_dtype, used_dtype)) return rc;
+    if (int rc = softmax_common_check("depth_softmax_forward", pixels, D, logits_dtype, used_dtype)) return rc;
     if (pixels == 0) return MMT_OK;
     MMT_REQUIRE_PTR(logits);
     MMT_REQUIRE_PTR(probs);
@@ -245,8 +122,8 @@ extern "C" int mmt_depth_softmax_forward(int64_t pixels, int D, const void *logi
     if (oracle != nullptr && depth_used == nullptr)
         return mmt::fail(MMT_ERR_NULL_POINTER, "depth_softmax_forward: an oracle needs a depth_used output");
     const bool lb = logits_dtype == MMT_DTYPE_BF16, ub = used_dtype == MMT_DTYPE_BF16;
-    const bool vec4 = D % 4 == 0 && aligned(logits, logit_row_stride, lb ? 2 : 4) && aligned(probs, D, 4) &&
-                      aligned(oracle, oracle_row_stride, 4) && aligned(depth_used, D, ub ? 2 : 4);
+    const bool vec4 = D % 4 == 0 && softmax_aligned(logits, logit_row_stride, lb ? 2 : 4) && softmax_aligned(probs, D, 4) &&
+                      softmax_aligned(oracle, oracle_row_stride, 4) && softmax_aligned(depth_used, D, ub ? 2 : 4);
     SoftmaxArgs a{pixels, D, logits, logit_row_stride, probs, oracle, oracle_row_stride, depth_used, nullptr, nullptr, nullptr};
     mmt::TimedSeq seq;
     launch_types<true>(a, lb, ub, vec4, seq, (hipStream_t)stream);
@@ -256,14 +133,14 @@ extern "C" int mmt_depth_softmax_forward(int64_t pixels, int D, const void *logi
 extern "C" int mmt_depth_softmax_backward(int64_t pixels, int D, const float *probs, const float *grad_probs, const void *grad_used,
                                           int used_dtype, const float *oracle, int64_t oracle_row_stride, void *grad_logits,
                                           int logits_dtype, void *stream) {
-    if (int rc = common_check("depth_softmax_backward", pixels, D, logits_dtype, used_dtype)) return rc;
+    if (int rc = softmax_common_check("depth_softmax_backward", pixels, D, logits_dtype, used_dtype)) return rc;
     if (pixels == 0) return MMT_OK;
     MMT_REQUIRE_PTR(probs);
     MMT_REQUIRE_PTR(grad_logits);
     if (oracle != nullptr && oracle_row_stride < D) return mmt::fail(MMT_ERR_BAD_SHAPE, "depth_softmax_backward: row strides must be >= D");
     const bool lb = logits_dtype == MMT_DTYPE_BF16, ub = used_dtype == MMT_DTYPE_BF16;
-    const bool vec4 = D % 4 == 0 && aligned(probs, D, 4) && aligned(grad_probs, D, 4) && aligned(grad_used, D, ub ? 2 : 4) &&
-                      aligned(oracle, oracle_row_stride, 4) && aligned(grad_logits, D, lb ? 2 : 4);
+    const bool vec4 = D % 4 == 0 && softmax_aligned(probs, D, 4) && softmax_aligned(grad_probs, D, 4) && softmax_aligned(grad_used, D, ub ? 2 : 4) &&
+                      softmax_aligned(oracle, oracle_row_stride, 4) && softmax_aligned(grad_logits, D, lb ? 2 : 4);
     SoftmaxArgs a{pixels, D, nullptr, 0, const_cast<float *>(probs), oracle, oracle_row_stride, nullptr, grad_probs, grad_used, grad_logits};
     mmt::TimedSeq seq;
     launch_types<false>(a, lb, ub, vec4, seq, (hipStream_t)stream);

@@ -26,6 +26,7 @@
 namespace {
 
 using namespace mmt::plan;
+#include "depth_softmax_body.h"
 
 constexpr int kPlanMaxB = 64;            // samples per call
 constexpr int kPlanMaxN = 16;            // cameras per sample
@@ -385,101 +386,150 @@ __device__ __forceinline__ void plan_build(const PlanArgs &a, int bi, int nb) {
 // dependent rounds of loads instead of the probe's five or six.  Round 5's two launches took 10.7 + 3.6 us per step.
 __device__ __forceinline__ unsigned char *snap_base(const PlanArgs &a, int k) { return a.cache + a.scratch_off + (int64_t)k * a.snap_stride; }
 
-__global__ __launch_bounds__(kBuildThreads) void lss_plan_lookup(PlanArgs a) {
+__device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg, const int nwg) {      // workgroup wg of the nwg that do the lookup
     unsigned *flags = reinterpret_cast<unsigned *>(a.cache + kFlagOff);
     const int tid = threadIdx.x, nthr = kBuildThreads;
-    if (blockIdx.x != 0) {
-        // ---- a builder: wait for workgroup 0 (bounded: a wait that runs out leaves the to-do list unbuilt, which the forward counts as stale)
+    if (wg != 0) {
+        // ---- a builder: wait for workgroup 0's word -- the launch's token: there is a to-do list (acquire, then build); token + 1:
+        // nothing to learn, leave without reading anything.  (Bounded: a wait that runs out leaves the list unbuilt, which the forward counts as stale.)
         __shared__ int s_go;
         if (tid == 0) {
             int spins = 0;
-            while (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.token && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); ++spins; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            s_go = spins < (1 << 22) ? 1 : 0;
+            unsigned v = __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (v != a.token && v != a.token + 1u && spins < (1 << 22)) {
+                __builtin_amdgcn_s_sleep(4); ++spins;
+                v = __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (v == a.token) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_go = v == a.token ? 1 : 0;
         }
         __syncthreads();
-        if (s_go) plan_build(a, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+        if (s_go) plan_build(a, wg - 1, nwg - 1);
         return;
     }
     // ---- workgroup 0
-    __shared__ unsigned long long s_axes2;
-    __shared__ unsigned s_bad[kSnaps];
-    __shared__ int s_res[4];             // plan_probe's result; [3]: the snapshot that matched, or -1
+    __shared__ unsigned long long s_axpart[kBuildThreads / 64];
+    __shared__ unsigned s_badpart[kBuildThreads / 64];
+    __shared__ int s_res[4];             // plan_probe's result
     CacheHeader *hdr = reinterpret_cast<CacheHeader *>(a.cache);
     Verdict *verdict = reinterpret_cast<Verdict *>(a.cache + kVerdictOff);
-    const int words = a.B * a.d.N * 16;
+    const int words = a.B * a.d.N * 16, vwords = a.B * (int)(sizeof(Verdict) / 4);
     const unsigned *mats = reinterpret_cast<const unsigned *>(a.combine);
-    const bool have_snaps = a.snap_stride > 0;
+    const int64_t voff = 256 + (((int64_t)words * 4 + 255) & ~255ll);                  // a snapshot: [SnapHdr 256 B][matrices][verdicts]
+    const bool have_snaps = a.snap_stride > 0 && voff + (int64_t)vwords * 4 <= a.snap_stride;
+    // ONE round of loads, none depending on another: the header, the axes, the batch's matrices, and all kSnaps snapshots'
+    // headers, matrices and verdicts whether valid or not (the addresses are inside the scratch either way; what a void one holds is not used)
     const unsigned h_magic = hdr->magic, h_sig_lo = hdr->sig_lo, h_sig_hi = hdr->sig_hi, h_ax_lo = hdr->axes_lo, h_ax_hi = hdr->axes_hi,
-                   h_nslots = hdr->nslots, h_snaps = hdr->snaps, h_next = hdr->snap_next;
-    const bool table_ok = h_magic == kPlanMagic && h_sig_lo == a.sig_lo && h_sig_hi == a.sig_hi && h_nslots == (unsigned)a.nslots;
-    const int nsn = (have_snaps && table_ok) ? (int)(h_snaps < (unsigned)kSnaps ? h_snaps : (unsigned)kSnaps) : 0;
-    if (tid == 0) { s_axes2 = 0ull; s_res[0] = 0; s_res[1] = 0; s_res[2] = 0; s_res[3] = -1; }
-    if (tid < kSnaps) s_bad[tid] = tid < nsn ? 0u : 1u;
-    __syncthreads();
-    if (nsn > 0) {
-        // one round of loads: the axes' contents (hashed as the probe hashes them), the batch's matrices against every snapshot's
+                   h_nslots = hdr->nslots, h_snaps = hdr->snaps, h_next = hdr->snap_next, h_clock = hdr->clock, h_hits = hdr->hits, h_calls = hdr->calls;
+    unsigned bad = 0u, sn_hit[kSnaps] = {0u, 0u, 0u, 0u};
+    unsigned vw[kSnaps] = {0u, 0u, 0u, 0u};
+    if (have_snaps) {
         unsigned long long part = 0ull;
         const int na = a.d.fW + a.d.fH + a.d.D;
         for (int i = tid; i < na; i += nthr) {
             const float v = i < a.d.fW ? a.fu[i] : (i < a.d.fW + a.d.fH ? a.fv[i - a.d.fW] : a.fd[i - a.d.fW - a.d.fH]);
             part += mix64(((unsigned long long)i << 32) | __float_as_uint(v));
         }
-        if (part) atomicAdd(&s_axes2, part);
-        for (int k = 0; k < nsn; ++k) {
+#pragma unroll
+        for (int k = 0; k < kSnaps; ++k) {
             const SnapHdr sh = *reinterpret_cast<const SnapHdr *>(snap_base(a, k));
-            const unsigned *sm = reinterpret_cast<const unsigned *>(snap_base(a, k) + 256);
-            bool bad = sh.valid != 1u || sh.B != (unsigned)a.B || sh.words != (unsigned)words;
-            if (!bad) for (int i = tid; i < words; i += nthr) bad = bad || sm[i] != mats[i];
-            if (bad) s_bad[k] = 1u;
+            if (sh.valid != 1u || sh.B != (unsigned)a.B || sh.words != (unsigned)words) bad |= 1u << k;
+            sn_hit[k] = sh.n_hit;
+            if (tid < vwords) vw[k] = reinterpret_cast<const unsigned *>(snap_base(a, k) + voff)[tid];       // (vwords <= kPlanMaxB * 16 = the workgroup's threads)
         }
-        __syncthreads();
-        if (tid == 0 && (unsigned)s_axes2 == h_ax_lo && (unsigned)(s_axes2 >> 32) == h_ax_hi)
-            for (int k = nsn - 1; k >= 0; --k) if (!s_bad[k]) s_res[3] = k;
-        __syncthreads();
+        for (int i = tid; i < words; i += nthr) {
+            const unsigned m = mats[i];
+#pragma unroll
+            for (int k = 0; k < kSnaps; ++k) if (reinterpret_cast<const unsigned *>(snap_base(a, k) + 256)[i] != m) bad |= 1u << k;
+        }
+        // the workgroup's sum / or: per wave by cross-lane steps, the waves' parts through LDS (one barrier, nothing to initialise)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { part += __shfl_xor(part, o); bad |= (unsigned)__shfl_xor((int)bad, o); }
+        if ((tid & 63) == 0) { s_axpart[tid >> 6] = part; s_badpart[tid >> 6] = bad; }
     }
-    const int hit = s_res[3];
+    if (tid == 0) { s_res[0] = 0; s_res[1] = 0; s_res[2] = 0; }
+    __syncthreads();
+    int hit = -1;
+    if (have_snaps) {
+        unsigned long long ax = 0ull;
+        unsigned badall = 0u;
+#pragma unroll
+        for (int w = 0; w < kBuildThreads / 64; ++w) { ax += s_axpart[w]; badall |= s_badpart[w]; }
+        const bool table_ok = h_magic == kPlanMagic && h_sig_lo == a.sig_lo && h_sig_hi == a.sig_hi && h_nslots == (unsigned)a.nslots &&
+                              (unsigned)ax == h_ax_lo && (unsigned)(ax >> 32) == h_ax_hi;
+        const int nsn = table_ok ? (int)(h_snaps < (unsigned)kSnaps ? h_snaps : (unsigned)kSnaps) : 0;
+#pragma unroll
+        for (int k = kSnaps - 1; k >= 0; --k) if (k < nsn && !((badall >> k) & 1u)) hit = k;
+    }
     if (hit >= 0) {
-        const unsigned *sv = reinterpret_cast<const unsigned *>(snap_base(a, hit) + 256 + (((int64_t)words * 4 + 255) & ~255ll));
-        unsigned *dv = reinterpret_cast<unsigned *>(verdict);
-        for (int i = tid; i < a.B * (int)(sizeof(Verdict) / 4); i += nthr) dv[i] = sv[i];
-        if (tid == 0) {
-            const SnapHdr sh = *reinterpret_cast<const SnapHdr *>(snap_base(a, hit));
-            hdr->todo_count = 0; hdr->clock += 1; hdr->hits += sh.n_hit; hdr->calls += 1;
-        }
-    } else {
-        plan_probe(a, s_res);
-        __syncthreads();
-        if (have_snaps) {
-            if (s_res[0] > 0 || s_res[1]) {
-                if (tid == 0) { hdr->snaps = 0; hdr->snap_next = 0; }            // a build follows (or the table was reset): every snapshot is void
-            }
-            if (s_res[0] == 0) {
-                // every calibration of the batch is known: remember the batch
-                const int k = (s_res[1] ? 0 : (int)h_next) % kSnaps;
-                unsigned *sm = reinterpret_cast<unsigned *>(snap_base(a, k) + 256);
-                unsigned *sv = reinterpret_cast<unsigned *>(snap_base(a, k) + 256 + (((int64_t)words * 4 + 255) & ~255ll));
-                const unsigned *dv = reinterpret_cast<const unsigned *>(verdict);
-                for (int i = tid; i < words; i += nthr) sm[i] = mats[i];
-                for (int i = tid; i < a.B * (int)(sizeof(Verdict) / 4); i += nthr) sv[i] = dv[i];
-                if (tid == 0) {
-                    *reinterpret_cast<SnapHdr *>(snap_base(a, k)) = SnapHdr{1u, (unsigned)a.B, (unsigned)words, (unsigned)s_res[2]};
-                    const unsigned base_n = s_res[1] ? 0u : (table_ok ? h_snaps : 0u);
-                    hdr->snaps = base_n > (unsigned)(k + 1) ? base_n : (unsigned)(k + 1);
-                    hdr->snap_next = (unsigned)(k + 1) % kSnaps;
-                }
+        // the builders have nothing to read: let them go before the verdicts are even written
+        if (tid == 0 && nwg > 1) __hip_atomic_store(&flags[0], a.token + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned v = vw[0], nh = sn_hit[0];
+#pragma unroll
+        for (int k = 1; k < kSnaps; ++k) if (hit == k) { v = vw[k]; nh = sn_hit[k]; }
+        if (tid < vwords) reinterpret_cast<unsigned *>(verdict)[tid] = v;
+        if (tid == 0) { hdr->todo_count = 0; hdr->clock = h_clock + 1u; hdr->hits = h_hits + nh; hdr->calls = h_calls + 1u; }
+        return;
+    }
+    plan_probe(a, s_res);
+    __syncthreads();
+    const int n_todo = s_res[0];
+    if (have_snaps) {
+        const bool table_was_ok = h_magic == kPlanMagic && h_sig_lo == a.sig_lo && h_sig_hi == a.sig_hi && h_nslots == (unsigned)a.nslots;
+        if ((n_todo > 0 || s_res[1]) && tid == 0) { hdr->snaps = 0; hdr->snap_next = 0; }    // a build follows (or the table was reset): every snapshot is void
+        if (n_todo == 0) {
+            // every calibration of the batch is known: remember the batch
+            const int k = (s_res[1] ? 0 : (int)h_next) % kSnaps;
+            unsigned *sm = reinterpret_cast<unsigned *>(snap_base(a, k) + 256);
+            unsigned *sv = reinterpret_cast<unsigned *>(snap_base(a, k) + voff);
+            const unsigned *dv = reinterpret_cast<const unsigned *>(verdict);
+            for (int i = tid; i < words; i += nthr) sm[i] = mats[i];
+            for (int i = tid; i < vwords; i += nthr) sv[i] = dv[i];
+            if (tid == 0) {
+                *reinterpret_cast<SnapHdr *>(snap_base(a, k)) = SnapHdr{1u, (unsigned)a.B, (unsigned)words, (unsigned)s_res[2]};
+                const unsigned base_n = (s_res[1] || !table_was_ok) ? 0u : h_snaps;
+                hdr->snaps = base_n > (unsigned)(k + 1) ? base_n : (unsigned)(k + 1);
+                hdr->snap_next = (unsigned)(k + 1) % kSnaps;
             }
         }
     }
-    // ---- publish: every storing wave drains, the workgroup meets, lane 0 releases at agent scope and raises the flag
+    if (nwg == 1) return;
+    if (n_todo == 0) {
+        if (tid == 0) __hip_atomic_store(&flags[0], a.token + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // ---- publish the to-do list: every storing wave drains, the workgroup meets, lane 0 releases at agent scope and raises the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && gridDim.x > 1) {
+    if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&flags[0], a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (a token per launch: no re-arming, and whatever an
                                                                                                 // uninitialised cache holds here is not it)
     }
+}
+
+__global__ __launch_bounds__(kBuildThreads) void lss_plan_lookup(PlanArgs a) { plan_lookup_body(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// ---- the lookup as a rider of the depth softmax ---------------------------------------------------------------------------------
+// A lookup of known calibrations is a few dependent memory round trips in ONE workgroup: 4.8 us as a launch of its own on an idle
+// card, 6-10 us inside a training step -- against a forward of 28 us.  The depth softmax (csrc/depth_softmax.hip) runs between the
+// moment the matrices exist and the forward anyway, for 7.7 us over some hundred workgroups: this kernel is that softmax with the
+// lookup's 1 + g workgroups in FRONT of its grid (they start first; what they do ends long before the softmax's rows do), so the
+// steady state has no launch for the lookup at all.  A batch with calibrations to learn makes this launch as long as the build
+// (1.6 ms per calibration, once).  The softmax's rows are spread over workgroups of 1 024 threads here (the build's shape).
+__global__ __launch_bounds__(kBuildThreads) void lss_plan_lookup_softmax(PlanArgs a, SoftmaxArgs s, int variant, int nlookup) {
+    if ((int)blockIdx.x < nlookup) { plan_lookup_body(a, (int)blockIdx.x, nlookup); return; }
+    const int blk = (int)blockIdx.x - nlookup, nblk = (int)gridDim.x - nlookup, tid = threadIdx.x;
+#define MMT_RIDER_CASE(id, LT, UT, NV) case id: softmax_fwd_rows<LT, UT, 4, NV, (NV <= 4 ? 2 : 1)>(s, blk, nblk, tid, kBuildThreads); break;
+    switch (variant) {          // (logits type, depth_used type, 16-byte pieces per lane)
+        MMT_RIDER_CASE(0, float, float, 2) MMT_RIDER_CASE(1, float, float, 4) MMT_RIDER_CASE(2, float, float, 8)
+        MMT_RIDER_CASE(3, float, bf16_t, 2) MMT_RIDER_CASE(4, float, bf16_t, 4) MMT_RIDER_CASE(5, float, bf16_t, 8)
+        MMT_RIDER_CASE(6, bf16_t, float, 2) MMT_RIDER_CASE(7, bf16_t, float, 4) MMT_RIDER_CASE(8, bf16_t, float, 8)
+        MMT_RIDER_CASE(9, bf16_t, bf16_t, 2) MMT_RIDER_CASE(10, bf16_t, bf16_t, 4) MMT_RIDER_CASE(11, bf16_t, bf16_t, 8)
+        default: break;
+    }
+#undef MMT_RIDER_CASE
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------------------
@@ -976,10 +1026,14 @@ int fill_plan_args(const char *what, int B, int N, int D, int fH, int fW, int nx
     return MMT_OK;
 }
 
-void launch_prepare(mmt::TimedSeq &seq, const PlanArgs &p, hipStream_t st, bool last) {
+unsigned next_token() {
     static std::atomic<unsigned> counter{0x5EED0001u};
+    return counter.fetch_add(2u);                  // (odd: never 0, never the previous launch's; the launch also uses token + 1)
+}
+
+void launch_prepare(mmt::TimedSeq &seq, const PlanArgs &p, hipStream_t st, bool last) {
     PlanArgs q = p;
-    q.token = counter.fetch_add(2u);               // (odd: never 0, never the previous launch's)
+    q.token = next_token();
     const int g = p.B < kBuildPar ? p.B : kBuildPar;
     seq.launch(last, lss_plan_lookup, dim3((unsigned)(1 + g)), dim3(kBuildThreads), 0, st, q);
 }
@@ -1051,6 +1105,47 @@ extern "C" int mmt_lss_plan_prepare(int B, int N, int D, int fH, int fW, int nx,
     mmt::TimedSeq seq;
     launch_prepare(seq, p, (hipStream_t)stream, true);
     return mmt::check_launch("lss_plan_prepare");
+}
+
+extern "C" int mmt_depth_softmax_forward_plan_prepare(int64_t pixels, int D, const void *logits, int64_t logit_row_stride, int logits_dtype,
+                                                      float *probs, const float *oracle, int64_t oracle_row_stride, void *depth_used, int used_dtype,
+                                                      int B, int N, int fH, int fW, int nx, int ny, int nz, const float *combine,
+                                                      const float *frustum_u, const float *frustum_v, const float *frustum_d,
+                                                      const float *voxel_coord_host, const float *voxel_size_host, void *plan_cache,
+                                                      int64_t plan_cache_bytes, void *stream) {
+    const char *who = "depth_softmax_forward_plan_prepare";
+    if (int rc = softmax_common_check(who, pixels, D, logits_dtype, used_dtype)) return rc;
+    if (const int rc = plan_shape_ok(who, B, N, D, fH, fW, 64, nx, ny, nz, false)) return rc;
+    if (pixels != (int64_t)B * N * fH * fW)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: %lld softmax rows for a batch of %d x %d cameras of %d x %d pixels", who, (long long)pixels, B, N, fH, fW);
+    MMT_REQUIRE_PTR(logits);
+    MMT_REQUIRE_PTR(probs);
+    if (logit_row_stride < D || (oracle != nullptr && oracle_row_stride < D)) return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: row strides must be >= D", who);
+    if (oracle != nullptr && depth_used == nullptr) return mmt::fail(MMT_ERR_NULL_POINTER, "%s: an oracle needs a depth_used output", who);
+    PlanArgs p = {};
+    if (const int rc = fill_plan_args(who, B, N, D, fH, fW, nx, ny, nz, combine, frustum_u, frustum_v, frustum_d, voxel_coord_host, voxel_size_host,
+                                      plan_cache, plan_cache_bytes, &p)) return rc;
+    const bool lb = logits_dtype == MMT_DTYPE_BF16, ub = used_dtype == MMT_DTYPE_BF16;
+    const bool vec4 = D % 4 == 0 && softmax_aligned(logits, logit_row_stride, lb ? 2 : 4) && softmax_aligned(probs, D, 4) &&
+                      softmax_aligned(oracle, oracle_row_stride, 4) && softmax_aligned(depth_used, D, ub ? 2 : 4);
+    if (!vec4)      // rows the 16-byte pieces cannot take: the caller makes the two launches (mmt_depth_softmax_rides_lookup says so beforehand)
+        return mmt::fail(MMT_ERR_BAD_SHAPE, "%s: rows of D %% 4 == 0 elements on 16-byte (fp32) / 8-byte (bf16) boundaries only -- call mmt_lss_plan_prepare and "
+                         "mmt_depth_softmax_forward instead", who);
+    const int pieces = (int)mmt::ceil_div(D, kGroup * 4);
+    const int variant = (lb ? 6 : 0) + (ub ? 3 : 0) + (pieces <= 2 ? 0 : (pieces <= 4 ? 1 : 2));
+    SoftmaxArgs a{pixels, D, logits, logit_row_stride, probs, oracle, oracle_row_stride, depth_used, nullptr, nullptr, nullptr};
+    p.token = next_token();
+    static const char *dbg = getenv("MMT_RIDER_NOLOOKUP");          // experiments only: the softmax in this kernel's shape, no lookup
+    const int nlookup = (dbg && dbg[0] == '1') ? 0 : 1 + (B < kBuildPar ? B : kBuildPar);
+    // the softmax's share of the grid: the kernel keeps the build's 128 registers, so a CU holds ONE workgroup of it -- as many
+    // workgroups as fit the chip beside the lookup's in one round, their lane groups striding over the pixels with two rows in flight
+    // (a second round of workgroups would double the launch: 9.2 against 6.5 us at BASELINE configs[3])
+    const int64_t want = mmt::ceil_div(pixels * kGroup, (int64_t)kBuildThreads);
+    const int room = 256 - nlookup;                  // (MI355X: 256 CUs)
+    const int nsm = (int)(want < 1 ? 1 : (want > room && room > 0 ? room : want));
+    mmt::TimedSeq seq;
+    seq.launch(true, lss_plan_lookup_softmax, dim3((unsigned)(nlookup + nsm)), dim3(kBuildThreads), 0, (hipStream_t)stream, p, a, variant, nlookup);
+    return mmt::check_launch(who);
 }
 
 extern "C" int mmt_lss_plan_cache_layout(int N, int D, int fH, int fW, int nx, int ny, int64_t plan_cache_bytes, int64_t *layout_host) {

@@ -422,7 +422,7 @@ class LSSFPN(nn.Module):
         batch_size, num_sweeps, num_cams = sweep_imgs.shape[:3]
         # plan form of the fused forward: its lookup of the batch's calibrations depends on the matrices only -- issue it now, in
         # front of the image backbone, so that the forward kernel finds the verdicts ready
-        plan_cache = plan_combine = None
+        plan_cache = plan_combine = pending_lookup = None
         if (self.fused_lift_splat and self.camera_form and self._has_frustum_axes and self.plan_form and isinstance(mats_dict, dict)
                 and os.environ.get("MMT_LIFT_SPLAT_TILES", "0") != "1" and os.environ.get("MMT_LIFT_SPLAT_V1", "0") != "1"):
             fH_, fW_ = self.frustum_v.numel(), self.frustum_u.numel()
@@ -441,8 +441,15 @@ class LSSFPN(nn.Module):
                          and getattr(plan_cache, "_mmt_frustum_version", None) == self._frustum_version
                          and not torch.cuda.is_current_stream_capturing())
                 if not fresh:
-                    plan_prepare(plan_combine, (self.frustum_u, self.frustum_v, self.frustum_d), self._voxel_num_host, self._voxel_coord_host,
-                                 self._voxel_size_host, plan_cache)
+                    lookup = (plan_combine, (self.frustum_u, self.frustum_v, self.frustum_d), self._voxel_num_host, self._voxel_coord_host,
+                              self._voxel_size_host, plan_cache)
+                    # The lookup rides in the depth softmax's launch (mmt_depth_softmax_forward_plan_prepare: its workgroups in front
+                    # of the softmax's grid) -- as a launch of its own it costs 5-10 us of a step whose forward takes 28.
+                    # MMT_PLAN_LOOKUP_RIDER=0: the launch of its own, here, in front of the image backbone (A/B).
+                    if self.depth_channels <= 512 and os.environ.get("MMT_ATEN_SOFTMAX", "0") != "1" and os.environ.get("MMT_PLAN_LOOKUP_RIDER", "1") != "0":
+                        pending_lookup = lookup
+                    else:
+                        plan_prepare(*lookup)
                     plan_cache._mmt_prepared_for = ckey0
                     plan_cache._mmt_frustum_version = self._frustum_version
                 self._watch_plan_cache(plan_cache)
@@ -464,8 +471,10 @@ class LSSFPN(nn.Module):
         # kernels' bf16 operand comes out of the same launch.
         used_bf16 = self.hot_path_dtype == "bf16" and self.fused_lift_splat
         if D <= 512 and os.environ.get("MMT_ATEN_SOFTMAX", "0") != "1":
-            depth, depth_used = depth_softmax(depth_logits, depth_oracle, torch.bfloat16 if used_bf16 else torch.float32)
+            depth, depth_used = depth_softmax(depth_logits, depth_oracle, torch.bfloat16 if used_bf16 else torch.float32, plan_lookup=pending_lookup)
         else:       # (more bins than the kernel takes; or the A/B switch of bench.py --aten-softmax)
+            if pending_lookup is not None:
+                plan_prepare(*pending_lookup)
             depth = depth_logits.softmax(1)
             depth_used = depth
             if depth_oracle is not None:

@@ -157,7 +157,7 @@ class DepthSoftmax(Function):
     lift multiplies the context with -- None when it would equal probs (no oracle, fp32)."""
 
     @staticmethod
-    def forward(ctx, logits, oracle, used_bf16):
+    def forward(ctx, logits, oracle, used_bf16, plan_lookup=None):
         if not logits.is_cuda:
             raise RuntimeError("depth logits must be a CUDAtensor ")
         if logits.dtype not in (torch.float32, torch.bfloat16) or logits.dim() != 4:
@@ -176,9 +176,24 @@ class DepthSoftmax(Function):
             used = torch.empty((BN, fH, fW, D), dtype=torch.bfloat16 if used_bf16 else torch.float32, device=logits.device)
         lt = _lib.DTYPE_BF16 if logits.dtype == torch.bfloat16 else _lib.DTYPE_F32
         ut = _lib.DTYPE_BF16 if used_bf16 else _lib.DTYPE_F32
+        u_ptr = used.data_ptr() if used is not None else 0
         with torch.cuda.device(logits.device):
-            _lib.timed_call("softmax", "mmt_depth_softmax_forward", BN * fH * fW, D, logits.data_ptr(), R, lt, probs.data_ptr(),
-                            o_ptr, o_R, used.data_ptr() if used is not None else 0, ut, _stream())
+            if plan_lookup is not None:
+                # the plan form's calibration lookup rides in this launch (mmt_depth_softmax_forward_plan_prepare)
+                combine, (fu, fv, fd), voxel_num, vc, vs, plan_cache = plan_lookup
+                B, N = combine.shape[:2]
+                if (B * N, D, fH, fW) != (BN, fd.numel(), fv.numel(), fu.numel()):
+                    raise RuntimeError("depth_softmax: the lookup that rides along is for another batch shape")
+                if not softmax_rides_lookup(logits, R, oracle, o_R, D, used_bf16):
+                    raise RuntimeError("depth_softmax: these rows cannot carry the lookup (softmax_rides_lookup)")
+                ptr, nbytes = _plan_ptr(plan_cache)
+                nx, ny, nz = [int(v) for v in voxel_num]
+                _lib.timed_call("softmax", "mmt_depth_softmax_forward_plan_prepare", BN * fH * fW, D, logits.data_ptr(), R, lt, probs.data_ptr(),
+                                o_ptr, o_R, u_ptr, ut, B, N, fH, fW, nx, ny, nz, combine.data_ptr(), fu.data_ptr(), fv.data_ptr(), fd.data_ptr(),
+                                _lib.float3([float(v) for v in vc]), _lib.float3([float(v) for v in vs]), ptr, nbytes, _stream())
+            else:
+                _lib.timed_call("softmax", "mmt_depth_softmax_forward", BN * fH * fW, D, logits.data_ptr(), R, lt, probs.data_ptr(),
+                                o_ptr, o_R, u_ptr, ut, _stream())
         ctx.save_for_backward(probs, *([oracle] if oracle is not None else []))
         ctx.meta = (BN, D, fH, fW, lt, ut, o_R, logits.dtype)
         return probs.permute(0, 3, 1, 2), (used.permute(0, 3, 1, 2) if used is not None else None)
@@ -206,15 +221,42 @@ class DepthSoftmax(Function):
             _lib.timed_call("softmax_backward", "mmt_depth_softmax_backward", BN * fH * fW, D, probs.data_ptr(),
                             gp.data_ptr() if gp is not None else 0, gu.data_ptr() if gu is not None else 0, ut,
                             rest[0].data_ptr() if rest else 0, o_R, grad_logits.data_ptr(), lt, _stream())
-        return grad_logits.permute(0, 3, 1, 2), None, None
+        return grad_logits.permute(0, 3, 1, 2), None, None, None
 
 
-def depth_softmax(logits, oracle=None, used_dtype=torch.float32):
+def softmax_rides_lookup(logits_rows, row_stride, oracle_rows, oracle_stride, D, used_bf16):
+    """Whether mmt_depth_softmax_forward_plan_prepare takes these rows: 16-byte pieces (D % 4 == 0, every row on a 16-byte (fp32) /
+    8-byte (bf16) boundary)."""
+    eb = 2 if logits_rows.dtype == torch.bfloat16 else 4
+    ok = D % 4 == 0 and D <= 512 and row_stride % 4 == 0 and logits_rows.data_ptr() % (4 * eb) == 0
+    if oracle_rows is not None:
+        ok = ok and oracle_stride % 4 == 0 and oracle_rows.data_ptr() % 16 == 0
+    return ok
+
+
+def depth_softmax(logits, oracle=None, used_dtype=torch.float32, plan_lookup=None):
     """logits [B*N, D, fH, fW] (fp32 or bf16; free when channels_last or a channel slice of a channels_last tensor)
     -> (probs, depth_used), both channels_last [B*N, D, fH, fW]: probs = softmax(logits, 1) in fp32; depth_used = probs with the
     rows of foreground pixels (torch.max(oracle, 1).values > 0) replaced by the oracle's, in `used_dtype` (fp32 or bf16).
-    Without an oracle and with used_dtype fp32, depth_used IS probs."""
-    probs, used = DepthSoftmax.apply(logits, oracle, used_dtype == torch.bfloat16)
+    Without an oracle and with used_dtype fp32, depth_used IS probs.
+    plan_lookup = (combine, axes, voxel_num, voxel_coord, voxel_size, plan_cache): plan_prepare's operands -- the lookup of the batch's
+    calibrations then rides in the softmax's launch (no launch of its own in the steady state); when the rows cannot carry it
+    (softmax_rides_lookup) it is made as a call of its own first."""
+    if plan_lookup is not None:
+        BN, D, fH, fW = logits.shape
+        combine, axes = plan_lookup[0], plan_lookup[1]
+        shape_ok = (combine.shape[0] * combine.shape[1], axes[2].numel(), axes[1].numel(), axes[0].numel()) == (BN, D, fH, fW)
+
+        def pieces_ok(t):       # (what _pixel_rows has to copy comes out contiguous and aligned)
+            R = t.stride(3)
+            natural = t.stride(1) == 1 and R >= D and t.stride(2) == fW * R and t.stride(0) == fH * fW * R
+            return (not natural) or (R % 4 == 0 and t.data_ptr() % (4 * t.element_size()) == 0)
+
+        if not (shape_ok and D % 4 == 0 and D <= 512 and logits.dim() == 4 and pieces_ok(logits)
+                and (oracle is None or oracle.dtype != torch.float32 or pieces_ok(oracle))):
+            plan_prepare(*plan_lookup)
+            plan_lookup = None
+    probs, used = DepthSoftmax.apply(logits, oracle, used_dtype == torch.bfloat16, plan_lookup)
     return probs, (probs if used is None else used)
 
 

@@ -375,3 +375,62 @@ def test_prepared_flag_on_an_unprepared_cache_writes_nothing_and_is_counted(mmt_
     out = _forward(cb, axes, vc, vs, vn, depth, ctx, cache, prepared=True)
     assert bool(torch.isnan(out).all()) and plan_cache_counters(cache)["stale"] == B
 
+
+
+@pytest.mark.parametrize("dtypes", [("f32", "f32"), ("f32", "bf16"), ("bf16", "bf16")])
+@pytest.mark.parametrize("D", [40, 112, 200])
+def test_lookup_riding_in_the_depth_softmax(mmt_lib, dtypes, D):
+    """mmt_depth_softmax_forward_plan_prepare == mmt_depth_softmax_forward + mmt_lss_plan_prepare: the same probabilities bit for
+    bit (the rows' arithmetic is shared), the same verdicts and counters as a lookup of its own on a twin cache -- through learning
+    (first call), known calibrations (probe), batches seen before (snapshots) and a sample mix with a new calibration."""
+    from mm_training_amd import synthetic
+    from mm_training_amd.ops.bev_geometry import depth_softmax, frustum_axes, new_plan_cache, plan_cache_counters, plan_prepare
+    lt, ut = [torch.bfloat16 if d == "bf16" else torch.float32 for d in dtypes]
+    B, N, fH, fW = 3, 2, 16, 22
+    H, W = fH * 16, fW * 16
+    step = 56.0 / D
+    fr = _frustum((H, W), 16, (2.0, 2.0 + D * step - 1e-3, step))
+    axes = tuple(a.cuda() for a in frustum_axes(fr))
+    assert axes[2].numel() == D
+    vc, vs, vn = [-51.2 + 0.4, -51.2 + 0.4, -1.0], [0.8, 0.8, 8.0], [128, 128, 1]
+
+    def batch(seed):
+        s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=seed)
+        return s2e.matmul(torch.inverse(K)).contiguous().cuda()
+
+    rider, twin = [new_plan_cache(N, D, fH, fW, vn, "cuda", slots=8) for _ in range(2)]
+    lay = _layout(N, D, fH, fW, vn[0], vn[1], rider)
+    g = torch.Generator().manual_seed(D)
+    b0, b1 = batch(1), batch(2)
+    mixed = torch.stack([b0[0], batch(3)[1], b1[2]]).contiguous()
+    for it, comb in enumerate([b0, b0, b1, b0, b1, mixed, mixed, b0]):
+        logits = (torch.randn(B * N, D, fH, fW, generator=g) * 3).cuda().to(lt).contiguous(memory_format=torch.channels_last)
+        oracle = None
+        if it % 2:
+            oracle = torch.zeros(B * N, D, fH, fW)
+            oracle[:, it % D, ::3, ::2] = 1.0
+            oracle = oracle.cuda().contiguous(memory_format=torch.channels_last)
+        p0, u0 = depth_softmax(logits, oracle, ut)
+        plan_prepare(comb, axes, vn, vc, vs, twin)
+        p1, u1 = depth_softmax(logits, oracle, ut, plan_lookup=(comb, axes, vn, vc, vs, rider))
+        torch.cuda.synchronize()
+        assert torch.equal(p0, p1) and torch.equal(u0, u1)
+        assert np.array_equal(_verdicts(rider, lay, B), _verdicts(twin, _layout(N, D, fH, fW, vn[0], vn[1], twin), B)), it
+        c0, c1 = plan_cache_counters(twin), plan_cache_counters(rider)
+        assert c0 == c1 and c1["stale"] == 0, (it, c0, c1)
+    assert c1["learnt"] == 2 * B + 1 and c1["calls"] == 8
+    # rows that cannot carry the lookup (D % 4 != 0 here): depth_softmax makes the two launches itself
+    # and the raw entry point refuses
+    from mm_training_amd import _lib
+    from mm_training_amd.ops.bev_geometry import _plan_ptr
+    ptr, nbytes = _plan_ptr(rider)
+    x = torch.randn(B * N * fH * fW, D + 2, device="cuda")
+    out = torch.empty_like(x)
+    with pytest.raises(RuntimeError, match="16-byte"):
+        _lib.call("mmt_depth_softmax_forward_plan_prepare", B * N * fH * fW, D + 2, x.data_ptr(), D + 2, 0, out.data_ptr(), 0, 0, 0, 0, B, N, fH, fW,
+                  vn[0], vn[1], vn[2], b0.data_ptr(), axes[0].data_ptr(), axes[1].data_ptr(), axes[2].data_ptr(), _lib.float3(vc), _lib.float3(vs), ptr, nbytes,
+                  torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(RuntimeError, match="softmax rows for a batch"):
+        _lib.call("mmt_depth_softmax_forward_plan_prepare", B * N * fH * fW - 1, D, x.data_ptr(), D + 2, 0, out.data_ptr(), 0, 0, 0, 0, B, N, fH, fW,
+                  vn[0], vn[1], vn[2], b0.data_ptr(), axes[0].data_ptr(), axes[1].data_ptr(), axes[2].data_ptr(), _lib.float3(vc), _lib.float3(vs), ptr, nbytes,
+                  torch.cuda.current_stream().cuda_stream)

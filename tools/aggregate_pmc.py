@@ -13,6 +13,7 @@ KERNELS = [
     # camera form (round 3: the kernels compute the cells themselves; last template argument true) before the geom form
     # (lss_ray_fwd<...>; for columns of up to 16 rows lss_ray_fwd_reg<...>; the camera form's other shapes lss_ray_fwd_blk<...>)
     ("lift_splat_forward_plan", ("lss_plan_fwd<float, ",)), ("lift_splat_forward_plan_bf16", ("lss_plan_fwd<unsigned short, ",)),
+    ("depth_softmax_fwd", ("lss_plan_lookup_softmax",)),      # (the depth softmax with the calibration lookup riding in its launch)
     ("lss_plan_lookup", ("lss_plan_lookup",)), ("lss_plan_probe", ("lss_plan_probe",)), ("lss_plan_build", ("lss_plan_build",)),
     ("lift_splat_forward_camera", ("lss_ray_fwd_blk<float, ",)),
     ("lift_splat_forward_camera_bf16", ("lss_ray_fwd_blk<unsigned short, ",)),
