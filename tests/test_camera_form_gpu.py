@@ -299,8 +299,11 @@ def test_lssfpn_camera_form_is_the_default_and_runs_no_geometry_kernel(mmt_lib, 
 
     assert m.plan_form
     bev_p, g_p, calls_p = run(True, mats)                                  # the default: camera form, its forward in the plan form
-    assert "mmt_lss_splat_forward_plan" in calls_p and "mmt_lss_plan_prepare" in calls_p and "mmt_lss_splat_backward_cam" in calls_p
-    assert calls_p.index("mmt_lss_plan_prepare") == 0 and "mmt_frustum_geometry" not in calls_p     # the lookup goes first, in front of the nets
+    assert "mmt_lss_splat_forward_plan" in calls_p and "mmt_lss_splat_backward_cam" in calls_p and "mmt_frustum_geometry" not in calls_p
+    # the lookup rides in the depth softmax's launch -- or, for rows that cannot take 16-byte pieces (this frustum's D), goes right in front of it
+    rider, own = "mmt_depth_softmax_forward_plan_prepare" in calls_p, "mmt_lss_plan_prepare" in calls_p
+    assert rider != own and (rider or calls_p.index("mmt_lss_plan_prepare") + 1 == calls_p.index("mmt_depth_softmax_forward"))
+    assert (calls_p.index("mmt_depth_softmax_forward_plan_prepare") if rider else calls_p.index("mmt_lss_plan_prepare")) < calls_p.index("mmt_lss_splat_forward_plan")
     m.plan_form = False
     bev_c, g_c, calls_c = run(True, mats)
     # (two passes through the MIOpen backbone in front of the pooling: its split-K forward kernels leave the last bits open, and with the
