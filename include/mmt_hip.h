@@ -173,7 +173,8 @@ int mmt_depth_softmax_forward(int64_t pixels, int D, const void *logits, int64_t
 /* The same forward with the plan form's calibration lookup (mmt_lss_plan_prepare, below) riding in its launch (ABI 14): the
  * lookup's 1 + min(B, 8) workgroups go in front of the softmax's grid, so a step whose calibrations are known launches
  * nothing for the lookup -- as a launch of its own it costs 4.8 us on an idle card and 6-10 us inside a training step, against
- * a forward of 28 us.  The softmax rows are those of the batch the lookup is for: pixels == B * N * fH * fW, D = the frustum's
+ * a forward of 28 us; riding, 0.6-1.1 us on the softmax's 6.4.  A batch with calibrations to learn makes this launch as long as the
+ * build (256-thread workgroups here: ~6 ms per calibration, once).  The softmax rows are those of the batch the lookup is for: pixels == B * N * fH * fW, D = the frustum's
  * depth bins.  Rows must take 16-byte pieces (D % 4 == 0, every row on a 16-byte (fp32) / 8-byte (bf16) boundary:
  * MMT_ERR_BAD_SHAPE otherwise -- make the two calls instead).  Afterwards the forward is told MMT_LSS_PLAN_PREPARED. */
 int mmt_depth_softmax_forward_plan_prepare(int64_t pixels, int D, const void *logits, int64_t logit_row_stride, int logits_dtype,

@@ -262,13 +262,14 @@ struct DevRowCells {                     // the cells of a mixed block's rows, f
     }
 };
 
+template <int NT>       // threads of the workgroup (1 024 in a launch of its own; 256 as a rider of the depth softmax: same plan, four times as long)
 __device__ __forceinline__ void plan_build(const PlanArgs &a, int bi, int nb) {
     const CacheHeader *hdr = reinterpret_cast<const CacheHeader *>(a.cache);
     const int4 *todo = reinterpret_cast<const int4 *>(a.cache + kTodoOff);
     const int *dup = reinterpret_cast<const int *>(a.cache + kDupOff);
     Verdict *verdict = reinterpret_cast<Verdict *>(a.cache + kVerdictOff);
     const int ntodo = (int)hdr->todo_count;
-    const int tid = threadIdx.x, nt = kBuildThreads;
+    const int tid = threadIdx.x, nt = NT;
     const Dims &d = a.d;
     Scratch sc;
     scratch_carve(d, kBuildThreads, a.cache + a.scratch_off + (int64_t)bi * a.scratch_bytes, &sc);
@@ -386,9 +387,11 @@ __device__ __forceinline__ void plan_build(const PlanArgs &a, int bi, int nb) {
 // dependent rounds of loads instead of the probe's five or six.  Round 5's two launches took 10.7 + 3.6 us per step.
 __device__ __forceinline__ unsigned char *snap_base(const PlanArgs &a, int k) { return a.cache + a.scratch_off + (int64_t)k * a.snap_stride; }
 
-__device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg, const int nwg) {      // workgroup wg of the nwg that do the lookup
+template <int NT>
+__device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg, const int nwg) {      // workgroup wg (NT threads) of the nwg that do the lookup
     unsigned *flags = reinterpret_cast<unsigned *>(a.cache + kFlagOff);
-    const int tid = threadIdx.x, nthr = kBuildThreads;
+    const int tid = threadIdx.x, nthr = NT;
+    constexpr int VW = (kPlanMaxB * (int)(sizeof(Verdict) / 4) + NT - 1) / NT;     // verdict words per thread
     if (wg != 0) {
         // ---- a builder: wait for workgroup 0's word -- the launch's token: there is a to-do list (acquire, then build); token + 1:
         // nothing to learn, leave without reading anything.  (Bounded: a wait that runs out leaves the list unbuilt, which the forward counts as stale.)
@@ -404,12 +407,12 @@ __device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg
             s_go = v == a.token ? 1 : 0;
         }
         __syncthreads();
-        if (s_go) plan_build(a, wg - 1, nwg - 1);
+        if (s_go) plan_build<NT>(a, wg - 1, nwg - 1);
         return;
     }
     // ---- workgroup 0
-    __shared__ unsigned long long s_axpart[kBuildThreads / 64];
-    __shared__ unsigned s_badpart[kBuildThreads / 64];
+    __shared__ unsigned long long s_axpart[NT / 64];
+    __shared__ unsigned s_badpart[NT / 64];
     __shared__ int s_res[4];             // plan_probe's result
     CacheHeader *hdr = reinterpret_cast<CacheHeader *>(a.cache);
     Verdict *verdict = reinterpret_cast<Verdict *>(a.cache + kVerdictOff);
@@ -422,7 +425,7 @@ __device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg
     const unsigned h_magic = hdr->magic, h_sig_lo = hdr->sig_lo, h_sig_hi = hdr->sig_hi, h_ax_lo = hdr->axes_lo, h_ax_hi = hdr->axes_hi,
                    h_nslots = hdr->nslots, h_snaps = hdr->snaps, h_next = hdr->snap_next, h_clock = hdr->clock, h_hits = hdr->hits, h_calls = hdr->calls;
     unsigned bad = 0u, sn_hit[kSnaps] = {0u, 0u, 0u, 0u};
-    unsigned vw[kSnaps] = {0u, 0u, 0u, 0u};
+    unsigned vw[kSnaps][VW] = {};
     if (have_snaps) {
         unsigned long long part = 0ull;
         const int na = a.d.fW + a.d.fH + a.d.D;
@@ -435,7 +438,9 @@ __device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg
             const SnapHdr sh = *reinterpret_cast<const SnapHdr *>(snap_base(a, k));
             if (sh.valid != 1u || sh.B != (unsigned)a.B || sh.words != (unsigned)words) bad |= 1u << k;
             sn_hit[k] = sh.n_hit;
-            if (tid < vwords) vw[k] = reinterpret_cast<const unsigned *>(snap_base(a, k) + voff)[tid];       // (vwords <= kPlanMaxB * 16 = the workgroup's threads)
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+                if (tid + j * NT < vwords) vw[k][j] = reinterpret_cast<const unsigned *>(snap_base(a, k) + voff)[tid + j * NT];
         }
         for (int i = tid; i < words; i += nthr) {
             const unsigned m = mats[i];
@@ -454,7 +459,7 @@ __device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg
         unsigned long long ax = 0ull;
         unsigned badall = 0u;
 #pragma unroll
-        for (int w = 0; w < kBuildThreads / 64; ++w) { ax += s_axpart[w]; badall |= s_badpart[w]; }
+        for (int w = 0; w < NT / 64; ++w) { ax += s_axpart[w]; badall |= s_badpart[w]; }
         const bool table_ok = h_magic == kPlanMagic && h_sig_lo == a.sig_lo && h_sig_hi == a.sig_hi && h_nslots == (unsigned)a.nslots &&
                               (unsigned)ax == h_ax_lo && (unsigned)(ax >> 32) == h_ax_hi;
         const int nsn = table_ok ? (int)(h_snaps < (unsigned)kSnaps ? h_snaps : (unsigned)kSnaps) : 0;
@@ -464,10 +469,16 @@ __device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg
     if (hit >= 0) {
         // the builders have nothing to read: let them go before the verdicts are even written
         if (tid == 0 && nwg > 1) __hip_atomic_store(&flags[0], a.token + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned v = vw[0], nh = sn_hit[0];
+        unsigned nh = sn_hit[0];
 #pragma unroll
-        for (int k = 1; k < kSnaps; ++k) if (hit == k) { v = vw[k]; nh = sn_hit[k]; }
-        if (tid < vwords) reinterpret_cast<unsigned *>(verdict)[tid] = v;
+        for (int k = 1; k < kSnaps; ++k) if (hit == k) nh = sn_hit[k];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            unsigned v = vw[0][j];
+#pragma unroll
+            for (int k = 1; k < kSnaps; ++k) if (hit == k) v = vw[k][j];
+            if (tid + j * NT < vwords) reinterpret_cast<unsigned *>(verdict)[tid + j * NT] = v;
+        }
         if (tid == 0) { hdr->todo_count = 0; hdr->clock = h_clock + 1u; hdr->hits = h_hits + nh; hdr->calls = h_calls + 1u; }
         return;
     }
@@ -509,19 +520,23 @@ __device__ __forceinline__ void plan_lookup_body(const PlanArgs &a, const int wg
     }
 }
 
-__global__ __launch_bounds__(kBuildThreads) void lss_plan_lookup(PlanArgs a) { plan_lookup_body(a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(kBuildThreads) void lss_plan_lookup(PlanArgs a) { plan_lookup_body<kBuildThreads>(a, (int)blockIdx.x, (int)gridDim.x); }
 
 // ---- the lookup as a rider of the depth softmax ---------------------------------------------------------------------------------
-// A lookup of known calibrations is a few dependent memory round trips in ONE workgroup: 4.8 us as a launch of its own on an idle
-// card, 6-10 us inside a training step -- against a forward of 28 us.  The depth softmax (csrc/depth_softmax.hip) runs between the
-// moment the matrices exist and the forward anyway, for 7.7 us over some hundred workgroups: this kernel is that softmax with the
-// lookup's 1 + g workgroups in FRONT of its grid (they start first; what they do ends long before the softmax's rows do), so the
-// steady state has no launch for the lookup at all.  A batch with calibrations to learn makes this launch as long as the build
-// (1.6 ms per calibration, once).  The softmax's rows are spread over workgroups of 1 024 threads here (the build's shape).
-__global__ __launch_bounds__(kBuildThreads) void lss_plan_lookup_softmax(PlanArgs a, SoftmaxArgs s, int variant, int nlookup) {
-    if ((int)blockIdx.x < nlookup) { plan_lookup_body(a, (int)blockIdx.x, nlookup); return; }
+// A lookup of known calibrations is one round of memory loads in ONE workgroup: 4.8 us as a launch of its own on an idle card,
+// 6-10 us inside a training step -- against a forward of 27 us.  The depth softmax (csrc/depth_softmax.hip) runs between the
+// moment the matrices exist and the forward anyway, for 6.4 us over a thousand workgroups: this kernel is that softmax -- its grid,
+// its 256 threads, its rows' code -- with the lookup's 1 + g workgroups in FRONT (they start first; what they do ends long before the
+// softmax's rows do), so the steady state has no launch for the lookup at all.  The lookup and the build run with 256 threads here
+// (the plan does not depend on the thread count; a batch with calibrations to learn makes this launch as long as the build:
+// ~6 ms per calibration instead of 1.6, once).  Why 256: the same rows in workgroups of 1 024 threads take 7.2-7.6 us instead
+// of 6.2 (tools/ubench/softmax_shape.hip), while the build's 128 registers, 16 KB of LDS and private segment cost the 256-thread
+// shape 0.3 us.
+constexpr int kRiderThreads = 256;
+__global__ __launch_bounds__(kRiderThreads, 4) void lss_plan_lookup_softmax(PlanArgs a, SoftmaxArgs s, int variant, int nlookup) {
+    if ((int)blockIdx.x < nlookup) { plan_lookup_body<kRiderThreads>(a, (int)blockIdx.x, nlookup); return; }
     const int blk = (int)blockIdx.x - nlookup, nblk = (int)gridDim.x - nlookup, tid = threadIdx.x;
-#define MMT_RIDER_CASE(id, LT, UT, NV) case id: softmax_fwd_rows<LT, UT, 4, NV, (NV <= 4 ? 2 : 1)>(s, blk, nblk, tid, kBuildThreads); break;
+#define MMT_RIDER_CASE(id, LT, UT, NV) case id: softmax_fwd_rows<LT, UT, 4, NV>(s, blk, nblk, tid, kRiderThreads); break;
     switch (variant) {          // (logits type, depth_used type, 16-byte pieces per lane)
         MMT_RIDER_CASE(0, float, float, 2) MMT_RIDER_CASE(1, float, float, 4) MMT_RIDER_CASE(2, float, float, 8)
         MMT_RIDER_CASE(3, float, bf16_t, 2) MMT_RIDER_CASE(4, float, bf16_t, 4) MMT_RIDER_CASE(5, float, bf16_t, 8)
@@ -1137,14 +1152,10 @@ extern "C" int mmt_depth_softmax_forward_plan_prepare(int64_t pixels, int D, con
     p.token = next_token();
     static const char *dbg = getenv("MMT_RIDER_NOLOOKUP");          // experiments only: the softmax in this kernel's shape, no lookup
     const int nlookup = (dbg && dbg[0] == '1') ? 0 : 1 + (B < kBuildPar ? B : kBuildPar);
-    // the softmax's share of the grid: the kernel keeps the build's 128 registers, so a CU holds ONE workgroup of it -- as many
-    // workgroups as fit the chip beside the lookup's in one round, their lane groups striding over the pixels with two rows in flight
-    // (a second round of workgroups would double the launch: 9.2 against 6.5 us at BASELINE configs[3])
-    const int64_t want = mmt::ceil_div(pixels * kGroup, (int64_t)kBuildThreads);
-    const int room = 256 - nlookup;                  // (MI355X: 256 CUs)
-    const int nsm = (int)(want < 1 ? 1 : (want > room && room > 0 ? room : want));
+    // the softmax's share of the grid: what the stand-alone kernel launches (csrc/depth_softmax.hip)
+    const int nsm = mmt::stream_grid(pixels * kGroup, kRiderThreads, 256 * 32);
     mmt::TimedSeq seq;
-    seq.launch(true, lss_plan_lookup_softmax, dim3((unsigned)(nlookup + nsm)), dim3(kBuildThreads), 0, (hipStream_t)stream, p, a, variant, nlookup);
+    seq.launch(true, lss_plan_lookup_softmax, dim3((unsigned)(nlookup + nsm)), dim3(kRiderThreads), 0, (hipStream_t)stream, p, a, variant, nlookup);
     return mmt::check_launch(who);
 }
 

@@ -419,6 +419,23 @@ def test_lookup_riding_in_the_depth_softmax(mmt_lib, dtypes, D):
         c0, c1 = plan_cache_counters(twin), plan_cache_counters(rider)
         assert c0 == c1 and c1["stale"] == 0, (it, c0, c1)
     assert c1["learnt"] == 2 * B + 1 and c1["calls"] == 8
+    # the plans learnt inside the softmax's launch (256-thread workgroups) serve the forward like those of the lookup's own launch (1 024)
+    C = 64
+    depth = torch.rand(B * N, fH, fW, D, generator=g).cuda()
+    ctx = torch.randn(B * N, fH, fW, C, generator=g).cuda()
+    o_r = _forward(b0, axes, vc, vs, vn, depth, ctx, rider, prepared=True)
+    o_t = _forward(b0, axes, vc, vs, vn, depth, ctx, twin, prepared=True)
+    assert torch.equal(o_r, o_t) and bool(torch.isfinite(o_r).all())
+    for slot in range(2 * B + 1):
+        lr, lt_ = _layout(N, D, fH, fW, vn[0], vn[1], rider), _layout(N, D, fH, fW, vn[0], vn[1], twin)
+        a_ = rider[lr["base"] + lr["slots_off"] + slot * lr["slot_bytes"]:lr["base"] + lr["slots_off"] + (slot + 1) * lr["slot_bytes"]]
+        b_ = twin[lt_["base"] + lt_["slots_off"] + slot * lt_["slot_bytes"]:lt_["base"] + lt_["slots_off"] + (slot + 1) * lt_["slot_bytes"]]
+        meta_a, meta_b = a_[:64].view(torch.int32).cpu().numpy(), b_[:64].view(torch.int32).cpu().numpy()
+        assert np.array_equal(meta_a[:5], meta_b[:5]) and np.array_equal(meta_a[6:], meta_b[6:]), slot      # (word 5: the LRU stamp)
+        njobs = int(meta_a[3])
+        ra = a_[lr["records_off"]:lr["records_off"] + njobs * P.JOB_BYTES]
+        rb = b_[lt_["records_off"]:lt_["records_off"] + njobs * P.JOB_BYTES]
+        assert torch.equal(ra, rb), slot
     # rows that cannot carry the lookup (D % 4 != 0 here): depth_softmax makes the two launches itself
     # and the raw entry point refuses
     from mm_training_amd import _lib
