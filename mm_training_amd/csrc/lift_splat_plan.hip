@@ -684,6 +684,30 @@ __device__ __forceinline__ float4 load_depth4(const __amdgpu_buffer_rsrc_t &rs, 
     }
 }
 
+// the depths of kWindowBins consecutive bins of one pixel row from element e of the depth tensor on (bf16: e is even), as fp32.
+// A window that leaves the pixel's D bins reads the next pixel's (or, past the tensor, the descriptor's zeros): the masks of
+// the runs never select those.
+template <typename FT>
+__device__ __forceinline__ void load_window(const __amdgpu_buffer_rsrc_t &rs, unsigned e, float (&win)[kWindowBins]) {
+    static_assert(kWindowBins == 8, "two 16-byte loads (fp32) / one (bf16)");
+    if constexpr (sizeof(FT) == 4) {
+        const mmt_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 4u, 0, 0);          // (dword-aligned, not 16-byte aligned)
+        const mmt_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 4u + 16u, 0, 0);
+        win[0] = __uint_as_float(a.x); win[1] = __uint_as_float(a.y); win[2] = __uint_as_float(a.z); win[3] = __uint_as_float(a.w);
+        win[4] = __uint_as_float(b.x); win[5] = __uint_as_float(b.y); win[6] = __uint_as_float(b.z); win[7] = __uint_as_float(b.w);
+    } else {
+        // bf16: w0 is even, and so is the pixel's first element unless D is odd -- then e may sit at an odd 2-byte address: the eight
+        // elements from e - 1 on (dword-aligned) and the ninth on its own, moved down by one
+        const bool odd = (e & 1u) != 0u;
+        const mmt_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (e & ~1u) * 2u, 0, 0);
+        const unsigned last = odd ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, (e + 7u) * 2u, 0, 0) : 0u;
+        const unsigned x0 = odd ? (a.x >> 16) | (a.y << 16) : a.x, x1 = odd ? (a.y >> 16) | (a.z << 16) : a.y;
+        const unsigned x2 = odd ? (a.z >> 16) | (a.w << 16) : a.z, x3 = odd ? (a.w >> 16) | (last << 16) : a.w;
+        win[0] = bf16_lo(x0); win[1] = bf16_hi(x0); win[2] = bf16_lo(x1); win[3] = bf16_hi(x1);
+        win[4] = bf16_lo(x2); win[5] = bf16_hi(x2); win[6] = bf16_lo(x3); win[7] = bf16_hi(x3);
+    }
+}
+
 #define PLAN_FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 // 4 waves per SIMD for C <= 80 (a 128-register cap: two loop-invariant values are spilled and reloaded once per unit, outside the
@@ -805,6 +829,19 @@ __global__ __launch_bounds__(kFwdThreads, (S <= 5 ? PLAN_FWD_WAVES : 1)) void ls
                 const PairRec pr = pairs[pi];
                 const int n = pr.col / d.fW, w = pr.col - n * d.fW;
                 const int bn = b * d.N + n, r0 = pr.rb * 16;
+                const int myrow = (r0 + li) < d.fH ? (r0 + li) : d.fH - 1;
+                const unsigned pix = (unsigned)((((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D);
+                // the pair's depth window: bins [w0, w0 + kWindowBins) of this lane's image row (w0 even: a dword-aligned address in bf16
+                // too).  ONE load per pair where round 5 made one (bf16: two) per run; issued in front of the context rows (loads return
+                // in order, and the weights are needed first).
+                const unsigned e0 = pix + pr.w0;
+                float win[kWindowBins];
+#ifdef PLAN_EXP_NODEPTH    // ablation build: no depth traffic (results are wrong)
+#pragma unroll
+                for (int k = 0; k < kWindowBins; ++k) win[k] = __uint_as_float(0x3f800000u | ((e0 + k) & 0xFFFFu));
+#else
+                load_window<FT>(drs, e0, win);
+#endif
                 Acc<S> ctx[16];
                 const unsigned row_bytes = (unsigned)(d.fW * C) * (unsigned)sizeof(FT);
                 const unsigned cvoff = (unsigned)((((int64_t)bn * d.fH + r0) * d.fW + w) * C) * (unsigned)sizeof(FT);
@@ -816,50 +853,46 @@ __global__ __launch_bounds__(kFwdThreads, (S <= 5 ? PLAN_FWD_WAVES : 1)) void ls
                     load_ctx_buf<FT, S>(crs, cvoff, (unsigned)h * row_bytes, li, ctx[h]);       // (rows past the image: zeroed below)
 #endif
                 }
-                const int myrow = (r0 + li) < d.fH ? (r0 + li) : d.fH - 1;
-                const unsigned pix = (unsigned)((((int64_t)bn * d.fH + myrow) * d.fW + w) * d.D);
-                float4 dv[kMaxPairRuns];
-#pragma unroll
-                for (int r = 0; r < kMaxPairRuns; ++r) {
-                    dv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < pr.nruns) dv[r] = load_depth4<FT>(drs, pix + runs[pr.run0 + r].d0);
-                }
 #ifdef PLAN_STAMPS
                 if (pi == g) { PLAN_STAMP(8); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PLAN_STAMP(9); }
 #endif
-                // a run's weight per image row: its (up to four) bins' depths under the run's row masks -- lane li is row li
-                float wsum[kMaxPairRuns];
-#pragma unroll
-                for (int r = 0; r < kMaxPairRuns; ++r) {
-                    wsum[r] = 0.f;
-                    if (r < pr.nruns) {
-                        const uint2 mk = *reinterpret_cast<const uint2 *>(runs[pr.run0 + r].mask);
-                        float wv = ((mk.x >> li) & 1u) ? dv[r].x : 0.f;
-                        wv += ((mk.x >> (16 + li)) & 1u) ? dv[r].y : 0.f;
-                        wv += ((mk.y >> li) & 1u) ? dv[r].z : 0.f;
-                        wv += ((mk.y >> (16 + li)) & 1u) ? dv[r].w : 0.f;
-                        wsum[r] = wv;
-                    }
-                }
                 if (r0 + 16 > d.fH) {          // rows past the image: their weights are zero, and so must their context be (0 * NaN)
 #pragma unroll
                     for (int h = 0; h < 16; ++h) if (r0 + h >= d.fH) ctx[h].zero();
                 }
-#pragma unroll
-                for (int r = 0; r < kMaxPairRuns; ++r) {
-                    if (r < pr.nruns) {
-                        const float wr = wsum[r];
-                        Acc<S> acc;
-                        acc.zero();
+                // the runs: a run's weight of image row li = the window's bins under the run's row masks (eight 16-bit masks at the
+                // window's positions, shifted there by the builder: fixed positions, no register indexed at run time); the next run's
+                // words are fetched from the record while this one's sixteen rows are multiplied
+                const RunRec *rr = runs + pr.run0;
+                uint2 mlo = *reinterpret_cast<const uint2 *>(&rr->wlo), mhi = *reinterpret_cast<const uint2 *>(&rr->whi);
+                int pslot = rr->pslot;
+#pragma unroll 1
+                for (int r = 0; r < pr.nruns; ++r) {
+                    const unsigned t0 = mlo.x >> li, t1 = mlo.y >> li, t2 = mhi.x >> li, t3 = mhi.y >> li;
+                    const int ps = pslot;
+                    if (r + 1 < pr.nruns) {
+                        ++rr;
+                        mlo = *reinterpret_cast<const uint2 *>(&rr->wlo); mhi = *reinterpret_cast<const uint2 *>(&rr->whi);
+                        pslot = rr->pslot;
+                    }
+                    float wr = (t0 & 1u) ? win[0] : 0.f;
+                    wr += (t0 & 0x10000u) ? win[1] : 0.f;
+                    wr += (t1 & 1u) ? win[2] : 0.f;
+                    wr += (t1 & 0x10000u) ? win[3] : 0.f;
+                    wr += (t2 & 1u) ? win[4] : 0.f;
+                    wr += (t2 & 0x10000u) ? win[5] : 0.f;
+                    wr += (t3 & 1u) ? win[6] : 0.f;
+                    wr += (t3 & 0x10000u) ? win[7] : 0.f;
+                    Acc<S> acc;
+                    acc.zero();
 #ifdef PLAN_EXP_NOFMA      // ablation build: one row's products instead of sixteen (results are wrong)
 #define PLAN_STEP(h) if (h == 0) acc.fma(row_bcast<h>(wr), ctx[h]); else acc.q[0].x += ctx[h].q[0].x + ctx[h].q[1].y + ctx[h].s[0];
 #else
 #define PLAN_STEP(h) acc.fma(row_bcast<h>(wr), ctx[h]);
 #endif
-                        PLAN_FOR16(PLAN_STEP)
+                    PLAN_FOR16(PLAN_STEP)
 #undef PLAN_STEP
-                        store_row<S>(partial + (int)runs[pr.run0 + r].pslot * C, li, acc);
-                    }
+                    store_row<S>(partial + ps * C, li, acc);
                 }
             }
 #ifdef PLAN_STAMPS
@@ -1032,7 +1065,7 @@ int fill_plan_args(const char *what, int B, int N, int D, int fH, int fW, int nx
     mmt::make_cam_grid(vc, vs, &p->q);
     mmt::make_cam_range(&p->q, nx, ny, nz);
     // what the learnt plans depend on besides the matrices and the axes' contents (hashed on the device)
-    int words[20] = {N, D, fH, fW, nx, ny, nz, kMaxRuns, kMaxPairRuns, kRunBins, kTile, kJobBytes, slots, 1 /* layout version */};
+    int words[20] = {N, D, fH, fW, nx, ny, nz, kMaxRuns, kMaxPairRuns, kRunBins, kTile, kJobBytes, slots, 2 /* layout version */, kWindowBins};
     memcpy(words + 14, p->q.lo, 12);
     memcpy(words + 17, p->q.vs, 12);
     uint64_t h = 0xCBF29CE484222325ull;

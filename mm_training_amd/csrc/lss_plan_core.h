@@ -32,11 +32,14 @@ constexpr int kTileCells = kTile * kTile;
 #define PLAN_MAX_RUNS 96
 #endif
 #ifndef PLAN_MAX_PAIR_RUNS
-#define PLAN_MAX_PAIR_RUNS 4
+#define PLAN_MAX_PAIR_RUNS 8
 #endif
 constexpr int kMaxRuns = PLAN_MAX_RUNS;  // runs (= partial rows in LDS) per job (<= 255: a record's cell_begin is bytes)
-constexpr int kMaxPairRuns = PLAN_MAX_PAIR_RUNS;   // runs per pair record (a lane group keeps their depths in registers)
-constexpr int kRunBins = 4;              // depth bins per run (one 16-byte depth load per image row)
+constexpr int kMaxPairRuns = PLAN_MAX_PAIR_RUNS;   // runs per pair record
+constexpr int kRunBins = 4;              // depth bins per run
+constexpr int kWindowBins = 8;           // depth bins a lane group loads per PAIR and image row (one 16-byte load in bf16, two in fp32): every run of
+                                         // the pair takes its bins out of that window (round 5 loaded four bins per RUN: 2.3 runs per pair at BASELINE
+                                         // configs[4], every load a cache line per image row -- 12 of the kernel's 46 us there)
 constexpr int kGroups = 8;               // record groups of a plan: neighbouring tiles (one XCD's share at batch 1), heaviest tiles first inside
 constexpr int kSummaryUniformBit = 0x10000;   // = mmt::kSummaryUniform (mmt_camera.h)
 
@@ -44,7 +47,7 @@ constexpr int kSummaryUniformBit = 0x10000;   // = mmt::kSummaryUniform (mmt_cam
 constexpr int kJobCellBeginOff = 16;
 constexpr int kJobPairsOff = 96;
 constexpr int kJobRunsOff = kJobPairsOff + 8 * kMaxRuns;
-constexpr int kJobBytes = kJobRunsOff + 16 * kMaxRuns;      // 2400 = 150 x 16
+constexpr int kJobBytes = kJobRunsOff + 24 * kMaxRuns;      // 3168 = 198 x 16
 
 struct Dims {
     int N, D, fH, fW, nb;                // cameras, depth bins, image rows / columns of the feature map, 16-row blocks per column
@@ -89,8 +92,10 @@ struct JobDesc { int32_t tile, c0, ncells, run_begin, nruns, chain, pad1, pad2; 
 // the head walks the whole chain and sums the records' partial rows in order; a workgroup that meets a link skips it
 constexpr uint32_t kChainNone = 0, kChainHead = 1, kChainLink = 2, kChainMore = 4;      // kChainMore: the next record continues this chain
 struct JobHeader { uint16_t ncells, npairs, nruns, c0; int32_t tile; uint32_t chain; };
-struct PairRec { uint16_t col; uint8_t rb; uint8_t nruns; uint16_t run0; uint16_t live; };       // col = camera * fW + column; live: bit i = row i of the block is in some run of the pair
-struct RunRec { uint16_t d0; uint8_t len; uint8_t pslot; uint16_t mask[kRunBins]; uint32_t cell_local; };   // pslot: partial row; cell_local: index in the job
+struct PairRec { uint16_t col; uint8_t rb; uint8_t nruns; uint16_t run0; uint16_t w0; };         // col = camera * fW + column; w0: first bin of the pair's depth window (even)
+struct RunRec { uint16_t d0; uint8_t len; uint8_t pslot; uint32_t cell_local; uint64_t wlo, whi; };   // pslot: partial row; cell_local: index in the job;
+// wlo / whi: eight 16-bit row masks, bits [16 k, 16 k + 16) = the rows of the block that take window bin w0 + k (d0 / len: the run's loaded bins, for the record)
+static_assert(sizeof(PairRec) == 8 && sizeof(RunRec) == 24, "record layout");
 
 // A tile's 64 cells are numbered along a Z curve (x bits at the even, y bits at the odd positions), so that a job -- a range of
 // consecutive cells -- is a compact block (2 x 2, 4 x 2, 4 x 4, ...) and not a strip: a column's ray then crosses several of
@@ -349,7 +354,8 @@ PLAN_HD void phase_write_jobs(const Dims &d, Scratch &s, int tid, int nt) {
 }
 // phase 10: the job records the forward kernel reads.  A job's runs are contiguous in the cell-sorted list; their position
 // there is the partial row (`pslot`), `cell_begin` delimits the cells' partial rows.  The record lists the runs PAIR-major
-// (by key: camera, column, row block, bin), cut into pairs of at most kMaxPairRuns runs of one (column, row block).
+// (by key: camera, column, row block, bin), cut into pairs of at most kMaxPairRuns runs of one (column, row block) whose bins fit
+// one window of kWindowBins bins.
 PLAN_HD void phase_records(const Dims &, Scratch &s, uint8_t *records, int njobs, int tid, int nt) {
     for (int j = tid; j < njobs; j += nt) {
         const JobDesc jd = s.jobs[j];
@@ -371,24 +377,31 @@ PLAN_HD void phase_records(const Dims &, Scratch &s, uint8_t *records, int njobs
         }
         PairRec *pairs = reinterpret_cast<PairRec *>(rec + kJobPairsOff);
         RunRec *rr = reinterpret_cast<RunRec *>(rec + kJobRunsOff);
-        int npairs = 0;
+        int npairs = 0, w0 = 0;
         uint32_t pkey = 0xFFFFFFFFu;
         for (int p = 0; p < jd.nruns; ++p) {
             const int i = order[p];
             const RunTmp r = runs[i];
             RunRec o;
             o.d0 = (uint16_t)((r.key & 0x7FFu) - (r.cell_len >> 30)); o.len = (uint8_t)(((r.cell_len >> 28) & 3u) + 1); o.pslot = (uint8_t)i;
-            o.mask[0] = r.mask[0]; o.mask[1] = r.mask[1]; o.mask[2] = r.mask[2]; o.mask[3] = r.mask[3];
             o.cell_local = (r.cell_len & 0x0FFFFFFFu) - (uint32_t)ctm0;
-            rr[p] = o;
             const uint32_t pk = r.key >> 11;          // (column, row block)
-            if (pk != pkey || pairs[npairs - 1].nruns >= kMaxPairRuns) {
-                PairRec pr; pr.col = (uint16_t)(r.key >> 16); pr.rb = (uint8_t)((r.key >> 11) & 31u); pr.nruns = 0; pr.run0 = (uint16_t)p; pr.live = 0;
+            // a pair's runs share ONE window of kWindowBins depth bins that starts at the even bin at or below its first run's
+            // (loaded) bin -- a dword-aligned address in bf16 too -- so a run whose bins would leave the window opens a new pair
+            if (pk != pkey || pairs[npairs - 1].nruns >= kMaxPairRuns || (int)o.d0 + (int)o.len - w0 > kWindowBins) {
+                w0 = (int)o.d0 & ~1;
+                PairRec pr; pr.col = (uint16_t)(r.key >> 16); pr.rb = (uint8_t)((r.key >> 11) & 31u); pr.nruns = 0; pr.run0 = (uint16_t)p; pr.w0 = (uint16_t)w0;
                 pairs[npairs++] = pr;
                 pkey = pk;
             }
+            {   // the run's four masks moved to its place in the window (a 128-bit shift by 16 bits per bin; masks past the run's length are zero)
+                const uint64_t m = (uint64_t)r.mask[0] | ((uint64_t)r.mask[1] << 16) | ((uint64_t)r.mask[2] << 32) | ((uint64_t)r.mask[3] << 48);
+                const int off = (int)o.d0 - w0;
+                o.wlo = off < 4 ? (m << (16 * off)) : 0ull;
+                o.whi = off == 0 ? 0ull : (off < 4 ? (m >> (64 - 16 * off)) : (m << (16 * (off - 4))));
+            }
+            rr[p] = o;
             ++pairs[npairs - 1].nruns;
-            pairs[npairs - 1].live |= (uint16_t)(o.mask[0] | o.mask[1] | o.mask[2] | o.mask[3]);
         }
         JobHeader h; h.ncells = (uint16_t)jd.ncells; h.npairs = (uint16_t)npairs; h.nruns = (uint16_t)jd.nruns; h.c0 = (uint16_t)jd.c0; h.tile = jd.tile; h.chain = (uint32_t)jd.chain;
         *reinterpret_cast<JobHeader *>(rec) = h;

@@ -13,12 +13,12 @@ _CORE = os.path.join(_HERE, "..", "mm_training_amd", "csrc", "lss_plan_core.h")
 _OUT = os.path.join(_HERE, "native", "_build", "libplanhost.so")
 
 UNIFORM = 0x10000
-MAX_RUNS, MAX_PAIR_RUNS, RUN_BINS, TILE = 96, 4, 4, 8
+MAX_RUNS, MAX_PAIR_RUNS, RUN_BINS, WINDOW_BINS, TILE = 96, 8, 4, 8, 8
 HDR = np.dtype([("ncells", "<u2"), ("npairs", "<u2"), ("nruns", "<u2"), ("c0", "<u2"), ("tile", "<i4"), ("chain", "<u4")])
 CHAIN_HEAD, CHAIN_LINK, CHAIN_MORE = 1, 2, 4
-PAIR = np.dtype([("col", "<u2"), ("rb", "u1"), ("nruns", "u1"), ("run0", "<u2"), ("live", "<u2")])
-RUN = np.dtype([("d0", "<u2"), ("len", "u1"), ("pslot", "u1"), ("mask", "<u2", (4,)), ("cell_local", "<u4")])
-CELL_BEGIN_OFF, PAIRS_OFF, RUNS_OFF, JOB_BYTES = 16, 96, 96 + 8 * MAX_RUNS, 96 + 8 * MAX_RUNS + 16 * MAX_RUNS
+PAIR = np.dtype([("col", "<u2"), ("rb", "u1"), ("nruns", "u1"), ("run0", "<u2"), ("w0", "<u2")])
+RUN = np.dtype([("d0", "<u2"), ("len", "u1"), ("pslot", "u1"), ("cell_local", "<u4"), ("wmask", "<u2", (8,))])
+CELL_BEGIN_OFF, PAIRS_OFF, RUNS_OFF, JOB_BYTES = 16, 96, 96 + 8 * MAX_RUNS, 96 + 8 * MAX_RUNS + 24 * MAX_RUNS
 
 _lib = None
 
@@ -88,7 +88,7 @@ def decode(record):
     h = record[:16].view(HDR)[0]
     cb = record[CELL_BEGIN_OFF:CELL_BEGIN_OFF + 65].astype(np.int64)
     pairs = record[PAIRS_OFF:PAIRS_OFF + 8 * int(h["npairs"])].view(PAIR)
-    runs = record[RUNS_OFF:RUNS_OFF + 16 * int(h["nruns"])].view(RUN)
+    runs = record[RUNS_OFF:RUNS_OFF + 24 * int(h["nruns"])].view(RUN)
     return dict(h=h, cell_begin=cb, pairs=pairs, runs=runs)
 
 
@@ -107,7 +107,7 @@ def emulate_forward(d, records, depth, context, dtype=np.float64):
     N, fH, fW, D = depth.shape
     C = context.shape[-1]
     out = np.full((d["ny"], d["nx"], C), np.nan, dtype)
-    dp = np.zeros((N, d["nb"] * 16, fW, D + RUN_BINS), dtype)
+    dp = np.zeros((N, d["nb"] * 16, fW, D + WINDOW_BINS), dtype)
     dp[:, :fH, :, :D] = depth
     cx = np.zeros((N, d["nb"] * 16, fW, C), dtype)
     cx[:, :fH] = context
@@ -120,17 +120,18 @@ def emulate_forward(d, records, depth, context, dtype=np.float64):
         for pr in job["pairs"]:
             n, w, rb = int(pr["col"]) // fW, int(pr["col"]) % fW, int(pr["rb"])
             assert 1 <= int(pr["nruns"]) <= MAX_PAIR_RUNS
-            live = 0
+            w0 = int(pr["w0"])                       # the pair's depth window: bins [w0, w0 + WINDOW_BINS) of every image row, w0 even
+            assert w0 % 2 == 0
             for r in job["runs"][int(pr["run0"]):int(pr["run0"]) + int(pr["nruns"])]:
+                assert w0 <= int(r["d0"]) and int(r["d0"]) + int(r["len"]) - w0 <= WINDOW_BINS
+                assert all(int(m) == 0 for k, m in enumerate(r["wmask"]) if not int(r["d0"]) <= w0 + k < int(r["d0"]) + int(r["len"]))
                 wgt = np.zeros(16, dtype)
-                live |= int(np.bitwise_or.reduce(r["mask"]))
-                for j in range(int(r["len"])):
-                    bits = (int(r["mask"][j]) >> np.arange(16)) & 1
-                    wgt += bits * dp[n, rb * 16:(rb + 1) * 16, w, int(r["d0"]) + j]
+                for k in range(WINDOW_BINS):             # what the kernel does: the window's bins under the run's row masks
+                    bits = (int(r["wmask"][k]) >> np.arange(16)) & 1
+                    wgt += bits * dp[n, rb * 16:(rb + 1) * 16, w, w0 + k]
                 assert not written[int(r["pslot"])]
                 partial[int(r["pslot"])] = wgt @ cx[n, rb * 16:(rb + 1) * 16, w]
                 written[int(r["pslot"])] = True
-            assert live == int(pr["live"])          # the rows whose context the kernel loads
         assert written[:nruns].all()
         xs, ys = job_cells(d, job)
         cb = job["cell_begin"]

@@ -100,6 +100,21 @@ def main():
         m = s[:, 7] == x
         rel_start[m] = (s[m, 0] - s[m, 0].min()).float()
     print("workgroup start times, quantiles:", [int(v) for v in rel_start[worked].quantile(qs)])
+    # per XCD, over the workgroups that had a unit: how well the units pack (sum of lives / slots against the span)
+    for x in sorted(set(w[:, 7].tolist())):
+        wx = w[w[:, 7] == x]
+        med = wx[:, 0].float().median()
+        wx = wx[(wx[:, 0].float() - med).abs() < 1e6]        # (a few workgroups carry a stamp of another clock domain: left out)
+        t0 = wx[:, 0].min()
+        st_rel = (wx[:, 0] - t0).float(); en_rel = (wx[:, 5] - t0).float()
+        print("   xcd %d timeline: starts p10/p50/p90/max %6d %6d %6d %6d   ends p10/p50/p90/max %6d %6d %6d %6d   units whose life > 50k: %d" % (
+            x, *[int(st_rel.quantile(q)) for q in (0.1, 0.5, 0.9, 1.0)], *[int(en_rel.quantile(q)) for q in (0.1, 0.5, 0.9, 1.0)], int(((wx[:, 5] - wx[:, 0]) > 50000).sum())))
+        span = int((wx[:, 5] - t0).max())
+        life = (wx[:, 5] - wx[:, 0]).float()
+        order = torch.argsort(wx[:, 0])
+        print("xcd %d: %4d units, span %6d cycles, sum of lives %8d (= %5.0f per slot at 128 slots), longest life %6d started at %6d; starts p50 %6d p90 %6d; pairs %d runs %d" % (
+            x, len(wx), span, int(life.sum()), float(life.sum()) / 128, int(life.max()), int((wx[life.argmax(), 0] - t0)), int((wx[:, 0] - t0).float().median()), int((wx[:, 0] - t0).float().quantile(0.9)),
+            int((wx[:, 6] >> 32).sum()), int((wx[:, 6] & 0xFFFFFFFF).sum())))
 
 
 if __name__ == "__main__":
