@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
     if (tid == 0) { nmis = 0; nkept = 0; }
     __syncthreads();
 #ifdef LSS_STAMPS   // diagnostic build: grad_context receives 4 s_memtime stamps per workgroup instead of its rows
-    unsigned long long *cstamps = reinterpret_cast<unsigned long long *>(a.grad_context) + (int64_t)blockIdx.x * 4;
+    unsigned long long *cstamps = reinterpret_cast<unsigned long long *>(a.grad_context) + (int64_t)blockIdx.x * 8;
 #define COL_STAMP(i) do { if (threadIdx.x == 0) cstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define COL_STAMP(i) do { } while (0)
@@ -104,28 +104,52 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
     COL_STAMP(0);
 
     // ---- the block's 16 context rows -> wave 0's G tile (free until the products start), as whole 16-byte vectors; the A
-    // operand of the grad_depth product is read out of it after phase A's barrier (round 2: 20 strided dword loads per lane)
-    {
-        constexpr int VEC = sizeof(FT) == 2 ? 8 : 4, CV = C / VEC;
-        for (int e = tid; e < 16 * CV; e += kColBlock) {
-            const int prow = e / CV, cvi = e - prow * CV;
-            const FT *src = context + ((int64_t)bn * HW + (row0 + (prow < nrow ? prow : 0)) * a.fW + col) * C + cvi * VEC;
-            float *dst = gw0 + prow * CP + cvi * VEC;
-            if constexpr (sizeof(FT) == 2) {
-                const uint4 r = *reinterpret_cast<const uint4 *>(src);
-                *reinterpret_cast<float4 *>(dst) = make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
-                *reinterpret_cast<float4 *>(dst + 4) = make_float4(bf16_lo(r.z), bf16_hi(r.z), bf16_lo(r.w), bf16_hi(r.w));
-            } else {
-                *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+    // operand of the grad_depth product is read out of it after phase A's barrier (round 2: 20 strided dword loads per lane).
+    // The loads are ISSUED here and parked in LDS behind phase A (round 5 waited for them in front of it: a memory round trip
+    // or two before phase A's own loads were even issued -- 3 of the workgroup's 14 us in the stamps)
+    constexpr int VEC = sizeof(FT) == 2 ? 8 : 4, CV = C / VEC, NCI = (16 * CV + kColBlock - 1) / kColBlock;
+    uint4 creg[NCI];
+#pragma unroll
+    for (int i = 0; i < NCI; ++i) {
+        const int e = tid + i * kColBlock, ec = e < 16 * CV ? e : 16 * CV - 1;
+        const int prow = ec / CV, cvi = ec - prow * CV;
+        creg[i] = *reinterpret_cast<const uint4 *>(context + ((int64_t)bn * HW + (row0 + (prow < nrow ? prow : 0)) * a.fW + col) * C + cvi * VEC);
+    }
+    auto park_context = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) {
+            const int e = tid + i * kColBlock;
+            if (e < 16 * CV) {
+                const int prow = e / CV, cvi = e - prow * CV;
+                float *dst = gw0 + prow * CP + cvi * VEC;
+                const uint4 r = creg[i];
+                if constexpr (sizeof(FT) == 2) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+                    *reinterpret_cast<float4 *>(dst + 4) = make_float4(bf16_lo(r.z), bf16_hi(r.z), bf16_lo(r.w), bf16_hi(r.w));
+                } else {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+                }
             }
         }
-    }
+    };
 
     // ---- phase A: a thread takes one bin of all 16 rows (coalesced along the bins in the pixel-major order), all 32 loads in
     // flight at once: kept test, the column's cell = the smallest row offset among the kept pixels, who shares it, who does not
     const int64_t tcol = col_point(a, bn, row0, col, 0);               // point (row0, col, bin 0); rows / bins are strides away
     const int64_t rstep = a.pm ? (int64_t)a.fW * D : a.fW;
     const int64_t dstep = a.pm ? 1 : (int64_t)HW;
+    // phase A's loads of this thread's first (at D <= 128: only) bin go out FIRST: the camera operands below are waited for before
+    // they are used, and with the depths behind them that wait was a memory round trip in front of phase A's own (stamps: 2.4 us)
+    float dv0[16];
+    int2 sv0 = make_int2(-1, 0);
+    {
+        const int64_t tb = tcol + (tid < D ? tid : 0) * dstep;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dv0[u] = ld_scalar<FT>(depth + tb + (u < nrow ? u : 0) * rstep);
+        if constexpr (CAM) {
+            if (a.summary) sv0 = a.summary[(((int64_t)bn * a.rblocks + rb) * a.fW + col) * D + (tid < D ? tid : 0)];
+        }
+    }
     float cm[12], cv[16];
     float cu = 0.f;
     bool cv_sorted = false;
@@ -133,10 +157,14 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) cm[k] = a.combine[bn * 16 + k];
         cu = a.fu[col];
+        // the block's 16 row coordinates: ONE vector load (lane u takes row u's) handed out with v_readlane -- sixteen uniform loads
+        // compile to sixteen s_load_dword, each waited for before the next is issued (2 us in front of phase A's loads in the stamps)
+        const int fvl = __float_as_int(a.fv[row0 + ((lane & 15) < nrow ? (lane & 15) : nrow - 1)]);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) cv[u] = a.fv[row0 + (u < nrow ? u : nrow - 1)];
+        for (int u = 0; u < 16; ++u) cv[u] = __int_as_float(__builtin_amdgcn_readlane(fvl, u));
         cv_sorted = mmt_rows_sorted<16>(cv, nrow);
     }
+    int tmis = 0, tkept = 0;
     for (int bin = tid; bin < Dp; bin += kColBlock) {
         int gx[16], gy[16], gz[16];
         float dv[16];
@@ -145,8 +173,11 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
         for (int u = 0; u < 16; ++u) {
             const int64_t t = tb + (u < nrow ? u : 0) * rstep;
             if constexpr (!CAM) { gx[u] = a.geom[t * 3]; gy[u] = a.geom[t * 3 + 1]; gz[u] = a.geom[t * 3 + 2]; }
-            dv[u] = ld_scalar<FT>(depth + t);
+            dv[u] = bin == tid ? dv0[u] : ld_scalar<FT>(depth + t);
         }
+#ifdef LSS_STAMPS
+        COL_STAMP(3); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); COL_STAMP(4);
+#endif
         unsigned o[16];
         unsigned m = kOut;
         if constexpr (CAM) {
@@ -155,7 +186,7 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
             int x0, y0;
             unsigned zmask;
             if (a.summary) {      // written by the forward: two dwords per bin instead of the geometry
-                const int2 sv = a.summary[(((int64_t)bn * a.rblocks + rb) * a.fW + col) * D + (bin < D ? bin : 0)];
+                const int2 sv = bin == tid ? sv0 : a.summary[(((int64_t)bn * a.rblocks + rb) * a.fW + col) * D + (bin < D ? bin : 0)];
                 in0 = sv.x >= 0; x0 = sv.x & 0xFFFF; y0 = sv.x >> 16;
                 zmask = (unsigned)sv.y & 0xFFFFu;
                 uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
@@ -196,10 +227,21 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
             mis += f == 2;
             kept += f != 0;
         }
-        if (mis) atomicAdd(&nmis, mis);
-        if (a.stats && kept) atomicAdd(&nkept, kept);
+        tmis += mis; tkept += kept;
     }
+    {   // one LDS atomic per wave and counter (every lane adding to the same word is 64 serialised read-modify-writes)
+        int pk = (tmis << 16) | tkept;                                  // (<= 7 * 16 points per lane, 64 lanes: 13 bits each)
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) pk += __shfl_xor(pk, m);
+        if (lane == 0) {
+            if (pk >> 16) atomicAdd(&nmis, pk >> 16);
+            if (a.stats && (pk & 0xFFFF)) atomicAdd(&nkept, pk & 0xFFFF);
+        }
+    }
+    park_context();
+    COL_STAMP(5);
     __syncthreads();
+    COL_STAMP(6);
     float ctxA[C4];                       // Ctx[pixel = lane & 15][4 j + (lane >> 4)], in registers for the rest of the kernel
     {
         const int prow = lane & 15;

@@ -32,7 +32,11 @@ constexpr int kPlanMaxB = 64;            // samples per call
 constexpr int kPlanMaxN = 16;            // cameras per sample
 constexpr int kBuildPar = 8;             // calibrations learnt concurrently (scratch areas)
 constexpr int kBuildThreads = 1024;
-constexpr int kFwdThreads = 256;
+#ifndef PLAN_FWD_THREADS
+#define PLAN_FWD_THREADS 256
+#endif
+constexpr int kFwdThreads = PLAN_FWD_THREADS;     // 16 lanes per lane group
+constexpr int kFwdGroups = kFwdThreads / 16;
 constexpr unsigned kPlanMagic = 0x4E4C504Du;      // "MPLN"
 constexpr int kStateEmpty = 0, kStateReady = 1, kStateBrute = 2;
 
@@ -958,8 +962,8 @@ __global__ __launch_bounds__(kFwdThreads, (S <= 5 ? PLAN_FWD_WAVES : 1)) void ls
         if (tile < 0) continue;
         const int tx0 = (tile % d.tiles_x) * kTile, ty0 = (tile / d.tiles_x) * kTile;
 #pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) {
-            const int mylocal = g + 16 * pass;
+        for (int pass = 0; pass < kTileCells / kFwdGroups; ++pass) {
+            const int mylocal = g + kFwdGroups * pass;
             Acc<S> acc;
             acc.zero();
 #pragma unroll 1
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(kFwdThreads, (S <= 5 ? PLAN_FWD_WAVES : 1)) void ls
                     if (sv.y & mmt::kSummaryUniform) {
                         if (zm != 0u && sv.x >= 0) {
                             const int lx = (sv.x & 0xFFFF) - tx0, ly = (sv.x >> 16) - ty0;
-                            cand = (unsigned)lx < (unsigned)kTile && (unsigned)ly < (unsigned)kTile && ((ly * kTile + lx) >> 4) == pass;
+                            cand = (unsigned)lx < (unsigned)kTile && (unsigned)ly < (unsigned)kTile && (ly * kTile + lx) / kFwdGroups == pass;
                         }
                     } else cand = zm != 0u;
                 }
@@ -1090,7 +1094,7 @@ static int plan_fwd_wgs() {
     // 2 048 over the batch: at BASELINE configs[3] (1 280 records) the same as 1 024 (22.1 / 22.2 us), at configs[4] (1 844 records: a
     // record per workgroup) 46.2 against 50.2 us, at the reference's native frustum 52.4 against 60.2 (tools/scratch/plan_wgs.sh)
     static const char *env = getenv("MMT_PLAN_WGS");          // experiments only
-    return (env && atoi(env) > 0) ? atoi(env) : 2048;
+    return (env && atoi(env) > 0) ? atoi(env) : 2048 * 256 / kFwdThreads;
 }
 
 template <typename FT>

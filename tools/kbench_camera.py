@@ -142,7 +142,7 @@ def main():
                         assert bwd(h0, cam == 1, flags, summary if cam == 2 else None) == 0, h0.mmt_last_error()
                     torch.cuda.synchronize()
                     nwg = 8 * ((B * N + 7) // 8) * fW * ((fH + 15) // 16) if name == "column" else 4096
-                    s64 = gc.view(-1)[:8 * min(nwg, gc.numel() // 8)].view(torch.int64).view(-1, 4).cpu()
+                    s64 = gc.view(-1)[:16 * min(nwg, gc.numel() // 16)].view(torch.int64).view(-1, 8).cpu()      # (8 stamps per workgroup: tools/scratch/col_stamps8.py shows them all)
                     s64 = s64[(s64[:, 0] != 0) & (s64[:, 1] != 0) & (s64[:, 2] != 0)]
                     dd = (s64[:, 1:3] - s64[:, 0:2]).float()
                     span = (s64[:, 2].max() - s64[:, 0].min()).item()
