@@ -58,7 +58,7 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-// LDS (dynamic): dep [16][Dp] fp32 | ref [Dp] int | flag [16][Dp] bytes | G tiles of the 2 waves [2][16][CP] fp32
+// LDS (dynamic): dep [16][Dp] fp32 | ref [Dp] int | flag [Dp] words (2 bits per row) | G tiles of the 2 waves [2][16][CP] fp32
 // (20 KB at D = 112, C = 80; the kernel takes 156 VGPRs -- the geometry phase's 16-row arrays -- so a CU holds six workgroups
 // of two waves: 1 536 slots, every workgroup of the cfg4 launch (1 056) is resident at once, the 2 112 of configs[4] take two
 // rounds.  Capping the registers at 128 spills and was slower; round 2 also kept every point's own row offset in LDS, 7 KB
@@ -66,7 +66,10 @@ __device__ __forceinline__ float quad_sum(float v) {
 // (CP = C + 4; after the products: the grad_context total and the lists / partial sums of the mismatch pass)
 // NT = C / 16 (N tiles of the grad_context product); C / 4 <= 64 lanes move one row.
 template <typename FT, int NT, bool CAM>
-__global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
+#ifndef COL_MIN_WAVES
+#define COL_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs a) {
     extern __shared__ __align__(16) unsigned char col_lds[];
     constexpr int C = 16 * NT, C4 = C / 4, CP = C + 4;
     constexpr int NV = (16 * C4) / 64;                       // 16-byte vectors of a G tile per lane
@@ -88,8 +91,9 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
 
     float *dep = reinterpret_cast<float *>(col_lds);                   // [16][Dp] depth value (0 for dropped points)
     int *ref = reinterpret_cast<int *>(dep + 16 * Dp);                 // [Dp] byte offset of the COLUMN's row per bin, or kOut
-    unsigned char *flag = reinterpret_cast<unsigned char *>(ref + Dp); // [16][Dp] 0 dropped, 1 in the column's cell, 2 mismatch
-    float *gw0 = reinterpret_cast<float *>(flag + 16 * Dp);            // G tiles [16][CP], one per wave
+    unsigned *flag = reinterpret_cast<unsigned *>(ref + Dp);           // [Dp] bits [2 u, 2 u + 2) of a bin's word: row u is 0 dropped, 1 in the column's cell, 2 mismatch
+    float *gw0 = reinterpret_cast<float *>(flag + Dp);                 // (ONE word per bin: sixteen byte stores per thread kept the CU's LDS port busy -- twelve waves do phase A at once)
+    auto flag_of = [&](int row, int bin) __attribute__((always_inline)) { return (int)((flag[bin] >> (2 * row)) & 3u); };
     float *gw1 = gw0 + 16 * CP;
     float *gw = wave == 0 ? gw0 : gw1;
     __shared__ int nmis, nkept;
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
         unsigned o[16];
         unsigned m = kOut;
         if constexpr (CAM) {
-            const mmt_cam_column cc = mmt_cam_column_make(cm, cu, a.fd[bin < D ? bin : 0]);
+            // (the column's geometry is made only where it is used: with the forward's summary and a level camera nothing of it runs)
+            auto column = [&]() __attribute__((always_inline)) { return mmt_cam_column_make(cm, cu, a.fd[bin < D ? bin : 0]); };
             bool uniform, in0;
             int x0, y0;
             unsigned zmask;
@@ -191,15 +196,24 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
                 zmask = (unsigned)sv.y & 0xFFFFu;
                 uniform = __all((sv.y & mmt::kSummaryUniform) != 0);
             } else {
-                zmask = mmt_cam_column_cells<16>(cc, cv, nrow, cv_sorted, a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
+                zmask = mmt_cam_column_cells<16>(column(), cv, nrow, cv_sorted, a.q, a.nx, a.ny, a.nz, uniform, in0, x0, y0);
             }
             if (bin >= D) zmask = 0u;
             if (uniform) {
-                const unsigned oc = in0 ? (unsigned)(((int)(b * a.sb) + y0 * (int)a.sy + x0 * (int)a.sx) * 4) : kOut;
+                // every wave of a level camera comes here: the rows that pass z all sit in the column's cell -- nobody mismatches, and what
+                // the general tail below works out per row (sixteen offsets, comparisons, flags: 250 VALU operations a thread, with three
+                // waves per SIMD at it together 4 k cycles in the stamps) is a bit of zmask
+                const unsigned zm = in0 ? zmask : 0u;
+                ref[bin] = zm ? (int)(unsigned)(((int)(b * a.sb) + y0 * (int)a.sy + x0 * (int)a.sx) * 4) : (int)kOut;
+                unsigned fw = zm;                                   // bit u -> bits [2 u, 2 u + 2) = 1
+                fw = (fw | (fw << 8)) & 0x00FF00FFu; fw = (fw | (fw << 4)) & 0x0F0F0F0Fu; fw = (fw | (fw << 2)) & 0x33333333u; fw = (fw | (fw << 1)) & 0x55555555u;
+                flag[bin] = fw;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) o[u] = ((zmask >> u) & 1u) ? oc : kOut;
-                m = zmask ? oc : kOut;
+                for (int u = 0; u < 16; ++u) dep[u * Dp + bin] = ((zm >> u) & 1u) ? dv[u] : 0.f;
+                tkept += __popc(zm);
+                continue;
             } else {
+                const mmt_cam_column cc = column();
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     int x, y;
@@ -219,16 +233,19 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
         }
         ref[bin] = (int)m;
         int mis = 0, kept = 0;
+        unsigned fword = 0u;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int f = o[u] == kOut ? 0 : (o[u] == m ? 1 : 2);
-            flag[u * Dp + bin] = (unsigned char)f;
+            fword |= (unsigned)f << (2 * u);
             dep[u * Dp + bin] = f ? dv[u] : 0.f;
             mis += f == 2;
             kept += f != 0;
         }
+        flag[bin] = fword;
         tmis += mis; tkept += kept;
     }
+    COL_STAMP(7);
     {   // one LDS atomic per wave and counter (every lane adding to the same word is 64 serialised read-modify-writes)
         int pk = (tmis << 16) | tkept;                                  // (<= 7 * 16 points per lane, 64 lanes: 13 bits each)
 #pragma unroll
@@ -292,12 +309,12 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
         // grad_context partial [16 pixels x C]: K = the batch's 16 bins
         {
             const float *dA = dep + (lane & 15) * Dp + bb * kBins + (lane >> 4);
-            const unsigned char *fA = flag + (lane & 15) * Dp + bb * kBins + (lane >> 4);
+            const unsigned *fA = flag + bb * kBins + (lane >> 4);
             const float *gC = gw + (lane >> 4) * CP + (lane & 15);
             float av[4], cv[4][NT];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                av[j] = fA[4 * j] == 1 ? dA[4 * j] : 0.f;              // mismatches are left to the pass below
+                av[j] = ((fA[4 * j] >> (2 * (lane & 15))) & 3u) == 1u ? dA[4 * j] : 0.f;      // mismatches are left to the pass below
 #pragma unroll
                 for (int n = 0; n < NT; ++n) cv[j][n] = gC[4 * j * CP + 16 * n];
             }
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int prow = 4 * (lane >> 4) + i;
-                gw[prow * 20 + (lane & 15)] = flag[prow * Dp + bin] == 1 ? accD[i] + accD2[i] : 0.f;     // rows padded to 20 floats
+                gw[prow * 20 + (lane & 15)] = flag_of(prow, bin) == 1 ? accD[i] + accD2[i] : 0.f;     // rows padded to 20 floats
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int prow = 4 * (lane >> 4) + i;
-                const int f = flag[prow * Dp + bin];
+                const int f = flag_of(prow, bin);
                 if (prow < nrow && bin < D && f != 2)
                     st_scalar<FT>(grad_depth + tcol + prow * rstep + bin * dstep, f == 1 ? accD[i] + accD2[i] : 0.f);
             }
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(kColBlock) void lss_col_bwd(ColArgs a) {
             int cnt = 0;
             for (int d0 = 0; d0 < D; d0 += C4) {
                 const int bin = d0 + li;
-                const bool mm = act && bin < D && flag[prc * Dp + (bin < D ? bin : 0)] == 2;
+                const bool mm = act && bin < D && flag_of(prc, bin < D ? bin : 0) == 2;
                 const unsigned long long seg = (__ballot(mm) >> (g < G ? g * C4 : 0)) & gmask;
                 if (mm) klist[cnt + __popcll(seg & ((1ull << li) - 1ull))] = bin;
                 cnt += __popcll(seg);
@@ -486,7 +503,7 @@ int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx,
     a.span_bytes = (int)(span * 4);
     a.grad_depth = grad_depth; a.grad_context = grad_context;
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
-    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
+    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)Dp * 4 + (size_t)2 * 16 * (C + 4) * 4;
     const int64_t grid = 8ll * ((a.BN + 7) / 8) * fW * a.rblocks;
     mmt::TimedSeq seq;
     const dim3 g((unsigned)grid), blk(kColBlock);
@@ -509,7 +526,7 @@ namespace mmt {
 // true when the column kernel takes this shape (C in {64, 80, 128}; LDS within 64 KB; a gradient map below 1 GiB)
 bool lss_col_backward_fits(int D, int fH, int fW, int C, int64_t span, int64_t grid_units) {
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
-    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)16 * Dp + (size_t)2 * 16 * (C + 4) * 4;
+    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)Dp * 4 + (size_t)2 * 16 * (C + 4) * 4;
     const int C4 = C / 4, NGR = (kColBlock / 64) * (64 / C4);
     if (NGR * Dp + NGR * C4 > 16 * (C + 4)) return false;            // the lists of the mismatch pass live in wave 1's tile
     return (C == 64 || C == 80 || C == 128) && lds <= 64 * 1024 && span * 4 < (1ll << 30) && grid_units < (1ll << 28);

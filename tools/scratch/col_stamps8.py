@@ -38,7 +38,7 @@ for _ in range(4):
 torch.cuda.synchronize()
 s = gc.view(-1)[:nwg * 16].view(torch.int64).view(-1, 8).cpu()
 s = s[(s[:, 0] != 0) & (s[:, 2] != 0)]
-names = [("issue", 0, 3), ("arrive", 3, 4), ("cells+LDS", 4, 5), ("barrier", 5, 6), ("ctx operand", 6, 1), ("products", 1, 2), ("life", 0, 2)]
+names = [("issue", 0, 3), ("arrive", 3, 4), ("cells+dep stores", 4, 7), ("reduce+park", 7, 5), ("barrier", 5, 6), ("ctx operand", 6, 1), ("products", 1, 2), ("life", 0, 2)]
 for n, a, b in names:
     v = (s[:, b] - s[:, a]).float()
     print("%-12s mean %7.0f p50 %7.0f p90 %7.0f max %7.0f" % (n, v.mean(), v.median(), v.quantile(0.9), v.max()))
