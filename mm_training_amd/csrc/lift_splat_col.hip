@@ -259,11 +259,19 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
     COL_STAMP(5);
     __syncthreads();
     COL_STAMP(6);
-    float ctxA[C4];                       // Ctx[pixel = lane & 15][4 j + (lane >> 4)], in registers for the rest of the kernel
+    // Ctx[pixel = lane & 15][channel C4 * (lane >> 4) + j], in registers for the rest of the kernel.  The products sum over all
+    // channels, so which of them a (register, lane quarter) pair stands for is free as long as both operands agree: a quarter
+    // takes C4 CONSECUTIVE channels and both operands are read from LDS as 16-byte vectors (round 5: channel 4 j + quarter, a
+    // dword per read: 20 reads per operand and batch; the rows' stride of C + 4 floats keeps eight lanes' vectors on distinct banks)
+    static_assert(C4 % 4 == 0, "16-byte operand reads");
+    float ctxA[C4];
     {
         const int prow = lane & 15;
 #pragma unroll
-        for (int j = 0; j < C4; ++j) ctxA[j] = prow < nrow ? gw0[prow * CP + 4 * j + (lane >> 4)] : 0.f;
+        for (int j = 0; j < C4; j += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(gw0 + prow * CP + C4 * (lane >> 4) + j);
+            ctxA[j] = prow < nrow ? v.x : 0.f; ctxA[j + 1] = prow < nrow ? v.y : 0.f; ctxA[j + 2] = prow < nrow ? v.z : 0.f; ctxA[j + 3] = prow < nrow ? v.w : 0.f;
+        }
     }
     __syncthreads();                      // wave 0 stages its first G tile into gw0 next
     COL_STAMP(1);
@@ -293,72 +301,76 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (bb + kColBlock / 64 < nb) fetch(bb + kColBlock / 64);       // the next batch's rows are on their way during the MFMAs
-        // grad_depth tile [16 pixels x 16 bins]: K = C.  B operands first (registers), then the MFMAs back to back
+        // grad_depth tile, TRANSPOSED [16 bins x 16 pixels] = G [16 x C] * Ctx^T: K = C.  The operands of the two matrices have the same
+        // lane layout (row / column = lane & 15, k = lane >> 4), so which one is "A" is free -- and with the bins as rows a lane ends
+        // up with four consecutive BINS of one pixel: its 16 bytes of grad_depth, without the turn through LDS round 5 made
+        // (4 LDS writes, a read and two wave barriers per batch).  Same products, same k order: the same bits.
         f32x4 accD = {0.f, 0.f, 0.f, 0.f}, accD2 = {0.f, 0.f, 0.f, 0.f};
         {
-            const float *gB = gw + (lane & 15) * CP + (lane >> 4);
+            const float *gB = gw + (lane & 15) * CP + C4 * (lane >> 4);
             float bv[C4];
 #pragma unroll
-            for (int j = 0; j < C4; ++j) bv[j] = gB[4 * j];
+            for (int j = 0; j < C4; j += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(gB + j);
+                bv[j] = v.x; bv[j + 1] = v.y; bv[j + 2] = v.z; bv[j + 3] = v.w;
+            }
 #pragma unroll
             for (int j = 0; j < C4; j += 2) {
-                accD = __builtin_amdgcn_mfma_f32_16x16x4f32(ctxA[j], bv[j], accD, 0, 0, 0);
-                accD2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ctxA[j + 1], bv[j + 1], accD2, 0, 0, 0);
+                accD = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], ctxA[j], accD, 0, 0, 0);
+                accD2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j + 1], ctxA[j + 1], accD2, 0, 0, 0);
             }
         }
         // grad_context partial [16 pixels x C]: K = the batch's 16 bins
         {
             const float *dA = dep + (lane & 15) * Dp + bb * kBins + (lane >> 4);
             const unsigned *fA = flag + bb * kBins + (lane >> 4);
-            const float *gC = gw + (lane >> 4) * CP + (lane & 15);
+            // N tile n of the product <-> channels: the tiles of a full group of four interleaved -- tile 4 g + i is channel
+            // 64 g + 4 (lane & 15) + i, so a lane reads its four tiles' B elements as ONE 16-byte vector --, a leftover tile
+            // (C = 80: the fifth) plain: channel 64 g + (lane & 15)
+            const float *gC = gw + (lane >> 4) * CP;
             float av[4], cv[4][NT];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 av[j] = ((fA[4 * j] >> (2 * (lane & 15))) & 3u) == 1u ? dA[4 * j] : 0.f;      // mismatches are left to the pass below
 #pragma unroll
-                for (int n = 0; n < NT; ++n) cv[j][n] = gC[4 * j * CP + 16 * n];
+                for (int g4 = 0; g4 < NT / 4; ++g4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(gC + 4 * j * CP + 64 * g4 + 4 * (lane & 15));
+                    cv[j][4 * g4] = v.x; cv[j][4 * g4 + 1] = v.y; cv[j][4 * g4 + 2] = v.z; cv[j][4 * g4 + 3] = v.w;
+                }
+#pragma unroll
+                for (int n = 4 * (NT / 4); n < NT; ++n) cv[j][n] = gC[4 * j * CP + 64 * (NT / 4) + 16 * (n - 4 * (NT / 4)) + (lane & 15)];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) accC[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cv[j][n], accC[n], 0, 0, 0);
         }
-        // grad_depth: the lane holds pixel 4 * (lane >> 4) + i, bin bb * 16 + (lane & 15) -- a dword per lane.  4-byte stores cost
-        // the fabric ~6x as much per byte as 16-byte ones (8.5 of this kernel's 23 us in an ablation build), so in the pixel-major
-        // order the tile is turned through LDS (its own G tile: the products are done with it) and leaves as ONE 16-byte store
-        // per lane: pixel lane >> 2, bins 4 * (lane & 3) .. + 3.  Mismatching elements are written as they come and
-        // overwritten by the pass below (after a workgroup barrier).
-        if (a.vec && bb * kBins + kBins <= D) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                             // every lane is done reading the tile
-            const int bin = bb * kBins + (lane & 15);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int prow = 4 * (lane >> 4) + i;
-                gw[prow * 20 + (lane & 15)] = flag_of(prow, bin) == 1 ? accD[i] + accD2[i] : 0.f;     // rows padded to 20 floats
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int prow = lane >> 2, b4 = 4 * (lane & 3);
-            if (prow < nrow) {
-                const float4 v4 = *reinterpret_cast<const float4 *>(gw + prow * 20 + b4);
-                FT *dst = grad_depth + tcol + prow * rstep + (bb * kBins + b4);
-                if constexpr (sizeof(FT) == 2) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(v4.x, v4.y); pk.y = pack_bf16x2(v4.z, v4.w);
-                    *reinterpret_cast<uint2 *>(dst) = pk;
-                } else {
-                    *reinterpret_cast<float4 *>(dst) = v4;
+        // grad_depth: the lane holds pixel lane & 15, bins bb * 16 + 4 * (lane >> 4) .. + 3: one 16-byte (bf16: 8-byte) store in the
+        // pixel-major order (4-byte stores cost the fabric ~6x as much per byte: 8.5 of this kernel's 23 us in a round-2 ablation
+        // build).  Mismatching elements are written as they come and overwritten by the pass below (after a workgroup barrier).
+        {
+            const int prow = lane & 15, b4 = bb * kBins + 4 * (lane >> 4);
+            const uint4 fw = *reinterpret_cast<const uint4 *>(flag + b4);        // the four bins' flag words (b4 is a multiple of 4)
+            const unsigned sh = 2u * prow;
+            const int f0 = (int)((fw.x >> sh) & 3u), f1 = (int)((fw.y >> sh) & 3u), f2 = (int)((fw.z >> sh) & 3u), f3 = (int)((fw.w >> sh) & 3u);
+            const float v0 = f0 == 1 ? accD[0] + accD2[0] : 0.f, v1 = f1 == 1 ? accD[1] + accD2[1] : 0.f;
+            const float v2 = f2 == 1 ? accD[2] + accD2[2] : 0.f, v3 = f3 == 1 ? accD[3] + accD2[3] : 0.f;
+            if (a.vec && bb * kBins + kBins <= D) {
+                if (prow < nrow) {
+                    FT *dst = grad_depth + tcol + prow * rstep + b4;
+                    if constexpr (sizeof(FT) == 2) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v0, v1); pk.y = pack_bf16x2(v2, v3);
+                        *reinterpret_cast<uint2 *>(dst) = pk;
+                    } else {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
+                    }
                 }
-            }
-        } else {
-            const int bin = bb * kBins + (lane & 15);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int prow = 4 * (lane >> 4) + i;
-                const int f = flag_of(prow, bin);
-                if (prow < nrow && bin < D && f != 2)
-                    st_scalar<FT>(grad_depth + tcol + prow * rstep + bin * dstep, f == 1 ? accD[i] + accD2[i] : 0.f);
+            } else if (prow < nrow) {
+                if (b4 < D && f0 != 2) st_scalar<FT>(grad_depth + tcol + prow * rstep + (int64_t)b4 * dstep, v0);
+                if (b4 + 1 < D && f1 != 2) st_scalar<FT>(grad_depth + tcol + prow * rstep + (int64_t)(b4 + 1) * dstep, v1);
+                if (b4 + 2 < D && f2 != 2) st_scalar<FT>(grad_depth + tcol + prow * rstep + (int64_t)(b4 + 2) * dstep, v2);
+                if (b4 + 3 < D && f3 != 2) st_scalar<FT>(grad_depth + tcol + prow * rstep + (int64_t)(b4 + 3) * dstep, v3);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -367,9 +379,14 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
     COL_STAMP(2);
     // ---- grad_context: the two waves' partial sums meet in LDS
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int i = 0; i < 4; ++i) {
+        float *row = gw + (4 * (lane >> 4) + i) * CP;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gw[(4 * (lane >> 4) + i) * CP + 16 * n + (lane & 15)] = accC[n][i];
+        for (int g4 = 0; g4 < NT / 4; ++g4)
+            *reinterpret_cast<float4 *>(row + 64 * g4 + 4 * (lane & 15)) = make_float4(accC[4 * g4][i], accC[4 * g4 + 1][i], accC[4 * g4 + 2][i], accC[4 * g4 + 3][i]);
+#pragma unroll
+        for (int n = 4 * (NT / 4); n < NT; ++n) row[64 * (NT / 4) + 16 * (n - 4 * (NT / 4)) + (lane & 15)] = accC[n][i];
+    }
     __syncthreads();
     float *sum = gw0;                                                    // wave 0's tile becomes the total
     for (int e = tid; e < 16 * C4; e += kColBlock) {
