@@ -33,7 +33,7 @@ extern "C" {
  *    grad_output that spans 2 GiB or more; mmt_timing_* / mmt_arm_kernel_timing (measurement support)
  * 4: mmt_hard_voxelize_mean (+ table / scratch sizes), bf16 storage entry points (*_bf16), kernel timing accepted
  *    by the lift-splat, voxelize, VFE and pillar-scatter entry points as well */
-#define MMT_ABI_VERSION 14  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
+#define MMT_ABI_VERSION 15  /* 10: the plan form of the fused lift-splat forward (mmt_lss_plan_*, mmt_lss_splat_forward_plan*); additive
                              * 11: region-owner voxelizer -- mmt_voxelize_table_elems / _scratch_elems / _workspace_elems take the point
                              *     count / max_points as well; the table needs no zero fill and holds a cell directory
                              * 12: mmt_clip_adamw_step takes bf16_shadow_ptrs (may be NULL); mmt_channel_blocks_split / _gather;
@@ -42,7 +42,9 @@ extern "C" {
                              * 13: mmt_dcn_forward / mmt_dcn_backward (+ _supported / _workspace_bytes): the deformable convolution as implicit
                              *     GEMMs on the fp32 matrix cores, no column buffer; additive
                              * 14: mmt_lss_plan_prepare is ONE launch with a fast path for batches seen before;
-                             *     mmt_depth_softmax_forward_plan_prepare (the lookup rides in the depth softmax's launch); additive */
+                             *     mmt_depth_softmax_forward_plan_prepare (the lookup rides in the depth softmax's launch); additive
+                             * 15: mmt_voxelize_fused_launch (the cells + owner passes of the voxelizer as one launch: opt-in); the plan form's
+                             *     job records carry a depth window per pair (3168 bytes; plan caches of ABI 14 are rebuilt); additive */
 
 #define MMT_OK 0
 #define MMT_ERR_NULL_POINTER (-1)
@@ -573,6 +575,13 @@ int mmt_lift_splat_backward_bf16(int B, int N, int D, int HW, int C, int num_vox
  * workspace: int32, at least mmt_voxelize_workspace_elems(...) elements (device), any contents (table + scratch of
  * mmt_hard_voxelize_mean below in one buffer: every word the kernels read is written by them first). */
 int64_t mmt_voxelize_workspace_elems(int batch_size, int64_t total_points, const int32_t *grid_host, int max_points);
+/* The cells pass and the region-owner pass of the voxelizer as ONE launch (the owners wait, inside the launch, for their
+ * sample's cells workgroups: write-through stores + a token word per workgroup, no fences): two launches per voxelization
+ * instead of three, same outputs bit for bit.  OFF by default -- on MI355X the hand-off inside the launch costs more than
+ * the kernel boundary it replaces (24.3 against 23.1 us at 4 x 40 k points).  on: 0 / 1 sets it for every
+ * later call of this process (also: MMT_VOX_FUSED=1 in the environment), < 0 only asks; returns the previous setting.
+ * Replaces nothing in the reference (models/bev_depth.py:181 calls mmcv's op); a measurement knob. */
+int mmt_voxelize_fused_launch(int on);
 int mmt_hard_voxelize(int batch_size, int64_t total_points, int num_features,
                       const float *points, const int32_t *point_offsets,
                       const float *voxel_size_host, const float *range_min_host,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mmt_dcn_forward": (_c_int, [_c_int] * 6 + [_c_ptr] * 5 + [_c_i64, _c_int, _c_ptr]),
     "mmt_dcn_backward": (_c_int, [_c_int] * 6 + [_c_ptr] * 8 + [_c_i64, _c_ptr]),
     "mmt_voxelize_workspace_elems": (_c_i64, [_c_int, _c_i64, _c_ptr, _c_int]),
+    "mmt_voxelize_fused_launch": (_c_int, [_c_int]),
     "mmt_voxelize_table_elems": (_c_i64, [_c_int, _c_ptr, _c_i64]),
     "mmt_voxelize_scratch_elems": (_c_i64, [_c_int, _c_ptr, _c_i64, _c_int]),
     "mmt_hard_voxelize_mean": (_c_int, [_c_int, _c_i64, _c_int] + [_c_ptr] * 5 + [_c_int, _c_int, _c_int] + [_c_ptr] * 7 + [_c_ptr]),

@@ -33,6 +33,9 @@
 //              Rows past a sample's voxel count are marked empty (coors -1, num_points 0, mean 0) by the same kernel.
 // The workgroups of a sample's regions sit on 8 / B XCDs (B | 8) or one (8 | B): what they all read is fetched into
 // that many L2s, not eight.
+#include <stdlib.h>
+#include <atomic>
+
 #include "mmt_common.h"
 
 namespace {
@@ -47,6 +50,8 @@ constexpr int kStreamDepth = 10;      // 16-byte loads of region ids in flight p
                                       // 20 measured the same at 2 x 80 k points)
 constexpr int kSlowChunk = kTile * 8; // points per step when a batch has to be done again step by step (vox_own)
 constexpr int kMinRegion = 1024, kMaxRegion = 4096;
+constexpr int kCellTile = 1024;       // points per cells workgroup of the fused cells + own launch
+constexpr int kSc1 = 16;              // cache policy of a buffer load / store: sc1 (write-through / not served from this CU's L1)
 constexpr int kTableMagic = 0x32584f56;   // "VOX2": the table holds a cell directory of the region-owner form
 
 // the cell directory inside the caller's table (int32 units from its start; the table is 8-byte aligned)
@@ -93,6 +98,8 @@ struct VoxArgs {
     int32_t *head_of;
     int32_t *vidp;
     int ntiles;
+    unsigned *cdone;               // fused cells + own launch: [ceil(N / kCellTile) + B] a cells workgroup's word = the launch's token when its bytes are out
+    unsigned *epoch;               // the word the launch's token is made of (epoch + 1); vox_emit, the next launch, advances it
     unsigned long long *stamps;    // -DVOX_STAMPS builds only (tools/scratch/vox_stamps.py): phase time stamps of the first 1024 workgroups
     float *voxels;                 // may be NULL (only the mean is wanted)
     int32_t *coors;
@@ -206,9 +213,98 @@ __device__ __forceinline__ unsigned match_halves(unsigned w, unsigned rr) {
     return ~(((x & 0x7fff7fffu) + 0x7fff7fffu) | x) & 0x80008000u;
 }
 
-// LDS: head [R] | cur [R] | eidx [kEntries] | enext [kEntries] | filled (u8) [R]
+// ---- the fused cells + own launch (round 6) -------------------------------------------------------------------------------
+// vox_cells and vox_own as ONE launch: the first workgroups do the cells pass -- a workgroup per (sample, tile of kCellTile
+// points) --, the ones behind them are the region owners.  An owner needs the region bytes and cell positions of its whole
+// sample; it sets up its LDS while the cells workgroups of its sample work, then waits for them: every cells workgroup
+// writes its bytes with write-through (sc1) 16-byte stores, drains them (vmcnt(0) in every storing wave, then the
+// workgroup's barrier) and leaves the launch's token in a word of its own; an owner's first wave polls its sample's words
+// with sc1 loads, the workgroup's barrier releases the other waves, and every load of the handed-over bytes is an sc1
+// load (MI355X_MICROARCH.md, "Inter-workgroup visibility": flag per storing workgroup, sc1 on both sides, no fences).
+// Workgroups are dispatched in index order and an owner only waits for workgroups in front of it, so the wait ends whatever
+// the residency is; it is bounded all the same (a wait that runs out leaves the header without its magic: the table is
+// refused by everything that reads it).  The token is the value of a word in the scratch + 1, advanced by vox_emit -- the
+// launch behind this one -- so a captured graph replays with fresh tokens, and whatever an uninitialised scratch holds
+// cannot look "done" unless a word happens to hold exactly the token.
+__device__ __forceinline__ int cell_tiles(int n) { const int t = (n + kCellTile - 1) / kCellTile; return t > 0 ? t : 1; }
+
+// first cells workgroup and number of cells workgroups of sample b (every wave for itself, same answer)
+__device__ __forceinline__ void cells_range(const int32_t *offsets, int B, int b, int *first_out, int *count_out) {
+    const int lane = threadIdx.x & 63;
+    int first = 0, count = 1;
+    for (int b0 = 0; b0 <= b; b0 += 64) {
+        const int s = b0 + lane;
+        const int n = s < B ? offsets[s + 1] - offsets[s] : 0;
+        const int t = s < B && s <= b ? cell_tiles(n) : 0;
+        const int incl = wave_incl_scan(t);
+        if (b < b0 + 64) {
+            first += __builtin_amdgcn_readlane(incl - t, b - b0);
+            count = __builtin_amdgcn_readlane(t, b - b0);
+        } else first += __builtin_amdgcn_readlane(incl, 63);
+    }
+    *first_out = first; *count_out = count;
+}
+
+// LDS (the owners' dynamic block, free in a cells workgroup): region ids [kCellTile] RT | cell positions [kCellTile] u16
 template <typename RT>
-__global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
+__device__ __forceinline__ void cells_role(const VoxArgs &a, int B, int widx) {
+    extern __shared__ __align__(16) int lds[];
+    RT *l_reg = reinterpret_cast<RT *>(lds);
+    unsigned short *l_loc = reinterpret_cast<unsigned short *>(l_reg + kCellTile);
+    const unsigned token = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    // (sample, tile) of this workgroup: sample b owns cell_tiles(n_b) consecutive workgroups
+    int b = -1, tile = 0, beg = 0, n = 0;
+    {
+        int first = 0;
+        for (int s = 0; s < B; ++s) {              // (B is small; the offsets are uniform: scalar loads)
+            const int o0 = a.offsets[s], ns = a.offsets[s + 1] - o0, t = cell_tiles(ns);
+            if (widx < first + t) { b = s; tile = widx - first; beg = o0; n = ns; break; }
+            first += t;
+        }
+    }
+    if (b < 0) return;
+    const int p0 = tile * kCellTile;
+    const int npad = (n + 15) & ~15;               // the sample's slice is filled up to its 16-element boundary: no region, not a head
+    const int m = npad - p0 < kCellTile ? npad - p0 : kCellTile;        // elements this workgroup leaves (a multiple of 16; 0 for an empty sample)
+#pragma unroll
+    for (int it = 0; it < kCellTile / kTile; ++it) {
+        const int k = it * kTile + threadIdx.x, i = p0 + k;
+        unsigned r = ~0u, loc = 0;
+        if (i < n) {
+            const float *p = a.points + (int64_t)(beg + i) * a.F;
+            const int cx = cell_coord(p[0], a.rmin[0], a.vs[0]);
+            const int cy = cell_coord(p[1], a.rmin[1], a.vs[1]);
+            const int cz = cell_coord(p[2], a.rmin[2], a.vs[2]);
+            if (!(cx < 0 || cx >= a.gx || cy < 0 || cy >= a.gy || cz < 0 || cz >= a.gz)) {
+                const int cell = (cz * a.gy + cy) * a.gx + cx;
+                r = (unsigned)cell >> a.shift;
+                loc = (unsigned)cell & (unsigned)(a.R - 1);
+            }
+        }
+        l_reg[k] = (RT)r;
+        l_loc[k] = (unsigned short)loc;
+    }
+    __syncthreads();
+    // out as 16-byte write-through stores: region ids, cell positions, zeroed count bytes
+    const int64_t f0 = flag_base(beg, b) + p0;
+    const __amdgpu_buffer_rsrc_t rs_reg = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<RT *>(a.reg) + f0, 0, m * (int)sizeof(RT), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_loc = __builtin_amdgcn_make_buffer_rsrc(a.cloc + f0, 0, m * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_flg = __builtin_amdgcn_make_buffer_rsrc(a.flag + f0, 0, m, 0x00020000);
+    const mmt_u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int c = threadIdx.x; c < m * (int)sizeof(RT) / 16; c += kTile)
+        __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const mmt_u32x4 *>(l_reg)[c], rs_reg, c * 16, 0, kSc1);
+    for (int c = threadIdx.x; c < m * 2 / 16; c += kTile)
+        __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const mmt_u32x4 *>(l_loc)[c], rs_loc, c * 16, 0, kSc1);
+    for (int c = threadIdx.x; c < m / 16; c += kTile) __builtin_amdgcn_raw_buffer_store_b128(zero, rs_flg, c * 16, 0, kSc1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(a.cdone + widx, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS: head [R] | cur [R] | eidx [kEntries] | enext [kEntries] | filled (u8) [R]
+// FUSED: a region owner of the fused cells + own launch (waits for its sample's cells workgroups, reads what they left with sc1 loads)
+template <typename RT, bool FUSED>
+__device__ __forceinline__ void own_role(const VoxArgs &a, int B, int widx) {
     extern __shared__ __align__(16) int lds[];
     __shared__ int s_count, s_over;
     __shared__ int wpop[kMaxRegion / 64], wpre[kMaxRegion / 64];
@@ -224,21 +320,40 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
     VSTAMP(0);
     int b, r;
     {
-        const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int x = widx & 7, q = widx >> 3;
         if (B <= 8 && 8 % B == 0) { const int xps = 8 / B; b = x / xps; r = q * xps + x % xps; }
         else if (B % 8 == 0) { const int per = B / 8; b = x + 8 * (q % per); r = q / per; }
-        else { b = blockIdx.x / a.NR; r = blockIdx.x - b * a.NR; }
+        else { b = widx / a.NR; r = widx - b * a.NR; }
         if (b >= B || r >= a.NR) return;
     }
     const int beg = a.offsets[b], n = a.offsets[b + 1] - beg;
     const int64_t fb = flag_base(beg, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npad_ = (n + 15) & ~15;
+    // (fused launch: the sample's region ids and cell positions through buffer descriptors -- sc1 loads)
+    const __amdgpu_buffer_rsrc_t rs_reg = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<RT *>(a.reg) + fb, 0, npad_ * (int)sizeof(RT), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cloc = __builtin_amdgcn_make_buffer_rsrc(a.cloc + fb, 0, npad_ * 2, 0x00020000);
     for (int c = threadIdx.x * 4; c < R; c += kTile * 4) {         // (16-byte LDS stores; R is a multiple of 1024)
         *reinterpret_cast<int4 *>(head + c) = make_int4(kInf, kInf, kInf, kInf);
         *reinterpret_cast<int4 *>(cur + c) = make_int4(kInf, kInf, kInf, kInf);
         *reinterpret_cast<int *>(filled + c) = 0;
     }
     if (threadIdx.x == 0) { s_count = 0; s_over = 0; }
+    if (FUSED && wave == 0) {
+        // the sample's cells workgroups: all of their words must hold this launch's token
+        const unsigned token = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        int first, count;
+        cells_range(a.offsets, B, b, &first, &count);
+        int spins = 0;
+        for (int c0 = 0; c0 < count; c0 += 64) {
+            const unsigned *w = a.cdone + first + (c0 + lane < count ? c0 + lane : count - 1);
+            while (!__all(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token)) {
+                if (++spins > (1 << 20)) break;                    // (~0.1 s: never met; the table is left without its magic)
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (spins > (1 << 20) && lane == 0) a.header[1] = (int32_t)(token ^ 0xDEADDEADu);      // vox_emit does not sign a table that carries this launch's mark
+    }
     __syncthreads();
 
     VSTAMP(1);
@@ -254,7 +369,10 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
 #pragma unroll
         for (int j = 0; j < kPer; ++j) idx[j] = j * kTile + threadIdx.x < count ? eidx[j * kTile + threadIdx.x] : -1;
 #pragma unroll
-        for (int j = 0; j < kPer; ++j) cl[j] = (int)a.cloc[fb + (idx[j] >= 0 ? idx[j] : 0)];        // (unconditional: one round trip for all)
+        for (int j = 0; j < kPer; ++j) {                             // (unconditional: one round trip for all)
+            if (FUSED) cl[j] = (int)__builtin_amdgcn_raw_buffer_load_b16(rs_cloc, (unsigned)(idx[j] >= 0 ? idx[j] : 0) * 2u, 0, kSc1);
+            else cl[j] = (int)a.cloc[fb + (idx[j] >= 0 ? idx[j] : 0)];
+        }
         VSTAMP(5);
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
@@ -321,7 +439,10 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
 #pragma unroll
             for (int u = 0; u < kDepth; ++u) {               // unconditional loads (clamped address): all in flight together
                 const int p = base + u * kChunk + threadIdx.x * kPts;
-                v[u] = *reinterpret_cast<const uint4 *>(reg + (p < npad ? p : npad - kPts));
+                if (FUSED) {
+                    const mmt_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs_reg, (unsigned)(p < npad ? p : npad - kPts) * (unsigned)sizeof(RT), 0, kSc1);
+                    v[u] = make_uint4(q.x, q.y, q.z, q.w);
+                } else v[u] = *reinterpret_cast<const uint4 *>(reg + (p < npad ? p : npad - kPts));
             }
 #pragma unroll
             for (int u = 0; u < kDepth; ++u) {
@@ -380,10 +501,14 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
                 if (p >= npad) continue;                           // (no barrier below)
                 unsigned v[kWide ? 4 : 2];
                 if (kWide) {
-                    const uint4 q = *reinterpret_cast<const uint4 *>(reg + p);
+                    uint4 q;
+                    if (FUSED) { const mmt_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_reg, (unsigned)p * 2u, 0, kSc1); q = make_uint4(t.x, t.y, t.z, t.w); }
+                    else q = *reinterpret_cast<const uint4 *>(reg + p);
                     v[0] = q.x; v[1] = q.y; v[kWide ? 2 : 0] = q.z; v[kWide ? 3 : 1] = q.w;
                 } else {
-                    const uint2 q = *reinterpret_cast<const uint2 *>(reg + p);
+                    uint2 q;
+                    if (FUSED) { typedef unsigned u32x2 __attribute__((ext_vector_type(2))); const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_reg, (unsigned)p, 0, kSc1); q = make_uint2(t.x, t.y); }
+                    else q = *reinterpret_cast<const uint2 *>(reg + p);
                     v[0] = q.x; v[1] = q.y;
                 }
 #pragma unroll
@@ -484,6 +609,16 @@ __global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) {
     VSTAMP(4);
 }
 
+template <typename RT>
+__global__ __launch_bounds__(kTile) void vox_own(VoxArgs a, int B) { own_role<RT, false>(a, B, (int)blockIdx.x); }
+
+// the first ncells workgroups do the cells pass, the rest are the region owners
+template <typename RT>
+__global__ __launch_bounds__(kTile) void vox_cells_own(VoxArgs a, int B, int ncells) {
+    if ((int)blockIdx.x < ncells) cells_role<RT>(a, B, (int)blockIdx.x);
+    else own_role<RT, true>(a, B, (int)blockIdx.x - ncells);
+}
+
 // nonzero bytes of a dword of count bytes (each < 128: max_points <= 127), added to acc
 __device__ __forceinline__ int nonzero_bytes(unsigned v, int acc) { return acc + __popc((v + 0x7f7f7f7fu) & 0x80808080u); }
 
@@ -509,7 +644,13 @@ __global__ __launch_bounds__(kTile) void vox_emit(VoxArgs a, int B) {
     const int my_tiles = (n + kTile - 1) / kTile;
     const int64_t fb = flag_base(beg, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.header[0] = kTableMagic;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the fused cells + own launch in front of this one made its token of *epoch + 1: sign the table unless an owner gave up
+        // waiting (own_role), and advance the word for the next voxelization (a captured graph replays with fresh tokens)
+        const unsigned e = *a.epoch;
+        a.header[0] = (unsigned)a.header[1] == ((e + 1u) ^ 0xDEADDEADu) ? 0 : kTableMagic;
+        *a.epoch = e + 1u;
+    }
 
     // this point's count byte and cell: requested together with the stream of the sample's count bytes
     const int i = tile * kTile + threadIdx.x;
@@ -827,6 +968,7 @@ namespace {
 unsigned long long *g_vox_stamps = nullptr;
 #endif
 int64_t vox_tiles(int64_t N) { return mmt::ceil_div(N > 0 ? N : 1, kTile); }
+std::atomic<int> g_vox_fused{[] { const char *e = getenv("MMT_VOX_FUSED"); return e && atoi(e) != 0 ? 1 : 0; }()};
 
 int vox_check(const char *what, int B, int64_t N, int F, const int32_t *grid_host, int max_points, int max_voxels, int nf) {
     if (B <= 0 || B > 65535 || N < 0 || F < 3 || max_points <= 0 || max_points > 127 || max_voxels <= 0 || nf < 0 || nf > F)
@@ -847,7 +989,7 @@ int64_t align4(int64_t ints) { return (ints + 3) & ~(int64_t)3; }
 
 // scratch (int32 units; every part starts on a 16-byte boundary of the aligned base): lists | region ids | cell positions | count bytes
 constexpr int64_t kMaxTcumTiles = 2 * kEntries - 1;            // vox_own's tile histogram lives in the list's LDS (2 x kEntries ints)
-struct ScratchLayout { int64_t lists, reg, cloc, flag, tcum, elems; };
+struct ScratchLayout { int64_t lists, reg, cloc, flag, tcum, cdone, elems; };
 ScratchLayout scratch_layout(int B, int64_t N, int max_points, bool wide, int NR) {
     ScratchLayout l;
     const int64_t slots = N + 32 * (int64_t)B + 32;          // flag positions (flag_base: every sample's slice 16-byte aligned)
@@ -856,7 +998,8 @@ ScratchLayout scratch_layout(int B, int64_t N, int max_points, bool wide, int NR
     l.cloc = l.reg + align4(mmt::ceil_div(slots * (wide ? 2 : 1), 4));
     l.flag = l.cloc + align4(mmt::ceil_div(slots * 2, 4));
     l.tcum = l.flag + align4(mmt::ceil_div(slots, 4));
-    l.elems = l.tcum + align4(mmt::ceil_div((int64_t)B * (vox_tiles(N) + 1) * NR, 2)) + 4;  // + 4: the base is aligned up to 16 bytes
+    l.cdone = l.tcum + align4(mmt::ceil_div((int64_t)B * (vox_tiles(N) + 1) * NR, 2));       // [0]: the epoch word; [4 ..]: the cells workgroups' words
+    l.elems = l.cdone + align4(4 + mmt::ceil_div(N > 0 ? N : 1, kCellTile) + B) + 4;          // + 4: the base is aligned up to 16 bytes
     return l;
 }
 
@@ -890,6 +1033,8 @@ int vox_run(const char *what, int B, int64_t N, int F, const float *points, cons
     a.cloc = reinterpret_cast<unsigned short *>(base + l.cloc);
     a.flag = reinterpret_cast<unsigned char *>(base + l.flag);
     a.tcum = vox_tiles(N) <= kMaxTcumTiles ? reinterpret_cast<unsigned short *>(base + l.tcum) : nullptr;
+    a.epoch = reinterpret_cast<unsigned *>(base + l.cdone);
+    a.cdone = a.epoch + 4;
     a.voxels = voxels; a.coors = coors; a.num_points = num_points; a.voxel_count = voxel_count; a.mean = mean;
     mmt::TimedSeq seq;   // armed by mmt_arm_kernel_timing (bench only)
     const unsigned gpts = (unsigned)mmt::stream_grid(N > 0 ? N : 1, kTile, 4096);
@@ -898,7 +1043,12 @@ int vox_run(const char *what, int B, int64_t N, int F, const float *points, cons
     unsigned gown = (unsigned)((int64_t)B * d.NR);
     if (B <= 8 && 8 % B == 0) gown = 8u * (unsigned)mmt::ceil_div(d.NR, 8 / B);
     const size_t lds_own = (size_t)d.R * 9 + (size_t)kEntries * 8;
-    if (a.wide) {
+    const bool fused = g_vox_fused.load(std::memory_order_relaxed) != 0;      // (off by default: measured slower than the three launches, see mmt_voxelize_fused_launch)
+    const int ncells = (int)(mmt::ceil_div(N > 0 ? N : 1, kCellTile) + B);       // cells workgroups of the fused launch: sample b has max(ceil(n_b / kCellTile), 1)
+    if (fused) {
+        if (a.wide) seq.launch(false, vox_cells_own<unsigned short>, dim3(ncells + gown), dim3(kTile), lds_own, st, a, B, ncells);
+        else seq.launch(false, vox_cells_own<unsigned char>, dim3(ncells + gown), dim3(kTile), lds_own, st, a, B, ncells);
+    } else if (a.wide) {
         seq.launch(false, vox_cells<unsigned short>, dim3(gpts), dim3(kTile), 0, st, a, B, (int)N);
         seq.launch(false, vox_own<unsigned short>, dim3(gown), dim3(kTile), lds_own, st, a, B);
     } else {
@@ -918,6 +1068,11 @@ int vox_run(const char *what, int B, int64_t N, int F, const float *points, cons
 #ifdef VOX_STAMPS
 extern "C" int mmt_vox_debug_stamps(unsigned long long *host) { if (!g_vox_stamps) return 1; (void)hipDeviceSynchronize(); return (int)hipMemcpy(host, g_vox_stamps, 1024 * 16 * 8, hipMemcpyDeviceToHost); }
 #endif
+
+extern "C" int mmt_voxelize_fused_launch(int on) {
+    if (on < 0) return g_vox_fused.load(std::memory_order_relaxed);
+    return g_vox_fused.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
 
 extern "C" int64_t mmt_voxelize_table_elems(int B, const int32_t *grid, int64_t total_points) {
     if (B <= 0 || grid == nullptr || total_points < 0) return 0;

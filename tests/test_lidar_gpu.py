@@ -132,6 +132,33 @@ def test_voxelize_region_owner_paths(mmt_lib, oracle_mod):
     _check(oracle_mod, [pts[:50000]], 100, 40)                                         # max_points above the usual, voxel cap inside the packed region
 
 
+def test_voxelize_fused_cells_and_owner_launch(mmt_lib, oracle_mod):
+    """mmt_voxelize_fused_launch(1): the cells pass and the region owners in ONE launch (the owners wait for their sample's cells
+    workgroups inside the launch; opt-in, measured slower than the kernel boundary it replaces).  Same outputs bit for bit
+    against the oracle on the shapes that exercise the hand-off: the BASELINE batch, ragged / empty samples (an empty sample
+    still owns a cells workgroup), clouds of several cells workgroups and streaming batches, 16-bit region ids, a cloud
+    packed into one region -- twice over, so the second round runs on the first one's tokens."""
+    lib = mmt_lib.lib()
+    before = lib.mmt_voxelize_fused_launch(1)
+    try:
+        assert lib.mmt_voxelize_fused_launch(-1) == 1
+        wide = [-204.8, -64.0, -5.0, 204.8, 64.0, 3.0]
+        for _ in range(2):
+            _check(oracle_mod, _frames([40000] * 4), 15, 25000)
+            _check(oracle_mod, _frames([1000, 0, 777, 1, 0, 2049], seed=11), 15, 25000)
+            _check(oracle_mod, _frames([100000, 50001], seed=42), 15, 25000)
+            _check(oracle_mod, _frames([30000, 12000], rng_range=wide, seed=41), 15, 25000, rng=wide)
+            g = torch.Generator().manual_seed(43)
+            pts = torch.rand(90000, 5, generator=g)
+            pts[:, 0] = 3.0 + pts[:, 0] * 6.0
+            pts[:, 1] = 1.0 + pts[:, 1] * 0.4
+            pts[:, 2] = pts[:, 2] * 6 - 4
+            _check(oracle_mod, [pts, _frames([7000], seed=44)[0]], 15, 25000)
+    finally:
+        lib.mmt_voxelize_fused_launch(before)
+    assert lib.mmt_voxelize_fused_launch(-1) == before
+
+
 def test_voxelize_boundaries_and_nonfinite(mmt_lib, oracle_mod):
     pts = torch.zeros(64, 5)
     edge = [RANGE[0], RANGE[0] - 1e-4, RANGE[3], RANGE[3] - 1e-4, 0.0, 0.2, 0.19999, -0.0]

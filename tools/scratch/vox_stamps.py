@@ -17,7 +17,8 @@ st = buf.reshape(1024, 16).astype(np.int64)
 def rep(name, a, b, rows):
     d = (st[rows, b] - st[rows, a]) * 10.0 / 1000.0   # 100 MHz -> us
     print(f"{name}: mean {d.mean():.2f} us  max {d.max():.2f}  min {d.min():.2f}")
-own = slice(0, 512)
+o0 = int(os.environ.get("VOX_OWN_ROW0", "0"))      # fused cells + own launch: the owners follow the cells workgroups (ceil(N / 1024) + B of them)
+own = slice(o0, o0 + 512)
 t0 = st[own, 0].min()
 print("own: first start..last end", (st[own, 4].max() - t0) / 100.0, "us; start spread", (st[own, 0].max() - t0) / 100.0)
 rep("own init (offsets, LDS init)", 0, 1, own)
