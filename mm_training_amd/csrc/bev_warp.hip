@@ -47,18 +47,40 @@ __device__ __forceinline__ void forward_affine(const float *bda, int H, int W, d
 }
 
 // one lane group of C/4 lanes per output cell
+// The samples' matrices are worked out ONCE per workgroup (thread b takes sample b: a dozen double operations and four double
+// divisions) and read from LDS: round 2 had every thread invert its sample's matrix itself -- some 150 instructions in
+// front of every 16-byte row piece, half of the forward's time and a third of the backward's (the kernels are VALU-bound).
+constexpr int kWarpMaxB = 64;          // samples whose matrices a workgroup keeps in LDS (more: every thread computes its own)
+
 __global__ __launch_bounds__(kBlock) void bev_warp_kernel(WarpArgs a) {
+    __shared__ double s_m[kWarpMaxB][6];
+    const bool shared = a.B <= kWarpMaxB;
+    if (shared && (int)threadIdx.x < a.B) {
+        double t[6];
+        inverse_affine(a.bda + threadIdx.x * 16, a.H, a.W, t);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_m[threadIdx.x][k] = t[k];
+    }
+    __syncthreads();
     const int C4 = a.C >> 2;
     const int64_t cells = (int64_t)a.B * a.H * a.W;
     const int64_t total = cells * C4;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t cell = i / C4;
-        const int c4 = (int)(i - cell * C4);
-        const int b = (int)(cell / ((int64_t)a.H * a.W));
-        const int rem = (int)(cell - (int64_t)b * a.H * a.W);
+        // (cell, piece) of the item: 32-bit divisions where the item count allows (a 64-bit division is ~150 instructions)
+        int64_t cell;
+        int c4, b, rem;
+        if (total < (1ll << 31)) {
+            const unsigned i32 = (unsigned)i, cell32 = i32 / (unsigned)C4, hw = (unsigned)(a.H * a.W);
+            c4 = (int)(i32 - cell32 * (unsigned)C4); b = (int)(cell32 / hw); rem = (int)(cell32 - (unsigned)b * hw); cell = cell32;
+        } else {
+            cell = i / C4; c4 = (int)(i - cell * C4); b = (int)(cell / ((int64_t)a.H * a.W)); rem = (int)(cell - (int64_t)b * a.H * a.W);
+        }
         const int v = rem / a.W, u = rem - v * a.W;
         double m[6];
-        inverse_affine(a.bda + b * 16, a.H, a.W, m);
+        if (shared) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = s_m[b][k];
+        } else inverse_affine(a.bda + b * 16, a.H, a.W, m);
         const float sx = (float)(m[0] * u + m[1] * v + m[2]);
         const float sy = (float)(m[3] * u + m[4] * v + m[5]);
         const float fx0 = floorf(sx), fy0 = floorf(sy);
@@ -89,20 +111,41 @@ __global__ __launch_bounds__(kBlock) void bev_warp_kernel(WarpArgs a) {
 // inside the training step, bound by the memory-side atomic units, and not reproducible.
 // a.x = grad of the warped map (row stride in_stride), a.y = grad of the source map (accumulated into).
 __global__ __launch_bounds__(kBlock) void bev_warp_backward_gather(WarpArgs a) {
+    __shared__ double s_m[kWarpMaxB][6], s_f[kWarpMaxB][6];
+    const bool shared = a.B <= kWarpMaxB;
+    if (shared && (int)threadIdx.x < a.B) {
+        double t[6];
+        inverse_affine(a.bda + threadIdx.x * 16, a.H, a.W, t);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_m[threadIdx.x][k] = t[k];
+        forward_affine(a.bda + threadIdx.x * 16, a.H, a.W, t);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_f[threadIdx.x][k] = t[k];
+    }
+    __syncthreads();
     const int C4 = a.C >> 2;
     const int64_t cells = (int64_t)a.B * a.H * a.W;
     const int64_t total = cells * C4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x), 0, (int)((cells - 1) * a.in_stride + a.C) * 4, 0x00020000);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t cell = i / C4;
-        const int c4 = (int)(i - cell * C4);
-        const int b = (int)(cell / ((int64_t)a.H * a.W));
-        const int rem = (int)(cell - (int64_t)b * a.H * a.W);
+        int64_t cell;
+        int c4, b, rem;
+        if (total < (1ll << 31)) {        // (32-bit divisions: see bev_warp_kernel)
+            const unsigned i32 = (unsigned)i, cell32 = i32 / (unsigned)C4, hw = (unsigned)(a.H * a.W);
+            c4 = (int)(i32 - cell32 * (unsigned)C4); b = (int)(cell32 / hw); rem = (int)(cell32 - (unsigned)b * hw); cell = cell32;
+        } else {
+            cell = i / C4; c4 = (int)(i - cell * C4); b = (int)(cell / ((int64_t)a.H * a.W)); rem = (int)(cell - (int64_t)b * a.H * a.W);
+        }
         const int ys = rem / a.W, xs = rem - ys * a.W;
         double m[6], f[6];
-        inverse_affine(a.bda + b * 16, a.H, a.W, m);
-        forward_affine(a.bda + b * 16, a.H, a.W, f);
+        if (shared) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { m[k] = s_m[b][k]; f[k] = s_f[b][k]; }
+        } else {
+            inverse_affine(a.bda + b * 16, a.H, a.W, m);
+            forward_affine(a.bda + b * 16, a.H, a.W, f);
+        }
         const double uc = f[0] * xs + f[1] * ys + f[2], vc = f[3] * xs + f[4] * ys + f[5];
         const double hu = fabs(f[0]) + fabs(f[1]) + 0.01, hv = fabs(f[3]) + fabs(f[4]) + 0.01;
         // non-finite matrices contribute nothing in the forward either (sx != sx / out of range)
