@@ -870,7 +870,7 @@ __global__ __launch_bounds__(kFwdThreads, (S <= 5 ? PLAN_FWD_WAVES : 1)) void ls
                 const RunRec *rr = runs + pr.run0;
                 uint2 mlo = *reinterpret_cast<const uint2 *>(&rr->wlo), mhi = *reinterpret_cast<const uint2 *>(&rr->whi);
                 int pslot = rr->pslot;
-#pragma unroll 1
+#pragma unroll 1     // (unrolled four times with early exits: 2 % faster at BASELINE configs[3], 6 % slower at configs[4])
                 for (int r = 0; r < pr.nruns; ++r) {
                     const unsigned t0 = mlo.x >> li, t1 = mlo.y >> li, t2 = mhi.x >> li, t3 = mhi.y >> li;
                     const int ps = pslot;

@@ -32,10 +32,10 @@ constexpr int kTileCells = kTile * kTile;
 #define PLAN_MAX_RUNS 96
 #endif
 #ifndef PLAN_MAX_PAIR_RUNS
-#define PLAN_MAX_PAIR_RUNS 8
+#define PLAN_MAX_PAIR_RUNS 4
 #endif
 constexpr int kMaxRuns = PLAN_MAX_RUNS;  // runs (= partial rows in LDS) per job (<= 255: a record's cell_begin is bytes)
-constexpr int kMaxPairRuns = PLAN_MAX_PAIR_RUNS;   // runs per pair record
+constexpr int kMaxPairRuns = PLAN_MAX_PAIR_RUNS;   // runs per pair record (4: a wave runs as long as the longest of its four pairs -- 6 / 8 / 12 measured 4 % slower at BASELINE configs[3])
 constexpr int kRunBins = 4;              // depth bins per run
 constexpr int kWindowBins = 8;           // depth bins a lane group loads per PAIR and image row (one 16-byte load in bf16, two in fp32): every run of
                                          // the pair takes its bins out of that window (round 5 loaded four bins per RUN: 2.3 runs per pair at BASELINE

@@ -13,7 +13,7 @@ _CORE = os.path.join(_HERE, "..", "mm_training_amd", "csrc", "lss_plan_core.h")
 _OUT = os.path.join(_HERE, "native", "_build", "libplanhost.so")
 
 UNIFORM = 0x10000
-MAX_RUNS, MAX_PAIR_RUNS, RUN_BINS, WINDOW_BINS, TILE = 96, 8, 4, 8, 8
+MAX_RUNS, MAX_PAIR_RUNS, RUN_BINS, WINDOW_BINS, TILE = 96, 4, 4, 8, 8
 HDR = np.dtype([("ncells", "<u2"), ("npairs", "<u2"), ("nruns", "<u2"), ("c0", "<u2"), ("tile", "<i4"), ("chain", "<u4")])
 CHAIN_HEAD, CHAIN_LINK, CHAIN_MORE = 1, 2, 4
 PAIR = np.dtype([("col", "<u2"), ("rb", "u1"), ("nruns", "u1"), ("run0", "<u2"), ("w0", "<u2")])
