@@ -25,6 +25,7 @@ constexpr unsigned kOut = 0x80000000u;          // row offset of a dropped point
 struct ColArgs {
     int BN, N, D, fH, fW, C, nx, ny, nz;
     int pm, rblocks;
+    int split, seg;               // column segments per camera, columns per segment (workgroup -> XCD balance, see the kernel)
     int vec;                      // grad_depth may leave as 16-byte (fp32) / 8-byte (bf16) vectors: pixel-major, D % 4 == 0, aligned
     const int32_t *geom;          // geom form; camera form (template CAM): the cell comes from the matrix (mmt_camera.h)
     const float *combine, *fu, *fv, *fd;
@@ -73,12 +74,19 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
     extern __shared__ __align__(16) unsigned char col_lds[];
     constexpr int C = 16 * NT, C4 = C / 4, CP = C + 4;
     constexpr int NV = (16 * C4) / 64;                       // 16-byte vectors of a G tile per lane
+    // Workgroup -> (camera, column, row block).  Workgroup i runs on XCD i % 8; a camera's neighbouring columns read neighbouring
+    // gradient rows, so they share an XCD -- but the XCDs must also carry the same number of workgroups: with BN cameras dealt
+    // whole, BASELINE configs[4] (12 cameras) put two cameras on four XCDs and one on the other four (352 against 176 workgroups;
+    // the kernel lasted as long as the loaded half).  A camera is cut into `split` segments of columns so that the units
+    // (camera, segment) are a multiple of 8 wherever that is possible: 12 cameras -> 24 half cameras, three per XCD.
     const int L = blockIdx.x, xcd = L & 7, i0 = L >> 3;
-    const int per = a.fW * a.rblocks;
+    const int per = a.seg * a.rblocks;
     const int q = i0 / per, r = i0 - q * per;
-    const int bn = q * 8 + xcd;                              // the columns of one camera share an XCD
-    if (bn >= a.BN) return;
-    const int col = r / a.rblocks, rb = r - col * a.rblocks;
+    const int unit = q * 8 + xcd;
+    if (unit >= a.BN * a.split) return;
+    const int bn = unit / a.split, sg = unit - bn * a.split;
+    const int col = sg * a.seg + r / a.rblocks, rb = r % a.rblocks;
+    if (col >= a.fW) return;
     const int row0 = rb * 16;
     const int nrow = (a.fH - row0) < 16 ? (a.fH - row0) : 16;
     const int D = a.D, HW = a.fH * a.fW;
@@ -521,7 +529,14 @@ int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx,
     a.grad_depth = grad_depth; a.grad_context = grad_context;
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
     const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)Dp * 4 + (size_t)2 * 16 * (C + 4) * 4;
-    const int64_t grid = 8ll * ((a.BN + 7) / 8) * fW * a.rblocks;
+    {
+        int gcd = a.BN, e = 8;
+        while (e) { const int t = gcd % e; gcd = e; e = t; }
+        a.split = 8 / gcd;                                   // BN * split is a multiple of 8
+        if (a.split > fW) a.split = 1;
+        a.seg = (fW + a.split - 1) / a.split;
+    }
+    const int64_t grid = 8ll * ((a.BN * a.split + 7) / 8) * a.seg * a.rblocks;
     mmt::TimedSeq seq;
     const dim3 g((unsigned)grid), blk(kColBlock);
     if (cam) {

@@ -207,11 +207,19 @@ def test_camera_form_equals_geom_form(mmt_lib, cfg, bf16):
                     & (gq[..., 2] >= 0) & (gq[..., 2] < vn[2])).sum().item()
             frac = float(column_mismatch_fraction(geom_pm, vn, pixel_major=True))
             # a 1-in-8 pseudo-random sample of the workgroups (= (camera, column, 16-row block) units) reports
+            # (the kernel's workgroup -> (camera, column, row block) map: cameras cut into `split` column segments so that the
+            # (camera, segment) units are a multiple of 8 and every XCD carries the same number of workgroups)
             rb = (fH + 15) // 16
-            unit = torch.arange(8 * ((B * N + 7) // 8) * fW * rb, dtype=torch.int64)
+            split = 8 // math.gcd(B * N, 8)
+            if split > fW:
+                split = 1
+            seg = (fW + split - 1) // split
+            unit = torch.arange(8 * ((B * N * split + 7) // 8) * seg * rb, dtype=torch.int64)
             sampled = ((unit * 0x9E3779B1) & 0xFFFFFFFF) >> 29 == 0
             xcd, rest = unit & 7, unit >> 3
-            bn_u, col_u, rb_u = (rest // (fW * rb)) * 8 + xcd, (rest % (fW * rb)) // rb, rest % rb
+            cs_u = (rest // (seg * rb)) * 8 + xcd                    # (camera, segment)
+            bn_u, col_u, rb_u = cs_u // split, (cs_u % split) * seg + (rest % (seg * rb)) // rb, rest % rb
+            sampled = sampled & (cs_u < B * N * split) & (col_u < fW)
             kmask = ((gq[..., 0] >= 0) & (gq[..., 0] < vn[0]) & (gq[..., 1] >= 0) & (gq[..., 1] < vn[1])
                      & (gq[..., 2] >= 0) & (gq[..., 2] < vn[2])).view(B * N, fH, fW, D).cpu()
             big = torch.where(kmask, (gq[..., 1] * vn[0] + gq[..., 0]).view(B * N, fH, fW, D).cpu(), torch.full((1,), 1 << 40, dtype=torch.int64))

@@ -42,3 +42,12 @@ names = [("issue", 0, 3), ("arrive", 3, 4), ("cells+dep stores", 4, 7), ("reduce
 for n, a, b in names:
     v = (s[:, b] - s[:, a]).float()
     print("%-12s mean %7.0f p50 %7.0f p90 %7.0f max %7.0f" % (n, v.mean(), v.median(), v.quantile(0.9), v.max()))
+# timeline per XCD (workgroup i runs on XCD i % 8; the XCDs' counters are not synchronised)
+full = gc.view(-1)[:nwg * 16].view(torch.int64).view(-1, 8).cpu()
+for x in range(8):
+    sx = full[x::8]
+    sx = sx[(sx[:, 0] != 0) & (sx[:, 2] != 0)]
+    t0 = sx[:, 0].min()
+    st_, en_ = (sx[:, 0] - t0).float(), (sx[:, 2] - t0).float()
+    q = torch.tensor([0.1, 0.5, 0.9, 1.0])
+    print("xcd %d: %4d workgroups; starts p10/p50/p90/max %s; ends %s" % (x, len(sx), [int(v) for v in st_.quantile(q)], [int(v) for v in en_.quantile(q)]))
