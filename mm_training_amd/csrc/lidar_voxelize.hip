@@ -227,6 +227,10 @@ __device__ __forceinline__ unsigned match_halves(unsigned w, unsigned rr) {
 // launch behind this one -- so a captured graph replays with fresh tokens, and whatever an uninitialised scratch holds
 // cannot look "done" unless a word happens to hold exactly the token.
 __device__ __forceinline__ int cell_tiles(int n) { const int t = (n + kCellTile - 1) / kCellTile; return t > 0 ? t : 1; }
+// the word cells workgroup w leaves when its bytes are out: made of the launch's epoch AND of w, so that a scratch buffer that
+// holds the same value everywhere (fresh zeros; an older call's 0xFF region bytes where the epoch word now lies and its zeroed
+// count bytes where the words now lie -- tests/soak/fuzz_lidar.py found exactly that) cannot look "done" in more than one place
+__device__ __forceinline__ unsigned cells_token(unsigned epoch, int w) { return (epoch + 1u) * 0x9E3779B1u + (unsigned)w * 0x85EBCA6Bu + 0x2545F491u; }
 
 // first cells workgroup and number of cells workgroups of sample b (every wave for itself, same answer)
 __device__ __forceinline__ void cells_range(const int32_t *offsets, int B, int b, int *first_out, int *count_out) {
@@ -251,7 +255,7 @@ __device__ __forceinline__ void cells_role(const VoxArgs &a, int B, int widx) {
     extern __shared__ __align__(16) int lds[];
     RT *l_reg = reinterpret_cast<RT *>(lds);
     unsigned short *l_loc = reinterpret_cast<unsigned short *>(l_reg + kCellTile);
-    const unsigned token = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const unsigned epoch = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (sample, tile) of this workgroup: sample b owns cell_tiles(n_b) consecutive workgroups
     int b = -1, tile = 0, beg = 0, n = 0;
     {
@@ -298,7 +302,7 @@ __device__ __forceinline__ void cells_role(const VoxArgs &a, int B, int widx) {
     for (int c = threadIdx.x; c < m / 16; c += kTile) __builtin_amdgcn_raw_buffer_store_b128(zero, rs_flg, c * 16, 0, kSc1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(a.cdone + widx, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(a.cdone + widx, cells_token(epoch, widx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // LDS: head [R] | cur [R] | eidx [kEntries] | enext [kEntries] | filled (u8) [R]
@@ -341,13 +345,15 @@ __device__ __forceinline__ void own_role(const VoxArgs &a, int B, int widx) {
     if (threadIdx.x == 0) { s_count = 0; s_over = 0; }
     if (FUSED && wave == 0) {
         // the sample's cells workgroups: all of their words must hold this launch's token
-        const unsigned token = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        const unsigned epoch = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), token = epoch + 1u;
         int first, count;
         cells_range(a.offsets, B, b, &first, &count);
         int spins = 0;
         for (int c0 = 0; c0 < count; c0 += 64) {
-            const unsigned *w = a.cdone + first + (c0 + lane < count ? c0 + lane : count - 1);
-            while (!__all(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token)) {
+            const int wi = first + (c0 + lane < count ? c0 + lane : count - 1);
+            const unsigned *w = a.cdone + wi;
+            const unsigned want = cells_token(epoch, wi);
+            while (!__all(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want)) {
                 if (++spins > (1 << 20)) break;                    // (~0.1 s: never met; the table is left without its magic)
                 __builtin_amdgcn_s_sleep(2);
             }
