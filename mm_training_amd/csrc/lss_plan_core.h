@@ -354,8 +354,8 @@ PLAN_HD void phase_write_jobs(const Dims &d, Scratch &s, int tid, int nt) {
 }
 // phase 10: the job records the forward kernel reads.  A job's runs are contiguous in the cell-sorted list; their position
 // there is the partial row (`pslot`), `cell_begin` delimits the cells' partial rows.  The record lists the runs PAIR-major
-// (by key: camera, column, row block, bin), cut into pairs of at most kMaxPairRuns runs of one (column, row block) whose bins fit
-// one window of kWindowBins bins.
+// (a pair = consecutive runs, by key, of one (column, row block), at most kMaxPairRuns of them, whose bins fit one window of kWindowBins
+// bins), the pairs by falling number of runs.
 PLAN_HD void phase_records(const Dims &, Scratch &s, uint8_t *records, int njobs, int tid, int nt) {
     for (int j = tid; j < njobs; j += nt) {
         const JobDesc jd = s.jobs[j];
@@ -377,31 +377,50 @@ PLAN_HD void phase_records(const Dims &, Scratch &s, uint8_t *records, int njobs
         }
         PairRec *pairs = reinterpret_cast<PairRec *>(rec + kJobPairsOff);
         RunRec *rr = reinterpret_cast<RunRec *>(rec + kJobRunsOff);
-        int npairs = 0, w0 = 0;
-        uint32_t pkey = 0xFFFFFFFFu;
-        for (int p = 0; p < jd.nruns; ++p) {
+        // The pairs are found in key order (a pair = consecutive runs of one (column, row block) that fit a window) but LISTED by falling
+        // number of runs: the forward hands four consecutive pairs to the four lane groups of a wave, and the wave loops as long as the
+        // longest of them -- pairs of equal length side by side waste nothing (listed in key order a wave ran 3.6 iterations for a mean
+        // of 2.9 runs per pair at BASELINE configs[3]).  One scan per length: nothing to store between the passes.
+        auto run_rec = [&](int p) {
             const int i = order[p];
             const RunTmp r = runs[i];
             RunRec o;
             o.d0 = (uint16_t)((r.key & 0x7FFu) - (r.cell_len >> 30)); o.len = (uint8_t)(((r.cell_len >> 28) & 3u) + 1); o.pslot = (uint8_t)i;
             o.cell_local = (r.cell_len & 0x0FFFFFFFu) - (uint32_t)ctm0;
-            const uint32_t pk = r.key >> 11;          // (column, row block)
-            // a pair's runs share ONE window of kWindowBins depth bins that starts at the even bin at or below its first run's
-            // (loaded) bin -- a dword-aligned address in bf16 too -- so a run whose bins would leave the window opens a new pair
-            if (pk != pkey || pairs[npairs - 1].nruns >= kMaxPairRuns || (int)o.d0 + (int)o.len - w0 > kWindowBins) {
-                w0 = (int)o.d0 & ~1;
-                PairRec pr; pr.col = (uint16_t)(r.key >> 16); pr.rb = (uint8_t)((r.key >> 11) & 31u); pr.nruns = 0; pr.run0 = (uint16_t)p; pr.w0 = (uint16_t)w0;
-                pairs[npairs++] = pr;
-                pkey = pk;
+            o.wlo = 0ull; o.whi = 0ull;
+            return o;
+        };
+        int npairs = 0, nout = 0;
+        for (int want = kMaxPairRuns; want >= 1; --want) {
+            int pstart = 0;
+            while (pstart < jd.nruns) {
+                // the pair that starts at key rank pstart: runs of its (column, row block) while they are at most kMaxPairRuns and fit the
+                // window of kWindowBins bins from the even bin at or below the first run's (a dword-aligned address in bf16 too)
+                const RunRec first = run_rec(pstart);
+                const uint32_t pk = runs[order[pstart]].key >> 11;
+                const int w0 = (int)first.d0 & ~1;
+                int pend = pstart + 1;
+                while (pend < jd.nruns && pend - pstart < kMaxPairRuns && (runs[order[pend]].key >> 11) == pk) {
+                    const RunRec o = run_rec(pend);
+                    if ((int)o.d0 + (int)o.len - w0 > kWindowBins) break;
+                    ++pend;
+                }
+                if (pend - pstart == want) {
+                    PairRec pr; pr.col = (uint16_t)(pk >> 5); pr.rb = (uint8_t)(pk & 31u); pr.nruns = (uint8_t)want; pr.run0 = (uint16_t)nout; pr.w0 = (uint16_t)w0;
+                    pairs[npairs++] = pr;
+                    for (int p = pstart; p < pend; ++p) {
+                        RunRec o = run_rec(p);
+                        const RunTmp r = runs[order[p]];
+                        // the run's four masks moved to its place in the window (a 128-bit shift by 16 bits per bin; masks past the run's length are zero)
+                        const uint64_t m = (uint64_t)r.mask[0] | ((uint64_t)r.mask[1] << 16) | ((uint64_t)r.mask[2] << 32) | ((uint64_t)r.mask[3] << 48);
+                        const int off = (int)o.d0 - w0;
+                        o.wlo = off < 4 ? (m << (16 * off)) : 0ull;
+                        o.whi = off == 0 ? 0ull : (off < 4 ? (m >> (64 - 16 * off)) : (m << (16 * (off - 4))));
+                        rr[nout++] = o;
+                    }
+                }
+                pstart = pend;
             }
-            {   // the run's four masks moved to its place in the window (a 128-bit shift by 16 bits per bin; masks past the run's length are zero)
-                const uint64_t m = (uint64_t)r.mask[0] | ((uint64_t)r.mask[1] << 16) | ((uint64_t)r.mask[2] << 32) | ((uint64_t)r.mask[3] << 48);
-                const int off = (int)o.d0 - w0;
-                o.wlo = off < 4 ? (m << (16 * off)) : 0ull;
-                o.whi = off == 0 ? 0ull : (off < 4 ? (m >> (64 - 16 * off)) : (m << (16 * (off - 4))));
-            }
-            rr[p] = o;
-            ++pairs[npairs - 1].nruns;
         }
         JobHeader h; h.ncells = (uint16_t)jd.ncells; h.npairs = (uint16_t)npairs; h.nruns = (uint16_t)jd.nruns; h.c0 = (uint16_t)jd.c0; h.tile = jd.tile; h.chain = (uint32_t)jd.chain;
         *reinterpret_cast<JobHeader *>(rec) = h;
