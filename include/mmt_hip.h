@@ -43,7 +43,7 @@ extern "C" {
                              *     GEMMs on the fp32 matrix cores, no column buffer; additive
                              * 14: mmt_lss_plan_prepare is ONE launch with a fast path for batches seen before;
                              *     mmt_depth_softmax_forward_plan_prepare (the lookup rides in the depth softmax's launch); additive
-                             * 15: mmt_voxelize_fused_launch (the cells + owner passes of the voxelizer as one launch: opt-in); the plan form's
+                             * 15: mmt_voxelize_fused_launch (the cells + owner passes of the voxelizer as one launch: opt-in); mmt_bev_warp_affine_backward_assign; the plan form's
                              *     job records carry a depth window per pair (3168 bytes; plan caches of ABI 14 are rebuilt); additive */
 
 #define MMT_OK 0
@@ -270,6 +270,12 @@ int mmt_bev_warp_affine(int batch_size, int H, int W, int C, const float *bda_ma
 int mmt_bev_warp_affine_backward(int batch_size, int H, int W, int C, const float *bda_mat,
                                  const float *grad_output, int64_t grad_out_row_stride,
                                  float *grad_input, int64_t grad_in_row_stride, void *stream);
+/* (ABI 15) the same, but grad_input is ASSIGNED: the gather writes every row of it exactly once, so a caller that has nothing to
+ * add to needs neither the zero fill nor the kernel's read of it (what autograd's backward of bev_augment_image wants).
+ * Both take an input / grad_output that spans less than 2 GiB (rows are read through a buffer descriptor). */
+int mmt_bev_warp_affine_backward_assign(int batch_size, int H, int W, int C, const float *bda_mat,
+                                        const float *grad_output, int64_t grad_out_row_stride,
+                                        float *grad_input, int64_t grad_in_row_stride, void *stream);
 
 /* Deformable 3x3 convolution, the data-dependent halves: replaces
  * mmcv 'DCN' (DeformConv2dPack) inside DepthNet, layers/backbones/lss_fpn.py:189-197.

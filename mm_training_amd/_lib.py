@@ -74,6 +74,7 @@ SIGNATURES = {
     "mmt_centerpoint_targets": (_c_int, [_c_int, _c_int, _c_ptr, _c_ptr] + [_c_int] * 4 + [ctypes.c_float] * 4 + [_c_int, ctypes.c_float, _c_int, _c_int] + [_c_ptr] * 7 + [_c_ptr]),
     "mmt_bev_warp_affine": (_c_int, [_c_int] * 4 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "mmt_bev_warp_affine_backward": (_c_int, [_c_int] * 4 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
+    "mmt_bev_warp_affine_backward_assign": (_c_int, [_c_int] * 4 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "mmt_bn_workspace_elems": (_c_i64, [_c_int]),
     "mmt_bn_relu_forward": (_c_int, [_c_i64, _c_int] + [_c_ptr] * 6 + [ctypes.c_float, ctypes.c_float, _c_int] + [_c_ptr] * 3 + [_c_ptr]),
     "mmt_bn_relu_backward": (_c_int, [_c_i64, _c_int] + [_c_ptr] * 4 + [_c_int, _c_int] + [_c_ptr] * 5 + [_c_ptr]),

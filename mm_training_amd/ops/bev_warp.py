@@ -49,9 +49,9 @@ class BevWarpConcat(Function):
         (bda,) = ctx.saved_tensors
         B, C, H, W, c_other = ctx.dims
         grad_out = _channels_last(grad_out, "grad_out")
-        grad_x = torch.zeros((B, H, W, C), dtype=torch.float32, device=grad_out.device).permute(0, 3, 1, 2)
+        grad_x = torch.empty((B, H, W, C), dtype=torch.float32, device=grad_out.device).permute(0, 3, 1, 2)       # (assigned: every row written once)
         with torch.cuda.device(grad_out.device):
-            _lib.timed_call("bev_warp_backward", "mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + c_other,
+            _lib.timed_call("bev_warp_backward", "mmt_bev_warp_affine_backward_assign", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + c_other,
                       grad_x.data_ptr(), C, _stream())
         grad_other = grad_out[:, C:] if c_other else None
         return grad_x, None, grad_other
@@ -104,8 +104,8 @@ class BevWarpConcatPillars(Function):
         grad_x = grad_feats = None
         with torch.cuda.device(grad_out.device):
             if ctx.needs_input_grad[0]:
-                grad_x = torch.zeros((B, H, W, C), dtype=torch.float32, device=grad_out.device).permute(0, 3, 1, 2)
-                _lib.timed_call("bev_warp_backward", "mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + Cl,
+                grad_x = torch.empty((B, H, W, C), dtype=torch.float32, device=grad_out.device).permute(0, 3, 1, 2)       # (assigned: every row written once)
+                _lib.timed_call("bev_warp_backward", "mmt_bev_warp_affine_backward_assign", B, H, W, C, bda.data_ptr(), grad_out.data_ptr(), C + Cl,
                           grad_x.data_ptr(), C, _stream())
             if ctx.needs_input_grad[2]:
                 grad_feats = torch.empty((M, Cl), dtype=torch.float32, device=grad_out.device)

@@ -100,6 +100,27 @@ def test_backward_is_the_exact_adjoint_of_the_forward(mmt_lib, kind):
     assert torch.equal(x.grad, x2.grad)
 
 
+def test_backward_assign_equals_accumulate_on_zeros(mmt_lib):
+    """mmt_bev_warp_affine_backward_assign (ABI 15) stores what mmt_bev_warp_affine_backward adds to a zeroed buffer -- bit for bit, into
+    a buffer that held NaNs, strided rows on both sides, a sample whose map is zoomed in (cells under more output cells than the
+    kernel keeps in LDS take its long path)."""
+    from mm_training_amd import _lib
+    rng = np.random.default_rng(5)
+    B, C, H, W, S_in, S_out = 3, 80, 33, 47, 160, 96
+    bda = _bda(B, rng)
+    bda[2, :2, :2] *= 2.2
+    bda = bda.cuda().contiguous()
+    go = torch.from_numpy(rng.standard_normal((B, H, W, S_in)).astype(np.float32)).cuda()
+    acc = torch.zeros(B, H, W, S_out, device="cuda")
+    asg = torch.full((B, H, W, S_out), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), go.data_ptr(), S_in, acc.data_ptr(), S_out, st)
+    _lib.call("mmt_bev_warp_affine_backward_assign", B, H, W, C, bda.data_ptr(), go.data_ptr(), S_in, asg.data_ptr(), S_out, st)
+    assert torch.equal(acc[..., :C], asg[..., :C]) and bool(torch.isnan(asg[..., C:]).all())
+    _lib.call("mmt_bev_warp_affine_backward", B, H, W, C, bda.data_ptr(), go.data_ptr(), S_in, acc.data_ptr(), S_out, st)      # accumulates
+    assert torch.allclose(acc[..., :C], 2 * asg[..., :C], rtol=1e-6, atol=1e-6)
+
+
 def test_concat_buffer(mmt_lib):
     """The warped camera map lands in channels [0, C) of the camera|LiDAR buffer, the LiDAR map in
     [C, C+C2) (models/bev_depth.py:187-192); gradients flow to both."""

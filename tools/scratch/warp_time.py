@@ -23,7 +23,8 @@ res = {}
 for rnd in range(3):
     for p, h in zip(libs, hs):
         for name, fn in (("fwd", lambda: h.mmt_bev_warp_affine(B, H, W, C, bda.data_ptr(), x.data_ptr(), C, y.data_ptr(), S, st)),
-                         ("bwd", lambda: h.mmt_bev_warp_affine_backward(B, H, W, C, bda.data_ptr(), y.data_ptr(), S, gx.data_ptr(), C, st))):
+                         ("bwd", lambda: h.mmt_bev_warp_affine_backward(B, H, W, C, bda.data_ptr(), y.data_ptr(), S, gx.data_ptr(), C, st)),
+                         ("bwd_assign", lambda: h.mmt_bev_warp_affine_backward_assign(B, H, W, C, bda.data_ptr(), y.data_ptr(), S, gx.data_ptr(), C, st) if hasattr(h, "mmt_bev_warp_affine_backward_assign") else 0)):
             for _ in range(5): assert fn() == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(); e0.record()
