@@ -229,6 +229,35 @@ __global__ __launch_bounds__(kBlock) void normalize_flip_kernel(NormArgs a) {
     }
 }
 
+// Planar (NCHW) output: four pixels of a row per thread (W % 4 == 0, 16-byte aligned planes) -- one 16-byte load per plane, reversed
+// for a flipped camera, one 16-byte store per plane, and no integer division per pixel (the kernel above spends two 64-bit
+// divisions on every pixel): 20.1 -> 16.6 us at [24, 3, 256, 704].  Same arithmetic, same bits.  The channels-last output keeps
+// the kernel above: three variants with 16-byte accesses (four pixels per thread = 48 bytes at a 48-byte stride; a thread per
+// 16-byte piece of the interleaved row reading the planes; the same through an LDS copy of the row) took 23 / 26 / 26 us against its 20.
+__global__ __launch_bounds__(kBlock) void normalize_flip_rows_kernel(NormArgs a, int w4) {      // w4 = W / 4; grid.y walks the rows
+    const int64_t hw = (int64_t)a.H * a.W, rows = a.n * a.H;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int64_t img = row / a.H;
+        const int h = (int)(row - img * a.H);
+        const bool fl = a.flipped != nullptr && a.flipped[img];
+        for (int q = blockIdx.x * kBlock + threadIdx.x; q < w4; q += gridDim.x * kBlock) {
+            const int w = 4 * q, ws = fl ? a.W - 4 - w : w;
+            const float *src = a.in + (img * a.c_in) * hw + (int64_t)h * a.W + ws;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + c * hw);
+                const float x[4] = {fl ? t.w : t.x, fl ? t.z : t.y, fl ? t.y : t.z, fl ? t.x : t.w};
+                float4 v;
+                v.x = __fdiv_rn(__fsub_rn(__fmul_rn(x[0], a.scale), a.mean[c]), a.stdv[c]);
+                v.y = __fdiv_rn(__fsub_rn(__fmul_rn(x[1], a.scale), a.mean[c]), a.stdv[c]);
+                v.z = __fdiv_rn(__fsub_rn(__fmul_rn(x[2], a.scale), a.mean[c]), a.stdv[c]);
+                v.w = __fdiv_rn(__fsub_rn(__fmul_rn(x[3], a.scale), a.mean[c]), a.stdv[c]);
+                *reinterpret_cast<float4 *>(a.out + (img * 3 + c) * hw + (int64_t)h * a.W + w) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mmt_hflip(int64_t n, int group, int rows, int W, int elems, const float *in, const uint8_t *flipped, float *out,
@@ -259,7 +288,11 @@ extern "C" int mmt_normalize_flip_images(int64_t n_images, int channels_in, int 
     a.in = images; a.flipped = flipped; a.out = out;
     const dim3 grid(mmt::stream_grid(n_images * H * W, kBlock, 256 * 64)), block(kBlock);
     if (channels_last) hipLaunchKernelGGL(normalize_flip_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(normalize_flip_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    else if (W % 4 == 0 && (((uintptr_t)images | (uintptr_t)out) & 15) == 0) {
+        const int64_t rows = n_images * H;
+        hipLaunchKernelGGL(normalize_flip_rows_kernel, dim3((unsigned)((W / 4 + kBlock - 1) / kBlock), (unsigned)(rows < 32768 ? rows : 32768)), block, 0,
+                           (hipStream_t)stream, a, W / 4);
+    } else hipLaunchKernelGGL(normalize_flip_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
     return mmt::check_launch("normalize_flip_images");
 }
 
