@@ -679,6 +679,7 @@ struct RayArgs {
     int32_t *excl;                 // forward (register walk, camera form), nullable: the exclusive-cell cache
     ExclShape xs;
     int wpc;                       // backward: workgroups per camera
+    int split, wps;                // backward: segments per camera, workgroups per segment (XCD balance)
     const int32_t *geom;           // geom form: int32 voxel indices per point; camera form (template CAM): unused
     const float *combine, *fu, *fv, *fd;   // camera form: [B*N, 16] matrices and the frustum's three axes (mmt_camera.h)
     mmt::CamGrid q;
@@ -1531,9 +1532,13 @@ template <typename FT, int C4T, bool CAM>
 __global__ __launch_bounds__(kBlock, 6) void lss_ray_bwd(RayArgs a) {
     extern __shared__ __align__(16) float ray_lds[];
     const int L = blockIdx.x, xcd = L & 7, i = L >> 3;
-    const int q = i / a.wpc, w = i - q * a.wpc;
-    const int bn = q * 8 + xcd;
-    if (bn >= a.BN) return;
+    // (camera, segment of its workgroups) units dealt to the XCDs, a multiple of 8 of them where possible, so that every XCD carries
+    // the same number of workgroups (lift_splat_col.hip: 12 cameras dealt whole put twice the work on four of the eight XCDs)
+    const int q = i / a.wps, wi = i - q * a.wps;
+    const int unit = q * 8 + xcd;
+    if (unit >= a.BN * a.split) return;
+    const int bn = unit / a.split, w = (unit - bn * a.split) * a.wps + wi;
+    if (w >= a.wpc) return;
     const int C = a.C, D = a.D;
     const int C4 = C4T > 0 ? C4T : C >> 2;
     const int G = 64 / C4, Q = C4 >> 2;
@@ -1990,7 +1995,14 @@ int backward_impl(const char *what, int B, int N, int D, int fH, int fW, int C, 
             r.grad_out = grad_out; r.sb = sb; r.sy = sy; r.sx = sx; r.span_bytes = (int)(span * 4);
             r.grad_depth = grad_depth; r.grad_context = grad_context;
             r.wpc = (fH * fW + NGR - 1) / NGR;
-            const int64_t grid = 8ll * ((r.BN + 7) / 8) * r.wpc;
+            {
+                int gcd = r.BN, e = 8;
+                while (e) { const int t = gcd % e; gcd = e; e = t; }
+                r.split = 8 / gcd;                              // BN * split is a multiple of 8
+                if (r.split > r.wpc) r.split = 1;
+                r.wps = (r.wpc + r.split - 1) / r.split;
+            }
+            const int64_t grid = 8ll * ((r.BN * r.split + 7) / 8) * r.wps;
             if (grid >= (1ll << 31)) return mmt::fail(MMT_ERR_TOO_LARGE, "%s: grid too large", what);
             const size_t lds_req = lds;
             const dim3 g((unsigned)grid), blk(kBlock);
