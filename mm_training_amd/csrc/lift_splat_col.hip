@@ -104,6 +104,9 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
     auto flag_of = [&](int row, int bin) __attribute__((always_inline)) { return (int)((flag[bin] >> (2 * row)) & 3u); };
     float *gw1 = gw0 + 16 * CP;
     float *gw = wave == 0 ? gw0 : gw1;
+    unsigned *own = reinterpret_cast<unsigned *>(gw1 + 16 * CP);       // [16][Dp] a pixel's OWN row offset, written where a block's rows are looked at one by one:
+                                                                       // what the mismatch pass walks (it recomputed the geometry per entry -- a load of the bin's
+                                                                       // depth coordinate and two divisions in front of every gradient row: 12 of 28 us at 0.5 degrees of pitch)
     __shared__ int nmis, nkept;
     if (tid == 0) { nmis = 0; nkept = 0; }
     __syncthreads();
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
             dv[u] = bin == tid ? dv0[u] : ld_scalar<FT>(depth + t);
         }
 #ifdef LSS_STAMPS
-        COL_STAMP(3); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); COL_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); COL_STAMP(4);
 #endif
         unsigned o[16];
         unsigned m = kOut;
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int f = o[u] == kOut ? 0 : (o[u] == m ? 1 : 2);
+            own[u * Dp + bin] = o[u];
             fword |= (unsigned)f << (2 * u);
             dep[u * Dp + bin] = f ? dv[u] : 0.f;
             mis += f == 2;
@@ -450,17 +454,7 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
                 for (int u = 0; u < 4; ++u) {
                     const bool on = act && (e0 + u) < cnt;
                     const int bin = on ? klist[e0 + u] : 0;
-                    unsigned o = kOut;                    // the point's OWN row (flag 2: kept, so its indices are in range)
-                    if constexpr (CAM) {
-                        int x_, y_;
-                        const mmt_cam_column cc_ = mmt_cam_column_make(cm, cu, a.fd[bin]);
-                        mmt_cam_row_xy(cc_, a.fv[row0 + prc], a.q, a.nx, a.ny, x_, y_);
-                        if (on) o = (unsigned)(((int)(b * a.sb) + y_ * (int)a.sy + x_ * (int)a.sx) * 4);
-                    } else {
-                        const int64_t t_ = tcol + prc * rstep + bin * dstep;
-                        const int x_ = a.geom[t_ * 3], y_ = a.geom[t_ * 3 + 1];
-                        if (on) o = (unsigned)(((int)(b * a.sb) + y_ * (int)a.sy + x_ * (int)a.sx) * 4);
-                    }
+                    const unsigned o = on ? own[prc * Dp + bin] : kOut;        // the point's OWN row, left by phase A
                     dv[u] = on ? dep[prc * Dp + bin] : 0.f;
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + (g < G ? (unsigned)li * 16u : 0x40000000u), 0, 0);
                 }
@@ -491,6 +485,7 @@ __global__ __launch_bounds__(kColBlock, COL_MIN_WAVES) void lss_col_bwd(ColArgs 
         }
         __syncthreads();
     }
+    COL_STAMP(3);         // (after the mismatch pass)
 #ifndef LSS_STAMPS
     for (int e = tid; e < 16 * C4; e += kColBlock) {
         const int prow = e / C4, c4 = e - prow * C4;
@@ -528,7 +523,7 @@ int launch(const char *what, int B, int N, int D, int fH, int fW, int C, int nx,
     a.span_bytes = (int)(span * 4);
     a.grad_depth = grad_depth; a.grad_context = grad_context;
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
-    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)Dp * 4 + (size_t)2 * 16 * (C + 4) * 4;
+    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)Dp * 4 + (size_t)2 * 16 * (C + 4) * 4 + (size_t)16 * Dp * 4;
     {
         int gcd = a.BN, e = 8;
         while (e) { const int t = gcd % e; gcd = e; e = t; }
@@ -558,7 +553,7 @@ namespace mmt {
 // true when the column kernel takes this shape (C in {64, 80, 128}; LDS within 64 KB; a gradient map below 1 GiB)
 bool lss_col_backward_fits(int D, int fH, int fW, int C, int64_t span, int64_t grid_units) {
     const int Dp = ((D + kBins - 1) / kBins) * kBins;
-    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)Dp * 4 + (size_t)2 * 16 * (C + 4) * 4;
+    const size_t lds = (size_t)16 * Dp * 4 + (size_t)Dp * 4 + (size_t)Dp * 4 + (size_t)2 * 16 * (C + 4) * 4 + (size_t)16 * Dp * 4;
     const int C4 = C / 4, NGR = (kColBlock / 64) * (64 / C4);
     if (NGR * Dp + NGR * C4 > 16 * (C + 4)) return false;            // the lists of the mismatch pass live in wave 1's tile
     return (C == 64 || C == 80 || C == 128) && lds <= 64 * 1024 && span * 4 < (1ll << 30) && grid_units < (1ll << 28);

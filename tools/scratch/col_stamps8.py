@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase stamps of lss_col_bwd (a -DLSS_STAMPS build of lift_splat_col.hip writes 8 s_memtime stamps per workgroup into grad_context):
-0 entry | 3 phase A's loads issued | 4 arrived | 5 cells, flags, LDS stores done | 6 after the barrier | 1 context operand in registers | 2 products done
+0 entry | 4 phase A's loads arrived | 3 mismatch pass done | 5 cells, flags, LDS stores done | 6 after the barrier | 1 context operand in registers | 2 products done
    python tools/build_variant.py colstamps lift_splat_col.hip -DLSS_STAMPS && python tools/scratch/col_stamps8.py [cfg4|cfg5] [f32|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,7 +14,11 @@ h = load("mm_training_amd/variants/libmmt_colstamps.so")
 B, N, D, fH, fW, C, (H, W), d_bound, bounds = SHAPES[shape]
 sd = torch.bfloat16 if bf16 else torch.float32
 s2e, K = synthetic.camera_rig(B, N, W, H, jitter=0.02, seed=0)
-combine = s2e.matmul(torch.inverse(K)).contiguous().cuda()
+import math
+pitch = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0        # degrees about the cameras' x axis (tools/kbench_camera.py --pitch)
+c_, s_ = math.cos(math.radians(pitch)), math.sin(math.radians(pitch))
+rx = torch.tensor([[1, 0, 0, 0], [0, c_, -s_, 0], [0, s_, c_, 0], [0, 0, 0, 1]], dtype=torch.float32)
+combine = s2e.matmul(rx).matmul(torch.inverse(K)).contiguous().cuda()
 fu = torch.linspace(0, W - 1, fW).cuda(); fv = torch.linspace(0, H - 1, fH).cuda(); fd = torch.arange(*d_bound, dtype=torch.float).cuda()
 vs = [b[2] for b in bounds]; vc = [b[0] + b[2] / 2.0 for b in bounds]
 nx, ny, nz = [int((b[1] - b[0]) / b[2]) for b in bounds]
@@ -37,8 +41,8 @@ for _ in range(4):
     assert rc == 0, h.mmt_last_error()
 torch.cuda.synchronize()
 s = gc.view(-1)[:nwg * 16].view(torch.int64).view(-1, 8).cpu()
-s = s[(s[:, 0] != 0) & (s[:, 2] != 0)]
-names = [("issue", 0, 3), ("arrive", 3, 4), ("cells+dep stores", 4, 7), ("reduce+park", 7, 5), ("barrier", 5, 6), ("ctx operand", 6, 1), ("products", 1, 2), ("life", 0, 2)]
+s = s[(s[:, 0] != 0) & (s[:, 2] != 0) & (s[:, 3] != 0)]
+names = [("start to arrival", 0, 4), ("cells+dep stores", 4, 7), ("reduce+park", 7, 5), ("barrier", 5, 6), ("ctx operand", 6, 1), ("products", 1, 2), ("sum + mismatch pass", 2, 3), ("life", 0, 3)]
 for n, a, b in names:
     v = (s[:, b] - s[:, a]).float()
     print("%-12s mean %7.0f p50 %7.0f p90 %7.0f max %7.0f" % (n, v.mean(), v.median(), v.quantile(0.9), v.max()))
