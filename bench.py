@@ -1102,6 +1102,10 @@ def train_main(args, rank, local_rank, world):
         add_alone((res.get("roofline_softmax") or {}).get("backward"), alone, ("softmax_backward",), _lib)
         add_alone(res.get("roofline_lidar"), alone, ("voxelize", "scatter"), _lib)
         add_alone(res.get("roofline_lidar_backward"), alone, ("scatter_backward",), _lib)
+        # (the warp's backward is the first hand-written kernel of the backward pass: in the multi-stream step its dispatch-attached
+        # time is almost all time shared with the weight-gradient stream -- ~0.2 ms for a 12 us kernel)
+        add_alone(res.get("roofline_bev_warp"), alone, ("bev_warp",), _lib)
+        add_alone((res.get("roofline_bev_warp") or {}).get("backward"), alone, ("bev_warp_backward",), _lib)
         res["config"]["streams_note"] = (
             "the timed steps run on several HIP streams (weight gradients of the convolutions on a low-priority side stream, task heads on "
             "two): `avg_ms` / `frac` of a roofline object are the kernel's dispatch-attached time INSIDE those steps, i.e. while it may "
